@@ -1,0 +1,23 @@
+# Builds the HIP C-ABI library (gfx950) and the oracle's C helpers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := blackbox_amd/csrc
+SRCS  := $(CSRC)/bbx_ctx.hip $(CSRC)/bbx_overscan.hip $(CSRC)/bbx_calibrate.hip \
+         $(CSRC)/bbx_mask.hip $(CSRC)/bbx_select.hip $(CSRC)/bbx_lacosmic.hip $(CSRC)/bbx_xtalk.hip
+OBJS  := $(SRCS:.hip=.o)
+LIB   := blackbox_amd/libbbx_hip.so
+# -ffp-contract=off: results must match numpy's unfused float32/float64 arithmetic
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -ffp-contract=off -std=c++17 -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h include/bbx.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -f $(OBJS) $(LIB)
+
+.PHONY: all clean

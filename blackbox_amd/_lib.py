@@ -1,0 +1,78 @@
+"""ctypes binding of libbbx_hip.so (the C ABI declared in include/bbx.h).
+
+The library is mandatory: if it is missing or a symbol cannot be resolved the
+import of this module raises -- there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbbx_hip.so')
+
+BBX_RAW_U16, BBX_RAW_F32 = 0, 1
+
+
+class BBXError(RuntimeError):
+    def __init__(self, code, what, detail=''):
+        self.code = code
+        msg = '{} failed: {} ({})'.format(what, _strerror(code), code)
+        if detail:
+            msg += ' -- ' + detail
+        RuntimeError.__init__(self, msg)
+
+
+class Geom(C.Structure):
+    _fields_ = [('ny_raw', C.c_int32), ('nx_raw', C.c_int32),
+                ('ysize_chan', C.c_int32), ('xsize_chan', C.c_int32)]
+
+
+if not os.path.isfile(LIB_PATH):
+    raise ImportError('{} not found: build it with `make` (hipcc, gfx950); the '
+                      'reduction has no CPU fallback'.format(LIB_PATH))
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_pf = C.POINTER(C.c_float)
+_pd = C.POINTER(C.c_double)
+_pg = C.POINTER(Geom)
+
+# every symbol include/bbx.h declares, with its signature
+SIGNATURES = {
+    'bbx_ctx_create': (_i, [_i, C.POINTER(_vp)]),
+    'bbx_ctx_destroy': (None, [_vp]),
+    'bbx_strerror': (C.c_char_p, [_i]),
+    'bbx_last_hip_error': (C.c_char_p, [_vp]),
+    'bbx_version': (_i, []),
+    'bbx_sync': (_i, [_vp, _vp]),
+    'bbx_overscan_stats': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp]),
+    'bbx_vos_std': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp]),
+    'bbx_satcol_counts': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _pf, _i, _i, _vp, _vp]),
+    'bbx_calibrate': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp]),
+    'bbx_mask_finish': (_i, [_vp, _pg, _vp, _vp, _vp]),
+    'bbx_lacosmic': (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _f, _i, _f, _vp, _vp]),
+    'bbx_xtalk': (_i, [_vp, _pg, _vp, _vp, _pd, _vp]),
+    'bbx_mask_counts': (_i, [_vp, C.c_int64, _vp, _vp, _vp]),
+    'bbx_edge_fill': (_i, [_vp, _pg, _vp, _vp, _vp, _vp]),
+    'bbx_count_objects': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError if the export is missing
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def _strerror(code):
+    return lib.bbx_strerror(int(code)).decode()
+
+
+def f32x16(values):
+    arr = (C.c_float * 16)(*[float(v) for v in values])
+    return arr
+
+
+def check(code, what, ctx=None):
+    if code != 0:
+        detail = ''
+        if ctx is not None and code == -2:
+            detail = lib.bbx_last_hip_error(ctx).decode()
+        raise BBXError(code, what, detail)

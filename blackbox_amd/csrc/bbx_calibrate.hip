@@ -1,0 +1,120 @@
+// bbx_calibrate.hip -- fused calibration pass over one CCD frame.
+//
+// One read of the raw data sections (+ flat, bias, BPM), one write of the reduced
+// float32 frame and of the uint8 mask:  HBM-bound, algorithmic bytes per pixel
+// = raw(2|4) + flat 4 + [bias 4] + bpm 1 + out 4 + mask 1  (SURVEY.md section 8d).
+//
+// Arithmetic follows numpy's evaluation of the reference statements exactly
+// (float32 storage after every statement, float64 where numpy promotes):
+//   data *= gain[c]                      f32 * f32            blackbox.py:7460
+//   data[chan] -= fit_vos_col[:,None]    f64 subtract -> f32  blackbox.py:6553
+//   data[data_sec] -= oscan              f64 subtract -> f32  blackbox.py:6844
+//   data -= data_mbias                   f32                  blackbox.py:1679
+//   mask_init: non-finite -> 0 / bad, >= satlevel_c -> saturated   4408-4414, 4494-4498
+//   data /= data_mflat                   f32 (IEEE division)  blackbox.py:1825
+// Compile with -ffp-contract=off: no fused multiply-adds may be formed.
+#include "bbx_common.h"
+
+struct calib_args {
+    const void* raw; const double* vfit; const double* oscan;
+    const float* bias; const float* flat; const uint8_t* bpm;
+    float* data; uint8_t* mask;
+    uint32_t* satlist; int32_t* counters; int32_t* err; uint32_t satcap;
+    f32x16 gain, sat;
+    bbx_dims d;
+};
+
+template <int RAW_T>
+__device__ __forceinline__ void calib_pixel(const calib_args& a, float rawv, int c, int rl, int x, size_t o,
+                                            float& out, uint8_t& m) {
+    float v = rawv;
+    if (RAW_T == BBX_RAW_F32 && !isfinite(v)) v = 0.f;
+    v = v * a.gain.v[c];
+    v = (float)((double)v - a.vfit[c * a.d.dy + rl]);
+    v = (float)((double)v - a.oscan[c * a.d.xsz + x]);
+    if (a.bias) v = v - a.bias[o];
+    m = a.bpm ? a.bpm[o] : (uint8_t)0;
+    if (!isfinite(v)) { v = 0.f; if (m == 0) m |= BBX_MASK_BAD; }
+    if (v >= a.sat.v[c]) {
+        m |= BBX_MASK_SAT;
+        unsigned k = atomicAdd((unsigned*)&a.counters[CNT_SAT], 1u);
+        if (k < a.satcap) a.satlist[k] = (uint32_t)o; else atomicOr(a.err, BBX_DERR_LIST_OVERFLOW);
+    }
+    if (a.flat) v = v / a.flat[o];
+    out = v;
+}
+
+// VEC = 4: xsize_chan % 4 == 0, a thread owns 4 consecutive pixels of one channel row
+template <int RAW_T, int VEC>
+__global__ __launch_bounds__(256) void k_calibrate(calib_args a) {
+    const bbx_dims& d = a.d;
+    const int ngx = d.nx / VEC;
+    const size_t total = (size_t)d.ny * ngx;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int Y = (int)(t / ngx), X = (int)(t - (size_t)Y * ngx) * VEC;
+        const int iy = Y / d.ysz, y = Y - iy * d.ysz;
+        const int ix = X / d.xsz, x = X - ix * d.xsz;
+        const int c = iy * 8 + ix;
+        const int rl = (iy == 0) ? y : (d.os_y + y);           // channel-local row (data_sec origin)
+        const size_t ri = (size_t)(iy * d.dy + rl) * d.nx_raw + (size_t)ix * d.dx + x;
+        const size_t o = (size_t)Y * d.nx + X;
+        if (VEC == 4) {
+            float r[4];
+            if (RAW_T == BBX_RAW_U16) {
+                ushort4 u = *(const ushort4*)((const uint16_t*)a.raw + ri);
+                r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w;
+            } else {
+                float4 f = *(const float4*)((const float*)a.raw + ri);
+                r[0] = f.x; r[1] = f.y; r[2] = f.z; r[3] = f.w;
+            }
+            float ov[4]; uint8_t mv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) calib_pixel<RAW_T>(a, r[k], c, rl, x + k, o + k, ov[k], mv[k]);
+            *(float4*)(a.data + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            *(uchar4*)(a.mask + o) = make_uchar4(mv[0], mv[1], mv[2], mv[3]);
+        } else {
+            float ov; uint8_t mv;
+            calib_pixel<RAW_T>(a, raw_load<RAW_T>(a.raw, ri), c, rl, x, o, ov, mv);
+            a.data[o] = ov; a.mask[o] = mv;
+        }
+    }
+}
+
+extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type,
+                             const float* h_gain, const double* d_vfit, const double* d_oscan,
+                             const float* d_bias, const float* d_flat, const uint8_t* d_bpm,
+                             const float* h_satlevel, float* d_data, uint8_t* d_mask, void* stream) {
+    if (!ctx || !d_raw || !h_gain || !d_vfit || !d_oscan || !h_satlevel || !d_data || !d_mask) return BBX_ERR_ARG;
+    if (raw_type != BBX_RAW_U16 && raw_type != BBX_RAW_F32) return BBX_ERR_ARG;
+    calib_args a;
+    int rc = bbx_make_dims(g, &a.d); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npix = (size_t)a.d.ny * a.d.nx;
+    if (npix >= 0xffffffffull) return BBX_ERR_ARG;
+    // saturated-pixel queue: worst case every pixel
+    if (!ctx->d_satlist || ctx->cap_satlist < (int64_t)npix) {
+        if (ctx->d_satlist) { BBX_HIP(hipDeviceSynchronize()); BBX_HIP(hipFree(ctx->d_satlist)); ctx->d_satlist = nullptr; }
+        BBX_HIP(hipMalloc((void**)&ctx->d_satlist, npix * sizeof(uint32_t)));
+        ctx->cap_satlist = (int64_t)npix;
+    }
+    a.raw = d_raw; a.vfit = d_vfit; a.oscan = d_oscan; a.bias = d_bias; a.flat = d_flat; a.bpm = d_bpm;
+    a.data = d_data; a.mask = d_mask; a.satlist = ctx->d_satlist; a.counters = ctx->d_counters;
+    a.err = ctx->d_err; a.satcap = (uint32_t)ctx->cap_satlist;
+    for (int i = 0; i < 16; i++) { a.gain.v[i] = h_gain[i]; a.sat.v[i] = h_satlevel[i]; }
+    BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_SAT], 0, sizeof(int32_t), s));
+    // vector path needs 4-pixel groups inside one channel row and aligned addresses
+    bool vec = (a.d.xsz % 4 == 0) && (a.d.dx % 4 == 0) && (((uintptr_t)d_raw) % 16 == 0) &&
+               (((uintptr_t)d_data) % 16 == 0) && (((uintptr_t)d_mask) % 4 == 0);
+    const size_t groups = vec ? npix / 4 : npix;
+    unsigned grid = (unsigned)((groups + 255) / 256);
+    if (grid > 256u * 16u) grid = 256u * 16u;               // grid-stride beyond 16 blocks per CU
+    if (vec) {
+        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate<BBX_RAW_U16, 4>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_calibrate<BBX_RAW_F32, 4>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate<BBX_RAW_U16, 1>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_calibrate<BBX_RAW_F32, 1>), dim3(grid), dim3(256), 0, s, a);
+    }
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}

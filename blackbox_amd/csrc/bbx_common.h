@@ -1,0 +1,137 @@
+// bbx_common.h -- internal helpers shared by the HIP translation units (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/bbx.h"
+
+#define BBX_WAVE 64
+
+struct bbx_dims {
+    int ny_raw, nx_raw, ysz, xsz;   // raw shape, channel data section
+    int dy, dx;                     // channel size incl. overscans
+    int os_y, os_x;                 // overscan rows / columns per channel
+    int vos_x0, vos_w;              // vertical overscan strip: column offset in channel, width
+    int hos_rows;                   // rows of os_sec_hori (os_y - 10)
+    int ny, nx;                     // reduced frame shape
+};
+
+// reference define_sections, blackbox.py:6334-6402 (xbin = ybin = 1)
+static inline int bbx_make_dims(const bbx_geom* g, bbx_dims* d) {
+    if (!g || g->ny_raw <= 0 || g->nx_raw <= 0 || g->ysize_chan <= 0 || g->xsize_chan <= 0)
+        return BBX_ERR_ARG;
+    d->ny_raw = g->ny_raw; d->nx_raw = g->nx_raw;
+    d->ysz = g->ysize_chan; d->xsz = g->xsize_chan;
+    if (d->ny_raw % 2 || d->nx_raw % 8) return BBX_ERR_ARG;
+    d->dy = d->ny_raw / 2; d->dx = d->nx_raw / 8;
+    d->os_y = (d->ny_raw - 2 * d->ysz) / 2;
+    d->os_x = (d->nx_raw - 8 * d->xsz) / 8;
+    if (d->os_y != d->dy - d->ysz || d->os_x != d->dx - d->xsz) return BBX_ERR_ARG;
+    d->hos_rows = d->os_y - 10;            // ncut_hori = 10
+    d->vos_x0 = d->xsz + 5;                // ncut_vert = 5
+    d->vos_w = d->dx - 1 - d->vos_x0;      // last column dropped
+    if (d->hos_rows <= 0 || d->vos_w <= 0) return BBX_ERR_ARG;
+    d->ny = 2 * d->ysz; d->nx = 8 * d->xsz;
+    return BBX_OK;
+}
+
+// device-side error flags (bits) kept in ctx->d_err[0]
+#define BBX_DERR_LIST_OVERFLOW 1
+#define BBX_DERR_NOTCONV       2
+
+struct bbx_ctx {
+    int device;
+    char hip_err[256];
+    // --- persistent small device state
+    int32_t* d_err;            // [4] error flags
+    // --- work lists (device).  Capacities in elements.
+    uint32_t* d_satlist;  int64_t cap_satlist;   // saturated pixel indices (reduced frame)
+    int32_t*  d_counters;      // [64] device counters (see enum below)
+    // --- scratch, (re)allocated on demand by bbx_ws()
+    void*  d_ws[16];
+    size_t ws_bytes[16];
+};
+
+enum {
+    CNT_SAT = 0,        // saturated pixels queued by calibrate
+    CNT_CAND = 1,       // LA-Cosmic candidates of the current iteration
+    CNT_STAGE2 = 2,     // LA-Cosmic pixels that passed the first growth step
+    CNT_CRLIST = 3,     // cumulative CR pixel list
+    CNT_NEWCR = 4,      // CR pixels flagged in the current iteration
+    CNT_CC_N = 5,       // connected-component scratch: list length
+    CNT_CC_ROOTS = 6,   // connected-component scratch: roots
+    CNT_TILES = 7,      // fill-holes: unresolved tiles
+    CNT_BGNEED = 8,     // LA-Cosmic: pixels that needed the background level
+    CNT_TMP = 9,
+    CNT_MAX = 64
+};
+
+// workspace slots
+enum {
+    WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP,
+    WS_MAX
+};
+
+int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line);
+void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc);
+
+// small per-channel parameter vectors travel as by-value kernel arguments
+struct f32x16 { float v[16]; };
+struct f64x256 { double v[256]; };
+
+#define BBX_HIP(call)                                                         \
+    do {                                                                      \
+        hipError_t _e = (call);                                               \
+        if (_e != hipSuccess) return bbx_hip_fail(ctx, _e, #call, __LINE__);  \
+    } while (0)
+
+#define BBX_LAUNCH_CHECK()                                                    \
+    do {                                                                      \
+        hipError_t _e = hipGetLastError();                                    \
+        if (_e != hipSuccess) return bbx_hip_fail(ctx, _e, "kernel launch", __LINE__); \
+    } while (0)
+
+// ---- device helpers -------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// byte-wide atomic OR through the aligned 32-bit word (little endian)
+__device__ __forceinline__ unsigned atomic_or_u8(uint8_t* base, size_t idx, unsigned bits) {
+    size_t a = (size_t)(base + idx);
+    unsigned* w = (unsigned*)(a & ~(size_t)3);
+    unsigned sh = (unsigned)(a & 3) * 8;
+    unsigned old = atomicOr(w, bits << sh);
+    return (old >> sh) & 0xffu;
+}
+
+// raw pixel fetch: u16 or f32 -> float
+template <int RAW_T>
+__device__ __forceinline__ float raw_load(const void* raw, size_t i) {
+    if (RAW_T == BBX_RAW_U16) return (float)((const uint16_t*)raw)[i];
+    return ((const float*)raw)[i];
+}
+
+// float -> order-preserving uint32 key (radix select) and back
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}

@@ -1,0 +1,433 @@
+// bbx_mask.hip -- mask_init tail, fill_sat_holes, connected-object counts, mask counts.
+//
+// Saturated pixels are rare (tens of stars per frame), so everything here works
+// on the sparse pixel queue that bbx_calibrate leaves behind, plus a 1-bit-per-
+// pixel plane (14 MB for a 10560^2 frame) for the 3x3 closing and the hole fill.
+// The full-resolution uint8 mask is only touched at the (few) pixels that change.
+#include "bbx_common.h"
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------
+// sparse: crosstalk flags + saturated-connected ring + bit plane of M = sat | satcon
+// (mask_init, blackbox.py:4504-4531, 4557-4562; fill_sat_holes 4590-4591)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sat_scatter(const uint32_t* __restrict__ satlist,
+                                                     const int32_t* __restrict__ counters, bbx_dims d,
+                                                     uint8_t* mask, u64* bitsM, int W) {
+    const int n = counters[CNT_SAT];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = satlist[i];
+        const int Y = p / d.nx, X = p - Y * d.nx;
+        const int iy = Y / d.ysz, y = Y - iy * d.ysz;
+        const int ix = X / d.xsz, x = X - ix * d.xsz;
+        const int c = iy * 8 + ix;
+        // victims: same pixel position in the 15 other channels, y-flipped across rows
+        for (int v = 0; v < 16; v++) {
+            if (v == c) continue;
+            const int vy = v >> 3, vx = v & 7;
+            const int yy = (vy == iy) ? y : (d.ysz - 1 - y);
+            atomic_or_u8(mask, (size_t)(vy * d.ysz + yy) * d.nx + (size_t)vx * d.xsz + x, BBX_MASK_XTALK);
+        }
+        // 3x3 dilation ring and the bit plane
+        for (int dyy = -1; dyy <= 1; dyy++) {
+            const int Yn = Y + dyy;
+            if (Yn < 0 || Yn >= d.ny) continue;
+            for (int dxx = -1; dxx <= 1; dxx++) {
+                const int Xn = X + dxx;
+                if (Xn < 0 || Xn >= d.nx) continue;
+                const size_t q = (size_t)Yn * d.nx + Xn;
+                if ((dyy || dxx) && !(mask[q] & BBX_MASK_SAT)) atomic_or_u8(mask, q, BBX_MASK_SATCON);
+                atomicOr(&bitsM[(size_t)Yn * W + (Xn >> 6)], 1ull << (Xn & 63));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// 3x3 binary closing on the bit plane (ndimage.binary_closing, border_value 0)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ u64 row3(const u64* __restrict__ b, int r, int w, int ny, int W, bool outside_one) {
+    // OR (dilate) helper input: word w of rows r-1..r+1 combined with OR
+    u64 v = 0;
+    for (int k = -1; k <= 1; k++) {
+        int rr = r + k;
+        if (rr < 0 || rr >= ny) { if (outside_one) v = ~0ull; continue; }
+        v |= b[(size_t)rr * W + w];
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_bits_dilate(const u64* __restrict__ in, u64* __restrict__ out, int ny, int nx, int W) {
+    const size_t total = (size_t)ny * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
+        u64 n = row3(in, r, w, ny, W, false);
+        u64 nl = (w > 0) ? row3(in, r, w - 1, ny, W, false) : 0ull;
+        u64 nr = (w < W - 1) ? row3(in, r, w + 1, ny, W, false) : 0ull;
+        u64 h = n | (n << 1) | (n >> 1) | (nl >> 63) | (nr << 63);
+        if (w == W - 1 && (nx & 63)) h &= (1ull << (nx & 63)) - 1;        // stay inside the image
+        out[i] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bits_erode(const u64* __restrict__ in, u64* __restrict__ out, int ny, int nx, int W) {
+    const size_t total = (size_t)ny * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
+        u64 res = ~0ull;
+        for (int k = -1; k <= 1; k++) {
+            const int rr = r + k;
+            if (rr < 0 || rr >= ny) { res = 0; break; }                    // border_value = 0
+            const u64 c = in[(size_t)rr * W + w];
+            const u64 l = (w > 0) ? in[(size_t)rr * W + w - 1] : 0ull;
+            const u64 rt = (w < W - 1) ? in[(size_t)rr * W + w + 1] : 0ull;
+            res &= c & ((c << 1) | (l >> 63)) & ((c >> 1) | (rt << 63));
+        }
+        out[i] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// hole filling (ndimage.binary_fill_holes, 3x3 structure): background reached from
+// outside the image through 8-connected background is NOT a hole.
+//   tile = 64 px (one word) x 64 rows.  Empty tiles 4-connected to the frame edge
+//   through empty tiles are resolved wholesale (coarse flood, one workgroup, LDS);
+//   the remaining tiles are flooded at pixel level with word-parallel bit tricks.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_occupancy(const u64* __restrict__ bitsC, uint8_t* __restrict__ occ,
+                                                        int ny, int W, int TH) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * TH) return;
+    const int ty = t / W, tx = t - ty * W;
+    u64 any = 0;
+    for (int r = ty * 64; r < ty * 64 + 64 && r < ny; r++) any |= bitsC[(size_t)r * W + tx];
+    occ[t] = any ? 1 : 0;
+}
+
+#define COARSE_MAX 49152
+// state per tile: 0 = unresolved, 1 = resolved outside (empty + connected to the edge)
+__global__ __launch_bounds__(1024) void k_coarse_flood(const uint8_t* __restrict__ occ, uint8_t* __restrict__ state,
+                                                       int W, int TH, uint32_t* __restrict__ tiles,
+                                                       int32_t* counters, int32_t* err) {
+    __shared__ uint8_t st[COARSE_MAX];
+    __shared__ int changed;
+    const int nt = W * TH;
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+        const int ty = t / W, tx = t - ty * W;
+        const bool edge = (tx == 0 || ty == 0 || tx == W - 1 || ty == TH - 1);
+        st[t] = (!occ[t] && edge) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int iter = 0; iter < 2 * (W + TH) + 4 * nt; iter++) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            if (st[t] || occ[t]) continue;
+            const int ty = t / W, tx = t - ty * W;
+            bool r = (tx > 0 && st[t - 1]) || (tx < W - 1 && st[t + 1]) || (ty > 0 && st[t - W]) ||
+                     (ty < TH - 1 && st[t + W]);
+            if (r) { st[t] = 1; changed = 1; }
+        }
+        __syncthreads();
+        const int c = changed;
+        __syncthreads();
+        if (!c) break;
+    }
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+        state[t] = st[t];
+        if (!st[t]) { int k = atomicAdd(&counters[CNT_TILES], 1); tiles[k] = (uint32_t)t; }
+    }
+    (void)err;
+}
+
+// R plane init: resolved tiles all ones; unresolved zero; pad bits of the last word one
+__global__ __launch_bounds__(256) void k_reach_init(u64* __restrict__ R, const uint8_t* __restrict__ state, int ny, int nx, int W) {
+    const size_t total = (size_t)ny * W;
+    const u64 pad = (nx & 63) ? ~((1ull << (nx & 63)) - 1) : 0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
+        u64 v = state[(r >> 6) * W + w] ? ~0ull : 0ull;
+        if (w == W - 1) v |= pad;
+        R[i] = v;
+    }
+}
+
+__device__ __forceinline__ u64 reach3(const u64* R, int r, int w, int ny, int W) {
+    // OR of rows r-1..r+1 of word w; outside the image everything is reachable
+    if (w < 0 || w >= W) return ~0ull;
+    u64 v = R[(size_t)r * W + w];
+    v |= (r > 0) ? R[(size_t)(r - 1) * W + w] : ~0ull;
+    v |= (r < ny - 1) ? R[(size_t)(r + 1) * W + w] : ~0ull;
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void k_fine_flood(u64* R, const u64* __restrict__ bitsC,
+                                                     const uint32_t* __restrict__ tiles, const int32_t* counters,
+                                                     int ny, int nx, int W, int32_t* err) {
+    __shared__ int changed;
+    const int ntile = counters[CNT_TILES];
+    const long long nwork = (long long)ntile * 64;
+    const u64 pad = (nx & 63) ? ~((1ull << (nx & 63)) - 1) : 0ull;
+    const long long max_iter = 64 + nwork;      // every productive sweep adds >= 1 bit to >= 1 word-row
+    long long iter = 0;
+    for (;; iter++) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (long long k = threadIdx.x; k < nwork; k += blockDim.x) {
+            const uint32_t t = tiles[k >> 6];
+            const int ty = t / W, w = t - ty * W;
+            const int r = ty * 64 + (int)(k & 63);
+            if (r >= ny) continue;
+            u64 bg = ~bitsC[(size_t)r * W + w];
+            if (w == W - 1) bg |= pad;
+            const u64 cur = R[(size_t)r * W + w];
+            const u64 n = reach3(R, r, w, ny, W);
+            const u64 nl = reach3(R, r, w - 1, ny, W);
+            const u64 nr = reach3(R, r, w + 1, ny, W);
+            u64 x = (cur | n | (n << 1) | (n >> 1) | (nl >> 63) | (nr << 63)) & bg;
+            for (;;) {                       // fill along the row inside the word
+                const u64 yv = (x | (x << 1) | (x >> 1)) & bg;
+                if (yv == x) break;
+                x = yv;
+            }
+            if (x != cur) { R[(size_t)r * W + w] = x; changed = 1; }
+        }
+        __syncthreads();
+        const int c = changed;
+        __syncthreads();
+        if (!c) break;
+        if (iter > max_iter) { if (threadIdx.x == 0) atomicOr(err, BBX_DERR_NOTCONV); break; }
+    }
+}
+
+// new mask pixels: closing-added or hole pixels (= not reached) where the mask is 0
+__global__ __launch_bounds__(256) void k_fill_apply(const u64* __restrict__ R, const uint32_t* __restrict__ tiles,
+                                                    const int32_t* counters, uint8_t* mask, int ny, int nx, int W) {
+    const long long nwork = (long long)counters[CNT_TILES] * 64;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nwork; k += (long long)gridDim.x * blockDim.x) {
+        const uint32_t t = tiles[k >> 6];
+        const int ty = t / W, w = t - ty * W;
+        const int r = ty * 64 + (int)(k & 63);
+        if (r >= ny) continue;
+        u64 h = ~R[(size_t)r * W + w];
+        while (h) {
+            const int b = __ffsll((long long)h) - 1;
+            h &= h - 1;
+            const int X = w * 64 + b;
+            if (X < nx) {
+                const size_t q = (size_t)r * nx + X;
+                if (mask[q] == 0) mask[q] = BBX_MASK_SATCON;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// number of 8-connected objects in a sparse pixel list: hash + lock-free union-find
+// (ndimage.label(..., structure=ones((3,3)))[1])
+// ---------------------------------------------------------------------------------
+#define HEMPTY 0xffffffffu
+__device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
+    k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k;
+}
+
+__global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                   uint32_t* keys, uint32_t* vals, uint32_t hmask, uint32_t* parent,
+                                                   int cap, int32_t* err) {
+    int n = *cnt;
+    if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = list[i];
+        uint32_t h = hash_u32(p) & hmask;
+        for (;;) {
+            const uint32_t old = atomicCAS(&keys[h], HEMPTY, p);
+            if (old == HEMPTY || old == p) { vals[h] = (uint32_t)i; break; }
+            h = (h + 1) & hmask;
+        }
+        parent[i] = (uint32_t)i;
+    }
+}
+
+__device__ __forceinline__ int cc_lookup(const uint32_t* keys, const uint32_t* vals, uint32_t hmask, uint32_t p) {
+    uint32_t h = hash_u32(p) & hmask;
+    for (;;) {
+        const uint32_t k = keys[h];
+        if (k == p) return (int)vals[h];
+        if (k == HEMPTY) return -1;
+        h = (h + 1) & hmask;
+    }
+}
+
+__device__ __forceinline__ uint32_t cc_find(uint32_t* parent, uint32_t i) {
+    uint32_t p = *(volatile uint32_t*)&parent[i];
+    while (p != i) {
+        const uint32_t gp = *(volatile uint32_t*)&parent[p];
+        if (gp != p) parent[i] = gp;          // path halving (benign race)
+        i = p; p = gp;
+    }
+    return i;
+}
+
+__global__ __launch_bounds__(256) void k_cc_union(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                  const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                  uint32_t hmask, uint32_t* parent, int ny, int nx, int cap) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = list[i];
+        const int Y = p / nx, X = p - Y * nx;
+        const int ox[4] = {1, -1, 0, 1}, oy[4] = {0, 1, 1, 1};
+        for (int k = 0; k < 4; k++) {
+            const int Xn = X + ox[k], Yn = Y + oy[k];
+            if (Xn < 0 || Xn >= nx || Yn >= ny) continue;
+            const int j = cc_lookup(keys, vals, hmask, (uint32_t)(Yn * nx + Xn));
+            if (j < 0) continue;
+            uint32_t a = (uint32_t)i, b = (uint32_t)j;
+            for (;;) {
+                a = cc_find(parent, a); b = cc_find(parent, b);
+                if (a == b) break;
+                if (a < b) { uint32_t t = a; a = b; b = t; }      // a > b: hang a under b
+                const uint32_t old = atomicCAS(&parent[a], a, b);
+                if (old == a) break;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_count(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ parent,
+                                                  int32_t* out, int cap) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    int c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        c += (parent[i] == (uint32_t)i) ? 1 : 0;
+    c = wave_sum_i32(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// compaction of (mask & bit) pixels into a list
+__global__ __launch_bounds__(256) void k_compact_bit(const uint8_t* __restrict__ mask, size_t npix, int bit,
+                                                     uint32_t* list, int32_t* cnt, uint32_t cap, int32_t* err) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        if ((mask[i] & bit) == bit) {
+            unsigned k = atomicAdd((unsigned*)cnt, 1u);
+            if (k < cap) list[k] = (uint32_t)i; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        }
+    }
+}
+
+// count objects of a device-resident list (length in *d_cnt, at most cap entries are
+// considered; more raises the overflow flag) -> *d_out
+int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt, size_t cap, int ny, int nx,
+                      int32_t* d_out, hipStream_t s) {
+    int rc;
+    size_t hsize = 1024;
+    while (hsize < 2 * cap) hsize <<= 1;
+    uint32_t* hash = (uint32_t*)bbx_ws(ctx, WS_HASH, hsize * 2 * sizeof(uint32_t), &rc); if (rc) return rc;
+    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
+    uint32_t* keys = hash; uint32_t* vals = hash + hsize;
+    BBX_HIP(hipMemsetAsync(keys, 0xff, hsize * sizeof(uint32_t), s));
+    BBX_HIP(hipMemsetAsync(d_out, 0, sizeof(int32_t), s));
+    const unsigned grid = 1024;
+    hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent,
+                       (int)cap, ctx->d_err);
+    hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent, ny, nx,
+                       (int)cap);
+    hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, d_cnt, parent, d_out, (int)cap);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_mask_counts(const uint8_t* __restrict__ mask, size_t n4,
+                                                     unsigned long long* __restrict__ out) {
+    // bits in reporting order: bad, edge, saturated, saturated-connected, satellite, cosmic
+    const unsigned bits[6] = {1u, 32u, 4u, 8u, 16u, 2u};
+    long long c[6] = {0, 0, 0, 0, 0, 0};
+    const uint32_t* m4 = (const uint32_t*)mask;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t w = m4[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k] += __popc(w & (bits[k] * 0x01010101u));
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        long long v = wave_sum_i64(c[k]);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[k], (unsigned long long)v);
+    }
+}
+
+__global__ void k_mask_counts_tail(const uint8_t* __restrict__ mask, size_t from, size_t n,
+                                   unsigned long long* __restrict__ out) {
+    const unsigned bits[6] = {1u, 32u, 4u, 8u, 16u, 2u};
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (size_t i = from; i < n; i++)
+            for (int k = 0; k < 6; k++) if (mask[i] & bits[k]) out[k] += 1;
+}
+
+extern "C" {
+
+int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d_nobj_sat, void* stream) {
+    if (!ctx || !d_mask || !d_nobj_sat) return BBX_ERR_ARG;
+    bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
+    if (!ctx->d_satlist) return BBX_ERR_ARG;                 // bbx_calibrate must have run
+    hipStream_t s = (hipStream_t)stream;
+    const int W = (d.nx + 63) / 64, TH = (d.ny + 63) / 64;
+    if ((size_t)W * TH > COARSE_MAX) return BBX_ERR_ARG;
+    const size_t nwords = (size_t)d.ny * W;
+    u64* bitsM = (u64*)bbx_ws(ctx, WS_BITS_M, nwords * 8, &rc); if (rc) return rc;
+    u64* bitsC = (u64*)bbx_ws(ctx, WS_BITS_C, nwords * 8, &rc); if (rc) return rc;
+    u64* bitsR = (u64*)bbx_ws(ctx, WS_BITS_R, nwords * 8, &rc); if (rc) return rc;
+    char* tws = (char*)bbx_ws(ctx, WS_TILES, (size_t)W * TH * (2 + sizeof(uint32_t)), &rc); if (rc) return rc;
+    uint8_t* occ = (uint8_t*)tws; uint8_t* state = occ + (size_t)W * TH;
+    uint32_t* tiles = (uint32_t*)(tws + (((size_t)2 * W * TH + 15) & ~(size_t)15));
+    // (tiles offset may exceed the requested size by the alignment slack; bbx_ws over-allocates by 1/8 + 256)
+    BBX_HIP(hipMemsetAsync(bitsM, 0, nwords * 8, s));
+    BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_TILES], 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_sat_scatter, dim3(512), dim3(256), 0, s, ctx->d_satlist, ctx->d_counters, d, d_mask, bitsM, W);
+    // NOBJ-SAT: objects of the saturated pixels themselves (blackbox.py:4544-4550)
+    rc = bbx_cc_count_list(ctx, ctx->d_satlist, &ctx->d_counters[CNT_SAT],
+                           (size_t)ctx->cap_satlist > (1u << 22) ? (size_t)(1u << 22) : (size_t)ctx->cap_satlist,
+                           d.ny, d.nx, d_nobj_sat, s);
+    if (rc) return rc;
+    const unsigned gw = (unsigned)((nwords + 255) / 256 > 4096 ? 4096 : (nwords + 255) / 256);
+    hipLaunchKernelGGL(k_bits_dilate, dim3(gw), dim3(256), 0, s, bitsM, bitsR, d.ny, d.nx, W);   // R as temp
+    hipLaunchKernelGGL(k_bits_erode, dim3(gw), dim3(256), 0, s, bitsR, bitsC, d.ny, d.nx, W);
+    hipLaunchKernelGGL(k_tile_occupancy, dim3((W * TH + 255) / 256), dim3(256), 0, s, bitsC, occ, d.ny, W, TH);
+    hipLaunchKernelGGL(k_coarse_flood, dim3(1), dim3(1024), 0, s, occ, state, W, TH, tiles, ctx->d_counters, ctx->d_err);
+    hipLaunchKernelGGL(k_reach_init, dim3(gw), dim3(256), 0, s, bitsR, state, d.ny, d.nx, W);
+    hipLaunchKernelGGL(k_fine_flood, dim3(1), dim3(1024), 0, s, bitsR, bitsC, tiles, ctx->d_counters, d.ny, d.nx, W, ctx->d_err);
+    hipLaunchKernelGGL(k_fill_apply, dim3(256), dim3(256), 0, s, bitsR, tiles, ctx->d_counters, d_mask, d.ny, d.nx, W);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_count_objects(bbx_ctx* ctx, int ny, int nx, const uint8_t* d_mask, int bit, int32_t* d_count, void* stream) {
+    if (!ctx || !d_mask || !d_count || ny <= 0 || nx <= 0 || bit <= 0 || bit > 255) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const size_t npix = (size_t)ny * nx;
+    if (npix >= 0xffffffffull) return BBX_ERR_ARG;
+    // list capacity: 1/16 of the frame is far beyond any real mask plane; more is
+    // reported as BBX_ERR_OVERFLOW by bbx_sync
+    const size_t cap = npix / 16 + 1024;
+    uint32_t* list = (uint32_t*)bbx_ws(ctx, WS_CCLIST, cap * sizeof(uint32_t), &rc); if (rc) return rc;
+    BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_CC_N], 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_compact_bit, dim3(2048), dim3(256), 0, s, d_mask, npix, bit, list, &ctx->d_counters[CNT_CC_N],
+                       (uint32_t)cap, ctx->d_err);
+    BBX_LAUNCH_CHECK();
+    return bbx_cc_count_list(ctx, list, &ctx->d_counters[CNT_CC_N], cap, ny, nx, d_count, s);
+}
+
+int bbx_mask_counts(bbx_ctx* ctx, int64_t npix, const uint8_t* d_mask, int64_t* d_counts, void* stream) {
+    if (!ctx || !d_mask || !d_counts || npix <= 0) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    BBX_HIP(hipMemsetAsync(d_counts, 0, 6 * sizeof(int64_t), s));
+    const size_t n4 = (size_t)npix / 4;
+    if (((uintptr_t)d_mask) % 4) return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_mask_counts, dim3(2048), dim3(256), 0, s, d_mask, n4, (unsigned long long*)d_counts);
+    if (n4 * 4 < (size_t)npix)
+        hipLaunchKernelGGL(k_mask_counts_tail, dim3(1), dim3(64), 0, s, d_mask, n4 * 4, (size_t)npix, (unsigned long long*)d_counts);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+}  // extern "C"

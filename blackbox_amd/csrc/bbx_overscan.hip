@@ -1,0 +1,293 @@
+// bbx_overscan.hip -- overscan strip reductions (reference os_corr, blackbox.py:6407-6879)
+//
+// The bulk reductions run here; the float64 polynomial / spline fits on the
+// resulting <= 5300-point vectors stay on the host (blackbox_amd/overscan.py),
+// as SURVEY.md section 7 plans.  All kernels are HBM-bound strip readers.
+#include "bbx_common.h"
+
+#define VOS_VMAX 8      // values per lane -> strips up to 512 columns wide
+
+// ---------------------------------------------------------------------------------
+// per (channel,row): astropy sigma_clipped_stats(axis=1, mask_value=0,
+// cenfunc='mean') of the gain-corrected vertical overscan (os_corr 6480-6490).
+// One wave per row; values live in registers as float64; clip loop follows
+// astropy's C gufunc (mean, std ddof=0, closed interval, <= 5 bound updates,
+// final bounds applied to all values).
+// ---------------------------------------------------------------------------------
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_vos_rowstats(const void* __restrict__ raw, bbx_dims d,
+                                                      f32x16 gain, double* __restrict__ mean_out) {
+    const int lane = threadIdx.x & 63;
+    const int row_id = blockIdx.x * 4 + (threadIdx.x >> 6);      // 0 .. 16*dy-1
+    if (row_id >= 16 * d.dy) return;
+    const int c = row_id / d.dy, r = row_id - c * d.dy;
+    const int iy = c >> 3, ix = c & 7;
+    const size_t base = (size_t)(iy * d.dy + r) * d.nx_raw + (size_t)ix * d.dx + d.vos_x0;
+    const float g = gain.v[c];
+    double v[VOS_VMAX];
+    bool ok[VOS_VMAX];      // still inside the running clip
+    bool valid[VOS_VMAX];   // finite and != mask_value(0)
+#pragma unroll
+    for (int j = 0; j < VOS_VMAX; j++) {
+        int col = lane + 64 * j;
+        valid[j] = false; v[j] = 0.0;
+        if (col < d.vos_w) {
+            float f = raw_load<RAW_T>(raw, base + col);
+            if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;   // scrub, blackbox.py:1461-1468
+            f = f * g;                                          // gain_corr, float32 multiply
+            v[j] = (double)f;
+            valid[j] = isfinite(f) && !(fabs(v[j]) <= 1e-8);
+        }
+        ok[j] = valid[j];
+    }
+    double lo = __longlong_as_double(0x7ff8000000000000LL), hi = lo;   // NaN until computed
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < VOS_VMAX; j++) n += ok[j] ? 1 : 0;
+    n = wave_sum_i32(n);
+    for (int it = 0; it < 5 && n > 0; it++) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < VOS_VMAX; j++) if (ok[j]) s += v[j];
+        s = wave_sum_f64(s);
+        const double mean = s / (double)n;
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < VOS_VMAX; j++) if (ok[j]) { double t = mean - v[j]; q += t * t; }
+        q = wave_sum_f64(q);
+        const double sd = sqrt(q / (double)n);
+        lo = mean - 3.0 * sd;
+        hi = mean + 3.0 * sd;
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < VOS_VMAX; j++) { ok[j] = ok[j] && v[j] >= lo && v[j] <= hi; m += ok[j] ? 1 : 0; }
+        m = wave_sum_i32(m);
+        if (m == n) break;
+        n = m;
+    }
+    // final: every valid value inside the last bounds (NaN bounds reject nothing
+    // -- only reachable with n == 0, where the mean is NaN anyway)
+    double s = 0.0; int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < VOS_VMAX; j++) {
+        bool keep = valid[j] && !(v[j] < lo) && !(v[j] > hi);
+        if (keep) { s += v[j]; cnt++; }
+    }
+    s = wave_sum_f64(s); cnt = wave_sum_i32(cnt);
+    if (lane == 0) mean_out[row_id] = s / (double)cnt;            // 0/0 -> NaN like nanmean of all-NaN
+}
+
+// gain-corrected copy of the horizontal overscan rows (os_sec_hori), all dx columns
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_hos_copy(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
+                                                  float* __restrict__ hos) {
+    const int total = 16 * d.hos_rows * d.dx;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int x = i % d.dx; int t = i / d.dx; int r = t % d.hos_rows; int c = t / d.hos_rows;
+        int iy = c >> 3, ix = c & 7;
+        // os_sec_hori: lower row channels [dy-cut, dy), upper row channels [dy, dy+cut)
+        int gy = (iy == 0) ? (d.dy - d.hos_rows + r) : (d.dy + r);
+        float f = raw_load<RAW_T>(raw, (size_t)gy * d.nx_raw + (size_t)ix * d.dx + x);
+        if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;
+        hos[i] = f * gain.v[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_nonfinite(const float* __restrict__ raw, size_t n,
+                                                         unsigned long long* __restrict__ out) {
+    long long cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        cnt += isfinite(raw[i]) ? 0 : 1;
+    cnt = wave_sum_i64(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
+}
+
+// ---------------------------------------------------------------------------------
+// read noise: clipped std of the fit-subtracted vertical overscan (os_corr 6572)
+// ---------------------------------------------------------------------------------
+struct vos_state {          // per channel
+    double lo, hi;          // running intersection of the clip intervals
+    double mean, std;       // statistics of the current survivors
+    long long n;            // survivors counted by the last pass
+    int frozen;             // clip loop finished
+    int pad;
+};
+#define VSTD_BLOCKS 64      // partial-sum blocks per channel
+
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_vos_std_pass(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
+                                                      const double* __restrict__ vfit,
+                                                      const vos_state* __restrict__ st,
+                                                      double* __restrict__ partial /*[16][VSTD_BLOCKS][3]*/) {
+    const int c = blockIdx.y, b = blockIdx.x;
+    const int iy = c >> 3, ix = c & 7;
+    const double lo = st[c].lo, hi = st[c].hi;
+    const float g = gain.v[c];
+    const long long total = (long long)d.dy * d.vos_w;
+    double s1 = 0.0, s2 = 0.0; long long n = 0;
+    for (long long i = (long long)b * 256 + threadIdx.x; i < total; i += (long long)VSTD_BLOCKS * 256) {
+        int r = (int)(i / d.vos_w), col = (int)(i - (long long)r * d.vos_w);
+        float f = raw_load<RAW_T>(raw, (size_t)(iy * d.dy + r) * d.nx_raw + (size_t)ix * d.dx + d.vos_x0 + col);
+        if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;
+        f = f * g;
+        float x = (float)((double)f - vfit[c * d.dy + r]);       // float32 array -= float64 column
+        double xd = (double)x;
+        bool keep = isfinite(x) && !(fabs(xd) <= 1e-8) && xd >= lo && xd <= hi;
+        if (keep) { s1 += xd; s2 += xd * xd; n++; }
+    }
+    // deterministic block reduction: wave shuffle, then waves in order
+    __shared__ double sh1[4], sh2[4]; __shared__ long long shn[4];
+    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2); n = wave_sum_i64(n);
+    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = s1; sh2[threadIdx.x >> 6] = s2; shn[threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
+        double q = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+        long long m = shn[0] + shn[1] + shn[2] + shn[3];
+        double* p = partial + ((size_t)c * VSTD_BLOCKS + b) * 3;
+        p[0] = a; p[1] = q; p[2] = (double)m;
+    }
+}
+
+// one thread per channel: fold the partials in fixed order, update the clip state.
+// Follows SigmaClip._sigmaclip_noaxis: bounds from the survivors' mean/std, survivors
+// = survivors inside the closed interval, stop when nothing changed or after 5
+// iterations; the pass after the last filter delivers the returned statistics.
+__global__ void k_vos_std_update(vos_state* st, const double* __restrict__ partial, int pass,
+                                 double* __restrict__ std_out) {
+    int c = threadIdx.x;
+    if (c >= 16) return;
+    vos_state s = st[c];
+    if (!s.frozen) {
+        double a = 0.0, q = 0.0, m = 0.0;
+        for (int b = 0; b < VSTD_BLOCKS; b++) {
+            const double* p = partial + ((size_t)c * VSTD_BLOCKS + b) * 3;
+            a += p[0]; q += p[1]; m += p[2];
+        }
+        long long n = (long long)m;
+        double mean = a / m;
+        double var = q / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double sd = sqrt(var);
+        bool unchanged = (pass > 0 && n == s.n);
+        s.mean = mean; s.std = sd; s.n = n;
+        if (unchanged || pass >= 5 || n == 0) {
+            s.frozen = 1;
+        } else {
+            double lo = mean - 3.0 * sd, hi = mean + 3.0 * sd;
+            if (lo > s.lo) s.lo = lo;
+            if (hi < s.hi) s.hi = hi;
+        }
+        st[c] = s;
+    }
+    std_out[c] = s.std;
+}
+
+__global__ void k_vos_std_init(vos_state* st) {
+    int c = threadIdx.x;
+    if (c < 16) {
+        st[c].lo = -__builtin_huge_val(); st[c].hi = __builtin_huge_val();
+        st[c].mean = 0; st[c].std = 0; st[c].n = -1; st[c].frozen = 0; st[c].pad = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// BlackGEM: per-column counts of near-saturated pixels (os_corr 6624-6640)
+// ---------------------------------------------------------------------------------
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_satcol(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
+                                                const double* __restrict__ vfit, f32x16 thr, int rows1,
+                                                int rows2, int* __restrict__ counts) {
+    const int c = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= d.xsz) return;
+    const int iy = c >> 3, ix = c & 7;
+    const int k0 = blockIdx.y * 64;                 // distance from the overscan edge
+    int n1 = 0, n2 = 0;
+    for (int k = k0; k < k0 + 64 && k < rows2; k++) {
+        // data-section row: upper channels count from row 0, lower from the top row down
+        int y = (iy == 1) ? k : (d.ysz - 1 - k);
+        int rl = (iy == 0) ? y : (d.os_y + y);      // channel-local row
+        float f = raw_load<RAW_T>(raw, (size_t)(iy * d.dy + rl) * d.nx_raw + (size_t)ix * d.dx + x);
+        if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;
+        f = f * gain.v[c];
+        float v = (float)((double)f - vfit[c * d.dy + rl]);
+        if (v >= thr.v[c]) { n2++; if (k < rows1) n1++; }
+    }
+    if (n1) atomicAdd(&counts[(0 * 16 + c) * d.xsz + x], n1);
+    if (n2) atomicAdd(&counts[(1 * 16 + c) * d.xsz + x], n2);
+}
+
+static f32x16 load16(const float* h) { f32x16 r; for (int i = 0; i < 16; i++) r.v[i] = h[i]; return r; }
+
+extern "C" {
+
+int bbx_overscan_stats(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type,
+                       const float* h_gain, double* d_mean_vos_col, float* d_hos,
+                       int64_t* d_n_infnan, void* stream) {
+    if (!ctx || !d_raw || !h_gain || !d_mean_vos_col || !d_hos || !d_n_infnan) return BBX_ERR_ARG;
+    bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
+    if (d.vos_w > 64 * VOS_VMAX) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    f32x16 gain = load16(h_gain);
+    const int rows = 16 * d.dy;
+    dim3 grid((rows + 3) / 4), block(256);
+    BBX_HIP(hipMemsetAsync(d_n_infnan, 0, sizeof(int64_t), s));
+    if (raw_type == BBX_RAW_U16) {
+        hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_U16>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        hipLaunchKernelGGL(k_hos_copy<BBX_RAW_U16>, dim3(256), block, 0, s, d_raw, d, gain, d_hos);
+    } else if (raw_type == BBX_RAW_F32) {
+        hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_F32>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        hipLaunchKernelGGL(k_hos_copy<BBX_RAW_F32>, dim3(256), block, 0, s, d_raw, d, gain, d_hos);
+        hipLaunchKernelGGL(k_count_nonfinite, dim3(2048), block, 0, s, (const float*)d_raw,
+                           (size_t)d.ny_raw * d.nx_raw, (unsigned long long*)d_n_infnan);
+    } else return BBX_ERR_ARG;
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_vos_std(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type, const float* h_gain,
+                const double* d_vfit, double* d_std_vos, void* stream) {
+    if (!ctx || !d_raw || !h_gain || !d_vfit || !d_std_vos) return BBX_ERR_ARG;
+    bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    f32x16 gain = load16(h_gain);
+    char* ws = (char*)bbx_ws(ctx, WS_STRIP, 16 * sizeof(vos_state) + 16 * VSTD_BLOCKS * 3 * sizeof(double), &rc);
+    if (rc) return rc;
+    vos_state* st = (vos_state*)ws;
+    double* partial = (double*)(ws + 16 * sizeof(vos_state));
+    hipLaunchKernelGGL(k_vos_std_init, dim3(1), dim3(64), 0, s, st);
+    for (int pass = 0; pass < 6; pass++) {
+        if (raw_type == BBX_RAW_U16)
+            hipLaunchKernelGGL(k_vos_std_pass<BBX_RAW_U16>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain,
+                               d_vfit, st, partial);
+        else if (raw_type == BBX_RAW_F32)
+            hipLaunchKernelGGL(k_vos_std_pass<BBX_RAW_F32>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain,
+                               d_vfit, st, partial);
+        else return BBX_ERR_ARG;
+        hipLaunchKernelGGL(k_vos_std_update, dim3(1), dim3(64), 0, s, st, partial, pass, d_std_vos);
+    }
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_satcol_counts(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type, const float* h_gain,
+                      const double* d_vfit, const float* h_thr, int rows1, int rows2, int32_t* d_counts,
+                      void* stream) {
+    if (!ctx || !d_raw || !h_gain || !d_vfit || !h_thr || !d_counts) return BBX_ERR_ARG;
+    bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
+    if (rows1 <= 0 || rows2 < rows1 || rows2 > d.ysz) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    f32x16 gain = load16(h_gain), thr = load16(h_thr);
+    BBX_HIP(hipMemsetAsync(d_counts, 0, (size_t)2 * 16 * d.xsz * sizeof(int32_t), s));
+    dim3 grid((d.xsz + 255) / 256, (rows2 + 63) / 64, 16);
+    if (raw_type == BBX_RAW_U16)
+        hipLaunchKernelGGL(k_satcol<BBX_RAW_U16>, grid, dim3(256), 0, s, d_raw, d, gain, d_vfit, thr, rows1, rows2, d_counts);
+    else if (raw_type == BBX_RAW_F32)
+        hipLaunchKernelGGL(k_satcol<BBX_RAW_F32>, grid, dim3(256), 0, s, d_raw, d, gain, d_vfit, thr, rows1, rows2, d_counts);
+    else return BBX_ERR_ARG;
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// bbx_xtalk.hip -- crosstalk correction (reference xtalk_corr, blackbox.py:7138-7258)
+//
+// The reference stacks the 16 channels, builds a y-flipped copy, and runs four
+// float64 matmuls with K = 8.  Here one thread owns one pixel position (y, x) of
+// the channel grid: it reads the 16 source values that couple to each other -- the
+// 8 lower-row channels at row y and the 8 upper-row channels at the mirrored row
+// ysize-1-y -- applies the 16x16 coefficient matrix in float64 registers and writes
+// the 16 corrected victims back in place.  Every pixel is read once and written
+// once: 4N + N (mask) + 4N bytes, HBM-bound (16 float64 FMAs per output pixel are
+// far below the vector rate, so no MFMA reshaping).
+#include "bbx_common.h"
+
+__global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __restrict__ mask, bbx_dims d, f64x256 cf) {
+    const size_t total = (size_t)d.ysz * d.xsz;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(t / d.xsz), x = (int)(t - (size_t)y * d.xsz);
+        size_t off[16];
+        double src[16];
+        float val[16];
+        bool victim_ok[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int iy = c >> 3, ix = c & 7;
+            const int Y = (iy == 0) ? y : (d.ysz + (d.ysz - 1 - y));
+            off[c] = (size_t)Y * d.nx + (size_t)ix * d.xsz + x;
+            const float v = data[off[c]];
+            const uint8_t m = mask[off[c]];
+            val[c] = v;
+            // mask_source: positive, not bad, not cosmic (7178-7180); mask_victim: not edge (7184)
+            const bool use = (v > 0.f) && !(m & BBX_MASK_BAD) && !(m & BBX_MASK_COSMIC);
+            src[c] = use ? (double)v : 0.0;
+            victim_ok[c] = !(m & BBX_MASK_EDGE);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            double q_lo = 0.0, q_hi = 0.0;                     // the two K=8 quadrant products
+#pragma unroll
+            for (int s = 0; s < 8; s++) q_lo = fma(src[s], cf.v[s * 16 + v], q_lo);
+#pragma unroll
+            for (int s = 8; s < 16; s++) q_hi = fma(src[s], cf.v[s * 16 + v], q_hi);
+            const double corr = (0.0 + q_lo) + q_hi;
+            data[off[v]] = (float)((double)val[v] - (victim_ok[v] ? corr : corr * 0.0));
+        }
+    }
+}
+
+extern "C" int bbx_xtalk(bbx_ctx* ctx, const bbx_geom* g, float* d_data, const uint8_t* d_mask,
+                         const double* h_coeffs, void* stream) {
+    if (!ctx || !d_data || !d_mask || !h_coeffs) return BBX_ERR_ARG;
+    bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
+    f64x256 cf;
+    for (int i = 0; i < 256; i++) cf.v[i] = h_coeffs[i];
+    const size_t total = (size_t)d.ysz * d.xsz;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 256u * 16u) grid = 256u * 16u;
+    hipLaunchKernelGGL(k_xtalk, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}

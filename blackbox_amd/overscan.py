@@ -1,0 +1,236 @@
+"""Host side of os_corr: the float64 fits on the small overscan vectors.
+
+The bulk strip reductions run on the GPU (csrc/bbx_overscan.hip); what is left
+are <= 5300-point polynomial fits and a 180-point smoothing spline per channel
+(blackbox.py:6497-6517 and 6660-6814), which SURVEY.md section 7 keeps on the
+host in numpy/scipy because the reference itself uses np.polyfit (LAPACK lstsq)
+and scipy's FITPACK spline -- re-deriving those bit for bit would be pointless.
+
+Numerical convention of the horizontal-overscan statistics: the reference
+environment (astropy 4.3 + bottleneck) accumulates the clipped mean/std of the
+float32 strips in float32 with a running sum.  ``accum='f32seq'`` (default)
+reproduces that order, which makes the reduced pixels bit-identical to the
+golden vectors; ``accum='f64'`` uses float64 accumulators (differences of <= 2
+float32 ulp per pixel).
+"""
+import warnings
+
+import numpy as np
+from scipy import interpolate, ndimage
+
+IDX_SWITCH = 150      # blackbox.py:6683
+OVERLAP = 30          # blackbox.py:6684
+
+
+def _seqsum32(v):
+    return np.cumsum(v, dtype=np.float32)[-1] if v.size else np.float32(0)
+
+
+def _mean_std_flat(v, accum):
+    n = v.size
+    if accum == 'f32seq' and v.dtype == np.float32:
+        mean = np.float32(_seqsum32(v) / np.float32(n))
+        dev = v - mean
+        std = np.float32(np.sqrt(_seqsum32(dev * dev) / np.float32(n)))
+        return mean, std
+    v = v.astype(np.float64)
+    mean = v.sum() / n
+    return mean, np.sqrt(((v - mean) ** 2).sum() / n)
+
+
+def clipped_stats_flat(values, sigma=3.0, maxiters=5, accum='f32seq'):
+    """astropy sigma_clipped_stats(values, sigma=sigma, cenfunc='mean') on a
+    flattened array -> (mean, std, n_survivors)"""
+    v = np.ascontiguousarray(values).ravel()
+    v = v[np.isfinite(v)]
+    for _ in range(maxiters):
+        if v.size == 0:
+            break
+        mean, std = _mean_std_flat(v, accum)
+        lo = float(mean) - float(std) * sigma
+        hi = float(mean) + float(std) * sigma
+        if accum == 'f32seq' and v.dtype == np.float32:
+            keep = (v >= np.float32(lo)) & (v <= np.float32(hi))
+        else:
+            vv = v.astype(np.float64)
+            keep = (vv >= lo) & (vv <= hi)
+        if keep.all():
+            break
+        v = v[keep]
+    if v.size == 0:
+        return np.nan, np.nan, 0
+    mean, std = _mean_std_flat(v, accum)
+    return mean, std, v.size
+
+
+def vos_polyfit(mean_vos_col, nrows, i_chan, poldeg=3):
+    """blackbox.py:6497-6556.  -> (fit[dy] float64, coeffs low->high order,
+    polyfit_ok, mean level)"""
+    nrows_chan = mean_vos_col.size
+    y_vos = np.arange(nrows_chan)
+    polyfit_ok = True
+    p = None
+    try:
+        mean, stddev, _ = clipped_stats_flat(mean_vos_col, sigma=5, accum='f64')
+        if stddev == 0:
+            mask_fit = np.ones(nrows_chan, dtype=bool)
+        else:
+            with np.errstate(invalid='ignore'):
+                mask_fit = np.abs(mean_vos_col - mean) / stddev <= 5
+        if i_chan < 8:
+            mask_fit[nrows:] = False
+        else:
+            mask_fit[:nrows_chan - nrows] = False
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')          # os_corr runs with warnings as errors (6432)
+            p = np.polyfit(y_vos[mask_fit], mean_vos_col[mask_fit], poldeg)
+    except Exception:
+        polyfit_ok = False
+    if p is None:
+        # the reference would reuse the previous channel's coefficients (or raise on
+        # the first channel); treat as a failed fit with the median level
+        level = np.nanmedian(mean_vos_col)
+        return np.full(nrows_chan, level), np.full(poldeg + 1, np.nan), False, level
+    fit = np.polyval(p, y_vos)
+    if not np.all(np.isfinite(fit)):
+        polyfit_ok = False
+    if polyfit_ok:
+        level = np.mean(fit)
+    else:
+        level = np.nanmedian(mean_vos_col)
+        fit = np.full(nrows_chan, level)
+    return fit, p[::-1], polyfit_ok, level
+
+
+def hos_mask_ml1(data_hos, data_limit=2000):
+    """blackbox.py:6586-6614"""
+    mask_hos = data_hos > data_limit
+    mask_x = np.sum(mask_hos, axis=0) > 0.5 * mask_hos.shape[0]
+    mask_x_open = ndimage.binary_opening(mask_x, structure=np.ones(2))
+    mask_hos[:, np.logical_xor(mask_x, mask_x_open)] = False
+    return ndimage.binary_dilation(mask_hos, structure=np.ones((3, 3), dtype=bool),
+                                   iterations=2)
+
+
+def hos_column_stats(data_hos, mask_hos, accum='f32seq'):
+    """blackbox.py:6649-6659: sigma_clip(axis=0, sigma=2.5, cenfunc='mean') then
+    per-column count / mean / std(ddof=1).  float32 results like the reference."""
+    d64 = data_hos.astype(np.float64)
+    ok = np.isfinite(d64) & ~mask_hos
+    lo = np.full(d64.shape[1], np.nan)
+    hi = np.full(d64.shape[1], np.nan)
+    cur = ok.copy()
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for _ in range(5):
+            n = cur.sum(axis=0)
+            mean = np.where(cur, d64, 0.0).sum(axis=0) / n
+            dev = np.where(cur, mean[None, :] - d64, 0.0)
+            std = np.sqrt((dev * dev).sum(axis=0) / n)
+            upd = n > 0
+            lo = np.where(upd, mean - 2.5 * std, lo)
+            hi = np.where(upd, mean + 2.5 * std, hi)
+            cur = cur & (d64 >= lo[None, :]) & (d64 <= hi[None, :])
+        ok = ok & ~(d64 < lo[None, :]) & ~(d64 > hi[None, :])
+        n = ok.sum(axis=0)
+        if accum == 'f32seq':
+            f = np.float32
+            tot = np.zeros(d64.shape[1], f)
+            for i in range(data_hos.shape[0]):
+                tot = tot + np.where(ok[i], data_hos[i], f(0))
+            mean = tot / n.astype(f)
+            dev = np.where(ok, data_hos - mean[None, :], f(0)).astype(f)
+            sq = dev * dev
+            tot2 = np.zeros_like(tot)
+            for i in range(data_hos.shape[0]):
+                tot2 = tot2 + sq[i]
+            std = np.sqrt(tot2 / (n - 1).astype(f))
+        else:
+            mean = np.where(ok, d64, 0.0).sum(axis=0) / n
+            dev = np.where(ok, d64 - mean[None, :], 0.0)
+            std = np.sqrt((dev * dev).sum(axis=0) / (n - 1))
+            mean = mean.astype(np.float32)
+            std = std.astype(np.float32)
+    return n, mean, std
+
+
+def _polyfit_quiet(x, y, deg):
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        return np.polyfit(x, y, deg)
+
+
+def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
+            accum='f32seq'):
+    """blackbox.py:6660-6814 -> oscan float64[ncols]"""
+    ncols = mean_hos.size
+    mask_valid = n > 1
+    xcol = np.arange(ncols) + 1
+    err_hos = np.zeros(ncols, np.float32)
+    weights = np.zeros(ncols, np.float32)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        err_hos[mask_valid] = (std_hos[mask_valid].astype(np.float64) /
+                               np.sqrt(n[mask_valid])).astype(np.float32)
+        mask_nonzero = err_hos != 0
+        weights[mask_nonzero] = np.float32(1) / err_hos[mask_nonzero]
+    if np.all(mask_valid[0:3]):
+        weights[0:3] = 0
+    idx_fit = np.arange(IDX_SWITCH + OVERLAP)
+    npoints = int(np.sum(mask_valid[idx_fit] & mask_nonzero[idx_fit]))
+    sel = mask_valid[idx_fit]
+    y2fit = mean_hos[idx_fit][sel].copy()
+    nfit = y2fit.size
+    # 3-point running median of the points to fit (6703-6708), from the original values
+    med = [np.median(y2fit[max(k - 1, 3):min(k + 2, nfit)]) for k in range(3, nfit)]
+    y2fit[3:] = np.asarray(med, np.float32)
+    xs, ws = xcol[idx_fit][sel], weights[idx_fit][sel]
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        try:
+            splfit = interpolate.UnivariateSpline(xs, y2fit, w=ws, k=2, s=npoints)
+        except UserWarning:
+            warnings.simplefilter('ignore')
+            splfit = interpolate.UnivariateSpline(xs, y2fit, w=ws, k=3, s=1.5 * npoints)
+    mask_valid_poly = mask_valid.copy()
+    mask_valid_poly[0:IDX_SWITCH - OVERLAP] = False
+    mhp = mean_hos[mask_valid_poly]
+    mean, stddev, _ = clipped_stats_flat(mhp, sigma=5, accum=accum)
+    if stddev == 0:
+        keep = np.ones(mhp.size, dtype=bool)
+    elif accum == 'f32seq':
+        with np.errstate(invalid='ignore'):
+            keep = np.abs(mhp - np.float32(mean)) / np.float32(stddev) <= np.float32(5)
+    else:
+        with np.errstate(invalid='ignore'):
+            keep = np.abs(mhp.astype(np.float64) - mean) / stddev <= 5
+    mask_valid_poly[mask_valid_poly] = keep
+    err3 = np.float32(3) * err_hos
+
+    def fit_iter(mask_fit, deg):
+        fit = None
+        for _ in range(3):
+            p = _polyfit_quiet(xcol[mask_fit], mean_hos[mask_fit], deg)
+            fit = np.polyval(p, xcol)
+            with np.errstate(invalid='ignore'):
+                mask_fit &= np.abs(fit - mean_hos) <= err3
+        return fit
+
+    if not bg2_chan9:
+        oscan = fit_iter(mask_valid_poly, 7)
+    else:
+        idx_split = 654                                   # blackbox.py:6763
+        m1 = mask_valid_poly.copy()
+        m1[idx_split:] = False
+        fit1 = fit_iter(m1, 5)
+        m2 = mask_valid_poly.copy()
+        m2[:idx_split] = False
+        fit2 = fit_iter(m2, 5)
+        oscan = fit1
+        oscan[idx_split:] = fit2[idx_split:]
+    oscan[0:IDX_SWITCH] = splfit(xcol[0:IDX_SWITCH])
+    oscan[0:3][mask_valid[0:3]] = mean_hos[0:3][mask_valid[0:3]]
+    mask_usemean = mask_valid.copy()
+    if mask_sat_row is not None:
+        mask_usemean &= ~mask_sat_row
+    mask_usemean[IDX_SWITCH:] = False
+    oscan[mask_usemean] = mean_hos[mask_usemean]
+    return oscan

@@ -1,0 +1,372 @@
+"""Per-image reduction on one MI355X: Python mirror of the reference's stage
+functions (same names, same argument meaning, same header keywords) on top of
+the HIP C ABI (include/bbx.h).  Order of operations = blackbox_reduce,
+blackbox.py:1451-1990.
+
+Arrays live in HBM as torch tensors (torch is used for device memory and streams
+only); every stage calls hand-written kernels through ctypes.  There is no CPU
+fallback: importing this module without libbbx_hip.so raises.
+
+Fusion map (reference statement -> kernel):
+  gain_corr 7460 + os_corr 6553/6844-6847 + `data -= mbias` 1679 + mask_init
+  4408-4414/4494-4498/4538 + `data /= mflat` 1825      -> bbx_calibrate (one pass)
+  os_corr strip statistics 6480-6490, 6572-6573, 6636-6640 -> bbx_overscan_stats,
+                                                              bbx_vos_std, bbx_satcol_counts
+  mask_init 4504-4562 + fill_sat_holes 4584-4596       -> bbx_mask_finish
+  cosmics_corr 4259-4370 (astroscrappy)                 -> bbx_lacosmic
+  xtalk_corr 7138-7258                                  -> bbx_xtalk
+  mask_header 4601-4620, edge fill 1968-1974            -> bbx_mask_counts, bbx_edge_fill
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, overscan, settings
+from ._lib import lib, check, Geom, BBX_RAW_U16, BBX_RAW_F32
+
+get_par = settings.get_par
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Context:
+    """one per worker process / GPU (bbx_ctx)"""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError('blackbox_amd needs a GPU (MI355X); no CPU fallback')
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        check(lib.bbx_ctx_create(device, C.byref(h)), 'bbx_ctx_create')
+        self.h = h
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self):
+        check(lib.bbx_sync(self.h, self.stream()), 'bbx_sync', self.h)
+
+    def close(self):
+        if self.h:
+            lib.bbx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def raw_type_of(raw):
+    if raw.dtype == torch.uint16:
+        return BBX_RAW_U16
+    if raw.dtype == torch.int16:
+        raise TypeError('raw int16: apply BZERO and pass uint16')
+    if raw.dtype == torch.float32:
+        return BBX_RAW_F32
+    raise TypeError('raw frame must be uint16 or float32, got {}'.format(raw.dtype))
+
+
+def geometry(raw_shape, ysize_chan=None, xsize_chan=None):
+    ysize_chan = ysize_chan or settings.ysize_chan
+    xsize_chan = xsize_chan or settings.xsize_chan
+    return Geom(int(raw_shape[0]), int(raw_shape[1]), int(ysize_chan), int(xsize_chan))
+
+
+def define_sections(data_shape, xbin=1, ybin=1, tel=None, ysize_chan=None, xsize_chan=None):
+    """blackbox.py:6334-6402 (host index helper; the kernels carry the same maths)"""
+    ysize, xsize = data_shape
+    ny, nx = settings.ny, settings.nx
+    dy, dx = ysize // ny, xsize // nx
+    ysc = (ysize_chan or settings.ysize_chan) // ybin
+    xsc = (xsize_chan or settings.xsize_chan) // xbin
+    ysize_os = (ysize - ny * ysc) // ny
+    xsize_os = (xsize - nx * xsc) // nx
+    chan_sec = tuple((slice(y, y + dy), slice(x, x + dx))
+                     for y in range(0, ysize, dy) for x in range(0, xsize, dx))
+    data_sec = tuple((slice(y, y + ysc), slice(x, x + xsc))
+                     for y in range(0, ysize, dy + ysize_os) for x in range(0, xsize, dx))
+    ncut_vert = max(5 // xbin, 1)
+    os_sec_vert = tuple((slice(y, y + dy), slice(x + xsc + ncut_vert, x + dx - 1))
+                        for y in range(0, ysize, dy) for x in range(0, xsize, dx))
+    cut = ysize_os - max(10 // ybin, 1)
+    os_sec_hori = tuple((slice(y, y + cut), slice(x, x + dx))
+                        for y in range(dy - cut, dy + cut, cut) for x in range(0, xsize, dx))
+    data_sec_red = tuple((slice(y, y + ysc), slice(x, x + xsc))
+                         for y in range(0, ysize - ny * ysize_os, ysc)
+                         for x in range(0, xsize - nx * xsize_os, xsc))
+    return chan_sec, data_sec, os_sec_hori, os_sec_vert, data_sec_red
+
+
+class OverscanSolution:
+    """what os_corr determines before any pixel is rewritten"""
+    __slots__ = ('vfit', 'oscan', 'd_vfit', 'd_oscan', 'header', 'aux')
+
+
+def gain_corr(header, tel):
+    """blackbox.py:7442-7465 (header part; the multiplication itself is fused into
+    every kernel that reads the raw frame: float32 raw * float32(gain))"""
+    gain = get_par(settings.gain, tel)
+    for c in range(16):
+        header['GAIN{}'.format(c + 1)] = (gain[c], '[e-/ADU] gain applied to channel {}'.format(c + 1))
+    return gain
+
+
+def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
+    """os_corr (blackbox.py:6407-6879) up to the point where the overscan vectors
+    are known: strip statistics on the GPU, fits on the host.  Updates [header]
+    (BIAS{c}A{k}, VFITOK{c}, BIASM{c}, RDN{c}, BIASMEAN, RDNOISE, N-INFNAN)."""
+    dev = ctx.device
+    gain = get_par(settings.gain, tel)
+    g32 = _lib.f32x16(gain)
+    rt = raw_type_of(raw)
+    ny_raw, nx_raw = raw.shape
+    ysz, xsz = geom.ysize_chan, geom.xsize_chan
+    dy, dx = ny_raw // 2, nx_raw // 8
+    os_y = dy - ysz
+    hos_rows = os_y - 10
+    d_mean = torch.empty(16 * dy, dtype=torch.float64, device=dev)
+    d_hos = torch.empty((16, hos_rows, dx), dtype=torch.float32, device=dev)
+    d_ninf = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(lib.bbx_overscan_stats(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_mean), _ptr(d_hos),
+                                 _ptr(d_ninf), ctx.stream()), 'bbx_overscan_stats', ctx.h)
+    # one device->host hop: 16*dy float64 + the hos strips (< 2 MB)
+    mean_vos_col = d_mean.cpu().numpy().reshape(16, dy)
+    hos = d_hos.cpu().numpy()
+    header['N-INFNAN'] = (int(d_ninf.item()), 'number of pixels with infinite/nan values')
+    vfit = np.empty((16, dy))
+    mean_vos = np.zeros(16)
+    for c in range(16):
+        fit, coeffs, ok, level = overscan.vos_polyfit(mean_vos_col[c], ysz, c, settings.voscan_poldeg)
+        for k, v in enumerate(coeffs):
+            header['BIAS{}A{}'.format(c + 1, k)] = (
+                float(v) if np.isfinite(v) else 'None',
+                '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
+        header['VFITOK{}'.format(c + 1)] = (bool(ok), 'channel {} vert. overscan polyfit finite?'.format(c + 1))
+        vfit[c] = fit
+        mean_vos[c] = level
+    d_vfit = torch.from_numpy(vfit.reshape(-1)).to(dev)
+    # read noise per channel on the GPU (float64 accumulators)
+    d_std = torch.empty(16, dtype=torch.float64, device=dev)
+    check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit), _ptr(d_std), ctx.stream()),
+          'bbx_vos_std', ctx.h)
+    mask_sat_rows = None
+    if tel != 'ML1':
+        lim = settings.os_ypix_lim[tel]
+        satl = np.array(get_par(settings.satlevel, tel)) * np.array(gain)
+        thr = _lib.f32x16(np.float32(0.9 * satl))
+        d_cnt = torch.empty((2, 16, xsz), dtype=torch.int32, device=dev)
+        check(lib.bbx_satcol_counts(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit), thr,
+                                    int(lim[0]), int(lim[1]), _ptr(d_cnt), ctx.stream()),
+              'bbx_satcol_counts', ctx.h)
+        cnt = d_cnt.cpu().numpy()
+        mask_sat_rows = (cnt[0] >= 3) | (cnt[1] >= 10)
+    oscan = np.empty((16, xsz))
+    aux = dict(dlevel=[], mean_hos=[], n_hos=[])
+    for c in range(16):
+        # horizontal overscan rows after the vertical fit: float32 - float64 -> float32
+        rl0 = (dy - hos_rows) if c < 8 else 0
+        strip = (hos[c].astype(np.float64) - vfit[c][rl0:rl0 + hos_rows, None]).astype(np.float32)
+        dlevel, _, _ = overscan.clipped_stats_flat(strip[:, xsz - 300:xsz], accum=accum)
+        strip -= np.float32(dlevel)
+        data_hos = strip[:, :xsz]
+        if tel == 'ML1':
+            mask_hos = overscan.hos_mask_ml1(data_hos, data_limit)
+            msr = None
+        else:
+            msr = mask_sat_rows[c]
+            mask_hos = np.zeros(data_hos.shape, dtype=bool) | msr[None, :]
+        n, mean_hos, std_hos = overscan.hos_column_stats(data_hos, mask_hos, accum=accum)
+        oscan[c] = overscan.hos_fit(n, mean_hos, std_hos, msr, bg2_chan9=(tel == 'BG2' and c == 8),
+                                    accum=accum)
+        aux['dlevel'].append(float(dlevel))
+        aux['mean_hos'].append(mean_hos)
+        aux['n_hos'].append(n)
+    std_vos = d_std.cpu().numpy()
+    for c in range(16):
+        header['BIASM{}'.format(c + 1)] = (float(mean_vos[c]), '[e-] channel {} mean vertical overscan'.format(c + 1))
+    for c in range(16):
+        header['RDN{}'.format(c + 1)] = (float(std_vos[c]), '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1))
+    header['BIASMEAN'] = (float(np.nanmean(mean_vos)), '[e-] average all channel means vert. overscan')
+    header['RDNOISE'] = (float(np.nanmean(std_vos)), '[e-] average all channel sigmas vert. overscan')
+    sol = OverscanSolution()
+    sol.vfit, sol.oscan = vfit, oscan
+    sol.d_vfit = d_vfit
+    sol.d_oscan = torch.from_numpy(oscan.reshape(-1)).to(dev)
+    sol.aux = aux
+    return sol
+
+
+def satlevels(header, tel):
+    """mask_init 4448-4463: channel saturation thresholds in e-"""
+    gain = np.array(get_par(settings.gain, tel))
+    bias = np.array([header['BIASM{}'.format(c + 1)][0] if isinstance(header['BIASM{}'.format(c + 1)], tuple)
+                     else header['BIASM{}'.format(c + 1)] for c in range(16)])
+    return np.array(get_par(settings.satlevel, tel)) * gain - bias
+
+
+def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=None, bpm=None):
+    """gain + overscan + crop (+ master bias) + first half of mask_init (+ master
+    flat) in one pass -> (data float32, mask uint8) device tensors"""
+    dev = ctx.device
+    ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
+    gain = get_par(settings.gain, tel)
+    sat = satlevels(header, tel)
+    header_mask['SATURATE'] = header['SATURATE'] = (float(np.mean(sat)), '[e-] mean saturation threshold')
+    for c in range(16):
+        key = 'SATLEV{}'.format(c + 1)
+        header[key] = header_mask[key] = (round(float(sat[c]), 1), '[e-] channel {} saturation threshold'.format(c + 1))
+    data = torch.empty((ny, nx), dtype=torch.float32, device=dev)
+    mask = torch.empty((ny, nx), dtype=torch.uint8, device=dev)
+    for t, name, dt in ((mbias, 'master bias', torch.float32), (mflat, 'master flat', torch.float32),
+                        (bpm, 'bad pixel mask', torch.uint8)):
+        if t is not None and (t.dtype != dt or tuple(t.shape) != (ny, nx) or not t.is_contiguous()):
+            raise ValueError('{}: expected contiguous {} of shape {}'.format(name, dt, (ny, nx)))
+    check(lib.bbx_calibrate(ctx.h, C.byref(geom), _ptr(raw), raw_type_of(raw), _lib.f32x16(gain),
+                            _ptr(sol.d_vfit), _ptr(sol.d_oscan), _ptr(mbias), _ptr(mflat), _ptr(bpm),
+                            _lib.f32x16(np.float32(sat)), _ptr(data), _ptr(mask), ctx.stream()),
+          'bbx_calibrate', ctx.h)
+    return data, mask
+
+
+def mask_init_finish(ctx, mask, header, header_mask, geom):
+    """second half of mask_init (blackbox.py:4504-4566) + fill_sat_holes"""
+    d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    check(lib.bbx_mask_finish(ctx.h, C.byref(geom), _ptr(mask), _ptr(d_n), ctx.stream()), 'bbx_mask_finish', ctx.h)
+    return d_n
+
+
+def cosmics_corr(ctx, data, header, data_mask, header_mask, tel):
+    """blackbox.py:4259-4370.  In place; returns the device stats tensor
+    [per-iteration counts x6, n objects, n pixels]."""
+    ny, nx = data.shape
+    hv = header['RDNOISE']
+    readnoise = hv[0] if isinstance(hv, tuple) else hv
+    d_stats = torch.zeros(8, dtype=torch.int32, device=ctx.device)
+    check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(data_mask),
+                           float(get_par(settings.sigclip, tel)), float(get_par(settings.sigfrac, tel)),
+                           float(get_par(settings.objlim, tel)), int(get_par(settings.niter, tel)),
+                           float(np.float32(readnoise)), _ptr(d_stats), ctx.stream()), 'bbx_lacosmic', ctx.h)
+    return d_stats
+
+
+def detect_cosmics(ctx, data, mask, sigclip, sigfrac, objlim, niter, readnoise):
+    """astroscrappy-style call on device tensors (in place) -> stats tensor"""
+    ny, nx = data.shape
+    d_stats = torch.zeros(8, dtype=torch.int32, device=ctx.device)
+    check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(mask), float(sigclip), float(sigfrac), float(objlim),
+                           int(niter), float(np.float32(readnoise)), _ptr(d_stats), ctx.stream()),
+          'bbx_lacosmic', ctx.h)
+    return d_stats
+
+
+def read_crosstalk(path):
+    """ASCII table 'victim source correction', 1-based channels -> coeffs[source, victim]
+    (blackbox.py:7157-7198)"""
+    coeffs = np.zeros((16, 16))
+    with open(path) as f:
+        first = f.readline().split()
+        if first[:3] != ['victim', 'source', 'correction']:
+            v, s, c = first[:3]
+            coeffs[int(s) - 1, int(v) - 1] = float(c)
+        for line in f:
+            p = line.split()
+            if len(p) >= 3:
+                coeffs[int(p[1]) - 1, int(p[0]) - 1] = float(p[2])
+    return coeffs
+
+
+def xtalk_corr(ctx, data, coeffs, data_mask, geom):
+    """blackbox.py:7138-7258, in place on the device"""
+    cf = (C.c_double * 256)(*[float(v) for v in np.asarray(coeffs, dtype=np.float64).reshape(-1)])
+    check(lib.bbx_xtalk(ctx.h, C.byref(geom), _ptr(data), _ptr(data_mask), cf, ctx.stream()), 'bbx_xtalk', ctx.h)
+
+
+def mask_header(ctx, data_mask, header_mask):
+    """blackbox.py:4601-4620"""
+    d_c = torch.zeros(6, dtype=torch.int64, device=ctx.device)
+    check(lib.bbx_mask_counts(ctx.h, data_mask.numel(), _ptr(data_mask), _ptr(d_c), ctx.stream()),
+          'bbx_mask_counts', ctx.h)
+    counts = d_c.cpu().numpy()
+    text = (('bad', 'BP'), ('edge', 'EP'), ('saturated', 'SP'), ('saturated-connected', 'SCP'),
+            ('satellite trail', 'STP'), ('cosmic ray', 'CRP'))
+    for (mask_type, t), n in zip(text, counts):
+        value = settings.mask_value[mask_type]
+        header_mask['M-{}'.format(t)] = (True, '{} pixels included in mask?'.format(mask_type))
+        header_mask['M-{}VAL'.format(t)] = (value, 'value added to mask for {} pixels'.format(mask_type))
+        header_mask['M-{}NUM'.format(t)] = (int(n), 'number of {} pixels'.format(mask_type))
+
+
+def edge_fill(ctx, data, data_mask, geom):
+    """blackbox.py:1959-1974"""
+    d_med = torch.empty(16, dtype=torch.float32, device=ctx.device)
+    check(lib.bbx_edge_fill(ctx.h, C.byref(geom), _ptr(data), _ptr(data_mask), _ptr(d_med), ctx.stream()),
+          'bbx_edge_fill', ctx.h)
+    return d_med
+
+
+def count_objects(ctx, data_mask, bit):
+    ny, nx = data_mask.shape
+    d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    check(lib.bbx_count_objects(ctx.h, ny, nx, _ptr(data_mask), int(bit), _ptr(d_n), ctx.stream()),
+          'bbx_count_objects', ctx.h)
+    return d_n
+
+
+def hval(header, key):
+    v = header[key]
+    return v[0] if isinstance(v, tuple) else v
+
+
+def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None,
+                  exptime=None, ysize_chan=None, xsize_chan=None, do_cosmics=True, crmask_override=None,
+                  accum='f32seq', stages=None):
+    """The hot path of blackbox_reduce for an 'object' frame (blackbox.py:1451-1974):
+    raw device tensor -> (data, mask, header, header_mask).  Failures of a stage
+    follow the reference convention: flag <STEP>-P False and carry on."""
+    header_mask = {}
+    geom = geometry(raw.shape, ysize_chan, xsize_chan)
+    gain_corr(header, tel)
+    header['GAIN'] = (1.0, '[e-/ADU] effective gain all channels')
+    header['GAIN-P'] = (True, 'corrected for gain?')
+    sol = os_solve(ctx, raw, header, tel, geom, accum=accum)
+    header['OS-P'] = (True, 'corrected for overscan?')
+    use_bias = mbias is not None and get_par(settings.subtract_mbias, tel)
+    data, mask = calibrate(ctx, raw, sol, header, header_mask, tel, geom,
+                           mbias=mbias if use_bias else None, mflat=mflat, bpm=bpm)
+    header['MBIAS-P'] = (bool(use_bias), 'corrected for master bias?')
+    header['MFLAT-P'] = (mflat is not None, 'corrected for master flat?')
+    d_nobj = mask_init_finish(ctx, mask, header, header_mask, geom)
+    header['MASK-P'] = (True, 'mask image created?')
+    d_stats = None
+    if crmask_override is not None:
+        # test hook: take the cosmic-ray pixels as given instead of detecting them
+        mask |= (crmask_override.to(mask.device).to(torch.uint8) * 2)
+    elif do_cosmics:
+        try:
+            d_stats = cosmics_corr(ctx, data, header, mask, header_mask, tel)
+            header['COSMIC-P'] = (True, 'corrected for cosmic rays?')
+        except _lib.BBXError:
+            header['NCOSMICS'] = ('None', '[/s] number of cosmic rays identified')
+            header['COSMIC-P'] = (False, 'corrected for cosmic rays?')
+    if xtalk_coeffs is not None:
+        xtalk_corr(ctx, data, xtalk_coeffs, mask, geom)
+        header['XTALK-P'] = (True, 'corrected for crosstalk?')
+    if stages is not None:
+        stages['data_xtalk'] = data.clone()
+    mask_header(ctx, mask, header_mask)
+    edge_fill(ctx, data, mask, geom)
+    ctx.sync()
+    nobj = int(d_nobj.item())
+    header_mask['NOBJ-SAT'] = header['NOBJ-SAT'] = (nobj, 'number of saturated objects')
+    if d_stats is not None:
+        st = d_stats.cpu().numpy()
+        t = float(exptime) if exptime else 1.0
+        header['NCOSMICS'] = header_mask['NCOSMICS'] = (st[6] / t, '[/s] number of cosmic rays identified')
+        header['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
+    return data, mask, header, header_mask

@@ -1,0 +1,212 @@
+"""Seeded synthetic MeerLICHT/BlackGEM CCD frames (numpy only, host side).
+
+Used by the golden-vector generator (oracle/gen_golden.py, runs under the
+container's python3.9 / numpy 1.26), by the tests and by bench.py (python3.10 /
+numpy 2.2).  To make the very same pixels come out under both interpreters the
+generator restricts itself to operations that are bit-reproducible everywhere:
+
+* random numbers only from ``numpy.random.RandomState.random_sample`` (the
+  legacy MT19937 stream is frozen by numpy policy),
+* IEEE-exact arithmetic only: + - * / sqrt floor.  No exp/log/pow/sin/cos.
+  Gaussian-like noise is an Irwin-Hall sum of 4 uniforms, stars are Moffat
+  beta=2 profiles 1/(1+r^2/a^2)^2, the bias "exponential" rise in the
+  horizontal overscan is a rational function.
+
+The geometry follows the reference's define_sections (blackbox.py:6334-6402):
+ny x nx = 2 x 8 channels, each channel = data section (ysize_chan x xsize_chan)
+plus a vertical overscan strip to its right and horizontal overscan rows
+between the two channel rows.
+"""
+import numpy as np
+
+NY, NX = 2, 8          # set_blackbox.py:335
+SQRT3 = 3.0 ** 0.5
+
+from .settings import gain as GAIN      # set_blackbox.py:241-281
+
+
+def _gauss(rs, shape):
+    """unit-variance, zero-mean Irwin-Hall(4) deviates, exact arithmetic"""
+    u = rs.random_sample((4,) + tuple(shape))
+    return (u[0] + u[1] + u[2] + u[3] - 2.0) * SQRT3
+
+
+def raw_shape(ysize_chan, xsize_chan, os_y=20, os_x=180):
+    return (NY * (ysize_chan + os_y), NX * (xsize_chan + os_x))
+
+
+def make_scene(ysize_chan, xsize_chan, seed, n_stars=40, n_sat=2, n_cr=30,
+               sky=250.0, trail=False):
+    """Noise-free scene in electrons on the reduced (NY*ysize, NX*xsize) grid,
+    plus the cosmic-ray layer (kept apart so tests know the truth)."""
+    rs = np.random.RandomState(seed)
+    ny, nx = NY * ysize_chan, NX * xsize_chan
+    scene = np.zeros((ny, nx)) + sky
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    # slow sky gradient (exact: linear)
+    scene += 0.05 * sky * (xx / float(nx) - 0.5) + 0.03 * sky * (yy / float(ny) - 0.5)
+
+    def add_star(x0, y0, flux, fwhm):
+        a = fwhm / (2.0 * (2.0 ** 0.5 - 1.0) ** 0.5)      # Moffat beta=2
+        r = int(4 * fwhm) + 2
+        xl, xh = max(0, int(x0) - r), min(nx, int(x0) + r + 1)
+        yl, yh = max(0, int(y0) - r), min(ny, int(y0) + r + 1)
+        dx = xx[yl:yh, xl:xh] - x0
+        dy = yy[yl:yh, xl:xh] - y0
+        q = 1.0 + (dx * dx + dy * dy) / (a * a)
+        scene[yl:yh, xl:xh] += flux / (3.141592653589793 * a * a) / (q * q)
+
+    u = rs.random_sample((n_stars, 4))
+    for k in range(n_stars):
+        # power-law-ish fluxes 1e3..1e6 e- via exact ops: 1e3 * (1 + 999 u^4)
+        flux = 1.0e3 * (1.0 + 999.0 * u[k, 2] * u[k, 2] * u[k, 2] * u[k, 2])
+        add_star(u[k, 0] * nx, u[k, 1] * ny, flux, 3.0 + 2.0 * u[k, 3])
+    u = rs.random_sample((max(n_sat, 1), 3))
+    for k in range(n_sat):
+        add_star(20 + u[k, 0] * (nx - 40), 8 + u[k, 1] * (ny - 16),
+                 2.0e7 * (1.0 + u[k, 2]), 4.0)
+    if trail:
+        # one straight trail, width ~6 px (Moffat-like cross section), 150 e-/px
+        x0, x1 = 0.0, float(nx)
+        y0, y1 = 0.2 * ny, 0.7 * ny
+        norm = ((x1 - x0) ** 2 + (y1 - y0) ** 2) ** 0.5
+        d = ((xx - x0) * (y1 - y0) - (yy - y0) * (x1 - x0)) / norm
+        q = 1.0 + d * d / 9.0
+        scene += 150.0 / (q * q)
+
+    cr = np.zeros((ny, nx))
+    u = rs.random_sample((max(n_cr, 1), 6))
+    for k in range(n_cr):
+        x0 = int(3 + u[k, 0] * (nx - 6))
+        y0 = int(3 + u[k, 1] * (ny - 6))
+        length = 1 + int(u[k, 2] * 12)
+        amp = 300.0 + 2.0e4 * u[k, 3] * u[k, 3]
+        # direction on a coarse grid: steps in {-1,0,1}
+        sx = int(u[k, 4] * 3) - 1
+        sy = int(u[k, 5] * 3) - 1
+        if sx == 0 and sy == 0:
+            sx = 1
+        for j in range(length):
+            x, y = x0 + j * sx, y0 + j * sy
+            if 0 <= x < nx and 0 <= y < ny:
+                cr[y, x] += amp
+    return scene, cr
+
+
+def make_flat(ysize_chan, xsize_chan, seed):
+    rs = np.random.RandomState(seed + 7001)
+    ny, nx = NY * ysize_chan, NX * xsize_chan
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    r2 = ((xx - 0.5 * nx) / (0.5 * nx)) ** 2 + ((yy - 0.5 * ny) / (0.5 * ny)) ** 2
+    flat = 1.0 - 0.05 * r2 + 0.005 * _gauss(rs, (ny, nx))
+    return flat.astype(np.float32)
+
+
+def make_bias(ysize_chan, xsize_chan, seed):
+    rs = np.random.RandomState(seed + 7002)
+    ny, nx = NY * ysize_chan, NX * xsize_chan
+    return _gauss(rs, (ny, nx)).astype(np.float32)
+
+
+def make_bpm(ysize_chan, xsize_chan, seed, edge=6, frac_bad=2e-4):
+    """uint8 bad-pixel mask: bad=1, edge=32 (set_zogy.mask_value)"""
+    rs = np.random.RandomState(seed + 7003)
+    ny, nx = NY * ysize_chan, NX * xsize_chan
+    bpm = np.zeros((ny, nx), dtype=np.uint8)
+    bpm[rs.random_sample((ny, nx)) < frac_bad] = 1
+    if edge > 0:
+        bpm[:edge, :] = 32
+        bpm[-edge:, :] = 32
+        bpm[:, :edge] = 32
+        bpm[:, -edge:] = 32
+    return bpm
+
+
+def make_xtalk(seed, scale=2e-4):
+    """(victim, source, correction) rows, 1-based channels, 240 coefficients
+    (format of blackbox.py:7157-7161)"""
+    rs = np.random.RandomState(seed + 7004)
+    u = rs.random_sample((16, 16))
+    rows = []
+    for v in range(16):
+        for s in range(16):
+            if v != s:
+                rows.append((v + 1, s + 1, scale * u[v, s]))
+    return rows
+
+
+def write_xtalk(path, rows):
+    with open(path, 'w') as f:
+        f.write('victim source correction\n')
+        for v, s, c in rows:
+            f.write('{} {} {!r}\n'.format(v, s, float(c)))
+
+
+def make_raw(ysize_chan, xsize_chan, seed, tel='ML1', os_y=20, os_x=180,
+             flat=None, bias=None, scene=None, cr=None, bias_adu=3000.0,
+             rdnoise_adu=4.0, hos_bleed=False):
+    """Raw uint16 frame with overscans.  Inverse of the calibration: a scene in
+    e- goes through x flat, + master bias, / gain, + per-channel bias level with
+    a cubic row trend and the horizontal-overscan column structure, + read
+    noise, rounded to ADU and clipped to uint16."""
+    rs = np.random.RandomState(seed + 7005)
+    gain = GAIN[tel]
+    dy, dx = ysize_chan + os_y, xsize_chan + os_x
+    raw = np.zeros((NY * dy, NX * dx))
+    if scene is None:
+        scene, cr = make_scene(ysize_chan, xsize_chan, seed)
+    img = scene + (cr if cr is not None else 0.0)
+    # shot noise (Gaussian approximation, exact ops)
+    img = img + np.sqrt(np.maximum(img, 0.0)) * _gauss(rs, img.shape)
+    if flat is not None:
+        img = img * flat.astype(np.float64)
+    if bias is not None:
+        img = img + bias.astype(np.float64)
+    ub = rs.random_sample((16, 4))
+    yrow = np.arange(dy, dtype=np.float64)
+    xcol = np.arange(dx, dtype=np.float64)
+    for c in range(16):
+        iy, ix = c // NX, c % NX
+        y0, x0 = iy * dy, ix * dx
+        level = bias_adu + 150.0 * (ub[c, 0] - 0.5)
+        t = yrow / dy - 0.5
+        trend = 2.0 * ub[c, 1] * t + 3.0 * (ub[c, 2] - 0.5) * t * t * t
+        q = 1.0 + xcol / 20.0
+        colstruct = 20.0 * (0.5 + ub[c, 3]) / (q * q)
+        chan = np.zeros((dy, dx)) + level + trend[:, None]
+        chan = chan + rdnoise_adu * (1.0 + 0.3 * (ub[c, 3] - 0.5)) * _gauss(rs, (dy, dx))
+        # data section rows inside the channel: lower row [0, ysize), upper row
+        # [os_y, dy)  (define_sections: data_sec y origin = dy + ysize_os)
+        ys = 0 if iy == 0 else os_y
+        sec = img[iy * ysize_chan:(iy + 1) * ysize_chan,
+                  ix * xsize_chan:(ix + 1) * xsize_chan]
+        chan[ys:ys + ysize_chan, :xsize_chan] += sec / gain[c]
+        # column structure of the bias shows up in the data columns and in the
+        # horizontal overscan rows alike (that is what os_corr fits)
+        chan[:, :xsize_chan] += colstruct[None, :xsize_chan]
+        if hos_bleed:
+            # charge bleeding into the horizontal overscan rows: a 3-column
+            # block (masked + dilated by os_corr, blackbox.py:6590-6614) and one
+            # isolated column (restored by the binary_opening trick)
+            yo = ysize_chan if iy == 0 else 0
+            cb = 40 + int(ub[c, 0] * (xsize_chan - 80))
+            chan[yo:yo + os_y, cb:cb + 3] += 3000.0
+            ci = 40 + int(ub[c, 1] * (xsize_chan - 80))
+            chan[yo:yo + os_y, ci] += 2500.0
+        raw[y0:y0 + dy, x0:x0 + dx] = chan
+    raw = np.floor(raw + 0.5)
+    raw = np.minimum(np.maximum(raw, 0.0), 65535.0)
+    return raw.astype(np.uint16)
+
+
+def make_case(ysize_chan, xsize_chan, seed, tel='ML1', os_y=20, os_x=45,
+              with_bias=False, hos_bleed=False, **scene_kw):
+    """Everything one reduction needs, keyed like the golden fixtures."""
+    scene, cr = make_scene(ysize_chan, xsize_chan, seed, **scene_kw)
+    flat = make_flat(ysize_chan, xsize_chan, seed)
+    bias = make_bias(ysize_chan, xsize_chan, seed) if with_bias else None
+    raw = make_raw(ysize_chan, xsize_chan, seed, tel=tel, os_y=os_y, os_x=os_x,
+                   flat=flat, bias=bias, scene=scene, cr=cr, hos_bleed=hos_bleed)
+    return dict(raw=raw, flat=flat, bias=bias,
+                bpm=make_bpm(ysize_chan, xsize_chan, seed),
+                xtalk=make_xtalk(seed), scene=scene, cr=cr)

@@ -1,0 +1,167 @@
+/* bbx.h -- C ABI of libbbx_hip.so: the MI355X (gfx950) implementation of the
+ * per-image reduction hot path of BlackBOX.
+ *
+ * The reference (pmvreeswijk/BlackBOX v1.5.1) has no FFI: its boundary is the
+ * Python call boundary of the stage functions in blackbox.py.  Each entry point
+ * below names the reference function (file:line) whose bulk array work it
+ * replaces; the Python mirrors of those functions (blackbox_amd/reduce.py) keep
+ * the reference's names and argument meaning and call these through ctypes.
+ * INTEGRATION.md shows the binding a BlackBOX maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch / numpy types.  `d_` = device pointer
+ *    (hipMalloc'ed by the caller, e.g. a torch tensor's data_ptr()), `h_` = host
+ *    pointer.  The caller owns every buffer.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL
+ *    = default stream) unless its comment says "synchronises".
+ *  - return value: 0 = BBX_OK, negative = error (bbx_strerror).  HIP errors are
+ *    reported, never swallowed; there is no CPU fallback.
+ *  - images are C-order, row 0 first (numpy layout of the FITS data array).
+ *  - one bbx_ctx per worker process / GPU; a ctx is not thread-safe.
+ *
+ * Geometry (reference define_sections, blackbox.py:6334-6402): the raw frame is
+ * NY x NX = 2 x 8 channels of (dy x dx) pixels; each channel holds a data
+ * section (ysize_chan x xsize_chan) at its left, a vertical overscan strip at
+ * its right, and horizontal overscan rows between the two channel rows.  The
+ * reduced frame is (2*ysize_chan) x (8*xsize_chan).
+ */
+#ifndef BBX_H
+#define BBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBX_OK            0
+#define BBX_ERR_ARG      -1   /* bad argument / geometry */
+#define BBX_ERR_HIP      -2   /* a HIP runtime call failed (see bbx_last_hip_error) */
+#define BBX_ERR_NOMEM    -3
+#define BBX_ERR_OVERFLOW -4   /* a device work list overflowed its capacity */
+#define BBX_ERR_NOTCONV  -5   /* an iterative device loop hit its bound */
+
+#define BBX_NCHAN 16
+
+/* mask bits: set_zogy.mask_value */
+#define BBX_MASK_BAD        1
+#define BBX_MASK_COSMIC     2
+#define BBX_MASK_SAT        4
+#define BBX_MASK_SATCON     8
+#define BBX_MASK_SATELLITE 16
+#define BBX_MASK_EDGE      32
+#define BBX_MASK_XTALK     64
+
+#define BBX_RAW_U16 0         /* raw pixels uint16 (BZERO-scaled FITS BITPIX 16) */
+#define BBX_RAW_F32 1         /* raw pixels float32 */
+
+typedef struct bbx_ctx bbx_ctx;
+
+typedef struct {
+    int32_t ny_raw, nx_raw;          /* raw frame shape, e.g. 10600 x 12000 */
+    int32_t ysize_chan, xsize_chan;  /* channel data section, e.g. 5280 x 1320 */
+} bbx_geom;
+
+/* ---- context ------------------------------------------------------------------ */
+int  bbx_ctx_create(int device, bbx_ctx **out);          /* synchronises */
+void bbx_ctx_destroy(bbx_ctx *ctx);                      /* synchronises */
+const char *bbx_strerror(int code);
+const char *bbx_last_hip_error(const bbx_ctx *ctx);
+int  bbx_version(void);
+/* hipStreamSynchronize(stream) + check of the ctx's device-side error flags
+ * (list overflow, non-convergence).  Call before trusting host copies. */
+int  bbx_sync(bbx_ctx *ctx, void *stream);
+
+/* ---- a2 + a4 + a5(i): overscan statistics ---------------------------------------
+ * replaces: inf/nan scrub blackbox.py:1461-1468, gain_corr 7442-7465 (applied on
+ * the fly, raw is not modified), and the strip reductions of os_corr 6480-6490.
+ *  d_mean_vos_col [16*dy] f64 : per channel and row, 3-sigma/5-iteration clipped
+ *      mean of the gain-corrected vertical overscan (zeros excluded).
+ *  d_hos [16*hos_rows*dx] f32 : gain-corrected horizontal-overscan rows
+ *      (os_sec_hori) of each channel, BEFORE subtraction of the vertical fit.
+ *  d_n_infnan [1] i64 : number of non-finite raw pixels (always 0 for u16).   */
+int bbx_overscan_stats(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw,
+                       int raw_type, const float *h_gain /*[16]*/,
+                       double *d_mean_vos_col, float *d_hos, int64_t *d_n_infnan,
+                       void *stream);
+
+/* ---- a5(ii): read noise --------------------------------------------------------
+ * replaces os_corr 6572-6573: 3-sigma/5-iteration clipped std (zeros excluded) of
+ * each channel's vertical overscan after subtraction of the row fit.
+ *  d_vfit [16*dy] f64 : fitted vertical-overscan level per channel row.
+ *  d_std_vos [16] f64 (RDN{c});  float64 accumulators (tolerance) */
+int bbx_vos_std(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_type,
+                const float *h_gain, const double *d_vfit, double *d_std_vos,
+                void *stream);
+
+/* ---- a5(iii, BlackGEM): saturated columns near the overscan ----------------------
+ * replaces os_corr 6624-6640: per channel and data column, the number of pixels
+ * >= h_thr[c] in the [rows1] / [rows2] rows of the data section nearest to the
+ * horizontal overscan, after gain and vertical-fit subtraction.
+ *  d_counts [2*16*xsize_chan] i32                                               */
+int bbx_satcol_counts(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw,
+                      int raw_type, const float *h_gain, const double *d_vfit,
+                      const float *h_thr /*[16]*/, int rows1, int rows2,
+                      int32_t *d_counts, void *stream);
+
+/* ---- a4 + a5(iv) + a6 + a9(first half): fused calibration ------------------------
+ * replaces, in one pass over the frame: gain_corr 7460, the per-row and
+ * per-column overscan subtractions + crop of os_corr 6553/6844-6847, master-bias
+ * subtraction 1679, the non-finite scrub + saturation compare of mask_init
+ * 4408-4414/4494-4498/4538, and flat division 1825.
+ *  d_oscan [16*xsize_chan] f64 : horizontal-overscan vector per channel.
+ *  d_bias, d_flat : reduced-shape f32 masters or NULL.  d_bpm : u8 or NULL.
+ *  h_satlevel [16] : saturation thresholds in e- (SATLEV{c}, compared in f32).
+ *  d_data [N] f32, d_mask [N] u8 : outputs.  Saturated pixels get bit 4 and are
+ *  queued in the ctx for bbx_mask_finish.                                       */
+int bbx_calibrate(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_type,
+                  const float *h_gain, const double *d_vfit, const double *d_oscan,
+                  const float *d_bias, const float *d_flat, const uint8_t *d_bpm,
+                  const float *h_satlevel, float *d_data, uint8_t *d_mask,
+                  void *stream);
+
+/* ---- a9 (second half): mask_init tail + fill_sat_holes ---------------------------
+ * replaces mask_init 4504-4562 (crosstalk flags of saturated pixels in the 15
+ * other channels, NOBJ-SAT label count, 3x3 dilation -> saturated-connected) and
+ * fill_sat_holes 4584-4596 (3x3 closing + hole filling, new pixels where the
+ * mask was 0).  Uses the saturated-pixel queue left by bbx_calibrate.
+ *  d_nobj_sat [1] i32                                                           */
+int bbx_mask_finish(bbx_ctx *ctx, const bbx_geom *g, uint8_t *d_mask,
+                    int32_t *d_nobj_sat, void *stream);
+
+/* ---- a10: LA-Cosmic ----------------------------------------------------------------
+ * replaces cosmics_corr 4259-4370 = astroscrappy.detect_cosmics(sepmed=False,
+ * cleantype='medmask', gain=1, satlevel=inf) + mask update + NCOSMICS label count.
+ * In place: d_data becomes the cleaned array, CR pixels get bit 2 in d_mask.
+ *  d_stats [8] i32 : [0..niter-1] pixels flagged per iteration, [6] number of
+ *  8-connected CR objects, [7] total CR pixels.                                  */
+int bbx_lacosmic(bbx_ctx *ctx, int ny, int nx, float *d_data, uint8_t *d_mask,
+                 float sigclip, float sigfrac, float objlim, int niter,
+                 float readnoise, int32_t *d_stats, void *stream);
+
+/* ---- a11: crosstalk -------------------------------------------------------------------
+ * replaces xtalk_corr 7138-7258.  h_coeffs[source*16 + victim], float64.          */
+int bbx_xtalk(bbx_ctx *ctx, const bbx_geom *g, float *d_data, const uint8_t *d_mask,
+              const double *h_coeffs /*[256]*/, void *stream);
+
+/* ---- a13: mask_header counts + edge fill ---------------------------------------------
+ * replaces mask_header 4601-4620 (d_counts[6] i64: bad, edge, saturated,
+ * saturated-connected, satellite trail, cosmic ray -- pixels with that bit set)
+ * and the edge fill 1959-1974 (edge pixels <- np.median of their channel;
+ * d_chan_median [16] f32 also returned).                                        */
+int bbx_mask_counts(bbx_ctx *ctx, int64_t npix, const uint8_t *d_mask,
+                    int64_t *d_counts, void *stream);
+int bbx_edge_fill(bbx_ctx *ctx, const bbx_geom *g, float *d_data,
+                  const uint8_t *d_mask, float *d_chan_median, void *stream);
+
+/* ---- generic: number of 8-connected objects of (mask & bit) --------------------------
+ * replaces ndimage.label(..., structure=ones(3,3)) counts (NOBJ-SAT 4545,
+ * NCOSMICS 4355, NSATS 4230).                                                     */
+int bbx_count_objects(bbx_ctx *ctx, int ny, int nx, const uint8_t *d_mask,
+                      int bit, int32_t *d_count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBX_H */
