@@ -45,7 +45,7 @@ SIGNATURES = {
     'bbx_version': (_i, []),
     'bbx_sync': (_i, [_vp, _vp]),
     'bbx_overscan_stats': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp]),
-    'bbx_vos_std': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp]),
+    'bbx_vos_std': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _pf, _vp, _vp]),
     'bbx_satcol_counts': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _pf, _i, _i, _vp, _vp]),
     'bbx_calibrate': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp]),
     'bbx_mask_finish': (_i, [_vp, _pg, _vp, _vp, _vp]),

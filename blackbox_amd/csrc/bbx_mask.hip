@@ -406,9 +406,9 @@ int bbx_count_objects(bbx_ctx* ctx, int ny, int nx, const uint8_t* d_mask, int b
     int rc;
     const size_t npix = (size_t)ny * nx;
     if (npix >= 0xffffffffull) return BBX_ERR_ARG;
-    // list capacity: 1/16 of the frame is far beyond any real mask plane; more is
+    // list capacity: 1/8 of the frame is far beyond any real mask plane; more is
     // reported as BBX_ERR_OVERFLOW by bbx_sync
-    const size_t cap = npix / 16 + 1024;
+    const size_t cap = npix / 8 + 1024;
     uint32_t* list = (uint32_t*)bbx_ws(ctx, WS_CCLIST, cap * sizeof(uint32_t), &rc); if (rc) return rc;
     BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_CC_N], 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_compact_bit, dim3(2048), dim3(256), 0, s, d_mask, npix, bit, list, &ctx->d_counters[CNT_CC_N],

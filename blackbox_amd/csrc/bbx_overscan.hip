@@ -116,7 +116,7 @@ struct vos_state {          // per channel
 
 template <int RAW_T>
 __global__ __launch_bounds__(256) void k_vos_std_pass(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
-                                                      const double* __restrict__ vfit,
+                                                      const double* __restrict__ vfit, f32x16 dlevel,
                                                       const vos_state* __restrict__ st,
                                                       double* __restrict__ partial /*[16][VSTD_BLOCKS][3]*/) {
     const int c = blockIdx.y, b = blockIdx.x;
@@ -131,6 +131,10 @@ __global__ __launch_bounds__(256) void k_vos_std_pass(const void* __restrict__ r
         if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;
         f = f * g;
         float x = (float)((double)f - vfit[c * d.dy + r]);       // float32 array -= float64 column
+        // rows shared with the horizontal overscan section also received `-= dlevel`
+        // (os_sec_hori spans the full channel width, blackbox.py:6568)
+        const bool in_hos = (iy == 0) ? (r >= d.dy - d.hos_rows) : (r < d.hos_rows);
+        if (in_hos) x = x - dlevel.v[c];
         double xd = (double)x;
         bool keep = isfinite(x) && !(fabs(xd) <= 1e-8) && xd >= lo && xd <= hi;
         if (keep) { s1 += xd; s2 += xd * xd; n++; }
@@ -247,11 +251,11 @@ int bbx_overscan_stats(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int r
 }
 
 int bbx_vos_std(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type, const float* h_gain,
-                const double* d_vfit, double* d_std_vos, void* stream) {
-    if (!ctx || !d_raw || !h_gain || !d_vfit || !d_std_vos) return BBX_ERR_ARG;
+                const double* d_vfit, const float* h_dlevel, double* d_std_vos, void* stream) {
+    if (!ctx || !d_raw || !h_gain || !d_vfit || !h_dlevel || !d_std_vos) return BBX_ERR_ARG;
     bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    f32x16 gain = load16(h_gain);
+    f32x16 gain = load16(h_gain), dlev = load16(h_dlevel);
     char* ws = (char*)bbx_ws(ctx, WS_STRIP, 16 * sizeof(vos_state) + 16 * VSTD_BLOCKS * 3 * sizeof(double), &rc);
     if (rc) return rc;
     vos_state* st = (vos_state*)ws;
@@ -260,10 +264,10 @@ int bbx_vos_std(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type
     for (int pass = 0; pass < 6; pass++) {
         if (raw_type == BBX_RAW_U16)
             hipLaunchKernelGGL(k_vos_std_pass<BBX_RAW_U16>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain,
-                               d_vfit, st, partial);
+                               d_vfit, dlev, st, partial);
         else if (raw_type == BBX_RAW_F32)
             hipLaunchKernelGGL(k_vos_std_pass<BBX_RAW_F32>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain,
-                               d_vfit, st, partial);
+                               d_vfit, dlev, st, partial);
         else return BBX_ERR_ARG;
         hipLaunchKernelGGL(k_vos_std_update, dim3(1), dim3(64), 0, s, st, partial, pass, d_std_vos);
     }

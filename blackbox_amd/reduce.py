@@ -151,10 +151,6 @@ def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
         vfit[c] = fit
         mean_vos[c] = level
     d_vfit = torch.from_numpy(vfit.reshape(-1)).to(dev)
-    # read noise per channel on the GPU (float64 accumulators)
-    d_std = torch.empty(16, dtype=torch.float64, device=dev)
-    check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit), _ptr(d_std), ctx.stream()),
-          'bbx_vos_std', ctx.h)
     mask_sat_rows = None
     if tel != 'ML1':
         lim = settings.os_ypix_lim[tel]
@@ -168,13 +164,22 @@ def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
         mask_sat_rows = (cnt[0] >= 3) | (cnt[1] >= 10)
     oscan = np.empty((16, xsz))
     aux = dict(dlevel=[], mean_hos=[], n_hos=[])
+    strips = []
     for c in range(16):
         # horizontal overscan rows after the vertical fit: float32 - float64 -> float32
         rl0 = (dy - hos_rows) if c < 8 else 0
         strip = (hos[c].astype(np.float64) - vfit[c][rl0:rl0 + hos_rows, None]).astype(np.float32)
         dlevel, _, _ = overscan.clipped_stats_flat(strip[:, xsz - 300:xsz], accum=accum)
         strip -= np.float32(dlevel)
-        data_hos = strip[:, :xsz]
+        strips.append(strip)
+        aux['dlevel'].append(float(dlevel))
+    # read noise per channel on the GPU (float64 accumulators); runs while the host fits
+    d_std = torch.empty(16, dtype=torch.float64, device=dev)
+    check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit),
+                          _lib.f32x16(np.float32(aux['dlevel'])), _ptr(d_std), ctx.stream()),
+          'bbx_vos_std', ctx.h)
+    for c in range(16):
+        data_hos = strips[c][:, :xsz]
         if tel == 'ML1':
             mask_hos = overscan.hos_mask_ml1(data_hos, data_limit)
             msr = None
@@ -184,7 +189,6 @@ def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
         n, mean_hos, std_hos = overscan.hos_column_stats(data_hos, mask_hos, accum=accum)
         oscan[c] = overscan.hos_fit(n, mean_hos, std_hos, msr, bg2_chan9=(tel == 'BG2' and c == 8),
                                     accum=accum)
-        aux['dlevel'].append(float(dlevel))
         aux['mean_hos'].append(mean_hos)
         aux['n_hos'].append(n)
     std_vos = d_std.cpu().numpy()

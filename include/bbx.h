@@ -90,10 +90,13 @@ int bbx_overscan_stats(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw,
  * replaces os_corr 6572-6573: 3-sigma/5-iteration clipped std (zeros excluded) of
  * each channel's vertical overscan after subtraction of the row fit.
  *  d_vfit [16*dy] f64 : fitted vertical-overscan level per channel row.
+ *  h_dlevel [16] f32  : level offset of the horizontal overscan (os_corr 6565-6568);
+ *      it was subtracted from the full-width overscan rows, i.e. also from the
+ *      corner that the vertical strip shares with them.
  *  d_std_vos [16] f64 (RDN{c});  float64 accumulators (tolerance) */
 int bbx_vos_std(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_type,
-                const float *h_gain, const double *d_vfit, double *d_std_vos,
-                void *stream);
+                const float *h_gain, const double *d_vfit, const float *h_dlevel,
+                double *d_std_vos, void *stream);
 
 /* ---- a5(iii, BlackGEM): saturated columns near the overscan ----------------------
  * replaces os_corr 6624-6640: per channel and data column, the number of pixels

@@ -78,10 +78,20 @@ def test_golden_reduction(ctx, name):
         assert hv(header, 'VFITOK%d' % (c + 1)) == ghdr['VFITOK%d' % (c + 1)]
         for k in range(4):
             assert hv(header, 'BIAS%dA%d' % (c + 1, k)) == pytest.approx(ghdr['BIAS%dA%d' % (c + 1, k)], rel=1e-6, abs=1e-12)
-        # read noise: float64 accumulators here, float32 running sums in the reference
-        # environment (bottleneck) => relative tolerance 2e-5
-        assert hv(header, 'RDN%d' % (c + 1)) == pytest.approx(ghdr['RDN%d' % (c + 1)], rel=2e-5)
-    assert hv(header, 'RDNOISE') == pytest.approx(ghdr['RDNOISE'], rel=2e-5)
+        # read noise: float64 accumulators here; the reference environment (bottleneck)
+        # keeps a float32 running sum over ~1e5..1e6 values, itself only good to ~1e-5..1e-4
+        # => relative tolerance 1e-4 against the golden value ...
+        assert hv(header, 'RDN%d' % (c + 1)) == pytest.approx(ghdr['RDN%d' % (c + 1)], rel=1e-4)
+    assert hv(header, 'RDNOISE') == pytest.approx(ghdr['RDNOISE'], rel=1e-4)
+    # ... and 1e-6 against the oracle's float64 evaluation of the same statistic (the
+    # two differ only through the float32-vs-float64 dlevel applied to the corner rows)
+    o_raw = raw.copy()
+    o_raw[~np.isfinite(o_raw)] = 0
+    O.gain_corr(o_raw, settings.gain[tel], ys, xs)
+    _, oh, _ = O.os_corr(o_raw, ys, xs, tel=tel, gain=settings.gain[tel], satlevel=settings.satlevel[tel],
+                         accum='f64', ypix_lim=settings.os_ypix_lim)
+    for c in range(16):
+        assert hv(header, 'RDN%d' % (c + 1)) == pytest.approx(oh['RDN%d' % (c + 1)], rel=1e-6)
     assert hv(header, 'BIASMEAN') == pytest.approx(ghdr['BIASMEAN'], rel=1e-12)
 
     # --- full chain with the golden cosmic-ray pixels --------------------------------------
