@@ -1,0 +1,117 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference's
+own functions (oracle/gen_golden.py).  accum='bn32' must reproduce them bit for bit;
+accum='f64' (float64 accumulators) stays inside the stated float32 tolerance."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bbx_oracle as O
+from blackbox_amd import settings, synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    meta = json.loads(str(g['meta']))
+    case = synth.make_case(meta['ysize_chan'], meta['xsize_chan'], meta['seed'], tel=meta['tel'],
+                           os_y=meta['os_y'], os_x=meta['os_x'], with_bias=meta['with_bias'], **meta['kw'])
+    # the synthetic inputs must be the very ones the reference saw
+    assert hashlib.sha256(case['raw'].tobytes()).hexdigest() == meta['sha_raw']
+    assert hashlib.sha256(case['flat'].tobytes()).hexdigest() == meta['sha_flat']
+    assert hashlib.sha256(case['bpm'].tobytes()).hexdigest() == meta['sha_bpm']
+    return g, meta, case
+
+
+def run_oracle(meta, case, accum):
+    tel, ys, xs = meta['tel'], meta['ysize_chan'], meta['xsize_chan']
+    gain, sat = settings.gain[tel], settings.satlevel[tel]
+    data = case['raw'].astype(np.float32)
+    for (y, x), v in zip(meta['nan_at'], (np.nan, np.inf)):
+        data[y, x] = v
+    bad = ~np.isfinite(data)
+    n_infnan = int(bad.sum())
+    data[bad] = 0
+    O.gain_corr(data, gain, ys, xs)
+    data, header, aux = O.os_corr(data, ys, xs, tel=tel, gain=gain, satlevel=sat, accum=accum,
+                                  ypix_lim=settings.os_ypix_lim)
+    header['N-INFNAN'] = n_infnan
+    data_os = data.copy()
+    if meta['with_bias']:
+        data -= case['bias']
+    mask, hm = O.mask_init(data, header, case['bpm'], gain, sat, ys, xs)
+    mask_init = mask.copy()
+    data /= case['flat']
+    crmask = (case['cr'] > 0) & (mask == 0)
+    mask[crmask] |= 2
+    O.xtalk_corr(data, O.xtalk_coeffs(case['xtalk']), mask, ys, xs)
+    data_xtalk = data.copy()
+    hm.update(O.mask_header(mask))
+    O.edge_fill(data, mask, ys, xs)
+    return dict(data_os=data_os, mask_init=mask_init, data_xtalk=data_xtalk, data_final=data,
+                mask_final=mask, header=header, header_mask=hm)
+
+
+@pytest.mark.parametrize('name', ['ml1_small', 'ml1_small_b', 'bg3_tall'])
+def test_oracle_reproduces_reference_exactly(name):
+    g, meta, case = load_case(name)
+    ss = meta['subsample']
+    r = run_oracle(meta, case, 'bn32')
+    ghdr = json.loads(str(g['header']))
+    gmh = json.loads(str(g['header_mask']))
+    assert np.array_equal(r['data_os'][::ss], g['data_os'])
+    assert np.array_equal(r['mask_init'][::ss], g['mask_init'])
+    assert np.array_equal(r['mask_final'][::ss], g['mask_final'])
+    # crosstalk: float64 K=8+8 contraction (BLAS summation order in the reference) rounded to float32
+    np.testing.assert_allclose(r['data_xtalk'][::ss], g['data_xtalk'], rtol=1.2e-7, atol=0)
+    assert (r['data_xtalk'][::ss] != g['data_xtalk']).mean() < 1e-6
+    np.testing.assert_allclose(r['data_final'][::ss], g['data_final'], rtol=1.2e-7, atol=0)
+    if ss == 1:
+        assert hashlib.sha256(r['data_os'].tobytes()).hexdigest() == meta['sha_data_os']
+        assert hashlib.sha256(r['mask_final'].tobytes()).hexdigest() == meta['sha_mask_final']
+    h = r['header']
+    for k, v in ghdr.items():
+        if k.startswith('GAIN'):
+            continue
+        if isinstance(v, bool):
+            assert h[k] == v, k
+        elif k.startswith('RDN'):
+            assert h[k] == pytest.approx(v, rel=1e-7), k      # float32 running sums mimicked
+        elif k.startswith('BIAS') and 'A' in k[4:]:
+            assert h[k] == pytest.approx(v, rel=1e-6, abs=1e-12), k
+        elif isinstance(v, float):
+            assert h[k] == pytest.approx(v, rel=1e-12), k
+    for k in ('M-BPNUM', 'M-EPNUM', 'M-SPNUM', 'M-SCPNUM', 'M-STPNUM', 'M-CRPNUM', 'NOBJ-SAT'):
+        assert r['header_mask'][k] == int(gmh[k]), k
+
+
+@pytest.mark.parametrize('name', ['ml1_small', 'bg3_tall'])
+def test_oracle_f64_within_tolerance(name):
+    """float64 accumulators for the strip statistics: pixels within
+    |d| <= 2e-3 e- + 2e-6 |x| of the reference (hard part 6)"""
+    g, meta, case = load_case(name)
+    ss = meta['subsample']
+    r = run_oracle(meta, case, 'f64')
+    ghdr = json.loads(str(g['header']))
+    d = np.abs(r['data_os'][::ss].astype(np.float64) - g['data_os'])
+    assert np.all(d <= 2e-3 + 2e-6 * np.abs(g['data_os']))
+    assert np.array_equal(r['mask_init'][::ss], g['mask_init'])
+    for c in range(16):
+        assert r['header']['RDN%d' % (c + 1)] == pytest.approx(ghdr['RDN%d' % (c + 1)], rel=1e-4)
+
+
+def test_define_sections_golden():
+    ref = json.load(open(os.path.join(GOLD, 'sections.json')))
+    for label in ('full', 'small'):
+        secs = O.define_sections(tuple(ref[label]['shape']), *ref[label]['chan'])
+        got = [[[s[0].start, s[0].stop, s[1].start, s[1].stop] for s in sec] for sec in secs]
+        assert got == ref[label]['secs']
+    from blackbox_amd import reduce as reduce_geom
+    for label in ('full', 'small'):
+        secs = reduce_geom.define_sections(tuple(ref[label]['shape']), ysize_chan=ref[label]['chan'][0],
+                                           xsize_chan=ref[label]['chan'][1])
+        got = [[[s[0].start, s[0].stop, s[1].start, s[1].stop] for s in sec] for sec in secs]
+        assert got == ref[label]['secs']
