@@ -1,0 +1,105 @@
+// bbx_bsel.h -- "bracketed select": exact order statistics of image segments without a
+// dedicated pass over the frame.
+//
+//   1. sample   : BSEL_S strided samples per segment                      (tiny)
+//   2. bracket  : [lo, hi] = sample order statistics around the target quantile,
+//                 wide enough to hold the wanted rank with overwhelming probability
+//   3. feed     : any kernel that streams the segment anyway calls bsel_feed() per pixel:
+//                 counts values below lo and stages the values inside the bracket
+//                 (~5 % of the pixels) in LDS; bsel_drain() moves them to a side buffer
+//                 with ONE global atomic per workgroup -- no extra HBM read of the frame
+//   4. finish   : rank' = rank - below; exact radix select inside the small buffer.
+//                 If the rank fell outside the bracket (or a buffer overflowed) the
+//                 segment is flagged and the full 3-pass radix select over the frame runs
+//                 instead, so the result is exact in every case.
+#pragma once
+#include "bbx_common.h"
+
+#define BSEL_S 16384
+#define BSEL_MAXSEG 16
+#define BSEL_LBUF 6144            // LDS staging entries per workgroup (24 KB)
+
+struct bsel_seg {
+    float lo, hi;                 // closed bracket
+    uint32_t nsample;             // valid samples
+    uint32_t nbuf;                // values appended (may exceed cap -> overflow -> fail)
+    unsigned long long below;     // valid values < lo
+    unsigned long long n;         // valid values
+    uint32_t fail;                // 1 -> full select required
+    uint32_t pad;
+    float result[2];              // lower / upper middle element (ranks (n-1)/2 and n/2)
+};
+
+struct bsel_dev {                 // passed by value to feeding kernels
+    bsel_seg* seg;                // [nseg]
+    float* buf;                   // [nseg][cap]
+    uint32_t cap;
+    int ysz, xsz, SX;             // segment rectangles
+};
+
+struct bsel_acc { unsigned n, below; };
+struct bsel_lds { float v[BSEL_LBUF]; unsigned cnt; unsigned base; };
+
+__device__ __forceinline__ void bsel_lds_init(bsel_lds& L) {
+    if (threadIdx.x == 0) { L.cnt = 0; L.base = 0; }
+    __syncthreads();
+}
+
+// per pixel; every lane of the wave must call it (ballot)
+__device__ __forceinline__ void bsel_feed(bsel_lds& L, float lo, float hi, float v, bool valid, bsel_acc& acc) {
+    bool app = false;
+    if (valid) {
+        acc.n++;
+        if (v < lo) acc.below++;
+        else if (v <= hi) app = true;
+    }
+    const unsigned long long m = __ballot(app);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&L.cnt, (unsigned)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (app) {
+            const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < BSEL_LBUF) L.v[pos] = v;
+        }
+    }
+}
+
+// workgroup-wide (contains barriers): move the staged values to the side buffer when the
+// stage could overflow before the next call ([reserve] = max appends until then) or [force]
+__device__ __forceinline__ void bsel_drain(const bsel_dev& b, int seg, bsel_lds& L, unsigned reserve, bool force) {
+    __syncthreads();
+    const unsigned c = L.cnt;
+    if (force || c + reserve > BSEL_LBUF) {
+        if (threadIdx.x == 0) {
+            L.base = c ? atomicAdd(&b.seg[seg].nbuf, c) : 0u;
+            if (c > BSEL_LBUF) atomicOr(&b.seg[seg].fail, 1u);       // staged values were dropped
+        }
+        __syncthreads();
+        const unsigned base = L.base, n = c < BSEL_LBUF ? c : BSEL_LBUF;
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned pos = base + i;
+            if (pos < b.cap) b.buf[(size_t)seg * b.cap + pos] = L.v[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) L.cnt = 0;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void bsel_flush(const bsel_dev& b, int seg, bsel_acc& acc) {
+    const int n = wave_sum_i32((int)acc.n), bl = wave_sum_i32((int)acc.below);
+    if ((threadIdx.x & 63) == 0) {
+        if (n) atomicAdd(&b.seg[seg].n, (unsigned long long)n);
+        if (bl) atomicAdd(&b.seg[seg].below, (unsigned long long)bl);
+    }
+    acc.n = 0; acc.below = 0;
+}
+
+// host-side entry points (bbx_select.hip)
+int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, int ny, int nx, int ysz, int xsz,
+                     bsel_dev* out, hipStream_t s);
+int bbx_bsel_finish(bbx_ctx* ctx, const bsel_dev& b, const float* d_data, const uint8_t* d_mask, int ny, int nx,
+                    hipStream_t s);

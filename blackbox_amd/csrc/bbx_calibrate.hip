@@ -44,39 +44,81 @@ __device__ __forceinline__ void calib_pixel(const calib_args& a, float rawv, int
     out = v;
 }
 
-// VEC = 4: xsize_chan % 4 == 0, a thread owns 4 consecutive pixels of one channel row
-template <int RAW_T, int VEC>
-__global__ __launch_bounds__(256) void k_calibrate(calib_args a) {
+// Vector path (xsize_chan % 4 == 0): block = 256 threads x 4 pixels wide, CAL_ROWS rows tall.
+// A thread keeps its 4 oscan values in registers for all rows; vfit[row] is block-uniform.
+#define CAL_ROWS 8
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
     const bbx_dims& d = a.d;
-    const int ngx = d.nx / VEC;
-    const size_t total = (size_t)d.ny * ngx;
+    const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (X >= d.nx) return;
+    const int ix = X / d.xsz, x = X - ix * d.xsz;
+    const int Y0 = blockIdx.y * CAL_ROWS;
+    const int iy = Y0 / d.ysz;                                   // CAL_ROWS divides ysize_chan (checked by the host)
+    const int c = iy * 8 + ix;
+    const double os0 = a.oscan[c * d.xsz + x], os1 = a.oscan[c * d.xsz + x + 1],
+                 os2 = a.oscan[c * d.xsz + x + 2], os3 = a.oscan[c * d.xsz + x + 3];
+    const float g = a.gain.v[c], sat = a.sat.v[c];
+#pragma unroll 4
+    for (int k = 0; k < CAL_ROWS; k++) {
+        const int Y = Y0 + k;
+        const int y = Y - iy * d.ysz;
+        const int rl = (iy == 0) ? y : (d.os_y + y);
+        const size_t ri = (size_t)(iy * d.dy + rl) * d.nx_raw + (size_t)ix * d.dx + x;
+        const size_t o = (size_t)Y * d.nx + X;
+        float r[4];
+        if (RAW_T == BBX_RAW_U16) {
+            const ushort4 u = *(const ushort4*)((const uint16_t*)a.raw + ri);
+            r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w;
+        } else {
+            const float4 f = *(const float4*)((const float*)a.raw + ri);
+            r[0] = f.x; r[1] = f.y; r[2] = f.z; r[3] = f.w;
+        }
+        const double vf = a.vfit[c * d.dy + rl];
+        float fl[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+        uint8_t m[4] = {0, 0, 0, 0};
+        if (a.flat) { const float4 t = *(const float4*)(a.flat + o); fl[0] = t.x; fl[1] = t.y; fl[2] = t.z; fl[3] = t.w; }
+        if (a.bias) { const float4 t = *(const float4*)(a.bias + o); bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
+        if (a.bpm) { const uchar4 t = *(const uchar4*)(a.bpm + o); m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w; }
+        const double os[4] = {os0, os1, os2, os3};
+        float ov[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v = r[q];
+            if (RAW_T == BBX_RAW_F32 && !isfinite(v)) v = 0.f;
+            v = v * g;
+            v = (float)((double)v - vf);
+            v = (float)((double)v - os[q]);
+            if (a.bias) v = v - bi[q];
+            if (!isfinite(v)) { v = 0.f; if (m[q] == 0) m[q] |= BBX_MASK_BAD; }
+            if (v >= sat) {
+                m[q] |= BBX_MASK_SAT;
+                const unsigned kk = atomicAdd((unsigned*)&a.counters[CNT_SAT], 1u);
+                if (kk < a.satcap) a.satlist[kk] = (uint32_t)(o + q); else atomicOr(a.err, BBX_DERR_LIST_OVERFLOW);
+            }
+            if (a.flat) v = v / fl[q];
+            ov[q] = v;
+        }
+        *(float4*)(a.data + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        *(uchar4*)(a.mask + o) = make_uchar4(m[0], m[1], m[2], m[3]);
+    }
+}
+
+// scalar path for geometries without 4-pixel alignment (small test frames)
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_calibrate_s(calib_args a) {
+    const bbx_dims& d = a.d;
+    const size_t total = (size_t)d.ny * d.nx;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int Y = (int)(t / ngx), X = (int)(t - (size_t)Y * ngx) * VEC;
+        const int Y = (int)(t / d.nx), X = (int)(t - (size_t)Y * d.nx);
         const int iy = Y / d.ysz, y = Y - iy * d.ysz;
         const int ix = X / d.xsz, x = X - ix * d.xsz;
         const int c = iy * 8 + ix;
         const int rl = (iy == 0) ? y : (d.os_y + y);           // channel-local row (data_sec origin)
         const size_t ri = (size_t)(iy * d.dy + rl) * d.nx_raw + (size_t)ix * d.dx + x;
-        const size_t o = (size_t)Y * d.nx + X;
-        if (VEC == 4) {
-            float r[4];
-            if (RAW_T == BBX_RAW_U16) {
-                ushort4 u = *(const ushort4*)((const uint16_t*)a.raw + ri);
-                r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w;
-            } else {
-                float4 f = *(const float4*)((const float*)a.raw + ri);
-                r[0] = f.x; r[1] = f.y; r[2] = f.z; r[3] = f.w;
-            }
-            float ov[4]; uint8_t mv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) calib_pixel<RAW_T>(a, r[k], c, rl, x + k, o + k, ov[k], mv[k]);
-            *(float4*)(a.data + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-            *(uchar4*)(a.mask + o) = make_uchar4(mv[0], mv[1], mv[2], mv[3]);
-        } else {
-            float ov; uint8_t mv;
-            calib_pixel<RAW_T>(a, raw_load<RAW_T>(a.raw, ri), c, rl, x, o, ov, mv);
-            a.data[o] = ov; a.mask[o] = mv;
-        }
+        float ov; uint8_t mv;
+        calib_pixel<RAW_T>(a, raw_load<RAW_T>(a.raw, ri), c, rl, x, t, ov, mv);
+        a.data[t] = ov; a.mask[t] = mv;
     }
 }
 
@@ -102,18 +144,21 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
     a.err = ctx->d_err; a.satcap = (uint32_t)ctx->cap_satlist;
     for (int i = 0; i < 16; i++) { a.gain.v[i] = h_gain[i]; a.sat.v[i] = h_satlevel[i]; }
     BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_SAT], 0, sizeof(int32_t), s));
-    // vector path needs 4-pixel groups inside one channel row and aligned addresses
-    bool vec = (a.d.xsz % 4 == 0) && (a.d.dx % 4 == 0) && (((uintptr_t)d_raw) % 16 == 0) &&
-               (((uintptr_t)d_data) % 16 == 0) && (((uintptr_t)d_mask) % 4 == 0);
-    const size_t groups = vec ? npix / 4 : npix;
-    unsigned grid = (unsigned)((groups + 255) / 256);
-    if (grid > 256u * 16u) grid = 256u * 16u;               // grid-stride beyond 16 blocks per CU
+    // vector path needs 4-pixel groups inside one channel row, aligned addresses and
+    // row strips that do not straddle the two channel rows
+    bool vec = (a.d.xsz % 4 == 0) && (a.d.dx % 4 == 0) && (a.d.ysz % CAL_ROWS == 0) && (((uintptr_t)d_raw) % 16 == 0) &&
+               (((uintptr_t)d_data) % 16 == 0) && (((uintptr_t)d_mask) % 4 == 0) &&
+               (!d_flat || ((uintptr_t)d_flat) % 16 == 0) && (!d_bias || ((uintptr_t)d_bias) % 16 == 0) &&
+               (!d_bpm || ((uintptr_t)d_bpm) % 4 == 0);
     if (vec) {
-        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate<BBX_RAW_U16, 4>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_calibrate<BBX_RAW_F32, 4>), dim3(grid), dim3(256), 0, s, a);
+        dim3 grid((a.d.nx / 4 + 255) / 256, a.d.ny / CAL_ROWS);
+        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL(k_calibrate_v4<BBX_RAW_U16>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_calibrate_v4<BBX_RAW_F32>, grid, dim3(256), 0, s, a);
     } else {
-        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate<BBX_RAW_U16, 1>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_calibrate<BBX_RAW_F32, 1>), dim3(grid), dim3(256), 0, s, a);
+        unsigned grid = (unsigned)((npix + 255) / 256);
+        if (grid > 256u * 16u) grid = 256u * 16u;
+        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL(k_calibrate_s<BBX_RAW_U16>, dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_calibrate_s<BBX_RAW_F32>, dim3(grid), dim3(256), 0, s, a);
     }
     BBX_LAUNCH_CHECK();
     return BBX_OK;

@@ -20,12 +20,9 @@
 //   4. k_lac_clean  masked 5x5 median at every pixel of the cumulative CR list.
 // All arithmetic is float32 in the order fixed by oracle/lacosmic.py; build with
 // -ffp-contract=off.  Results are bit-identical to the dense algorithm.
-#include "bbx_common.h"
+#include "bbx_bsel.h"
 #include "bbx_mednet.h"
 
-struct sel_query { uint32_t prefix; uint32_t pad; unsigned long long k; unsigned long long n; };
-int bbx_select_run(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, int ny, int nx, int ysz, int xsz,
-                   int nq_per_seg, int rule, sel_query** d_q_out, hipStream_t s);
 int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt, size_t cap, int ny, int nx,
                       int32_t* d_out, hipStream_t s);
 
@@ -66,19 +63,109 @@ __device__ __forceinline__ float lplus_at(const float* __restrict__ a, int j, in
 }
 
 // ---- 1. dense candidate pass ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lac_cand(const float* __restrict__ a, lac_par p, uint32_t* __restrict__ cand,
-                                                  int32_t* counters, uint32_t cap, int32_t* err) {
+// One read of the frame.  Block = 256 threads x 4 columns, walking CAND_ROWS rows with a
+// 3-row register window; left/right neighbours come from the adjacent lanes; the loads of
+// CAND_B rows are issued together to keep enough bytes in flight.  With FEED the same pass
+// feeds the bracketed select of the background level (reads the mask too; dynamic LDS =
+// sizeof(bsel_lds)).
+#define CAND_ROWS 32
+#define CAND_B 4
+template <bool FEED>
+__global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a, const uint8_t* __restrict__ mask,
+                                                     lac_par p, uint32_t* __restrict__ cand, int32_t* counters,
+                                                     uint32_t cap, int32_t* err, bsel_dev b) {
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    bsel_lds& L = *reinterpret_cast<bsel_lds*>(dyn_lds);
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool act = x0 < p.nx;                                 // nx % 4 == 0 on this path
+    const int j0 = blockIdx.y * CAND_ROWS;
+    const int j1 = min(j0 + CAND_ROWS, p.ny);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 up = (act && j0 > 0) ? *(const float4*)(a + (size_t)(j0 - 1) * p.nx + x0) : zero;
+    float4 cur = act ? *(const float4*)(a + (size_t)j0 * p.nx + x0) : zero;
+    float lo = 0.f, hi = 0.f;
+    bsel_acc acc = {0, 0};
+    if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; bsel_lds_init(L); }
+    for (int jb = j0; jb < j1; jb += CAND_B) {
+        float4 nxt[CAND_B]; float le[CAND_B], re[CAND_B]; uchar4 mk[CAND_B];
+#pragma unroll
+        for (int k = 0; k < CAND_B; k++) {
+            const int j = jb + k;
+            const size_t row = (size_t)j * p.nx;
+            nxt[k] = (act && j + 1 < p.ny) ? *(const float4*)(a + row + p.nx + x0) : zero;
+            le[k] = (lane == 0 && act && x0 > 0 && j < p.ny) ? a[row + x0 - 1] : 0.f;
+            re[k] = (lane == 63 && act && x0 + 4 < p.nx && j < p.ny) ? a[row + x0 + 4] : 0.f;
+            mk[k] = make_uchar4(0, 0, 0, 0);
+            if (FEED && act && j < p.ny) mk[k] = *(const uchar4*)(mask + row + x0);
+        }
+#pragma unroll
+        for (int k = 0; k < CAND_B; k++) {
+            const int j = jb + k;
+            if (j >= j1) break;                                  // block-uniform
+            const size_t row = (size_t)j * p.nx;
+            const float4 dn = nxt[k];
+            float l = __shfl_up(cur.w, 1, 64), r = __shfl_down(cur.x, 1, 64);
+            if (lane == 0) l = le[k];
+            if (lane == 63) r = re[k];
+            // the 2-pixel frame of the image never holds candidates (sp == 0 there), so every
+            // tested pixel has all four neighbours: interior form of L+
+            const bool rowok = (j >= 2 && j < p.ny - 2);
+            const float c4[4] = {cur.x, cur.y, cur.z, cur.w};
+            const float u4[4] = {up.x, up.y, up.z, up.w};
+            const float d4[4] = {dn.x, dn.y, dn.z, dn.w};
+            const float l4[4] = {l, cur.x, cur.y, cur.z};
+            const float r4[4] = {cur.y, cur.z, cur.w, r};
+            const uint8_t mm[4] = {mk[k].x, mk[k].y, mk[k].z, mk[k].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = x0 + q;
+                if (act && rowok && i >= 2 && i < p.nx - 2) {
+                    const float lp = lplus_px(c4[q], u4[q], d4[q], l4[q], r4[q], true, true, true, true);
+                    if (lp > p.T) {
+                        const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
+                        if (kk < cap) cand[kk] = (uint32_t)(row + i); else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                    }
+                }
+                if (FEED) bsel_feed(L, lo, hi, c4[q], act && !(mm[q] & ~BBX_MASK_COSMIC), acc);
+            }
+            up = cur; cur = dn;
+        }
+        if (FEED) bsel_drain(b, 0, L, 1024u * CAND_B, jb + CAND_B >= j1);
+    }
+    if (FEED) bsel_flush(b, 0, acc);
+}
+
+// scalar variant for frames whose width is not a multiple of 4 (small test frames)
+template <bool FEED>
+__global__ __launch_bounds__(256) void k_lac_cand_s(const float* __restrict__ a, const uint8_t* __restrict__ mask,
+                                                    lac_par p, uint32_t* __restrict__ cand, int32_t* counters,
+                                                    uint32_t cap, int32_t* err, bsel_dev b) {
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    bsel_lds& L = *reinterpret_cast<bsel_lds*>(dyn_lds);
     const size_t npix = (size_t)p.ny * p.nx;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(o / p.nx), i = (int)(o - (size_t)j * p.nx);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nend = ((npix + stride - 1) / stride) * stride;      // every thread runs the same trip count
+    float lo = 0.f, hi = 0.f;
+    bsel_acc acc = {0, 0};
+    if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; bsel_lds_init(L); }
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < nend; o += stride) {
+        const bool in = o < npix;
+        const int j = in ? (int)(o / p.nx) : 0, i = in ? (int)(o - (size_t)j * p.nx) : 0;
         // the outer 2-pixel frame has sp == 0 (median filter copies its border)
-        if (j < 2 || i < 2 || j >= p.ny - 2 || i >= p.nx - 2) continue;
-        const float lp = lplus_at(a, j, i, p.ny, p.nx);
-        if (lp > p.T) {
-            const unsigned k = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
-            if (k < cap) cand[k] = (uint32_t)o; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        if (in && !(j < 2 || i < 2 || j >= p.ny - 2 || i >= p.nx - 2)) {
+            const float lp = lplus_at(a, j, i, p.ny, p.nx);
+            if (lp > p.T) {
+                const unsigned k = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
+                if (k < cap) cand[k] = (uint32_t)o; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+            }
+        }
+        if (FEED) {
+            bsel_feed(L, lo, hi, in ? a[o] : 0.f, in && !(mask[o] & ~BBX_MASK_COSMIC), acc);
+            bsel_drain(b, 0, L, 256u, o + stride >= nend);
         }
     }
+    if (FEED) bsel_flush(b, 0, acc);
 }
 
 // ---- wave-cooperative evaluation ----------------------------------------------------
@@ -245,7 +332,7 @@ __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, 
 // ---- 4. clean_medmask on the cumulative CR list -------------------------------------------------
 __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __restrict__ mask, lac_par p,
                                                    const uint32_t* __restrict__ crlist, const int32_t* __restrict__ counters,
-                                                   uint32_t cap, const sel_query* __restrict__ bg) {
+                                                   uint32_t cap, const bsel_seg* __restrict__ bg) {
     const int n = min((uint32_t)counters[CNT_CRLIST], cap);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -263,7 +350,7 @@ __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __re
         const int cnt = __popcll(__ballot(ok));
         // +inf padding sorts last; a genuine +inf pixel would too, and is then picked in order
         const float med = wave_sort_pick(v, 32, cnt > 0 ? (cnt - 1) / 2 : 0);
-        if (lane == 0) a[o] = (cnt > 0) ? med : key2f(bg->prefix);
+        if (lane == 0) a[o] = (cnt > 0) ? med : bg->result[0];
     }
 }
 
@@ -296,19 +383,30 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     int32_t* cnt = ctx->d_counters;
     BBX_HIP(hipMemsetAsync(d_stats, 0, 8 * sizeof(int32_t), s));
     BBX_HIP(hipMemsetAsync(&cnt[CNT_CAND], 0, 4 * sizeof(int32_t), s));      // CAND, STAGE2, CRLIST, NEWCR
-    // background level of the unmasked input pixels (needed when a CR pixel has no good neighbour)
-    sel_query* bg;
-    rc = bbx_select_run(ctx, d_data, d_mask, ny, nx, ny, nx, 1, 0, &bg, s);
+    // background level of the unmasked input pixels (needed when a CR pixel has no good
+    // neighbour): bracketed select fed by the first candidate pass, no extra read of the frame
+    bsel_dev bs;
+    rc = bbx_bsel_prepare(ctx, d_data, d_mask, ny, nx, ny, nx, &bs, s);
     if (rc) return rc;
     const unsigned gdense = 256u * 16u, gsparse = 256u * 8u;
+    const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
+    const dim3 gvec((nx / 4 + 255) / 256, (ny + CAND_ROWS - 1) / CAND_ROWS);
     for (int it = 0; it < niter; it++) {
         BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
-        hipLaunchKernelGGL(k_lac_cand, dim3(gdense), dim3(256), 0, s, d_data, p, cand, cnt, (uint32_t)cap, ctx->d_err);
+        if (it == 0) {
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s);
+            if (rc) return rc;
+        } else {
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+        }
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_grow2, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
-        hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bg);
+        hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
         hipLaunchKernelGGL(k_lac_iter_end, dim3(1), dim3(64), 0, s, cnt, d_stats, it);
     }
     BBX_LAUNCH_CHECK();

@@ -116,18 +116,38 @@ __global__ __launch_bounds__(1024) void k_coarse_flood(const uint8_t* __restrict
     for (int t = threadIdx.x; t < nt; t += blockDim.x) {
         const int ty = t / W, tx = t - ty * W;
         const bool edge = (tx == 0 || ty == 0 || tx == W - 1 || ty == TH - 1);
-        st[t] = (!occ[t] && edge) ? 1 : 0;
+        st[t] = occ[t] ? 2 : (edge ? 1 : 0);          // bit 1 = occupied, bit 0 = resolved outside
     }
     __syncthreads();
-    for (int iter = 0; iter < 2 * (W + TH) + 4 * nt; iter++) {
+    // run-length propagation: one thread sweeps a whole tile row (both directions), then a
+    // whole tile column; an empty frame is resolved after a single round
+    for (int iter = 0; iter < nt + 4; iter++) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-            if (st[t] || occ[t]) continue;
-            const int ty = t / W, tx = t - ty * W;
-            bool r = (tx > 0 && st[t - 1]) || (tx < W - 1 && st[t + 1]) || (ty > 0 && st[t - W]) ||
-                     (ty < TH - 1 && st[t + W]);
-            if (r) { st[t] = 1; changed = 1; }
+        for (int ty = threadIdx.x; ty < TH; ty += blockDim.x) {
+            bool run = false;
+            for (int tx = 0; tx < W; tx++) {
+                const int t = ty * W + tx;
+                if (st[t] & 2) run = false; else if (st[t]) run = true; else if (run) { st[t] = 1; changed = 1; }
+            }
+            run = false;
+            for (int tx = W - 1; tx >= 0; tx--) {
+                const int t = ty * W + tx;
+                if (st[t] & 2) run = false; else if (st[t]) run = true; else if (run) { st[t] = 1; changed = 1; }
+            }
+        }
+        __syncthreads();
+        for (int tx = threadIdx.x; tx < W; tx += blockDim.x) {
+            bool run = false;
+            for (int ty = 0; ty < TH; ty++) {
+                const int t = ty * W + tx;
+                if (st[t] & 2) run = false; else if (st[t]) run = true; else if (run) { st[t] = 1; changed = 1; }
+            }
+            run = false;
+            for (int ty = TH - 1; ty >= 0; ty--) {
+                const int t = ty * W + tx;
+                if (st[t] & 2) run = false; else if (st[t]) run = true; else if (run) { st[t] = 1; changed = 1; }
+            }
         }
         __syncthreads();
         const int c = changed;
@@ -135,8 +155,8 @@ __global__ __launch_bounds__(1024) void k_coarse_flood(const uint8_t* __restrict
         if (!c) break;
     }
     for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-        state[t] = st[t];
-        if (!st[t]) { int k = atomicAdd(&counters[CNT_TILES], 1); tiles[k] = (uint32_t)t; }
+        state[t] = st[t] & 1;
+        if (!(st[t] & 1)) { int k = atomicAdd(&counters[CNT_TILES], 1); tiles[k] = (uint32_t)t; }
     }
     (void)err;
 }

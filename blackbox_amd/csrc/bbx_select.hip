@@ -1,142 +1,366 @@
-// bbx_select.hip -- exact order statistics over image segments (3-pass radix select)
-// and the edge fill that uses them.
+// bbx_select.hip -- exact order statistics over image segments, and the edge fill.
 //
 //   * LA-Cosmic background level = element (n-1)/2 of the sorted unmasked pixels
 //     (astroscrappy's quick-select median; oracle/lacosmic.py lower_median)
-//   * edge fill (blackbox.py:1968-1974): edge pixels <- np.median(channel) = mean of
-//     the two middle elements of the 5280x1320 values (float32)
+//   * edge fill (blackbox.py:1968-1974): edge pixels <- np.median(channel) = float32
+//     mean of the two middle elements of the channel's 5280x1320 values
 //
-// A query = (segment, rank k).  Each pass histograms 11/11/10 key bits of the pixels
-// whose higher key bits match the query's prefix; a one-wave scan kernel then picks
-// the bin that holds rank k.  Keys are the order-preserving uint32 image of float32.
-// Every pass is one HBM-bound read of the frame (4N bytes, + N with a mask filter).
-#include "bbx_common.h"
+// Fast path = bracketed select (bbx_bsel.h): the frame is not re-read; the kernels that
+// stream it anyway feed a ~5 % side buffer, and a 3-digit (11/11/10 bit) radix select runs
+// on that buffer.  Slow path (exact fallback, taken only when a rank falls outside its
+// bracket) = the same radix select over the whole frame.  Keys are the order-preserving
+// uint32 image of float32.
+#include "bbx_bsel.h"
 
-#define SEL_MAXQ 32
 #define SEL_BINS 2048
 
-struct sel_query { uint32_t prefix; uint32_t pad; unsigned long long k; unsigned long long n; };
+// fold popular bins per wave into single LDS atomics (sky-dominated data put most of a
+// wave into one bin), the rest go direct.  All 64 lanes must call.
+__device__ __forceinline__ void hist_add(uint32_t* lh, uint32_t bin, bool hit) {
+    for (int round = 0; round < 2; round++) {
+        const unsigned long long act = __ballot(hit);
+        if (!act) return;
+        const int leader = __ffsll((long long)act) - 1;
+        const uint32_t b0 = __shfl(bin, leader, 64);
+        const unsigned long long m = __ballot(hit && bin == b0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[b0], (uint32_t)__popcll(m));
+        if (bin == b0) hit = false;
+    }
+    if (hit) atomicAdd(&lh[bin], 1u);
+}
 
+// wave-level: locate the bin holding rank rk in histogram h[nb]; returns (bin, rank inside)
+__device__ __forceinline__ bool wave_find_bin(const uint32_t* h, int nb, unsigned long long rk, int* bin,
+                                              unsigned long long* rk_in, unsigned long long* total) {
+    const int lane = threadIdx.x & 63, per = nb / 64;
+    unsigned long long mine = 0;
+    for (int k = 0; k < per; k++) mine += h[lane * per + k];
+    unsigned long long incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    *total = __shfl(incl, 63, 64);
+    const unsigned long long excl = incl - mine;
+    if (rk >= excl && rk < incl) {
+        unsigned long long acc = excl; int b = lane * per;
+        for (int k = 0; k < per; k++, b++) { if (acc + h[b] > rk) break; acc += h[b]; }
+        *bin = b; *rk_in = rk - acc;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------
+// workgroup-wide radix select of two ranks in a small float array (the samples)
+// ---------------------------------------------------------------------------------
+__device__ void wg_select2(const float* __restrict__ v, uint32_t count, unsigned long long r0, unsigned long long r1,
+                           float* out0, float* out1) {
+    __shared__ uint32_t lh[2][SEL_BINS];
+    __shared__ uint32_t s_prefix[2];
+    __shared__ unsigned long long s_rank[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_prefix[0] = s_prefix[1] = 0; s_rank[0] = r0; s_rank[1] = r1; }
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    uint32_t himask = 0;
+    for (int p = 0; p < 3; p++) {
+        for (int i = tid; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t pre0 = s_prefix[0], pre1 = s_prefix[1];
+        const uint32_t dmask = (1u << nbits[p]) - 1u;
+        const uint32_t cend = ((count + 63u) / 64u) * 64u;
+        for (uint32_t i = tid; i < cend; i += blockDim.x) {
+            const bool in = i < count;
+            const uint32_t key = in ? f2key(v[i]) : 0u;
+            const uint32_t bin = (key >> shifts[p]) & dmask;
+            hist_add(lh[0], bin, in && ((key & himask) == pre0));
+            if (pre1 != pre0) hist_add(lh[1], bin, in && ((key & himask) == pre1));
+        }
+        __syncthreads();
+        const int q = tid >> 6;
+        if (q < 2) {
+            const uint32_t* h = (q == 1 && pre1 == pre0) ? lh[0] : lh[q];
+            int b; unsigned long long rin, total;
+            if (wave_find_bin(h, 1 << nbits[p], s_rank[q], &b, &rin, &total)) {
+                s_rank[q] = rin;
+                s_prefix[q] |= ((uint32_t)b) << shifts[p];
+            }
+        }
+        __syncthreads();
+        himask |= dmask << shifts[p];
+    }
+    if (tid == 0) { *out0 = key2f(s_prefix[0]); *out1 = key2f(s_prefix[1]); }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------
+// bracketed select: sample, bracket
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bsel_init(bsel_seg* seg, int nseg) {
+    const int i = threadIdx.x;
+    if (i < nseg) {
+        bsel_seg s;
+        s.lo = 0.f; s.hi = 0.f; s.nsample = 0; s.nbuf = 0; s.below = 0; s.n = 0; s.fail = 0; s.pad = 0;
+        s.result[0] = s.result[1] = 0.f;
+        seg[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bsel_sample(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                     int nx, int ysz, int xsz, int SX, bsel_seg* seg,
+                                                     float* __restrict__ samples) {
+    const int sg = blockIdx.y;
+    const int sy = sg / SX, sx = sg - sy * SX;
+    const unsigned long long npix = (unsigned long long)ysz * xsz;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // 0 .. BSEL_S-1
+    float v = __builtin_huge_valf();
+    int ok = 0;
+    if (npix >= BSEL_S || (unsigned long long)i < npix) {
+        const unsigned long long j = (npix >= BSEL_S) ? ((unsigned long long)i * npix) / BSEL_S : (unsigned long long)i;
+        const int y = (int)(j / xsz), x = (int)(j - (unsigned long long)y * xsz);
+        const size_t o = (size_t)(sy * ysz + y) * nx + (size_t)sx * xsz + x;
+        if (!mask || !(mask[o] & ~BBX_MASK_COSMIC)) { v = data[o]; ok = (v == v) ? 1 : 0; if (!ok) v = __builtin_huge_valf(); }
+    }
+    samples[(size_t)sg * BSEL_S + i] = v;
+    ok = wave_sum_i32(ok);
+    if ((threadIdx.x & 63) == 0 && ok) atomicAdd(&seg[sg].nsample, (unsigned)ok);
+}
+
+__global__ __launch_bounds__(1024) void k_bsel_bracket(bsel_seg* seg, const float* __restrict__ samples) {
+    const int sg = blockIdx.x;
+    __shared__ float lo, hi;
+    const uint32_t m = seg[sg].nsample;
+    if (m < 256) {                       // too few valid samples: go straight to the full select
+        if (threadIdx.x == 0) { seg[sg].fail = 1; seg[sg].lo = __builtin_huge_valf(); seg[sg].hi = -__builtin_huge_valf(); }
+        return;
+    }
+    const long long target = ((long long)m - 1) / 2;
+    const long long margin = (long long)(3.0f * sqrtf((float)m)) + 8;      // +-6 sigma of the sample rank
+    const long long rlo = target - margin < 0 ? 0 : target - margin;
+    const long long rhi = target + margin > (long long)m - 1 ? (long long)m - 1 : target + margin;
+    wg_select2(samples + (size_t)sg * BSEL_S, BSEL_S, (unsigned long long)rlo, (unsigned long long)rhi, &lo, &hi);
+    if (threadIdx.x == 0) {
+        seg[sg].lo = (rlo == 0) ? -__builtin_huge_valf() : lo;
+        seg[sg].hi = (rhi == (long long)m - 1) ? __builtin_huge_valf() : hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// finish: ranks, then 3 digit passes; source = side buffer, or the frame for segments
+// whose bracket failed
+// ---------------------------------------------------------------------------------
 struct sel_args {
-    const float* data; const uint8_t* mask;   // mask != NULL: only pixels with (mask & ~2) == 0 count
-    int ny, nx, ysz, xsz, SX;                 // segments: rectangles ysz x xsz, SX per row
-    int nq_per_seg;                           // 1 or 2 queries per segment
-    int shift, bits;                          // current digit
-    uint32_t himask;                          // mask of the key bits already fixed
-    sel_query* q; uint32_t* hist;             // hist[query][SEL_BINS]
+    const float* data; const uint8_t* mask;
+    int nx, ysz, xsz, SX;
+    int shift, bits; uint32_t himask;
+    bsel_dev b;
+    uint32_t* prefix;                         // prefix[seg][2]
+    unsigned long long* rank;                 // rank[seg][2] (remaining)
+    uint32_t* hist;                           // hist[seg][2][SEL_BINS]
 };
 
-__global__ __launch_bounds__(256) void k_sel_hist(sel_args a) {
+__global__ void k_sel_plan(sel_args a, int nseg) {
+    const int sg = threadIdx.x;
+    if (sg >= nseg) return;
+    bsel_seg* s = &a.b.seg[sg];
+    const unsigned long long n = s->n, below = s->below;
+    const unsigned long long k0 = n ? (n - 1) / 2 : 0, k1 = n / 2;
+    const uint32_t nbuf = s->nbuf;
+    if (s->fail || nbuf > a.b.cap || k0 < below || k1 >= below + nbuf) s->fail = 1;
+    a.rank[sg * 2] = s->fail ? k0 : k0 - below;
+    a.rank[sg * 2 + 1] = s->fail ? k1 : k1 - below;
+    a.prefix[sg * 2] = a.prefix[sg * 2 + 1] = 0;
+}
+
+// histogram of one key digit over the side buffers (segments that did not fail)
+__global__ __launch_bounds__(256) void k_sel_hist_buf(sel_args a) {
     __shared__ uint32_t lh[2][SEL_BINS];
-    // block = (row Y, segment column sx)
-    const int Y = blockIdx.x, sx = blockIdx.y;
-    const int seg = (Y / a.ysz) * a.SX + sx;
-    const int nq = a.nq_per_seg;
-    for (int i = threadIdx.x; i < nq * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
+    const int sg = blockIdx.y;
+    const bsel_seg* s = &a.b.seg[sg];
+    if (s->fail) return;
+    const uint32_t count = s->nbuf;
+    const uint32_t per = (count + gridDim.x - 1) / gridDim.x;
+    const uint32_t i0 = blockIdx.x * per, i1 = min(count, i0 + per);
+    if (i0 >= i1) return;
+    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
     __syncthreads();
-    uint32_t pre[2];
-    for (int k = 0; k < nq; k++) pre[k] = a.q[seg * nq + k].prefix;
+    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1];
+    const uint32_t dmask = (1u << a.bits) - 1u;
+    const float* v = a.b.buf + (size_t)sg * a.b.cap;
+    const uint32_t span = ((i1 - i0 + 63u) / 64u) * 64u;
+    for (uint32_t k = threadIdx.x; k < span; k += blockDim.x) {
+        const bool in = i0 + k < i1;
+        const uint32_t key = in ? f2key(v[i0 + k]) : 0u;
+        const uint32_t bin = (key >> a.shift) & dmask;
+        hist_add(lh[0], bin, in && ((key & a.himask) == pre0));
+        if (pre1 != pre0) hist_add(lh[1], bin, in && ((key & a.himask) == pre1));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
+        const uint32_t c = (&lh[0][0])[i];
+        if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
+    }
+}
+
+// the same over the frame, for segments flagged `fail` (every other block exits at once)
+__global__ __launch_bounds__(256) void k_sel_hist_frame(sel_args a) {
+    __shared__ uint32_t lh[2][SEL_BINS];
+    const int Y = blockIdx.x, sx = blockIdx.y;
+    const int sg = (Y / a.ysz) * a.SX + sx;
+    if (!a.b.seg[sg].fail) return;
+    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1];
     const size_t row = (size_t)Y * a.nx + (size_t)sx * a.xsz;
     const uint32_t dmask = (1u << a.bits) - 1u;
-    const int xend = ((a.xsz + 63) / 64) * 64;          // keep whole waves in the loop (ballots)
+    const int xend = ((a.xsz + 63) / 64) * 64;
     for (int x = threadIdx.x; x < xend; x += blockDim.x) {
         bool in = x < a.xsz;
         if (in && a.mask && (a.mask[row + x] & ~BBX_MASK_COSMIC)) in = false;
         const uint32_t key = in ? f2key(a.data[row + x]) : 0u;
-        for (int k = 0; k < nq; k++) {
-            bool hit = in && ((key & a.himask) == pre[k]);
-            const uint32_t bin = (key >> a.shift) & dmask;
-            // sky-dominated frames put most of a wave into one bin: fold up to two
-            // popular bins per wave into single LDS atomics, the rest go direct
-            for (int round = 0; round < 2; round++) {
-                const unsigned long long act = __ballot(hit);
-                if (!act) break;
-                const int leader = __ffsll((long long)act) - 1;
-                const uint32_t b0 = __shfl(bin, leader, 64);
-                const unsigned long long m = __ballot(hit && bin == b0);
-                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[k][b0], (uint32_t)__popcll(m));
-                if (bin == b0) hit = false;
-            }
-            if (hit) atomicAdd(&lh[k][bin], 1u);
-        }
+        const uint32_t bin = (key >> a.shift) & dmask;
+        hist_add(lh[0], bin, in && ((key & a.himask) == pre0));
+        if (pre1 != pre0) hist_add(lh[1], bin, in && ((key & a.himask) == pre1));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nq * SEL_BINS; i += blockDim.x) {
-        const uint32_t v = (&lh[0][0])[i];
-        if (v) atomicAdd(&a.hist[(size_t)(seg * nq + i / SEL_BINS) * SEL_BINS + (i % SEL_BINS)], v);
+    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
+        const uint32_t c = (&lh[0][0])[i];
+        if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
     }
 }
 
-// one wave per query: locate the bin that contains rank k
-// first pass (himask == 0) also fixes n and turns the rank rule into k
-//   rule 0: k = (n-1)/2         rule 1: k = n/2 - 1 (even n) or (n-1)/2     rule 2: k = n/2
-__global__ void k_sel_scan(sel_query* q, uint32_t* hist, int nquery, int shift, int bits, int first, int rule_base,
-                           int nq_per_seg) {
-    const int qi = blockIdx.x;
-    if (qi >= nquery) return;
-    uint32_t* h = hist + (size_t)qi * SEL_BINS;
-    if (threadIdx.x == 0) {
-        sel_query s = q[qi];
-        const int nb = 1 << bits;
-        if (first) {
-            unsigned long long n = 0;
-            for (int b = 0; b < nb; b++) n += h[b];
-            s.n = n;
-            const int rule = (nq_per_seg == 2) ? (1 + (qi & 1)) : rule_base;
-            if (n == 0) s.k = 0;
-            else if (rule == 0) s.k = (n - 1) / 2;
-            else if (rule == 1) s.k = (n & 1) ? (n - 1) / 2 : n / 2 - 1;
-            else s.k = n / 2;
-        }
-        unsigned long long acc = 0; int b = 0;
-        for (; b < nb; b++) { if (acc + h[b] > s.k) break; acc += h[b]; }
-        if (b == nb) b = nb - 1;
-        s.k -= acc;
-        s.prefix |= ((uint32_t)b) << shift;
-        q[qi] = s;
-        for (int i = 0; i < nb; i++) h[i] = 0;
+__global__ __launch_bounds__(128) void k_sel_scan(sel_args a, int last) {
+    const int sg = blockIdx.x;
+    const int q = threadIdx.x >> 6;
+    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1];
+    uint32_t* h0 = a.hist + (size_t)sg * 2 * SEL_BINS;
+    const uint32_t* h = (q == 1 && pre1 == pre0) ? h0 : h0 + q * SEL_BINS;
+    const int nb = 1 << a.bits;
+    int b = 0; unsigned long long rin = 0, total = 0;
+    const bool found = wave_find_bin(h, nb, a.rank[sg * 2 + q], &b, &rin, &total);
+    __syncthreads();                                         // both waves have read prefix/hist
+    if (found) {
+        a.rank[sg * 2 + q] = rin;
+        const uint32_t pre = (q ? pre1 : pre0) | (((uint32_t)b) << a.shift);
+        a.prefix[sg * 2 + q] = pre;
+        if (last) a.b.seg[sg].result[q] = key2f(pre);
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * nb; k += 128) h0[(k / nb) * SEL_BINS + (k % nb)] = 0;
 }
 
-__global__ void k_sel_init(sel_query* q, uint32_t* hist, int nquery) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nquery * SEL_BINS; i += gridDim.x * blockDim.x) hist[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < nquery) { q[threadIdx.x].prefix = 0; q[threadIdx.x].k = 0; q[threadIdx.x].n = 0; q[threadIdx.x].pad = 0; }
+__global__ void k_sel_zero(uint32_t* hist, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hist[i] = 0;
 }
 
-// results live in ctx workspace WS_SEL as sel_query[]; value = key2f(prefix)
-int bbx_select_run(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, int ny, int nx, int ysz, int xsz,
-                   int nq_per_seg, int rule, sel_query** d_q_out, hipStream_t s) {
+static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, float** samples, float** buf,
+                     uint32_t** prefix, unsigned long long** rank, uint32_t** hist) {
     int rc;
-    if (ny % ysz || nx % xsz) return BBX_ERR_ARG;
-    const int SX = nx / xsz, SY = ny / ysz;
-    const int nquery = SX * SY * nq_per_seg;
-    if (nquery > SEL_MAXQ || nq_per_seg < 1 || nq_per_seg > 2) return BBX_ERR_ARG;
-    char* ws = (char*)bbx_ws(ctx, WS_SEL, SEL_MAXQ * sizeof(sel_query) + (size_t)SEL_MAXQ * SEL_BINS * 4, &rc);
+    const size_t o_seg = 0;
+    const size_t o_rank = o_seg + BSEL_MAXSEG * sizeof(bsel_seg);
+    const size_t o_prefix = o_rank + BSEL_MAXSEG * 2 * sizeof(unsigned long long);
+    const size_t o_hist = o_prefix + BSEL_MAXSEG * 2 * sizeof(uint32_t);
+    const size_t o_samples = o_hist + (size_t)BSEL_MAXSEG * 2 * SEL_BINS * 4;
+    const size_t o_buf = o_samples + (size_t)nseg * BSEL_S * 4;
+    const size_t total = o_buf + (size_t)nseg * cap * 4;
+    char* ws = (char*)bbx_ws(ctx, WS_SEL, total, &rc);
     if (rc) return rc;
-    sel_args a;
-    a.data = d_data; a.mask = d_mask; a.ny = ny; a.nx = nx; a.ysz = ysz; a.xsz = xsz; a.SX = SX;
-    a.nq_per_seg = nq_per_seg; a.q = (sel_query*)ws; a.hist = (uint32_t*)(ws + SEL_MAXQ * sizeof(sel_query));
-    hipLaunchKernelGGL(k_sel_init, dim3(64), dim3(256), 0, s, a.q, a.hist, nquery);
-    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
-    uint32_t himask = 0;
-    for (int p = 0; p < 3; p++) {
-        a.shift = shifts[p]; a.bits = nbits[p]; a.himask = himask;
-        hipLaunchKernelGGL(k_sel_hist, dim3(ny, SX), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_sel_scan, dim3(nquery), dim3(64), 0, s, a.q, a.hist, nquery, a.shift, a.bits, p == 0, rule,
-                           nq_per_seg);
-        himask |= ((1u << nbits[p]) - 1u) << shifts[p];
-    }
-    BBX_LAUNCH_CHECK();
-    *d_q_out = a.q;
+    *seg = (bsel_seg*)(ws + o_seg); *rank = (unsigned long long*)(ws + o_rank);
+    *prefix = (uint32_t*)(ws + o_prefix); *hist = (uint32_t*)(ws + o_hist);
+    *samples = (float*)(ws + o_samples); *buf = (float*)(ws + o_buf);
     return BBX_OK;
 }
 
-// np.median of a float32 array with an even count: float32 mean of the two middle values
-__global__ void k_chan_median(const sel_query* __restrict__ q, float* __restrict__ med) {
+int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, int ny, int nx, int ysz, int xsz,
+                     bsel_dev* out, hipStream_t s) {
+    if (ny % ysz || nx % xsz) return BBX_ERR_ARG;
+    const int SX = nx / xsz, nseg = SX * (ny / ysz);
+    if (nseg > BSEL_MAXSEG) return BBX_ERR_ARG;
+    // side buffer: 1/8 of the segment (the bracket holds ~5 %), at least 64k values
+    const size_t segpix = (size_t)ysz * xsz;
+    uint32_t cap = (uint32_t)(segpix / 8 + 65536);
+    bsel_seg* seg; float *samples, *buf; uint32_t *prefix, *hist; unsigned long long* rank;
+    int rc = ws_layout(ctx, nseg, cap, &seg, &samples, &buf, &prefix, &rank, &hist);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bsel_init, dim3(1), dim3(256), 0, s, seg, nseg);
+    hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, nx, ysz, xsz, SX, seg, samples);
+    hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
+    BBX_LAUNCH_CHECK();
+    out->seg = seg; out->buf = buf; out->cap = cap; out->ysz = ysz; out->xsz = xsz; out->SX = SX;
+    return BBX_OK;
+}
+
+int bbx_bsel_finish(bbx_ctx* ctx, const bsel_dev& b, const float* d_data, const uint8_t* d_mask, int ny, int nx,
+                    hipStream_t s) {
+    const int SX = b.SX, nseg = SX * (ny / b.ysz);
+    bsel_seg* seg; float *samples, *buf; uint32_t *prefix, *hist; unsigned long long* rank;
+    int rc = ws_layout(ctx, nseg, b.cap, &seg, &samples, &buf, &prefix, &rank, &hist);
+    if (rc) return rc;
+    sel_args a;
+    a.data = d_data; a.mask = d_mask; a.nx = nx; a.ysz = b.ysz; a.xsz = b.xsz; a.SX = SX;
+    a.b = b; a.prefix = prefix; a.rank = rank; a.hist = hist;
+    hipLaunchKernelGGL(k_sel_zero, dim3(32), dim3(256), 0, s, hist, nseg * 2 * SEL_BINS);
+    hipLaunchKernelGGL(k_sel_plan, dim3(1), dim3(64), 0, s, a, nseg);
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    uint32_t himask = 0;
+    const int bufblocks = nseg == 1 ? 512 : 64;
+    for (int p = 0; p < 3; p++) {
+        a.shift = shifts[p]; a.bits = nbits[p]; a.himask = himask;
+        hipLaunchKernelGGL(k_sel_hist_buf, dim3(bufblocks, nseg), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_sel_hist_frame, dim3(ny, SX), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_sel_scan, dim3(nseg), dim3(128), 0, s, a, p == 2);
+        himask |= ((1u << nbits[p]) - 1u) << shifts[p];
+    }
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// edge fill
+// ---------------------------------------------------------------------------------
+// standalone feeder (used when no other kernel streams the frame after its last change)
+__global__ __launch_bounds__(256) void k_bsel_feed_frame(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                         int ny, int nx, bsel_dev b) {
+    __shared__ bsel_lds L;
+    // block = (group of 4 rows, segment column sx)
+    const int sx = blockIdx.y;
+    bsel_lds_init(L);
+    bsel_acc acc = {0, 0};
+    const int xend = ((b.xsz + 63) / 64) * 64;
+    for (int Y = blockIdx.x * 4; Y < min(ny, blockIdx.x * 4 + 4); Y++) {
+        const int sg = (Y / b.ysz) * b.SX + sx;
+        const int sg_next = ((Y + 1) / b.ysz) * b.SX + sx;
+        const float lo = b.seg[sg].lo, hi = b.seg[sg].hi;
+        const size_t row = (size_t)Y * nx + (size_t)sx * b.xsz;
+        for (int x0 = 0; x0 < xend; x0 += 1024) {
+            for (int x = x0 + threadIdx.x; x < min(xend, x0 + 1024); x += blockDim.x) {
+                const bool in = x < b.xsz;
+                bool valid = in;
+                if (in && mask && (mask[row + x] & ~BBX_MASK_COSMIC)) valid = false;
+                const float v = in ? data[row + x] : 0.f;
+                bsel_feed(L, lo, hi, v, valid, acc);
+            }
+            // at most 1024 appends until the next drain point; force at the end of a
+            // segment / of the block's rows
+            const bool lastchunk = x0 + 1024 >= xend;
+            const bool force = lastchunk && (Y + 1 >= min(ny, (int)blockIdx.x * 4 + 4) || sg_next != sg);
+            bsel_drain(b, sg, L, 1024, force);
+        }
+        if (sg_next != sg || Y + 1 >= min(ny, (int)blockIdx.x * 4 + 4)) bsel_flush(b, sg, acc);
+    }
+}
+
+int bbx_bsel_feed_frame(const float* d_data, const uint8_t* d_mask, int ny, int nx, const bsel_dev& b, hipStream_t s) {
+    hipLaunchKernelGGL(k_bsel_feed_frame, dim3((ny + 3) / 4, b.SX), dim3(256), 0, s, d_data, d_mask, ny, nx, b);
+    return BBX_OK;
+}
+
+// np.median of a float32 array: odd n -> middle element, even n -> float32 mean of the two
+__global__ void k_chan_median(const bsel_seg* __restrict__ seg, float* __restrict__ med) {
     const int c = threadIdx.x;
     if (c < 16) {
-        const float lo = key2f(q[2 * c].prefix), hi = key2f(q[2 * c + 1].prefix);
-        med[c] = (q[2 * c].n & 1) ? lo : (lo + hi) * 0.5f;
+        const float lo = seg[c].result[0], hi = seg[c].result[1];
+        med[c] = (seg[c].n & 1) ? lo : (lo + hi) * 0.5f;
     }
 }
 
@@ -156,10 +380,11 @@ extern "C" int bbx_edge_fill(bbx_ctx* ctx, const bbx_geom* g, float* d_data, con
     if (!ctx || !d_data || !d_mask || !d_chan_median) return BBX_ERR_ARG;
     bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    sel_query* q;
-    rc = bbx_select_run(ctx, d_data, nullptr, d.ny, d.nx, d.ysz, d.xsz, 2, 1, &q, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_chan_median, dim3(1), dim3(64), 0, s, q, d_chan_median);
+    bsel_dev b;
+    rc = bbx_bsel_prepare(ctx, d_data, nullptr, d.ny, d.nx, d.ysz, d.xsz, &b, s); if (rc) return rc;
+    bbx_bsel_feed_frame(d_data, nullptr, d.ny, d.nx, b, s);
+    rc = bbx_bsel_finish(ctx, b, d_data, nullptr, d.ny, d.nx, s); if (rc) return rc;
+    hipLaunchKernelGGL(k_chan_median, dim3(1), dim3(64), 0, s, b.seg, d_chan_median);
     hipLaunchKernelGGL(k_edge_fill, dim3(2048), dim3(256), 0, s, d_data, d_mask, d, d_chan_median);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
