@@ -44,12 +44,14 @@ SIGNATURES = {
     'bbx_last_hip_error': (C.c_char_p, [_vp]),
     'bbx_version': (_i, []),
     'bbx_sync': (_i, [_vp, _vp]),
+    'bbx_profile_enable': (_i, [_vp, _i]),
+    'bbx_profile_read': (_i, [_vp, _pd, C.POINTER(C.c_int32), _i]),
     'bbx_overscan_stats': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp]),
     'bbx_vos_std': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _pf, _vp, _vp]),
     'bbx_satcol_counts': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _pf, _i, _i, _vp, _vp]),
     'bbx_calibrate': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp]),
     'bbx_mask_finish': (_i, [_vp, _pg, _vp, _vp, _vp]),
-    'bbx_lacosmic': (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _f, _i, _f, _vp, _vp]),
+    'bbx_lacosmic': (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
     'bbx_xtalk': (_i, [_vp, _pg, _vp, _vp, _pd, _vp]),
     'bbx_mask_counts': (_i, [_vp, C.c_int64, _vp, _vp, _vp]),
     'bbx_edge_fill': (_i, [_vp, _pg, _vp, _vp, _vp, _vp]),

@@ -150,6 +150,7 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
                (((uintptr_t)d_data) % 16 == 0) && (((uintptr_t)d_mask) % 4 == 0) &&
                (!d_flat || ((uintptr_t)d_flat) % 16 == 0) && (!d_bias || ((uintptr_t)d_bias) % 16 == 0) &&
                (!d_bpm || ((uintptr_t)d_bpm) % 4 == 0);
+    bbx_prof_start(ctx, BBX_PROF_CALIBRATE, s);
     if (vec) {
         dim3 grid((a.d.nx / 4 + 255) / 256, a.d.ny / CAL_ROWS);
         if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL(k_calibrate_v4<BBX_RAW_U16>, grid, dim3(256), 0, s, a);
@@ -160,6 +161,7 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
         if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL(k_calibrate_s<BBX_RAW_U16>, dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_calibrate_s<BBX_RAW_F32>, dim3(grid), dim3(256), 0, s, a);
     }
+    bbx_prof_stop(ctx, s);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

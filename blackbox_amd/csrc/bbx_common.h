@@ -51,7 +51,14 @@ struct bbx_ctx {
     // --- scratch, (re)allocated on demand by bbx_ws()
     void*  d_ws[16];
     size_t ws_bytes[16];
+    // --- optional per-kernel timing (bbx_profile_enable): hipEvent pairs on the launch stream
+    int prof_on, prof_n;
+    hipEvent_t* prof_ev;       // [2 * BBX_PROF_MAX]
+    int* prof_slot;            // [BBX_PROF_MAX]
 };
+#define BBX_PROF_MAX 8192
+void bbx_prof_start(bbx_ctx* ctx, int slot, hipStream_t s);
+void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s);
 
 enum {
     CNT_SAT = 0,        // saturated pixels queued by calibrate

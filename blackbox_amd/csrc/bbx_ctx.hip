@@ -27,9 +27,47 @@ void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc) {
     return ctx->d_ws[slot];
 }
 
+void bbx_prof_start(bbx_ctx* ctx, int slot, hipStream_t s) {
+    if (!ctx->prof_on || ctx->prof_n >= BBX_PROF_MAX) return;
+    ctx->prof_slot[ctx->prof_n] = slot;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], s);
+}
+void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s) {
+    if (!ctx->prof_on || ctx->prof_n >= BBX_PROF_MAX) return;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], s);
+    ctx->prof_n++;
+}
+
 extern "C" {
 
 int bbx_version(void) { return 100; }
+
+int bbx_profile_enable(bbx_ctx* ctx, int on) {
+    if (!ctx) return BBX_ERR_ARG;
+    if (on && !ctx->prof_ev) {
+        ctx->prof_ev = (hipEvent_t*)calloc(2 * BBX_PROF_MAX, sizeof(hipEvent_t));
+        ctx->prof_slot = (int*)calloc(BBX_PROF_MAX, sizeof(int));
+        if (!ctx->prof_ev || !ctx->prof_slot) return BBX_ERR_NOMEM;
+        for (int i = 0; i < 2 * BBX_PROF_MAX; i++) BBX_HIP(hipEventCreate(&ctx->prof_ev[i]));
+    }
+    ctx->prof_on = on ? 1 : 0;
+    ctx->prof_n = 0;
+    return BBX_OK;
+}
+
+int bbx_profile_read(bbx_ctx* ctx, double* ms_total, int32_t* calls, int nslots) {
+    if (!ctx || !ms_total || !calls || nslots <= 0) return BBX_ERR_ARG;
+    for (int i = 0; i < nslots; i++) { ms_total[i] = 0.0; calls[i] = 0; }
+    for (int k = 0; k < ctx->prof_n; k++) {
+        float ms = 0.f;
+        BBX_HIP(hipEventSynchronize(ctx->prof_ev[2 * k + 1]));
+        BBX_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]));
+        const int sl = ctx->prof_slot[k];
+        if (sl >= 0 && sl < nslots) { ms_total[sl] += ms; calls[sl]++; }
+    }
+    ctx->prof_n = 0;
+    return BBX_OK;
+}
 
 const char* bbx_strerror(int code) {
     switch (code) {
@@ -73,6 +111,7 @@ void bbx_ctx_destroy(bbx_ctx* ctx) {
     if (ctx->d_satlist) (void)hipFree(ctx->d_satlist);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->prof_ev) { for (int i = 0; i < 2 * BBX_PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]); free(ctx->prof_ev); free(ctx->prof_slot); }
     free(ctx);
 }
 

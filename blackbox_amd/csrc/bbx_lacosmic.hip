@@ -33,7 +33,8 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
 
 struct lac_par {
     int ny, nx;
-    float sigclip, sigcliplow, objlim, rn2, T;
+    float sigclip, sigcliplow, objlim;
+    const float* rnp;            // device: {float32(rn*rn), prune threshold T}
 };
 
 // L+ of pixel (j,i): 2x2 replicate -> Laplacian -> clip -> 2x2 mean, closed form with
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     bsel_lds& L = *reinterpret_cast<bsel_lds*>(dyn_lds);
     const int lane = threadIdx.x & 63;
+    const float T = p.rnp[1];
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const bool act = x0 < p.nx;                                 // nx % 4 == 0 on this path
     const int j0 = blockIdx.y * CAND_ROWS;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
                 const int i = x0 + q;
                 if (act && rowok && i >= 2 && i < p.nx - 2) {
                     const float lp = lplus_px(c4[q], u4[q], d4[q], l4[q], r4[q], true, true, true, true);
-                    if (lp > p.T) {
+                    if (lp > T) {
                         const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
                         if (kk < cap) cand[kk] = (uint32_t)(row + i); else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
                     }
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void k_lac_cand_s(const float* __restrict__ a,
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     bsel_lds& L = *reinterpret_cast<bsel_lds*>(dyn_lds);
     const size_t npix = (size_t)p.ny * p.nx;
+    const float T = p.rnp[1];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t nend = ((npix + stride - 1) / stride) * stride;      // every thread runs the same trip count
     float lo = 0.f, hi = 0.f;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void k_lac_cand_s(const float* __restrict__ a,
         // the outer 2-pixel frame has sp == 0 (median filter copies its border)
         if (in && !(j < 2 || i < 2 || j >= p.ny - 2 || i >= p.nx - 2)) {
             const float lp = lplus_at(a, j, i, p.ny, p.nx);
-            if (lp > p.T) {
+            if (lp > T) {
                 const unsigned k = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
                 if (k < cap) cand[k] = (uint32_t)o; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
             }
@@ -199,7 +202,7 @@ __device__ __forceinline__ float s_at(const float* __restrict__ a, int j, int i,
         m5 = v[12];
     }
     m5 = fmaxf(m5, 0.00001f);
-    const float noise = sqrtf(m5 + p.rn2);
+    const float noise = sqrtf(m5 + p.rnp[0]);
     *noise_out = noise;
     return lplus_at(a, j, i, p.ny, p.nx) / (2.0f * noise);
 }
@@ -362,8 +365,33 @@ __global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
     }
 }
 
+// readnoise -> {rn2, T} on the device.  With d_rdn16 the read noise is the float32 image of
+// np.nanmean of the 16 channel sigmas (header RDNOISE, blackbox.py:6867) evaluated in numpy's
+// pairwise order for 16 elements, so no host round trip is needed between os_corr and here.
+__global__ void k_lac_rn(float readnoise, const double* __restrict__ rdn16, float sigclip, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float rn = readnoise;
+    if (rdn16) {
+        double r[8]; int n = 0;
+        for (int i = 0; i < 8; i++) {
+            const double a = rdn16[i], b = rdn16[i + 8];
+            r[i] = ((a == a) ? a : 0.0) + ((b == b) ? b : 0.0);
+            n += (a == a) + (b == b);
+        }
+        const double sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        rn = (float)(sum / (double)n);
+    }
+    const float rn2 = rn * rn;
+    out[0] = rn2;
+    // prune threshold: sp <= L+/(2*sqrtf(rn2)); the (1 - 1e-5) factor absorbs the float32
+    // roundings of the division and of 2*noise (see DESIGN.md, LA-Cosmic)
+    out[1] = 2.0f * sigclip * sqrtf(rn2) * (1.0f - 1e-5f);
+    out[2] = rn;
+}
+
 extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t* d_mask, float sigclip,
-                            float sigfrac, float objlim, int niter, float readnoise, int32_t* d_stats, void* stream) {
+                            float sigfrac, float objlim, int niter, float readnoise, const double* d_rdn16,
+                            int32_t* d_stats, void* stream) {
     if (!ctx || !d_data || !d_mask || !d_stats || ny < 8 || nx < 8 || niter < 0 || niter > 6) return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)ny * nx;
@@ -371,10 +399,9 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     int rc;
     lac_par p;
     p.ny = ny; p.nx = nx; p.sigclip = sigclip; p.sigcliplow = sigfrac * sigclip; p.objlim = objlim;
-    p.rn2 = readnoise * readnoise;
-    // prune threshold: sp <= L+/(2*sqrtf(rn2)); the (1 - 1e-5) factor absorbs the float32
-    // roundings of the division and of 2*noise (see DESIGN.md, LA-Cosmic)
-    p.T = 2.0f * sigclip * sqrtf(p.rn2) * (1.0f - 1e-5f);
+    float* rnp = (float*)bbx_ws(ctx, WS_MISC, 64, &rc); if (rc) return rc;
+    p.rnp = rnp;
+    hipLaunchKernelGGL(k_lac_rn, dim3(1), dim3(64), 0, s, readnoise, d_rdn16, sigclip, rnp);
     const size_t cap = npix / 4 + 4096;
     uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, cap * 4, &rc); if (rc) return rc;
     uint32_t* stage2 = (uint32_t*)bbx_ws(ctx, WS_STAGE2, cap * 4, &rc); if (rc) return rc;
@@ -393,21 +420,26 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     const dim3 gvec((nx / 4 + 255) / 256, (ny + CAND_ROWS - 1) / CAND_ROWS);
     for (int it = 0; it < niter; it++) {
         BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
+        bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
         if (it == 0) {
             if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            bbx_prof_stop(ctx, s);
             rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s);
             if (rc) return rc;
         } else {
             if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            bbx_prof_stop(ctx, s);
         }
+        bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_grow2, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
         hipLaunchKernelGGL(k_lac_iter_end, dim3(1), dim3(64), 0, s, cnt, d_stats, it);
+        bbx_prof_stop(ctx, s);
     }
     BBX_LAUNCH_CHECK();
     // NCOSMICS: 8-connected objects of the CR pixels (blackbox.py:4354-4356)

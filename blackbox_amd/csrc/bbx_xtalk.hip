@@ -53,7 +53,9 @@ extern "C" int bbx_xtalk(bbx_ctx* ctx, const bbx_geom* g, float* d_data, const u
     const size_t total = (size_t)d.ysz * d.xsz;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 256u * 16u) grid = 256u * 16u;
+    bbx_prof_start(ctx, BBX_PROF_XTALK, (hipStream_t)stream);
     hipLaunchKernelGGL(k_xtalk, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    bbx_prof_stop(ctx, (hipStream_t)stream);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -159,8 +159,24 @@ def _polyfit_quiet(x, y, deg):
         return np.polyfit(x, y, deg)
 
 
+def _running_median3(y):
+    """[np.median(y[max(k-1,3):min(k+2,n)]) for k in range(3, n)] as float32, vectorised
+    (blackbox.py:6703-6708): interior points take the median of 3 neighbours, the two
+    end points the mean of 2 (np.median of an even count)."""
+    n = y.size
+    if n < 6:
+        return np.asarray([np.median(y[max(k - 1, 3):min(k + 2, n)]) for k in range(3, n)], np.float32)
+    a, b, c = y[3:n - 2], y[4:n - 1], y[5:n]
+    mid = np.maximum(np.minimum(a, b), np.minimum(np.maximum(a, b), c))
+    out = np.empty(n - 3, np.float32)
+    out[0] = (y[3] + y[4]) / np.float32(2)
+    out[1:-1] = mid
+    out[-1] = (y[n - 2] + y[n - 1]) / np.float32(2)
+    return out
+
+
 def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
-            accum='f32seq'):
+            accum='f32seq', lazy_spline=True):
     """blackbox.py:6660-6814 -> oscan float64[ncols]"""
     ncols = mean_hos.size
     mask_valid = n > 1
@@ -179,17 +195,27 @@ def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
     sel = mask_valid[idx_fit]
     y2fit = mean_hos[idx_fit][sel].copy()
     nfit = y2fit.size
-    # 3-point running median of the points to fit (6703-6708), from the original values
-    med = [np.median(y2fit[max(k - 1, 3):min(k + 2, nfit)]) for k in range(3, nfit)]
-    y2fit[3:] = np.asarray(med, np.float32)
-    xs, ws = xcol[idx_fit][sel], weights[idx_fit][sel]
-    with warnings.catch_warnings():
-        warnings.simplefilter('error')
-        try:
-            splfit = interpolate.UnivariateSpline(xs, y2fit, w=ws, k=2, s=npoints)
-        except UserWarning:
-            warnings.simplefilter('ignore')
-            splfit = interpolate.UnivariateSpline(xs, y2fit, w=ws, k=3, s=1.5 * npoints)
+    # columns below IDX_SWITCH take the raw column mean wherever it is usable; the spline
+    # value only survives in the others.  The reference always builds the spline; here it is
+    # built only when such a column exists (same output, the spline fit is the costly part).
+    mask_usemean = mask_valid.copy()
+    if mask_sat_row is not None:
+        mask_usemean &= ~mask_sat_row
+    mask_usemean[IDX_SWITCH:] = False
+    keeps_spline = ~mask_usemean[:IDX_SWITCH]
+    keeps_spline[0:3] &= ~mask_valid[0:3]
+    splfit = None
+    if lazy_spline is False or keeps_spline.any():
+        # 3-point running median of the points to fit (6703-6708), from the original values
+        y2fit[3:] = _running_median3(y2fit)
+        xs, ws = xcol[idx_fit][sel], weights[idx_fit][sel]
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            try:
+                splfit = interpolate.UnivariateSpline(xs, y2fit, w=ws, k=2, s=npoints)
+            except UserWarning:
+                warnings.simplefilter('ignore')
+                splfit = interpolate.UnivariateSpline(xs, y2fit, w=ws, k=3, s=1.5 * npoints)
     mask_valid_poly = mask_valid.copy()
     mask_valid_poly[0:IDX_SWITCH - OVERLAP] = False
     mhp = mean_hos[mask_valid_poly]
@@ -226,11 +252,55 @@ def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
         fit2 = fit_iter(m2, 5)
         oscan = fit1
         oscan[idx_split:] = fit2[idx_split:]
-    oscan[0:IDX_SWITCH] = splfit(xcol[0:IDX_SWITCH])
+    if splfit is not None:
+        oscan[0:IDX_SWITCH] = splfit(xcol[0:IDX_SWITCH])
     oscan[0:3][mask_valid[0:3]] = mean_hos[0:3][mask_valid[0:3]]
-    mask_usemean = mask_valid.copy()
-    if mask_sat_row is not None:
-        mask_usemean &= ~mask_sat_row
-    mask_usemean[IDX_SWITCH:] = False
     oscan[mask_usemean] = mean_hos[mask_usemean]
     return oscan
+
+
+# --------------------------------------------------------------------------------
+# per-channel work units (what the host worker pool executes; pure numpy/scipy,
+# picklable arguments, no GPU)
+# --------------------------------------------------------------------------------
+def channel_phase1(c, mean_vos_col, hos, ysz, xsz, poldeg=3, accum='f32seq'):
+    """vertical-overscan fit and horizontal-overscan level of channel [c].
+    [hos]: gain-corrected overscan rows (hos_rows, dx) float32 as copied from the device.
+    -> dict(fit, coeffs, ok, level, dlevel, strip)"""
+    dy = mean_vos_col.size
+    hos_rows = hos.shape[0]
+    fit, coeffs, ok, level = vos_polyfit(mean_vos_col, ysz, c, poldeg)
+    # overscan rows after the vertical fit: float32 - float64 -> float32 (blackbox.py:6553)
+    rl0 = (dy - hos_rows) if c < 8 else 0
+    strip = (hos.astype(np.float64) - fit[rl0:rl0 + hos_rows, None]).astype(np.float32)
+    dlevel, _, _ = clipped_stats_flat(strip[:, xsz - 300:xsz], accum=accum)
+    strip -= np.float32(dlevel)
+    return dict(fit=fit, coeffs=coeffs, ok=ok, level=level, dlevel=float(dlevel), strip=strip)
+
+
+def channel_phase2(c, strip, xsz, tel, data_limit=2000, mask_sat_row=None, accum='f32seq'):
+    """horizontal-overscan vector of channel [c] -> oscan float64[xsz]"""
+    data_hos = strip[:, :xsz]
+    if tel == 'ML1':
+        mask_hos = hos_mask_ml1(data_hos, data_limit)
+        mask_sat_row = None
+    else:
+        mask_hos = np.zeros(data_hos.shape, dtype=bool) | mask_sat_row[None, :]
+    n, mean_hos, std_hos = hos_column_stats(data_hos, mask_hos, accum=accum)
+    return hos_fit(n, mean_hos, std_hos, mask_sat_row, bg2_chan9=(tel == 'BG2' and c == 8), accum=accum)
+
+
+def channel_solve(args):
+    """both phases for telescopes without the saturated-column step (ML1)"""
+    c, mean_vos_col, hos, ysz, xsz, poldeg, tel, data_limit, accum = args
+    r = channel_phase1(c, mean_vos_col, hos, ysz, xsz, poldeg, accum)
+    r['oscan'] = channel_phase2(c, r.pop('strip'), xsz, tel, data_limit, None, accum)
+    return r
+
+
+def _phase1_star(args):
+    return channel_phase1(*args)
+
+
+def _phase2_star(args):
+    return channel_phase2(*args)

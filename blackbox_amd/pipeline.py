@@ -1,0 +1,331 @@
+"""Throughput path: several frames in flight on one GPU.
+
+The reference farms one frame per worker process (blackbox.py:363-379); on one
+MI355X the device work of a frame is ~2-3 ms while the host-side overscan fits
+(numpy/scipy, kept bit-compatible with the reference) cost ~15-40 ms of one core.
+So a frame goes through three stages and up to [depth] frames overlap:
+
+  A  (GPU, stream A)   overscan strip statistics            -> small D2H (pinned)
+  B  (host pool)       16 per-channel fit tasks in worker processes (no GPU there)
+  C  (GPU, stream C)   read-noise statistics, fused calibration, mask_init tail,
+                       LA-Cosmic, [crosstalk, mask counts, edge fill]
+
+Stage C of successive frames is serialised on one stream (the bbx_ctx workspace is
+per context); stage A uses no workspace and overlaps with it.  No collective, no
+inter-GPU traffic: one FramePipeline per GPU / process.
+"""
+import ctypes as C
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, overscan, settings
+from . import reduce as R
+from ._lib import lib, check
+
+get_par = settings.get_par
+
+
+def default_workers():
+    n = os.cpu_count() or 4
+    world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+    return max(2, min(int(os.environ.get('BBX_HOST_WORKERS', 12)), max(2, n // max(1, world) - 1)))
+
+
+class HostPool:
+    """spawned numpy/scipy worker processes for the per-channel overscan fits; they
+    never touch the GPU (safe to create after HIP is initialised: spawn, not fork)"""
+
+    def __init__(self, nworkers=None):
+        self.n = nworkers or default_workers()
+        # one BLAS/OpenMP thread per worker: the fits are tiny, thread pools only fight each other
+        saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+        for k in saved:
+            os.environ[k] = '1'
+        try:
+            self.pool = mp.get_context('spawn').Pool(self.n)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        # warm up: import numpy/scipy in every worker
+        self.pool.map(_noop, range(self.n * 2))
+
+    def submit(self, fn, tasks):
+        return self.pool.map_async(fn, tasks, chunksize=1)
+
+    def close(self):
+        self.pool.terminate()
+        self.pool.join()
+
+
+def _noop(i):
+    return i
+
+
+class _Frame:
+    __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
+                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot')
+
+
+class FramePipeline:
+    def __init__(self, ctx, tel, geom, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None, exptime=60.0,
+                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False):
+        self.ctx, self.tel, self.geom = ctx, tel, geom
+        self.mflat, self.bpm = mflat, bpm
+        self.mbias = mbias if (mbias is not None and get_par(settings.subtract_mbias, tel)) else None
+        self.xtalk = xtalk_coeffs
+        self.exptime = exptime
+        self.pool = pool or HostPool()
+        self.own_pool = pool is None
+        self.depth = depth
+        self.do_cosmics, self.do_finish, self.accum = do_cosmics, do_finish, accum
+        self.keep_outputs = keep_outputs
+        self.sA = torch.cuda.Stream(device=ctx.device)
+        self.sC = torch.cuda.Stream(device=ctx.device)
+        self.gain = get_par(settings.gain, tel)
+        self.g32 = _lib.f32x16(self.gain)
+        g = geom
+        self.dy, self.dx = g.ny_raw // 2, g.nx_raw // 8
+        self.ysz, self.xsz = g.ysize_chan, g.xsize_chan
+        self.hos_rows = self.dy - self.ysz - 10
+        self.two_phase = tel != 'ML1'
+        self.t_stats = [0.0, 0.0, 0.0, 0]      # wall: start->stats on host, fits, device stage; frames
+        # staging buffers, one set per frame in flight (pinned host + device), allocated once:
+        # pin_memory()/hipHostMalloc costs ~10 ms per call and must stay out of the frame loop
+        dev = ctx.device
+        self.slots = []
+        for _ in range(depth):
+            self.slots.append(dict(
+                d_mean=torch.empty(16 * self.dy, dtype=torch.float64, device=dev),
+                d_hos=torch.empty((16, self.hos_rows, self.dx), dtype=torch.float32, device=dev),
+                d_ninf=torch.zeros(1, dtype=torch.int64, device=dev),
+                h_mean=torch.empty(16 * self.dy, dtype=torch.float64, pin_memory=True),
+                h_hos=torch.empty((16, self.hos_rows, self.dx), dtype=torch.float32, pin_memory=True),
+                h_ninf=torch.empty(1, dtype=torch.int64, pin_memory=True),
+                h_vfit=torch.empty(16 * self.dy, dtype=torch.float64, pin_memory=True),
+                h_oscan=torch.empty(16 * self.xsz, dtype=torch.float64, pin_memory=True),
+                d_vfit=torch.empty(16 * self.dy, dtype=torch.float64, device=dev),
+                d_oscan=torch.empty(16 * self.xsz, dtype=torch.float64, device=dev),
+                d_std=torch.empty(16, dtype=torch.float64, device=dev),
+                d_cnt6=torch.zeros(6, dtype=torch.int64, device=dev),
+                h_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, pin_memory=True),
+                d_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev),
+                h_out=(torch.empty(16, dtype=torch.float64, pin_memory=True),
+                       torch.empty(1, dtype=torch.int32, pin_memory=True),
+                       torch.zeros(8, dtype=torch.int32, pin_memory=True),
+                       torch.zeros(6, dtype=torch.int64, pin_memory=True))))
+        self.free_slots = list(range(depth))
+
+    def close(self):
+        if self.own_pool:
+            self.pool.close()
+
+    # ---- stage A ------------------------------------------------------------------
+    def _start(self, idx, raw, header):
+        ctx, dev = self.ctx, self.ctx.device
+        f = _Frame()
+        f.idx, f.raw, f.header, f.hm, f.t0 = idx, raw, header, {}, time.perf_counter()
+        R.gain_corr(header, self.tel)
+        f.slot = self.free_slots.pop()
+        sl = self.slots[f.slot]
+        with torch.cuda.stream(self.sA):
+            d_mean, d_hos, d_ninf = sl['d_mean'], sl['d_hos'], sl['d_ninf']
+            check(lib.bbx_overscan_stats(ctx.h, C.byref(self.geom), R._ptr(raw), R.raw_type_of(raw), self.g32,
+                                         R._ptr(d_mean), R._ptr(d_hos), R._ptr(d_ninf), ctx.stream()),
+                  'bbx_overscan_stats', ctx.h)
+            f.h_mean, f.h_hos, f.h_ninf = sl['h_mean'], sl['h_hos'], sl['h_ninf']
+            f.h_mean.copy_(d_mean, non_blocking=True)
+            f.h_hos.copy_(d_hos, non_blocking=True)
+            f.h_ninf.copy_(d_ninf, non_blocking=True)
+            f.evA = torch.cuda.Event()
+            f.evA.record()
+        f.state = 'A'
+        return f
+
+    # ---- stage B ------------------------------------------------------------------
+    def _submit_fits(self, f):
+        mv = f.h_mean.numpy().reshape(16, self.dy)
+        hos = f.h_hos.numpy()
+        if not self.two_phase:
+            tasks = [(c, mv[c], hos[c], self.ysz, self.xsz, settings.voscan_poldeg, self.tel, 2000, self.accum)
+                     for c in range(16)]
+            f.res = self.pool.submit(overscan.channel_solve, tasks)
+        else:
+            tasks = [(c, mv[c], hos[c], self.ysz, self.xsz, settings.voscan_poldeg, self.accum) for c in range(16)]
+            f.res = self.pool.submit(overscan._phase1_star, tasks)
+        f.d_keep = None
+        f.state = 'B'
+
+    def _fill_header_vos(self, f, results):
+        h = f.header
+        h['N-INFNAN'] = (int(f.h_ninf.item()), 'number of pixels with infinite/nan values')
+        for c, r in enumerate(results):
+            for k, v in enumerate(r['coeffs']):
+                h['BIAS{}A{}'.format(c + 1, k)] = (float(v) if np.isfinite(v) else 'None',
+                                                    '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
+            h['VFITOK{}'.format(c + 1)] = (bool(r['ok']), 'channel {} vert. overscan polyfit finite?'.format(c + 1))
+        mean_vos = np.array([r['level'] for r in results])
+        for c in range(16):
+            h['BIASM{}'.format(c + 1)] = (float(mean_vos[c]), '[e-] channel {} mean vertical overscan'.format(c + 1))
+        h['BIASMEAN'] = (float(np.nanmean(mean_vos)), '[e-] average all channel means vert. overscan')
+
+    def _satcol(self, f, results):
+        """BlackGEM: per-column saturation counts need the vertical fit (two-phase)"""
+        ctx, dev = self.ctx, self.ctx.device
+        f.p1 = results
+        vfit = np.stack([r['fit'] for r in results])
+        lim = settings.os_ypix_lim[self.tel]
+        satl = np.array(get_par(settings.satlevel, self.tel)) * np.array(self.gain)
+        with torch.cuda.stream(self.sC):
+            sl = self.slots[f.slot]
+            sl['h_vfit'].numpy()[:] = vfit.reshape(-1)
+            d_vfit = sl['d_vfit']
+            d_vfit.copy_(sl['h_vfit'], non_blocking=True)
+            d_cnt = sl['d_cnt']
+            check(lib.bbx_satcol_counts(ctx.h, C.byref(self.geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
+                                        R._ptr(d_vfit), _lib.f32x16(np.float32(0.9 * satl)), int(lim[0]), int(lim[1]),
+                                        R._ptr(d_cnt), ctx.stream()), 'bbx_satcol_counts', ctx.h)
+            f.h_cnt = sl['h_cnt']
+            f.h_cnt.copy_(d_cnt, non_blocking=True)
+            f.evS = torch.cuda.Event()
+            f.evS.record()
+            f.d_keep = (d_vfit, d_cnt)
+        f.state = 'S'
+
+    def _submit_phase2(self, f):
+        cnt = f.h_cnt.numpy()
+        msr = (cnt[0] >= 3) | (cnt[1] >= 10)
+        tasks = [(c, f.p1[c]['strip'], self.xsz, self.tel, 2000, msr[c], self.accum) for c in range(16)]
+        f.res2 = self.pool.submit(overscan._phase2_star, tasks)
+        f.state = 'B2'
+
+    # ---- stage C ------------------------------------------------------------------
+    def _device_stage(self, f, results):
+        ctx, dev, geom, tel = self.ctx, self.ctx.device, self.geom, self.tel
+        self._fill_header_vos(f, results)
+        vfit = np.stack([r['fit'] for r in results])
+        oscan = np.stack([r['oscan'] for r in results])
+        dlevel = np.float32([r['dlevel'] for r in results])
+        h, hm = f.header, f.hm
+        with torch.cuda.stream(self.sC):
+            self.sC.wait_event(f.evA)
+            sol = R.OverscanSolution()
+            sol.vfit, sol.oscan = vfit, oscan
+            sl = self.slots[f.slot]
+            sl['h_vfit'].numpy()[:] = vfit.reshape(-1)
+            sl['h_oscan'].numpy()[:] = oscan.reshape(-1)
+            sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
+            sol.d_vfit.copy_(sl['h_vfit'], non_blocking=True)
+            sol.d_oscan.copy_(sl['h_oscan'], non_blocking=True)
+            d_std = sl['d_std']
+            check(lib.bbx_vos_std(ctx.h, C.byref(geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
+                                  R._ptr(sol.d_vfit), _lib.f32x16(dlevel), R._ptr(d_std), ctx.stream()),
+                  'bbx_vos_std', ctx.h)
+            data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat,
+                                     bpm=self.bpm)
+            d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom)
+            d_stats = None
+            if self.do_cosmics:
+                # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
+                d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std)
+            if self.do_finish:
+                if self.xtalk is not None:
+                    R.xtalk_corr(ctx, data, self.xtalk, mask, geom)
+                d_cnt = sl['d_cnt6']
+                check(lib.bbx_mask_counts(ctx.h, mask.numel(), R._ptr(mask), R._ptr(d_cnt), ctx.stream()),
+                      'bbx_mask_counts', ctx.h)
+                R.edge_fill(ctx, data, mask, geom)
+            else:
+                d_cnt = sl['d_cnt6']
+            # scalar results: one small pinned D2H
+            f.h_out = sl['h_out']
+            f.h_out[0].copy_(d_std, non_blocking=True)
+            f.h_out[1].copy_(d_nobj, non_blocking=True)
+            if d_stats is not None:
+                f.h_out[2].copy_(d_stats, non_blocking=True)
+            f.h_out[3].copy_(d_cnt, non_blocking=True)
+            f.evC = torch.cuda.Event()
+            f.evC.record()
+            f.d_keep = (sol, d_std, d_nobj, d_stats, d_cnt)
+            f.data, f.mask = (data, mask) if self.keep_outputs else (None, None)
+        f.state = 'C'
+
+    def _finalize(self, f):
+        h, hm = f.header, f.hm
+        std = f.h_out[0].numpy()
+        for c in range(16):
+            h['RDN{}'.format(c + 1)] = (float(std[c]), '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1))
+        h['RDNOISE'] = (float(np.nanmean(std)), '[e-] average all channel sigmas vert. overscan')
+        nobj = int(f.h_out[1].item())
+        h['NOBJ-SAT'] = hm['NOBJ-SAT'] = (nobj, 'number of saturated objects')
+        if self.do_cosmics:
+            st = f.h_out[2].numpy()
+            h['NCOSMICS'] = hm['NCOSMICS'] = (st[6] / float(self.exptime), '[/s] number of cosmic rays identified')
+            h['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
+        f.d_keep = None
+        f.state = 'done'
+
+    # ---- driver --------------------------------------------------------------------
+    def run(self, frames, on_done=None):
+        """frames: iterable of (raw device tensor, header dict).  Processes all of them with
+        up to [depth] in flight; calls on_done(idx, frame) in completion order."""
+        it = iter(enumerate(frames))
+        live, ndone, exhausted = [], 0, False
+        while True:
+            progressed = False
+            while not exhausted and len(live) < self.depth:
+                try:
+                    idx, (raw, header) = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                live.append(self._start(idx, raw, header))
+                progressed = True
+            for f in live:
+                if f.state == 'A' and f.evA.query():
+                    f.tA = time.perf_counter()
+                    self._submit_fits(f)
+                    progressed = True
+                elif f.state == 'B' and f.res.ready():
+                    f.tB = time.perf_counter()
+                    results = f.res.get()
+                    if self.two_phase:
+                        self._satcol(f, results)
+                    else:
+                        self._device_stage(f, results)
+                    progressed = True
+                elif f.state == 'S' and f.evS.query():
+                    self._submit_phase2(f)
+                    progressed = True
+                elif f.state == 'B2' and f.res2.ready():
+                    osc = f.res2.get()
+                    for r, o in zip(f.p1, osc):
+                        r['oscan'] = o
+                    self._device_stage(f, f.p1)
+                    progressed = True
+                elif f.state == 'C' and f.evC.query():
+                    f.tC = time.perf_counter()
+                    self.t_stats[0] += f.tA - f.t0
+                    self.t_stats[1] += f.tB - f.tA
+                    self.t_stats[2] += f.tC - f.tB
+                    self.t_stats[3] += 1
+                    self._finalize(f)
+                    progressed = True
+            for f in [x for x in live if x.state == 'done']:
+                live.remove(f)
+                self.free_slots.append(f.slot)
+                ndone += 1
+                if on_done:
+                    on_done(f.idx, f)
+            if exhausted and not live:
+                break
+            if not progressed:
+                time.sleep(0.0002)
+        check(lib.bbx_sync(self.ctx.h, C.c_void_p(self.sC.cuda_stream)), 'bbx_sync', self.ctx.h)
+        return ndone

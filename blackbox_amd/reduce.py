@@ -245,17 +245,21 @@ def mask_init_finish(ctx, mask, header, header_mask, geom):
     return d_n
 
 
-def cosmics_corr(ctx, data, header, data_mask, header_mask, tel):
+def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None):
     """blackbox.py:4259-4370.  In place; returns the device stats tensor
-    [per-iteration counts x6, n objects, n pixels]."""
+    [per-iteration counts x6, n objects, n pixels].  readnoise = header RDNOISE, or -- when
+    the 16 channel sigmas are still on the device -- their nanmean taken there."""
     ny, nx = data.shape
-    hv = header['RDNOISE']
-    readnoise = hv[0] if isinstance(hv, tuple) else hv
+    readnoise = 0.0
+    if d_rdn16 is None:
+        hv = header['RDNOISE']
+        readnoise = hv[0] if isinstance(hv, tuple) else hv
     d_stats = torch.zeros(8, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(data_mask),
                            float(get_par(settings.sigclip, tel)), float(get_par(settings.sigfrac, tel)),
                            float(get_par(settings.objlim, tel)), int(get_par(settings.niter, tel)),
-                           float(np.float32(readnoise)), _ptr(d_stats), ctx.stream()), 'bbx_lacosmic', ctx.h)
+                           float(np.float32(readnoise)), _ptr(d_rdn16), _ptr(d_stats), ctx.stream()),
+          'bbx_lacosmic', ctx.h)
     return d_stats
 
 
@@ -264,7 +268,7 @@ def detect_cosmics(ctx, data, mask, sigclip, sigfrac, objlim, niter, readnoise):
     ny, nx = data.shape
     d_stats = torch.zeros(8, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(mask), float(sigclip), float(sigfrac), float(objlim),
-                           int(niter), float(np.float32(readnoise)), _ptr(d_stats), ctx.stream()),
+                           int(niter), float(np.float32(readnoise)), _ptr(None), _ptr(d_stats), ctx.stream()),
           'bbx_lacosmic', ctx.h)
     return d_stats
 

@@ -73,6 +73,20 @@ int  bbx_version(void);
  * (list overflow, non-convergence).  Call before trusting host copies. */
 int  bbx_sync(bbx_ctx *ctx, void *stream);
 
+/* per-kernel timing: when enabled, the library brackets its main kernels with hipEvents
+ * on the launch stream (the reference logs wall time per stage with log_timing_memory,
+ * e.g. blackbox.py:4366-4367).  Slots: */
+#define BBX_PROF_CALIBRATE 0   /* k_calibrate            (1 launch / frame)  */
+#define BBX_PROF_LAC_DENSE 1   /* k_lac_cand             (niter launches)    */
+#define BBX_PROF_LAC_SPARSE 2  /* seed+grow+clean        (niter groups)      */
+#define BBX_PROF_XTALK 3       /* k_xtalk                                     */
+#define BBX_PROF_VOS_STD 4     /* read-noise passes      (1 group / frame)   */
+#define BBX_PROF_MASK_FINISH 5 /* mask_init tail + fill  (1 group / frame)   */
+#define BBX_PROF_NSLOTS 8
+int  bbx_profile_enable(bbx_ctx *ctx, int on);
+/* synchronises on the recorded events; ms_total/calls have nslots entries; resets */
+int  bbx_profile_read(bbx_ctx *ctx, double *ms_total, int32_t *calls, int nslots);
+
 /* ---- a2 + a4 + a5(i): overscan statistics ---------------------------------------
  * replaces: inf/nan scrub blackbox.py:1461-1468, gain_corr 7442-7465 (applied on
  * the fly, raw is not modified), and the strip reductions of os_corr 6480-6490.
@@ -137,11 +151,14 @@ int bbx_mask_finish(bbx_ctx *ctx, const bbx_geom *g, uint8_t *d_mask,
  * replaces cosmics_corr 4259-4370 = astroscrappy.detect_cosmics(sepmed=False,
  * cleantype='medmask', gain=1, satlevel=inf) + mask update + NCOSMICS label count.
  * In place: d_data becomes the cleaned array, CR pixels get bit 2 in d_mask.
+ *  readnoise : RDNOISE in e-; if d_rdn16 != NULL it is instead taken on the device as
+ *  float32(nanmean(d_rdn16[0..15])) (the 16 RDN{c} of bbx_vos_std), sparing a host hop.
  *  d_stats [8] i32 : [0..niter-1] pixels flagged per iteration, [6] number of
  *  8-connected CR objects, [7] total CR pixels.                                  */
 int bbx_lacosmic(bbx_ctx *ctx, int ny, int nx, float *d_data, uint8_t *d_mask,
                  float sigclip, float sigfrac, float objlim, int niter,
-                 float readnoise, int32_t *d_stats, void *stream);
+                 float readnoise, const double *d_rdn16, int32_t *d_stats,
+                 void *stream);
 
 /* ---- a11: crosstalk -------------------------------------------------------------------
  * replaces xtalk_corr 7138-7258.  h_coeffs[source*16 + victim], float64.          */

@@ -31,7 +31,7 @@ def test_bad_arguments_are_rejected_without_gpu():
     assert _lib.lib.bbx_sync(None, None) == -1
     g = _lib.Geom(10600, 12000, 5280, 1320)
     assert _lib.lib.bbx_mask_finish(None, ctypes.byref(g), None, None, None) == -1
-    assert _lib.lib.bbx_lacosmic(None, 100, 100, None, None, 15.0, 0.01, 3.0, 3, 8.0, None, None) == -1
+    assert _lib.lib.bbx_lacosmic(None, 100, 100, None, None, 15.0, 0.01, 3.0, 3, 8.0, None, None, None) == -1
 
 
 def test_product_never_imports_oracle():
