@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
     const double os0 = a.oscan[c * d.xsz + x], os1 = a.oscan[c * d.xsz + x + 1],
                  os2 = a.oscan[c * d.xsz + x + 2], os3 = a.oscan[c * d.xsz + x + 3];
     const float g = a.gain.v[c], sat = a.sat.v[c];
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < CAL_ROWS; k++) {
         const int Y = Y0 + k;
         const int y = Y - iy * d.ysz;

@@ -71,45 +71,89 @@ __device__ __forceinline__ float lplus_at(const float* __restrict__ a, int j, in
 // sizeof(bsel_lds)).
 #define CAND_ROWS 32
 #define CAND_B 4
+#define CAND_Q 8        // per-thread staging slots for candidate indices (LDS)
+#define FEED_Q 16       // per-thread staging slots for in-bracket values (LDS)
+
+// exclusive prefix sum of one value per thread over a 256-thread block
+__device__ __forceinline__ unsigned block_excl_scan256(unsigned v, unsigned* wsum, unsigned* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const unsigned x = wsum[w]; if (w < wid) off += x; tot += x; }
+    *total = tot;
+    __syncthreads();
+    return off + incl - v;
+}
+
+// No atomic sits in the row loop: hits are staged in per-thread LDS slots (slot-major, no
+// bank conflicts) and compacted once per block with ONE global atomic per list; a thread
+// that overflows its slots appends directly (rare: dense star cores / degenerate brackets).
 template <bool FEED>
 __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a, const uint8_t* __restrict__ mask,
                                                      lac_par p, uint32_t* __restrict__ cand, int32_t* counters,
                                                      uint32_t cap, int32_t* err, bsel_dev b) {
     extern __shared__ __align__(16) unsigned char dyn_lds[];
-    bsel_lds& L = *reinterpret_cast<bsel_lds*>(dyn_lds);
-    const int lane = threadIdx.x & 63;
+    uint32_t* lcand = reinterpret_cast<uint32_t*>(dyn_lds);                       // [CAND_Q][256]
+    float* lfeed = reinterpret_cast<float*>(dyn_lds + CAND_Q * 256 * 4);          // [FEED_Q][256]
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned gbase[2];
+    const int tid = threadIdx.x, lane = tid & 63;
     const float T = p.rnp[1];
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int x0 = (blockIdx.x * 256 + tid) * 4;
     const bool act = x0 < p.nx;                                 // nx % 4 == 0 on this path
     const int j0 = blockIdx.y * CAND_ROWS;
     const int j1 = min(j0 + CAND_ROWS, p.ny);
+    // loads are unconditional on clamped (always valid) addresses and masked afterwards: a
+    // `cond ? *ptr : zero` select makes hipcc pick between a global and a private pointer and
+    // fall back to scalar flat loads
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 up = (act && j0 > 0) ? *(const float4*)(a + (size_t)(j0 - 1) * p.nx + x0) : zero;
-    float4 cur = act ? *(const float4*)(a + (size_t)j0 * p.nx + x0) : zero;
+    const int xc = act ? x0 : 0;
+    float4 up = *(const float4*)(a + (size_t)max(j0 - 1, 0) * p.nx + xc);
+    float4 cur = *(const float4*)(a + (size_t)j0 * p.nx + xc);
+    if (!(act && j0 > 0)) up = zero;
+    if (!act) cur = zero;
     float lo = 0.f, hi = 0.f;
-    bsel_acc acc = {0, 0};
-    if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; bsel_lds_init(L); }
-    for (int jb = j0; jb < j1; jb += CAND_B) {
-        float4 nxt[CAND_B]; float le[CAND_B], re[CAND_B]; uchar4 mk[CAND_B];
+    unsigned ncand = 0, nfeed = 0, nvalid = 0, nbelow = 0;
+    if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; }
+    bool colok[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) colok[q] = act && (x0 + q >= 2) && (x0 + q < p.nx - 2);
+    struct batch { float4 nxt[CAND_B]; float le[CAND_B], re[CAND_B]; uchar4 mk[CAND_B]; };
+    // loads of a batch of CAND_B rows (clamped addresses, masked values)
+    auto load_batch = [&](batch& t, int jb) {
 #pragma unroll
         for (int k = 0; k < CAND_B; k++) {
             const int j = jb + k;
-            const size_t row = (size_t)j * p.nx;
-            nxt[k] = (act && j + 1 < p.ny) ? *(const float4*)(a + row + p.nx + x0) : zero;
-            le[k] = (lane == 0 && act && x0 > 0 && j < p.ny) ? a[row + x0 - 1] : 0.f;
-            re[k] = (lane == 63 && act && x0 + 4 < p.nx && j < p.ny) ? a[row + x0 + 4] : 0.f;
-            mk[k] = make_uchar4(0, 0, 0, 0);
-            if (FEED && act && j < p.ny) mk[k] = *(const uchar4*)(mask + row + x0);
+            const int jn = min(j + 1, p.ny - 1), jc = min(j, p.ny - 1);
+            t.nxt[k] = *(const float4*)(a + (size_t)jn * p.nx + xc);
+            if (!(act && j + 1 < p.ny)) t.nxt[k] = zero;
+            // one lane per wave fetches the pixel left / right of the wave's span
+            const int xe = (lane == 0) ? max(x0 - 1, 0) : min(x0 + 4, p.nx - 1);
+            float e = 0.f;
+            if ((lane == 0 || lane == 63) && act) e = a[(size_t)jc * p.nx + xe];
+            t.le[k] = (lane == 0 && x0 > 0) ? e : 0.f;
+            t.re[k] = (lane == 63 && x0 + 4 < p.nx) ? e : 0.f;
+            t.mk[k] = make_uchar4(0, 0, 0, 0);
+            if (FEED) { t.mk[k] = *(const uchar4*)(mask + (size_t)jc * p.nx + xc); }
         }
+    };
+    auto compute_batch = [&](const batch& t, int jb) {
 #pragma unroll
         for (int k = 0; k < CAND_B; k++) {
             const int j = jb + k;
             if (j >= j1) break;                                  // block-uniform
-            const size_t row = (size_t)j * p.nx;
-            const float4 dn = nxt[k];
+            const float4 dn = t.nxt[k];
             float l = __shfl_up(cur.w, 1, 64), r = __shfl_down(cur.x, 1, 64);
-            if (lane == 0) l = le[k];
-            if (lane == 63) r = re[k];
+            if (lane == 0) l = t.le[k];
+            if (lane == 63) r = t.re[k];
             // the 2-pixel frame of the image never holds candidates (sp == 0 there), so every
             // tested pixel has all four neighbours: interior form of L+
             const bool rowok = (j >= 2 && j < p.ny - 2);
@@ -118,24 +162,72 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
             const float d4[4] = {dn.x, dn.y, dn.z, dn.w};
             const float l4[4] = {l, cur.x, cur.y, cur.z};
             const float r4[4] = {cur.y, cur.z, cur.w, r};
-            const uint8_t mm[4] = {mk[k].x, mk[k].y, mk[k].z, mk[k].w};
+            const uint8_t mm[4] = {t.mk[k].x, t.mk[k].y, t.mk[k].z, t.mk[k].w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int i = x0 + q;
-                if (act && rowok && i >= 2 && i < p.nx - 2) {
-                    const float lp = lplus_px(c4[q], u4[q], d4[q], l4[q], r4[q], true, true, true, true);
+                // cheap exact-safe reject: L+ is the mean of four clipped half-Laplacians, hence
+                // <= their maximum = 2c - min(u,d) - min(l,r); the float32 roundings of either
+                // form stay below 1e-5*|4c|, which the slack term covers
+                const float c = c4[q];
+                const float quick = (c + c) - fminf(u4[q], d4[q]) - fminf(l4[q], r4[q]);
+                if (rowok && colok[q] && quick > T - 4e-5f * fabsf(c)) {
+                    const float lp = lplus_px(c, u4[q], d4[q], l4[q], r4[q], true, true, true, true);
                     if (lp > T) {
-                        const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
-                        if (kk < cap) cand[kk] = (uint32_t)(row + i); else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                        const uint32_t idx = (uint32_t)((size_t)j * p.nx + x0 + q);
+                        if (ncand < CAND_Q) { lcand[ncand * 256 + tid] = idx; ncand++; }
+                        else {
+                            const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
+                            if (kk < cap) cand[kk] = idx; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                        }
                     }
                 }
-                if (FEED) bsel_feed(L, lo, hi, c4[q], act && !(mm[q] & ~BBX_MASK_COSMIC), acc);
+                if (FEED) {
+                    const bool valid = act && !(mm[q] & ~BBX_MASK_COSMIC);
+                    const bool below = valid && c < lo;
+                    const bool inb = valid && c >= lo && c <= hi;
+                    nvalid += valid ? 1u : 0u;
+                    nbelow += below ? 1u : 0u;
+                    if (inb) {
+                        if (nfeed < FEED_Q) { lfeed[nfeed * 256 + tid] = c; nfeed++; }
+                        else {
+                            const unsigned kk = atomicAdd(&b.seg[0].nbuf, 1u);
+                            if (kk < b.cap) b.buf[kk] = c;
+                        }
+                    }
+                }
             }
             up = cur; cur = dn;
         }
-        if (FEED) bsel_drain(b, 0, L, 1024u * CAND_B, jb + CAND_B >= j1);
+    };
+    // software pipeline: the loads of the next batch are in flight while this one is computed
+    batch bA, bB;
+    load_batch(bA, j0);
+    for (int jb = j0; jb < j1; jb += 2 * CAND_B) {
+        load_batch(bB, jb + CAND_B);
+        compute_batch(bA, jb);
+        load_batch(bA, jb + 2 * CAND_B);
+        compute_batch(bB, jb + CAND_B);
     }
-    if (FEED) bsel_flush(b, 0, acc);
+    // ---- compaction: one global atomic per list and block
+    unsigned total;
+    unsigned off = block_excl_scan256(ncand, wsum, &total);
+    if (tid == 0) gbase[0] = total ? atomicAdd((unsigned*)&counters[CNT_CAND], total) : 0u;
+    __syncthreads();
+    for (unsigned k = 0; k < ncand; k++) {
+        const unsigned pos = gbase[0] + off + k;
+        if (pos < cap) cand[pos] = lcand[k * 256 + tid]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+    }
+    if (FEED) {
+        off = block_excl_scan256(nfeed, wsum, &total);
+        if (tid == 0) gbase[1] = total ? atomicAdd(&b.seg[0].nbuf, total) : 0u;
+        __syncthreads();
+        for (unsigned k = 0; k < nfeed; k++) {
+            const unsigned pos = gbase[1] + off + k;
+            if (pos < b.cap) b.buf[pos] = lfeed[k * 256 + tid];
+        }
+        bsel_acc acc = {nvalid, nbelow};
+        bsel_flush(b, 0, acc);
+    }
 }
 
 // scalar variant for frames whose width is not a multiple of 4 (small test frames)
@@ -299,7 +391,12 @@ __global__ __launch_bounds__(256) void k_lac_grow1(lac_par p, const uint32_t* __
 }
 
 // ---- 3b. second growth: dilate3(stage2) & good & sp > sigcliplow -----------------------------
-// one wave per (stage-2 pixel, neighbour); sp is evaluated once per pixel (F_SEEN claim)
+// One wave per stage-2 pixel p evaluates all 9 neighbours at once: lanes 0..48 hold s on the
+// 7x7 block around p (each lane one 5x5 median of the image), then lanes 0..8 gather the 25
+// s values of "their" neighbour's window with wave shuffles and run the median network in
+// registers.  Neighbours shared by adjacent stage-2 pixels are simply evaluated again (no
+// claim/atomic on the critical path); the F_FINAL bit makes the per-iteration count unique.
+#define F_FINAL 8u
 __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, uint8_t* mask, lac_par p,
                                                    const uint32_t* __restrict__ stage2, uint32_t cap, uint8_t* flags,
                                                    uint32_t* __restrict__ crlist, int32_t* counters, int32_t* err) {
@@ -307,26 +404,43 @@ __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, 
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
-    for (long long w = wave; w < (long long)n * 9; w += nwaves) {
-        const uint32_t o = stage2[w / 9];
-        const int nb = (int)(w % 9);
-        const int j = (int)(o / p.nx) + nb / 3 - 1, i = (int)(o % p.nx) + nb % 3 - 1;
-        // sp == 0 inside the 2-pixel frame: cannot exceed sigcliplow > 0
-        if (j < 2 || i < 2 || j >= p.ny - 2 || i >= p.nx - 2) continue;
-        const size_t r = (size_t)j * p.nx + i;
-        unsigned old = 0;
-        if (lane == 0) old = atomic_or_u8(flags, r, F_SEEN);
-        old = __shfl(old, 0, 64);
-        if (old & F_SEEN) continue;
-        if (!good_px(mask, r)) continue;
-        float noise;
-        const float sp = sp_wave(a, j, i, p, &noise);
-        if (sp > p.sigcliplow && lane == 0) {
-            const unsigned om = atomic_or_u8(mask, r, BBX_MASK_COSMIC);
-            atomicAdd(&counters[CNT_NEWCR], 1);
-            if (!(om & BBX_MASK_COSMIC)) {
-                const unsigned q = atomicAdd((unsigned*)&counters[CNT_CRLIST], 1u);
-                if (q < cap) crlist[q] = (uint32_t)r; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+    for (int w = wave; w < n; w += nwaves) {
+        const uint32_t o = stage2[w];
+        const int j = (int)(o / p.nx), i = (int)(o % p.nx);      // >= 2 px inside the frame
+        // s on the 7x7 block (positions outside the image are never read back)
+        float sv = 0.f, nz;
+        if (lane < 49) {
+            const int qj = j + lane / 7 - 3, qi = i + lane % 7 - 3;
+            if (qj >= 0 && qi >= 0 && qj < p.ny && qi < p.nx) sv = s_at(a, qj, qi, p, &nz);
+        }
+        // neighbour handled by this lane (lanes 0..8)
+        const int ry = (lane < 9 ? lane / 3 : 1) - 1, rx = (lane < 9 ? lane % 3 : 1) - 1;
+        const int rj = j + ry, ri = i + rx;
+        float v[25];
+#pragma unroll
+        for (int e = 0; e < 25; e++) {
+            const int src = (ry + e / 5 - 2 + 3) * 7 + (rx + e % 5 - 2 + 3);
+            v[e] = __shfl(sv, src, 64);
+        }
+        const float s_c = v[12];
+        // sp == 0 inside the 2-pixel frame (median filter copies its border): cannot pass
+        const bool inner = !(rj < 2 || ri < 2 || rj >= p.ny - 2 || ri >= p.nx - 2);
+        if (lane < 9 && inner) {
+            const size_t r = (size_t)rj * p.nx + ri;
+            if (good_px(mask, r)) {
+                BBX_MED25(v);
+                const float sp = s_c - v[12];
+                if (sp > p.sigcliplow) {
+                    const unsigned of = atomic_or_u8(flags, r, F_FINAL);
+                    if (!(of & F_FINAL)) {
+                        const unsigned om = atomic_or_u8(mask, r, BBX_MASK_COSMIC);
+                        atomicAdd(&counters[CNT_NEWCR], 1);
+                        if (!(om & BBX_MASK_COSMIC)) {
+                            const unsigned q = atomicAdd((unsigned*)&counters[CNT_CRLIST], 1u);
+                            if (q < cap) crlist[q] = (uint32_t)r; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                        }
+                    }
+                }
             }
         }
     }
@@ -361,6 +475,7 @@ __global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         stats[it] = counters[CNT_NEWCR];
         stats[7] = counters[CNT_CRLIST];
+        if (it < 4) { stats[8 + 2 * it] = counters[CNT_CAND]; stats[9 + 2 * it] = counters[CNT_STAGE2]; }
         counters[CNT_NEWCR] = 0; counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0;
     }
 }
@@ -408,7 +523,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     uint32_t* crlist = (uint32_t*)bbx_ws(ctx, WS_CRLIST, cap * 4, &rc); if (rc) return rc;
     uint8_t* flags = (uint8_t*)bbx_ws(ctx, WS_FLAGS, npix + 16, &rc); if (rc) return rc;
     int32_t* cnt = ctx->d_counters;
-    BBX_HIP(hipMemsetAsync(d_stats, 0, 8 * sizeof(int32_t), s));
+    BBX_HIP(hipMemsetAsync(d_stats, 0, 16 * sizeof(int32_t), s));
     BBX_HIP(hipMemsetAsync(&cnt[CNT_CAND], 0, 4 * sizeof(int32_t), s));      // CAND, STAGE2, CRLIST, NEWCR
     // background level of the unmasked input pixels (needed when a CR pixel has no good
     // neighbour): bracketed select fed by the first candidate pass, no extra read of the frame
@@ -422,13 +537,13 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
         bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
         if (it == 0) {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), (CAND_Q + FEED_Q) * 256 * 4, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
             bbx_prof_stop(ctx, s);
             rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s);
             if (rc) return rc;
         } else {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), CAND_Q * 256 * 4, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
             bbx_prof_stop(ctx, s);
         }

@@ -1,0 +1,195 @@
+"""Minimal FITS image reader/writer (numpy only).
+
+The reference reads frames with astropy (`read_hdulist`, faithful copy at
+blackbox_slurm_google.py:1144-1253: last HDU, `.astype(dtype)`) and writes them with
+`fits.writeto` (blackbox.py:1987-1990).  astropy is not part of the GPU box's Python,
+so the hot path owns this small uncompressed-image implementation: BITPIX 8 / 16 / 32 /
+-32 / -64 primary or IMAGE-extension HDUs, BZERO/BSCALE for the unsigned-16 raw frames.
+Tile-compressed (.fz) files are out of scope.
+
+Headers are plain dicts {KEY: (value, comment)} -- the same shape the stage functions
+fill -- or {KEY: value}.
+"""
+import numpy as np
+
+BLOCK = 2880
+_BITPIX = {8: '>u1', 16: '>i2', 32: '>i4', 64: '>i8', -32: '>f4', -64: '>f8'}
+
+
+def _parse_value(s):
+    s = s.strip()
+    if not s:
+        return None
+    if s[0] == "'":
+        end = 1
+        while True:
+            end = s.find("'", end)
+            if end < 0:
+                return s[1:].rstrip()
+            if end + 1 < len(s) and s[end + 1] == "'":
+                end += 2
+                continue
+            break
+        return s[1:end].replace("''", "'").rstrip()
+    v = s.split('/')[0].strip()
+    if v == 'T':
+        return True
+    if v == 'F':
+        return False
+    try:
+        return int(v)
+    except ValueError:
+        pass
+    try:
+        return float(v.replace('D', 'E'))
+    except ValueError:
+        return v
+
+
+def _read_header(f):
+    cards = {}
+    order = []
+    while True:
+        block = f.read(BLOCK)
+        if len(block) < BLOCK:
+            raise EOFError('truncated FITS header')
+        done = False
+        for i in range(0, BLOCK, 80):
+            card = block[i:i + 80].decode('ascii', 'replace')
+            key = card[:8].strip()
+            if key == 'END':
+                done = True
+                break
+            if not key or key in ('COMMENT', 'HISTORY') or card[8:10] != '= ':
+                continue
+            body = card[10:]
+            val = _parse_value(body)
+            comment = ''
+            if isinstance(val, str) and body.lstrip().startswith("'"):
+                rest = body[body.find("'", body.find("'") + 1) + 1:] if body.count("'") >= 2 else ''
+                comment = rest.split('/', 1)[1].strip() if '/' in rest else ''
+            elif '/' in body:
+                comment = body.split('/', 1)[1].strip()
+            cards[key] = (val, comment)
+            order.append(key)
+        if done:
+            break
+    return cards
+
+
+def _hv(h, k, default=None):
+    v = h.get(k, default)
+    return v[0] if isinstance(v, tuple) else v
+
+
+def read_hdus(path):
+    """-> list of (header dict, data ndarray or None)"""
+    out = []
+    with open(path, 'rb') as f:
+        while True:
+            pos = f.tell()
+            probe = f.read(1)
+            if not probe:
+                break
+            f.seek(pos)
+            h = _read_header(f)
+            naxis = _hv(h, 'NAXIS', 0)
+            bitpix = _hv(h, 'BITPIX', 8)
+            data = None
+            if naxis > 0:
+                shape = tuple(int(_hv(h, 'NAXIS%d' % k)) for k in range(naxis, 0, -1))
+                npix = int(np.prod(shape))
+                raw = np.fromfile(f, dtype=_BITPIX[bitpix], count=npix)
+                if raw.size != npix:
+                    raise EOFError('truncated FITS data in {}'.format(path))
+                data = raw.reshape(shape)
+                f.seek((-(npix * abs(bitpix) // 8)) % BLOCK, 1)       # data units are padded to 2880 bytes
+            out.append((h, data))
+    return out
+
+
+def read_image(path, dtype=None, get_header=False):
+    """last HDU with data, like zogy.read_hdulist; unsigned-16 raws (BITPIX 16, BZERO 32768)
+    come back as uint16, everything else scaled by BSCALE/BZERO when present."""
+    hdus = read_hdus(path)
+    h, data = None, None
+    for hh, dd in hdus:
+        if dd is not None:
+            h, data = hh, dd
+    if data is None:
+        raise ValueError('no image data in {}'.format(path))
+    bzero = _hv(h, 'BZERO', 0) or 0
+    bscale = _hv(h, 'BSCALE', 1) or 1
+    if data.dtype == np.dtype('>i2') and bzero == 32768 and bscale == 1:
+        data = (data.astype(np.int32) + 32768).astype(np.uint16)
+    elif bzero != 0 or bscale != 1:
+        data = data.astype(np.float64) * bscale + bzero
+    else:
+        data = data.astype(data.dtype.newbyteorder('='))
+    if dtype is not None:
+        data = data.astype(dtype, copy=False)
+    return (data, h) if get_header else data
+
+
+def _card(key, value, comment=''):
+    if isinstance(value, tuple):
+        value, comment = value[0], (value[1] if len(value) > 1 else comment)
+    key = str(key).upper()[:8]
+    if isinstance(value, (bool, np.bool_)):
+        v = '{:>20}'.format('T' if value else 'F')
+    elif isinstance(value, (int, np.integer)):
+        v = '{:>20d}'.format(int(value))
+    elif isinstance(value, (float, np.floating)):
+        if not np.isfinite(value):
+            v = "'{:<8}'".format(str(value))
+        else:
+            v = '{:>20}'.format(repr(float(value)).upper().replace('E+', 'E'))
+            if len(v) > 20:
+                v = '{:>20.13G}'.format(float(value))
+    else:
+        s = str(value).replace("'", "''")[:68]
+        v = "'{:<8}'".format(s)
+    card = '{:<8}= {}'.format(key, v)
+    if comment:
+        card += ' / ' + str(comment)
+    return card[:80].ljust(80)
+
+
+def write_image(path, data, header=None):
+    """uncompressed primary-HDU image: uint8 -> BITPIX 8, uint16 -> BITPIX 16 + BZERO,
+    float32 -> BITPIX -32 (what blackbox.py:1987-1990 writes for _red and _mask)"""
+    data = np.asarray(data)
+    extra = []
+    if data.dtype == np.uint8:
+        bitpix, out = 8, data
+    elif data.dtype == np.uint16:
+        bitpix, out = 16, (data.astype(np.int32) - 32768).astype('>i2')
+        extra = [('BSCALE', 1, ''), ('BZERO', 32768, '')]
+    elif data.dtype == np.int16:
+        bitpix, out = 16, data.astype('>i2')
+    elif data.dtype == np.int32:
+        bitpix, out = 32, data.astype('>i4')
+    elif data.dtype == np.float64:
+        bitpix, out = -64, data.astype('>f8')
+    else:
+        bitpix, out = -32, data.astype('>f4')
+    cards = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', bitpix, 'array data type'),
+             _card('NAXIS', data.ndim, 'number of array dimensions')]
+    for k in range(data.ndim):
+        cards.append(_card('NAXIS%d' % (k + 1), data.shape[data.ndim - 1 - k]))
+    for k, v, c in extra:
+        cards.append(_card(k, v, c))
+    skip = {'SIMPLE', 'BITPIX', 'NAXIS', 'EXTEND', 'BZERO', 'BSCALE', 'END'}
+    for k, v in (header or {}).items():
+        ku = str(k).upper()
+        if ku in skip or ku.startswith('NAXIS') or len(ku) > 8:
+            continue
+        cards.append(_card(ku, v))
+    cards.append('END'.ljust(80))
+    hdr = ''.join(cards).encode('ascii', 'replace')
+    hdr += b' ' * ((-len(hdr)) % BLOCK)
+    with open(path, 'wb') as f:
+        f.write(hdr)
+        buf = out.tobytes()
+        f.write(buf)
+        f.write(b'\0' * ((-len(buf)) % BLOCK))

@@ -118,7 +118,7 @@ class FramePipeline:
                 d_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev),
                 h_out=(torch.empty(16, dtype=torch.float64, pin_memory=True),
                        torch.empty(1, dtype=torch.int32, pin_memory=True),
-                       torch.zeros(8, dtype=torch.int32, pin_memory=True),
+                       torch.zeros(16, dtype=torch.int32, pin_memory=True),
                        torch.zeros(6, dtype=torch.int64, pin_memory=True))))
         self.free_slots = list(range(depth))
 

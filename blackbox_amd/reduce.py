@@ -254,7 +254,7 @@ def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None):
     if d_rdn16 is None:
         hv = header['RDNOISE']
         readnoise = hv[0] if isinstance(hv, tuple) else hv
-    d_stats = torch.zeros(8, dtype=torch.int32, device=ctx.device)
+    d_stats = torch.zeros(16, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(data_mask),
                            float(get_par(settings.sigclip, tel)), float(get_par(settings.sigfrac, tel)),
                            float(get_par(settings.objlim, tel)), int(get_par(settings.niter, tel)),
@@ -266,7 +266,7 @@ def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None):
 def detect_cosmics(ctx, data, mask, sigclip, sigfrac, objlim, niter, readnoise):
     """astroscrappy-style call on device tensors (in place) -> stats tensor"""
     ny, nx = data.shape
-    d_stats = torch.zeros(8, dtype=torch.int32, device=ctx.device)
+    d_stats = torch.zeros(16, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(mask), float(sigclip), float(sigfrac), float(objlim),
                            int(niter), float(np.float32(readnoise)), _ptr(None), _ptr(d_stats), ctx.stream()),
           'bbx_lacosmic', ctx.h)

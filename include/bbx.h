@@ -153,8 +153,9 @@ int bbx_mask_finish(bbx_ctx *ctx, const bbx_geom *g, uint8_t *d_mask,
  * In place: d_data becomes the cleaned array, CR pixels get bit 2 in d_mask.
  *  readnoise : RDNOISE in e-; if d_rdn16 != NULL it is instead taken on the device as
  *  float32(nanmean(d_rdn16[0..15])) (the 16 RDN{c} of bbx_vos_std), sparing a host hop.
- *  d_stats [8] i32 : [0..niter-1] pixels flagged per iteration, [6] number of
- *  8-connected CR objects, [7] total CR pixels.                                  */
+ *  d_stats [16] i32 : [0..niter-1] pixels flagged per iteration, [6] number of
+ *  8-connected CR objects, [7] total CR pixels, [8+2k],[9+2k] (k<4) work-list sizes of
+ *  iteration k (pruned candidates, first-growth survivors) for diagnostics.                                  */
 int bbx_lacosmic(bbx_ctx *ctx, int ny, int nx, float *d_data, uint8_t *d_mask,
                  float sigclip, float sigfrac, float objlim, int niter,
                  float readnoise, const double *d_rdn16, int32_t *d_stats,
