@@ -110,12 +110,12 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype):
 
 def cpu_baseline(seconds_budget=30.0):
     """oracle (numpy/scipy restatement, single core) on a bounded sub-frame of the same
-    kind of scene: 2x8 channels of 330x330 px (1/102 of the frame), scaled by area"""
+    kind of scene: 2x8 channels of 660x330 px (1/32 of the frame), scaled by area"""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bbx_oracle as O
     import lacosmic as L
     from blackbox_amd import settings, synth
-    ys, xs = 330, 330
+    ys, xs = 660, 330
     case = synth.make_case(ys, xs, 4242, tel='ML1', os_y=20, os_x=45, n_stars=200, n_sat=2, n_cr=6)
     t0 = time.perf_counter()
     data = case['raw'].astype('float32')
@@ -128,7 +128,7 @@ def cpu_baseline(seconds_budget=30.0):
     dt = time.perf_counter() - t0
     frac = (2 * ys * 8 * xs) / 111513600.0
     return dict(value=frac / dt, unit='frames/s', cores=1, kind='port',
-                sample='oracle (numpy/scipy) on a 660x2640 px sub-frame (1/%.0f of a frame) in %.1f s, scaled by area'
+                sample='oracle (numpy/scipy) on a 1320x2640 px sub-frame (1/%.0f of a frame) in %.1f s, scaled by area'
                        % (1 / frac, dt))
 
 
@@ -245,6 +245,19 @@ def main():
                     others={k: dict(avg_launch_ms=per[k][0], achieved=per[k][1] / (per[k][0] * 1e-3) / 1e9,
                                     frac=per[k][1] / (per[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) for k in per if k != dom})
         roof['frac'] = roof['achieved'] / roof['peak']
+        # HBM traffic per launch from the committed rocprofv3 --pmc passes of this command
+        # (profiles/r01_pmc_traffic.json: FETCH_SIZE/WRITE_SIZE, gfx950 correction applied)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
+            if not args.small and args.raw == 'u16':
+                if dom == 'k_calibrate':
+                    roof['traffic'] = pmc['k_calibrate_v4<0>']['traffic_bytes_per_launch']
+                else:
+                    roof['traffic'] = (pmc['k_lac_cand_v4<true>']['traffic_bytes_per_launch'] +
+                                       2 * pmc['k_lac_cand_v4<false>']['traffic_bytes_per_launch']) / 3.0
+                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+        except Exception:
+            pass
         out = dict(metric='10560x10560 fp32 frames/sec end-to-end reduce (calibration + LA-Cosmic)',
                    value=args.steps * world / dt, unit='frames/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True,
