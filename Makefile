@@ -3,7 +3,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := blackbox_amd/csrc
 SRCS  := $(CSRC)/bbx_ctx.hip $(CSRC)/bbx_overscan.hip $(CSRC)/bbx_calibrate.hip \
-         $(CSRC)/bbx_mask.hip $(CSRC)/bbx_select.hip $(CSRC)/bbx_lacosmic.hip $(CSRC)/bbx_xtalk.hip
+         $(CSRC)/bbx_mask.hip $(CSRC)/bbx_select.hip $(CSRC)/bbx_lacosmic.hip $(CSRC)/bbx_xtalk.hip \
+         $(CSRC)/bbx_stack.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := blackbox_amd/libbbx_hip.so
 # -ffp-contract=off: results must match numpy's unfused float32/float64 arithmetic
@@ -11,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -ffp-contract=off -std=c++17 -Wall 
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h include/bbx.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h $(CSRC)/bbx_bsel.h include/bbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -55,6 +55,7 @@ SIGNATURES = {
     'bbx_xtalk': (_i, [_vp, _pg, _vp, _vp, _pd, _vp]),
     'bbx_mask_counts': (_i, [_vp, C.c_int64, _vp, _vp, _vp]),
     'bbx_edge_fill': (_i, [_vp, _pg, _vp, _vp, _vp, _vp]),
+    'bbx_median_stack': (_i, [_vp, C.c_int64, _i, C.POINTER(_vp), _pf, _vp, _i, _vp, _vp]),
     'bbx_count_objects': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

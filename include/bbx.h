@@ -176,6 +176,16 @@ int bbx_mask_counts(bbx_ctx *ctx, int64_t npix, const uint8_t *d_mask,
 int bbx_edge_fill(bbx_ctx *ctx, const bbx_geom *g, float *d_data,
                   const uint8_t *d_mask, float *d_chan_median, void *stream);
 
+/* ---- a8: master frames ------------------------------------------------------------------
+ * replaces master_prep 4906-5073: per-pixel np.median of nframes (<= 32) reduced
+ * calibration frames; each frame is first divided by h_norm[i] (flats: MEDSEC of
+ * 4929-4941; NULL or 1 for bias/dark; 0 = leave as is); with flat_fix != 0 pixels that
+ * are BPM-edge (== 32) or <= 0 become 1 (5071-5073).
+ *  h_frames : host array of nframes device pointers, each npix float32.             */
+int bbx_median_stack(bbx_ctx *ctx, int64_t npix, int nframes, const float *const *h_frames,
+                     const float *h_norm, const uint8_t *d_bpm, int flat_fix,
+                     float *d_out, void *stream);
+
 /* ---- generic: number of 8-connected objects of (mask & bit) --------------------------
  * replaces ndimage.label(..., structure=ones(3,3)) counts (NOBJ-SAT 4545,
  * NCOSMICS 4355, NSATS 4230).                                                     */

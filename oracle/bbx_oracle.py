@@ -545,3 +545,19 @@ def xtalk_corr(data, coeffs, data_mask, ysize_chan, xsize_chan):
         d = data[sec[i]]
         d[...] = (d.astype(np.float64) - corr[i] * mask_victim[sec[i]]
                   ).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------
+# master frames
+# --------------------------------------------------------------------------------
+def master_median(cube, imgtype, medsec=None, bpm=None):
+    """blackbox.py:4929-4941, 4984, 5071-5073: [cube] float32 (nfiles, ny, nx), modified in
+    place like the reference; returns the master (float32)."""
+    if imgtype == 'flat':
+        for i in range(cube.shape[0]):
+            if medsec[i] != 0:
+                cube[i] /= np.float32(medsec[i])
+    master = np.median(cube, axis=0)
+    if imgtype == 'flat' and bpm is not None:
+        master[(bpm == 32) | (master <= 0)] = 1
+    return master

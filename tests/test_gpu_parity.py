@@ -211,3 +211,24 @@ def test_fill_holes_shapes(ctx):
     ctx.sync()
     assert np.array_equal(m.cpu().numpy(), mask_o)
     assert int(n.item()) == hm['NOBJ-SAT']
+
+
+@pytest.mark.parametrize('n,imgtype', [(1, 'bias'), (2, 'bias'), (5, 'flat'), (15, 'flat'), (20, 'bias')])
+def test_master_median_stack(ctx, n, imgtype):
+    """a8: normalise + pixel-wise median + flat fix == numpy, bit for bit"""
+    from blackbox_amd import masters
+    rs = np.random.RandomState(n)
+    shape = (96, 200)
+    cube = (rs.normal(30000 if imgtype == 'flat' else 0, 50, (n,) + shape)).astype(np.float32)
+    if imgtype == 'flat':
+        cube[:, 10:14, 20:30] = -5.0                      # non-positive pixels -> 1
+    medsec = [float(np.float32(np.median(c[40:80, 50:150]))) for c in cube] if imgtype == 'flat' else None
+    bpm = np.zeros(shape, np.uint8)
+    bpm[:3] = 32
+    bpm[50, 60] = 1
+    frames = [torch.from_numpy(c.copy()).to(ctx.device) for c in cube]
+    out = masters.master_median(ctx, frames, imgtype, medsec=medsec, bpm=torch.from_numpy(bpm).to(ctx.device))
+    ctx.sync()
+    ref = O.master_median(cube.copy(), imgtype, medsec=medsec, bpm=bpm)
+    assert ref.dtype == np.float32
+    assert np.array_equal(out.cpu().numpy(), ref)
