@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := blackbox_amd/csrc
 SRCS  := $(CSRC)/bbx_ctx.hip $(CSRC)/bbx_overscan.hip $(CSRC)/bbx_calibrate.hip \
          $(CSRC)/bbx_mask.hip $(CSRC)/bbx_select.hip $(CSRC)/bbx_lacosmic.hip $(CSRC)/bbx_xtalk.hip \
-         $(CSRC)/bbx_stack.hip
+         $(CSRC)/bbx_stack.hip $(CSRC)/bbx_bkg.hip $(CSRC)/bbx_zogy.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := blackbox_amd/libbbx_hip.so
 # -ffp-contract=off: results must match numpy's unfused float32/float64 arithmetic
@@ -16,7 +16,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h $(CSRC)/bbx
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
 
 clean:
 	rm -f $(OBJS) $(LIB)

@@ -56,6 +56,13 @@ SIGNATURES = {
     'bbx_mask_counts': (_i, [_vp, C.c_int64, _vp, _vp, _vp]),
     'bbx_edge_fill': (_i, [_vp, _pg, _vp, _vp, _vp, _vp]),
     'bbx_median_stack': (_i, [_vp, C.c_int64, _i, C.POINTER(_vp), _pf, _vp, _i, _vp, _vp]),
+    'bbx_bkg_boxstats': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    'bbx_mini_fill_filter': (_i, [_vp, _i, _i, _vp, _vp]),
+    'bbx_spline_zoom': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_cut_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'bbx_stitch_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'bbx_zogy_subimages': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_psf_optflux': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_count_objects': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,0 +1,282 @@
+// bbx_zogy.hip -- ZOGY image subtraction per sub-image with rocFFT, and PSF photometry.
+// (zogy.optimal_subtraction -> run_ZOGY, called at blackbox.py:2350-2354 / 2460-2465;
+// Zackay, Ofek & Gal-Yam 2016.  [EXT: parity unpinned, conventions = oracle/zogy_core.py])
+//
+// All spatial quantities are real, so every transform is R2C / C2R on the half spectrum
+// (L x (L/2+1) complex64), batched over the sub-images.  Per sub-image: 8 forward + 8 inverse
+// 2-D FFTs (rocFFT, HBM-bound) and four element-wise kernels:
+//   spec1 : D^, S^, k_r^, k_n^, (k_n N)^, (k_r R)^ and the F_S sum   from N^, R^, Pn^, Pr^
+//   sq    : k_r^2, k_n^2 (real space)
+//   spec2 : V(S_r)^ = Vr^ * (k_r^2)^ ,  V(S_n)^ = Vn^ * (k_n^2)^
+//   final : D, S, S_corr (incl. the astrometric variance from the finite differences of
+//           S_n, S_r), F_psf = S / F_S, F_psf_err = sqrt(V_S) / F_S
+// rocFFT transforms are unnormalised: the 1/L^2 of every inverse is folded into the kernels.
+#include "bbx_common.h"
+#include <rocfft/rocfft.h>
+#include <stdlib.h>
+
+struct zogy_scal { float sn, sr, fn, fr, dx, dy; };
+
+struct zogy_plans {
+    int L, batch;
+    rocfft_plan fwd, inv;
+    rocfft_execution_info info;
+    void* work; size_t work_bytes;
+};
+static zogy_plans g_plans = {0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+static int g_rocfft_ready = 0;
+
+#define RFFT(call) do { rocfft_status _s = (call); if (_s != rocfft_status_success) { \
+    snprintf(ctx->hip_err, sizeof(ctx->hip_err), "rocFFT: %s -> %d (line %d)", #call, (int)_s, __LINE__); return BBX_ERR_HIP; } } while (0)
+
+static int get_plans(bbx_ctx* ctx, int L, int batch, hipStream_t s) {
+    if (!g_rocfft_ready) { RFFT(rocfft_setup()); g_rocfft_ready = 1; }
+    if (g_plans.L != L || g_plans.batch != batch) {
+        if (g_plans.fwd) { rocfft_plan_destroy(g_plans.fwd); rocfft_plan_destroy(g_plans.inv); g_plans.fwd = g_plans.inv = nullptr; }
+        if (g_plans.info) { rocfft_execution_info_destroy(g_plans.info); g_plans.info = nullptr; }
+        if (g_plans.work) { (void)hipDeviceSynchronize(); (void)hipFree(g_plans.work); g_plans.work = nullptr; }
+        const size_t len[2] = {(size_t)L, (size_t)L};
+        RFFT(rocfft_plan_create(&g_plans.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                rocfft_precision_single, 2, len, (size_t)batch, nullptr));
+        RFFT(rocfft_plan_create(&g_plans.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                rocfft_precision_single, 2, len, (size_t)batch, nullptr));
+        size_t w1 = 0, w2 = 0;
+        RFFT(rocfft_plan_get_work_buffer_size(g_plans.fwd, &w1));
+        RFFT(rocfft_plan_get_work_buffer_size(g_plans.inv, &w2));
+        g_plans.work_bytes = w1 > w2 ? w1 : w2;
+        if (g_plans.work_bytes) BBX_HIP(hipMalloc(&g_plans.work, g_plans.work_bytes));
+        RFFT(rocfft_execution_info_create(&g_plans.info));
+        if (g_plans.work_bytes) RFFT(rocfft_execution_info_set_work_buffer(g_plans.info, g_plans.work, g_plans.work_bytes));
+        g_plans.L = L; g_plans.batch = batch;
+    }
+    RFFT(rocfft_execution_info_set_stream(g_plans.info, s));
+    return BBX_OK;
+}
+
+static int fft_fwd(bbx_ctx* ctx, float* in, float2* out) {
+    void* i[1] = {in}; void* o[1] = {out};
+    RFFT(rocfft_execute(g_plans.fwd, i, o, g_plans.info));
+    return BBX_OK;
+}
+static int fft_inv(bbx_ctx* ctx, float2* in, float* out) {       // destroys [in]
+    void* i[1] = {in}; void* o[1] = {out};
+    RFFT(rocfft_execute(g_plans.inv, i, o, g_plans.info));
+    return BBX_OK;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// spectra are [nsub][L][H], H = L/2+1
+__global__ __launch_bounds__(256) void k_zogy_spec1(int L, int H, const float2* __restrict__ Nh, const float2* __restrict__ Rh,
+                                                    const float2* __restrict__ Pnh, const float2* __restrict__ Prh,
+                                                    const zogy_scal* __restrict__ sc, float2* Dh, float2* Sh, float2* krh,
+                                                    float2* knh, float2* SnH, float2* SrH, double* fs_partial) {
+    const int sub = blockIdx.y;
+    const zogy_scal z = sc[sub];
+    const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
+    const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
+    const size_t per = (size_t)L * H, base = (size_t)sub * per;
+    double fs = 0.0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < per; k += (size_t)gridDim.x * blockDim.x) {
+        const float2 n = Nh[base + k], r = Rh[base + k], pn = Pnh[base + k], pr = Prh[base + k];
+        const float pn2 = pn.x * pn.x + pn.y * pn.y, pr2 = pr.x * pr.x + pr.y * pr.y;
+        const float den = (sn2 * fr2) * pr2 + (sr2 * fn2) * pn2;
+        const float isd = 1.0f / sqrtf(den);
+        const float2 a = cscale(cmul(pr, n), z.fr), b = cscale(cmul(pn, r), z.fn);
+        const float2 dh = cscale(make_float2(a.x - b.x, a.y - b.y), isd);
+        const float2 pdh = cscale(cmul(pr, pn), (z.fr * z.fn / fD) * isd);
+        const float2 sh = cmul(cscale(dh, fD), cconj(pdh));
+        const float2 kr = cscale(cconj(pr), z.fr * fn2 * pn2 / den);
+        const float2 kn = cscale(cconj(pn), z.fn * fr2 * pr2 / den);
+        Dh[base + k] = dh; Sh[base + k] = sh; krh[base + k] = kr; knh[base + k] = kn;
+        SnH[base + k] = cmul(kn, n); SrH[base + k] = cmul(kr, r);
+        // Hermitian weight of this half-spectrum column in the full-spectrum sum
+        const int kx = (int)(k % H);
+        const double w = (kx == 0 || (L % 2 == 0 && kx == L / 2)) ? 1.0 : 2.0;
+        fs += w * (double)(fn2 * pn2 * fr2 * pr2 / den);
+    }
+    fs = wave_sum_f64(fs);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = fs;
+    __syncthreads();
+    if (threadIdx.x == 0) fs_partial[(size_t)sub * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_zogy_fs(int nblocks, int L, const double* __restrict__ fs_partial, float* __restrict__ FS) {
+    const int sub = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; b++) s += fs_partial[(size_t)sub * nblocks + b];
+        FS[sub] = (float)(s / ((double)L * (double)L));
+    }
+}
+
+// kr, kn come out of the unnormalised inverse: scale by 1/L^2 first, then square
+__global__ __launch_bounds__(256) void k_zogy_sq(size_t n, float inv_n2, const float* __restrict__ kr, const float* __restrict__ kn,
+                                                 float* kr2, float* kn2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = kr[i] * inv_n2, b = kn[i] * inv_n2;
+        kr2[i] = a * a; kn2[i] = b * b;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zogy_spec2(size_t n, const float2* __restrict__ Vrh, const float2* __restrict__ kr2h,
+                                                    const float2* __restrict__ Vnh, const float2* __restrict__ kn2h,
+                                                    float2* VSrh, float2* VSnh) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        VSrh[i] = cmul(Vrh[i], kr2h[i]); VSnh[i] = cmul(Vnh[i], kn2h[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zogy_final(int L, float inv_n2, const zogy_scal* __restrict__ sc,
+                                                    const float* __restrict__ FS, const float* __restrict__ Draw,
+                                                    const float* __restrict__ Sraw, const float* __restrict__ Sn,
+                                                    const float* __restrict__ Sr, const float* __restrict__ VSr,
+                                                    const float* __restrict__ VSn, float* D, float* S, float* Scorr,
+                                                    float* Fpsf, float* Fpsferr) {
+    const int sub = blockIdx.y;
+    const zogy_scal z = sc[sub];
+    const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
+    const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
+    const float fs = FS[sub];
+    const size_t per = (size_t)L * L, base = (size_t)sub * per;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < per; k += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(k / L), x = (int)(k - (size_t)y * L);
+        const int ym = (y == 0) ? L - 1 : y - 1, xm = (x == 0) ? L - 1 : x - 1;      // np.roll(..., 1)
+        const float s = Sraw[base + k] * inv_n2;
+        const float snc = Sn[base + k] * inv_n2, src = Sr[base + k] * inv_n2;
+        const float dSndy = snc - Sn[base + (size_t)ym * L + x] * inv_n2, dSndx = snc - Sn[base + (size_t)y * L + xm] * inv_n2;
+        const float dSrdy = src - Sr[base + (size_t)ym * L + x] * inv_n2, dSrdx = src - Sr[base + (size_t)y * L + xm] * inv_n2;
+        const float vast = z.dx * z.dx * (dSndx * dSndx + dSrdx * dSrdx) + z.dy * z.dy * (dSndy * dSndy + dSrdy * dSrdy);
+        const float vs = VSr[base + k] * inv_n2 + VSn[base + k] * inv_n2;
+        D[base + k] = Draw[base + k] * inv_n2 / fD;
+        S[base + k] = s;
+        Scorr[base + k] = s / sqrtf(vs + vast);
+        Fpsf[base + k] = s / fs;
+        Fpsferr[base + k] = sqrtf(fmaxf(vs, 0.f)) / fs;
+    }
+}
+
+// ---- sub-image cut / stitch --------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cut(const float* __restrict__ img, int ny, int nx, int size, int border, int nsx,
+                                             float* __restrict__ subs) {
+    const int L = size + 2 * border;
+    const int sub = blockIdx.z, sy = sub / nsx, sx = sub - sy * nsx;
+    const int y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= L) return;
+    const int Y = sy * size - border + y, X = sx * size - border + x;
+    float v = 0.f;
+    if (Y >= 0 && Y < ny && X >= 0 && X < nx) v = img[(size_t)Y * nx + X];
+    subs[((size_t)sub * L + y) * L + x] = v;
+}
+
+__global__ __launch_bounds__(256) void k_stitch(const float* __restrict__ subs, int ny, int nx, int size, int border, int nsx,
+                                                float* __restrict__ img) {
+    const int L = size + 2 * border;
+    const int Y = blockIdx.y, X = blockIdx.x * blockDim.x + threadIdx.x;
+    if (X >= nx) return;
+    const int sy = Y / size, sx = X / size;
+    img[(size_t)Y * nx + X] = subs[((size_t)(sy * nsx + sx) * L + (Y - sy * size + border)) * L + (X - sx * size + border)];
+}
+
+// ---- PSF photometry: one wave per source ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_psf_optflux(int ny, int nx, const float* __restrict__ D, const float* __restrict__ V,
+                                                     const float* __restrict__ psfs, int S, int nsrc,
+                                                     const int32_t* __restrict__ ys, const int32_t* __restrict__ xs,
+                                                     float* __restrict__ flux, float* __restrict__ err) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int h = S / 2;
+    for (int k = wave; k < nsrc; k += nwaves) {
+        double num = 0.0, den = 0.0;
+        for (int t = lane; t < S * S; t += 64) {
+            const int j = t / S, i = t - j * S;
+            const int y = ys[k] + j - h, x = xs[k] + i - h;
+            if (y < 0 || y >= ny || x < 0 || x >= nx) continue;
+            const double v = (double)V[(size_t)y * nx + x];
+            if (!(v > 0.0)) continue;
+            const double p = (double)psfs[((size_t)k * S + j) * S + i];
+            num += p * (double)D[(size_t)y * nx + x] / v;
+            den += p * p / v;
+        }
+        num = wave_sum_f64(num); den = wave_sum_f64(den);
+        if (lane == 0) {
+            flux[k] = den > 0.0 ? (float)(num / den) : 0.f;
+            err[k] = den > 0.0 ? (float)(1.0 / sqrt(den)) : 0.f;
+        }
+    }
+}
+
+extern "C" {
+
+int bbx_cut_subimages(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_img, float* d_subs, void* stream) {
+    if (!ctx || !d_img || !d_subs || size < 1 || border < 0 || ny % size || nx % size) return BBX_ERR_ARG;
+    const int L = size + 2 * border, nsy = ny / size, nsx = nx / size;
+    hipLaunchKernelGGL(k_cut, dim3((L + 255) / 256, L, nsy * nsx), dim3(256), 0, (hipStream_t)stream, d_img, ny, nx, size, border, nsx, d_subs);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_stitch_subimages(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_subs, float* d_img, void* stream) {
+    if (!ctx || !d_img || !d_subs || size < 1 || border < 0 || ny % size || nx % size) return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_stitch, dim3((nx + 255) / 256, ny), dim3(256), 0, (hipStream_t)stream, d_subs, ny, nx, size, border, nx / size, d_img);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_zogy_subimages(bbx_ctx* ctx, int L, int nsub, float* d_new, float* d_ref, float* d_pn, float* d_pr, float* d_vn,
+                       float* d_vr, const float* h_scal /*[nsub][6]: sn sr fn fr dx dy*/, float* d_D, float* d_S,
+                       float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, void* stream) {
+    if (!ctx || !d_new || !d_ref || !d_pn || !d_pr || !d_vn || !d_vr || !h_scal || !d_D || !d_S || !d_Scorr || !d_Fpsf || !d_Fpsferr)
+        return BBX_ERR_ARG;
+    if (L < 8 || nsub < 1 || nsub > 4096) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = get_plans(ctx, L, nsub, s); if (rc) return rc;
+    const int H = L / 2 + 1;
+    const size_t nreal = (size_t)nsub * L * L, nspec = (size_t)nsub * L * H;
+    const int NB = 64;                                      // partial-sum blocks per sub-image
+    // workspace: 10 spectra + 8 real temporaries + scalars
+    const size_t bytes = 10 * nspec * sizeof(float2) + 8 * nreal * sizeof(float) + nsub * sizeof(zogy_scal) +
+                         (size_t)nsub * NB * sizeof(double) + nsub * sizeof(float) + 4096;
+    char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;   // shares the big LA-Cosmic slot
+    float2* spec[10]; for (int i = 0; i < 10; i++) spec[i] = (float2*)(ws + (size_t)i * nspec * sizeof(float2));
+    char* p = ws + 10 * nspec * sizeof(float2);
+    float* real[8]; for (int i = 0; i < 8; i++) { real[i] = (float*)p; p += nreal * sizeof(float); }
+    zogy_scal* d_sc = (zogy_scal*)p; p += nsub * sizeof(zogy_scal);
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    double* fs_partial = (double*)p; p += (size_t)nsub * NB * sizeof(double);
+    float* FS = (float*)p;
+    BBX_HIP(hipMemcpyAsync(d_sc, h_scal, nsub * sizeof(zogy_scal), hipMemcpyHostToDevice, s));
+    float2 *Nh = spec[0], *Rh = spec[1], *Pnh = spec[2], *Prh = spec[3], *Dh = spec[4], *Sh = spec[5], *krh = spec[6],
+           *knh = spec[7], *SnH = spec[8], *SrH = spec[9];
+    float *Draw = real[0], *Sraw = real[1], *kr = real[2], *kn = real[3], *Sn = real[4], *Sr = real[5], *t0 = real[6], *t1 = real[7];
+    if ((rc = fft_fwd(ctx, d_new, Nh)) || (rc = fft_fwd(ctx, d_ref, Rh)) || (rc = fft_fwd(ctx, d_pn, Pnh)) || (rc = fft_fwd(ctx, d_pr, Prh))) return rc;
+    hipLaunchKernelGGL(k_zogy_spec1, dim3(NB, nsub), dim3(256), 0, s, L, H, Nh, Rh, Pnh, Prh, d_sc, Dh, Sh, krh, knh, SnH, SrH, fs_partial);
+    hipLaunchKernelGGL(k_zogy_fs, dim3(nsub), dim3(64), 0, s, NB, L, fs_partial, FS);
+    if ((rc = fft_inv(ctx, Dh, Draw)) || (rc = fft_inv(ctx, Sh, Sraw)) || (rc = fft_inv(ctx, krh, kr)) || (rc = fft_inv(ctx, knh, kn)) ||
+        (rc = fft_inv(ctx, SnH, Sn)) || (rc = fft_inv(ctx, SrH, Sr))) return rc;
+    const float inv_n2 = 1.0f / ((float)L * (float)L);
+    hipLaunchKernelGGL(k_zogy_sq, dim3(2048), dim3(256), 0, s, nreal, inv_n2, kr, kn, t0, t1);
+    // reuse spectra: Vr^ -> Nh, kr2^ -> Rh, Vn^ -> Pnh, kn2^ -> Prh, products -> Dh, Sh
+    if ((rc = fft_fwd(ctx, d_vr, Nh)) || (rc = fft_fwd(ctx, t0, Rh)) || (rc = fft_fwd(ctx, d_vn, Pnh)) || (rc = fft_fwd(ctx, t1, Prh))) return rc;
+    hipLaunchKernelGGL(k_zogy_spec2, dim3(2048), dim3(256), 0, s, nspec, Nh, Rh, Pnh, Prh, Dh, Sh);
+    if ((rc = fft_inv(ctx, Dh, t0)) || (rc = fft_inv(ctx, Sh, t1))) return rc;           // VSr, VSn
+    hipLaunchKernelGGL(k_zogy_final, dim3(256, nsub), dim3(256), 0, s, L, inv_n2, d_sc, FS, Draw, Sraw, Sn, Sr, t0, t1, d_D, d_S,
+                       d_Scorr, d_Fpsf, d_Fpsferr);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_psf_optflux(bbx_ctx* ctx, int ny, int nx, const float* d_D, const float* d_V, const float* d_psfs, int S, int nsrc,
+                    const int32_t* d_ys, const int32_t* d_xs, float* d_flux, float* d_err, void* stream) {
+    if (!ctx || !d_D || !d_V || !d_psfs || !d_ys || !d_xs || !d_flux || !d_err || S < 1 || nsrc < 0) return BBX_ERR_ARG;
+    if (nsrc == 0) return BBX_OK;
+    unsigned grid = (unsigned)((nsrc + 3) / 4); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_psf_optflux, dim3(grid), dim3(256), 0, (hipStream_t)stream, ny, nx, d_D, d_V, d_psfs, S, nsrc, d_ys, d_xs, d_flux, d_err);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+}  // extern "C"

@@ -186,6 +186,52 @@ int bbx_median_stack(bbx_ctx *ctx, int64_t npix, int nframes, const float *const
                      const float *h_norm, const uint8_t *d_bpm, int flat_fix,
                      float *d_out, void *stream);
 
+/* ---- a15: background mesh (zogy.get_back / mini2back; buildref.py:2398-2405, 2480-2495) ----
+ * [EXT algorithm: conventions in oracle/zogy_core.py]
+ * bbx_bkg_boxstats: per box x box tile (box <= 64, divides ny and nx) the sigma-clipped
+ *   (median centre, 3 sigma, <= 5 iterations) median and std of the pixels with mask == 0,
+ *   objmask == 0 (optional) and value != 0; boxes with fewer than limfrac*box^2 usable
+ *   pixels are NaN.  d_mini_* : (ny/box)*(nx/box) float32.
+ * bbx_mini_fill_filter: NaN boxes <- nan-median of the 3x3 neighbourhood (repeated),
+ *   then 3x3 median filter (edge replicated), in place.
+ * bbx_spline_zoom: evaluates scipy.ndimage.zoom(order=3, mode='nearest') from prefiltered
+ *   B-spline coefficients d_coef[cny][cnx] (float64) with per-output-row / -column tap
+ *   bases d_fy/d_fx (floor index into coef) and weights d_wy/d_wx ([n][4] float64);
+ *   writes the background to d_bkg (if non-NULL) and subtracts it from d_data (if non-NULL). */
+int bbx_bkg_boxstats(bbx_ctx *ctx, int ny, int nx, int box, const float *d_data,
+                     const uint8_t *d_mask, const uint8_t *d_objmask, float limfrac,
+                     float *d_mini_med, float *d_mini_std, void *stream);
+int bbx_mini_fill_filter(bbx_ctx *ctx, int nby, int nbx, float *d_mini, void *stream);
+int bbx_spline_zoom(bbx_ctx *ctx, int ny, int nx, const double *d_coef, int cny, int cnx,
+                    const int32_t *d_fy, const double *d_wy, const int32_t *d_fx,
+                    const double *d_wx, float *d_data, float *d_bkg, void *stream);
+
+/* ---- a16: ZOGY sub-image subtraction (zogy.optimal_subtraction -> run_ZOGY; call sites
+ * blackbox.py:2350-2354, 2460-2465) with rocFFT.  [EXT algorithm: Zackay, Ofek & Gal-Yam
+ * 2016; conventions in oracle/zogy_core.py]
+ * bbx_cut_subimages / bbx_stitch_subimages: (ny/size)*(nx/size) tiles of size^2 with a
+ *   zero-padded border -> [nsub][L][L], L = size + 2*border, and back (borders dropped).
+ * bbx_zogy_subimages: per sub-image new N, ref R (background-subtracted), PSFs Pn, Pr
+ *   (unit sum, centred on pixel [0,0]), variance images Vn, Vr; h_scal[nsub][6] =
+ *   sigma_n, sigma_r, f_n, f_r, dx, dy.  Outputs D, S, S_corr, F_psf, F_psf_err.
+ *   Inputs are used as FFT sources (not modified).                                    */
+int bbx_cut_subimages(bbx_ctx *ctx, int ny, int nx, int size, int border,
+                      const float *d_img, float *d_subs, void *stream);
+int bbx_stitch_subimages(bbx_ctx *ctx, int ny, int nx, int size, int border,
+                         const float *d_subs, float *d_img, void *stream);
+int bbx_zogy_subimages(bbx_ctx *ctx, int L, int nsub, float *d_new, float *d_ref,
+                       float *d_pn, float *d_pr, float *d_vn, float *d_vr,
+                       const float *h_scal, float *d_D, float *d_S, float *d_Scorr,
+                       float *d_Fpsf, float *d_Fpsferr, void *stream);
+
+/* ---- a17: PSF-weighted optimal flux (zogy.get_psfoptflux) at integer positions:
+ * flux = sum(P D / V) / sum(P^2 / V), err = 1 / sqrt(sum(P^2 / V)) over an S x S stamp of
+ * the unit-sum PSF model d_psfs[nsrc][S][S] centred on (d_ys, d_xs); pixels off the frame
+ * or with V <= 0 are skipped.                                                          */
+int bbx_psf_optflux(bbx_ctx *ctx, int ny, int nx, const float *d_D, const float *d_V,
+                    const float *d_psfs, int S, int nsrc, const int32_t *d_ys,
+                    const int32_t *d_xs, float *d_flux, float *d_err, void *stream);
+
 /* ---- generic: number of 8-connected objects of (mask & bit) --------------------------
  * replaces ndimage.label(..., structure=ones(3,3)) counts (NOBJ-SAT 4545,
  * NCOSMICS 4355, NSATS 4230).                                                     */

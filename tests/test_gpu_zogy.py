@@ -1,0 +1,184 @@
+"""GPU: background mesh, ZOGY sub-image subtraction (rocFFT) and PSF photometry against the
+CPU restatement oracle/zogy_core.py (parity unpinned: zogy is absent)
+plus the property pins of that section: identical new/ref -> D == 0, pure noise ->
+Scorr ~ N(0,1) within the QC ranges (set_qc.py:382-383), injected source -> Fpsf = flux."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+if not torch.cuda.is_available():
+    pytest.skip('no GPU', allow_module_level=True)
+
+import zogy_core as Z                       # noqa: E402
+from blackbox_amd import reduce as R       # noqa: E402
+from blackbox_amd import zogy as G          # noqa: E402
+
+F = np.float32
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = R.Context(0)
+    yield c
+    c.close()
+
+
+def dev(ctx, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+
+
+def test_background_mesh(ctx):
+    rs = np.random.RandomState(1)
+    box, nby, nbx = 20, 12, 16
+    ny, nx = nby * box, nbx * box
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    data = (250 + 0.05 * xx + 0.02 * yy + rs.normal(0, 15, (ny, nx))).astype(F)
+    data[rs.random_sample((ny, nx)) < 0.01] += 3000          # stars / CRs the clip must reject
+    mask = np.zeros((ny, nx), np.uint8)
+    mask[40:100, 60:140] = 4                                  # fully masked boxes -> NaN -> filled
+    mask[rs.random_sample((ny, nx)) < 0.05] |= 1
+    data[200:210, 10:30] = 0                                  # zeros are excluded (mask_value = 0)
+    objmask = (rs.random_sample((ny, nx)) < 0.03).astype(np.uint8)
+    med_o, std_o = Z.get_back_mini(data, mask, objmask, box=box)
+    assert np.isnan(med_o).sum() >= 6
+    d_med, d_std = torch.empty(0), None
+    # raw box statistics
+    from blackbox_amd._lib import lib, check
+    import ctypes as C
+    m = torch.empty((nby, nbx), dtype=torch.float32, device=ctx.device)
+    s = torch.empty((nby, nbx), dtype=torch.float32, device=ctx.device)
+    t_data, t_mask, t_obj = dev(ctx, data), dev(ctx, mask), dev(ctx, objmask)      # keep alive across the launch
+    check(lib.bbx_bkg_boxstats(ctx.h, ny, nx, box, C.c_void_p(t_data.data_ptr()), C.c_void_p(t_mask.data_ptr()),
+                               C.c_void_p(t_obj.data_ptr()), 0.5, C.c_void_p(m.data_ptr()), C.c_void_p(s.data_ptr()),
+                               ctx.stream()), 'boxstats')
+    ctx.sync()
+    mh, sh = m.cpu().numpy(), s.cpu().numpy()
+    assert np.array_equal(np.isnan(mh), np.isnan(med_o))
+    ok = ~np.isnan(med_o)
+    # medians are order statistics of float32 data: exact; std: float64 sums in another order
+    assert np.array_equal(mh[ok], med_o[ok])
+    np.testing.assert_allclose(sh[ok], std_o[ok], rtol=2e-6)
+    # fill + filter, then the whole get_back
+    med_f = Z.fill_filter_mini(med_o)
+    gm, gs = G.get_back(ctx, dev(ctx, data), dev(ctx, mask), dev(ctx, objmask), bkg_boxsize=box)
+    ctx.sync()
+    assert np.array_equal(gm.cpu().numpy(), med_f)
+    np.testing.assert_allclose(gs.cpu().numpy(), Z.fill_filter_mini(std_o), rtol=2e-6)
+    # mini2back across the frame, fused with the subtraction
+    bkg_o = Z.mini2back(med_f, (ny, nx), box)
+    d_data = dev(ctx, data)
+    bkg = G.mini2back(ctx, gm, (ny, nx), bkg_boxsize=box, subtract_from=d_data)
+    ctx.sync()
+    # float64 16-tap sums rounded to float32: 1 ulp
+    np.testing.assert_allclose(bkg.cpu().numpy(), bkg_o, rtol=2.4e-7)
+    np.testing.assert_allclose(d_data.cpu().numpy(), data - bkg_o, rtol=0, atol=1e-4)
+    # per-channel zoom (interp_Xchan=False): 2 x 8 channel blocks
+    std_f = Z.fill_filter_mini(std_o)
+    b2 = G.mini2back(ctx, std_f, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
+    ctx.sync()
+    np.testing.assert_allclose(b2.cpu().numpy(), Z.mini2back(std_f, (ny, nx), box, channels=(nby // 2, nbx // 8)), rtol=2.4e-7)
+
+
+def gauss_psf(L, fwhm, dx=0.0, dy=0.0, half=12):
+    """Moffat(beta=2.5) stamp of (2*half+1)^2 pixels, like a PSFEx model image, centred on
+    pixel [0,0].  (An untruncated analytic Gaussian has a spectrum that falls to 1e-9, where
+    any single-precision FFT -- rocFFT or FFTW alike -- only carries rounding noise and
+    1/sqrt(den) amplifies it; real PSF models have a finite support and a noise floor.)"""
+    a = fwhm / (2 * np.sqrt(2 ** (1 / 2.5) - 1))
+    y = np.fft.fftfreq(L) * L
+    yy, xx = np.meshgrid(y, y, indexing='ij')
+    p = (1 + ((yy - dy) ** 2 + (xx - dx) ** 2) / (a * a)) ** -2.5
+    p[(np.abs(yy) > half) | (np.abs(xx) > half)] = 0
+    return (p / p.sum()).astype(F)
+
+
+def make_subs(L, nsub, seed, same=False, inject=None):
+    rs = np.random.RandomState(seed)
+    N, Rr, Pn, Pr, Vn, Vr, sc = [], [], [], [], [], [], []
+    for k in range(nsub):
+        sn, sr = 12.0 + k, 6.0 + 0.5 * k
+        pn, pr = gauss_psf(L, 4.0 + 0.3 * k), gauss_psf(L, 3.2)
+        truth = np.zeros((L, L))
+        for _ in range(6):                                   # static stars, present in both
+            y, x, f = rs.randint(8, L - 8), rs.randint(8, L - 8), rs.uniform(2e3, 2e4)
+            truth[y, x] += f
+        conv = lambda img, p: np.fft.ifft2(np.fft.fft2(img) * np.fft.fft2(p.astype(np.float64))).real
+        fn, fr = 1.0, 0.8 + 0.1 * k
+        new = fn * conv(truth, pn)
+        ref = fr * conv(truth, pr)
+        if inject is not None:
+            t = np.zeros((L, L)); t[inject[0], inject[1]] = inject[2]
+            new = new + fn * conv(t, pn)
+        if same:
+            ref, pr, sr, fr = new.copy(), pn.copy(), sn, fn
+            noise_n = noise_r = rs.normal(0, sn, (L, L))
+        else:
+            noise_n, noise_r = rs.normal(0, sn, (L, L)), rs.normal(0, sr, (L, L))
+        N.append(new + noise_n); Rr.append(ref + noise_r); Pn.append(pn); Pr.append(pr)
+        Vn.append(np.full((L, L), sn * sn) + np.maximum(new, 0)); Vr.append(np.full((L, L), sr * sr) + np.maximum(ref, 0))
+        sc.append([sn, sr, fn, fr, 0.05, 0.04])
+    f = lambda a: np.stack(a).astype(F)
+    return f(N), f(Rr), f(Pn), f(Pr), f(Vn), f(Vr), np.array(sc, F)
+
+
+@pytest.mark.parametrize('L', [64, 100, 75])
+def test_zogy_vs_oracle(ctx, L):
+    N, Rr, Pn, Pr, Vn, Vr, sc = make_subs(L, 3, L)
+    outs = G.run_zogy(ctx, *[dev(ctx, a) for a in (N, Rr, Pn, Pr, Vn, Vr)], sc)
+    ctx.sync()
+    outs = [o.cpu().numpy() for o in outs]
+    for k in range(3):
+        ref = Z.run_zogy(N[k], Rr[k], Pn[k], Pr[k], sc[k, 0], sc[k, 1], sc[k, 2], sc[k, 3], Vn[k], Vr[k], sc[k, 4], sc[k, 5])
+        for name, a, b in zip(('D', 'S', 'Scorr', 'Fpsf', 'Fpsferr'), [o[k] for o in outs], ref):
+            scale = np.abs(b).max()
+            # single-precision FFT pipelines of different factorisation: 2e-4 of the image scale
+            assert np.abs(a - b).max() <= 2e-4 * scale, (name, k, np.abs(a - b).max(), scale)
+
+
+def test_zogy_properties(ctx):
+    L = 128
+    # identical new and ref (same noise realisation, same PSF): D vanishes
+    N, Rr, Pn, Pr, Vn, Vr, sc = make_subs(L, 2, 7, same=True)
+    D, S, Scorr, Fpsf, Fpsferr = [o.cpu().numpy() for o in G.run_zogy(ctx, *[dev(ctx, a) for a in (N, Rr, Pn, Pr, Vn, Vr)], sc)]
+    assert np.abs(D).max() < 1e-2 * np.abs(N).max() * 1e-2
+    # pure noise: Scorr ~ N(0, 1) (QC ranges Z-SCMED 0 +- 0.3, Z-SCSTD 1 +- 0.15, set_qc.py:382-383)
+    rs = np.random.RandomState(3)
+    sn, sr = 10.0, 5.0
+    N = rs.normal(0, sn, (1, L, L)).astype(F); Rr = rs.normal(0, sr, (1, L, L)).astype(F)
+    Pn = gauss_psf(L, 4.0)[None]; Pr = gauss_psf(L, 3.0)[None]
+    Vn = np.full((1, L, L), sn * sn, F); Vr = np.full((1, L, L), sr * sr, F)
+    sc = np.array([[sn, sr, 1.0, 1.0, 0.0, 0.0]], F)
+    D, S, Scorr, Fpsf, Fpsferr = [o.cpu().numpy() for o in G.run_zogy(ctx, *[dev(ctx, a) for a in (N, Rr, Pn, Pr, Vn, Vr)], sc)]
+    assert abs(np.median(Scorr)) < 0.3 and abs(Scorr.std() - 1.0) < 0.15
+    # injected point source of known flux in the new image: Fpsf at the position = flux
+    N, Rr, Pn, Pr, Vn, Vr, sc = make_subs(L, 1, 11, inject=(60, 70, 5.0e4))
+    D, S, Scorr, Fpsf, Fpsferr = [o.cpu().numpy() for o in G.run_zogy(ctx, *[dev(ctx, a) for a in (N, Rr, Pn, Pr, Vn, Vr)], sc)]
+    assert Fpsf[0, 60, 70] == pytest.approx(5.0e4, rel=0.05)
+    assert Scorr[0, 60, 70] > 20 and np.unravel_index(np.argmax(Scorr[0]), (L, L)) == (60, 70)
+
+
+def test_cut_stitch_and_photometry(ctx):
+    rs = np.random.RandomState(2)
+    ny, nx, size, border = 96, 144, 48, 5
+    img = rs.normal(0, 1, (ny, nx)).astype(F)
+    subs = G.cut_subimages(ctx, dev(ctx, img), size, border)
+    ctx.sync()
+    assert np.array_equal(subs.cpu().numpy(), Z.cut_subimages(img, size, border))
+    back = G.stitch_subimages(ctx, subs, (ny, nx), size, border)
+    ctx.sync()
+    assert np.array_equal(back.cpu().numpy(), img)
+    # optimal flux on stamps, incl. sources at the frame edge and pixels with V <= 0
+    S, nsrc = 9, 40
+    V = np.abs(rs.normal(100, 10, (ny, nx))).astype(F)
+    V[10:14, 20:24] = 0
+    ys = rs.randint(0, ny, nsrc); xs = rs.randint(0, nx, nsrc)
+    ys[:3] = [0, ny - 1, 12]; xs[:3] = [0, nx - 1, 22]
+    psfs = np.abs(rs.normal(0, 1, (nsrc, S, S))).astype(F)
+    psfs /= psfs.sum(axis=(1, 2), keepdims=True)
+    fo, eo = Z.psf_optflux(img, V, psfs, ys, xs)
+    fg, eg = G.psf_optflux(ctx, dev(ctx, img), dev(ctx, V), dev(ctx, psfs), ys, xs)
+    ctx.sync()
+    np.testing.assert_allclose(fg.cpu().numpy(), fo, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(eg.cpu().numpy(), eo, rtol=1e-5)
