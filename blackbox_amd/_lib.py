@@ -59,10 +59,13 @@ SIGNATURES = {
     'bbx_bkg_boxstats': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'bbx_mini_fill_filter': (_i, [_vp, _i, _i, _vp, _vp]),
     'bbx_spline_zoom': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_variance': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp]),
+    'bbx_embed_psf': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_cut_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_stitch_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_zogy_subimages': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_find_peaks': (_i, [_vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_count_objects': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

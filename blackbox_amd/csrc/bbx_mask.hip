@@ -357,6 +357,66 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
     return BBX_OK;
 }
 
+// ---- peaks of connected regions of |img| >= thr (transient candidates on S_corr) ---------
+__global__ __launch_bounds__(256) void k_compact_abs(const float* __restrict__ img, size_t npix, float thr,
+                                                     uint32_t* list, int32_t* cnt, uint32_t cap, int32_t* err) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        if (fabsf(img[i]) >= thr) {                              // NaN compares false
+            const unsigned k = atomicAdd((unsigned*)cnt, 1u);
+            if (k < cap) list[k] = (uint32_t)i; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_peak(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, int cap,
+                                                 uint32_t* parent, const float* __restrict__ img,
+                                                 unsigned long long* __restrict__ best) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = list[i];
+        const uint32_t root = cc_find(parent, (uint32_t)i);
+        // largest |value| wins, ties go to the smallest pixel index (first in C order)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(fabsf(img[p])) << 32) | (0xffffffffu - p);
+        atomicMax(&best[root], key);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_peak_emit(const int32_t* __restrict__ cnt, int cap, const uint32_t* __restrict__ parent,
+                                                      const unsigned long long* __restrict__ best, const float* __restrict__ img,
+                                                      int nx, int max_out, int32_t* yx, float* val, int32_t* nout) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (parent[i] != (uint32_t)i) continue;
+        const uint32_t p = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
+        const int k = atomicAdd(nout, 1);
+        if (k < max_out) { yx[2 * k] = (int)(p / nx); yx[2 * k + 1] = (int)(p % nx); val[k] = img[p]; }
+    }
+}
+
+extern "C" int bbx_find_peaks(bbx_ctx* ctx, int ny, int nx, const float* d_img, float thr, int max_out, int32_t* d_yx,
+                              float* d_val, int32_t* d_count, void* stream) {
+    if (!ctx || !d_img || !d_yx || !d_val || !d_count || ny < 1 || nx < 1 || max_out < 1) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const size_t npix = (size_t)ny * nx;
+    if (npix >= 0xffffffffull) return BBX_ERR_ARG;
+    const size_t cap = npix / 16 + 1024;
+    uint32_t* list = (uint32_t*)bbx_ws(ctx, WS_CCLIST, cap * sizeof(uint32_t), &rc); if (rc) return rc;
+    unsigned long long* best = (unsigned long long*)bbx_ws(ctx, WS_STAGE2, cap * sizeof(unsigned long long), &rc); if (rc) return rc;
+    int32_t* cnt = &ctx->d_counters[CNT_CC_N];
+    BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
+    BBX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_compact_abs, dim3(2048), dim3(256), 0, s, d_img, npix, thr, list, cnt, (uint32_t)cap, ctx->d_err);
+    // union-find over the list (the object count itself is not needed: reuse its scratch)
+    rc = bbx_cc_count_list(ctx, list, cnt, cap, ny, nx, &ctx->d_counters[CNT_CC_ROOTS], s); if (rc) return rc;
+    uint32_t* parent = (uint32_t*)ctx->d_ws[WS_PARENT];
+    BBX_HIP(hipMemsetAsync(best, 0, cap * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_cc_peak, dim3(1024), dim3(256), 0, s, list, cnt, (int)cap, parent, d_img, best);
+    hipLaunchKernelGGL(k_cc_peak_emit, dim3(1024), dim3(256), 0, s, cnt, (int)cap, parent, best, d_img, nx, max_out, d_yx, d_val, d_count);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
 __global__ __launch_bounds__(256) void k_mask_counts(const uint8_t* __restrict__ mask, size_t n4,
                                                      unsigned long long* __restrict__ out) {
     // bits in reporting order: bad, edge, saturated, saturated-connected, satellite, cosmic

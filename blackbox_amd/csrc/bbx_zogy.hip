@@ -209,7 +209,41 @@ __global__ __launch_bounds__(256) void k_psf_optflux(int ny, int nx, const float
     }
 }
 
+// variance image of a background-subtracted frame: V = max(data, 0) + bkg_std^2
+__global__ __launch_bounds__(256) void k_variance(size_t n, const float* __restrict__ d, const float* __restrict__ sd, float* v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = sd[i];
+        v[i] = fmaxf(d[i], 0.f) + s * s;
+    }
+}
+
+// PSF stamps [nsub][S][S] (centre at S/2) -> [nsub][L][L] images centred on pixel [0,0] (wrap-around)
+__global__ __launch_bounds__(256) void k_embed_psf(int nsub, int S, int L, const float* __restrict__ st, float* __restrict__ out) {
+    const size_t n = (size_t)nsub * S * S;
+    const int h = S / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int sub = (int)(i / (S * S)), r = (int)(i % (S * S)), j = r / S, k = r % S;
+        const int y = ((j - h) % L + L) % L, x = ((k - h) % L + L) % L;
+        out[((size_t)sub * L + y) * L + x] = st[i];
+    }
+}
+
 extern "C" {
+
+int bbx_variance(bbx_ctx* ctx, int64_t n, const float* d_data, const float* d_bkgstd, float* d_var, void* stream) {
+    if (!ctx || !d_data || !d_bkgstd || !d_var || n <= 0) return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_variance, dim3(2048), dim3(256), 0, (hipStream_t)stream, (size_t)n, d_data, d_bkgstd, d_var);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_embed_psf(bbx_ctx* ctx, int nsub, int S, int L, const float* d_stamps, float* d_out, void* stream) {
+    if (!ctx || !d_stamps || !d_out || nsub < 1 || S < 1 || S > L) return BBX_ERR_ARG;
+    BBX_HIP(hipMemsetAsync(d_out, 0, (size_t)nsub * L * L * sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_embed_psf, dim3(1024), dim3(256), 0, (hipStream_t)stream, nsub, S, L, d_stamps, d_out);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
 
 int bbx_cut_subimages(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_img, float* d_subs, void* stream) {
     if (!ctx || !d_img || !d_subs || size < 1 || border < 0 || ny % size || nx % size) return BBX_ERR_ARG;

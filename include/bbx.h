@@ -215,6 +215,11 @@ int bbx_spline_zoom(bbx_ctx *ctx, int ny, int nx, const double *d_coef, int cny,
  *   (unit sum, centred on pixel [0,0]), variance images Vn, Vr; h_scal[nsub][6] =
  *   sigma_n, sigma_r, f_n, f_r, dx, dy.  Outputs D, S, S_corr, F_psf, F_psf_err.
  *   Inputs are used as FFT sources (not modified).                                    */
+/* helpers: V = max(data,0) + bkg_std^2 ; PSF stamps [nsub][S][S] -> [nsub][L][L] centred on [0,0] */
+int bbx_variance(bbx_ctx *ctx, int64_t n, const float *d_data, const float *d_bkgstd,
+                 float *d_var, void *stream);
+int bbx_embed_psf(bbx_ctx *ctx, int nsub, int S, int L, const float *d_stamps, float *d_out,
+                  void *stream);
 int bbx_cut_subimages(bbx_ctx *ctx, int ny, int nx, int size, int border,
                       const float *d_img, float *d_subs, void *stream);
 int bbx_stitch_subimages(bbx_ctx *ctx, int ny, int nx, int size, int border,
@@ -231,6 +236,13 @@ int bbx_zogy_subimages(bbx_ctx *ctx, int L, int nsub, float *d_new, float *d_ref
 int bbx_psf_optflux(bbx_ctx *ctx, int ny, int nx, const float *d_D, const float *d_V,
                     const float *d_psfs, int S, int nsrc, const int32_t *d_ys,
                     const int32_t *d_xs, float *d_flux, float *d_err, void *stream);
+
+/* ---- a17: transient candidates: 8-connected regions of |img| >= thr (|S_corr| >= T-NSIGMA,
+ * set_qc.py:387); per region the pixel of largest |value| (first in C order on ties).
+ * d_yx[max_out][2] (y, x), d_val[max_out], *d_count = number of regions (may exceed max_out,
+ * only the first max_out in arbitrary order are stored).                                  */
+int bbx_find_peaks(bbx_ctx *ctx, int ny, int nx, const float *d_img, float thr, int max_out,
+                   int32_t *d_yx, float *d_val, int32_t *d_count, void *stream);
 
 /* ---- generic: number of 8-connected objects of (mask & bit) --------------------------
  * replaces ndimage.label(..., structure=ones(3,3)) counts (NOBJ-SAT 4545,
