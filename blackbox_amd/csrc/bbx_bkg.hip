@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_bkg_boxstats(const float* __restrict__ 
     __shared__ float v[BOX_NS];
     __shared__ double red[4];
     __shared__ int redi[4];
-    __shared__ int s_a, s_b, s_n;
+    __shared__ int s_a, s_b;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int by = blockIdx.x / nbx, bx = blockIdx.x - by * nbx;
     const int npx = box * box;

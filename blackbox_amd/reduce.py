@@ -295,6 +295,23 @@ def xtalk_corr(ctx, data, coeffs, data_mask, geom):
     check(lib.bbx_xtalk(ctx.h, C.byref(geom), _ptr(data), _ptr(data_mask), cf, ctx.stream()), 'bbx_xtalk', ctx.h)
 
 
+NTHETA_SAT = 720
+
+
+def sat_detect(ctx, data, header, data_mask, header_mask):
+    """blackbox.py:4163-4254 (classical path; deterministic detector, see oracle/sattrail.py):
+    adds bit 16 to data_mask in place, sets NSATS.  Returns (nsats tensor, info tensor)."""
+    ny, nx = data.shape
+    th = np.arange(NTHETA_SAT) * (np.pi / NTHETA_SAT)
+    cs = np.empty(2 * NTHETA_SAT)
+    cs[0::2], cs[1::2] = np.cos(th), np.sin(th)
+    d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    d_info = torch.zeros(8, dtype=torch.float32, device=ctx.device)
+    check(lib.bbx_sat_trails(ctx.h, ny, nx, _ptr(data), _ptr(data_mask), cs.ctypes.data_as(C.POINTER(C.c_double)),
+                             NTHETA_SAT, _ptr(d_n), _ptr(d_info), ctx.stream()), 'bbx_sat_trails', ctx.h)
+    return d_n, d_info
+
+
 def mask_header(ctx, data_mask, header_mask):
     """blackbox.py:4601-4620"""
     d_c = torch.zeros(6, dtype=torch.int64, device=ctx.device)
@@ -333,7 +350,7 @@ def hval(header, key):
 
 def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None,
                   exptime=None, ysize_chan=None, xsize_chan=None, do_cosmics=True, crmask_override=None,
-                  accum='f32seq', stages=None):
+                  accum='f32seq', stages=None, detect_sats=True):
     """The hot path of blackbox_reduce for an 'object' frame (blackbox.py:1451-1974):
     raw device tensor -> (data, mask, header, header_mask).  Failures of a stage
     follow the reference convention: flag <STEP>-P False and carry on."""
@@ -367,11 +384,21 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
         header['XTALK-P'] = (True, 'corrected for crosstalk?')
     if stages is not None:
         stages['data_xtalk'] = data.clone()
+    d_nsats = None
+    if detect_sats and get_par(settings.detect_sats, tel):
+        try:
+            d_nsats, _ = sat_detect(ctx, data, header, mask, header_mask)
+            header['SAT-P'] = (True, 'processed for satellite trails?')
+        except _lib.BBXError:
+            header['NSATS'] = ('None', 'number of satellite trails identified')
+            header['SAT-P'] = (False, 'processed for satellite trails?')
     mask_header(ctx, mask, header_mask)
     edge_fill(ctx, data, mask, geom)
     ctx.sync()
     nobj = int(d_nobj.item())
     header_mask['NOBJ-SAT'] = header['NOBJ-SAT'] = (nobj, 'number of saturated objects')
+    if d_nsats is not None:
+        header['NSATS'] = header_mask['NSATS'] = (int(d_nsats.item()), 'number of satellite trails identified')
     if d_stats is not None:
         st = d_stats.cpu().numpy()
         t = float(exptime) if exptime else 1.0

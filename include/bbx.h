@@ -186,6 +186,18 @@ int bbx_median_stack(bbx_ctx *ctx, int64_t npix, int nframes, const float *const
                      const float *h_norm, const uint8_t *d_bpm, int flat_fix,
                      float *d_out, void *stream);
 
+/* ---- a12: satellite trails (sat_detect, blackbox.py:4163-4254) ------------------------------
+ * [EXT / unpinnable: acstools' probabilistic Hough is random, ASTA is a CNN; the deterministic
+ * detector is specified in oracle/sattrail.py]  2x2 sum binning, clipped level/sigma, edge
+ * pixels, full Hough accumulator over ntheta angles (h_cos_sin[2*k], [2*k+1] = cos, sin of
+ * theta_k, float64, supplied by the host so that both sides use the same table), strongest line
+ * with >= 200 votes and >= 0.2 x chord, perpendicular profile, strip -> bit 16 in d_mask.
+ *  d_nsats [1] i32 : 8-connected objects of bit 16 (NSATS).
+ *  d_info [8] f32  : level, sigma, votes, theta index, rho, strip lo, strip hi, found.     */
+int bbx_sat_trails(bbx_ctx *ctx, int ny, int nx, const float *d_data, uint8_t *d_mask,
+                   const double *h_cos_sin, int ntheta, int32_t *d_nsats, float *d_info,
+                   void *stream);
+
 /* ---- a15: background mesh (zogy.get_back / mini2back; buildref.py:2398-2405, 2480-2495) ----
  * [EXT algorithm: conventions in oracle/zogy_core.py]
  * bbx_bkg_boxstats: per box x box tile (box <= 64, divides ny and nx) the sigma-clipped
