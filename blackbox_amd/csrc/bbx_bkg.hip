@@ -15,6 +15,7 @@
 //                    subtraction from the frame (read 4N + write 4N).
 #include "bbx_common.h"
 #include "bbx_mednet.h"
+#include <rocprim/block/block_radix_sort.hpp>
 
 #define BOX_NS 4096
 
@@ -22,7 +23,11 @@ __global__ __launch_bounds__(256) void k_bkg_boxstats(const float* __restrict__ 
                                                       const uint8_t* __restrict__ objmask, int ny, int nx, int box,
                                                       int nbx, float limfrac, float* __restrict__ mini_med,
                                                       float* __restrict__ mini_std) {
-    __shared__ float v[BOX_NS];
+    // rocPRIM's block radix sort (256 threads x 16 keys, blocked arrangement) shares its LDS
+    // with the sorted array that the clip loop walks afterwards
+    using sort_t = rocprim::block_radix_sort<float, 256, BOX_NS / 256>;
+    __shared__ union { typename sort_t::storage_type sort; float v[BOX_NS]; } sh;
+    float* v = sh.v;
     __shared__ double red[4];
     __shared__ int redi[4];
     __shared__ int s_a, s_b;
@@ -30,7 +35,10 @@ __global__ __launch_bounds__(256) void k_bkg_boxstats(const float* __restrict__ 
     const int by = blockIdx.x / nbx, bx = blockIdx.x - by * nbx;
     const int npx = box * box;
     int cnt = 0;
-    for (int i = tid; i < BOX_NS; i += 256) {
+    float keys[BOX_NS / 256];
+#pragma unroll
+    for (int k = 0; k < BOX_NS / 256; k++) {
+        const int i = tid * (BOX_NS / 256) + k;
         float val = __builtin_huge_valf();
         if (i < npx) {
             const int y = by * box + i / box, x = bx * box + i % box;
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256) void k_bkg_boxstats(const float* __restrict__ 
             const bool rej = (mask[o] != 0) || (objmask && objmask[o] != 0) || (d == 0.f) || !(d == d);
             if (!rej) { val = d; cnt++; }
         }
-        v[i] = val;
+        keys[k] = val;
     }
     cnt = wave_sum_i32(cnt);
     if (lane == 0) redi[wid] = cnt;
@@ -50,18 +58,11 @@ __global__ __launch_bounds__(256) void k_bkg_boxstats(const float* __restrict__ 
         if (tid == 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[blockIdx.x] = nanv; mini_std[blockIdx.x] = nanv; }
         return;
     }
-    // bitonic sort (ascending; +inf padding ends up last)
-    for (int k = 2; k <= BOX_NS; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < BOX_NS / 2; t += 256) {
-                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
-                const bool up = ((i & k) == 0);
-                const float a = v[i], b = v[l];
-                if ((a > b) == up) { v[i] = b; v[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    sort_t().sort(keys, sh.sort);                        // ascending; +inf padding ends up last
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BOX_NS / 256; k++) v[tid * (BOX_NS / 256) + k] = keys[k];
+    __syncthreads();
     if (tid == 0) { s_a = 0; s_b = n0; }
     __syncthreads();
     double mean = 0.0, sd = 0.0, med = 0.0;
@@ -161,16 +162,36 @@ __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const doubl
                                                      const int32_t* __restrict__ fy, const double* __restrict__ wy,
                                                      const int32_t* __restrict__ fx, const double* __restrict__ wx,
                                                      float* data, float* bkg) {
-    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
-    if (X >= nx) return;
-    const int iy = fy[Y], ix = fx[X];
+    // the 4 coefficient rows of this output row are first folded with the row weights into a
+    // short LDS vector (a 256-pixel span touches only a handful of coefficient columns); each
+    // pixel then needs 4 taps instead of 16 strided float64 loads
+    __shared__ double rowc[512];
+    const int X0 = blockIdx.x * blockDim.x, X = X0 + threadIdx.x, Y = blockIdx.y;
+    const int iy = fy[Y];
+    const int j0 = fx[X0] - 1, j1 = fx[min(X0 + (int)blockDim.x - 1, nx - 1)] + 2;      // fx is non-decreasing
+    const int span = j1 - j0 + 1;
     double t = 0.0;
+    if (span <= 512) {
+        const double w0 = wy[Y * 4], w1 = wy[Y * 4 + 1], w2 = wy[Y * 4 + 2], w3 = wy[Y * 4 + 3];
+        for (int j = threadIdx.x; j < span; j += blockDim.x) {
+            const double* c0 = coef + (size_t)(iy - 1) * cnx + (j0 + j);
+            rowc[j] = ((c0[0] * w0 + c0[cnx] * w1) + c0[2 * (size_t)cnx] * w2) + c0[3 * (size_t)cnx] * w3;
+        }
+        __syncthreads();
+        if (X >= nx) return;
+        const int k = fx[X] - 1 - j0;
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const double wa = wy[Y * 4 + a];
-        const double* row = coef + (size_t)(iy - 1 + a) * cnx + (ix - 1);
+        for (int b = 0; b < 4; b++) t += rowc[k + b] * wx[X * 4 + b];
+    } else {
+        if (X >= nx) return;
+        const int ix = fx[X];
 #pragma unroll
-        for (int b = 0; b < 4; b++) t += row[b] * (wa * wx[X * 4 + b]);
+        for (int a = 0; a < 4; a++) {
+            const double wa = wy[Y * 4 + a];
+            const double* row = coef + (size_t)(iy - 1 + a) * cnx + (ix - 1);
+#pragma unroll
+            for (int b = 0; b < 4; b++) t += row[b] * (wa * wx[X * 4 + b]);
+        }
     }
     const float v = (float)t;
     const size_t o = (size_t)Y * nx + X;

@@ -423,7 +423,20 @@ __global__ __launch_bounds__(256) void k_mask_counts(const uint8_t* __restrict__
     const unsigned bits[6] = {1u, 32u, 4u, 8u, 16u, 2u};
     long long c[6] = {0, 0, 0, 0, 0, 0};
     const uint32_t* m4 = (const uint32_t*)mask;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n16 = n4 / 4;                                  // 16-byte groups (base is 16-B aligned or n16 = 0)
+    const uint4* m16 = (const uint4*)mask;
+    const bool al16 = (((uintptr_t)mask) & 15) == 0;
+    if (al16) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+            const uint4 w = m16[i];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const unsigned b = bits[k] * 0x01010101u;
+                c[k] += __popc(w.x & b) + __popc(w.y & b) + __popc(w.z & b) + __popc(w.w & b);
+            }
+        }
+    }
+    for (size_t i = (al16 ? n16 * 4 : 0) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t w = m4[i];
 #pragma unroll
         for (int k = 0; k < 6; k++) c[k] += __popc(w & (bits[k] * 0x01010101u));

@@ -74,41 +74,62 @@ __global__ void k_clip_update(sat_state* st, const double* __restrict__ partial,
     if (hi < st->hi) st->hi = hi;
 }
 
+// edge pixels -> compact list.  Hits are staged in LDS and flushed with one global atomic
+// per block and flush (a single global counter hammered per wave serialises badly).
+#define EDGE_STAGE 2048
 __global__ __launch_bounds__(256) void k_edge_compact(const float* __restrict__ b, size_t n, const sat_state* __restrict__ st,
                                                       uint32_t* list, int32_t* cnt, uint32_t cap, int32_t* err) {
+    __shared__ uint32_t stage[EDGE_STAGE];
+    __shared__ unsigned scnt, sbase;
     const double t0 = st->mean + 3.0 * st->std, t1 = st->mean + 50.0 * st->std;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double x = (double)b[i];
-        if (x > t0 && x < t1) {
-            const unsigned k = atomicAdd((unsigned*)cnt, 1u);
-            if (k < cap) list[k] = (uint32_t)i; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+    if (threadIdx.x == 0) scnt = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nend = ((n + stride - 1) / stride) * stride;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nend; i += stride) {
+        bool hit = false;
+        if (i < n) { const double x = (double)b[i]; hit = (x > t0 && x < t1); }
+        if (hit) { const unsigned k = atomicAdd(&scnt, 1u); stage[k] = (uint32_t)i; }      // <= 256 per round, room checked below
+        __syncthreads();
+        const unsigned c = scnt;
+        const bool last = (i + stride >= nend);
+        if (c + 256 > EDGE_STAGE || last) {
+            if (threadIdx.x == 0) sbase = c ? atomicAdd((unsigned*)cnt, c) : 0u;
+            __syncthreads();
+            for (unsigned k = threadIdx.x; k < c; k += blockDim.x) {
+                const unsigned pos = sbase + k;
+                if (pos < cap) list[pos] = stage[k]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) scnt = 0;
         }
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_hough_vote(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, uint32_t cap,
-                                                    int nxb, const double* __restrict__ cs, int ntheta, int nrho,
-                                                    unsigned* __restrict__ acc) {
+// Hough votes: one block per angle keeps the rho histogram of that angle in LDS and reports
+// only its best cell -- no global accumulator.  Order of the edge list does not matter.
+__global__ __launch_bounds__(1024) void k_hough_lds(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, uint32_t cap,
+                                                    int nxb, const double* __restrict__ cs, int nrho, sat_state* st) {
+    extern __shared__ unsigned hist[];
+    const int k = blockIdx.x;
     const uint32_t n = min((uint32_t)*cnt, cap);
+    for (int i = threadIdx.x; i < nrho; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const double c = cs[2 * k], s = cs[2 * k + 1];
     const int off = nrho / 2;
-    // block = 256 edge pixels x one theta chunk of 16
-    const int k0 = blockIdx.y * 16;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         const uint32_t p = list[e];
         const double y = (double)(p / nxb), x = (double)(p % nxb);
-        for (int k = k0; k < min(k0 + 16, ntheta); k++) {
-            const double r = x * cs[2 * k] + y * cs[2 * k + 1];
-            const int ir = (int)floor(r + 0.5) + off;
-            atomicAdd(&acc[(size_t)k * nrho + ir], 1u);
-        }
+        atomicAdd(&hist[(int)floor(x * c + y * s + 0.5) + off], 1u);
     }
-}
-
-__global__ __launch_bounds__(256) void k_hough_best(const unsigned* __restrict__ acc, size_t n, sat_state* st) {
+    __syncthreads();
     unsigned long long best = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned long long key = ((unsigned long long)acc[i] << 32) | (0xffffffffull - (unsigned long long)i);
-        if (acc[i] && key > best) best = key;
+    for (int i = threadIdx.x; i < nrho; i += blockDim.x) {
+        const unsigned v = hist[i];
+        const unsigned long long flat = (unsigned long long)k * nrho + i;
+        const unsigned long long key = ((unsigned long long)v << 32) | (0xffffffffull - flat);
+        if (v && key > best) best = key;
     }
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(best, o, 64); if (t > best) best = t; }
     if ((threadIdx.x & 63) == 0 && best) atomicMax(&st->best, best);
@@ -138,6 +159,10 @@ __global__ void k_trail_decide(sat_state* st, const double* __restrict__ cs, int
 
 __global__ __launch_bounds__(256) void k_trail_profile(const float* __restrict__ b, int nyb, int nxb, sat_state* st) {
     if (!st->accept) return;
+    __shared__ double lsum[SAT_NPROF];
+    __shared__ unsigned long long lcnt[SAT_NPROF];
+    for (int i = threadIdx.x; i < SAT_NPROF; i += blockDim.x) { lsum[i] = 0.0; lcnt[i] = 0; }
+    __syncthreads();
     const double c = st->c, s = st->s, rho = st->rho, t1 = st->mean + 50.0 * st->std;
     const size_t n = (size_t)nyb * nxb;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -146,8 +171,12 @@ __global__ __launch_bounds__(256) void k_trail_profile(const float* __restrict__
         if (d < -SAT_PROF_HALF || d > SAT_PROF_HALF) continue;
         const float f = b[i];
         if (!isfinite(f) || !((double)f < t1)) continue;
-        atomicAdd(&st->prof_sum[d + SAT_PROF_HALF], (double)f);
-        atomicAdd(&st->prof_n[d + SAT_PROF_HALF], 1ull);
+        atomicAdd(&lsum[d + SAT_PROF_HALF], (double)f);
+        atomicAdd(&lcnt[d + SAT_PROF_HALF], 1ull);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SAT_NPROF; i += blockDim.x) {
+        if (lcnt[i]) { atomicAdd(&st->prof_sum[i], lsum[i]); atomicAdd(&st->prof_n[i], lcnt[i]); }
     }
 }
 
@@ -212,7 +241,6 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     double* cs = (double*)(ws + o_cs); double* partial = (double*)(ws + o_part); sat_state* st = (sat_state*)(ws + o_st);
     int32_t* cnt = &ctx->d_counters[CNT_TMP];
     BBX_HIP(hipMemcpyAsync(cs, h_cos_sin, (size_t)ntheta * 16, hipMemcpyHostToDevice, s));
-    BBX_HIP(hipMemsetAsync(acc, 0, (size_t)ntheta * nrho * 4, s));
     BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_sat_init, dim3(1), dim3(128), 0, s, st);
     hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin);
@@ -221,8 +249,13 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
         hipLaunchKernelGGL(k_clip_update, dim3(1), dim3(64), 0, s, st, partial, SAT_BLOCKS);
     }
     hipLaunchKernelGGL(k_edge_compact, dim3(2048), dim3(256), 0, s, bin, nb, st, list, cnt, (uint32_t)cap, ctx->d_err);
-    hipLaunchKernelGGL(k_hough_vote, dim3(1024, (ntheta + 15) / 16), dim3(256), 0, s, list, cnt, (uint32_t)cap, nxb, cs, ntheta, nrho, acc);
-    hipLaunchKernelGGL(k_hough_best, dim3(1024), dim3(256), 0, s, acc, (size_t)ntheta * nrho, st);
+    if ((size_t)nrho * 4 <= 150 * 1024) {
+        // rho histogram of one angle fits in LDS (frames up to ~26k binned pixels across)
+        hipLaunchKernelGGL(k_hough_lds, dim3(ntheta), dim3(1024), (size_t)nrho * 4, s, list, cnt, (uint32_t)cap, nxb, cs, nrho, st);
+    } else {
+        return BBX_ERR_ARG;                                  // frame too large for the LDS histogram
+    }
+    (void)acc;
     hipLaunchKernelGGL(k_trail_decide, dim3(1), dim3(64), 0, s, st, cs, nrho, nyb, nxb);
     hipLaunchKernelGGL(k_trail_profile, dim3(2048), dim3(256), 0, s, bin, nyb, nxb, st);
     hipLaunchKernelGGL(k_trail_strip, dim3(1), dim3(64), 0, s, st);

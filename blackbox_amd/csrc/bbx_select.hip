@@ -350,8 +350,61 @@ __global__ __launch_bounds__(256) void k_bsel_feed_frame(const float* __restrict
     }
 }
 
+// fast feeder for 4-pixel-aligned segments: block = (segment column, strip of FEED_ROWS rows inside
+// one segment); a thread walks float4 groups, stages its in-bracket values in private LDS slots
+// (no atomics in the loop) and the block compacts them with one global atomic at the end.
+#define FEED_ROWS 16
+#define FEEDQ 24
+__global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                      int nx, bsel_dev b) {
+    __shared__ float stage[FEEDQ * 256];
+    __shared__ unsigned wsum[4], gbase;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sx = blockIdx.y, Y0 = blockIdx.x * FEED_ROWS;
+    const int sg = (Y0 / b.ysz) * b.SX + sx;
+    const float lo = b.seg[sg].lo, hi = b.seg[sg].hi;
+    const int ng = b.xsz / 4;
+    unsigned nst = 0, nvalid = 0, nbelow = 0;
+    for (int r = 0; r < FEED_ROWS; r++) {
+        const size_t row = (size_t)(Y0 + r) * nx + (size_t)sx * b.xsz;
+        for (int g = tid; g < ng; g += 256) {
+            const float4 f = *(const float4*)(data + row + 4 * g);
+            uchar4 m = make_uchar4(0, 0, 0, 0);
+            if (mask) m = *(const uchar4*)(mask + row + 4 * g);
+            const float v[4] = {f.x, f.y, f.z, f.w};
+            const uint8_t mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool valid = !(mm[q] & ~BBX_MASK_COSMIC);
+                nvalid += valid ? 1u : 0u;
+                nbelow += (valid && v[q] < lo) ? 1u : 0u;
+                if (valid && v[q] >= lo && v[q] <= hi) {
+                    if (nst < FEEDQ) { stage[nst * 256 + tid] = v[q]; nst++; }
+                    else { const unsigned k = atomicAdd(&b.seg[sg].nbuf, 1u); if (k < b.cap) b.buf[(size_t)sg * b.cap + k] = v[q]; }
+                }
+            }
+        }
+    }
+    // block compaction
+    unsigned incl = nst;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned off = 0, tot = 0;
+    for (int w = 0; w < 4; w++) { if (w < wid) off += wsum[w]; tot += wsum[w]; }
+    if (tid == 0) gbase = tot ? atomicAdd(&b.seg[sg].nbuf, tot) : 0u;
+    __syncthreads();
+    const unsigned base = gbase + off + incl - nst;
+    for (unsigned k = 0; k < nst; k++) { const unsigned pos = base + k; if (pos < b.cap) b.buf[(size_t)sg * b.cap + pos] = stage[k * 256 + tid]; }
+    bsel_acc acc = {nvalid, nbelow};
+    bsel_flush(b, sg, acc);
+}
+
 int bbx_bsel_feed_frame(const float* d_data, const uint8_t* d_mask, int ny, int nx, const bsel_dev& b, hipStream_t s) {
-    hipLaunchKernelGGL(k_bsel_feed_frame, dim3((ny + 3) / 4, b.SX), dim3(256), 0, s, d_data, d_mask, ny, nx, b);
+    const bool vec = (b.xsz % 4 == 0) && (b.xsz <= 2048) && (b.ysz % FEED_ROWS == 0) && (((uintptr_t)d_data) % 16 == 0) && (nx % 4 == 0) &&
+                     (!d_mask || ((uintptr_t)d_mask) % 4 == 0);
+    if (vec) hipLaunchKernelGGL(k_bsel_feed_v4, dim3(ny / FEED_ROWS, b.SX), dim3(256), 0, s, d_data, d_mask, nx, b);
+    else hipLaunchKernelGGL(k_bsel_feed_frame, dim3((ny + 3) / 4, b.SX), dim3(256), 0, s, d_data, d_mask, ny, nx, b);
     return BBX_OK;
 }
 

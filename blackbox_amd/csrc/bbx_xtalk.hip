@@ -10,36 +10,55 @@
 // far below the vector rate, so no MFMA reshaping).
 #include "bbx_common.h"
 
+// VEC pixels per thread and channel (4 when xsize_chan % 4 == 0: float4 / uchar4 accesses)
+template <int VEC>
 __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __restrict__ mask, bbx_dims d, f64x256 cf) {
-    const size_t total = (size_t)d.ysz * d.xsz;
+    const int ngx = d.xsz / VEC;
+    const size_t total = (size_t)d.ysz * ngx;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(t / d.xsz), x = (int)(t - (size_t)y * d.xsz);
+        const int y = (int)(t / ngx), x = (int)(t - (size_t)y * ngx) * VEC;
         size_t off[16];
-        double src[16];
-        float val[16];
-        bool victim_ok[16];
+        double src[16][VEC];
+        float val[16][VEC];
+        bool victim_ok[16][VEC];
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const int iy = c >> 3, ix = c & 7;
             const int Y = (iy == 0) ? y : (d.ysz + (d.ysz - 1 - y));
             off[c] = (size_t)Y * d.nx + (size_t)ix * d.xsz + x;
-            const float v = data[off[c]];
-            const uint8_t m = mask[off[c]];
-            val[c] = v;
-            // mask_source: positive, not bad, not cosmic (7178-7180); mask_victim: not edge (7184)
-            const bool use = (v > 0.f) && !(m & BBX_MASK_BAD) && !(m & BBX_MASK_COSMIC);
-            src[c] = use ? (double)v : 0.0;
-            victim_ok[c] = !(m & BBX_MASK_EDGE);
+            float v[VEC]; uint8_t m[VEC];
+            if (VEC == 4) {
+                const float4 f = *(const float4*)(data + off[c]);
+                const uchar4 b = *(const uchar4*)(mask + off[c]);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                m[0] = b.x; m[1] = b.y; m[2] = b.z; m[3] = b.w;
+            } else {
+                v[0] = data[off[c]]; m[0] = mask[off[c]];
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+                val[c][q] = v[q];
+                // mask_source: positive, not bad, not cosmic (7178-7180); mask_victim: not edge (7184)
+                const bool use = (v[q] > 0.f) && !(m[q] & BBX_MASK_BAD) && !(m[q] & BBX_MASK_COSMIC);
+                src[c][q] = use ? (double)v[q] : 0.0;
+                victim_ok[c][q] = !(m[q] & BBX_MASK_EDGE);
+            }
         }
 #pragma unroll
         for (int v = 0; v < 16; v++) {
-            double q_lo = 0.0, q_hi = 0.0;                     // the two K=8 quadrant products
+            float o[VEC];
 #pragma unroll
-            for (int s = 0; s < 8; s++) q_lo = fma(src[s], cf.v[s * 16 + v], q_lo);
+            for (int q = 0; q < VEC; q++) {
+                double q_lo = 0.0, q_hi = 0.0;                 // the two K=8 quadrant products
 #pragma unroll
-            for (int s = 8; s < 16; s++) q_hi = fma(src[s], cf.v[s * 16 + v], q_hi);
-            const double corr = (0.0 + q_lo) + q_hi;
-            data[off[v]] = (float)((double)val[v] - (victim_ok[v] ? corr : corr * 0.0));
+                for (int s = 0; s < 8; s++) q_lo = fma(src[s][q], cf.v[s * 16 + v], q_lo);
+#pragma unroll
+                for (int s = 8; s < 16; s++) q_hi = fma(src[s][q], cf.v[s * 16 + v], q_hi);
+                const double corr = (0.0 + q_lo) + q_hi;
+                o[q] = (float)((double)val[v][q] - (victim_ok[v][q] ? corr : corr * 0.0));
+            }
+            if (VEC == 4) *(float4*)(data + off[v]) = make_float4(o[0], o[1], o[2], o[3]);
+            else data[off[v]] = o[0];
         }
     }
 }
@@ -50,11 +69,13 @@ extern "C" int bbx_xtalk(bbx_ctx* ctx, const bbx_geom* g, float* d_data, const u
     bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
     f64x256 cf;
     for (int i = 0; i < 256; i++) cf.v[i] = h_coeffs[i];
-    const size_t total = (size_t)d.ysz * d.xsz;
+    const bool vec = false;          // measured on MI355X: the 4-wide variant is register-bound and slower
+    const size_t total = (size_t)d.ysz * (d.xsz / (vec ? 4 : 1));
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 256u * 16u) grid = 256u * 16u;
     bbx_prof_start(ctx, BBX_PROF_XTALK, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_xtalk, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    if (vec) hipLaunchKernelGGL(k_xtalk<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    else hipLaunchKernelGGL(k_xtalk<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
     bbx_prof_stop(ctx, (hipStream_t)stream);
     BBX_LAUNCH_CHECK();
     return BBX_OK;

@@ -1,0 +1,99 @@
+"""Full-size timings of every stage beyond bench.py's headline workload (BASELINE configs 3
+and 5): crosstalk, satellite trails, mask counts, edge fill, background mesh, ZOGY with 64
+sub-images of 1400^2, PSF photometry, master stack.  GPU box only.
+
+    python tools/stage_bench.py [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+import numpy as np
+
+
+def timed(torch, fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--skip-zogy', action='store_true')
+    args = ap.parse_args()
+    import torch
+    import bench
+    from blackbox_amd import masters, reduce as R, zogy as G
+    ctx = R.Context(0)
+    dev = ctx.device
+    ysz, xsz, os_y, os_x = 5280, 1320, 20, 180
+    raw, flat, bpm = bench.synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, 2000, 'u16')
+    geom = R.geometry(raw.shape, ysz, xsz)
+    N = 2 * ysz * 8 * xsz
+    out = {}
+    header, hm = {}, {}
+    R.gain_corr(header, 'ML1')
+    sol = R.os_solve(ctx, raw, header, 'ML1', geom)
+    data, mask = R.calibrate(ctx, raw, sol, header, hm, 'ML1', geom, mflat=flat, bpm=bpm)
+    R.mask_init_finish(ctx, mask, header, hm, geom)
+    R.cosmics_corr(ctx, data, header, mask, hm, 'ML1')
+    ctx.sync()
+    rs = np.random.RandomState(0)
+    coeffs = np.zeros((16, 16)); coeffs[~np.eye(16, dtype=bool)] = rs.uniform(0, 2e-4, 240)
+    GB = 1e-9
+    t = timed(torch, lambda: R.xtalk_corr(ctx, data, coeffs, mask, geom), args.reps)
+    out['xtalk'] = dict(ms=t, algorithmic_GB=9 * N * GB, GBps=9 * N * GB / (t * 1e-3))
+    t = timed(torch, lambda: R.sat_detect(ctx, data, {}, mask, {}), args.reps)
+    out['sat_trails'] = dict(ms=t)
+    t = timed(torch, lambda: R.mask_header(ctx, mask, {}), args.reps)
+    out['mask_header(incl. D2H sync)'] = dict(ms=t, algorithmic_GB=N * GB)
+    t = timed(torch, lambda: R.edge_fill(ctx, data, mask, geom), args.reps)
+    out['edge_fill'] = dict(ms=t)
+    t = timed(torch, lambda: G.get_back(ctx, data, mask), args.reps)
+    out['bkg_get_back(median+std mini)'] = dict(ms=t, algorithmic_GB=5 * N * GB)
+    mini, mini_std = G.get_back(ctx, data, mask)
+    work = data.clone()
+    t = timed(torch, lambda: G.mini2back(ctx, mini, data.shape, subtract_from=work, want_bkg=False), args.reps)
+    out['bkg_mini2back+subtract'] = dict(ms=t, algorithmic_GB=8 * N * GB)
+    frames = [flat * (1 + 0.01 * k) for k in range(15)]
+    t = timed(torch, lambda: masters.master_median(ctx, frames, 'flat', medsec=[1.0 + 0.01 * k for k in range(15)], bpm=bpm), 2)
+    out['master_flat_15'] = dict(ms=t, algorithmic_GB=(15 * 4 + 1 + 4) * N * GB, GBps=(15 * 4 + 5) * N * GB / (t * 1e-3))
+    del frames
+    if not args.skip_zogy:
+        ref = data * 0.9 + 3.0
+        S = 25
+        y, x = np.mgrid[0:S, 0:S] - S // 2
+        p = (1 + (y * y + x * x) / 4.0) ** -2.5
+        psf = torch.from_numpy(np.repeat((p / p.sum()).astype(np.float32)[None], 64, 0)).to(dev)
+        t0 = time.perf_counter()
+        res = G.optimal_subtraction(ctx, data, ref, mask, mask, psf, psf)
+        ctx.sync()
+        first = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        res = G.optimal_subtraction(ctx, data, ref, mask, mask, psf, psf)
+        ctx.sync()
+        out['optimal_subtraction(2 frames bkg + 64x1400^2 ZOGY + transients)'] = dict(ms=1e3 * (time.perf_counter() - t0), first_call_ms=first,
+                                                                                 ntrans=len(res['transients']))
+        subs = [G.cut_subimages(ctx, a) for a in (data, ref)]
+        L = subs[0].shape[1]
+        P = G.embed_psfs(ctx, psf, L)
+        V = torch.ones_like(subs[0]) * 300
+        sc = np.tile(np.array([[18, 9, 1, 1, 0.03, 0.03]], np.float32), (64, 1))
+        t = timed(torch, lambda: G.run_zogy(ctx, subs[0], subs[1], P, P, V, V, sc), 3)
+        out['run_zogy_64x%d' % L] = dict(ms=t, io_model_GB=34 * N * GB)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
