@@ -68,6 +68,101 @@ def _noop(i):
     return i
 
 
+class ShmArena:
+    """Per-slot staging buffers in one POSIX shared-memory block, registered with HIP as
+    pinned memory: the device copies straight into/out of it and the fit workers map the
+    same pages, so a fit task and its result are a few scalars instead of pickled arrays."""
+
+    FIELDS = ('mean', 'hos', 'vfit', 'oscan', 'strip')
+
+    def __init__(self, depth, dy, dx, hos_rows, xsz, name=None):
+        from multiprocessing import shared_memory
+        self.depth, self.dy, self.dx, self.hos_rows, self.xsz = depth, dy, dx, hos_rows, xsz
+        sizes = dict(mean=16 * dy * 8, hos=16 * hos_rows * dx * 4, vfit=16 * dy * 8, oscan=16 * xsz * 8,
+                     strip=16 * hos_rows * dx * 4)
+        self.off, o = {}, 0
+        for k in self.FIELDS:
+            self.off[k] = o
+            o += (sizes[k] + 4095) // 4096 * 4096
+        self.slot_bytes = o
+        self.owner = name is None
+        if self.owner:
+            self.shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * depth)
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+        self.name = self.shm.name
+        self.registered = False
+
+    def layout(self):
+        return (self.name, self.depth, self.dy, self.dx, self.hos_rows, self.xsz)
+
+    def view(self, slot, field):
+        shape, dt = {'mean': ((16, self.dy), np.float64), 'hos': ((16, self.hos_rows, self.dx), np.float32),
+                     'vfit': ((16, self.dy), np.float64), 'oscan': ((16, self.xsz), np.float64),
+                     'strip': ((16, self.hos_rows, self.dx), np.float32)}[field]
+        return np.ndarray(shape, dt, buffer=self.shm.buf, offset=slot * self.slot_bytes + self.off[field])
+
+    def register(self):
+        """hipHostRegister the block so non_blocking copies are truly asynchronous"""
+        addr = C.addressof(C.c_char.from_buffer(self.shm.buf))
+        rt = torch.cuda.cudart()
+        err = rt.cudaHostRegister(addr, self.shm.size, 0)
+        self.registered = int(err) == 0
+        self._addr = addr
+        return self.registered
+
+    def close(self):
+        if self.registered:
+            torch.cuda.cudart().cudaHostUnregister(self._addr)
+            self.registered = False
+        try:
+            self.shm.close()
+        except BufferError:
+            pass                         # numpy views still alive; the mapping goes with the process
+        if self.owner:
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
+
+
+_ARENAS = {}
+
+
+def _arena(layout):
+    a = _ARENAS.get(layout[0])
+    if a is None:
+        a = _ARENAS[layout[0]] = ShmArena(*layout[1:], name=layout[0])
+    return a
+
+
+def _shm_solve(args):
+    """worker: both phases of channel [c] of the frame staged in [slot] (ML1 path)"""
+    layout, slot, c, ysz, xsz, poldeg, tel, data_limit, accum = args
+    a = _arena(layout)
+    r = overscan.channel_solve((c, a.view(slot, 'mean')[c], a.view(slot, 'hos')[c], ysz, xsz, poldeg, tel,
+                                data_limit, accum))
+    a.view(slot, 'vfit')[c] = r.pop('fit')
+    a.view(slot, 'oscan')[c] = r.pop('oscan')
+    return r
+
+
+def _shm_phase1(args):
+    layout, slot, c, ysz, xsz, poldeg, accum = args
+    a = _arena(layout)
+    r = overscan.channel_phase1(c, a.view(slot, 'mean')[c], a.view(slot, 'hos')[c], ysz, xsz, poldeg, accum)
+    a.view(slot, 'vfit')[c] = r.pop('fit')
+    a.view(slot, 'strip')[c] = r.pop('strip')
+    return r
+
+
+def _shm_phase2(args):
+    layout, slot, c, xsz, tel, data_limit, msr, accum = args
+    a = _arena(layout)
+    a.view(slot, 'oscan')[c] = overscan.channel_phase2(c, a.view(slot, 'strip')[c], xsz, tel, data_limit, msr, accum)
+    return c
+
+
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
                  'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot')
@@ -99,17 +194,20 @@ class FramePipeline:
         # staging buffers, one set per frame in flight (pinned host + device), allocated once:
         # pin_memory()/hipHostMalloc costs ~10 ms per call and must stay out of the frame loop
         dev = ctx.device
+        self.arena = ShmArena(depth, self.dy, self.dx, self.hos_rows, self.xsz)
+        if not self.arena.register():
+            raise RuntimeError('hipHostRegister of the staging arena failed')
+        self.layout = self.arena.layout()
         self.slots = []
-        for _ in range(depth):
+        for i in range(depth):
+            hv = lambda k: torch.from_numpy(self.arena.view(i, k))
             self.slots.append(dict(
                 d_mean=torch.empty(16 * self.dy, dtype=torch.float64, device=dev),
                 d_hos=torch.empty((16, self.hos_rows, self.dx), dtype=torch.float32, device=dev),
                 d_ninf=torch.zeros(1, dtype=torch.int64, device=dev),
-                h_mean=torch.empty(16 * self.dy, dtype=torch.float64, pin_memory=True),
-                h_hos=torch.empty((16, self.hos_rows, self.dx), dtype=torch.float32, pin_memory=True),
+                h_mean=hv('mean').view(-1), h_hos=hv('hos'),
                 h_ninf=torch.empty(1, dtype=torch.int64, pin_memory=True),
-                h_vfit=torch.empty(16 * self.dy, dtype=torch.float64, pin_memory=True),
-                h_oscan=torch.empty(16 * self.xsz, dtype=torch.float64, pin_memory=True),
+                h_vfit=hv('vfit').view(-1), h_oscan=hv('oscan').view(-1),
                 d_vfit=torch.empty(16 * self.dy, dtype=torch.float64, device=dev),
                 d_oscan=torch.empty(16 * self.xsz, dtype=torch.float64, device=dev),
                 d_std=torch.empty(16, dtype=torch.float64, device=dev),
@@ -125,6 +223,8 @@ class FramePipeline:
     def close(self):
         if self.own_pool:
             self.pool.close()
+        self.slots = []
+        self.arena.close()
 
     # ---- stage A ------------------------------------------------------------------
     def _start(self, idx, raw, header):
@@ -150,15 +250,14 @@ class FramePipeline:
 
     # ---- stage B ------------------------------------------------------------------
     def _submit_fits(self, f):
-        mv = f.h_mean.numpy().reshape(16, self.dy)
-        hos = f.h_hos.numpy()
         if not self.two_phase:
-            tasks = [(c, mv[c], hos[c], self.ysz, self.xsz, settings.voscan_poldeg, self.tel, 2000, self.accum)
+            tasks = [(self.layout, f.slot, c, self.ysz, self.xsz, settings.voscan_poldeg, self.tel, 2000, self.accum)
                      for c in range(16)]
-            f.res = self.pool.submit(overscan.channel_solve, tasks)
+            f.res = self.pool.submit(_shm_solve, tasks)
         else:
-            tasks = [(c, mv[c], hos[c], self.ysz, self.xsz, settings.voscan_poldeg, self.accum) for c in range(16)]
-            f.res = self.pool.submit(overscan._phase1_star, tasks)
+            tasks = [(self.layout, f.slot, c, self.ysz, self.xsz, settings.voscan_poldeg, self.accum)
+                     for c in range(16)]
+            f.res = self.pool.submit(_shm_phase1, tasks)
         f.d_keep = None
         f.state = 'B'
 
@@ -179,12 +278,10 @@ class FramePipeline:
         """BlackGEM: per-column saturation counts need the vertical fit (two-phase)"""
         ctx, dev = self.ctx, self.ctx.device
         f.p1 = results
-        vfit = np.stack([r['fit'] for r in results])
         lim = settings.os_ypix_lim[self.tel]
         satl = np.array(get_par(settings.satlevel, self.tel)) * np.array(self.gain)
         with torch.cuda.stream(self.sC):
             sl = self.slots[f.slot]
-            sl['h_vfit'].numpy()[:] = vfit.reshape(-1)
             d_vfit = sl['d_vfit']
             d_vfit.copy_(sl['h_vfit'], non_blocking=True)
             d_cnt = sl['d_cnt']
@@ -201,25 +298,21 @@ class FramePipeline:
     def _submit_phase2(self, f):
         cnt = f.h_cnt.numpy()
         msr = (cnt[0] >= 3) | (cnt[1] >= 10)
-        tasks = [(c, f.p1[c]['strip'], self.xsz, self.tel, 2000, msr[c], self.accum) for c in range(16)]
-        f.res2 = self.pool.submit(overscan._phase2_star, tasks)
+        tasks = [(self.layout, f.slot, c, self.xsz, self.tel, 2000, msr[c], self.accum) for c in range(16)]
+        f.res2 = self.pool.submit(_shm_phase2, tasks)
         f.state = 'B2'
 
     # ---- stage C ------------------------------------------------------------------
     def _device_stage(self, f, results):
         ctx, dev, geom, tel = self.ctx, self.ctx.device, self.geom, self.tel
         self._fill_header_vos(f, results)
-        vfit = np.stack([r['fit'] for r in results])
-        oscan = np.stack([r['oscan'] for r in results])
         dlevel = np.float32([r['dlevel'] for r in results])
         h, hm = f.header, f.hm
         with torch.cuda.stream(self.sC):
             self.sC.wait_event(f.evA)
             sol = R.OverscanSolution()
-            sol.vfit, sol.oscan = vfit, oscan
             sl = self.slots[f.slot]
-            sl['h_vfit'].numpy()[:] = vfit.reshape(-1)
-            sl['h_oscan'].numpy()[:] = oscan.reshape(-1)
+            sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
             sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
             sol.d_vfit.copy_(sl['h_vfit'], non_blocking=True)
             sol.d_oscan.copy_(sl['h_oscan'], non_blocking=True)
@@ -304,9 +397,7 @@ class FramePipeline:
                     self._submit_phase2(f)
                     progressed = True
                 elif f.state == 'B2' and f.res2.ready():
-                    osc = f.res2.get()
-                    for r, o in zip(f.p1, osc):
-                        r['oscan'] = o
+                    f.res2.get()
                     self._device_stage(f, f.p1)
                     progressed = True
                 elif f.state == 'C' and f.evC.query():

@@ -1,0 +1,64 @@
+"""GPU: the pipelined throughput path (FramePipeline: device statistics -> host fit workers
+over the shared pinned arena -> device stage) must give exactly what the serial
+reduce_object gives for the same frames, for the one-phase (ML1) and the two-phase
+(BlackGEM, saturated-column step) overscan solve."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+if not torch.cuda.is_available():
+    pytest.skip('no GPU', allow_module_level=True)
+
+import bbx_oracle as O                                  # noqa: E402
+from blackbox_amd import reduce as R                    # noqa: E402
+from blackbox_amd import synth                          # noqa: E402
+from blackbox_amd.pipeline import FramePipeline, HostPool   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def pool():
+    p = HostPool(4)
+    yield p
+    p.close()
+
+
+@pytest.mark.parametrize('tel,ys,xs,os_y,os_x', [('ML1', 96, 330, 20, 45), ('BG3', 2640, 330, 20, 45)])
+def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
+    ctx = R.Context(0)
+    dev = ctx.device
+    cases = [synth.make_case(ys, xs, 100 + k, tel=tel, os_y=os_y, os_x=os_x, n_stars=60, n_sat=4, n_cr=60)
+             for k in range(4)]
+    flat = torch.from_numpy(cases[0]['flat']).to(dev)
+    bpm = torch.from_numpy(cases[0]['bpm']).to(dev)
+    coeffs = O.xtalk_coeffs(cases[0]['xtalk'])
+    raws = [torch.from_numpy(c['raw']).to(dev) for c in cases]
+    geom = R.geometry(raws[0].shape, ys, xs)
+
+    serial = []
+    for raw in raws:
+        d, m, h, hm = R.reduce_object(ctx, raw, {}, tel, mflat=flat, bpm=bpm, xtalk_coeffs=coeffs, exptime=60.0,
+                                      ysize_chan=ys, xsize_chan=xs, detect_sats=False)
+        serial.append((d.cpu().numpy(), m.cpu().numpy(), h))
+
+    pipe = FramePipeline(ctx, tel, geom, mflat=flat, bpm=bpm, xtalk_coeffs=coeffs, exptime=60.0, pool=pool,
+                         depth=3, do_finish=True, keep_outputs=True)
+    got = {}
+
+    def done(idx, f):
+        got[idx] = (f.data.cpu().numpy(), f.mask.cpu().numpy(), f.header)
+    n = pipe.run([(r, {}) for r in raws], on_done=done)
+    pipe.close()
+    assert n == len(raws) and sorted(got) == list(range(len(raws)))
+    for k in range(len(raws)):
+        d0, m0, h0 = serial[k]
+        d1, m1, h1 = got[k]
+        assert np.array_equal(m0, m1), 'frame %d: mask' % k
+        assert np.array_equal(d0, d1), 'frame %d: pixels' % k
+        keys = ['BIASMEAN', 'RDNOISE', 'NOBJ-SAT', 'NCOSMICS', 'N-INFNAN'] + \
+               ['%s%d' % (p, c + 1) for p in ('BIASM', 'RDN', 'VFITOK') for c in range(16)] + \
+               ['BIAS%dA%d' % (c + 1, j) for c in range(16) for j in range(4)]
+        for key in keys:
+            assert R.hval(h0, key) == R.hval(h1, key), (k, key)
+    ctx.close()
