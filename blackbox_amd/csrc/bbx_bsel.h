@@ -7,7 +7,10 @@
 //   3. feed     : any kernel that streams the segment anyway calls bsel_feed() per pixel:
 //                 counts values below lo and stages the values inside the bracket
 //                 (~5 % of the pixels) in LDS; bsel_drain() moves them to a side buffer
-//                 with ONE global atomic per workgroup -- no extra HBM read of the frame
+//                 with ONE global atomic per workgroup -- no extra HBM read of the frame.
+//                 Same-cache-line atomics retire at ~11 ns each on MI355X whatever the
+//                 address inside the line, so the counters and the side buffer are split
+//                 into BSEL_NSH shards (one 64-byte line each, picked by workgroup index)
 //   4. finish   : rank' = rank - below; exact radix select inside the small buffer.
 //                 If the rank fell outside the bracket (or a buffer overflowed) the
 //                 segment is flagged and the full 3-pass radix select over the frame runs
@@ -18,24 +21,50 @@
 #define BSEL_S 16384
 #define BSEL_MAXSEG 16
 #define BSEL_LBUF 6144            // LDS staging entries per workgroup (24 KB)
+#define BSEL_NSH 64               // shards per segment
 
 struct bsel_seg {
     float lo, hi;                 // closed bracket
     uint32_t nsample;             // valid samples
-    uint32_t nbuf;                // values appended (may exceed cap -> overflow -> fail)
-    unsigned long long below;     // valid values < lo
-    unsigned long long n;         // valid values
+    uint32_t nbuf;                // values in the side buffer    } sums over the shards,
+    unsigned long long below;     // valid values < lo            } formed by the plan kernel
+    unsigned long long n;         // valid values                 }
     uint32_t fail;                // 1 -> full select required
     uint32_t pad;
     float result[2];              // lower / upper middle element (ranks (n-1)/2 and n/2)
 };
 
+struct bsel_shard {               // exactly one cache line
+    uint32_t nbuf;                // values appended to this shard's region (may exceed capS -> fail)
+    uint32_t pad0;
+    unsigned long long below, n;
+    uint32_t pad[10];
+};
+
 struct bsel_dev {                 // passed by value to feeding kernels
     bsel_seg* seg;                // [nseg]
-    float* buf;                   // [nseg][cap]
-    uint32_t cap;
+    bsel_shard* shard;            // [nseg][BSEL_NSH]
+    float* buf;                   // [nseg][BSEL_NSH][capS]
+    uint32_t cap;                 // = BSEL_NSH * capS (segment stride of buf)
+    uint32_t capS;
     int ysz, xsz, SX;             // segment rectangles
 };
+
+__device__ __forceinline__ unsigned bsel_my_shard() {
+    return (blockIdx.x + blockIdx.y * gridDim.x) & (BSEL_NSH - 1);
+}
+// reserve [count] slots in shard [sh] of segment [seg]; returns the first index inside the region
+__device__ __forceinline__ unsigned bsel_reserve(const bsel_dev& b, int seg, unsigned sh, unsigned count) {
+    return atomicAdd(&b.shard[seg * BSEL_NSH + sh].nbuf, count);
+}
+__device__ __forceinline__ float* bsel_region(const bsel_dev& b, int seg, unsigned sh) {
+    return b.buf + (size_t)seg * b.cap + (size_t)sh * b.capS;
+}
+__device__ __forceinline__ void bsel_count(const bsel_dev& b, int seg, unsigned sh, unsigned n, unsigned below) {
+    bsel_shard* s = &b.shard[seg * BSEL_NSH + sh];
+    if (n) atomicAdd(&s->n, (unsigned long long)n);
+    if (below) atomicAdd(&s->below, (unsigned long long)below);
+}
 
 struct bsel_acc { unsigned n, below; };
 struct bsel_lds { float v[BSEL_LBUF]; unsigned cnt; unsigned base; };
@@ -73,15 +102,17 @@ __device__ __forceinline__ void bsel_drain(const bsel_dev& b, int seg, bsel_lds&
     __syncthreads();
     const unsigned c = L.cnt;
     if (force || c + reserve > BSEL_LBUF) {
+        const unsigned sh = bsel_my_shard();
         if (threadIdx.x == 0) {
-            L.base = c ? atomicAdd(&b.seg[seg].nbuf, c) : 0u;
+            L.base = c ? bsel_reserve(b, seg, sh, c) : 0u;
             if (c > BSEL_LBUF) atomicOr(&b.seg[seg].fail, 1u);       // staged values were dropped
         }
         __syncthreads();
         const unsigned base = L.base, n = c < BSEL_LBUF ? c : BSEL_LBUF;
+        float* reg = bsel_region(b, seg, sh);
         for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
             const unsigned pos = base + i;
-            if (pos < b.cap) b.buf[(size_t)seg * b.cap + pos] = L.v[i];
+            if (pos < b.capS) reg[pos] = L.v[i];
         }
         __syncthreads();
         if (threadIdx.x == 0) L.cnt = 0;
@@ -91,10 +122,7 @@ __device__ __forceinline__ void bsel_drain(const bsel_dev& b, int seg, bsel_lds&
 
 __device__ __forceinline__ void bsel_flush(const bsel_dev& b, int seg, bsel_acc& acc) {
     const int n = wave_sum_i32((int)acc.n), bl = wave_sum_i32((int)acc.below);
-    if ((threadIdx.x & 63) == 0) {
-        if (n) atomicAdd(&b.seg[seg].n, (unsigned long long)n);
-        if (bl) atomicAdd(&b.seg[seg].below, (unsigned long long)bl);
-    }
+    if ((threadIdx.x & 63) == 0) bsel_count(b, seg, bsel_my_shard(), (unsigned)n, (unsigned)bl);
     acc.n = 0; acc.below = 0;
 }
 

@@ -47,7 +47,9 @@ struct bbx_ctx {
     int32_t* d_err;            // [4] error flags
     // --- work lists (device).  Capacities in elements.
     uint32_t* d_satlist;  int64_t cap_satlist;   // saturated pixel indices (reduced frame)
-    int32_t*  d_counters;      // [64] device counters (see enum below)
+    void*     flags_clean_ptr; // LA-Cosmic flag plane known to be all-zero (see bbx_lacosmic)
+    size_t    flags_clean_bytes;
+    int32_t*  d_counters;      // [CNT_MAX] device counters (see enum below)
     // --- scratch, (re)allocated on demand by bbx_ws()
     void*  d_ws[16];
     size_t ws_bytes[16];
@@ -61,17 +63,19 @@ void bbx_prof_start(bbx_ctx* ctx, int slot, hipStream_t s);
 void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s);
 
 enum {
-    CNT_SAT = 0,        // saturated pixels queued by calibrate
-    CNT_CAND = 1,       // LA-Cosmic candidates of the current iteration
-    CNT_STAGE2 = 2,     // LA-Cosmic pixels that passed the first growth step
-    CNT_CRLIST = 3,     // cumulative CR pixel list
-    CNT_NEWCR = 4,      // CR pixels flagged in the current iteration
-    CNT_CC_N = 5,       // connected-component scratch: list length
-    CNT_CC_ROOTS = 6,   // connected-component scratch: roots
-    CNT_TILES = 7,      // fill-holes: unresolved tiles
-    CNT_BGNEED = 8,     // LA-Cosmic: pixels that needed the background level
-    CNT_TMP = 9,
-    CNT_MAX = 64
+    // one 64-byte line per counter: same-line atomics serialise (~11 ns each on MI355X)
+    CNT_SAT = 0,          // saturated pixels queued by calibrate
+    CNT_CAND = 16,        // LA-Cosmic candidates of the current iteration
+    CNT_STAGE2 = 32,      // LA-Cosmic pixels that passed the first growth step
+    CNT_CRLIST = 48,      // cumulative CR pixel list
+    CNT_NEWCR = 64,       // CR pixels flagged in the current iteration
+    CNT_CC_N = 80,        // connected-component scratch: list length
+    CNT_CC_ROOTS = 96,    // connected-component scratch: roots
+    CNT_TILES = 112,      // fill-holes: unresolved tiles
+    CNT_BGNEED = 128,     // LA-Cosmic: pixels that needed the background level
+    CNT_TMP = 144,
+    CNT_CANDOVF = 160,    // LA-Cosmic candidates that did not fit their tile segment
+    CNT_MAX = 256
 };
 
 // workspace slots

@@ -20,6 +20,7 @@
 //   4. k_lac_clean  masked 5x5 median at every pixel of the cumulative CR list.
 // All arithmetic is float32 in the order fixed by oracle/lacosmic.py; build with
 // -ffp-contract=off.  Results are bit-identical to the dense algorithm.
+#include <algorithm>
 #include "bbx_bsel.h"
 #include "bbx_mednet.h"
 
@@ -35,6 +36,7 @@ struct lac_par {
     int ny, nx;
     float sigclip, sigcliplow, objlim;
     const float* rnp;            // device: {float32(rn*rn), prune threshold T}
+    int dbg;
 };
 
 // L+ of pixel (j,i): 2x2 replicate -> Laplacian -> clip -> 2x2 mean, closed form with
@@ -64,15 +66,12 @@ __device__ __forceinline__ float lplus_at(const float* __restrict__ a, int j, in
 }
 
 // ---- 1. dense candidate pass ------------------------------------------------------
-// One read of the frame.  Block = 256 threads x 4 columns, walking CAND_ROWS rows with a
-// 3-row register window; left/right neighbours come from the adjacent lanes; the loads of
-// CAND_B rows are issued together to keep enough bytes in flight.  With FEED the same pass
-// feeds the bracketed select of the background level (reads the mask too; dynamic LDS =
-// sizeof(bsel_lds)).
+// One read of the frame: 5-point stencil on a rolling 3-row register window, left/right
+// neighbours from the adjacent lanes.  With FEED the same pass feeds the bracketed select
+// of the background level (reads the mask too).
 #define CAND_ROWS 32
-#define CAND_B 4
+#define CAND_PF 8       // rows of loads in flight per thread
 #define CAND_Q 8        // per-thread staging slots for candidate indices (LDS)
-#define FEED_Q 16       // per-thread staging slots for in-bracket values (LDS)
 
 // exclusive prefix sum of one value per thread over a 256-thread block
 __device__ __forceinline__ unsigned block_excl_scan256(unsigned v, unsigned* wsum, unsigned* total) {
@@ -93,140 +92,232 @@ __device__ __forceinline__ unsigned block_excl_scan256(unsigned v, unsigned* wsu
     return off + incl - v;
 }
 
-// No atomic sits in the row loop: hits are staged in per-thread LDS slots (slot-major, no
-// bank conflicts) and compacted once per block with ONE global atomic per list; a thread
-// that overflows its slots appends directly (rare: dense star cores / degenerate brackets).
+// Lane layout: a wave spans 64 x 4 columns but only lanes 1..62 produce results (248
+// columns); lanes 0 and 63 exist to hand their edge pixel to the neighbour lane (DPP wave
+// shift), so the row loop has no edge loads and no lane-dependent branch.  Out-of-image
+// lanes load from a clamped (valid) address and never produce.  Rows: rolling 3-row window
+// over CAND_ROWS rows with a ring of CAND_PF rows of loads in flight per thread.
+//
+// L+ is evaluated exactly for every pixel (packed float32 math, the operation order of
+// oracle/lacosmic.py): with T only ~2 sigma of the sky noise any cheaper upper bound of L+
+// passes in almost every wave-row, so a pre-filter only adds work.
+//
+// No global atomic on the common path: candidates are staged in per-thread LDS slots,
+// compacted inside the block and written to the block's own tile segment (tile_cnt/tile_seg);
+// k_lac_compact turns the segments into the dense list.  A tile with more than CAND_TILECAP
+// candidates, or a thread with more than CAND_Q, appends the excess to an overflow list.
+// FEED: in-bracket values go to a per-wave LDS queue; the block reserves side-buffer space
+// with one atomic on its shard (bbx_bsel.h) and copies the queues out coalesced.
+#define CAND_SPAN 248
+#define CAND_TILECAP 64
+#define FEED_WQ 1024    // per-wave LDS queue of in-bracket values (FEED)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// lane i <- lane i-1 / lane i+1 across the whole wave (DPP wave_shr:1 / wave_shl:1, one VALU
+// op); lane 0 resp. 63 receive 0
+__device__ __forceinline__ float lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// max(x, 0) as the hardware does it (IEEE maxNum: NaN -> 0, like fmaxf), without the
+// canonicalisation move clang puts in front of fmaxf
+__device__ __forceinline__ float relu_hw(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ f2 relu2(f2 x) { f2 r; r.x = relu_hw(x.x); r.y = relu_hw(x.y); return r; }
+
+// L+ of two pixels at once; same operation order as lplus_px with all four neighbours
+__device__ __forceinline__ f2 lplus2(f2 c, f2 u, f2 d, f2 l, f2 r) {
+    const f2 c4 = c * 4.0f;
+    const f2 a2 = (c4 - c) - l;            // left half:  4c - c(right replica) - l
+    const f2 a4 = (c4 - r) - c;            // right half: 4c - r - c(left replica)
+    const f2 tl = relu2((a2 - c) - u), bl = relu2((a2 - d) - c);
+    const f2 tr = relu2((a4 - c) - u), br = relu2((a4 - d) - c);
+    return (((tl + tr) + bl) + br) * 0.25f;
+}
+
 template <bool FEED>
 __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a, const uint8_t* __restrict__ mask,
-                                                     lac_par p, uint32_t* __restrict__ cand, int32_t* counters,
-                                                     uint32_t cap, int32_t* err, bsel_dev b) {
+                                                     lac_par p, uint32_t* __restrict__ tile_cnt,
+                                                     uint32_t* __restrict__ tile_seg, uint32_t* __restrict__ ovf,
+                                                     int32_t* counters, uint32_t capovf, int32_t* err, bsel_dev b) {
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     uint32_t* lcand = reinterpret_cast<uint32_t*>(dyn_lds);                       // [CAND_Q][256]
-    float* lfeed = reinterpret_cast<float*>(dyn_lds + CAND_Q * 256 * 4);          // [FEED_Q][256]
     __shared__ unsigned wsum[4];
-    __shared__ unsigned gbase[2];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ unsigned gbase;
+    __shared__ unsigned bacc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* wq = reinterpret_cast<float*>(dyn_lds + CAND_Q * 256 * 4) + wid * FEED_WQ;    // this wave's queue (FEED)
     const float T = p.rnp[1];
-    const int x0 = (blockIdx.x * 256 + tid) * 4;
-    const bool act = x0 < p.nx;                                 // nx % 4 == 0 on this path
+    const int x0 = (blockIdx.x * 4 + wid) * CAND_SPAN - 4 + lane * 4;
+    const bool prod = x0 >= 0 && x0 < p.nx && lane >= 1 && lane <= 62;      // nx % 4 == 0 on this path
+    const int xc = min(max(x0, 0), p.nx - 4);
     const int j0 = blockIdx.y * CAND_ROWS;
     const int j1 = min(j0 + CAND_ROWS, p.ny);
-    // loads are unconditional on clamped (always valid) addresses and masked afterwards: a
-    // `cond ? *ptr : zero` select makes hipcc pick between a global and a private pointer and
-    // fall back to scalar flat loads
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int xc = act ? x0 : 0;
-    float4 up = *(const float4*)(a + (size_t)max(j0 - 1, 0) * p.nx + xc);
-    float4 cur = *(const float4*)(a + (size_t)j0 * p.nx + xc);
-    if (!(act && j0 > 0)) up = zero;
-    if (!act) cur = zero;
+    const float* __restrict__ col = a + xc;
+    const uint8_t* __restrict__ mcol = mask + xc;
+    const size_t nx = (size_t)p.nx;
+    const int ylast = p.ny - 1;
+    float4 up = *(const float4*)(col + (size_t)max(j0 - 1, 0) * nx);
+    float4 cur = *(const float4*)(col + (size_t)j0 * nx);
+    float4 ring[CAND_PF];
+    uint32_t mring[CAND_PF];
+#pragma unroll
+    for (int k = 0; k < CAND_PF; k++) {
+        ring[k] = *(const float4*)(col + (size_t)min(j0 + 1 + k, ylast) * nx);
+        if (FEED) mring[k] = *(const uint32_t*)(mcol + (size_t)min(j0 + k, ylast) * nx);
+    }
     float lo = 0.f, hi = 0.f;
-    unsigned ncand = 0, nfeed = 0, nvalid = 0, nbelow = 0;
+    unsigned ncand = 0;
+    unsigned wcount = 0, wvalid = 0, wbelow = 0;               // wave-uniform (FEED)
+    const unsigned sh = bsel_my_shard();
     if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; }
     bool colok[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) colok[q] = act && (x0 + q >= 2) && (x0 + q < p.nx - 2);
-    struct batch { float4 nxt[CAND_B]; float le[CAND_B], re[CAND_B]; uchar4 mk[CAND_B]; };
-    // loads of a batch of CAND_B rows (clamped addresses, masked values)
-    auto load_batch = [&](batch& t, int jb) {
+    for (int q = 0; q < 4; q++) colok[q] = prod && (x0 + q >= 2) && (x0 + q < p.nx - 2);
+    // bits of a mask word that make a pixel invalid for the background statistics; lanes that
+    // do not produce see every pixel as invalid
+    const uint32_t badbits = 0x01010101u * (uint32_t)(0xff & ~BBX_MASK_COSMIC);
+    const uint32_t lanebad = prod ? 0u : 0xffffffffu;
+    for (int jb = j0; jb < j1; jb += CAND_PF) {
 #pragma unroll
-        for (int k = 0; k < CAND_B; k++) {
+        for (int k = 0; k < CAND_PF; k++) {
             const int j = jb + k;
-            const int jn = min(j + 1, p.ny - 1), jc = min(j, p.ny - 1);
-            t.nxt[k] = *(const float4*)(a + (size_t)jn * p.nx + xc);
-            if (!(act && j + 1 < p.ny)) t.nxt[k] = zero;
-            // one lane per wave fetches the pixel left / right of the wave's span
-            const int xe = (lane == 0) ? max(x0 - 1, 0) : min(x0 + 4, p.nx - 1);
-            float e = 0.f;
-            if ((lane == 0 || lane == 63) && act) e = a[(size_t)jc * p.nx + xe];
-            t.le[k] = (lane == 0 && x0 > 0) ? e : 0.f;
-            t.re[k] = (lane == 63 && x0 + 4 < p.nx) ? e : 0.f;
-            t.mk[k] = make_uchar4(0, 0, 0, 0);
-            if (FEED) { t.mk[k] = *(const uchar4*)(mask + (size_t)jc * p.nx + xc); }
-        }
-    };
-    auto compute_batch = [&](const batch& t, int jb) {
+            const float4 dn = ring[k];
+            uint32_t mk = 0;
+            if (FEED) mk = mring[k];
+            // refill the slot: row j+1+CAND_PF (and its mask row j+CAND_PF), clamped
+            ring[k] = *(const float4*)(col + (size_t)min(j + 1 + CAND_PF, ylast) * nx);
+            if (FEED) mring[k] = *(const uint32_t*)(mcol + (size_t)min(j + CAND_PF, ylast) * nx);
+            if (j < j1) {                                        // block-uniform
+                // the 2-pixel frame of the image never holds candidates (sp == 0 there), so every
+                // tested pixel has all four neighbours: interior form of L+
+                if (j >= 2 && j < p.ny - 2) {
+                    const float l = lane_prev(cur.w), r = lane_next(cur.x);
+                    const f2 lp01 = lplus2(f2{cur.x, cur.y}, f2{up.x, up.y}, f2{dn.x, dn.y}, f2{l, cur.x}, f2{cur.y, cur.z});
+                    const f2 lp23 = lplus2(f2{cur.z, cur.w}, f2{up.z, up.w}, f2{dn.z, dn.w}, f2{cur.y, cur.z}, f2{cur.w, r});
+                    const bool hit[4] = {colok[0] && lp01.x > T, colok[1] && lp01.y > T, colok[2] && lp23.x > T,
+                                         colok[3] && lp23.y > T};
+                    if (!(p.dbg & 2) && (hit[0] || hit[1] || hit[2] || hit[3])) {
 #pragma unroll
-        for (int k = 0; k < CAND_B; k++) {
-            const int j = jb + k;
-            if (j >= j1) break;                                  // block-uniform
-            const float4 dn = t.nxt[k];
-            float l = __shfl_up(cur.w, 1, 64), r = __shfl_down(cur.x, 1, 64);
-            if (lane == 0) l = t.le[k];
-            if (lane == 63) r = t.re[k];
-            // the 2-pixel frame of the image never holds candidates (sp == 0 there), so every
-            // tested pixel has all four neighbours: interior form of L+
-            const bool rowok = (j >= 2 && j < p.ny - 2);
-            const float c4[4] = {cur.x, cur.y, cur.z, cur.w};
-            const float u4[4] = {up.x, up.y, up.z, up.w};
-            const float d4[4] = {dn.x, dn.y, dn.z, dn.w};
-            const float l4[4] = {l, cur.x, cur.y, cur.z};
-            const float r4[4] = {cur.y, cur.z, cur.w, r};
-            const uint8_t mm[4] = {t.mk[k].x, t.mk[k].y, t.mk[k].z, t.mk[k].w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                // cheap exact-safe reject: L+ is the mean of four clipped half-Laplacians, hence
-                // <= their maximum = 2c - min(u,d) - min(l,r); the float32 roundings of either
-                // form stay below 1e-5*|4c|, which the slack term covers
-                const float c = c4[q];
-                const float quick = (c + c) - fminf(u4[q], d4[q]) - fminf(l4[q], r4[q]);
-                if (rowok && colok[q] && quick > T - 4e-5f * fabsf(c)) {
-                    const float lp = lplus_px(c, u4[q], d4[q], l4[q], r4[q], true, true, true, true);
-                    if (lp > T) {
-                        const uint32_t idx = (uint32_t)((size_t)j * p.nx + x0 + q);
-                        if (ncand < CAND_Q) { lcand[ncand * 256 + tid] = idx; ncand++; }
-                        else {
-                            const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
-                            if (kk < cap) cand[kk] = idx; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                        for (int q = 0; q < 4; q++) {
+                            if (hit[q]) {
+                                const uint32_t idx = (uint32_t)((size_t)j * nx + x0 + q);
+                                if (ncand < CAND_Q) { lcand[ncand * 256 + tid] = idx; ncand++; }
+                                else {
+                                    const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CANDOVF], 1u);
+                                    if (kk < capovf) ovf[kk] = idx; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                                }
+                            }
                         }
                     }
                 }
                 if (FEED) {
-                    const bool valid = act && !(mm[q] & ~BBX_MASK_COSMIC);
-                    const bool below = valid && c < lo;
-                    const bool inb = valid && c >= lo && c <= hi;
-                    nvalid += valid ? 1u : 0u;
-                    nbelow += below ? 1u : 0u;
-                    if (inb) {
-                        if (nfeed < FEED_Q) { lfeed[nfeed * 256 + tid] = c; nfeed++; }
-                        else {
-                            const unsigned kk = atomicAdd(&b.seg[0].nbuf, 1u);
-                            if (kk < b.cap) b.buf[kk] = c;
-                        }
+                    const float c4[4] = {cur.x, cur.y, cur.z, cur.w};
+                    const uint32_t bad = (mk & badbits) | lanebad;
+                    // room for this row's appends (at most 4 per lane)?  wave-uniform, rare
+                    if (wcount + 256u > FEED_WQ) {
+                        unsigned base = 0;
+                        if (lane == 0) base = bsel_reserve(b, 0, sh, wcount);
+                        base = __shfl(base, 0, 64);
+                        float* reg = bsel_region(b, 0, sh);
+                        for (unsigned i = lane; i < wcount; i += 64)
+                            if (base + i < b.capS) reg[base + i] = wq[i];
+                        wcount = 0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float c = c4[q];
+                        const bool valid = (bad & (0xffu << (8 * q))) == 0;
+                        const bool below = valid && c < lo;
+                        const bool inb = valid && !(c < lo) && c <= hi;
+                        wvalid += (unsigned)__popcll(__ballot(valid));
+                        wbelow += (unsigned)__popcll(__ballot(below));
+                        const unsigned long long m = __ballot(inb);
+                        if (inb) wq[wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
+                        wcount += (unsigned)__popcll(m);
                     }
                 }
             }
             up = cur; cur = dn;
         }
-    };
-    // software pipeline: the loads of the next batch are in flight while this one is computed
-    batch bA, bB;
-    load_batch(bA, j0);
-    for (int jb = j0; jb < j1; jb += 2 * CAND_B) {
-        load_batch(bB, jb + CAND_B);
-        compute_batch(bA, jb);
-        load_batch(bA, jb + 2 * CAND_B);
-        compute_batch(bB, jb + CAND_B);
     }
-    // ---- compaction: one global atomic per list and block
+    if (p.dbg & 1) return;
+    // ---- candidates -> this block's tile segment
+    const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
     unsigned total;
-    unsigned off = block_excl_scan256(ncand, wsum, &total);
-    if (tid == 0) gbase[0] = total ? atomicAdd((unsigned*)&counters[CNT_CAND], total) : 0u;
-    __syncthreads();
+    const unsigned off = block_excl_scan256(ncand, wsum, &total);
+    if (tid == 0) tile_cnt[tile] = min(total, (unsigned)CAND_TILECAP);
     for (unsigned k = 0; k < ncand; k++) {
-        const unsigned pos = gbase[0] + off + k;
-        if (pos < cap) cand[pos] = lcand[k * 256 + tid]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        const unsigned pos = off + k;
+        const uint32_t idx = lcand[k * 256 + tid];
+        if (pos < CAND_TILECAP) tile_seg[(size_t)tile * CAND_TILECAP + pos] = idx;
+        else {
+            const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CANDOVF], 1u);
+            if (kk < capovf) ovf[kk] = idx; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        }
     }
     if (FEED) {
-        off = block_excl_scan256(nfeed, wsum, &total);
-        if (tid == 0) gbase[1] = total ? atomicAdd(&b.seg[0].nbuf, total) : 0u;
+        // ---- in-bracket values: one reservation per block on its shard, queues copied coalesced
+        if (tid < 2) bacc[tid] = 0;
+        if (lane == 0) wsum[wid] = wcount;
         __syncthreads();
-        for (unsigned k = 0; k < nfeed; k++) {
-            const unsigned pos = gbase[1] + off + k;
-            if (pos < b.cap) b.buf[pos] = lfeed[k * 256 + tid];
+        if (tid == 0) {
+            const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            gbase = tot ? bsel_reserve(b, 0, sh, tot) : 0u;
         }
-        bsel_acc acc = {nvalid, nbelow};
-        bsel_flush(b, 0, acc);
+        if (lane == 0) { atomicAdd(&bacc[0], wvalid); atomicAdd(&bacc[1], wbelow); }
+        __syncthreads();
+        unsigned base = gbase;
+        for (int w = 0; w < wid; w++) base += wsum[w];
+        float* reg = bsel_region(b, 0, sh);
+        for (unsigned i = lane; i < wcount; i += 64)
+            if (base + i < b.capS) reg[base + i] = wq[i];
+        if (tid == 0) bsel_count(b, 0, sh, bacc[0], bacc[1]);
+    }
+}
+
+// tile segments (+ overflow list) -> dense candidate list.  Workgroup g owns the tiles
+// [g*tpb, (g+1)*tpb), tpb <= 256: it sums the counts of all earlier tiles itself (a few
+// KB of coalesced reads) instead of waiting for a scan, then copies its segments with one
+// independent load per (tile, slot) pair.  Workgroup 0 appends the overflow list.
+__global__ __launch_bounds__(256) void k_lac_compact(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_seg,
+                                                      int ntiles, int tpb, const uint32_t* __restrict__ ovf, uint32_t capovf,
+                                                      int32_t* counters, uint32_t* __restrict__ cand, uint32_t cap,
+                                                      int32_t* err) {
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned red[2][4];
+    __shared__ unsigned lcnt[256], lexcl[256];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int t0 = min((int)blockIdx.x * tpb, ntiles), t1 = min(t0 + tpb, ntiles);
+    unsigned before = 0, all = 0;
+    for (int t = tid; t < ntiles; t += 256) { const unsigned c = tile_cnt[t]; all += c; if (t < t0) before += c; }
+    before = (unsigned)wave_sum_i32((int)before); all = (unsigned)wave_sum_i32((int)all);
+    if (lane == 0) { red[0][wid] = before; red[1][wid] = all; }
+    const unsigned mine = (t0 + tid < t1) ? tile_cnt[t0 + tid] : 0u;
+    unsigned ltot;
+    const unsigned excl = block_excl_scan256(mine, wsum, &ltot);         // contains the barriers for red[]
+    lcnt[tid] = mine; lexcl[tid] = excl;
+    __syncthreads();
+    const unsigned base = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const unsigned tot = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const int npair = (t1 - t0) * CAND_TILECAP;
+    for (int q = tid; q < npair; q += 256) {
+        const int tl = q / CAND_TILECAP, slot = q % CAND_TILECAP;
+        if ((unsigned)slot < lcnt[tl]) {
+            const unsigned pos = base + lexcl[tl] + slot;
+            if (pos < cap) cand[pos] = tile_seg[(size_t)(t0 + tl) * CAND_TILECAP + slot];
+        }
+    }
+    if (blockIdx.x == 0) {
+        const unsigned novf = min((unsigned)counters[CNT_CANDOVF], capovf);
+        for (unsigned i = tid; i < novf; i += 256)
+            if (tot + i < cap) cand[tot + i] = ovf[i];
+        if (tid == 0) {
+            if (tot + novf > cap) atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+            counters[CNT_CAND] = (int32_t)min(tot + novf, cap);
+        }
     }
 }
 
@@ -471,13 +562,35 @@ __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __re
     }
 }
 
+// the flag plane is only ever written at listed pixels (candidates; 3x3 around stage-2
+// pixels): clearing exactly those keeps it all-zero between iterations without a memset
+__global__ __launch_bounds__(256) void k_lac_unflag(lac_par p, const uint32_t* __restrict__ cand,
+                                                    const uint32_t* __restrict__ stage2,
+                                                    const int32_t* __restrict__ counters, uint32_t cap,
+                                                    uint8_t* __restrict__ flags) {
+    const uint32_t n1 = min((uint32_t)counters[CNT_CAND], cap), n2 = min((uint32_t)counters[CNT_STAGE2], cap);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += stride) flags[cand[k]] = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < 9u * n2; k += stride) {
+        const uint32_t o = stage2[k / 9u];                   // >= 2 px inside the frame
+        const int e = (int)(k % 9u);
+        flags[(size_t)o + (size_t)((e / 3 - 1) * p.nx) + (e % 3 - 1)] = 0;
+    }
+}
+
 __global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         stats[it] = counters[CNT_NEWCR];
         stats[7] = counters[CNT_CRLIST];
         if (it < 4) { stats[8 + 2 * it] = counters[CNT_CAND]; stats[9 + 2 * it] = counters[CNT_STAGE2]; }
-        counters[CNT_NEWCR] = 0; counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0;
+        counters[CNT_NEWCR] = 0; counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CANDOVF] = 0;
     }
+}
+
+__global__ void k_lac_begin(int32_t* counters, int32_t* stats) {
+    const int t = threadIdx.x;
+    if (t < 16) stats[t] = 0;
+    if (t == 0) { counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0; counters[CNT_CANDOVF] = 0; }
 }
 
 // readnoise -> {rn2, T} on the device.  With d_rdn16 the read noise is the float32 image of
@@ -513,49 +626,62 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     if (npix >= 0xffffffffull || ((uintptr_t)d_mask) % 4) return BBX_ERR_ARG;
     int rc;
     lac_par p;
+    { const char* e = getenv("BBX_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.ny = ny; p.nx = nx; p.sigclip = sigclip; p.sigcliplow = sigfrac * sigclip; p.objlim = objlim;
     float* rnp = (float*)bbx_ws(ctx, WS_MISC, 64, &rc); if (rc) return rc;
     p.rnp = rnp;
     hipLaunchKernelGGL(k_lac_rn, dim3(1), dim3(64), 0, s, readnoise, d_rdn16, sigclip, rnp);
     const size_t cap = npix / 4 + 4096;
-    uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, cap * 4, &rc); if (rc) return rc;
+    const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
+    const int nwx = (nx + CAND_SPAN - 1) / CAND_SPAN;             // waves along x
+    const dim3 gvec((nwx + 3) / 4, (ny + CAND_ROWS - 1) / CAND_ROWS);
+    const size_t ntiles = (size_t)gvec.x * gvec.y, capovf = cap / 4 + 4096;
+    // candidate workspace: dense list | overflow list | per-tile counts | per-tile segments
+    uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (cap + capovf + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
+    uint32_t* ovf = cand + cap;
+    uint32_t* tile_cnt = ovf + capovf;
+    uint32_t* tile_seg = tile_cnt + ((ntiles + 63) / 64) * 64;
     uint32_t* stage2 = (uint32_t*)bbx_ws(ctx, WS_STAGE2, cap * 4, &rc); if (rc) return rc;
     uint32_t* crlist = (uint32_t*)bbx_ws(ctx, WS_CRLIST, cap * 4, &rc); if (rc) return rc;
     uint8_t* flags = (uint8_t*)bbx_ws(ctx, WS_FLAGS, npix + 16, &rc); if (rc) return rc;
     int32_t* cnt = ctx->d_counters;
-    BBX_HIP(hipMemsetAsync(d_stats, 0, 16 * sizeof(int32_t), s));
-    BBX_HIP(hipMemsetAsync(&cnt[CNT_CAND], 0, 4 * sizeof(int32_t), s));      // CAND, STAGE2, CRLIST, NEWCR
+    hipLaunchKernelGGL(k_lac_begin, dim3(1), dim3(64), 0, s, cnt, d_stats);
+    // the flag plane is kept all-zero between calls (k_lac_unflag); zero it when it is new
+    if (ctx->flags_clean_ptr != flags || ctx->flags_clean_bytes < npix) BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
+    ctx->flags_clean_ptr = nullptr;
     // background level of the unmasked input pixels (needed when a CR pixel has no good
     // neighbour): bracketed select fed by the first candidate pass, no extra read of the frame
     bsel_dev bs;
     rc = bbx_bsel_prepare(ctx, d_data, d_mask, ny, nx, ny, nx, &bs, s);
     if (rc) return rc;
     const unsigned gdense = 256u * 16u, gsparse = 256u * 8u;
-    const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
-    const dim3 gvec((nx / 4 + 255) / 256, (ny + CAND_ROWS - 1) / CAND_ROWS);
     for (int it = 0; it < niter; it++) {
-        BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
         bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
         if (it == 0) {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), (CAND_Q + FEED_Q) * 256 * 4, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), CAND_Q * 256 * 4 + 4 * FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
-            bbx_prof_stop(ctx, s);
-            rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s);
-            if (rc) return rc;
         } else {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), CAND_Q * 256 * 4, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), CAND_Q * 256 * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
-            bbx_prof_stop(ctx, s);
         }
+        bbx_prof_stop(ctx, s);
+        if (vec) {
+            const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, (ntiles + 127) / 128));
+            hipLaunchKernelGGL(k_lac_compact, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(256), 0, s, tile_cnt, tile_seg, (int)ntiles,
+                               tpb, ovf, (uint32_t)capovf, cnt, cand, (uint32_t)cap, ctx->d_err);
+        }
+        if (it == 0) { rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s); if (rc) return rc; }
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_grow2, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
+        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand, stage2, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_iter_end, dim3(1), dim3(64), 0, s, cnt, d_stats, it);
         bbx_prof_stop(ctx, s);
     }
+    ctx->flags_clean_ptr = flags; ctx->flags_clean_bytes = npix;
     BBX_LAUNCH_CHECK();
     // NCOSMICS: 8-connected objects of the CR pixels (blackbox.py:4354-4356)
     return bbx_cc_count_list(ctx, crlist, &cnt[CNT_CRLIST], cap, ny, nx, &d_stats[6], s);

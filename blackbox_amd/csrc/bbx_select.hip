@@ -96,8 +96,9 @@ __device__ void wg_select2(const float* __restrict__ v, uint32_t count, unsigned
 // ---------------------------------------------------------------------------------
 // bracketed select: sample, bracket
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bsel_init(bsel_seg* seg, int nseg) {
-    const int i = threadIdx.x;
+__global__ __launch_bounds__(256) void k_bsel_init(bsel_seg* seg, bsel_shard* shard, int nseg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nseg * BSEL_NSH) { bsel_shard z; memset(&z, 0, sizeof(z)); shard[i] = z; }
     if (i < nseg) {
         bsel_seg s;
         s.lo = 0.f; s.hi = 0.f; s.nsample = 0; s.nbuf = 0; s.below = 0; s.n = 0; s.fail = 0; s.pad = 0;
@@ -149,27 +150,77 @@ __global__ __launch_bounds__(1024) void k_bsel_bracket(bsel_seg* seg, const floa
 // finish: ranks, then 3 digit passes; source = side buffer, or the frame for segments
 // whose bracket failed
 // ---------------------------------------------------------------------------------
+// Digits are taken from key - klo, where [klo, khi] are the keys of the bracket: the values
+// in a side buffer span only B = bitlength(khi - klo) bits (typically 16-18 for a sky
+// bracket), so ceil(B/11) passes resolve the rank and their histograms are spread over
+// many bins (no hot bin, no atomic pile-up).  Failed segments use klo = 0, B = 32.
 struct sel_args {
     const float* data; const uint8_t* mask;
     int nx, ysz, xsz, SX;
-    int shift, bits; uint32_t himask;
+    int pass;
     bsel_dev b;
     uint32_t* prefix;                         // prefix[seg][2]
     unsigned long long* rank;                 // rank[seg][2] (remaining)
     uint32_t* hist;                           // hist[seg][2][SEL_BINS]
+    uint32_t* klo;                            // klo[seg]
+    int* nbits;                               // B[seg]
 };
+
+// digit of pass p for a segment with B significant bits: false when the pass is not needed
+struct sel_digit { int shift, bits; uint32_t dmask; bool fold; };
+__device__ __forceinline__ bool sel_digit_of(int B, int pass, sel_digit* d) {
+    const int rem = B - 11 * pass;
+    if (rem <= 0) return false;
+    d->bits = rem < 11 ? rem : 11;
+    d->shift = rem - d->bits;
+    d->dmask = (1u << d->bits) - 1u;
+    d->fold = (pass == 0 && B > 24);          // exponent-level digit: sky-dominated data pile into few bins
+    return true;
+}
+// do the bits above the current digit equal the prefix chosen so far?
+__device__ __forceinline__ bool sel_match(uint32_t key, uint32_t prefix, const sel_digit& d) {
+    const int hs = d.shift + d.bits;
+    return hs >= 32 ? true : ((key >> hs) == (prefix >> hs));
+}
 
 __global__ void k_sel_plan(sel_args a, int nseg) {
     const int sg = threadIdx.x;
     if (sg >= nseg) return;
     bsel_seg* s = &a.b.seg[sg];
-    const unsigned long long n = s->n, below = s->below;
+    unsigned long long n = 0, below = 0, nbuf = 0;
+    bool over = false;
+    for (int sh = 0; sh < BSEL_NSH; sh++) {
+        const bsel_shard* q = &a.b.shard[sg * BSEL_NSH + sh];
+        n += q->n; below += q->below; nbuf += q->nbuf;
+        over |= q->nbuf > a.b.capS;
+    }
+    s->n = n; s->below = below; s->nbuf = (uint32_t)nbuf;
     const unsigned long long k0 = n ? (n - 1) / 2 : 0, k1 = n / 2;
-    const uint32_t nbuf = s->nbuf;
-    if (s->fail || nbuf > a.b.cap || k0 < below || k1 >= below + nbuf) s->fail = 1;
+    if (s->fail || over || k0 < below || k1 >= below + nbuf) s->fail = 1;
     a.rank[sg * 2] = s->fail ? k0 : k0 - below;
     a.rank[sg * 2 + 1] = s->fail ? k1 : k1 - below;
     a.prefix[sg * 2] = a.prefix[sg * 2 + 1] = 0;
+    uint32_t klo = 0; int B = 32;
+    if (!s->fail) {
+        klo = f2key(s->lo);
+        const uint32_t range = f2key(s->hi) - klo;
+        B = range ? 32 - __clz(range) : 1;
+    }
+    a.klo[sg] = klo; a.nbits[sg] = B;
+}
+
+__device__ __forceinline__ void sel_hist_one(uint32_t* lh0, uint32_t* lh1, uint32_t key, bool in, uint32_t pre0, uint32_t pre1,
+                                             const sel_digit& d) {
+    const uint32_t bin = (key >> d.shift) & d.dmask;
+    const bool h0 = in && sel_match(key, pre0, d);
+    const bool h1 = in && pre1 != pre0 && sel_match(key, pre1, d);
+    if (d.fold) {
+        hist_add(lh0, bin, h0);
+        if (pre1 != pre0) hist_add(lh1, bin, h1);
+    } else {
+        if (h0) atomicAdd(&lh0[bin], 1u);
+        if (h1) atomicAdd(&lh1[bin], 1u);
+    }
 }
 
 // histogram of one key digit over the side buffers (segments that did not fail)
@@ -178,24 +229,27 @@ __global__ __launch_bounds__(256) void k_sel_hist_buf(sel_args a) {
     const int sg = blockIdx.y;
     const bsel_seg* s = &a.b.seg[sg];
     if (s->fail) return;
-    const uint32_t count = s->nbuf;
-    const uint32_t per = (count + gridDim.x - 1) / gridDim.x;
-    const uint32_t i0 = blockIdx.x * per, i1 = min(count, i0 + per);
+    sel_digit d;
+    if (!sel_digit_of(a.nbits[sg], a.pass, &d)) return;
+    // gridDim.x = BSEL_NSH * bps blocks: bps blocks share one shard's region
+    const int bps = gridDim.x / BSEL_NSH, sh = blockIdx.x / bps;
+    const uint32_t count = min(a.b.shard[sg * BSEL_NSH + sh].nbuf, a.b.capS);
+    const uint32_t per = (count + bps - 1) / bps;
+    const uint32_t i0 = (blockIdx.x % bps) * per, i1 = min(count, i0 + per);
     if (i0 >= i1) return;
+    const int nb2 = 2 << d.bits;
     for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1];
-    const uint32_t dmask = (1u << a.bits) - 1u;
-    const float* v = a.b.buf + (size_t)sg * a.b.cap;
+    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1], klo = a.klo[sg];
+    const float* v = bsel_region(a.b, sg, sh);
     const uint32_t span = ((i1 - i0 + 63u) / 64u) * 64u;
     for (uint32_t k = threadIdx.x; k < span; k += blockDim.x) {
         const bool in = i0 + k < i1;
-        const uint32_t key = in ? f2key(v[i0 + k]) : 0u;
-        const uint32_t bin = (key >> a.shift) & dmask;
-        hist_add(lh[0], bin, in && ((key & a.himask) == pre0));
-        if (pre1 != pre0) hist_add(lh[1], bin, in && ((key & a.himask) == pre1));
+        const uint32_t key = in ? f2key(v[i0 + k]) - klo : 0u;
+        sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
     }
     __syncthreads();
+    (void)nb2;
     for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
         const uint32_t c = (&lh[0][0])[i];
         if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
@@ -208,19 +262,18 @@ __global__ __launch_bounds__(256) void k_sel_hist_frame(sel_args a) {
     const int Y = blockIdx.x, sx = blockIdx.y;
     const int sg = (Y / a.ysz) * a.SX + sx;
     if (!a.b.seg[sg].fail) return;
+    sel_digit d;
+    if (!sel_digit_of(a.nbits[sg], a.pass, &d)) return;
     for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1];
+    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1], klo = a.klo[sg];
     const size_t row = (size_t)Y * a.nx + (size_t)sx * a.xsz;
-    const uint32_t dmask = (1u << a.bits) - 1u;
     const int xend = ((a.xsz + 63) / 64) * 64;
     for (int x = threadIdx.x; x < xend; x += blockDim.x) {
         bool in = x < a.xsz;
         if (in && a.mask && (a.mask[row + x] & ~BBX_MASK_COSMIC)) in = false;
-        const uint32_t key = in ? f2key(a.data[row + x]) : 0u;
-        const uint32_t bin = (key >> a.shift) & dmask;
-        hist_add(lh[0], bin, in && ((key & a.himask) == pre0));
-        if (pre1 != pre0) hist_add(lh[1], bin, in && ((key & a.himask) == pre1));
+        const uint32_t key = in ? f2key(a.data[row + x]) - klo : 0u;
+        sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
@@ -229,21 +282,23 @@ __global__ __launch_bounds__(256) void k_sel_hist_frame(sel_args a) {
     }
 }
 
-__global__ __launch_bounds__(128) void k_sel_scan(sel_args a, int last) {
+__global__ __launch_bounds__(128) void k_sel_scan(sel_args a) {
     const int sg = blockIdx.x;
+    sel_digit d;
+    if (!sel_digit_of(a.nbits[sg], a.pass, &d)) return;
     const int q = threadIdx.x >> 6;
     const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1];
     uint32_t* h0 = a.hist + (size_t)sg * 2 * SEL_BINS;
     const uint32_t* h = (q == 1 && pre1 == pre0) ? h0 : h0 + q * SEL_BINS;
-    const int nb = 1 << a.bits;
+    const int nb = d.bits < 6 ? 64 : (1 << d.bits);           // wave_find_bin wants a multiple of 64 (upper bins are empty)
     int b = 0; unsigned long long rin = 0, total = 0;
     const bool found = wave_find_bin(h, nb, a.rank[sg * 2 + q], &b, &rin, &total);
     __syncthreads();                                         // both waves have read prefix/hist
     if (found) {
         a.rank[sg * 2 + q] = rin;
-        const uint32_t pre = (q ? pre1 : pre0) | (((uint32_t)b) << a.shift);
+        const uint32_t pre = (q ? pre1 : pre0) | (((uint32_t)b) << d.shift);
         a.prefix[sg * 2 + q] = pre;
-        if (last) a.b.seg[sg].result[q] = key2f(pre);
+        if (d.shift == 0) a.b.seg[sg].result[q] = key2f(a.klo[sg] + pre);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * nb; k += 128) h0[(k / nb) * SEL_BINS + (k % nb)] = 0;
@@ -253,20 +308,26 @@ __global__ void k_sel_zero(uint32_t* hist, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hist[i] = 0;
 }
 
-static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, float** samples, float** buf,
-                     uint32_t** prefix, unsigned long long** rank, uint32_t** hist) {
+static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, bsel_shard** shard, float** samples, float** buf,
+                     uint32_t** prefix, unsigned long long** rank, uint32_t** hist, uint32_t** klo, int** nbits) {
     int rc;
-    const size_t o_seg = 0;
+    static_assert(sizeof(bsel_shard) == 64, "one cache line per shard");
+    const size_t o_shard = 0;
+    const size_t o_seg = o_shard + (size_t)BSEL_MAXSEG * BSEL_NSH * sizeof(bsel_shard);
     const size_t o_rank = o_seg + BSEL_MAXSEG * sizeof(bsel_seg);
     const size_t o_prefix = o_rank + BSEL_MAXSEG * 2 * sizeof(unsigned long long);
-    const size_t o_hist = o_prefix + BSEL_MAXSEG * 2 * sizeof(uint32_t);
+    const size_t o_klo = o_prefix + BSEL_MAXSEG * 2 * sizeof(uint32_t);
+    const size_t o_nbits = o_klo + BSEL_MAXSEG * sizeof(uint32_t);
+    const size_t o_hist = o_nbits + BSEL_MAXSEG * sizeof(int);
     const size_t o_samples = o_hist + (size_t)BSEL_MAXSEG * 2 * SEL_BINS * 4;
     const size_t o_buf = o_samples + (size_t)nseg * BSEL_S * 4;
     const size_t total = o_buf + (size_t)nseg * cap * 4;
     char* ws = (char*)bbx_ws(ctx, WS_SEL, total, &rc);
     if (rc) return rc;
+    *shard = (bsel_shard*)(ws + o_shard);
     *seg = (bsel_seg*)(ws + o_seg); *rank = (unsigned long long*)(ws + o_rank);
     *prefix = (uint32_t*)(ws + o_prefix); *hist = (uint32_t*)(ws + o_hist);
+    *klo = (uint32_t*)(ws + o_klo); *nbits = (int*)(ws + o_nbits);
     *samples = (float*)(ws + o_samples); *buf = (float*)(ws + o_buf);
     return BBX_OK;
 }
@@ -278,38 +339,38 @@ int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, i
     if (nseg > BSEL_MAXSEG) return BBX_ERR_ARG;
     // side buffer: 1/8 of the segment (the bracket holds ~5 %), at least 64k values
     const size_t segpix = (size_t)ysz * xsz;
-    uint32_t cap = (uint32_t)(segpix / 8 + 65536);
-    bsel_seg* seg; float *samples, *buf; uint32_t *prefix, *hist; unsigned long long* rank;
-    int rc = ws_layout(ctx, nseg, cap, &seg, &samples, &buf, &prefix, &rank, &hist);
+    // split over BSEL_NSH shards (workgroups pick shards round-robin; 2x headroom per shard)
+    const uint32_t capS = (uint32_t)(((segpix / 8 + 65536) / BSEL_NSH + 1023) / 1024 * 1024);
+    const uint32_t cap = capS * BSEL_NSH;
+    bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
+    int rc = ws_layout(ctx, nseg, cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bsel_init, dim3(1), dim3(256), 0, s, seg, nseg);
+    hipLaunchKernelGGL(k_bsel_init, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg);
     hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, nx, ysz, xsz, SX, seg, samples);
     hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
     BBX_LAUNCH_CHECK();
-    out->seg = seg; out->buf = buf; out->cap = cap; out->ysz = ysz; out->xsz = xsz; out->SX = SX;
+    out->seg = seg; out->shard = shard; out->buf = buf; out->cap = cap; out->capS = capS; out->ysz = ysz; out->xsz = xsz; out->SX = SX;
     return BBX_OK;
 }
 
 int bbx_bsel_finish(bbx_ctx* ctx, const bsel_dev& b, const float* d_data, const uint8_t* d_mask, int ny, int nx,
                     hipStream_t s) {
     const int SX = b.SX, nseg = SX * (ny / b.ysz);
-    bsel_seg* seg; float *samples, *buf; uint32_t *prefix, *hist; unsigned long long* rank;
-    int rc = ws_layout(ctx, nseg, b.cap, &seg, &samples, &buf, &prefix, &rank, &hist);
+    bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
+    int rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
     if (rc) return rc;
     sel_args a;
     a.data = d_data; a.mask = d_mask; a.nx = nx; a.ysz = b.ysz; a.xsz = b.xsz; a.SX = SX;
-    a.b = b; a.prefix = prefix; a.rank = rank; a.hist = hist;
+    a.b = b; a.prefix = prefix; a.rank = rank; a.hist = hist; a.klo = klo; a.nbits = nbits; a.pass = 0;
     hipLaunchKernelGGL(k_sel_zero, dim3(32), dim3(256), 0, s, hist, nseg * 2 * SEL_BINS);
     hipLaunchKernelGGL(k_sel_plan, dim3(1), dim3(64), 0, s, a, nseg);
-    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
-    uint32_t himask = 0;
-    const int bufblocks = nseg == 1 ? 512 : 64;
+    const int bufblocks = BSEL_NSH * (nseg == 1 ? 8 : 1);
+    // up to 3 digits of <= 11 bits; segments whose bracket spans fewer bits skip the later passes
     for (int p = 0; p < 3; p++) {
-        a.shift = shifts[p]; a.bits = nbits[p]; a.himask = himask;
+        a.pass = p;
         hipLaunchKernelGGL(k_sel_hist_buf, dim3(bufblocks, nseg), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_sel_hist_frame, dim3(ny, SX), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_sel_scan, dim3(nseg), dim3(128), 0, s, a, p == 2);
-        himask |= ((1u << nbits[p]) - 1u) << shifts[p];
+        hipLaunchKernelGGL(k_sel_scan, dim3(nseg), dim3(128), 0, s, a);
     }
     BBX_LAUNCH_CHECK();
     return BBX_OK;
@@ -363,6 +424,8 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
     const int sx = blockIdx.y, Y0 = blockIdx.x * FEED_ROWS;
     const int sg = (Y0 / b.ysz) * b.SX + sx;
     const float lo = b.seg[sg].lo, hi = b.seg[sg].hi;
+    const unsigned sh = bsel_my_shard();
+    float* reg = bsel_region(b, sg, sh);
     const int ng = b.xsz / 4;
     unsigned nst = 0, nvalid = 0, nbelow = 0;
     for (int r = 0; r < FEED_ROWS; r++) {
@@ -380,7 +443,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
                 nbelow += (valid && v[q] < lo) ? 1u : 0u;
                 if (valid && v[q] >= lo && v[q] <= hi) {
                     if (nst < FEEDQ) { stage[nst * 256 + tid] = v[q]; nst++; }
-                    else { const unsigned k = atomicAdd(&b.seg[sg].nbuf, 1u); if (k < b.cap) b.buf[(size_t)sg * b.cap + k] = v[q]; }
+                    else { const unsigned k = bsel_reserve(b, sg, sh, 1u); if (k < b.capS) reg[k] = v[q]; }
                 }
             }
         }
@@ -392,10 +455,10 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
     __syncthreads();
     unsigned off = 0, tot = 0;
     for (int w = 0; w < 4; w++) { if (w < wid) off += wsum[w]; tot += wsum[w]; }
-    if (tid == 0) gbase = tot ? atomicAdd(&b.seg[sg].nbuf, tot) : 0u;
+    if (tid == 0) gbase = tot ? bsel_reserve(b, sg, sh, tot) : 0u;
     __syncthreads();
     const unsigned base = gbase + off + incl - nst;
-    for (unsigned k = 0; k < nst; k++) { const unsigned pos = base + k; if (pos < b.cap) b.buf[(size_t)sg * b.cap + pos] = stage[k * 256 + tid]; }
+    for (unsigned k = 0; k < nst; k++) { const unsigned pos = base + k; if (pos < b.capS) reg[pos] = stage[k * 256 + tid]; }
     bsel_acc acc = {nvalid, nbelow};
     bsel_flush(b, sg, acc);
 }

@@ -60,7 +60,7 @@ class HostPool:
         return self.pool.map_async(fn, tasks, chunksize=1)
 
     def close(self):
-        self.pool.terminate()
+        self.pool.close()                   # workers exit after their queue drains (no SIGTERM)
         self.pool.join()
 
 

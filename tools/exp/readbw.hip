@@ -1,0 +1,83 @@
+// Read-bandwidth probes on a 10560x10560 float frame (446 MB): what does the memory system
+// give for (a) a flat grid-stride float4 stream, (b) the row-window tiling of k_lac_cand
+// (256 threads x float4 per row, R rows per block, PF rows in flight)?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void k_flat(const float4* __restrict__ a, size_t n4, float* out) {
+    float s = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        s += v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w + v2.x + v2.y + v2.z + v2.w + v3.x + v3.y + v3.z + v3.w;
+    }
+    for (; i < n4; i += stride) { const float4 v = a[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 123.456f) out[0] = s;
+}
+
+// contiguous chunk per block: block b reads [b*chunk, (b+1)*chunk) float4s, 8 loads in flight
+__global__ __launch_bounds__(256) void k_chunk(const float4* __restrict__ a, size_t n4, int per_thread, float* out) {
+    float s = 0.f;
+    const size_t base = (size_t)blockIdx.x * 256 * per_thread + threadIdx.x;
+    for (int k = 0; k < per_thread; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const size_t i = base + (size_t)(k + u) * 256; v[u] = a[i < n4 ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int PF>
+__global__ __launch_bounds__(256) void k_rows(const float* __restrict__ a, int ny, int nx, int R, float* out) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int xc = x0 < nx ? x0 : 0;
+    const int j0 = blockIdx.y * R;
+    const float* col = a + xc;
+    float4 ring[PF];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PF; k++) ring[k] = *(const float4*)(col + (size_t)min(j0 + k, ny - 1) * nx);
+    for (int jb = j0; jb < j0 + R; jb += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const float4 v = ring[k];
+            ring[k] = *(const float4*)(col + (size_t)min(jb + k + PF, ny - 1) * nx);
+            s += v.x + v.y + v.z + v.w;
+        }
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
+int main() {
+    const int ny = 10560, nx = 10560;
+    const size_t n = (size_t)ny * nx;
+    float *d, *o;
+    CK(hipMalloc(&d, n * 4 + 4096)); CK(hipMalloc(&o, 64));
+    CK(hipMemset(d, 0, n * 4));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](const char* name, auto launch) {
+        launch(); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < 10; r++) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        printf("%-34s %8.1f us  %6.2f TB/s\n", name, ms * 1e3, n * 4 / (ms * 1e-3) / 1e12);
+    };
+    for (int g : {1024, 2048, 4096, 8192, 16384})
+        { char nm[64]; snprintf(nm, 64, "flat grid=%d", g); timeit(nm, [&] { hipLaunchKernelGGL(k_flat, dim3(g), dim3(256), 0, 0, (const float4*)d, n / 4, o); }); }
+    for (int pt : {8, 16, 32, 64})
+        { char nm[64]; snprintf(nm, 64, "chunk per_thread=%d", pt); const int g = (int)((n / 4 + 256 * pt - 1) / (256 * pt));
+          timeit(nm, [&] { hipLaunchKernelGGL(k_chunk, dim3(g), dim3(256), 0, 0, (const float4*)d, n / 4, pt, o); }); }
+    for (int R : {8, 16, 32, 64, 128}) {
+        char nm[64];
+        const dim3 g((nx / 4 + 255) / 256, ny / R);
+        snprintf(nm, 64, "rows R=%d PF=4", R); timeit(nm, [&] { hipLaunchKernelGGL(k_rows<4>, g, dim3(256), 0, 0, d, ny, nx, R, o); });
+        snprintf(nm, 64, "rows R=%d PF=8", R); timeit(nm, [&] { hipLaunchKernelGGL(k_rows<8>, g, dim3(256), 0, 0, d, ny, nx, R, o); });
+    }
+    return 0;
+}

@@ -1,7 +1,7 @@
 """Summarise a rocprofv3 --kernel-trace --stats CSV directory: per-frame kernel times."""
 import csv, glob, sys
 d, nframes = sys.argv[1], float(sys.argv[2])
-f = glob.glob(d + '/*/*_kernel_stats.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_stats.csv') + glob.glob(d + '/*_kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 tot = 0
 for r in rows:
