@@ -36,7 +36,6 @@ struct lac_par {
     int ny, nx;
     float sigclip, sigcliplow, objlim;
     const float* rnp;            // device: {float32(rn*rn), prune threshold T}
-    int dbg;
 };
 
 // L+ of pixel (j,i): 2x2 replicate -> Laplacian -> clip -> 2x2 mean, closed form with
@@ -69,9 +68,16 @@ __device__ __forceinline__ float lplus_at(const float* __restrict__ a, int j, in
 // One read of the frame: 5-point stencil on a rolling 3-row register window, left/right
 // neighbours from the adjacent lanes.  With FEED the same pass feeds the bracketed select
 // of the background level (reads the mask too).
-#define CAND_ROWS 32
+#ifndef CAND_ROWS
+#define CAND_ROWS 16
+#endif
+#ifndef CAND_PF
 #define CAND_PF 8       // rows of loads in flight per thread
-#define CAND_Q 8        // per-thread staging slots for candidate indices (LDS)
+#endif
+#ifndef CAND_WPE
+#define CAND_WPE 1
+#endif
+#define CAND_WQ 512      // per-wave LDS queue of candidate indices
 
 // exclusive prefix sum of one value per thread over a 256-thread block
 __device__ __forceinline__ unsigned block_excl_scan256(unsigned v, unsigned* wsum, unsigned* total) {
@@ -102,12 +108,13 @@ __device__ __forceinline__ unsigned block_excl_scan256(unsigned v, unsigned* wsu
 // oracle/lacosmic.py): with T only ~2 sigma of the sky noise any cheaper upper bound of L+
 // passes in almost every wave-row, so a pre-filter only adds work.
 //
-// No global atomic on the common path: candidates are staged in per-thread LDS slots,
-// compacted inside the block and written to the block's own tile segment (tile_cnt/tile_seg);
+// No global atomic on the common path: candidates are queued per wave in LDS (they come in
+// clusters: star cores) and written to the wave's own tile segment (tile_cnt/tile_seg);
 // k_lac_compact turns the segments into the dense list.  A tile with more than CAND_TILECAP
-// candidates, or a thread with more than CAND_Q, appends the excess to an overflow list.
-// FEED: in-bracket values go to a per-wave LDS queue; the block reserves side-buffer space
-// with one atomic on its shard (bbx_bsel.h) and copies the queues out coalesced.
+// candidates appends the excess to an overflow list with one atomic per wave.
+// FEED: in-bracket values go to a second per-wave LDS queue; the wave reserves side-buffer
+// space with one atomic on its shard (bbx_bsel.h) and copies the queue out coalesced.
+// One wave per workgroup: no barrier anywhere, waves retire independently.
 #define CAND_SPAN 248
 #define CAND_TILECAP 64
 #define FEED_WQ 1024    // per-wave LDS queue of in-bracket values (FEED)
@@ -138,19 +145,16 @@ __device__ __forceinline__ f2 lplus2(f2 c, f2 u, f2 d, f2 l, f2 r) {
 }
 
 template <bool FEED>
-__global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __restrict__ a, const uint8_t* __restrict__ mask,
                                                      lac_par p, uint32_t* __restrict__ tile_cnt,
                                                      uint32_t* __restrict__ tile_seg, uint32_t* __restrict__ ovf,
                                                      int32_t* counters, uint32_t capovf, int32_t* err, bsel_dev b) {
     extern __shared__ __align__(16) unsigned char dyn_lds[];
-    uint32_t* lcand = reinterpret_cast<uint32_t*>(dyn_lds);                       // [CAND_Q][256]
-    __shared__ unsigned wsum[4];
-    __shared__ unsigned gbase;
-    __shared__ unsigned bacc[2];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float* wq = reinterpret_cast<float*>(dyn_lds + CAND_Q * 256 * 4) + wid * FEED_WQ;    // this wave's queue (FEED)
+    uint32_t* lcand = reinterpret_cast<uint32_t*>(dyn_lds);                       // [CAND_WQ]
+    const int lane = threadIdx.x;                                                 // one wave per workgroup
+    float* wq = reinterpret_cast<float*>(dyn_lds + CAND_WQ * 4);              // queue of in-bracket values (FEED)
     const float T = p.rnp[1];
-    const int x0 = (blockIdx.x * 4 + wid) * CAND_SPAN - 4 + lane * 4;
+    const int x0 = blockIdx.x * CAND_SPAN - 4 + lane * 4;
     const bool prod = x0 >= 0 && x0 < p.nx && lane >= 1 && lane <= 62;      // nx % 4 == 0 on this path
     const int xc = min(max(x0, 0), p.nx - 4);
     const int j0 = blockIdx.y * CAND_ROWS;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
         if (FEED) mring[k] = *(const uint32_t*)(mcol + (size_t)min(j0 + k, ylast) * nx);
     }
     float lo = 0.f, hi = 0.f;
-    unsigned ncand = 0;
+    unsigned wcand = 0;                                        // wave-uniform
     unsigned wcount = 0, wvalid = 0, wbelow = 0;               // wave-uniform (FEED)
     const unsigned sh = bsel_my_shard();
     if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; }
@@ -180,7 +184,11 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
     // do not produce see every pixel as invalid
     const uint32_t badbits = 0x01010101u * (uint32_t)(0xff & ~BBX_MASK_COSMIC);
     const uint32_t lanebad = prod ? 0u : 0xffffffffu;
-    for (int jb = j0; jb < j1; jb += CAND_PF) {
+    // fully unrolled (no loop back-edge): with a rolled loop the register renaming at the
+    // back-edge makes hipcc wait for all outstanding loads once per batch
+#pragma unroll
+    for (int jbi = 0; jbi < CAND_ROWS / CAND_PF; jbi++) {
+        const int jb = j0 + jbi * CAND_PF;
 #pragma unroll
         for (int k = 0; k < CAND_PF; k++) {
             const int j = jb + k;
@@ -199,17 +207,24 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
                     const f2 lp23 = lplus2(f2{cur.z, cur.w}, f2{up.z, up.w}, f2{dn.z, dn.w}, f2{cur.y, cur.z}, f2{cur.w, r});
                     const bool hit[4] = {colok[0] && lp01.x > T, colok[1] && lp01.y > T, colok[2] && lp23.x > T,
                                          colok[3] && lp23.y > T};
-                    if (!(p.dbg & 2) && (hit[0] || hit[1] || hit[2] || hit[3])) {
+                    // wave-level queue in LDS: candidates come in clusters (star cores), so the
+                    // staging is per wave, not per lane; wcand is wave-uniform
+                    if (__ballot(hit[0] || hit[1] || hit[2] || hit[3])) {
+                        const uint32_t idx0 = (uint32_t)((size_t)j * nx + x0);
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            if (hit[q]) {
-                                const uint32_t idx = (uint32_t)((size_t)j * nx + x0 + q);
-                                if (ncand < CAND_Q) { lcand[ncand * 256 + tid] = idx; ncand++; }
-                                else {
-                                    const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CANDOVF], 1u);
-                                    if (kk < capovf) ovf[kk] = idx; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
-                                }
+                            const unsigned long long m = __ballot(hit[q]);
+                            if (hit[q]) lcand[wcand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idx0 + q;
+                            wcand += (unsigned)__popcll(m);
+                        }
+                        if (wcand + 256u > CAND_WQ) {            // no room for another row: spill the queue (rare)
+                            unsigned base = 0;
+                            if (lane == 0) base = atomicAdd((unsigned*)&counters[CNT_CANDOVF], wcand);
+                            base = __shfl(base, 0, 64);
+                            for (unsigned i = lane; i < wcand; i += 64) {
+                                if (base + i < capovf) ovf[base + i] = lcand[i]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
                             }
+                            wcand = 0;
                         }
                     }
                 }
@@ -243,38 +258,29 @@ __global__ __launch_bounds__(256) void k_lac_cand_v4(const float* __restrict__ a
             up = cur; cur = dn;
         }
     }
-    if (p.dbg & 1) return;
-    // ---- candidates -> this block's tile segment
+    // ---- candidates -> this wave's tile segment; what does not fit goes to the overflow list
     const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
-    unsigned total;
-    const unsigned off = block_excl_scan256(ncand, wsum, &total);
-    if (tid == 0) tile_cnt[tile] = min(total, (unsigned)CAND_TILECAP);
-    for (unsigned k = 0; k < ncand; k++) {
-        const unsigned pos = off + k;
-        const uint32_t idx = lcand[k * 256 + tid];
-        if (pos < CAND_TILECAP) tile_seg[(size_t)tile * CAND_TILECAP + pos] = idx;
-        else {
-            const unsigned kk = atomicAdd((unsigned*)&counters[CNT_CANDOVF], 1u);
-            if (kk < capovf) ovf[kk] = idx; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+    const unsigned nseg = min(wcand, (unsigned)CAND_TILECAP);
+    if (lane == 0) tile_cnt[tile] = nseg;
+    for (unsigned i = lane; i < nseg; i += 64) tile_seg[(size_t)tile * CAND_TILECAP + i] = lcand[i];
+    if (wcand > nseg) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd((unsigned*)&counters[CNT_CANDOVF], wcand - nseg);
+        base = __shfl(base, 0, 64);
+        for (unsigned i = nseg + lane; i < wcand; i += 64) {
+            const unsigned pos = base + i - nseg;
+            if (pos < capovf) ovf[pos] = lcand[i]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
         }
     }
     if (FEED) {
-        // ---- in-bracket values: one reservation per block on its shard, queues copied coalesced
-        if (tid < 2) bacc[tid] = 0;
-        if (lane == 0) wsum[wid] = wcount;
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            gbase = tot ? bsel_reserve(b, 0, sh, tot) : 0u;
-        }
-        if (lane == 0) { atomicAdd(&bacc[0], wvalid); atomicAdd(&bacc[1], wbelow); }
-        __syncthreads();
-        unsigned base = gbase;
-        for (int w = 0; w < wid; w++) base += wsum[w];
+        // ---- in-bracket values: one reservation on the wave's shard, queue copied coalesced
+        unsigned base = 0;
+        if (lane == 0 && wcount) base = bsel_reserve(b, 0, sh, wcount);
+        base = __shfl(base, 0, 64);
         float* reg = bsel_region(b, 0, sh);
         for (unsigned i = lane; i < wcount; i += 64)
             if (base + i < b.capS) reg[base + i] = wq[i];
-        if (tid == 0) bsel_count(b, 0, sh, bacc[0], bacc[1]);
+        if (lane == 0) bsel_count(b, 0, sh, wvalid, wbelow);
     }
 }
 
@@ -292,7 +298,16 @@ __global__ __launch_bounds__(256) void k_lac_compact(const uint32_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int t0 = min((int)blockIdx.x * tpb, ntiles), t1 = min(t0 + tpb, ntiles);
     unsigned before = 0, all = 0;
-    for (int t = tid; t < ntiles; t += 256) { const unsigned c = tile_cnt[t]; all += c; if (t < t0) before += c; }
+    // tile_cnt is 16-byte aligned and padded with zeros to a multiple of 4 entries
+    const uint4* tc4 = reinterpret_cast<const uint4*>(tile_cnt);
+    const int n4 = (ntiles + 3) / 4;
+#pragma unroll 4
+    for (int g = tid; g < n4; g += 256) {
+        const uint4 c = tc4[g];
+        const int t = 4 * g;
+        all += c.x + c.y + c.z + c.w;
+        before += (t < t0 ? c.x : 0u) + (t + 1 < t0 ? c.y : 0u) + (t + 2 < t0 ? c.z : 0u) + (t + 3 < t0 ? c.w : 0u);
+    }
     before = (unsigned)wave_sum_i32((int)before); all = (unsigned)wave_sum_i32((int)all);
     if (lane == 0) { red[0][wid] = before; red[1][wid] = all; }
     const unsigned mine = (t0 + tid < t1) ? tile_cnt[t0 + tid] : 0u;
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(256) void k_lac_compact(const uint32_t* __restrict_
     const unsigned base = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const unsigned tot = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const int npair = (t1 - t0) * CAND_TILECAP;
+#pragma unroll 4
     for (int q = tid; q < npair; q += 256) {
         const int tl = q / CAND_TILECAP, slot = q % CAND_TILECAP;
         if ((unsigned)slot < lcnt[tl]) {
@@ -587,9 +603,10 @@ __global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
     }
 }
 
-__global__ void k_lac_begin(int32_t* counters, int32_t* stats) {
+__global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint32_t* tile_cnt_pad) {
     const int t = threadIdx.x;
     if (t < 16) stats[t] = 0;
+    if (t < 4 && tile_cnt_pad) tile_cnt_pad[t] = 0;          // k_lac_compact reads the counts four at a time
     if (t == 0) { counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0; counters[CNT_CANDOVF] = 0; }
 }
 
@@ -626,26 +643,25 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     if (npix >= 0xffffffffull || ((uintptr_t)d_mask) % 4) return BBX_ERR_ARG;
     int rc;
     lac_par p;
-    { const char* e = getenv("BBX_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.ny = ny; p.nx = nx; p.sigclip = sigclip; p.sigcliplow = sigfrac * sigclip; p.objlim = objlim;
     float* rnp = (float*)bbx_ws(ctx, WS_MISC, 64, &rc); if (rc) return rc;
     p.rnp = rnp;
     hipLaunchKernelGGL(k_lac_rn, dim3(1), dim3(64), 0, s, readnoise, d_rdn16, sigclip, rnp);
-    const size_t cap = npix / 4 + 4096;
+    const size_t cap = (npix / 4 + 4096) & ~(size_t)63;
     const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
     const int nwx = (nx + CAND_SPAN - 1) / CAND_SPAN;             // waves along x
-    const dim3 gvec((nwx + 3) / 4, (ny + CAND_ROWS - 1) / CAND_ROWS);
+    const dim3 gvec(nwx, (ny + CAND_ROWS - 1) / CAND_ROWS);                 // one wave per workgroup
     const size_t ntiles = (size_t)gvec.x * gvec.y, capovf = cap / 4 + 4096;
     // candidate workspace: dense list | overflow list | per-tile counts | per-tile segments
-    uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (cap + capovf + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
+    uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (cap + capovf + 64 + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
     uint32_t* ovf = cand + cap;
-    uint32_t* tile_cnt = ovf + capovf;
+    uint32_t* tile_cnt = ovf + ((capovf + 63) / 64) * 64;               // 16-byte aligned (cap is a multiple of 4)
     uint32_t* tile_seg = tile_cnt + ((ntiles + 63) / 64) * 64;
     uint32_t* stage2 = (uint32_t*)bbx_ws(ctx, WS_STAGE2, cap * 4, &rc); if (rc) return rc;
     uint32_t* crlist = (uint32_t*)bbx_ws(ctx, WS_CRLIST, cap * 4, &rc); if (rc) return rc;
     uint8_t* flags = (uint8_t*)bbx_ws(ctx, WS_FLAGS, npix + 16, &rc); if (rc) return rc;
     int32_t* cnt = ctx->d_counters;
-    hipLaunchKernelGGL(k_lac_begin, dim3(1), dim3(64), 0, s, cnt, d_stats);
+    hipLaunchKernelGGL(k_lac_begin, dim3(1), dim3(64), 0, s, cnt, d_stats, tile_cnt + ntiles);
     // the flag plane is kept all-zero between calls (k_lac_unflag); zero it when it is new
     if (ctx->flags_clean_ptr != flags || ctx->flags_clean_bytes < npix) BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
     ctx->flags_clean_ptr = nullptr;
@@ -658,10 +674,10 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     for (int it = 0; it < niter; it++) {
         bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
         if (it == 0) {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(256), CAND_Q * 256 * 4 + 4 * FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
         } else {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(256), CAND_Q * 256 * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
         }
         bbx_prof_stop(ctx, s);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cmath>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 __global__ __launch_bounds__(256) void k_flat(const float4* __restrict__ a, size_t n4, float* out) {
@@ -53,6 +54,53 @@ __global__ __launch_bounds__(256) void k_rows(const float* __restrict__ a, int n
     if (s == 123.456f) out[0] = s;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float lane_next(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); }
+__device__ __forceinline__ float relu_hw(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ f2 relu2(f2 x) { f2 r; r.x = relu_hw(x.x); r.y = relu_hw(x.y); return r; }
+__device__ __forceinline__ f2 lplus2(f2 c, f2 u, f2 d, f2 l, f2 r) {
+    const f2 c4 = c * 4.0f;
+    const f2 a2 = (c4 - c) - l, a4 = (c4 - r) - c;
+    const f2 tl = relu2((a2 - c) - u), bl = relu2((a2 - d) - c), tr = relu2((a4 - c) - u), br = relu2((a4 - d) - c);
+    return (((tl + tr) + bl) + br) * 0.25f;
+}
+// MODE 0: loads only; 1: + L+ of the 4 pixels (count hits); 2: half of the L+ work (2 of 4 pixels)
+template <int PF, int MODE, int BLK>
+__global__ __launch_bounds__(BLK) void k_lp(const float* __restrict__ a, int ny, int nx, int R, float T, unsigned* out) {
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)) * 248 - 4 + lane * 4;
+    const int xc = min(max(x0, 0), nx - 4);
+    const int j0 = blockIdx.y * R;
+    const float* col = a + xc;
+    float4 up = *(const float4*)(col + (size_t)max(j0 - 1, 0) * nx);
+    float4 cur = *(const float4*)(col + (size_t)j0 * nx);
+    float4 ring[PF];
+    unsigned hits = 0;
+#pragma unroll
+    for (int k = 0; k < PF; k++) ring[k] = *(const float4*)(col + (size_t)min(j0 + 1 + k, ny - 1) * nx);
+    for (int jb = j0; jb < j0 + R; jb += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const float4 dn = ring[k];
+            ring[k] = *(const float4*)(col + (size_t)min(jb + k + 1 + PF, ny - 1) * nx);
+            if (MODE == 0) { hits += (cur.x + up.y + dn.z > T) ? 1u : 0u; }
+            else {
+                const float l = lane_prev(cur.w), r = lane_next(cur.x);
+                const f2 lp01 = lplus2(f2{cur.x, cur.y}, f2{up.x, up.y}, f2{dn.x, dn.y}, f2{l, cur.x}, f2{cur.y, cur.z});
+                bool h = lp01.x > T || lp01.y > T;
+                if (MODE == 1) {
+                    const f2 lp23 = lplus2(f2{cur.z, cur.w}, f2{up.z, up.w}, f2{dn.z, dn.w}, f2{cur.y, cur.z}, f2{cur.w, r});
+                    h = h || lp23.x > T || lp23.y > T;
+                }
+                if (h) hits++;
+            }
+            up = cur; cur = dn;
+        }
+    }
+    if (hits > 1000000u) out[0] = hits;
+}
+
 int main() {
     const int ny = 10560, nx = 10560;
     const size_t n = (size_t)ny * nx;
@@ -78,6 +126,25 @@ int main() {
         const dim3 g((nx / 4 + 255) / 256, ny / R);
         snprintf(nm, 64, "rows R=%d PF=4", R); timeit(nm, [&] { hipLaunchKernelGGL(k_rows<4>, g, dim3(256), 0, 0, d, ny, nx, R, o); });
         snprintf(nm, 64, "rows R=%d PF=8", R); timeit(nm, [&] { hipLaunchKernelGGL(k_rows<8>, g, dim3(256), 0, 0, d, ny, nx, R, o); });
+    }
+    unsigned* oo = (unsigned*)o;
+    {   // realistic data: sky 1000 +- 33
+        std::vector<float> h(n);
+        unsigned st = 12345u;
+        for (size_t i = 0; i < n; i++) { st = st * 1664525u + 1013904223u; float u1 = ((st >> 8) + 1) / 16777217.0f; st = st * 1664525u + 1013904223u; float u2 = (st >> 8) / 16777216.0f;
+            h[i] = 1000.f + 33.f * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2); }
+        CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    const float T = 72.f;
+    for (int R : {16, 32}) {
+        char nm[64];
+        const int nwx = (nx + 247) / 248;
+        const dim3 g4((nwx + 3) / 4, ny / R), g1(nwx, ny / R);
+        snprintf(nm, 64, "lp R=%d PF=8 blk256 loads", R); timeit(nm, [&] { hipLaunchKernelGGL((k_lp<8, 0, 256>), g4, dim3(256), 0, 0, d, ny, nx, R, T, oo); });
+        snprintf(nm, 64, "lp R=%d PF=8 blk256 half", R); timeit(nm, [&] { hipLaunchKernelGGL((k_lp<8, 2, 256>), g4, dim3(256), 0, 0, d, ny, nx, R, T, oo); });
+        snprintf(nm, 64, "lp R=%d PF=8 blk256 full", R); timeit(nm, [&] { hipLaunchKernelGGL((k_lp<8, 1, 256>), g4, dim3(256), 0, 0, d, ny, nx, R, T, oo); });
+        snprintf(nm, 64, "lp R=%d PF=4 blk256 full", R); timeit(nm, [&] { hipLaunchKernelGGL((k_lp<4, 1, 256>), g4, dim3(256), 0, 0, d, ny, nx, R, T, oo); });
+        snprintf(nm, 64, "lp R=%d PF=8 blk64 full", R); timeit(nm, [&] { hipLaunchKernelGGL((k_lp<8, 1, 64>), g1, dim3(64), 0, 0, d, ny, nx, R, T, oo); });
     }
     return 0;
 }
