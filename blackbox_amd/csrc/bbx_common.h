@@ -105,20 +105,38 @@ struct f64x256 { double v[256]; };
     } while (0)
 
 // ---- device helpers -------------------------------------------------------------
+// Wave-wide sums, result in every lane.  Inside each 16-lane row the partial sums travel by
+// DPP row rotations (plain VALU moves, no LDS crossbar like __shfl/ds_bpermute); the four row
+// totals are then read with v_readlane and added in row order.
+template <int CTRL> __device__ __forceinline__ int dpp_mov_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = dpp_mov_i32<CTRL>(__double2loint(v)), hi = dpp_mov_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#define BBX_DPP_ROR(n) (0x120 + (n))          // row_ror:n
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov_f64<BBX_DPP_ROR(1)>(v);
+    v += dpp_mov_f64<BBX_DPP_ROR(2)>(v);
+    v += dpp_mov_f64<BBX_DPP_ROR(4)>(v);
+    v += dpp_mov_f64<BBX_DPP_ROR(8)>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov_i32<BBX_DPP_ROR(1)>(v);
+    v += dpp_mov_i32<BBX_DPP_ROR(2)>(v);
+    v += dpp_mov_i32<BBX_DPP_ROR(4)>(v);
+    v += dpp_mov_i32<BBX_DPP_ROR(8)>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    // counts: two 32-bit halves would need carries; the callers' totals fit 2^53 exactly
+    return (long long)wave_sum_f64((double)v);
 }
 
 // byte-wide atomic OR through the aligned 32-bit word (little endian)

@@ -146,7 +146,7 @@ __device__ __forceinline__ f2 lplus2(f2 c, f2 u, f2 d, f2 l, f2 r) {
 
 template <bool FEED>
 __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __restrict__ a, const uint8_t* __restrict__ mask,
-                                                     lac_par p, uint32_t* __restrict__ tile_cnt,
+                                                     lac_par p, uint8_t* __restrict__ tile_cnt,
                                                      uint32_t* __restrict__ tile_seg, uint32_t* __restrict__ ovf,
                                                      int32_t* counters, uint32_t capovf, int32_t* err, bsel_dev b) {
     extern __shared__ __align__(16) unsigned char dyn_lds[];
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
     }
     float lo = 0.f, hi = 0.f;
     unsigned wcand = 0;                                        // wave-uniform
-    unsigned wcount = 0, wvalid = 0, wbelow = 0;               // wave-uniform (FEED)
+    unsigned wcount = 0;                                       // wave-uniform (FEED)
+    unsigned lvalid = 0, lbelow = 0;                           // per lane (FEED)
     const unsigned sh = bsel_my_shard();
     if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; }
     bool colok[4];
@@ -241,14 +242,16 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
                             if (base + i < b.capS) reg[base + i] = wq[i];
                         wcount = 0;
                     }
+                    // valid pixels of this lane in the row: 4 - (number of non-zero bytes of bad)
+                    const uint32_t nzb = (((bad & 0x7f7f7f7fu) + 0x7f7f7f7fu) | bad) & 0x80808080u;
+                    lvalid += 4u - (unsigned)__popc(nzb);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const float c = c4[q];
-                        const bool valid = (bad & (0xffu << (8 * q))) == 0;
+                        const bool valid = (nzb & (0x80u << (8 * q))) == 0;
                         const bool below = valid && c < lo;
                         const bool inb = valid && !(c < lo) && c <= hi;
-                        wvalid += (unsigned)__popcll(__ballot(valid));
-                        wbelow += (unsigned)__popcll(__ballot(below));
+                        lbelow += below ? 1u : 0u;
                         const unsigned long long m = __ballot(inb);
                         if (inb) wq[wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
                         wcount += (unsigned)__popcll(m);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
     // ---- candidates -> this wave's tile segment; what does not fit goes to the overflow list
     const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned nseg = min(wcand, (unsigned)CAND_TILECAP);
-    if (lane == 0) tile_cnt[tile] = nseg;
+    if (lane == 0) tile_cnt[tile] = (uint8_t)nseg;
     for (unsigned i = lane; i < nseg; i += 64) tile_seg[(size_t)tile * CAND_TILECAP + i] = lcand[i];
     if (wcand > nseg) {
         unsigned base = 0;
@@ -280,51 +283,55 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
         float* reg = bsel_region(b, 0, sh);
         for (unsigned i = lane; i < wcount; i += 64)
             if (base + i < b.capS) reg[base + i] = wq[i];
-        if (lane == 0) bsel_count(b, 0, sh, wvalid, wbelow);
+        const int wv = wave_sum_i32((int)lvalid), wb = wave_sum_i32((int)lbelow);
+        if (lane == 0) bsel_count(b, 0, sh, (unsigned)wv, (unsigned)wb);
     }
 }
 
 // tile segments (+ overflow list) -> dense candidate list.  Workgroup g owns the tiles
-// [g*tpb, (g+1)*tpb), tpb <= 256: it sums the counts of all earlier tiles itself (a few
-// KB of coalesced reads) instead of waiting for a scan, then copies its segments with one
-// independent load per (tile, slot) pair.  Workgroup 0 appends the overflow list.
-__global__ __launch_bounds__(256) void k_lac_compact(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_seg,
+// [g*tpb, (g+1)*tpb), tpb <= 256 and a multiple of 16: it sums the (byte) counts of all
+// earlier tiles itself -- 16 counts per load, a few KB in all -- instead of waiting for a
+// scan, then every thread copies the segment of one tile.  Workgroup 0 appends the overflow
+// list.
+__global__ __launch_bounds__(256) void k_lac_compact(const uint8_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_seg,
                                                       int ntiles, int tpb, const uint32_t* __restrict__ ovf, uint32_t capovf,
                                                       int32_t* counters, uint32_t* __restrict__ cand, uint32_t cap,
                                                       int32_t* err) {
     __shared__ unsigned wsum[4];
     __shared__ unsigned red[2][4];
-    __shared__ unsigned lcnt[256], lexcl[256];
+    __shared__ unsigned lexcl[256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int t0 = min((int)blockIdx.x * tpb, ntiles), t1 = min(t0 + tpb, ntiles);
     unsigned before = 0, all = 0;
-    // tile_cnt is 16-byte aligned and padded with zeros to a multiple of 4 entries
+    // tile_cnt is 16-byte aligned and zero-padded to a multiple of 16 entries; t0 % 16 == 0
     const uint4* tc4 = reinterpret_cast<const uint4*>(tile_cnt);
-    const int n4 = (ntiles + 3) / 4;
-#pragma unroll 4
-    for (int g = tid; g < n4; g += 256) {
+    const int n16 = (ntiles + 15) / 16;
+#pragma unroll 2
+    for (int g = tid; g < n16; g += 256) {
         const uint4 c = tc4[g];
-        const int t = 4 * g;
-        all += c.x + c.y + c.z + c.w;
-        before += (t < t0 ? c.x : 0u) + (t + 1 < t0 ? c.y : 0u) + (t + 2 < t0 ? c.z : 0u) + (t + 3 < t0 ? c.w : 0u);
+        unsigned sum = __builtin_amdgcn_sad_u8(c.x, 0u, 0u);
+        sum = __builtin_amdgcn_sad_u8(c.y, 0u, sum);
+        sum = __builtin_amdgcn_sad_u8(c.z, 0u, sum);
+        sum = __builtin_amdgcn_sad_u8(c.w, 0u, sum);
+        all += sum;
+        if (16 * g < t0) before += sum;
     }
     before = (unsigned)wave_sum_i32((int)before); all = (unsigned)wave_sum_i32((int)all);
     if (lane == 0) { red[0][wid] = before; red[1][wid] = all; }
-    const unsigned mine = (t0 + tid < t1) ? tile_cnt[t0 + tid] : 0u;
+    const int t = t0 + tid;
+    const unsigned mine = (t < t1) ? tile_cnt[t] : 0u;
     unsigned ltot;
     const unsigned excl = block_excl_scan256(mine, wsum, &ltot);         // contains the barriers for red[]
-    lcnt[tid] = mine; lexcl[tid] = excl;
-    __syncthreads();
     const unsigned base = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const unsigned tot = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const int npair = (t1 - t0) * CAND_TILECAP;
-#pragma unroll 4
-    for (int q = tid; q < npair; q += 256) {
-        const int tl = q / CAND_TILECAP, slot = q % CAND_TILECAP;
-        if ((unsigned)slot < lcnt[tl]) {
-            const unsigned pos = base + lexcl[tl] + slot;
-            if (pos < cap) cand[pos] = tile_seg[(size_t)(t0 + tl) * CAND_TILECAP + slot];
-        }
+    // flat copy of the workgroup's ltot entries: entry e belongs to the last tile with lexcl <= e
+    lexcl[tid] = excl;
+    __syncthreads();
+    for (unsigned e = tid; e < ltot; e += 256) {
+        int lo = 0, hi = 255;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (lexcl[mid] <= e) lo = mid; else hi = mid - 1; }
+        const unsigned pos = base + e;
+        if (pos < cap) cand[pos] = tile_seg[(size_t)(t0 + lo) * CAND_TILECAP + (e - lexcl[lo])];
     }
     if (blockIdx.x == 0) {
         const unsigned novf = min((unsigned)counters[CNT_CANDOVF], capovf);
@@ -603,10 +610,10 @@ __global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
     }
 }
 
-__global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint32_t* tile_cnt_pad) {
+__global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt_pad) {
     const int t = threadIdx.x;
     if (t < 16) stats[t] = 0;
-    if (t < 4 && tile_cnt_pad) tile_cnt_pad[t] = 0;          // k_lac_compact reads the counts four at a time
+    if (t < 16 && tile_cnt_pad) tile_cnt_pad[t] = 0;         // k_lac_compact reads the counts sixteen at a time
     if (t == 0) { counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0; counters[CNT_CANDOVF] = 0; }
 }
 
@@ -655,8 +662,8 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     // candidate workspace: dense list | overflow list | per-tile counts | per-tile segments
     uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (cap + capovf + 64 + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
     uint32_t* ovf = cand + cap;
-    uint32_t* tile_cnt = ovf + ((capovf + 63) / 64) * 64;               // 16-byte aligned (cap is a multiple of 4)
-    uint32_t* tile_seg = tile_cnt + ((ntiles + 63) / 64) * 64;
+    uint32_t* tile_seg = ovf + ((capovf + 63) / 64) * 64;
+    uint8_t* tile_cnt = (uint8_t*)(tile_seg + ntiles * CAND_TILECAP);     // 16-byte aligned; one byte per tile (<= CAND_TILECAP)
     uint32_t* stage2 = (uint32_t*)bbx_ws(ctx, WS_STAGE2, cap * 4, &rc); if (rc) return rc;
     uint32_t* crlist = (uint32_t*)bbx_ws(ctx, WS_CRLIST, cap * 4, &rc); if (rc) return rc;
     uint8_t* flags = (uint8_t*)bbx_ws(ctx, WS_FLAGS, npix + 16, &rc); if (rc) return rc;
@@ -682,7 +689,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         }
         bbx_prof_stop(ctx, s);
         if (vec) {
-            const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, (ntiles + 127) / 128));
+            const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, ((ntiles + 127) / 128 + 15) / 16 * 16));
             hipLaunchKernelGGL(k_lac_compact, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(256), 0, s, tile_cnt, tile_seg, (int)ntiles,
                                tpb, ovf, (uint32_t)capovf, cnt, cand, (uint32_t)cap, ctx->d_err);
         }

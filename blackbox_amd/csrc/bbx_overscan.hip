@@ -112,79 +112,117 @@ struct vos_state {          // per channel
     int frozen;             // clip loop finished
     int pad;
 };
-#define VSTD_BLOCKS 64      // partial-sum blocks per channel
+#define VSTD_BLOCKS 128     // partial-sum workgroups per channel
 
-template <int RAW_T>
-__global__ __launch_bounds__(256) void k_vos_std_pass(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
-                                                      const double* __restrict__ vfit, f32x16 dlevel,
-                                                      const vos_state* __restrict__ st,
-                                                      double* __restrict__ partial /*[16][VSTD_BLOCKS][3]*/) {
-    const int c = blockIdx.y, b = blockIdx.x;
-    const int iy = c >> 3, ix = c & 7;
-    const double lo = st[c].lo, hi = st[c].hi;
-    const float g = gain.v[c];
-    const long long total = (long long)d.dy * d.vos_w;
-    double s1 = 0.0, s2 = 0.0; long long n = 0;
-    for (long long i = (long long)b * 256 + threadIdx.x; i < total; i += (long long)VSTD_BLOCKS * 256) {
-        int r = (int)(i / d.vos_w), col = (int)(i - (long long)r * d.vos_w);
-        float f = raw_load<RAW_T>(raw, (size_t)(iy * d.dy + r) * d.nx_raw + (size_t)ix * d.dx + d.vos_x0 + col);
-        if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;
-        f = f * g;
-        float x = (float)((double)f - vfit[c * d.dy + r]);       // float32 array -= float64 column
-        // rows shared with the horizontal overscan section also received `-= dlevel`
-        // (os_sec_hori spans the full channel width, blackbox.py:6568)
-        const bool in_hos = (iy == 0) ? (r >= d.dy - d.hos_rows) : (r < d.hos_rows);
-        if (in_hos) x = x - dlevel.v[c];
-        double xd = (double)x;
-        bool keep = isfinite(x) && !(fabs(xd) <= 1e-8) && xd >= lo && xd <= hi;
-        if (keep) { s1 += xd; s2 += xd * xd; n++; }
-    }
-    // deterministic block reduction: wave shuffle, then waves in order
-    __shared__ double sh1[4], sh2[4]; __shared__ long long shn[4];
-    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2); n = wave_sum_i64(n);
-    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = s1; sh2[threadIdx.x >> 6] = s2; shn[threadIdx.x >> 6] = n; }
+// Block reduction of (s1, s2, n) -> partial[c][b][3].  (The fold over the workgroups is a
+// separate tiny kernel: a "last workgroup folds" scheme needs a device-scope fence per
+// workgroup, and on this multi-XCD part each of those writes the L2 back.)
+__device__ __forceinline__ void vos_pass_finish(double s1, double s2, long long n, int c, int b,
+                                                double* __restrict__ partial) {
+    __shared__ double sh1[4], sh2[4], shn[4];
+    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+    const double nd = wave_sum_f64((double)n);
+    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = s1; sh2[threadIdx.x >> 6] = s2; shn[threadIdx.x >> 6] = nd; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
-        double q = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
-        long long m = shn[0] + shn[1] + shn[2] + shn[3];
         double* p = partial + ((size_t)c * VSTD_BLOCKS + b) * 3;
-        p[0] = a; p[1] = q; p[2] = (double)m;
+        p[0] = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
+        p[1] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+        p[2] = (shn[0] + shn[1]) + (shn[2] + shn[3]);
     }
 }
 
-// one thread per channel: fold the partials in fixed order, update the clip state.
-// Follows SigmaClip._sigmaclip_noaxis: bounds from the survivors' mean/std, survivors
-// = survivors inside the closed interval, stop when nothing changed or after 5
+// workgroup c (VSTD_BLOCKS threads): fold the channel's partials in fixed order and update the
+// clip state.  Follows SigmaClip._sigmaclip_noaxis: bounds from the survivors' mean/std,
+// survivors = survivors inside the closed interval, stop when nothing changed or after 5
 // iterations; the pass after the last filter delivers the returned statistics.
-__global__ void k_vos_std_update(vos_state* st, const double* __restrict__ partial, int pass,
-                                 double* __restrict__ std_out) {
-    int c = threadIdx.x;
-    if (c >= 16) return;
+__global__ __launch_bounds__(VSTD_BLOCKS) void k_vos_std_update(vos_state* st, const double* __restrict__ partial, int pass,
+                                                                double* __restrict__ std_out) {
+    __shared__ double sh[3][VSTD_BLOCKS / 64];
+    const int c = blockIdx.x;
     vos_state s = st[c];
-    if (!s.frozen) {
-        double a = 0.0, q = 0.0, m = 0.0;
-        for (int b = 0; b < VSTD_BLOCKS; b++) {
-            const double* p = partial + ((size_t)c * VSTD_BLOCKS + b) * 3;
-            a += p[0]; q += p[1]; m += p[2];
-        }
-        long long n = (long long)m;
-        double mean = a / m;
-        double var = q / m - mean * mean;
-        if (var < 0.0) var = 0.0;
-        double sd = sqrt(var);
-        bool unchanged = (pass > 0 && n == s.n);
-        s.mean = mean; s.std = sd; s.n = n;
-        if (unchanged || pass >= 5 || n == 0) {
-            s.frozen = 1;
-        } else {
-            double lo = mean - 3.0 * sd, hi = mean + 3.0 * sd;
-            if (lo > s.lo) s.lo = lo;
-            if (hi < s.hi) s.hi = hi;
-        }
-        st[c] = s;
+    if (s.frozen) return;
+    const double* p = partial + ((size_t)c * VSTD_BLOCKS + threadIdx.x) * 3;
+    double a = wave_sum_f64(p[0]), q = wave_sum_f64(p[1]), m = wave_sum_f64(p[2]);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = q; sh[2][threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    a = q = m = 0.0;
+    for (int w = 0; w < VSTD_BLOCKS / 64; w++) { a += sh[0][w]; q += sh[1][w]; m += sh[2][w]; }
+    const long long cnt = (long long)m;
+    const double mean = a / m;
+    double var = q / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double sd = sqrt(var);
+    const bool unchanged = (pass > 0 && cnt == s.n);
+    s.mean = mean; s.std = sd; s.n = cnt;
+    if (unchanged || pass >= 5 || cnt == 0) {
+        s.frozen = 1;
+    } else {
+        const double lo = mean - 3.0 * sd, hi = mean + 3.0 * sd;
+        if (lo > s.lo) s.lo = lo;
+        if (hi < s.hi) s.hi = hi;
     }
+    st[c] = s;
     std_out[c] = s.std;
+}
+
+// pass 0: residuals of the vertical overscan after the column fit -> compact float32 strip
+// [16][dy][vos_w] (read by the later passes with vector loads), plus the unclipped sums.
+// One wave per row; workgroup b of a channel takes the rows b*4+w, +4*VSTD_BLOCKS, ...
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_vos_strip(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
+                                                   const double* __restrict__ vfit, f32x16 dlevel,
+                                                   float* __restrict__ strip, double* __restrict__ partial) {
+    const int c = blockIdx.y, b = blockIdx.x;
+    const int iy = c >> 3, ix = c & 7;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float g = gain.v[c], dl = dlevel.v[c];
+    double s1 = 0.0, s2 = 0.0; long long n = 0;
+    for (int r = b * 4 + w; r < d.dy; r += 4 * VSTD_BLOCKS) {
+        const double vf = vfit[c * d.dy + r];
+        // rows shared with the horizontal overscan section also received `-= dlevel`
+        // (os_sec_hori spans the full channel width, blackbox.py:6568)
+        const bool in_hos = (iy == 0) ? (r >= d.dy - d.hos_rows) : (r < d.hos_rows);
+        const size_t src = (size_t)(iy * d.dy + r) * d.nx_raw + (size_t)ix * d.dx + d.vos_x0;
+        float* dst = strip + ((size_t)c * d.dy + r) * d.vos_w;
+        for (int col = lane; col < d.vos_w; col += 64) {
+            float f = raw_load<RAW_T>(raw, src + col);
+            if (RAW_T == BBX_RAW_F32 && !isfinite(f)) f = 0.f;
+            f = f * g;
+            float x = (float)((double)f - vf);                   // float32 array -= float64 column
+            if (in_hos) x = x - dl;
+            dst[col] = x;
+            const double xd = (double)x;
+            if (isfinite(x) && !(fabs(xd) <= 1e-8)) { s1 += xd; s2 += xd * xd; n++; }
+        }
+    }
+    vos_pass_finish(s1, s2, n, c, b, partial);
+}
+
+// passes 1..5 over the compact strip; channels whose clip loop has finished return at once
+__global__ __launch_bounds__(256) void k_vos_std_pass(const float* __restrict__ strip, bbx_dims d,
+                                                      const vos_state* __restrict__ st, double* __restrict__ partial) {
+    const int c = blockIdx.y, b = blockIdx.x;
+    if (st[c].frozen) return;
+    const double lo = st[c].lo, hi = st[c].hi;
+    const size_t total = (size_t)d.dy * d.vos_w;
+    const float* x = strip + (size_t)c * total;
+    double s1 = 0.0, s2 = 0.0; long long n = 0;
+    auto take = [&](float v) {
+        const double xd = (double)v;
+        if (isfinite(v) && !(fabs(xd) <= 1e-8) && xd >= lo && xd <= hi) { s1 += xd; s2 += xd * xd; n++; }
+    };
+    if (total % 4 == 0) {
+        const float4* x4 = (const float4*)x;            // strip and channel offsets are 16-byte aligned
+        for (size_t i = (size_t)b * 256 + threadIdx.x; i < total / 4; i += (size_t)VSTD_BLOCKS * 256) {
+            const float4 v = x4[i];
+            take(v.x); take(v.y); take(v.z); take(v.w);
+        }
+    } else {
+        for (size_t i = (size_t)b * 256 + threadIdx.x; i < total; i += (size_t)VSTD_BLOCKS * 256) take(x[i]);
+    }
+    vos_pass_finish(s1, s2, n, c, b, partial);
 }
 
 __global__ void k_vos_std_init(vos_state* st) {
@@ -256,20 +294,25 @@ int bbx_vos_std(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type
     bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     f32x16 gain = load16(h_gain), dlev = load16(h_dlevel);
-    char* ws = (char*)bbx_ws(ctx, WS_STRIP, 16 * sizeof(vos_state) + 16 * VSTD_BLOCKS * 3 * sizeof(double), &rc);
+    const size_t nstrip = (size_t)16 * d.dy * d.vos_w;
+    const size_t o_partial = 16 * sizeof(vos_state), o_strip = o_partial + 16 * VSTD_BLOCKS * 3 * sizeof(double);
+    char* ws = (char*)bbx_ws(ctx, WS_STRIP, o_strip + nstrip * sizeof(float), &rc);
     if (rc) return rc;
     vos_state* st = (vos_state*)ws;
-    double* partial = (double*)(ws + 16 * sizeof(vos_state));
+    double* partial = (double*)(ws + o_partial);
+    float* strip = (float*)(ws + o_strip);
     hipLaunchKernelGGL(k_vos_std_init, dim3(1), dim3(64), 0, s, st);
-    for (int pass = 0; pass < 6; pass++) {
-        if (raw_type == BBX_RAW_U16)
-            hipLaunchKernelGGL(k_vos_std_pass<BBX_RAW_U16>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain,
-                               d_vfit, dlev, st, partial);
-        else if (raw_type == BBX_RAW_F32)
-            hipLaunchKernelGGL(k_vos_std_pass<BBX_RAW_F32>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain,
-                               d_vfit, dlev, st, partial);
-        else return BBX_ERR_ARG;
-        hipLaunchKernelGGL(k_vos_std_update, dim3(1), dim3(64), 0, s, st, partial, pass, d_std_vos);
+    if (raw_type == BBX_RAW_U16)
+        hipLaunchKernelGGL(k_vos_strip<BBX_RAW_U16>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain, d_vfit, dlev,
+                           strip, partial);
+    else if (raw_type == BBX_RAW_F32)
+        hipLaunchKernelGGL(k_vos_strip<BBX_RAW_F32>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain, d_vfit, dlev,
+                           strip, partial);
+    else return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_vos_std_update, dim3(16), dim3(VSTD_BLOCKS), 0, s, st, partial, 0, d_std_vos);
+    for (int pass = 1; pass < 6; pass++) {
+        hipLaunchKernelGGL(k_vos_std_pass, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, strip, d, st, partial);
+        hipLaunchKernelGGL(k_vos_std_update, dim3(16), dim3(VSTD_BLOCKS), 0, s, st, partial, pass, d_std_vos);
     }
     BBX_LAUNCH_CHECK();
     return BBX_OK;
