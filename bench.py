@@ -140,8 +140,9 @@ def main():
     ap.add_argument('--raw', default='u16', choices=['u16', 'f32'])
     ap.add_argument('--small', action='store_true', help='reduced geometry (debug)')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--depth', type=int, default=6, help='frames in flight')
+    ap.add_argument('--depth', type=int, default=12, help='frames in flight')
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
+    ap.add_argument('--lanes', type=int, default=1, help='stage-C lanes (context + stream) per GPU')
     args = ap.parse_args()
 
     import torch
@@ -204,7 +205,7 @@ def main():
 
     # ---- timed region: K frames through the pipelined path -------------------------------------
     pool = HostPool(args.workers)
-    pipe = FramePipeline(ctx, tel, geom, mflat=flat, bpm=bpm, pool=pool, depth=args.depth)
+    pipe = FramePipeline(ctx, tel, geom, mflat=flat, bpm=bpm, pool=pool, depth=args.depth, lanes=args.lanes)
     pipe.run([(raw, {}) for _ in range(max(args.warmup, 1))])
     pipe.t_stats = [0.0, 0.0, 0.0, 0]
     check = _lib.check

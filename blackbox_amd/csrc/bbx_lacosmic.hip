@@ -36,6 +36,7 @@ struct lac_par {
     int ny, nx;
     float sigclip, sigcliplow, objlim;
     const float* rnp;            // device: {float32(rn*rn), prune threshold T}
+    int nwx, ntiles;             // dense pass: waves along x, tiles in all
 };
 
 // L+ of pixel (j,i): 2x2 replicate -> Laplacian -> clip -> 2x2 mean, closed form with
@@ -154,10 +155,17 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
     const int lane = threadIdx.x;                                                 // one wave per workgroup
     float* wq = reinterpret_cast<float*>(dyn_lds + CAND_WQ * 4);              // queue of in-bracket values (FEED)
     const float T = p.rnp[1];
-    const int x0 = blockIdx.x * CAND_SPAN - 4 + lane * 4;
+    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2), so
+    // workgroup L works on tile (L % 8) * chunk + L / 8 -- every XCD sweeps one contiguous band
+    // of the frame and finds the halo rows/columns shared with neighbouring tiles in its own L2
+    const unsigned chunk = gridDim.x >> 3;
+    const unsigned tile = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (tile >= (unsigned)p.ntiles) return;
+    const int bx = (int)(tile % (unsigned)p.nwx), by = (int)(tile / (unsigned)p.nwx);
+    const int x0 = bx * CAND_SPAN - 4 + lane * 4;
     const bool prod = x0 >= 0 && x0 < p.nx && lane >= 1 && lane <= 62;      // nx % 4 == 0 on this path
     const int xc = min(max(x0, 0), p.nx - 4);
-    const int j0 = blockIdx.y * CAND_ROWS;
+    const int j0 = by * CAND_ROWS;
     const int j1 = min(j0 + CAND_ROWS, p.ny);
     const float* __restrict__ col = a + xc;
     const uint8_t* __restrict__ mcol = mask + xc;
@@ -176,15 +184,16 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
     unsigned wcand = 0;                                        // wave-uniform
     unsigned wcount = 0;                                       // wave-uniform (FEED)
     unsigned lvalid = 0, lbelow = 0;                           // per lane (FEED)
+    unsigned wbelow = 0;                                       // wave-uniform (FEED): rows without masked pixels
     const unsigned sh = bsel_my_shard();
     if (FEED) { lo = b.seg[0].lo; hi = b.seg[0].hi; }
     bool colok[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) colok[q] = prod && (x0 + q >= 2) && (x0 + q < p.nx - 2);
-    // bits of a mask word that make a pixel invalid for the background statistics; lanes that
-    // do not produce see every pixel as invalid
+    // bits of a mask word that make a pixel invalid for the background statistics
     const uint32_t badbits = 0x01010101u * (uint32_t)(0xff & ~BBX_MASK_COSMIC);
-    const uint32_t lanebad = prod ? 0u : 0xffffffffu;
+    const float lo_l = prod ? lo : __builtin_nanf(""), hi_l = prod ? hi : __builtin_nanf("");
+    const unsigned vrow = prod ? 4u : 0u;
     // fully unrolled (no loop back-edge): with a rolled loop the register renaming at the
     // back-edge makes hipcc wait for all outstanding loads once per batch
 #pragma unroll
@@ -210,11 +219,11 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
                                          colok[3] && lp23.y > T};
                     // wave-level queue in LDS: candidates come in clusters (star cores), so the
                     // staging is per wave, not per lane; wcand is wave-uniform
-                    if (__ballot(hit[0] || hit[1] || hit[2] || hit[3])) {
+                    if (__builtin_amdgcn_ballot_w64(hit[0] || hit[1] || hit[2] || hit[3])) {
                         const uint32_t idx0 = (uint32_t)((size_t)j * nx + x0);
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const unsigned long long m = __ballot(hit[q]);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit[q]);
                             if (hit[q]) lcand[wcand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idx0 + q;
                             wcand += (unsigned)__popcll(m);
                         }
@@ -231,7 +240,6 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
                 }
                 if (FEED) {
                     const float c4[4] = {cur.x, cur.y, cur.z, cur.w};
-                    const uint32_t bad = (mk & badbits) | lanebad;
                     // room for this row's appends (at most 4 per lane)?  wave-uniform, rare
                     if (wcount + 256u > FEED_WQ) {
                         unsigned base = 0;
@@ -242,19 +250,43 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
                             if (base + i < b.capS) reg[base + i] = wq[i];
                         wcount = 0;
                     }
-                    // valid pixels of this lane in the row: 4 - (number of non-zero bytes of bad)
-                    const uint32_t nzb = (((bad & 0x7f7f7f7fu) + 0x7f7f7f7fu) | bad) & 0x80808080u;
-                    lvalid += 4u - (unsigned)__popc(nzb);
+                    // lanes that do not produce compare against NaN bounds (lo_l, hi_l): never
+                    // below, never inside.  Rows without any masked pixel (wave-uniform test, the
+                    // usual case) skip the per-pixel validity logic.
+                    const uint32_t bad = mk & badbits;
+                    if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
+                        lvalid += vrow;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float c = c4[q];
-                        const bool valid = (nzb & (0x80u << (8 * q))) == 0;
-                        const bool below = valid && c < lo;
-                        const bool inb = valid && !(c < lo) && c <= hi;
-                        lbelow += below ? 1u : 0u;
-                        const unsigned long long m = __ballot(inb);
-                        if (inb) wq[wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
-                        wcount += (unsigned)__popcll(m);
+                        for (int q = 0; q < 4; q++) {
+                            const float c = c4[q];
+                            // the compare masks live in scalar registers: counting and combining them
+                            // is scalar-unit work, the vector unit only does the two compares
+                            const bool below = c < lo_l;
+                            const bool inb = !below && c <= hi_l;
+                            const unsigned long long mb = __builtin_amdgcn_ballot_w64(below);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(inb);
+                            wbelow += (unsigned)__popcll(mb);
+                            if (m) {
+                                if (inb)
+                                    wq[wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
+                                wcount += (unsigned)__popcll(m);
+                            }
+                        }
+                    } else {
+                        // valid pixels of this lane in the row: 4 - (number of non-zero bytes of bad)
+                        const uint32_t nzb = (((bad & 0x7f7f7f7fu) + 0x7f7f7f7fu) | bad) & 0x80808080u;
+                        if (prod) lvalid += 4u - (unsigned)__popc(nzb);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float c = c4[q];
+                            const bool valid = (nzb & (0x80u << (8 * q))) == 0;
+                            const bool below = valid && c < lo_l;
+                            const bool inb = valid && !(c < lo_l) && c <= hi_l;
+                            lbelow += below ? 1u : 0u;
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(inb);
+                            if (inb) wq[wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
+                            wcount += (unsigned)__popcll(m);
+                        }
                     }
                 }
             }
@@ -262,7 +294,6 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
         }
     }
     // ---- candidates -> this wave's tile segment; what does not fit goes to the overflow list
-    const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned nseg = min(wcand, (unsigned)CAND_TILECAP);
     if (lane == 0) tile_cnt[tile] = (uint8_t)nseg;
     for (unsigned i = lane; i < nseg; i += 64) tile_seg[(size_t)tile * CAND_TILECAP + i] = lcand[i];
@@ -283,7 +314,7 @@ __global__ __launch_bounds__(64, CAND_WPE) void k_lac_cand_v4(const float* __res
         float* reg = bsel_region(b, 0, sh);
         for (unsigned i = lane; i < wcount; i += 64)
             if (base + i < b.capS) reg[base + i] = wq[i];
-        const int wv = wave_sum_i32((int)lvalid), wb = wave_sum_i32((int)lbelow);
+        const int wv = wave_sum_i32((int)lvalid), wb = wave_sum_i32((int)lbelow) + (int)wbelow;
         if (lane == 0) bsel_count(b, 0, sh, (unsigned)wv, (unsigned)wb);
     }
 }
@@ -657,8 +688,9 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     const size_t cap = (npix / 4 + 4096) & ~(size_t)63;
     const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
     const int nwx = (nx + CAND_SPAN - 1) / CAND_SPAN;             // waves along x
-    const dim3 gvec(nwx, (ny + CAND_ROWS - 1) / CAND_ROWS);                 // one wave per workgroup
-    const size_t ntiles = (size_t)gvec.x * gvec.y, capovf = cap / 4 + 4096;
+    const size_t ntiles = (size_t)nwx * ((ny + CAND_ROWS - 1) / CAND_ROWS), capovf = cap / 4 + 4096;
+    const dim3 gvec((unsigned)(((ntiles + 7) / 8) * 8));                    // one wave per workgroup, see the tile order in the kernel
+    p.nwx = nwx; p.ntiles = (int)ntiles;
     // candidate workspace: dense list | overflow list | per-tile counts | per-tile segments
     uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (cap + capovf + 64 + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
     uint32_t* ovf = cand + cap;

@@ -10,9 +10,10 @@ So a frame goes through three stages and up to [depth] frames overlap:
   C  (GPU, stream C)   read-noise statistics, fused calibration, mask_init tail,
                        LA-Cosmic, [crosstalk, mask counts, edge fill]
 
-Stage C of successive frames is serialised on one stream (the bbx_ctx workspace is
-per context); stage A uses no workspace and overlaps with it.  No collective, no
-inter-GPU traffic: one FramePipeline per GPU / process.
+Stage C alternates between [lanes] contexts, each with its own workspace and stream, so
+the many short kernels of one frame (flood fill, select, sparse LA-Cosmic steps) overlap
+with the streaming kernels of the next; stage A uses no workspace and overlaps with both.
+No collective, no inter-GPU traffic: one FramePipeline per GPU / process.
 """
 import ctypes as C
 import multiprocessing as mp
@@ -29,10 +30,29 @@ from ._lib import lib, check
 get_par = settings.get_par
 
 
+def cpu_budget():
+    """cores this process may use: the cgroup CPU quota when there is one (os.cpu_count()
+    reports the whole host inside a container), else the affinity mask"""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 4
+
+
 def default_workers():
-    n = os.cpu_count() or 4
+    """fit workers per GPU process: the host fits are the CPU-side cost of a frame
+    (~20 ms of one core), so take the budget minus the orchestrating thread and the HIP
+    runtime's helper thread; BBX_HOST_WORKERS overrides"""
+    if 'BBX_HOST_WORKERS' in os.environ:
+        return max(1, int(os.environ['BBX_HOST_WORKERS']))
     world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
-    return max(2, min(int(os.environ.get('BBX_HOST_WORKERS', 12)), max(2, n // max(1, world) - 1)))
+    return max(2, min(32, cpu_budget() // max(1, world) - 2))
 
 
 class HostPool:
@@ -165,13 +185,16 @@ def _shm_phase2(args):
 
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
-                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot')
+                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane')
 
 
 class FramePipeline:
     def __init__(self, ctx, tel, geom, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None, exptime=60.0,
-                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False):
+                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=1):
         self.ctx, self.tel, self.geom = ctx, tel, geom
+        # stage-C lanes: (context, stream); lane 0 is the caller's context
+        self.lane_ctx = [ctx] + [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
+        self.lane_stream = [torch.cuda.Stream(device=ctx.device) for _ in self.lane_ctx]
         self.mflat, self.bpm = mflat, bpm
         self.mbias = mbias if (mbias is not None and get_par(settings.subtract_mbias, tel)) else None
         self.xtalk = xtalk_coeffs
@@ -182,7 +205,6 @@ class FramePipeline:
         self.do_cosmics, self.do_finish, self.accum = do_cosmics, do_finish, accum
         self.keep_outputs = keep_outputs
         self.sA = torch.cuda.Stream(device=ctx.device)
-        self.sC = torch.cuda.Stream(device=ctx.device)
         self.gain = get_par(settings.gain, tel)
         self.g32 = _lib.f32x16(self.gain)
         g = geom
@@ -225,6 +247,8 @@ class FramePipeline:
             self.pool.close()
         self.slots = []
         self.arena.close()
+        for c in self.lane_ctx[1:]:
+            c.close()
 
     # ---- stage A ------------------------------------------------------------------
     def _start(self, idx, raw, header):
@@ -233,6 +257,7 @@ class FramePipeline:
         f.idx, f.raw, f.header, f.hm, f.t0 = idx, raw, header, {}, time.perf_counter()
         R.gain_corr(header, self.tel)
         f.slot = self.free_slots.pop()
+        f.lane = idx % len(self.lane_ctx)
         sl = self.slots[f.slot]
         with torch.cuda.stream(self.sA):
             d_mean, d_hos, d_ninf = sl['d_mean'], sl['d_hos'], sl['d_ninf']
@@ -276,11 +301,12 @@ class FramePipeline:
 
     def _satcol(self, f, results):
         """BlackGEM: per-column saturation counts need the vertical fit (two-phase)"""
-        ctx, dev = self.ctx, self.ctx.device
+        ctx, dev = self.lane_ctx[f.lane], self.ctx.device
         f.p1 = results
         lim = settings.os_ypix_lim[self.tel]
         satl = np.array(get_par(settings.satlevel, self.tel)) * np.array(self.gain)
-        with torch.cuda.stream(self.sC):
+        with torch.cuda.stream(self.lane_stream[f.lane]):
+            self.lane_stream[f.lane].wait_event(f.evA)
             sl = self.slots[f.slot]
             d_vfit = sl['d_vfit']
             d_vfit.copy_(sl['h_vfit'], non_blocking=True)
@@ -304,12 +330,13 @@ class FramePipeline:
 
     # ---- stage C ------------------------------------------------------------------
     def _device_stage(self, f, results):
-        ctx, dev, geom, tel = self.ctx, self.ctx.device, self.geom, self.tel
+        ctx, dev, geom, tel = self.lane_ctx[f.lane], self.ctx.device, self.geom, self.tel
+        sC = self.lane_stream[f.lane]
         self._fill_header_vos(f, results)
         dlevel = np.float32([r['dlevel'] for r in results])
         h, hm = f.header, f.hm
-        with torch.cuda.stream(self.sC):
-            self.sC.wait_event(f.evA)
+        with torch.cuda.stream(sC):
+            sC.wait_event(f.evA)
             sol = R.OverscanSolution()
             sl = self.slots[f.slot]
             sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
@@ -418,5 +445,6 @@ class FramePipeline:
                 break
             if not progressed:
                 time.sleep(0.0002)
-        check(lib.bbx_sync(self.ctx.h, C.c_void_p(self.sC.cuda_stream)), 'bbx_sync', self.ctx.h)
+        for c, st in zip(self.lane_ctx, self.lane_stream):
+            check(lib.bbx_sync(c.h, C.c_void_p(st.cuda_stream)), 'bbx_sync', c.h)
         return ndone

@@ -1,0 +1,44 @@
+"""Merge two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic.
+
+    python3 tools/pmc_traffic.py <dir FETCH_SIZE pass> <dir WRITE_SIZE pass> > traffic.json
+
+Counter unit: KB.  bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports
+half of a wide coalesced read (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def load(d, counter):
+    f = (glob.glob(d + '/*counter_collection.csv') + glob.glob(d + '/*/*counter_collection.csv'))[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').strip()
+        a = acc.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
+    return acc
+
+
+def main():
+    fe, wr = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+    out = {'_note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 3 '
+                    '--warmup 1 --no-cpu --depth 1` on MI355X; counter unit KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 '
+                    '(gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section; '
+                    '8-B and 4-B/lane loads are uncalibrated)',
+           'kernels': {}}
+    for k, (n, v) in fe.items():
+        if not (k.startswith('k_') or 'rocclr' in k):
+            continue
+        w = wr.get(k, [n, 0.0])
+        fk, wk = v / n, w[1] / max(1, w[0])
+        out['kernels'][k] = dict(launches=n, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, traffic_bytes_per_launch=(2 * fk + wk) * 1024)
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main()
