@@ -49,6 +49,8 @@ struct bbx_ctx {
     uint32_t* d_satlist;  int64_t cap_satlist;   // saturated pixel indices (reduced frame)
     void*     flags_clean_ptr; // LA-Cosmic flag plane known to be all-zero (see bbx_lacosmic)
     size_t    flags_clean_bytes;
+    void*     hash_clean_ptr;  // connected-component key table known to be all-empty (see bbx_cc_count_list)
+    size_t    hash_clean_n;
     int32_t*  d_counters;      // [CNT_MAX] device counters (see enum below)
     // --- scratch, (re)allocated on demand by bbx_ws()
     void*  d_ws[16];
@@ -81,7 +83,7 @@ enum {
 // workspace slots
 enum {
     WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
-    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS,
     WS_MAX
 };
 

@@ -161,6 +161,130 @@ __global__ __launch_bounds__(1024) void k_coarse_flood(const uint8_t* __restrict
     (void)err;
 }
 
+// The same flood on bit rows, for tile grids up to CF_MAX x CF_MAX (a 10560^2 frame has
+// 165 x 165 tiles).  A tile row is CF_WORDS 64-bit words; "reached" spreads along the free
+// runs of a row in O(1) with the carry trick: for seeds X inside free runs F, (F + X) ^ F
+// marks every run from its seed up to the run's end (the carry ripples through the ones).
+// The other direction is the same on bit-reversed words.  Columns are filled the same way on
+// the transposed bit matrix, so one round costs two transposes instead of a serial walk
+// over the tiles, and the number of rounds is the number of turns of the longest free path
+// (1-3 for real frames).
+#define CF_MAX 256
+#define CF_WORDS 4
+__device__ __forceinline__ bool cf_fill_row(const u64* F, u64* S, int nw) {
+    u64 f[CF_WORDS], s0[CF_WORDS], s[CF_WORDS];
+#pragma unroll
+    for (int k = 0; k < CF_WORDS; k++) { f[k] = k < nw ? F[k] : 0ull; s0[k] = k < nw ? (S[k] & f[k]) : 0ull; s[k] = s0[k]; }
+    // towards higher bits
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < CF_WORDS; k++) {
+        const u64 x = s[k];
+        const u64 a = f[k] + x, b = a + carry;
+        carry = (u64)((a < x) | (b < a));
+        s[k] |= (b ^ f[k]) & f[k];
+    }
+    // towards lower bits: the same on the reversed row (word order and bit order)
+    carry = 0;
+#pragma unroll
+    for (int k = CF_WORDS - 1; k >= 0; k--) {
+        const u64 fr = __brevll(f[k]), x = __brevll(s[k]);
+        const u64 a = fr + x, b = a + carry;
+        carry = (u64)((a < x) | (b < a));
+        s[k] |= __brevll((b ^ fr) & fr);
+    }
+    bool ch = false;
+#pragma unroll
+    for (int k = 0; k < CF_WORDS; k++) if (k < nw) { ch |= (s[k] != s0[k]); S[k] = s[k]; }
+    return ch;
+}
+
+// dst[c][*] = transpose of src[r][*] (rows x cols bits); thread c builds column c
+__device__ __forceinline__ void cf_transpose(const u64 (*src)[CF_WORDS], u64 (*dst)[CF_WORDS], int rows, int cols, bool accumulate) {
+    const int c = threadIdx.x;
+    if (c < cols) {
+        const int cw = c >> 6, cb = c & 63;
+#pragma unroll
+        for (int k = 0; k < CF_WORDS; k++) {
+            u64 out = 0;
+            const int rend = min(rows, 64 * k + 64);
+#pragma unroll 8
+            for (int r = 64 * k; r < rend; r++) out |= ((src[r][cw] >> cb) & 1ull) << (r & 63);
+            dst[c][k] = accumulate ? (dst[c][k] | out) : out;
+        }
+    }
+}
+
+__global__ __launch_bounds__(CF_MAX) void k_coarse_flood_bits(const uint8_t* __restrict__ occ, uint8_t* __restrict__ state,
+                                                              int W, int TH, uint32_t* __restrict__ tiles, int32_t* counters) {
+    __shared__ u64 F[CF_MAX][CF_WORDS], R[CF_MAX][CF_WORDS], FT[CF_MAX][CF_WORDS], RT[CF_MAX][CF_WORDS];
+    __shared__ int changed;
+    const int t = threadIdx.x;
+    const int WW = (W + 63) >> 6, WH = (TH + 63) >> 6;
+    // occupancy bytes -> free / seed bit rows: a wave reads 64 consecutive tiles of a row
+    // (coalesced) and the ballot of "free" is the bit word
+    const int lane = t & 63, wave = t >> 6, nwave = CF_MAX / 64;
+    for (int idx = wave; idx < TH * WW; idx += nwave) {
+        const int ty = idx / WW, k = idx - ty * WW, tx = 64 * k + lane;
+        const bool fr = tx < W && occ[ty * W + tx] == 0;
+        const u64 m = __builtin_amdgcn_ballot_w64(fr);
+        if (lane == 0) {
+            u64 edge = (ty == 0 || ty == TH - 1) ? ~0ull : 0ull;
+            if (k == 0) edge |= 1ull;
+            if (k == ((W - 1) >> 6)) edge |= 1ull << ((W - 1) & 63);
+            F[ty][k] = m; R[ty][k] = m & edge;
+        }
+    }
+    __syncthreads();
+    cf_transpose(F, FT, TH, W, false);
+    __syncthreads();
+    for (int iter = 0; iter < 2 * CF_MAX; iter++) {
+        if (t == 0) changed = 0;
+        __syncthreads();
+        if (t < TH && cf_fill_row(F[t], R[t], WW)) changed = 1;
+        __syncthreads();
+        cf_transpose(R, RT, TH, W, false);
+        __syncthreads();
+        if (t < W && cf_fill_row(FT[t], RT[t], WH)) changed = 1;
+        __syncthreads();
+        cf_transpose(RT, R, W, TH, true);
+        __syncthreads();
+        const int c = changed;
+        __syncthreads();
+        if (!c) break;
+    }
+    // outputs: state per tile, and the list of unresolved tiles (this kernel is its only
+    // writer: a count pass, a 4-wave prefix, then the writes -- no atomics)
+    __shared__ unsigned wtot[CF_MAX / 64];
+    unsigned mycount = 0;
+    for (int idx = wave; idx < TH * WW; idx += nwave) {
+        const int ty = idx / WW, k = idx - ty * WW;
+        u64 valid = ~0ull;
+        if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
+        mycount += (unsigned)__popcll(~R[ty][k] & valid);
+    }
+    if (lane == 0) wtot[wave] = mycount;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < nwave; w++) { if (w < wave) base += wtot[w]; total += wtot[w]; }
+    for (int idx = wave; idx < TH * WW; idx += nwave) {
+        const int ty = idx / WW, k = idx - ty * WW, tx = 64 * k + lane;
+        const u64 r = R[ty][k];
+        if (tx < W) {
+            const bool reached = (r >> lane) & 1ull;
+            state[ty * W + tx] = reached ? 1 : 0;
+            u64 valid = ~0ull;
+            if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
+            const u64 un = ~r & valid;
+            if (!reached) tiles[base + (unsigned)__popcll(un & ((1ull << lane) - 1ull))] = (uint32_t)(ty * W + tx);
+        }
+        u64 valid = ~0ull;
+        if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
+        base += (unsigned)__popcll(~r & valid);
+    }
+    if (t == 0) counters[CNT_TILES] = (int32_t)total;
+}
+
 // R plane init: resolved tiles all ones; unresolved zero; pad bits of the last word one
 __global__ __launch_bounds__(256) void k_reach_init(u64* __restrict__ R, const uint8_t* __restrict__ state, int ny, int nx, int W) {
     const size_t total = (size_t)ny * W;
@@ -254,7 +378,7 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
 
 __global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                    uint32_t* keys, uint32_t* vals, uint32_t hmask, uint32_t* parent,
-                                                   int cap, int32_t* err) {
+                                                   uint32_t* __restrict__ slot, int cap, int32_t* err) {
     int n = *cnt;
     if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -262,7 +386,7 @@ __global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ 
         uint32_t h = hash_u32(p) & hmask;
         for (;;) {
             const uint32_t old = atomicCAS(&keys[h], HEMPTY, p);
-            if (old == HEMPTY || old == p) { vals[h] = (uint32_t)i; break; }
+            if (old == HEMPTY || old == p) { vals[h] = (uint32_t)i; slot[i] = h; break; }
             h = (h + 1) & hmask;
         }
         parent[i] = (uint32_t)i;
@@ -314,12 +438,17 @@ __global__ __launch_bounds__(256) void k_cc_union(const uint32_t* __restrict__ l
     }
 }
 
+// roots = objects; the pass also empties the hash slots this list used, so the table is
+// all-HEMPTY again for the next call (no 100+ MB memset per call)
 __global__ __launch_bounds__(256) void k_cc_count(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ parent,
+                                                  const uint32_t* __restrict__ slot, uint32_t* __restrict__ keys,
                                                   int32_t* out, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
     int c = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         c += (parent[i] == (uint32_t)i) ? 1 : 0;
+        keys[slot[i]] = HEMPTY;
+    }
     c = wave_sum_i32(c);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
@@ -342,17 +471,27 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
     int rc;
     size_t hsize = 1024;
     while (hsize < 2 * cap) hsize <<= 1;
-    uint32_t* hash = (uint32_t*)bbx_ws(ctx, WS_HASH, hsize * 2 * sizeof(uint32_t), &rc); if (rc) return rc;
-    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
-    uint32_t* keys = hash; uint32_t* vals = hash + hsize;
-    BBX_HIP(hipMemsetAsync(keys, 0xff, hsize * sizeof(uint32_t), s));
+    // keys and values in separate blocks: the key table must not be overwritten by the values
+    // of a call with a different table size
+    uint32_t* hash = (uint32_t*)bbx_ws(ctx, WS_HASH, hsize * sizeof(uint32_t), &rc); if (rc) return rc;
+    uint32_t* vals = (uint32_t*)bbx_ws(ctx, WS_HVALS, hsize * sizeof(uint32_t), &rc); if (rc) return rc;
+    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, 2 * cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
+    uint32_t* slot = parent + cap;
+    uint32_t* keys = hash;
+    // the key table is kept all-HEMPTY between calls (k_cc_count empties what it used); it is
+    // filled once when the workspace block is new or grew.  Slots of a smaller earlier table
+    // size are still part of the larger table's key range, so "clean" carries over.
+    if (ctx->hash_clean_ptr != (void*)hash || ctx->hash_clean_n < hsize) {
+        BBX_HIP(hipMemsetAsync(keys, 0xff, hsize * sizeof(uint32_t), s));
+        ctx->hash_clean_ptr = (void*)hash; ctx->hash_clean_n = hsize;
+    }
     BBX_HIP(hipMemsetAsync(d_out, 0, sizeof(int32_t), s));
     const unsigned grid = 1024;
     hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent,
-                       (int)cap, ctx->d_err);
+                       slot, (int)cap, ctx->d_err);
     hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent, ny, nx,
                        (int)cap);
-    hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, d_cnt, parent, d_out, (int)cap);
+    hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, d_cnt, parent, slot, keys, d_out, (int)cap);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
@@ -485,7 +624,10 @@ int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d
     hipLaunchKernelGGL(k_bits_dilate, dim3(gw), dim3(256), 0, s, bitsM, bitsR, d.ny, d.nx, W);   // R as temp
     hipLaunchKernelGGL(k_bits_erode, dim3(gw), dim3(256), 0, s, bitsR, bitsC, d.ny, d.nx, W);
     hipLaunchKernelGGL(k_tile_occupancy, dim3((W * TH + 255) / 256), dim3(256), 0, s, bitsC, occ, d.ny, W, TH);
-    hipLaunchKernelGGL(k_coarse_flood, dim3(1), dim3(1024), 0, s, occ, state, W, TH, tiles, ctx->d_counters, ctx->d_err);
+    if (W <= CF_MAX && TH <= CF_MAX)
+        hipLaunchKernelGGL(k_coarse_flood_bits, dim3(1), dim3(CF_MAX), 0, s, occ, state, W, TH, tiles, ctx->d_counters);
+    else
+        hipLaunchKernelGGL(k_coarse_flood, dim3(1), dim3(1024), 0, s, occ, state, W, TH, tiles, ctx->d_counters, ctx->d_err);
     hipLaunchKernelGGL(k_reach_init, dim3(gw), dim3(256), 0, s, bitsR, state, d.ny, d.nx, W);
     hipLaunchKernelGGL(k_fine_flood, dim3(1), dim3(1024), 0, s, bitsR, bitsC, tiles, ctx->d_counters, d.ny, d.nx, W, ctx->d_err);
     hipLaunchKernelGGL(k_fill_apply, dim3(256), dim3(256), 0, s, bitsR, tiles, ctx->d_counters, d_mask, d.ny, d.nx, W);
