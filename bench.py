@@ -252,7 +252,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
             if not args.small and args.raw == 'u16':
                 if dom == 'k_calibrate':
-                    roof['traffic'] = pmc['k_calibrate_v4<0>']['traffic_bytes_per_launch']
+                    roof['traffic'] = next(v for k, v in pmc.items() if k.startswith('k_calibrate_v4'))['traffic_bytes_per_launch']
                 else:
                     roof['traffic'] = (pmc['k_lac_cand_v4<true>']['traffic_bytes_per_launch'] +
                                        2 * pmc['k_lac_cand_v4<false>']['traffic_bytes_per_launch']) / 3.0

@@ -15,7 +15,60 @@
 // Compile with -ffp-contract=off: no fused multiply-adds may be formed.
 #include "bbx_common.h"
 
+// ---- nonlin_corr (blackbox.py:7394-7437, off upstream): per channel,
+//   counts = data / gain[c]                       (float32 / float32)
+//   frac   = spline_c(counts) if counts <= 50000 else 1     (float64; sic: the "else 1" halves
+//            the uncorrected pixels -- reproduced)
+//   data   = float32(float64(data) / (frac + 1))
+// spline_c = scipy UnivariateSpline; evaluated like FITPACK splev/fpbspl (de Boor recurrence,
+// float64, same operation order) from its knots t[n] and coefficients c[n].
+#define NL_MAXKNOTS 256
+#define NL_MAXDEG 5
+struct nonlin_tab {
+    int n[16];                       // knots per channel (0 = table unset)
+    int k;                           // degree
+    int pad[3];
+    double t[16][NL_MAXKNOTS];
+    double c[16][NL_MAXKNOTS];
+};
+
+__device__ __forceinline__ double nl_splev(const nonlin_tab* __restrict__ tab, int ch, double arg) {
+    const double* t = tab->t[ch];
+    const double* cf = tab->c[ch];
+    const int n = tab->n[ch], k = tab->k, k1 = k + 1, nk1 = n - k1;
+    // knot interval t(l) <= arg < t(l+1), 1-based l in [k1, nk1] (splev.f labels 35-40)
+    // = the first 0-based index in [k1, nk1] whose knot exceeds arg (nk1 if none): binary search
+    int l = k1, hi = nk1;
+    while (l < hi) { const int mid = (l + hi) >> 1; if (arg < t[mid]) hi = mid; else l = mid + 1; }
+    // non-zero B-splines at arg (fpbspl.f)
+    double h[NL_MAXDEG + 1], hh[NL_MAXDEG];
+    h[0] = 1.0;
+    for (int j = 1; j <= k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; i++) {
+            const int li = l + i, lj = li - j;           // 1-based
+            const double tli = t[li - 1], tlj = t[lj - 1];
+            if (tli == tlj) { h[i] = 0.0; continue; }
+            const double f = hh[i - 1] / (tli - tlj);
+            h[i - 1] = h[i - 1] + f * (tli - arg);
+            h[i] = f * (arg - tlj);
+        }
+    }
+    double sp = 0.0;
+    for (int j = 0; j < k1; j++) sp = sp + cf[l - k1 + j] * h[j];
+    return sp;
+}
+
+__device__ __forceinline__ float nl_apply(const nonlin_tab* __restrict__ tab, int ch, float v, float gain) {
+    const float counts = v / gain;
+    double frac = 1.0;
+    if (counts <= 50000.0f) frac = nl_splev(tab, ch, (double)counts);
+    return (float)((double)v / (frac + 1.0));
+}
+
 struct calib_args {
+    const nonlin_tab* nonlin;        // device table or NULL
     const void* raw; const double* vfit; const double* oscan;
     const float* bias; const float* flat; const uint8_t* bpm;
     float* data; uint8_t* mask;
@@ -32,6 +85,7 @@ __device__ __forceinline__ void calib_pixel(const calib_args& a, float rawv, int
     v = v * a.gain.v[c];
     v = (float)((double)v - a.vfit[c * a.d.dy + rl]);
     v = (float)((double)v - a.oscan[c * a.d.xsz + x]);
+    if (a.nonlin) v = nl_apply(a.nonlin, c, v, a.gain.v[c]);
     if (a.bias) v = v - a.bias[o];
     m = a.bpm ? a.bpm[o] : (uint8_t)0;
     if (!isfinite(v)) { v = 0.f; if (m == 0) m |= BBX_MASK_BAD; }
@@ -47,7 +101,7 @@ __device__ __forceinline__ void calib_pixel(const calib_args& a, float rawv, int
 // Vector path (xsize_chan % 4 == 0): block = 256 threads x 4 pixels wide, CAL_ROWS rows tall.
 // A thread keeps its 4 oscan values in registers for all rows; vfit[row] is block-uniform.
 #define CAL_ROWS 8
-template <int RAW_T>
+template <int RAW_T, bool NONLIN>
 __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
     const bbx_dims& d = a.d;
     const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -89,6 +143,7 @@ __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
             v = v * g;
             v = (float)((double)v - vf);
             v = (float)((double)v - os[q]);
+            if (NONLIN) v = nl_apply(a.nonlin, c, v, g);
             if (a.bias) v = v - bi[q];
             if (!isfinite(v)) { v = 0.f; if (m[q] == 0) m[q] |= BBX_MASK_BAD; }
             if (v >= sat) {
@@ -139,6 +194,7 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
         BBX_HIP(hipMalloc((void**)&ctx->d_satlist, npix * sizeof(uint32_t)));
         ctx->cap_satlist = (int64_t)npix;
     }
+    a.nonlin = ctx->nonlin_on ? (const nonlin_tab*)ctx->d_nonlin : nullptr;
     a.raw = d_raw; a.vfit = d_vfit; a.oscan = d_oscan; a.bias = d_bias; a.flat = d_flat; a.bpm = d_bpm;
     a.data = d_data; a.mask = d_mask; a.satlist = ctx->d_satlist; a.counters = ctx->d_counters;
     a.err = ctx->d_err; a.satcap = (uint32_t)ctx->cap_satlist;
@@ -153,8 +209,13 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
     bbx_prof_start(ctx, BBX_PROF_CALIBRATE, s);
     if (vec) {
         dim3 grid((a.d.nx / 4 + 255) / 256, a.d.ny / CAL_ROWS);
-        if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL(k_calibrate_v4<BBX_RAW_U16>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_calibrate_v4<BBX_RAW_F32>, grid, dim3(256), 0, s, a);
+        if (a.nonlin) {
+            if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_U16, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_F32, true>), grid, dim3(256), 0, s, a);
+        } else {
+            if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_U16, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_F32, false>), grid, dim3(256), 0, s, a);
+        }
     } else {
         unsigned grid = (unsigned)((npix + 255) / 256);
         if (grid > 256u * 16u) grid = 256u * 16u;
@@ -162,6 +223,49 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
         else hipLaunchKernelGGL(k_calibrate_s<BBX_RAW_F32>, dim3(grid), dim3(256), 0, s, a);
     }
     bbx_prof_stop(ctx, s);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+// ---- a7 standalone: nonlin_corr on an already overscan-corrected frame ------------------
+__global__ __launch_bounds__(256) void k_nonlin(float* data, bbx_dims d, f32x16 gain, const nonlin_tab* __restrict__ tab) {
+    const size_t total = (size_t)d.ny * d.nx;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int Y = (int)(t / d.nx), X = (int)(t - (size_t)Y * d.nx);
+        const int c = (Y / d.ysz) * 8 + X / d.xsz;
+        data[t] = nl_apply(tab, c, data[t], gain.v[c]);
+    }
+}
+
+extern "C" int bbx_nonlin_set(bbx_ctx* ctx, int degree, const int32_t* h_nknots, const double* h_t, const double* h_c) {
+    if (!ctx) return BBX_ERR_ARG;
+    if (!h_nknots) { ctx->nonlin_on = 0; return BBX_OK; }                      // disable
+    if (!h_t || !h_c || degree < 1 || degree > NL_MAXDEG) return BBX_ERR_ARG;
+    nonlin_tab* h = (nonlin_tab*)calloc(1, sizeof(nonlin_tab));
+    if (!h) return BBX_ERR_NOMEM;
+    h->k = degree;
+    for (int ch = 0; ch < 16; ch++) {
+        const int n = h_nknots[ch];
+        if (n < 2 * (degree + 1) || n > NL_MAXKNOTS) { free(h); return BBX_ERR_ARG; }
+        h->n[ch] = n;
+        for (int i = 0; i < n; i++) { h->t[ch][i] = h_t[ch * NL_MAXKNOTS + i]; h->c[ch][i] = h_c[ch * NL_MAXKNOTS + i]; }
+    }
+    if (!ctx->d_nonlin) {
+        hipError_t e = hipMalloc(&ctx->d_nonlin, sizeof(nonlin_tab));
+        if (e != hipSuccess) { free(h); return bbx_hip_fail(ctx, e, "hipMalloc(nonlin)", __LINE__); }
+    }
+    hipError_t e = hipMemcpy(ctx->d_nonlin, h, sizeof(nonlin_tab), hipMemcpyHostToDevice);
+    free(h);
+    if (e != hipSuccess) return bbx_hip_fail(ctx, e, "hipMemcpy(nonlin)", __LINE__);
+    ctx->nonlin_on = 1;
+    return BBX_OK;
+}
+
+extern "C" int bbx_nonlin_corr(bbx_ctx* ctx, const bbx_geom* g, float* d_data, const float* h_gain, void* stream) {
+    if (!ctx || !d_data || !h_gain || !ctx->d_nonlin) return BBX_ERR_ARG;
+    bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
+    f32x16 gain; for (int i = 0; i < 16; i++) gain.v[i] = h_gain[i];
+    hipLaunchKernelGGL(k_nonlin, dim3(4096), dim3(256), 0, (hipStream_t)stream, d_data, d, gain, (const nonlin_tab*)ctx->d_nonlin);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -49,6 +49,8 @@ struct bbx_ctx {
     uint32_t* d_satlist;  int64_t cap_satlist;   // saturated pixel indices (reduced frame)
     void*     flags_clean_ptr; // LA-Cosmic flag plane known to be all-zero (see bbx_lacosmic)
     size_t    flags_clean_bytes;
+    void*     d_nonlin;        // nonlin_tab (bbx_calibrate.hip) or NULL
+    int       nonlin_on;
     void*     hash_clean_ptr;  // connected-component key table known to be all-empty (see bbx_cc_count_list)
     size_t    hash_clean_n;
     int32_t*  d_counters;      // [CNT_MAX] device counters (see enum below)

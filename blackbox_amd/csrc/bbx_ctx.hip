@@ -109,6 +109,7 @@ void bbx_ctx_destroy(bbx_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < WS_MAX; i++) if (ctx->d_ws[i]) (void)hipFree(ctx->d_ws[i]);
     if (ctx->d_satlist) (void)hipFree(ctx->d_satlist);
+    if (ctx->d_nonlin) (void)hipFree(ctx->d_nonlin);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->prof_ev) { for (int i = 0; i < 2 * BBX_PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]); free(ctx->prof_ev); free(ctx->prof_slot); }

@@ -295,6 +295,61 @@ def xtalk_corr(ctx, data, coeffs, data_mask, geom):
     check(lib.bbx_xtalk(ctx.h, C.byref(geom), _ptr(data), _ptr(data_mask), cf, ctx.stream()), 'bbx_xtalk', ctx.h)
 
 
+NL_MAXKNOTS = 256
+
+
+def spline_tck(spl):
+    """(t, c, k) of a scipy UnivariateSpline (what its __call__ hands to FITPACK splev) or of
+    a (t, c, k) tuple"""
+    if isinstance(spl, (tuple, list)):
+        t, c, k = spl
+    else:
+        t, c, k = spl._eval_args
+    return np.asarray(t, np.float64), np.asarray(c, np.float64), int(k)
+
+
+def read_nonlin_splines(path):
+    """the reference's nonlin_corr_file: a pickled list of 16 scipy spline objects
+    (blackbox.py:7400-7401)"""
+    import pickle
+    with open(path, 'rb') as f:
+        return pickle.load(f)
+
+
+def set_nonlin(ctx, splines):
+    """load the 16 per-channel non-linearity splines into the context (None switches the
+    correction off); while set, calibrate() applies nonlin_corr between the overscan and the
+    master-bias steps like blackbox_reduce (blackbox.py:1604-1624)"""
+    if splines is None:
+        check(lib.bbx_nonlin_set(ctx.h, 0, None, None, None), 'bbx_nonlin_set', ctx.h)
+        return
+    if len(splines) != 16:
+        raise ValueError('need one spline per channel (16)')
+    tck = [spline_tck(s) for s in splines]
+    k = tck[0][2]
+    if any(x[2] != k for x in tck):
+        raise ValueError('splines of different degree')
+    n = (C.c_int32 * 16)()
+    t = np.zeros((16, NL_MAXKNOTS)); c = np.zeros((16, NL_MAXKNOTS))
+    for i, (ti, ci, _) in enumerate(tck):
+        if ti.size > NL_MAXKNOTS:
+            raise ValueError('spline with more than %d knots' % NL_MAXKNOTS)
+        n[i] = ti.size
+        t[i, :ti.size] = ti
+        c[i, :ci.size] = ci[:ti.size]
+    check(lib.bbx_nonlin_set(ctx.h, k, n, t.ctypes.data_as(_lib._pd), c.ctypes.data_as(_lib._pd)), 'bbx_nonlin_set', ctx.h)
+
+
+def nonlin_corr(ctx, data, geom, tel, splines=None):
+    """blackbox.py:7394-7437 in place on an overscan-corrected device frame (the splines
+    are those of the last set_nonlin unless given)"""
+    if splines is not None:
+        set_nonlin(ctx, splines)
+    g32 = _lib.f32x16(get_par(settings.gain, tel))
+    check(lib.bbx_nonlin_corr(ctx.h, C.byref(geom), _ptr(data), g32, ctx.stream()), 'bbx_nonlin_corr', ctx.h)
+    return data
+
+
 NTHETA_SAT = 720
 
 
@@ -350,7 +405,7 @@ def hval(header, key):
 
 def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None,
                   exptime=None, ysize_chan=None, xsize_chan=None, do_cosmics=True, crmask_override=None,
-                  accum='f32seq', stages=None, detect_sats=True):
+                  accum='f32seq', stages=None, detect_sats=True, nonlin_splines=None):
     """The hot path of blackbox_reduce for an 'object' frame (blackbox.py:1451-1974):
     raw device tensor -> (data, mask, header, header_mask).  Failures of a stage
     follow the reference convention: flag <STEP>-P False and carry on."""
@@ -361,6 +416,10 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
     header['GAIN-P'] = (True, 'corrected for gain?')
     sol = os_solve(ctx, raw, header, tel, geom, accum=accum)
     header['OS-P'] = (True, 'corrected for overscan?')
+    # non-linearity correction (off upstream: set_bb.correct_nonlin False): done inside the fused
+    # calibration pass when splines are given
+    set_nonlin(ctx, nonlin_splines)
+    header['NONLIN-P'] = (nonlin_splines is not None, 'corrected for non-linearity?')
     use_bias = mbias is not None and get_par(settings.subtract_mbias, tel)
     data, mask = calibrate(ctx, raw, sol, header, header_mask, tel, geom,
                            mbias=mbias if use_bias else None, mflat=mflat, bpm=bpm)

@@ -138,6 +138,21 @@ int bbx_calibrate(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_ty
                   const float *h_satlevel, float *d_data, uint8_t *d_mask,
                   void *stream);
 
+/* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
+ * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1
+ * (sic: uncorrected pixels end up divided by 2, reproduced as written); data /= frac + 1.
+ * The splines are scipy UnivariateSpline objects in the reference's pickle; here their
+ * (t, c, k) arrays, evaluated like FITPACK splev.
+ *  bbx_nonlin_set : degree k (1..5), h_nknots[16], h_t / h_c [16][256] float64 (rows padded to
+ *                   256 entries).  h_nknots == NULL switches the correction off again.  While
+ *                   set, bbx_calibrate applies it between the overscan and the bias steps
+ *                   (its place in blackbox_reduce, 1604-1624).
+ *  bbx_nonlin_corr: the function on its own, in place on an overscan-corrected frame.      */
+int bbx_nonlin_set(bbx_ctx *ctx, int degree, const int32_t *h_nknots, const double *h_t,
+                   const double *h_c);
+int bbx_nonlin_corr(bbx_ctx *ctx, const bbx_geom *g, float *d_data, const float *h_gain,
+                    void *stream);
+
 /* ---- a9 (second half): mask_init tail + fill_sat_holes ---------------------------
  * replaces mask_init 4504-4562 (crosstalk flags of saturated pixels in the 15
  * other channels, NOBJ-SAT label count, 3x3 dilation -> saturated-connected) and

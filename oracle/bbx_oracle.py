@@ -547,6 +547,22 @@ def xtalk_corr(data, coeffs, data_mask, ysize_chan, xsize_chan):
                   ).astype(np.float32)
 
 
+def nonlin_corr(data, splines, gain, ysize_chan, xsize_chan):
+    """blackbox.py:7394-7437, in place on the (overscan-corrected) reduced-shape float32 frame.
+    [splines]: 16 callables (scipy UnivariateSpline in the reference's pickle).  Uncorrected
+    pixels (counts > 50000) get frac = 1, i.e. are divided by 2 -- as the reference does."""
+    sec = define_sections(data.shape, ysize_chan, xsize_chan)[4]
+    for i in range(16):
+        # float32 array / python float -> float32 (numpy 1.x value-based casting, 7422)
+        counts = data[sec[i]] / np.float32(gain[i])
+        frac = np.ones(counts.shape)
+        m = counts <= 50000
+        frac[m] = splines[i](counts[m])
+        d = data[sec[i]]
+        d[...] = (d.astype(np.float64) / (frac + 1)).astype(np.float32)      # float32 /= float64
+    return data
+
+
 # --------------------------------------------------------------------------------
 # master frames
 # --------------------------------------------------------------------------------
