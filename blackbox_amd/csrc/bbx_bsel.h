@@ -19,7 +19,7 @@
 #include "bbx_common.h"
 
 #define BSEL_S 16384
-#define BSEL_MAXSEG 16
+#define BSEL_MAXSEG 64
 #define BSEL_LBUF 6144            // LDS staging entries per workgroup (24 KB)
 #define BSEL_NSH 64               // shards per segment
 
@@ -48,6 +48,7 @@ struct bsel_dev {                 // passed by value to feeding kernels
     uint32_t cap;                 // = BSEL_NSH * capS (segment stride of buf)
     uint32_t capS;
     int ysz, xsz, SX;             // segment rectangles
+    int stride;                   // elements between image rows (>= SX * xsz)
 };
 
 __device__ __forceinline__ unsigned bsel_my_shard() {
@@ -127,7 +128,9 @@ __device__ __forceinline__ void bsel_flush(const bsel_dev& b, int seg, bsel_acc&
 }
 
 // host-side entry points (bbx_select.hip)
+// [stride] = elements between rows of d_data / d_mask (0: = nx); the ny x nx area is cut into
+// (ny/ysz) x (nx/xsz) <= BSEL_MAXSEG segments
 int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, int ny, int nx, int ysz, int xsz,
-                     bsel_dev* out, hipStream_t s);
+                     bsel_dev* out, hipStream_t s, int stride = 0);
 int bbx_bsel_finish(bbx_ctx* ctx, const bsel_dev& b, const float* d_data, const uint8_t* d_mask, int ny, int nx,
                     hipStream_t s);

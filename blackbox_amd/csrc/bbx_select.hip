@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void k_sel_hist_frame(sel_args a) {
     for (int x = threadIdx.x; x < xend; x += blockDim.x) {
         bool in = x < a.xsz;
         if (in && a.mask && (a.mask[row + x] & ~BBX_MASK_COSMIC)) in = false;
+        if (in && !(a.data[row + x] == a.data[row + x])) in = false;             // NaN
         const uint32_t key = in ? f2key(a.data[row + x]) - klo : 0u;
         sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
     }
@@ -333,8 +334,10 @@ static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, bsel_
 }
 
 int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, int ny, int nx, int ysz, int xsz,
-                     bsel_dev* out, hipStream_t s) {
-    if (ny % ysz || nx % xsz) return BBX_ERR_ARG;
+                     bsel_dev* out, hipStream_t s, int stride) {
+    if (ysz < 1 || xsz < 1 || ny % ysz || nx % xsz) return BBX_ERR_ARG;
+    if (stride == 0) stride = nx;
+    if (stride < nx) return BBX_ERR_ARG;
     const int SX = nx / xsz, nseg = SX * (ny / ysz);
     if (nseg > BSEL_MAXSEG) return BBX_ERR_ARG;
     // side buffer: 1/8 of the segment (the bracket holds ~5 %), at least 64k values
@@ -346,10 +349,10 @@ int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, i
     int rc = ws_layout(ctx, nseg, cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_bsel_init, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg);
-    hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, nx, ysz, xsz, SX, seg, samples);
+    hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, stride, ysz, xsz, SX, seg, samples);
     hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
     BBX_LAUNCH_CHECK();
-    out->seg = seg; out->shard = shard; out->buf = buf; out->cap = cap; out->capS = capS; out->ysz = ysz; out->xsz = xsz; out->SX = SX;
+    out->seg = seg; out->shard = shard; out->buf = buf; out->cap = cap; out->capS = capS; out->ysz = ysz; out->xsz = xsz; out->SX = SX; out->stride = stride;
     return BBX_OK;
 }
 
@@ -360,7 +363,7 @@ int bbx_bsel_finish(bbx_ctx* ctx, const bsel_dev& b, const float* d_data, const 
     int rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
     if (rc) return rc;
     sel_args a;
-    a.data = d_data; a.mask = d_mask; a.nx = nx; a.ysz = b.ysz; a.xsz = b.xsz; a.SX = SX;
+    a.data = d_data; a.mask = d_mask; a.nx = b.stride; a.ysz = b.ysz; a.xsz = b.xsz; a.SX = SX;
     a.b = b; a.prefix = prefix; a.rank = rank; a.hist = hist; a.klo = klo; a.nbits = nbits; a.pass = 0;
     hipLaunchKernelGGL(k_sel_zero, dim3(32), dim3(256), 0, s, hist, nseg * 2 * SEL_BINS);
     hipLaunchKernelGGL(k_sel_plan, dim3(1), dim3(64), 0, s, a, nseg);
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_frame(const float* __restrict
                 bool valid = in;
                 if (in && mask && (mask[row + x] & ~BBX_MASK_COSMIC)) valid = false;
                 const float v = in ? data[row + x] : 0.f;
+                if (!(v == v)) valid = false;                              // NaN: like np.nanmedian
                 bsel_feed(L, lo, hi, v, valid, acc);
             }
             // at most 1024 appends until the next drain point; force at the end of a
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
             const uint8_t mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const bool valid = !(mm[q] & ~BBX_MASK_COSMIC);
+                const bool valid = !(mm[q] & ~BBX_MASK_COSMIC) && v[q] == v[q];       // NaN: like np.nanmedian
                 nvalid += valid ? 1u : 0u;
                 nbelow += (valid && v[q] < lo) ? 1u : 0u;
                 if (valid && v[q] >= lo && v[q] <= hi) {
@@ -464,10 +468,11 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
 }
 
 int bbx_bsel_feed_frame(const float* d_data, const uint8_t* d_mask, int ny, int nx, const bsel_dev& b, hipStream_t s) {
-    const bool vec = (b.xsz % 4 == 0) && (b.xsz <= 2048) && (b.ysz % FEED_ROWS == 0) && (((uintptr_t)d_data) % 16 == 0) && (nx % 4 == 0) &&
+    const bool vec = (b.xsz % 4 == 0) && (b.xsz <= 2048) && (b.ysz % FEED_ROWS == 0) && (((uintptr_t)d_data) % 16 == 0) && (b.stride % 4 == 0) &&
                      (!d_mask || ((uintptr_t)d_mask) % 4 == 0);
-    if (vec) hipLaunchKernelGGL(k_bsel_feed_v4, dim3(ny / FEED_ROWS, b.SX), dim3(256), 0, s, d_data, d_mask, nx, b);
-    else hipLaunchKernelGGL(k_bsel_feed_frame, dim3((ny + 3) / 4, b.SX), dim3(256), 0, s, d_data, d_mask, ny, nx, b);
+    (void)nx;
+    if (vec) hipLaunchKernelGGL(k_bsel_feed_v4, dim3(ny / FEED_ROWS, b.SX), dim3(256), 0, s, d_data, d_mask, b.stride, b);
+    else hipLaunchKernelGGL(k_bsel_feed_frame, dim3((ny + 3) / 4, b.SX), dim3(256), 0, s, d_data, d_mask, ny, b.stride, b);
     return BBX_OK;
 }
 
@@ -502,6 +507,86 @@ extern "C" int bbx_edge_fill(bbx_ctx* ctx, const bbx_geom* g, float* d_data, con
     rc = bbx_bsel_finish(ctx, b, d_data, nullptr, d.ny, d.nx, s); if (rc) return rc;
     hipLaunchKernelGGL(k_chan_median, dim3(1), dim3(64), 0, s, b.seg, d_chan_median);
     hipLaunchKernelGGL(k_edge_fill, dim3(2048), dim3(256), 0, s, d_data, d_mask, d, d_chan_median);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+
+// ---------------------------------------------------------------------------------
+// a14 / a8 statistics: per-segment median, mean, sigma and "lower-half" sigma
+// (get_flatstats, blackbox.py:3661-3820)
+// ---------------------------------------------------------------------------------
+#define RS_ROWS 8
+// block (chunk of RS_ROWS rows, segment column): float64 sums of the valid pixels of one
+// segment: n, sum x, sum x^2, and for x <= median: n_low, sum (x - median)^2
+__global__ __launch_bounds__(256) void k_seg_moments(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                     int stride, bsel_dev b, int nchunk, double* __restrict__ partial) {
+    const int sx = blockIdx.y;
+    const int sy = blockIdx.x / nchunk, cin = blockIdx.x - sy * nchunk;      // strip [cin] of segment row [sy]
+    const int Y0 = sy * b.ysz + cin * RS_ROWS, nrow = min(RS_ROWS, b.ysz - cin * RS_ROWS);
+    const int sg = sy * b.SX + sx;
+    const float lo = b.seg[sg].result[0], hi = b.seg[sg].result[1];
+    const float med = (b.seg[sg].n & 1) ? lo : (lo + hi) * 0.5f;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int r = 0; r < nrow; r++) {
+        const size_t row = (size_t)(Y0 + r) * stride + (size_t)sx * b.xsz;
+        for (int x = threadIdx.x; x < b.xsz; x += 256) {
+            const float v = data[row + x];
+            const bool valid = (v == v) && !(mask && (mask[row + x] & ~BBX_MASK_COSMIC));
+            if (valid) {
+                const double d = (double)v;
+                s[0] += 1.0; s[1] += d; s[2] += d * d;
+                if (v <= med) { const double e = (double)(v - med); s[3] += 1.0; s[4] += e * e; }
+            }
+        }
+    }
+    __shared__ double sh[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const double w = wave_sum_f64(s[k]); if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = w; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int k = threadIdx.x;
+        // partial[sg][strip within the segment][5]
+        partial[((size_t)sg * nchunk + cin) * 5 + k] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+    }
+}
+
+// one wave per segment: fold the partials in fixed order -> out[sg][8] =
+// {n, median, mean, sigma (ddof 0), n_low, sigma_low (ddof 1 about the median), 0, 0}
+__global__ __launch_bounds__(64) void k_seg_finalize(bsel_dev b, int nchunk, const double* __restrict__ partial,
+                                                     double* __restrict__ out) {
+    const int sg = blockIdx.x, lane = threadIdx.x;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int c = lane; c < nchunk; c += 64)
+        for (int k = 0; k < 5; k++) s[k] += partial[((size_t)sg * nchunk + c) * 5 + k];
+    for (int k = 0; k < 5; k++) s[k] = wave_sum_f64(s[k]);
+    if (lane == 0) {
+        const float lo = b.seg[sg].result[0], hi = b.seg[sg].result[1];
+        const float med = (b.seg[sg].n & 1) ? lo : (lo + hi) * 0.5f;
+        const double n = s[0], mean = s[1] / n;
+        double var = s[2] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double* o = out + (size_t)sg * 8;
+        o[0] = n; o[1] = n > 0 ? (double)med : __longlong_as_double(0x7ff8000000000000LL);
+        o[2] = mean; o[3] = sqrt(var); o[4] = s[3]; o[5] = sqrt(s[4] / (s[3] - 1.0)); o[6] = 0.0; o[7] = 0.0;
+    }
+}
+
+extern "C" int bbx_rect_stats(bbx_ctx* ctx, int ny, int nx, int stride, const float* d_data, const uint8_t* d_mask,
+                              int ysz, int xsz, double* d_out, void* stream) {
+    if (!ctx || !d_data || !d_out || ny < 1 || nx < 1 || stride < nx || ysz < 1 || xsz < 1) return BBX_ERR_ARG;
+    if (ny % ysz || nx % xsz) return BBX_ERR_ARG;
+    const int SX = nx / xsz, nseg = SX * (ny / ysz);
+    if (nseg > BSEL_MAXSEG) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bsel_dev b;
+    int rc = bbx_bsel_prepare(ctx, d_data, d_mask, ny, nx, ysz, xsz, &b, s, stride); if (rc) return rc;
+    bbx_bsel_feed_frame(d_data, d_mask, ny, nx, b, s);
+    rc = bbx_bsel_finish(ctx, b, d_data, d_mask, ny, nx, s); if (rc) return rc;
+    const int nchunk = (ysz + RS_ROWS - 1) / RS_ROWS;
+    double* partial = (double*)bbx_ws(ctx, WS_HIST, (size_t)nseg * nchunk * 5 * sizeof(double), &rc); if (rc) return rc;
+    hipLaunchKernelGGL(k_seg_moments, dim3((ny / ysz) * nchunk, SX), dim3(256), 0, s, d_data, d_mask, stride, b, nchunk, partial);
+    hipLaunchKernelGGL(k_seg_finalize, dim3(nseg), dim3(64), 0, s, b, nchunk, partial, d_out);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -138,6 +138,19 @@ int bbx_calibrate(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_ty
                   const float *h_satlevel, float *d_data, uint8_t *d_mask,
                   void *stream);
 
+/* ---- a14 (+ a8 header statistics): statistics of rectangular segments ---------------
+ * replaces the np.nanmedian / np.nanstd / np.ma.median calls of get_flatstats
+ * (blackbox.py:3661-3820): the ny x nx area at d_data (row stride [stride] elements; a
+ * sub-section of a frame is addressed by offsetting the pointers) is cut into
+ * (ny/ysz) x (nx/xsz) <= 64 segments; per segment, over the pixels that are not NaN and
+ * (when d_mask is given) have no mask bit other than "cosmic ray":
+ *   d_out[seg][8] f64 = { n, median (np.median of float32: float32 mean of the two middle
+ *   elements for even n), mean, sigma (ddof 0), n_low = #(x <= median),
+ *   sigma_low = sqrt(sum_{x<=median} (x - median)^2 / (n_low - 1)), 0, 0 }
+ * The medians are exact order statistics (bracketed select, no sort).                   */
+int bbx_rect_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float *d_data,
+                   const uint8_t *d_mask, int ysz, int xsz, double *d_out, void *stream);
+
 /* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
  * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1
  * (sic: uncorrected pixels end up divided by 2, reproduced as written); data /= frac + 1.

@@ -563,6 +563,50 @@ def nonlin_corr(data, splines, gain, ysize_chan, xsize_chan):
     return data
 
 
+def get_flatstats(data, data_mask, statsec, ysize_chan, xsize_chan, subsize, fraction=None, seed=0):
+    """blackbox.py:3661-3820 -> dict of the header values.  [fraction] None: the deterministic
+    variant (all valid pixels where the reference draws an unseeded random subsample);
+    a number: the reference's estimator with a seeded RandomState (0.2 for the frame, half of
+    it for the sub-images), to show the two agree within the sampling error."""
+    out = {}
+    mask_use = data_mask == 0
+    m = mask_use[statsec]
+    out['MEDSEC'] = np.nanmedian(data[statsec][m])
+    out['STDSEC'] = np.nanstd(data[statsec][m])
+    rs = np.random.RandomState(seed)
+    if fraction is None:
+        sel = data[mask_use]
+    else:
+        idx = rs.choice(data.size, int(fraction * data.size), replace=False)
+        sel = data.ravel()[idx][mask_use.ravel()[idx]]
+    out['FLATMED'] = np.nanmedian(sel)
+    out['FLATSTD'] = np.nanstd(sel)
+    sec = define_sections(data.shape, ysize_chan, xsize_chan)[4]
+    for i in range(16):
+        out['FLATM%d' % (i + 1)] = np.nanmedian(data[sec[i]])
+        out['FLATS%d' % (i + 1)] = np.nanstd(data[sec[i]])
+    ns = data.shape[0] // subsize
+    dm = np.ma.masked_array(data[:ns * subsize, :ns * subsize], mask=~mask_use[:ns * subsize, :ns * subsize]).reshape(
+        ns, subsize, -1, subsize).swapaxes(1, 2).reshape(ns, ns, -1)
+    if fraction is None:
+        mini_median = np.ma.median(dm, axis=2)
+    else:
+        idx = rs.choice(dm.shape[2], int(0.5 * fraction * dm.shape[2]), replace=False)
+        mini_median = np.ma.median(dm[:, :, idx], axis=2)
+    mm = mini_median.reshape(ns, ns, 1)
+    dm.mask |= (dm > mm)
+    mini_std = np.sqrt(np.ma.sum((dm - mm) ** 2, axis=2) / (np.ma.count(dm, axis=2) - 1))
+    from scipy import ndimage
+    cn = ndimage.binary_erosion(np.ones(mini_median.shape, dtype=bool))
+    mn, mx = np.amin(mini_median[cn]), np.amax(mini_median[cn])
+    out['RDIF-MAX'] = np.abs((mx - mn) / (mx + mn))
+    nz = mini_median[cn] != 0
+    out['RSTD-MAX'] = np.amax(mini_std[cn][nz] / np.abs(mini_median[cn][nz]))
+    out['mini_median'] = np.asarray(mini_median)
+    out['mini_std'] = np.asarray(mini_std)
+    return out
+
+
 # --------------------------------------------------------------------------------
 # master frames
 # --------------------------------------------------------------------------------

@@ -1,0 +1,60 @@
+"""a14 get_flatstats (blackbox.py:3661-3820): HIP segment statistics against the oracle's
+numpy restatement (deterministic variant), and the oracle's deterministic variant against
+the reference's random-subsample estimator."""
+import numpy as np
+import pytest
+
+import bbx_oracle as O
+
+
+def flat_frame(seed, ys=192, xs=48):
+    rs = np.random.RandomState(seed)
+    ny, nx = 2 * ys, 8 * xs
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    flat = 30000.0 * (1 - 0.1 * ((yy / ny - 0.5) ** 2 + (xx / nx - 0.5) ** 2))
+    data = (flat + rs.normal(0, 1, (ny, nx)) * np.sqrt(flat)).astype(np.float32)
+    # a few stars and bad pixels
+    mask = np.zeros((ny, nx), np.uint8)
+    mask[rs.randint(0, ny, 300), rs.randint(0, nx, 300)] = 1
+    data[rs.randint(0, ny, 200), rs.randint(0, nx, 200)] += 5e4
+    data[5, 7] = np.nan
+    return data, mask
+
+
+def test_oracle_estimator_vs_population():
+    data, mask = flat_frame(1)
+    sec = (slice(40, 120), slice(100, 300))
+    a = O.get_flatstats(data, mask, sec, 192, 48, 96)
+    b = O.get_flatstats(data, mask, sec, 192, 48, 96, fraction=0.2, seed=5)
+    assert a['MEDSEC'] == b['MEDSEC'] and a['STDSEC'] == b['STDSEC']
+    n = 0.2 * data.size
+    assert abs(a['FLATMED'] - b['FLATMED']) < 5 * 1.25 * a['FLATSTD'] / np.sqrt(n)
+    assert abs(a['FLATSTD'] - b['FLATSTD']) < 0.05 * a['FLATSTD']
+
+
+@pytest.mark.gpu
+def test_gpu_flatstats_vs_oracle():
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R
+    from blackbox_amd import flatstats as F
+    ctx = R.Context(0)
+    for seed, (ys, xs, sub) in ((1, (192, 48, 96)), (2, (180, 45, 60))):
+        data, mask = flat_frame(seed, ys, xs)
+        sec = (slice(37, 37 + 75), slice(30, 30 + 301))            # odd sizes: scalar / ragged paths
+        want = O.get_flatstats(data, mask, sec, ys, xs, sub)
+        h = F.get_flatstats(ctx, torch.from_numpy(data).to(ctx.device), {}, torch.from_numpy(mask).to(ctx.device),
+                            'ML1', statsec=sec, subsize=sub, ysize_chan=ys, xsize_chan=xs)
+        # medians are order statistics: exact
+        for k in ['MEDSEC', 'FLATMED'] + ['FLATM%d' % (c + 1) for c in range(16)]:
+            assert R.hval(h, k) == want[k], k
+        # sigmas: float64 moments here, float32 pairwise sums in numpy -> 2e-6 relative
+        for k in ['STDSEC', 'FLATSTD'] + ['FLATS%d' % (c + 1) for c in range(16)]:
+            assert R.hval(h, k) == pytest.approx(want[k], rel=2e-6), k
+        assert R.hval(h, 'RDIF-MAX') == pytest.approx(want['RDIF-MAX'], rel=1e-6)
+        assert R.hval(h, 'RSTD-MAX') == pytest.approx(want['RSTD-MAX'], rel=2e-6)
+        assert R.hval(h, 'RSTDSEC') == pytest.approx(want['STDSEC'] / want['MEDSEC'], rel=2e-6)
+        ns = data.shape[0] // sub
+        assert R.hval(h, 'NSUBSTOT') == ns * ns
+    ctx.close()
