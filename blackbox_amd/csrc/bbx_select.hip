@@ -590,3 +590,20 @@ extern "C" int bbx_rect_stats(bbx_ctx* ctx, int ny, int nx, int stride, const fl
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
+
+// in-place scaling of a rectangle: data[y][x] /= f or *= f (float32, IEEE)
+__global__ __launch_bounds__(256) void k_rect_scale(float* data, int ny, int nx, int stride, float f, int divide) {
+    const size_t total = (size_t)ny * nx;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t y = t / nx, x = t - y * nx;
+        float* p = data + y * stride + x;
+        *p = divide ? (*p / f) : (*p * f);
+    }
+}
+
+extern "C" int bbx_rect_scale(bbx_ctx* ctx, int ny, int nx, int stride, float* d_data, float factor, int divide, void* stream) {
+    if (!ctx || !d_data || ny < 1 || nx < 1 || stride < nx) return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_rect_scale, dim3(2048), dim3(256), 0, (hipStream_t)stream, d_data, ny, nx, stride, factor, divide);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}

@@ -37,3 +37,46 @@ def master_median(ctx, frames, imgtype, medsec=None, bpm=None):
                                1 if (imgtype == 'flat' and bpm is not None) else 0,
                                C.c_void_p(out.data_ptr()), ctx.stream()), 'bbx_median_stack', ctx.h)
     return out
+
+
+def _rect_scale(ctx, t, y0, x0, ny, nx, factor, divide):
+    NX = t.shape[1]
+    check(lib.bbx_rect_scale(ctx.h, ny, nx, NX, C.c_void_p(t.data_ptr() + 4 * (y0 * NX + x0)), C.c_float(float(factor)),
+                             1 if divide else 0, ctx.stream()), 'bbx_rect_scale', ctx.h)
+
+
+def gain_correction_factors(ctx, master, header, ysize_chan=None, xsize_chan=None, nrows_v=200, nrows_h=2000,
+                            ncols=200):
+    """GAINCF{c} of a master flat (blackbox.py:5085-5161): match the channels vertically
+    with the medians of the [nrows_v] rows next to the central row boundary, then
+    horizontally, pair of channel columns by pair, with the medians of [ncols] columns
+    either side of each boundary over 2*[nrows_h] central rows; factors normalised to a
+    mean of one.  Medians are exact (bbx_rect_stats); the frame copy is scaled channel by
+    channel on the device (float32, like numpy's in-place ops on the float32 master)."""
+    import numpy as np
+    from . import flatstats
+    NY, NX = master.shape
+    ysz, xsz = ysize_chan or NY // 2, xsize_chan or NX // 8
+    corr = master.clone()
+    med = np.zeros(16)
+    for c in range(16):
+        iy, ix = divmod(c, 8)
+        y0 = (ysz - nrows_v) if iy == 0 else ysz
+        med[c] = np.float32(flatstats.rect_stats(ctx, corr, None, y0, ix * xsz, nrows_v, xsz, nrows_v, xsz)[0, 1])
+        _rect_scale(ctx, corr, iy * ysz, ix * xsz, ysz, xsz, med[c], True)
+    factor = 1.0 / med
+    for i in range(1, 8):
+        x_index = i * xsz
+        m1 = np.float32(flatstats.rect_stats(ctx, corr, None, ysz - nrows_h, x_index - ncols, 2 * nrows_h, ncols,
+                                             2 * nrows_h, ncols)[0, 1])
+        m2 = np.float32(flatstats.rect_stats(ctx, corr, None, ysz - nrows_h, x_index, 2 * nrows_h, ncols,
+                                             2 * nrows_h, ncols)[0, 1])
+        ratio = np.float32(m1) / np.float32(m2)
+        _rect_scale(ctx, corr, 0, i * xsz, ysz, xsz, ratio, False)
+        _rect_scale(ctx, corr, ysz, i * xsz, ysz, xsz, ratio, False)
+        factor[i] *= ratio
+        factor[i + 8] *= ratio
+    factor /= np.mean(factor)
+    for c in range(16):
+        header['GAINCF{}'.format(c + 1)] = (float(factor[c]), 'channel {} gain correction factor'.format(c + 1))
+    return factor

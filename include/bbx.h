@@ -151,6 +151,12 @@ int bbx_calibrate(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_ty
 int bbx_rect_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float *d_data,
                    const uint8_t *d_mask, int ysz, int xsz, double *d_out, void *stream);
 
+/* ---- a8 (GAINCF): channel scaling of the master flat copy ---------------------------
+ * replaces `master_median_corr[data_sec_red[c]] /= med` and `*= ratio` (blackbox.py:5104,
+ * 5139-5140): float32 IEEE division / multiplication of a rectangle in place.            */
+int bbx_rect_scale(bbx_ctx *ctx, int ny, int nx, int stride, float *d_data, float factor,
+                   int divide, void *stream);
+
 /* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
  * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1
  * (sic: uncorrected pixels end up divided by 2, reproduced as written); data /= frac + 1.

@@ -621,3 +621,29 @@ def master_median(cube, imgtype, medsec=None, bpm=None):
     if imgtype == 'flat' and bpm is not None:
         master[(bpm == 32) | (master <= 0)] = 1
     return master
+
+
+def gain_correction_factors(master, ysize_chan, xsize_chan, nrows_v=200, nrows_h=2000, ncols=200):
+    """blackbox.py:5085-5161 -> factor_chan[16] (float64).  The float32 master copy is scaled
+    in place by float32 scalars (numpy 1.x value-based casting of np.float64/np.float32
+    scalars against a float32 array)."""
+    sec = define_sections(master.shape, ysize_chan, xsize_chan)[4]
+    corr = np.copy(master)
+    med = np.zeros(16)
+    for i in range(16):
+        d = corr[sec[i]]
+        med[i] = np.median(d[-nrows_v:, :]) if i < 8 else np.median(d[0:nrows_v, :])
+        d /= np.float32(med[i])
+    factor = 1. / med
+    dy, dx = ysize_chan, xsize_chan
+    for i in range(1, 8):
+        y_index, x_index = dy, i * dx
+        s1 = corr[y_index - nrows_h:y_index + nrows_h, x_index - ncols:x_index]
+        s2 = corr[y_index - nrows_h:y_index + nrows_h, x_index:x_index + ncols]
+        ratio = np.median(s1) / np.nanmedian(s2)
+        corr[sec[i]] *= np.float32(ratio)
+        corr[sec[i + 8]] *= np.float32(ratio)
+        factor[i] *= ratio
+        factor[i + 8] *= ratio
+    factor /= np.mean(factor)
+    return factor

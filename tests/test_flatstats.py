@@ -58,3 +58,31 @@ def test_gpu_flatstats_vs_oracle():
         ns = data.shape[0] // sub
         assert R.hval(h, 'NSUBSTOT') == ns * ns
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_gaincf_vs_oracle():
+    """GAINCF{c} (blackbox.py:5085-5161): exact strip medians + float32 channel scalings"""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R
+    from blackbox_amd import masters
+    ctx = R.Context(0)
+    ys, xs = 160, 72
+    rs = np.random.RandomState(4)
+    master = (1.0 + 0.01 * rs.normal(size=(2 * ys, 8 * xs))).astype(np.float32)
+    gains = 1 + 0.05 * rs.normal(size=16)
+    for c in range(16):
+        iy, ix = divmod(c, 8)
+        master[iy * ys:(iy + 1) * ys, ix * xs:(ix + 1) * xs] *= np.float32(gains[c])
+    want = O.gain_correction_factors(master, ys, xs, nrows_v=20, nrows_h=50, ncols=16)
+    h = {}
+    got = masters.gain_correction_factors(ctx, torch.from_numpy(master).to(ctx.device), h, ys, xs, nrows_v=20,
+                                          nrows_h=50, ncols=16)
+    assert np.array_equal(got, want)
+    # and they undo the injected gains up to the noise of the strip medians
+    rel = want * gains
+    assert np.std(rel / rel.mean()) < 3e-3
+    assert R.hval(h, 'GAINCF5') == want[4]
+    ctx.close()
