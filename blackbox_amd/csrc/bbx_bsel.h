@@ -32,6 +32,7 @@ struct bsel_seg {
     uint32_t fail;                // 1 -> full select required
     uint32_t pad;
     float result[2];              // lower / upper middle element (ranks (n-1)/2 and n/2)
+    double wlo, whi;              // value window of the valid pixels (sigma clipping); +-inf = none
 };
 
 struct bsel_shard {               // exactly one cache line
@@ -49,7 +50,15 @@ struct bsel_dev {                 // passed by value to feeding kernels
     uint32_t capS;
     int ysz, xsz, SX;             // segment rectangles
     int stride;                   // elements between image rows (>= SX * xsz)
+    int skip_zero;                // 1: pixels equal to 0 are invalid (astropy mask_value=0)
 };
+
+// value-side validity shared by the generic feeders: not NaN, inside the segment's window,
+// not the masked value
+__device__ __forceinline__ bool bsel_value_ok(float v, double wlo, double whi, int skip_zero) {
+    const double d = (double)v;
+    return (v == v) && d >= wlo && d <= whi && !(skip_zero && v == 0.f);
+}
 
 __device__ __forceinline__ unsigned bsel_my_shard() {
     return (blockIdx.x + blockIdx.y * gridDim.x) & (BSEL_NSH - 1);

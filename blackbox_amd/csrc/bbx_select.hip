@@ -103,13 +103,14 @@ __global__ __launch_bounds__(256) void k_bsel_init(bsel_seg* seg, bsel_shard* sh
         bsel_seg s;
         s.lo = 0.f; s.hi = 0.f; s.nsample = 0; s.nbuf = 0; s.below = 0; s.n = 0; s.fail = 0; s.pad = 0;
         s.result[0] = s.result[1] = 0.f;
+        s.wlo = -__builtin_huge_val(); s.whi = __builtin_huge_val();
         seg[i] = s;
     }
 }
 
 __global__ __launch_bounds__(256) void k_bsel_sample(const float* __restrict__ data, const uint8_t* __restrict__ mask,
                                                      int nx, int ysz, int xsz, int SX, bsel_seg* seg,
-                                                     float* __restrict__ samples) {
+                                                     float* __restrict__ samples, int skip_zero) {
     const int sg = blockIdx.y;
     const int sy = sg / SX, sx = sg - sy * SX;
     const unsigned long long npix = (unsigned long long)ysz * xsz;
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(256) void k_bsel_sample(const float* __restrict__ d
         const unsigned long long j = (npix >= BSEL_S) ? ((unsigned long long)i * npix) / BSEL_S : (unsigned long long)i;
         const int y = (int)(j / xsz), x = (int)(j - (unsigned long long)y * xsz);
         const size_t o = (size_t)(sy * ysz + y) * nx + (size_t)sx * xsz + x;
-        if (!mask || !(mask[o] & ~BBX_MASK_COSMIC)) { v = data[o]; ok = (v == v) ? 1 : 0; if (!ok) v = __builtin_huge_valf(); }
+        if (!mask || !(mask[o] & ~BBX_MASK_COSMIC)) {
+            v = data[o];
+            ok = bsel_value_ok(v, seg[sg].wlo, seg[sg].whi, skip_zero) ? 1 : 0;
+            if (!ok) v = __builtin_huge_valf();
+        }
     }
     samples[(size_t)sg * BSEL_S + i] = v;
     ok = wave_sum_i32(ok);
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void k_sel_hist_frame(sel_args a) {
     for (int x = threadIdx.x; x < xend; x += blockDim.x) {
         bool in = x < a.xsz;
         if (in && a.mask && (a.mask[row + x] & ~BBX_MASK_COSMIC)) in = false;
-        if (in && !(a.data[row + x] == a.data[row + x])) in = false;             // NaN
+        if (in && !bsel_value_ok(a.data[row + x], a.b.seg[sg].wlo, a.b.seg[sg].whi, a.b.skip_zero)) in = false;
         const uint32_t key = in ? f2key(a.data[row + x]) - klo : 0u;
         sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
     }
@@ -349,10 +354,10 @@ int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, i
     int rc = ws_layout(ctx, nseg, cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_bsel_init, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg);
-    hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, stride, ysz, xsz, SX, seg, samples);
+    hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, stride, ysz, xsz, SX, seg, samples, 0);
     hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
     BBX_LAUNCH_CHECK();
-    out->seg = seg; out->shard = shard; out->buf = buf; out->cap = cap; out->capS = capS; out->ysz = ysz; out->xsz = xsz; out->SX = SX; out->stride = stride;
+    out->seg = seg; out->shard = shard; out->buf = buf; out->cap = cap; out->capS = capS; out->ysz = ysz; out->xsz = xsz; out->SX = SX; out->stride = stride; out->skip_zero = 0;
     return BBX_OK;
 }
 
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_frame(const float* __restrict
         const int sg = (Y / b.ysz) * b.SX + sx;
         const int sg_next = ((Y + 1) / b.ysz) * b.SX + sx;
         const float lo = b.seg[sg].lo, hi = b.seg[sg].hi;
+        const double wlo = b.seg[sg].wlo, whi = b.seg[sg].whi;
         const size_t row = (size_t)Y * nx + (size_t)sx * b.xsz;
         for (int x0 = 0; x0 < xend; x0 += 1024) {
             for (int x = x0 + threadIdx.x; x < min(xend, x0 + 1024); x += blockDim.x) {
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_frame(const float* __restrict
                 bool valid = in;
                 if (in && mask && (mask[row + x] & ~BBX_MASK_COSMIC)) valid = false;
                 const float v = in ? data[row + x] : 0.f;
-                if (!(v == v)) valid = false;                              // NaN: like np.nanmedian
+                if (!bsel_value_ok(v, wlo, whi, b.skip_zero)) valid = false;  // NaN (np.nanmedian), clip window, mask_value
                 bsel_feed(L, lo, hi, v, valid, acc);
             }
             // at most 1024 appends until the next drain point; force at the end of a
@@ -428,6 +434,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
     const int sx = blockIdx.y, Y0 = blockIdx.x * FEED_ROWS;
     const int sg = (Y0 / b.ysz) * b.SX + sx;
     const float lo = b.seg[sg].lo, hi = b.seg[sg].hi;
+    const double wlo = b.seg[sg].wlo, whi = b.seg[sg].whi;
     const unsigned sh = bsel_my_shard();
     float* reg = bsel_region(b, sg, sh);
     const int ng = b.xsz / 4;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256) void k_bsel_feed_v4(const float* __restrict__ 
             const uint8_t mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const bool valid = !(mm[q] & ~BBX_MASK_COSMIC) && v[q] == v[q];       // NaN: like np.nanmedian
+                const bool valid = !(mm[q] & ~BBX_MASK_COSMIC) && bsel_value_ok(v[q], wlo, whi, b.skip_zero);
                 nvalid += valid ? 1u : 0u;
                 nbelow += (valid && v[q] < lo) ? 1u : 0u;
                 if (valid && v[q] >= lo && v[q] <= hi) {
@@ -527,12 +534,13 @@ __global__ __launch_bounds__(256) void k_seg_moments(const float* __restrict__ d
     const int sg = sy * b.SX + sx;
     const float lo = b.seg[sg].result[0], hi = b.seg[sg].result[1];
     const float med = (b.seg[sg].n & 1) ? lo : (lo + hi) * 0.5f;
+    const double wlo = b.seg[sg].wlo, whi = b.seg[sg].whi;
     double s[5] = {0, 0, 0, 0, 0};
     for (int r = 0; r < nrow; r++) {
         const size_t row = (size_t)(Y0 + r) * stride + (size_t)sx * b.xsz;
         for (int x = threadIdx.x; x < b.xsz; x += 256) {
             const float v = data[row + x];
-            const bool valid = (v == v) && !(mask && (mask[row + x] & ~BBX_MASK_COSMIC));
+            const bool valid = bsel_value_ok(v, wlo, whi, b.skip_zero) && !(mask && (mask[row + x] & ~BBX_MASK_COSMIC));
             if (valid) {
                 const double d = (double)v;
                 s[0] += 1.0; s[1] += d; s[2] += d * d;
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(256) void k_seg_moments(const float* __restrict__ d
 // one wave per segment: fold the partials in fixed order -> out[sg][8] =
 // {n, median, mean, sigma (ddof 0), n_low, sigma_low (ddof 1 about the median), 0, 0}
 __global__ __launch_bounds__(64) void k_seg_finalize(bsel_dev b, int nchunk, const double* __restrict__ partial,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out, double clip_sigma) {
     const int sg = blockIdx.x, lane = threadIdx.x;
     double s[5] = {0, 0, 0, 0, 0};
     for (int c = lane; c < nchunk; c += 64)
@@ -569,6 +577,13 @@ __global__ __launch_bounds__(64) void k_seg_finalize(bsel_dev b, int nchunk, con
         double* o = out + (size_t)sg * 8;
         o[0] = n; o[1] = n > 0 ? (double)med : __longlong_as_double(0x7ff8000000000000LL);
         o[2] = mean; o[3] = sqrt(var); o[4] = s[3]; o[5] = sqrt(s[4] / (s[3] - 1.0)); o[6] = 0.0; o[7] = 0.0;
+        if (clip_sigma > 0.0 && n > 0) {
+            // sigma clipping about the median (astropy sigma_clip, cenfunc='median'): the next
+            // round's survivors are this round's survivors inside median +- sigma * std
+            const double lo2 = (double)med - clip_sigma * o[3], hi2 = (double)med + clip_sigma * o[3];
+            if (lo2 > b.seg[sg].wlo) b.seg[sg].wlo = lo2;
+            if (hi2 < b.seg[sg].whi) b.seg[sg].whi = hi2;
+        }
     }
 }
 
@@ -586,7 +601,47 @@ extern "C" int bbx_rect_stats(bbx_ctx* ctx, int ny, int nx, int stride, const fl
     const int nchunk = (ysz + RS_ROWS - 1) / RS_ROWS;
     double* partial = (double*)bbx_ws(ctx, WS_HIST, (size_t)nseg * nchunk * 5 * sizeof(double), &rc); if (rc) return rc;
     hipLaunchKernelGGL(k_seg_moments, dim3((ny / ysz) * nchunk, SX), dim3(256), 0, s, d_data, d_mask, stride, b, nchunk, partial);
-    hipLaunchKernelGGL(k_seg_finalize, dim3(nseg), dim3(64), 0, s, b, nchunk, partial, d_out);
+    hipLaunchKernelGGL(k_seg_finalize, dim3(nseg), dim3(64), 0, s, b, nchunk, partial, d_out, 0.0);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+// counters back to zero for another select over the same segments; the clip window stays
+__global__ __launch_bounds__(256) void k_bsel_reset(bsel_seg* seg, bsel_shard* shard, int nseg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nseg * BSEL_NSH) { bsel_shard z; memset(&z, 0, sizeof(z)); shard[i] = z; }
+    if (i < nseg) { seg[i].lo = 0.f; seg[i].hi = 0.f; seg[i].nsample = 0; seg[i].nbuf = 0; seg[i].below = 0; seg[i].n = 0; seg[i].fail = 0; }
+}
+
+// astropy.stats.sigma_clipped_stats(x, sigma, maxiters, mask_value=0) per segment (cenfunc
+// median, stdfunc std): [maxiters] rounds of (median, std of the survivors -> clip), then
+// the statistics of the final survivors.  All rounds are enqueued without a host round trip.
+extern "C" int bbx_rect_clipped_stats(bbx_ctx* ctx, int ny, int nx, int stride, const float* d_data, const uint8_t* d_mask,
+                                      int ysz, int xsz, double sigma, int maxiters, int skip_zero, double* d_out,
+                                      void* stream) {
+    if (!ctx || !d_data || !d_out || ny < 1 || nx < 1 || stride < nx || ysz < 1 || xsz < 1) return BBX_ERR_ARG;
+    if (ny % ysz || nx % xsz || maxiters < 0 || maxiters > 20 || !(sigma > 0.0)) return BBX_ERR_ARG;
+    const int SX = nx / xsz, nseg = SX * (ny / ysz);
+    if (nseg > BSEL_MAXSEG) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bsel_dev b;
+    int rc = bbx_bsel_prepare(ctx, d_data, d_mask, ny, nx, ysz, xsz, &b, s, stride); if (rc) return rc;
+    b.skip_zero = skip_zero ? 1 : 0;
+    const int nchunk = (ysz + RS_ROWS - 1) / RS_ROWS;
+    double* partial = (double*)bbx_ws(ctx, WS_HIST, (size_t)nseg * nchunk * 5 * sizeof(double), &rc); if (rc) return rc;
+    bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
+    rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits); if (rc) return rc;
+    for (int it = 0; it <= maxiters; it++) {
+        // (prepare sampled without the mask value rule; sample again with the current window)
+        hipLaunchKernelGGL(k_bsel_reset, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg);
+        hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, stride, ysz, xsz, SX, seg,
+                           samples, b.skip_zero);
+        hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
+        bbx_bsel_feed_frame(d_data, d_mask, ny, nx, b, s);
+        rc = bbx_bsel_finish(ctx, b, d_data, d_mask, ny, nx, s); if (rc) return rc;
+        hipLaunchKernelGGL(k_seg_moments, dim3((ny / ysz) * nchunk, SX), dim3(256), 0, s, d_data, d_mask, stride, b, nchunk, partial);
+        hipLaunchKernelGGL(k_seg_finalize, dim3(nseg), dim3(64), 0, s, b, nchunk, partial, d_out, it < maxiters ? sigma : 0.0);
+    }
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -33,6 +33,19 @@ def rect_stats(ctx, data, mask, y0, x0, ny, nx, ysz, xsz):
     return out.cpu().numpy()
 
 
+def rect_clipped_stats(ctx, data, mask, y0, x0, ny, nx, ysz, xsz, sigma=3.0, maxiters=5, skip_zero=True):
+    """sigma_clipped_stats(..., mask_value=0) per segment -> numpy [nseg, 8] (n, median, mean, sigma, ...)"""
+    NY, NX = data.shape
+    nseg = (ny // ysz) * (nx // xsz)
+    out = torch.empty((nseg, 8), dtype=torch.float64, device=data.device)
+    off = y0 * NX + x0
+    dptr = C.c_void_p(data.data_ptr() + 4 * off)
+    mptr = C.c_void_p(mask.data_ptr() + off) if mask is not None else C.c_void_p(0)
+    check(lib.bbx_rect_clipped_stats(ctx.h, ny, nx, NX, dptr, mptr, ysz, xsz, float(sigma), int(maxiters),
+                                     1 if skip_zero else 0, R._ptr(out), ctx.stream()), 'bbx_rect_clipped_stats', ctx.h)
+    return out.cpu().numpy()
+
+
 def _finite(value, repl='None'):
     return value if np.isfinite(value) else repl
 

@@ -80,3 +80,27 @@ def gain_correction_factors(ctx, master, header, ysize_chan=None, xsize_chan=Non
     for c in range(16):
         header['GAINCF{}'.format(c + 1)] = (float(factor[c]), 'channel {} gain correction factor'.format(c + 1))
     return factor
+
+
+def master_level_stats(ctx, master, header, imgtype, ysize_chan=None, xsize_chan=None):
+    """header statistics of a master bias / dark (blackbox.py:5167-5230): sigma-clipped mean
+    and sigma of the frame and of each channel, zeros masked.  Keywords MBMEAN MBRDN
+    MBIASM{c} MBRDN{c} (bias) or MDMEAN MDRDN MDARKM{c} MDRDN{c} (dark)."""
+    from . import flatstats
+    NY, NX = master.shape
+    ysz, xsz = ysize_chan or NY // 2, xsize_chan or NX // 8
+    full = flatstats.rect_clipped_stats(ctx, master, None, 0, 0, NY, NX, NY, NX)[0]
+    chan = flatstats.rect_clipped_stats(ctx, master, None, 0, 0, NY, NX, ysz, xsz)
+    if imgtype == 'bias':
+        k = ('MBMEAN', 'MBRDN', 'MBIASM{}', 'MBRDN{}', 'bias')
+    elif imgtype == 'dark':
+        k = ('MDMEAN', 'MDRDN', 'MDARKM{}', 'MDRDN{}', 'dark')
+    else:
+        raise ValueError('bias or dark expected')
+    header[k[0]] = (float(full[2]), '[e-] mean master {}'.format(k[4]))
+    header[k[1]] = (float(full[3]), '[e-] sigma (STD) master {}'.format(k[4]))
+    for c in range(16):
+        header[k[2].format(c + 1)] = (float(chan[c, 2]), '[e-] channel {} mean master {}'.format(c + 1, k[4]))
+    for c in range(16):
+        header[k[3].format(c + 1)] = (float(chan[c, 3]), '[e-] channel {} sigma (STD) master {}'.format(c + 1, k[4]))
+    return full, chan

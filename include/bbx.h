@@ -151,6 +151,17 @@ int bbx_calibrate(bbx_ctx *ctx, const bbx_geom *g, const void *d_raw, int raw_ty
 int bbx_rect_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float *d_data,
                    const uint8_t *d_mask, int ysz, int xsz, double *d_out, void *stream);
 
+/* ---- a8 (MBMEAN, MBRDN, MBIASM{c}, MBRDN{c}, MD*): sigma-clipped statistics ------------
+ * replaces astropy.stats.sigma_clipped_stats(x, mask_value=0) of master_prep
+ * (blackbox.py:5167-5230; sigma 3, maxiters 5, centre = median, spread = std): per segment
+ * (same segmentation and validity rules as bbx_rect_stats, plus skip_zero: pixels equal to
+ * 0 are masked) [maxiters] rounds of clipping about the exact median, then
+ * d_out[seg][8] = { n, median, mean, sigma, ... } of the survivors.  The reference feeds a
+ * random 20 % subsample (unseeded); all pixels are used here.                             */
+int bbx_rect_clipped_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float *d_data,
+                           const uint8_t *d_mask, int ysz, int xsz, double sigma, int maxiters,
+                           int skip_zero, double *d_out, void *stream);
+
 /* ---- a8 (GAINCF): channel scaling of the master flat copy ---------------------------
  * replaces `master_median_corr[data_sec_red[c]] /= med` and `*= ratio` (blackbox.py:5104,
  * 5139-5140): float32 IEEE division / multiplication of a rectangle in place.            */

@@ -647,3 +647,19 @@ def gain_correction_factors(master, ysize_chan, xsize_chan, nrows_v=200, nrows_h
         factor[i + 8] *= ratio
     factor /= np.mean(factor)
     return factor
+
+
+def sigma_clipped_stats_median(x, sigma=3.0, maxiters=5, mask_value=0):
+    """astropy.stats.sigma_clipped_stats(x, mask_value=0) (astropy 4.3 defaults: centre
+    median, spread std ddof 0, closed interval) -> (mean, median, std, n) of the survivors"""
+    v = np.asarray(x).ravel()
+    v = v[np.isfinite(v) & (v != mask_value)]
+    for _ in range(maxiters):
+        n = v.size
+        if n == 0:
+            break
+        c, s = np.median(v), np.std(v.astype(np.float64))
+        v = v[(v >= c - sigma * s) & (v <= c + sigma * s)]
+        if v.size == n:
+            break
+    return np.mean(v.astype(np.float64)), np.median(v), np.std(v.astype(np.float64)), v.size

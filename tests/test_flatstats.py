@@ -86,3 +86,36 @@ def test_gpu_gaincf_vs_oracle():
     assert np.std(rel / rel.mean()) < 3e-3
     assert R.hval(h, 'GAINCF5') == want[4]
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_master_level_stats():
+    """MBMEAN / MBRDN / MBIASM{c} / MBRDN{c}: clipped statistics about the exact median"""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R
+    from blackbox_amd import masters
+    ctx = R.Context(0)
+    ys, xs = 120, 90
+    rs = np.random.RandomState(8)
+    m = rs.normal(0, 3, (2 * ys, 8 * xs)).astype(np.float32)
+    for c in range(16):
+        iy, ix = divmod(c, 8)
+        m[iy * ys:(iy + 1) * ys, ix * xs:(ix + 1) * xs] += np.float32(0.5 * c)
+    m[rs.randint(0, 2 * ys, 400), rs.randint(0, 8 * xs, 400)] += 200          # hot pixels: clipped
+    m[rs.randint(0, 2 * ys, 300), rs.randint(0, 8 * xs, 300)] = 0              # masked value
+    m[3, 3] = np.nan
+    h = {}
+    full, chan = masters.master_level_stats(ctx, torch.from_numpy(m).to(ctx.device), h, 'bias', ys, xs)
+    mean, med, std, n = O.sigma_clipped_stats_median(m)
+    assert full[0] == n and np.float32(full[1]) == med
+    assert R.hval(h, 'MBMEAN') == pytest.approx(mean, rel=1e-9, abs=1e-9)
+    assert R.hval(h, 'MBRDN') == pytest.approx(std, rel=1e-9)
+    sec = O.define_sections(m.shape, ys, xs)[4]
+    for c in range(16):
+        mean, med, std, n = O.sigma_clipped_stats_median(m[sec[c]])
+        assert chan[c, 0] == n and np.float32(chan[c, 1]) == med, c
+        assert R.hval(h, 'MBIASM%d' % (c + 1)) == pytest.approx(mean, rel=1e-9, abs=1e-9)
+        assert R.hval(h, 'MBRDN%d' % (c + 1)) == pytest.approx(std, rel=1e-9)
+    ctx.close()

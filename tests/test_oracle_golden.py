@@ -115,3 +115,24 @@ def test_define_sections_golden():
                                            xsize_chan=ref[label]['chan'][1])
         got = [[[s[0].start, s[0].stop, s[1].start, s[1].stop] for s in sec] for sec in secs]
         assert got == ref[label]['secs']
+
+
+def test_sigma_clipped_stats_vs_astropy_golden():
+    """oracle.sigma_clipped_stats_median against astropy 4.3.1 outputs (tests/golden/sigclip.npz,
+    made by oracle/gen_golden_sigclip.py in the reference environment)"""
+    import json
+    g = np.load(os.path.join(GOLD, 'sigclip.npz'))
+    for case in json.loads(str(g['meta']))['cases']:
+        rs = np.random.RandomState(case['seed'])
+        n = case['n']
+        x = rs.normal(10, 3, n).astype(np.float32)
+        k = int(case['frac_out'] * n)
+        if k:
+            x[rs.randint(0, n, k)] += 100
+        x[rs.randint(0, n, 20)] = 0
+        mean, med, std, _ = O.sigma_clipped_stats_median(x)
+        want = g['res_%d' % case['seed']]
+        # astropy accumulates the float32 survivors in float32 (bottleneck): 1e-6 relative
+        assert mean == pytest.approx(want[0], rel=2e-6)
+        assert med == pytest.approx(want[1], rel=1e-7)
+        assert std == pytest.approx(want[2], rel=5e-6)
