@@ -145,6 +145,37 @@ def psf_optflux(ctx, D, V, psfs, ys, xs):
     return flux, err
 
 
+def psf_poly_terms(x, y, polzero, polscal, poldeg):
+    """PSFEx polynomial terms of the source positions (pixel coordinates x, y; one
+    polynomial group over (x, y)): x' = (x - polzero[0]) / polscal[0], same for y; order
+    1, x', x'^2, .., y', x'y', .., y'^2, .. (y power outer, x power inner), float32.
+    -> array [nsrc, (poldeg+1)(poldeg+2)/2]"""
+    xn = ((np.asarray(x, np.float64) - polzero[0]) / polscal[0]).astype(np.float32)
+    yn = ((np.asarray(y, np.float64) - polzero[1]) / polscal[1]).astype(np.float32)
+    cols = []
+    for j in range(poldeg + 1):
+        for i in range(poldeg + 1 - j):
+            cols.append((xn ** np.float32(i)) * (yn ** np.float32(j)) if (i or j) else np.ones_like(xn))
+    return np.stack(cols, axis=1).astype(np.float32)
+
+
+def psf_model_stamps(ctx, basis, x, y, polzero, polscal, poldeg, normalize=True):
+    """PSF stamp of every source from a PSFEx model: basis [ncoef, S, S] float32 device
+    tensor (PSF_MASK), positions x, y (host arrays).  The contraction runs on the f32 MFMA
+    (bbx_psf_model).  -> device tensor [nsrc, S, S]; normalize: each stamp sums to one"""
+    terms = torch.from_numpy(psf_poly_terms(x, y, polzero, polscal, poldeg)).to(ctx.device)
+    ncoef, S = basis.shape[0], basis.shape[1]
+    if terms.shape[1] != ncoef:
+        raise ValueError('basis has %d planes, polynomial degree %d needs %d' % (ncoef, poldeg, terms.shape[1]))
+    nsrc = terms.shape[0]
+    out = torch.empty((nsrc, S, S), dtype=torch.float32, device=ctx.device)
+    check(lib.bbx_psf_model(ctx.h, nsrc, ncoef, S * S, _p(terms), _p(basis.contiguous()), _p(out), ctx.stream()),
+          'bbx_psf_model', ctx.h)
+    if normalize:
+        out /= out.sum(dim=(1, 2), keepdim=True)
+    return out
+
+
 def find_transients(ctx, Scorr, nsigma=None, max_out=100000):
     """connected regions of |Scorr| >= T-NSIGMA -> sorted list of (y, x, Scorr peak)"""
     nsigma = settings.transient_nsigma if nsigma is None else nsigma

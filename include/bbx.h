@@ -286,6 +286,14 @@ int bbx_zogy_subimages(bbx_ctx *ctx, int L, int nsub, float *d_new, float *d_ref
                        const float *h_scal, float *d_D, float *d_S, float *d_Scorr,
                        float *d_Fpsf, float *d_Fpsferr, void *stream);
 
+/* ---- a17: PSFEx model evaluation [EXT: zogy.get_psf / psfex poly] ----------------------
+ * stamp[s][p] = sum_k terms[s][k] * basis[k][p]: terms [nsrc][ncoef] f32 = the polynomial
+ * terms x'^i y'^j (i + j <= poldeg, PSFEx order) of each source position, basis
+ * [ncoef][npix] f32 = the PSF_MASK cube of the .psf file, out [nsrc][npix] f32.  f32 MFMA
+ * (v_mfma_f32_32x32x2_f32): k-ordered float32 fma chain.                                  */
+int bbx_psf_model(bbx_ctx *ctx, int nsrc, int ncoef, int npix, const float *d_terms,
+                  const float *d_basis, float *d_out, void *stream);
+
 /* ---- a17: PSF-weighted optimal flux (zogy.get_psfoptflux) at integer positions:
  * flux = sum(P D / V) / sum(P^2 / V), err = 1 / sqrt(sum(P^2 / V)) over an S x S stamp of
  * the unit-sum PSF model d_psfs[nsrc][S][S] centred on (d_ys, d_xs); pixels off the frame

@@ -205,3 +205,16 @@ def find_transients(Scorr, nsigma=6.0):
         i = np.argmax(a[ys, xs])
         out.append((int(ys[i]), int(xs[i]), float(Scorr[ys[i], xs[i]])))
     return sorted(out)
+
+
+def psf_model(terms, basis):
+    """stamp[s][p] = sum_k terms[s][k] * basis[k][p] as a k-ordered float32 fma chain (what
+    the f32 MFMA computes).  fma(a, b, c) in float32 = round32(a*b + c): a*b is exact in
+    float64, the float64 sum is rounded once more to float32 -- identical to a true fma except
+    in rare double-rounding cases (tests allow 1 ulp there)."""
+    terms = np.asarray(terms, np.float32); basis = np.asarray(basis, np.float32)
+    acc = np.zeros((terms.shape[0], basis.shape[1]), np.float32)
+    for k in range(terms.shape[1]):
+        acc = (terms[:, k:k + 1].astype(np.float64) * basis[k][None, :].astype(np.float64) + acc.astype(np.float64)
+               ).astype(np.float32)
+    return acc
