@@ -7,10 +7,15 @@ SRCS  := $(CSRC)/bbx_ctx.hip $(CSRC)/bbx_overscan.hip $(CSRC)/bbx_calibrate.hip 
          $(CSRC)/bbx_stack.hip $(CSRC)/bbx_bkg.hip $(CSRC)/bbx_zogy.hip $(CSRC)/bbx_sat.hip $(CSRC)/bbx_psf.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := blackbox_amd/libbbx_hip.so
+HOSTLIB := blackbox_amd/libbbx_host.so
 # -ffp-contract=off: results must match numpy's unfused float32/float64 arithmetic
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -ffp-contract=off -std=c++17 -Wall -Wno-unused-function
 
-all: $(LIB)
+all: $(LIB) $(HOSTLIB)
+
+# host-side C helpers of the overscan solve (same float operations as the numpy code)
+$(HOSTLIB): blackbox_amd/chost/bbx_host.c
+	gcc -O2 -fPIC -shared -ffp-contract=off -o $@ $< -lm
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h $(CSRC)/bbx_bsel.h include/bbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -19,6 +24,6 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(HOSTLIB)
 
 .PHONY: all clean

@@ -18,6 +18,23 @@ import warnings
 import numpy as np
 from scipy import interpolate, ndimage
 
+# optional C versions of the two hottest helpers (blackbox_amd/chost/bbx_host.c, built by
+# `make`): the same float operations in the same order, ~10x less interpreter overhead.
+# Without the library the numpy code below runs -- both are held to each other bit for bit
+# by tests/test_host_overscan.py.
+_HOST = None
+try:
+    import ctypes as _C
+    import os as _os
+    _HOST = _C.CDLL(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'libbbx_host.so'))
+    _HOST.bbx_hos_column_stats_f32seq.restype = _C.c_int
+    _HOST.bbx_hos_column_stats_f32seq.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.c_int, _C.c_void_p, _C.c_void_p,
+                                                  _C.c_void_p]
+    _HOST.bbx_clipped_stats_flat_f32seq.restype = _C.c_int64
+    _HOST.bbx_clipped_stats_flat_f32seq.argtypes = [_C.c_void_p, _C.c_int64, _C.c_double, _C.c_int, _C.c_void_p]
+except OSError:
+    _HOST = None
+
 IDX_SWITCH = 150      # blackbox.py:6683
 OVERLAP = 30          # blackbox.py:6684
 
@@ -42,6 +59,14 @@ def clipped_stats_flat(values, sigma=3.0, maxiters=5, accum='f32seq'):
     """astropy sigma_clipped_stats(values, sigma=sigma, cenfunc='mean') on a
     flattened array -> (mean, std, n_survivors)"""
     v = np.ascontiguousarray(values).ravel()
+    if _HOST is not None and accum == 'f32seq' and v.dtype == np.float32:
+        out = np.empty(2)
+        m = _HOST.bbx_clipped_stats_flat_f32seq(v.ctypes.data, v.size, float(sigma), int(maxiters), out.ctypes.data)
+        if m < 0:
+            raise MemoryError('bbx_clipped_stats_flat_f32seq')
+        if m == 0:
+            return np.nan, np.nan, 0
+        return np.float32(out[0]), np.float32(out[1]), int(m)
     v = v[np.isfinite(v)]
     for _ in range(maxiters):
         if v.size == 0:
@@ -63,6 +88,38 @@ def clipped_stats_flat(values, sigma=3.0, maxiters=5, accum='f32seq'):
     return mean, std, v.size
 
 
+_VANDER = {}
+
+
+def _vander_full(start, n, order):
+    """np.vander(np.arange(start, start + n) + 0.0, order), cached: np.polyfit builds it from
+    the selected abscissae on every call, row by row (cumulative products), so the rows of
+    the full matrix picked by the fit mask are the identical numbers"""
+    key = (start, n, order)
+    v = _VANDER.get(key)
+    if v is None:
+        if len(_VANDER) > 64:
+            _VANDER.clear()
+        v = _VANDER[key] = np.vander(np.arange(start, start + n) + 0.0, order)
+    return v
+
+
+def polyfit_exact(start, n, mask, y, deg):
+    """np.polyfit(np.arange(start, start+n)[mask], y, deg) -- the same float operations in the
+    same order (scaled Vandermonde, LAPACK gelsd through np.linalg.lstsq), without rebuilding
+    the Vandermonde matrix and without np.polyfit's argument handling.
+    -> (coefficients high -> low order, rank)"""
+    order = deg + 1
+    lhs = _vander_full(start, n, order)[mask]
+    rhs = np.asarray(y) + 0.0
+    rcond = lhs.shape[0] * np.finfo(np.float64).eps
+    scale = np.sqrt((lhs * lhs).sum(axis=0))
+    lhs /= scale
+    c, _, rank, _ = np.linalg.lstsq(lhs, rhs, rcond)
+    c = (c.T / scale).T
+    return c, rank
+
+
 def vos_polyfit(mean_vos_col, nrows, i_chan, poldeg=3):
     """blackbox.py:6497-6556.  -> (fit[dy] float64, coeffs low->high order,
     polyfit_ok, mean level)"""
@@ -81,9 +138,12 @@ def vos_polyfit(mean_vos_col, nrows, i_chan, poldeg=3):
             mask_fit[nrows:] = False
         else:
             mask_fit[:nrows_chan - nrows] = False
-        with warnings.catch_warnings():
-            warnings.simplefilter('error')          # os_corr runs with warnings as errors (6432)
-            p = np.polyfit(y_vos[mask_fit], mean_vos_col[mask_fit], poldeg)
+        # os_corr runs with warnings as errors (6432): a rank-deficient fit (np.polyfit's
+        # RankWarning) counts as a failed fit
+        p, rank = polyfit_exact(0, nrows_chan, mask_fit, mean_vos_col[mask_fit], poldeg)
+        if rank != poldeg + 1:
+            p = None
+            raise ValueError('rank-deficient vertical-overscan fit')
     except Exception:
         polyfit_ok = False
     if p is None:
@@ -102,19 +162,48 @@ def vos_polyfit(mean_vos_col, nrows, i_chan, poldeg=3):
     return fit, p[::-1], polyfit_ok, level
 
 
+def _open2(m):
+    """ndimage.binary_opening(m, structure=np.ones(2)) of a 1-D bool array: a True survives
+    iff its left or right neighbour is True (outside = False)"""
+    left = np.zeros_like(m); left[1:] = m[:-1]
+    right = np.zeros_like(m); right[:-1] = m[1:]
+    return m & (left | right)
+
+
+def _dilate5x5(m):
+    """ndimage.binary_dilation(m, structure=np.ones((3, 3)), iterations=2) of a 2-D bool
+    array = OR over the 5x5 neighbourhood (outside = False)"""
+    ny, nx = m.shape
+    p = np.zeros((ny + 4, nx + 4), bool)
+    p[2:-2, 2:-2] = m
+    rows = p[:, 0:nx] | p[:, 1:nx + 1] | p[:, 2:nx + 2] | p[:, 3:nx + 3] | p[:, 4:nx + 4]
+    return rows[0:ny] | rows[1:ny + 1] | rows[2:ny + 2] | rows[3:ny + 3] | rows[4:ny + 4]
+
+
 def hos_mask_ml1(data_hos, data_limit=2000):
-    """blackbox.py:6586-6614"""
+    """blackbox.py:6586-6614 (the two scipy.ndimage morphology calls written out for these
+    tiny arrays; tests/test_host_overscan.py holds them against scipy)"""
     mask_hos = data_hos > data_limit
+    if not mask_hos.any():
+        return mask_hos
     mask_x = np.sum(mask_hos, axis=0) > 0.5 * mask_hos.shape[0]
-    mask_x_open = ndimage.binary_opening(mask_x, structure=np.ones(2))
+    mask_x_open = _open2(mask_x)
     mask_hos[:, np.logical_xor(mask_x, mask_x_open)] = False
-    return ndimage.binary_dilation(mask_hos, structure=np.ones((3, 3), dtype=bool),
-                                   iterations=2)
+    return _dilate5x5(mask_hos)
 
 
 def hos_column_stats(data_hos, mask_hos, accum='f32seq'):
     """blackbox.py:6649-6659: sigma_clip(axis=0, sigma=2.5, cenfunc='mean') then
     per-column count / mean / std(ddof=1).  float32 results like the reference."""
+    if _HOST is not None and accum == 'f32seq' and data_hos.dtype == np.float32:
+        d = np.ascontiguousarray(data_hos)
+        mk = np.ascontiguousarray(mask_hos, dtype=np.uint8)
+        nrow, ncol = d.shape
+        n = np.empty(ncol, np.int64); mean = np.empty(ncol, np.float32); std = np.empty(ncol, np.float32)
+        if _HOST.bbx_hos_column_stats_f32seq(d.ctypes.data, mk.ctypes.data, nrow, ncol, n.ctypes.data, mean.ctypes.data,
+                                              std.ctypes.data) != 0:
+            raise MemoryError('bbx_hos_column_stats_f32seq')
+        return n, mean, std
     d64 = data_hos.astype(np.float64)
     ok = np.isfinite(d64) & ~mask_hos
     lo = np.full(d64.shape[1], np.nan)
@@ -234,7 +323,7 @@ def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
     def fit_iter(mask_fit, deg):
         fit = None
         for _ in range(3):
-            p = _polyfit_quiet(xcol[mask_fit], mean_hos[mask_fit], deg)
+            p, _ = polyfit_exact(1, ncols, mask_fit, mean_hos[mask_fit], deg)
             fit = np.polyval(p, xcol)
             with np.errstate(invalid='ignore'):
                 mask_fit &= np.abs(fit - mean_hos) <= err3

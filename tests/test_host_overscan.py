@@ -62,3 +62,65 @@ def test_vos_polyfit(chan):
     fit_o, co_o, ok_o, lev_o = O.vos_fit(v, 5280, chan)
     assert ok_p and ok_o
     assert np.array_equal(fit_p, fit_o) and np.array_equal(co_p, co_o) and lev_p == lev_o
+
+
+def test_fast_paths_equal_numpy_scipy():
+    """the cached-Vandermonde polyfit and the written-out morphology are the same numbers /
+    masks as np.polyfit and scipy.ndimage"""
+    from scipy import ndimage
+    from blackbox_amd import overscan as ov
+    rs = np.random.RandomState(3)
+    for n, deg, start in ((1320, 7, 1), (5300, 3, 0), (700, 5, 1)):
+        x = np.arange(start, start + n)
+        for dt in (np.float32, np.float64):
+            y = (1000 + 2e-3 * x + rs.normal(0, 3, n)).astype(dt)
+            m = rs.rand(n) > 0.2
+            p, rank = ov.polyfit_exact(start, n, m, y[m], deg)
+            assert rank == deg + 1
+            assert np.array_equal(p, np.polyfit(x[m], y[m], deg))
+    for _ in range(20):
+        m1 = rs.rand(rs.randint(1, 40)) > 0.5
+        assert np.array_equal(ov._open2(m1), ndimage.binary_opening(m1, structure=np.ones(2)))
+        m2 = rs.rand(rs.randint(1, 12), rs.randint(1, 60)) > 0.9
+        assert np.array_equal(ov._dilate5x5(m2), ndimage.binary_dilation(m2, structure=np.ones((3, 3), dtype=bool), iterations=2))
+    d = (1000 + rs.normal(0, 5, (10, 1320))).astype(np.float32)
+    d[:, 100:103] += 5000
+    d[3, 700] += 9000
+    want = d > 2000
+    mx = np.sum(want, axis=0) > 0.5 * want.shape[0]
+    mo = ndimage.binary_opening(mx, structure=np.ones(2))
+    want[:, np.logical_xor(mx, mo)] = False
+    want = ndimage.binary_dilation(want, structure=np.ones((3, 3), dtype=bool), iterations=2)
+    assert np.array_equal(ov.hos_mask_ml1(d, 2000), want)
+
+
+def test_c_helpers_equal_numpy():
+    """blackbox_amd/chost/bbx_host.c against the numpy code it restates (bit for bit)"""
+    from blackbox_amd import overscan as ov
+    if ov._HOST is None:
+        pytest.skip('libbbx_host.so not built')
+    host = ov._HOST
+    rs = np.random.RandomState(9)
+    try:
+        for trial in range(6):
+            nrow, ncol = (10, 1320) if trial < 3 else (rs.randint(2, 30), rs.randint(1, 200))
+            d = (5 + rs.normal(0, 8, (nrow, ncol))).astype(np.float32)
+            d[rs.randint(0, nrow, 40), rs.randint(0, ncol, 40)] += 300
+            if trial % 2:
+                d[rs.randint(0, nrow), rs.randint(0, ncol)] = np.nan
+            m = rs.rand(nrow, ncol) > 0.93
+            if trial == 2:
+                m[:, 5] = True                                    # a column without valid pixels
+            ov._HOST = host
+            got = ov.hos_column_stats(d, m)
+            gs = [ov.clipped_stats_flat(d[:, max(0, ncol - 300):], sigma=s) for s in (3.0, 5.0)]
+            ov._HOST = None
+            want = ov.hos_column_stats(d, m)
+            ws = [ov.clipped_stats_flat(d[:, max(0, ncol - 300):], sigma=s) for s in (3.0, 5.0)]
+            for a, b in zip(got, want):
+                assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True)
+            for a, b in zip(gs, ws):
+                assert a[2] == b[2] and np.array_equal(np.float32(a[:2]), np.float32(b[:2]), equal_nan=True)
+                assert type(a[0]) == type(b[0])
+    finally:
+        ov._HOST = host
