@@ -135,14 +135,14 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=120)
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--raw', default='u16', choices=['u16', 'f32'])
     ap.add_argument('--small', action='store_true', help='reduced geometry (debug)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--depth', type=int, default=12, help='frames in flight')
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
-    ap.add_argument('--lanes', type=int, default=1, help='stage-C lanes (context + stream) per GPU')
+    ap.add_argument('--lanes', type=int, default=2, help='stage-C lanes (context + stream) per GPU')
     args = ap.parse_args()
 
     import torch
@@ -196,6 +196,15 @@ def main():
         return ev, st
 
     frame_serial()
+    # kernels alone on the GPU (no second lane, no other frame in flight): isolated timings of
+    # the two dense kernels, reported next to the live ones of the timed region
+    _lib.check(_lib.lib.bbx_profile_enable(ctx.h, 1), 'bbx_profile_enable')
+    for _ in range(3):
+        frame_serial()
+    iso_ms = (C.c_double * 8)()
+    iso_calls = (C.c_int32 * 8)()
+    _lib.check(_lib.lib.bbx_profile_read(ctx.h, iso_ms, iso_calls, 8), 'bbx_profile_read', ctx.h)
+    _lib.check(_lib.lib.bbx_profile_enable(ctx.h, 0), 'bbx_profile_enable')
     t0 = time.perf_counter()
     ev, st = frame_serial()
     latency_ms = 1e3 * (time.perf_counter() - t0)
@@ -246,6 +255,10 @@ def main():
                     others={k: dict(avg_launch_ms=per[k][0], achieved=per[k][1] / (per[k][0] * 1e-3) / 1e9,
                                     frac=per[k][1] / (per[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) for k in per if k != dom})
         roof['frac'] = roof['achieved'] / roof['peak']
+        # the same kernels with the GPU to themselves (serial frames before the timed region)
+        roof['isolated'] = {k: dict(avg_launch_ms=iso_ms[sl] / max(1, iso_calls[sl]),
+                                    frac=by / (iso_ms[sl] / max(1, iso_calls[sl]) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                            for k, (sl, by) in kern.items()}
         # HBM traffic per launch from the committed rocprofv3 --pmc passes of this command
         # (profiles/r01_pmc_traffic.json: FETCH_SIZE/WRITE_SIZE, gfx950 correction applied)
         try:

@@ -52,7 +52,7 @@ def default_workers():
     if 'BBX_HOST_WORKERS' in os.environ:
         return max(1, int(os.environ['BBX_HOST_WORKERS']))
     world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
-    return max(2, min(32, cpu_budget() // max(1, world) - 2))
+    return max(2, min(12, cpu_budget() // max(1, world) - 2))
 
 
 class HostPool:
@@ -190,7 +190,7 @@ class _Frame:
 
 class FramePipeline:
     def __init__(self, ctx, tel, geom, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None, exptime=60.0,
-                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=1):
+                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=2):
         self.ctx, self.tel, self.geom = ctx, tel, geom
         # stage-C lanes: (context, stream); lane 0 is the caller's context
         self.lane_ctx = [ctx] + [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
