@@ -278,7 +278,7 @@ def main():
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload='configs[1]: one %dx%d raw (%s) -> %dx%d frame, gain+overscan+flat+mask_init+LA-Cosmic(niter=3), ML1'
                                % (raw.shape[0], raw.shape[1], args.raw, 2 * ysz, 8 * xsz),
-                               frames_per_gpu=args.steps, frames_in_flight=args.depth, host_fit_workers=pool.n,
+                               frames_per_gpu=args.steps, frames_in_flight=args.depth, stageC_lanes=args.lanes, host_fit_workers=pool.n,
                                parallelism='frame-per-gpu x%d (no collective)' % world),
                    pipeline_wall_ms_per_frame=dict(zip(['stageA_stats', 'stageB_host_fits', 'stageC_device'],
                                                        [1e3 * t / max(1, pipe.t_stats[3]) for t in pipe.t_stats[:3]])),
