@@ -93,18 +93,19 @@ class ShmArena:
     pinned memory: the device copies straight into/out of it and the fit workers map the
     same pages, so a fit task and its result are a few scalars instead of pickled arrays."""
 
-    FIELDS = ('mean', 'hos', 'vfit', 'oscan', 'strip')
+    FIELDS = ('mean', 'hos', 'ninf', 'vfit', 'oscan', 'strip')
 
     def __init__(self, depth, dy, dx, hos_rows, xsz, name=None):
         from multiprocessing import shared_memory
         self.depth, self.dy, self.dx, self.hos_rows, self.xsz = depth, dy, dx, hos_rows, xsz
-        sizes = dict(mean=16 * dy * 8, hos=16 * hos_rows * dx * 4, vfit=16 * dy * 8, oscan=16 * xsz * 8,
+        sizes = dict(mean=16 * dy * 8, hos=16 * hos_rows * dx * 4, ninf=8, vfit=16 * dy * 8, oscan=16 * xsz * 8,
                      strip=16 * hos_rows * dx * 4)
         self.off, o = {}, 0
         for k in self.FIELDS:
             self.off[k] = o
             o += (sizes[k] + 4095) // 4096 * 4096
         self.slot_bytes = o
+        self.sizes = sizes
         self.owner = name is None
         if self.owner:
             self.shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * depth)
@@ -118,9 +119,16 @@ class ShmArena:
 
     def view(self, slot, field):
         shape, dt = {'mean': ((16, self.dy), np.float64), 'hos': ((16, self.hos_rows, self.dx), np.float32),
+                     'ninf': ((1,), np.int64),
                      'vfit': ((16, self.dy), np.float64), 'oscan': ((16, self.xsz), np.float64),
                      'strip': ((16, self.hos_rows, self.dx), np.float32)}[field]
         return np.ndarray(shape, dt, buffer=self.shm.buf, offset=slot * self.slot_bytes + self.off[field])
+
+    def span(self, slot, first, last):
+        """uint8 view of the slot's bytes from the start of field [first] to the end of field [last]"""
+        a = slot * self.slot_bytes + self.off[first]
+        n = self.off[last] + self.sizes[last] - self.off[first]
+        return np.ndarray((n,), np.uint8, buffer=self.shm.buf, offset=a)
 
     def register(self):
         """hipHostRegister the block so non_blocking copies are truly asynchronous"""
@@ -220,26 +228,44 @@ class FramePipeline:
         if not self.arena.register():
             raise RuntimeError('hipHostRegister of the staging arena failed')
         self.layout = self.arena.layout()
+        # per slot: the device mirrors of the arena regions (one copy each way per stage instead
+        # of one per array: a torch copy_ costs ~30 us of the orchestrating thread) and one
+        # packed result record
+        ar = self.arena
         self.slots = []
         for i in range(depth):
-            hv = lambda k: torch.from_numpy(self.arena.view(i, k))
+            n_in = ar.off['ninf'] + ar.sizes['ninf'] - ar.off['mean']
+            n_vo = ar.off['oscan'] + ar.sizes['oscan'] - ar.off['vfit']
+            d_in = torch.empty(n_in, dtype=torch.uint8, device=dev)
+            d_vo = torch.empty(n_vo, dtype=torch.uint8, device=dev)
+
+            def dv(buf, base, k, dt, shape=None):
+                o = ar.off[k] - ar.off[base]
+                t = buf[o:o + ar.sizes[k]].view(dt)
+                return t.view(shape) if shape else t
+            d_res = torch.zeros(256, dtype=torch.uint8, device=dev)      # std[16] f64 | nobj i32 | stats[16] i32 | cnt[6] i64
+            h_res = torch.zeros(256, dtype=torch.uint8, pin_memory=True)
             self.slots.append(dict(
-                d_mean=torch.empty(16 * self.dy, dtype=torch.float64, device=dev),
-                d_hos=torch.empty((16, self.hos_rows, self.dx), dtype=torch.float32, device=dev),
-                d_ninf=torch.zeros(1, dtype=torch.int64, device=dev),
-                h_mean=hv('mean').view(-1), h_hos=hv('hos'),
-                h_ninf=torch.empty(1, dtype=torch.int64, pin_memory=True),
-                h_vfit=hv('vfit').view(-1), h_oscan=hv('oscan').view(-1),
-                d_vfit=torch.empty(16 * self.dy, dtype=torch.float64, device=dev),
-                d_oscan=torch.empty(16 * self.xsz, dtype=torch.float64, device=dev),
-                d_std=torch.empty(16, dtype=torch.float64, device=dev),
-                d_cnt6=torch.zeros(6, dtype=torch.int64, device=dev),
+                d_in=d_in, h_in=torch.from_numpy(ar.span(i, 'mean', 'ninf')),
+                d_mean=dv(d_in, 'mean', 'mean', torch.float64),
+                d_hos=dv(d_in, 'mean', 'hos', torch.float32, (16, self.hos_rows, self.dx)),
+                d_ninf=dv(d_in, 'mean', 'ninf', torch.int64),
+                h_ninf=torch.from_numpy(ar.view(i, 'ninf')),
+                d_vo=d_vo, h_vo=torch.from_numpy(ar.span(i, 'vfit', 'oscan')),
+                d_vfit=dv(d_vo, 'vfit', 'vfit', torch.float64), d_oscan=dv(d_vo, 'vfit', 'oscan', torch.float64),
+                d_res=d_res, h_res=h_res,
+                d_std=d_res[0:128].view(torch.float64), d_nobj=d_res[128:132].view(torch.int32),
+                d_stats=d_res[132:196].view(torch.int32), d_cnt6=d_res[200:248].view(torch.int64),
+                h_std=h_res[0:128].view(torch.float64), h_nobj=h_res[128:132].view(torch.int32),
+                h_stats=h_res[132:196].view(torch.int32), h_cnt6=h_res[200:248].view(torch.int64),
                 h_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, pin_memory=True),
-                d_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev),
-                h_out=(torch.empty(16, dtype=torch.float64, pin_memory=True),
-                       torch.empty(1, dtype=torch.int32, pin_memory=True),
-                       torch.zeros(16, dtype=torch.int32, pin_memory=True),
-                       torch.zeros(6, dtype=torch.int64, pin_memory=True))))
+                d_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev)))
+        # header keys / comments are the same for every frame
+        self._k_bias = [[('BIAS{}A{}'.format(c + 1, k), '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
+                         for k in range(settings.voscan_poldeg + 1)] for c in range(16)]
+        self._k_vfitok = [('VFITOK{}'.format(c + 1), 'channel {} vert. overscan polyfit finite?'.format(c + 1)) for c in range(16)]
+        self._k_biasm = [('BIASM{}'.format(c + 1), '[e-] channel {} mean vertical overscan'.format(c + 1)) for c in range(16)]
+        self._k_rdn = [('RDN{}'.format(c + 1), '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1)) for c in range(16)]
         self.free_slots = list(range(depth))
 
     def close(self):
@@ -264,10 +290,8 @@ class FramePipeline:
             check(lib.bbx_overscan_stats(ctx.h, C.byref(self.geom), R._ptr(raw), R.raw_type_of(raw), self.g32,
                                          R._ptr(d_mean), R._ptr(d_hos), R._ptr(d_ninf), ctx.stream()),
                   'bbx_overscan_stats', ctx.h)
-            f.h_mean, f.h_hos, f.h_ninf = sl['h_mean'], sl['h_hos'], sl['h_ninf']
-            f.h_mean.copy_(d_mean, non_blocking=True)
-            f.h_hos.copy_(d_hos, non_blocking=True)
-            f.h_ninf.copy_(d_ninf, non_blocking=True)
+            f.h_ninf = sl['h_ninf']
+            sl['h_in'].copy_(sl['d_in'], non_blocking=True)          # mean | hos | ninf in one copy
             f.evA = torch.cuda.Event()
             f.evA.record()
         f.state = 'A'
@@ -290,13 +314,12 @@ class FramePipeline:
         h = f.header
         h['N-INFNAN'] = (int(f.h_ninf.item()), 'number of pixels with infinite/nan values')
         for c, r in enumerate(results):
-            for k, v in enumerate(r['coeffs']):
-                h['BIAS{}A{}'.format(c + 1, k)] = (float(v) if np.isfinite(v) else 'None',
-                                                    '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
-            h['VFITOK{}'.format(c + 1)] = (bool(r['ok']), 'channel {} vert. overscan polyfit finite?'.format(c + 1))
+            for (key, comment), v in zip(self._k_bias[c], r['coeffs']):
+                h[key] = (float(v) if np.isfinite(v) else 'None', comment)
+            h[self._k_vfitok[c][0]] = (bool(r['ok']), self._k_vfitok[c][1])
         mean_vos = np.array([r['level'] for r in results])
         for c in range(16):
-            h['BIASM{}'.format(c + 1)] = (float(mean_vos[c]), '[e-] channel {} mean vertical overscan'.format(c + 1))
+            h[self._k_biasm[c][0]] = (float(mean_vos[c]), self._k_biasm[c][1])
         h['BIASMEAN'] = (float(np.nanmean(mean_vos)), '[e-] average all channel means vert. overscan')
 
     def _satcol(self, f, results):
@@ -309,7 +332,7 @@ class FramePipeline:
             self.lane_stream[f.lane].wait_event(f.evA)
             sl = self.slots[f.slot]
             d_vfit = sl['d_vfit']
-            d_vfit.copy_(sl['h_vfit'], non_blocking=True)
+            sl['d_vo'].copy_(sl['h_vo'], non_blocking=True)            # vfit (| oscan, not final yet)
             d_cnt = sl['d_cnt']
             check(lib.bbx_satcol_counts(ctx.h, C.byref(self.geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
                                         R._ptr(d_vfit), _lib.f32x16(np.float32(0.9 * satl)), int(lim[0]), int(lim[1]),
@@ -341,19 +364,18 @@ class FramePipeline:
             sl = self.slots[f.slot]
             sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
             sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
-            sol.d_vfit.copy_(sl['h_vfit'], non_blocking=True)
-            sol.d_oscan.copy_(sl['h_oscan'], non_blocking=True)
+            sl['d_vo'].copy_(sl['h_vo'], non_blocking=True)            # vfit | oscan in one copy
             d_std = sl['d_std']
             check(lib.bbx_vos_std(ctx.h, C.byref(geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
                                   R._ptr(sol.d_vfit), _lib.f32x16(dlevel), R._ptr(d_std), ctx.stream()),
                   'bbx_vos_std', ctx.h)
             data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat,
                                      bpm=self.bpm)
-            d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom)
+            d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom, d_n=sl['d_nobj'])
             d_stats = None
             if self.do_cosmics:
                 # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
-                d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std)
+                d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std, d_stats=sl['d_stats'])
             if self.do_finish:
                 if self.xtalk is not None:
                     R.xtalk_corr(ctx, data, self.xtalk, mask, geom)
@@ -363,13 +385,9 @@ class FramePipeline:
                 R.edge_fill(ctx, data, mask, geom)
             else:
                 d_cnt = sl['d_cnt6']
-            # scalar results: one small pinned D2H
-            f.h_out = sl['h_out']
-            f.h_out[0].copy_(d_std, non_blocking=True)
-            f.h_out[1].copy_(d_nobj, non_blocking=True)
-            if d_stats is not None:
-                f.h_out[2].copy_(d_stats, non_blocking=True)
-            f.h_out[3].copy_(d_cnt, non_blocking=True)
+            # scalar results: one small pinned D2H of the packed record
+            f.h_out = (sl['h_std'], sl['h_nobj'], sl['h_stats'], sl['h_cnt6'])
+            sl['h_res'].copy_(sl['d_res'], non_blocking=True)
             f.evC = torch.cuda.Event()
             f.evC.record()
             f.d_keep = (sol, d_std, d_nobj, d_stats, d_cnt)
@@ -380,7 +398,7 @@ class FramePipeline:
         h, hm = f.header, f.hm
         std = f.h_out[0].numpy()
         for c in range(16):
-            h['RDN{}'.format(c + 1)] = (float(std[c]), '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1))
+            h[self._k_rdn[c][0]] = (float(std[c]), self._k_rdn[c][1])
         h['RDNOISE'] = (float(np.nanmean(std)), '[e-] average all channel sigmas vert. overscan')
         nobj = int(f.h_out[1].item())
         h['NOBJ-SAT'] = hm['NOBJ-SAT'] = (nobj, 'number of saturated objects')

@@ -214,6 +214,9 @@ def satlevels(header, tel):
     return np.array(get_par(settings.satlevel, tel)) * gain - bias
 
 
+_SATLEV_KEYS = [('SATLEV{}'.format(c + 1), '[e-] channel {} saturation threshold'.format(c + 1)) for c in range(16)]
+
+
 def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=None, bpm=None):
     """gain + overscan + crop (+ master bias) + first half of mask_init (+ master
     flat) in one pass -> (data float32, mask uint8) device tensors"""
@@ -222,9 +225,8 @@ def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=N
     gain = get_par(settings.gain, tel)
     sat = satlevels(header, tel)
     header_mask['SATURATE'] = header['SATURATE'] = (float(np.mean(sat)), '[e-] mean saturation threshold')
-    for c in range(16):
-        key = 'SATLEV{}'.format(c + 1)
-        header[key] = header_mask[key] = (round(float(sat[c]), 1), '[e-] channel {} saturation threshold'.format(c + 1))
+    for c, (key, comment) in enumerate(_SATLEV_KEYS):
+        header[key] = header_mask[key] = (round(float(sat[c]), 1), comment)
     data = torch.empty((ny, nx), dtype=torch.float32, device=dev)
     mask = torch.empty((ny, nx), dtype=torch.uint8, device=dev)
     for t, name, dt in ((mbias, 'master bias', torch.float32), (mflat, 'master flat', torch.float32),
@@ -238,14 +240,16 @@ def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=N
     return data, mask
 
 
-def mask_init_finish(ctx, mask, header, header_mask, geom):
-    """second half of mask_init (blackbox.py:4504-4566) + fill_sat_holes"""
-    d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+def mask_init_finish(ctx, mask, header, header_mask, geom, d_n=None):
+    """second half of mask_init (blackbox.py:4504-4566) + fill_sat_holes; d_n: optional int32[1]
+    device tensor for the NOBJ-SAT count (set by the library)"""
+    if d_n is None:
+        d_n = torch.empty(1, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_mask_finish(ctx.h, C.byref(geom), _ptr(mask), _ptr(d_n), ctx.stream()), 'bbx_mask_finish', ctx.h)
     return d_n
 
 
-def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None):
+def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None, d_stats=None):
     """blackbox.py:4259-4370.  In place; returns the device stats tensor
     [per-iteration counts x6, n objects, n pixels].  readnoise = header RDNOISE, or -- when
     the 16 channel sigmas are still on the device -- their nanmean taken there."""
@@ -254,7 +258,8 @@ def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None):
     if d_rdn16 is None:
         hv = header['RDNOISE']
         readnoise = hv[0] if isinstance(hv, tuple) else hv
-    d_stats = torch.zeros(16, dtype=torch.int32, device=ctx.device)
+    if d_stats is None:
+        d_stats = torch.empty(16, dtype=torch.int32, device=ctx.device)       # zeroed by the library
     check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(data_mask),
                            float(get_par(settings.sigclip, tel)), float(get_par(settings.sigfrac, tel)),
                            float(get_par(settings.objlim, tel)), int(get_par(settings.niter, tel)),

@@ -17,15 +17,15 @@ if __name__ == '__main__':
     raw, flat, bpm = bench.synth_frame_device(torch, ctx.device, ysz, xsz, os_y, os_x, 2000, 'u16')
     geom = R.geometry(raw.shape, ysz, xsz)
     pool = HostPool(int(sys.argv[1]) if len(sys.argv) > 1 else 12)
-    pipe = FramePipeline(ctx, 'ML1', geom, mflat=flat, bpm=bpm, pool=pool, depth=int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    pipe = FramePipeline(ctx, 'ML1', geom, mflat=flat, bpm=bpm, pool=pool, depth=int(sys.argv[2]) if len(sys.argv) > 2 else 12, lanes=int(sys.argv[3]) if len(sys.argv) > 3 else 2)
     pipe.run([(raw, {}) for _ in range(6)])
     pipe.t_stats = [0.0, 0.0, 0.0, 0]
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
-    pipe.run([(raw, {}) for _ in range(30)])
+    pipe.run([(raw, {}) for _ in range(120)])
     pr.disable()
     dt = time.perf_counter() - t0
-    print('fps', 30 / dt, 'stats ms/frame', [1e3 * t / 30 for t in pipe.t_stats[:3]])
+    print('fps', 120 / dt, 'stats ms/frame', [1e3 * t / 120 for t in pipe.t_stats[:3]])
     pstats.Stats(pr).sort_stats('tottime').print_stats(22)
     pipe.close(); pool.close()
