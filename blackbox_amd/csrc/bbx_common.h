@@ -79,6 +79,7 @@ enum {
     CNT_BGNEED = 128,     // LA-Cosmic: pixels that needed the background level
     CNT_TMP = 144,
     CNT_CANDOVF = 160,    // LA-Cosmic candidates that did not fit their tile segment
+    CNT_CANDRAW = 176,    // LA-Cosmic candidates before the s > sigclip pre-filter
     CNT_MAX = 256
 };
 

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_lac_compact(const uint8_t* __restrict__
             if (tot + i < cap) cand[tot + i] = ovf[i];
         if (tid == 0) {
             if (tot + novf > cap) atomicOr(err, BBX_DERR_LIST_OVERFLOW);
-            counters[CNT_CAND] = (int32_t)min(tot + novf, cap);
+            counters[CNT_CANDRAW] = (int32_t)min(tot + novf, cap);
         }
     }
 }
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_lac_cand_s(const float* __restrict__ a,
         if (in && !(j < 2 || i < 2 || j >= p.ny - 2 || i >= p.nx - 2)) {
             const float lp = lplus_at(a, j, i, p.ny, p.nx);
             if (lp > T) {
-                const unsigned k = atomicAdd((unsigned*)&counters[CNT_CAND], 1u);
+                const unsigned k = atomicAdd((unsigned*)&counters[CNT_CANDRAW], 1u);
                 if (k < cap) cand[k] = (uint32_t)o; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
             }
         }
@@ -492,6 +492,37 @@ __device__ __forceinline__ float f_wave(const float* __restrict__ a, int j, int 
 }
 
 __device__ __forceinline__ bool good_px(const uint8_t* mask, size_t o) { return (mask[o] & ~BBX_MASK_COSMIC) == 0; }
+
+// ---- 1b. pre-filter: sp = s - medfilt5(s) <= s (s >= 0 everywhere), so only candidates with
+// s > sigclip (and no mask bit) can seed or join the first growth.  With the true local
+// noise instead of the read noise alone this drops ~80 % of the L+ > T list before the
+// wave-per-candidate stage.  One thread per candidate; survivors are appended wave by wave.
+__global__ __launch_bounds__(256) void k_lac_prefilter(const float* __restrict__ a, const uint8_t* __restrict__ mask, lac_par p,
+                                                       const uint32_t* __restrict__ raw, int32_t* counters, uint32_t cap,
+                                                       uint32_t* __restrict__ cand) {
+    const uint32_t n = min((uint32_t)counters[CNT_CANDRAW], cap);
+    const uint32_t nround = ((n + 63u) / 64u) * 64u;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += gridDim.x * blockDim.x) {
+        bool keep = false;
+        uint32_t o = 0;
+        if (k < n) {
+            o = raw[k];
+            if (good_px(mask, o)) {
+                const int j = (int)(o / p.nx), i = (int)(o - (uint32_t)j * p.nx);
+                float noise;
+                keep = s_at(a, j, i, p, &noise) > p.sigclip;
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (m) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd((unsigned*)&counters[CNT_CAND], (unsigned)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (keep) cand[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = o;
+        }
+    }
+}
 
 // ---- 2. seeds: one wave per candidate ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_lac_seed(const float* __restrict__ a, const uint8_t* __restrict__ mask, lac_par p,
@@ -638,6 +669,7 @@ __global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
         stats[7] = counters[CNT_CRLIST];
         if (it < 4) { stats[8 + 2 * it] = counters[CNT_CAND]; stats[9 + 2 * it] = counters[CNT_STAGE2]; }
         counters[CNT_NEWCR] = 0; counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CANDOVF] = 0;
+        counters[CNT_CANDRAW] = 0;
     }
 }
 
@@ -645,7 +677,10 @@ __global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt
     const int t = threadIdx.x;
     if (t < 16) stats[t] = 0;
     if (t < 16 && tile_cnt_pad) tile_cnt_pad[t] = 0;         // k_lac_compact reads the counts sixteen at a time
-    if (t == 0) { counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0; counters[CNT_CANDOVF] = 0; }
+    if (t == 0) {
+        counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0;
+        counters[CNT_CANDOVF] = 0; counters[CNT_CANDRAW] = 0;
+    }
 }
 
 // readnoise -> {rn2, T} on the device.  With d_rdn16 the read noise is the float32 image of
@@ -691,9 +726,10 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     const size_t ntiles = (size_t)nwx * ((ny + CAND_ROWS - 1) / CAND_ROWS), capovf = cap / 4 + 4096;
     const dim3 gvec((unsigned)(((ntiles + 7) / 8) * 8));                    // one wave per workgroup, see the tile order in the kernel
     p.nwx = nwx; p.ntiles = (int)ntiles;
-    // candidate workspace: dense list | overflow list | per-tile counts | per-tile segments
-    uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (cap + capovf + 64 + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
-    uint32_t* ovf = cand + cap;
+    // candidate workspace: filtered list | raw list | overflow list | per-tile segments | per-tile counts
+    uint32_t* cand = (uint32_t*)bbx_ws(ctx, WS_CAND, (2 * cap + capovf + 64 + ntiles + 64 + ntiles * CAND_TILECAP) * 4, &rc); if (rc) return rc;
+    uint32_t* cand_raw = cand + cap;
+    uint32_t* ovf = cand_raw + cap;
     uint32_t* tile_seg = ovf + ((capovf + 63) / 64) * 64;
     uint8_t* tile_cnt = (uint8_t*)(tile_seg + ntiles * CAND_TILECAP);     // 16-byte aligned; one byte per tile (<= CAND_TILECAP)
     uint32_t* stage2 = (uint32_t*)bbx_ws(ctx, WS_STAGE2, cap * 4, &rc); if (rc) return rc;
@@ -714,17 +750,18 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
         if (it == 0) {
             if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
-            else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
         } else {
             if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
-            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, ctx->d_err, bs);
+            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
         }
         bbx_prof_stop(ctx, s);
         if (vec) {
             const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, ((ntiles + 127) / 128 + 15) / 16 * 16));
             hipLaunchKernelGGL(k_lac_compact, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(256), 0, s, tile_cnt, tile_seg, (int)ntiles,
-                               tpb, ovf, (uint32_t)capovf, cnt, cand, (uint32_t)cap, ctx->d_err);
+                               tpb, ovf, (uint32_t)capovf, cnt, cand_raw, (uint32_t)cap, ctx->d_err);
         }
+        hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, cand);
         if (it == 0) { rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s); if (rc) return rc; }
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
