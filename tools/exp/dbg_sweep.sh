@@ -6,7 +6,7 @@ for d in "$@"; do
 import json
 try:
     d=json.loads(open("gpurun_out/dbg_$d.log").read().strip().splitlines()[-1])
-    print("dbg=$d", round(d["value"],1), d["device_ms_per_frame"])
+    print("dbg=$d", round(d["value"],1), d["device_ms_per_frame_serial"])
 except Exception as e:
     print("dbg=$d failed", e)
 PY

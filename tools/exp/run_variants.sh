@@ -9,7 +9,7 @@ for f in tools/exp/variants/libbbx_*.so; do
 import json
 try:
     d=json.loads(open("gpurun_out/var_$name.log").read().strip().splitlines()[-1])
-    print("$name", round(d["value"],1), {k: round(v,4) for k,v in d["device_ms_per_frame"].items()}, d["lacosmic_stats"][6:8])
+    print("$name", round(d["value"],1), {k: round(v,4) for k,v in d["device_ms_per_frame_serial"].items()}, d["lacosmic_stats"][6:8])
 except Exception as e:
     print("$name failed", e)
 PY
