@@ -152,9 +152,16 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # rehearsal knobs (a 1-GPU box): BBX_BENCH_BACKEND=gloo BBX_BENCH_ONE_GPU=1 run all ranks on cuda:0
+    backend = os.environ.get('BBX_BENCH_BACKEND', 'nccl')
+    if os.environ.get('BBX_BENCH_ONE_GPU'):
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     ctx = R.Context(local)
     dev = ctx.device
     if args.small:
@@ -233,7 +240,7 @@ def main():
     pipe.close()
     pool.close()
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
