@@ -1,0 +1,337 @@
+// bbx_fpack.hip -- FITS tile compression on the device: what
+// `fpack -q Q -D -Y` / `fpack -D -Y` (blackbox.py:812-857) do to the reduced float image
+// and to the uint8 mask, so that only the compressed bytes cross PCIe.
+//   RICE_1, one tile per image row (fpack's default tiling), block size 32;
+//   float rows: CFITSIO fits_quantize_float with SUBTRACTIVE_DITHER_1 -- noise = smallest
+//   non-zero of the 2nd/3rd/5th-order MAD estimates of the row (FnNoise5_float),
+//   delta = noise / Q, zero point = min rounded to a multiple of delta,
+//   q_i = NINT((x_i - zero) / delta + r_i - 0.5) with the fixed 10000-value random table.
+// One workgroup per row; the row lives in LDS from quantisation to the packed bit stream.
+// Exact order statistics (the three medians) by 4-pass radix select on the float bit
+// patterns.  Held byte-for-byte against CFITSIO through oracle/fpack.py
+// (tests/golden/fpack.npz).
+#include "bbx_common.h"
+
+#define FP_MAXNX 16384
+#define FP_NRANDOM 10000
+#define FP_NRESERVED 10
+
+struct fp_tile {                 // per-row result
+    uint32_t nbytes;             // compressed length
+    uint32_t flag;               // 0 ok, 1 = not quantisable (zero noise / range), 2 = NaN/Inf in the row
+    double zscale, zzero;
+};
+
+__device__ __forceinline__ int fp_nint(double x) { return (x >= 0.) ? (int)(x + 0.5) : (int)(x - 0.5); }
+
+// index into the random table for pixel i of a tile: the sequence starts at
+// int(rand[iseed] * 500) and, each time it reaches the end of the table, restarts at
+// int(rand[++iseed] * 500)
+__device__ __forceinline__ int fp_rand_index(const float* __restrict__ rnd, int iseed, int i) {
+    int start = (int)((double)rnd[iseed] * 500.);
+    while (i >= FP_NRANDOM - start) {
+        i -= FP_NRANDOM - start;
+        iseed = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
+        start = (int)((double)rnd[iseed] * 500.);
+    }
+    return start + i;
+}
+
+// sum over the 32 lanes of a half wave (lanes 0-31 / 32-63 separately)
+__device__ __forceinline__ unsigned long long half_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// exclusive prefix sum over the 32 lanes of a half wave
+__device__ __forceinline__ unsigned half_excl_scan_u32(unsigned v, int l32) {
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (l32 >= o) incl += t; }
+    return incl - v;
+}
+
+// OR [n] bits (n <= 32) of [val] into the big-endian bit stream at bit position [pos]
+__device__ __forceinline__ void put_bits(unsigned* words, unsigned pos, unsigned val, int n) {
+    if (n == 0) return;
+    const unsigned w = pos >> 5, o = pos & 31;
+    const unsigned long long v = ((unsigned long long)val << (64 - n)) >> o;       // aligned to the 64-bit window of words w, w+1
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    if (hi) atomicOr(&words[w], hi);
+    if (lo) atomicOr(&words[w + 1], lo);
+}
+
+template <int BYTEPIX> struct rice_par;
+template <> struct rice_par<1> { static constexpr int fsbits = 3, fsmax = 6, bbits = 8; };
+template <> struct rice_par<2> { static constexpr int fsbits = 4, fsmax = 14, bbits = 16; };
+template <> struct rice_par<4> { static constexpr int fsbits = 5, fsmax = 25, bbits = 32; };
+
+// zig-zag mapped difference of pixel i to its predecessor, in the integer width of the pixel
+template <int BYTEPIX>
+__device__ __forceinline__ unsigned rice_diff(const int* vals, int i) {
+    const int prev = vals[i ? i - 1 : 0];
+    int pd = vals[i] - prev;
+    if (BYTEPIX == 1) pd = (int)(signed char)pd;
+    if (BYTEPIX == 2) pd = (int)(short)pd;
+    unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
+    if (BYTEPIX == 1) d &= 0xffu;
+    if (BYTEPIX == 2) d &= 0xffffu;
+    return d;
+}
+
+// FLOAT_IN: src = float32 rows, quantised first; else src = integer rows of BYTEPIX bytes.
+// dynamic LDS: int vals[nxpad] | unsigned words[maxwords] | unsigned blkbits[nblk+1] | uint8 fsv[nblk] (+ float mode scratch)
+template <int BYTEPIX, bool FLOAT_IN>
+__global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
+                                                 float qlevel, int dither_seed, const float* __restrict__ rnd,
+                                                 uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles) {
+    typedef rice_par<BYTEPIX> RP;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int nblk = (nx + 31) / 32;
+    const int maxwords = (8 * BYTEPIX + nblk * RP::fsbits + nx * RP::bbits + 31) / 32 + 2;
+    int* vals = reinterpret_cast<int*>(lds);
+    unsigned* words = reinterpret_cast<unsigned*>(vals + ((nx + 3) & ~3));
+    unsigned* blkbits = words + maxwords;
+    uint8_t* fsv = reinterpret_cast<uint8_t*>(blkbits + nblk + 1);
+    __shared__ unsigned hist[3][256];
+    __shared__ unsigned sel_prefix[3], sel_rank[3];
+    __shared__ float red_min[4], red_max[4];
+    __shared__ double s_delta, s_zero;
+    __shared__ int s_flag;
+    fp_tile* out = &tiles[row];
+
+    if (FLOAT_IN) {
+        const float* f = (const float*)src + (size_t)row * row_stride_elems;
+        float* fv = reinterpret_cast<float*>(vals);
+        float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+        int bad = 0;
+        for (int i = tid; i < nx; i += 256) {
+            const float v = f[i];
+            fv[i] = v;
+            if (!isfinite(v)) bad = 1;
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        if (bad) s_flag = 2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+        if (lane == 0) { red_min[tid >> 6] = mn; red_max[tid >> 6] = mx; }
+        // lower medians of the 2nd / 3rd / 5th order differences: 4-pass radix select
+        const int nd = nx - 8;
+        if (tid < 3) { sel_prefix[tid] = 0; sel_rank[tid] = nd > 0 ? (unsigned)((nd - 1) / 2) : 0u; }
+        __syncthreads();
+        if (nd > 0) {
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                for (int i = tid; i < 3 * 256; i += 256) (&hist[0][0])[i] = 0;
+                __syncthreads();
+                const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1], p2 = sel_prefix[2];
+                for (int i = tid; i < nd; i += 256) {
+                    const float v1 = fv[i], v3 = fv[i + 2], v5 = fv[i + 4], v7 = fv[i + 6], v9 = fv[i + 8];
+                    const unsigned k2 = __float_as_uint(fabsf(v5 - v7));
+                    const unsigned k3 = __float_as_uint(fabsf((2.f * v5) - v3 - v7));
+                    const unsigned k5 = __float_as_uint(fabsf((6.f * v5) - (4.f * v3) - (4.f * v7) + v1 + v9));
+                    if (shift == 24 || (k2 >> (shift + 8)) == (p0 >> (shift + 8))) atomicAdd(&hist[0][(k2 >> shift) & 255u], 1u);
+                    if (shift == 24 || (k3 >> (shift + 8)) == (p1 >> (shift + 8))) atomicAdd(&hist[1][(k3 >> shift) & 255u], 1u);
+                    if (shift == 24 || (k5 >> (shift + 8)) == (p2 >> (shift + 8))) atomicAdd(&hist[2][(k5 >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid < 3) {
+                    unsigned r = sel_rank[tid], b = 0;
+                    for (; b < 256; b++) { const unsigned c = hist[tid][b]; if (r < c) break; r -= c; }
+                    sel_rank[tid] = r;
+                    sel_prefix[tid] |= b << shift;
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            const float minv = fminf(fminf(red_min[0], red_min[1]), fminf(red_min[2], red_min[3]));
+            const float maxv = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+            double n2 = 0., n3 = 0., n5 = 0.;
+            if (nd > 0) {
+                n2 = 1.0483579 * (double)__uint_as_float(sel_prefix[0]);
+                n3 = 0.6052697 * (double)__uint_as_float(sel_prefix[1]);
+                n5 = 0.1772048 * (double)__uint_as_float(sel_prefix[2]);
+            }
+            double stdev = n3;
+            if (n2 != 0. && n2 < stdev) stdev = n2;
+            if (n5 != 0. && n5 < stdev) stdev = n5;
+            const double delta = (qlevel == 0.f) ? stdev / 4. : stdev / (double)qlevel;
+            double zeropt = 0.;
+            int flag = s_flag;
+            const double minval = (double)minv, maxval = (double)maxv;
+            if (!flag) {
+                if (delta == 0. || (maxval - minval) / delta > 2. * 2147483647. - FP_NRESERVED) flag = 1;
+                else if ((maxval - minval) / delta < 2147483647. - FP_NRESERVED) {
+                    zeropt = minval;
+                    const long long iq = (long long)(zeropt / delta + 0.5);
+                    zeropt = (double)iq * delta;
+                } else zeropt = (minval + maxval) / 2.;
+            }
+            s_delta = delta; s_zero = zeropt; s_flag = flag;
+            out->zscale = delta; out->zzero = zeropt; out->flag = (uint32_t)flag;
+        }
+        __syncthreads();
+        if (s_flag) { if (tid == 0) out->nbytes = 0; return; }
+        const double delta = s_delta, zeropt = s_zero;
+        int iseed = (row + dither_seed - 1) % FP_NRANDOM;          // (tile number 1.. + ZDITHER0 - 1 - 1) % N_RANDOM
+        if (iseed < 0) iseed += FP_NRANDOM;
+        // the float row is replaced in place by the quantised integers (same LDS words; each
+        // element is read and rewritten by one thread, and the medians are done with it)
+        for (int i = tid; i < nx; i += 256)
+            vals[i] = fp_nint((((double)fv[i] - zeropt) / delta) + (double)rnd[fp_rand_index(rnd, iseed, i)] - 0.5);
+    } else {
+        if (BYTEPIX == 1) {
+            const uint8_t* p = (const uint8_t*)src + (size_t)row * row_stride_elems;
+            for (int i = tid; i < nx; i += 256) vals[i] = (int)(signed char)p[i];
+        } else if (BYTEPIX == 2) {
+            const short* p = (const short*)src + (size_t)row * row_stride_elems;
+            for (int i = tid; i < nx; i += 256) vals[i] = (int)p[i];
+        } else {
+            const int* p = (const int*)src + (size_t)row * row_stride_elems;
+            for (int i = tid; i < nx; i += 256) vals[i] = p[i];
+        }
+        if (tid == 0) { out->zscale = 1.0; out->zzero = 0.0; out->flag = 0; }
+    }
+    for (int i = tid; i < maxwords; i += 256) words[i] = 0;
+    __syncthreads();
+
+    // ---- pass 1: per 32-pixel block: split level fs and bit length
+    const int hw = tid >> 5, l32 = tid & 31;                      // 8 half waves, one block each at a time
+    for (int b = hw; b < nblk; b += 8) {
+        const int i = 32 * b + l32;
+        const bool in = i < nx;
+        const unsigned d = in ? rice_diff<BYTEPIX>(vals, i) : 0u;
+        const unsigned long long psum64 = half_sum_u64((unsigned long long)d);
+        const int thisblock = min(32, nx - 32 * b);
+        double dpsum = ((double)psum64 - (double)(thisblock / 2) - 1.) / (double)thisblock;
+        if (dpsum < 0.) dpsum = 0.;
+        unsigned psum = ((unsigned)dpsum) >> 1;
+        int fs = 0;
+        for (; psum > 0; fs++) psum >>= 1;
+        unsigned len;
+        int code;                                                 // what goes into the fsbits field
+        if (fs >= RP::fsmax) { len = in ? RP::bbits : 0; code = RP::fsmax + 1; }
+        else if (fs == 0 && psum64 == 0) { len = 0; code = 0; }
+        else { len = in ? ((d >> fs) + 1u + (unsigned)fs) : 0u; code = fs + 1; }
+        const unsigned long long tot = half_sum_u64((unsigned long long)len);
+        if (l32 == 0) { blkbits[b] = (unsigned)tot + RP::fsbits; fsv[b] = (uint8_t)code; }
+    }
+    __syncthreads();
+    // ---- exclusive scan of the block lengths (nblk <= 512); the stream starts with the first pixel
+    {
+        __shared__ unsigned wsum[4];
+        const unsigned a0 = (2 * tid < nblk) ? blkbits[2 * tid] : 0u, a1 = (2 * tid + 1 < nblk) ? blkbits[2 * tid + 1] : 0u;
+        const unsigned mine = a0 + a1;
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        unsigned base = 8 * BYTEPIX;
+        for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+        const unsigned excl = base + incl - mine;
+        __syncthreads();
+        if (2 * tid < nblk) blkbits[2 * tid] = excl;
+        if (2 * tid + 1 < nblk) blkbits[2 * tid + 1] = excl + a0;
+        if (tid == 255) blkbits[nblk] = excl + mine;              // total bits (threads beyond nblk hold zeros)
+    }
+    __syncthreads();
+    // ---- pass 2: write the codes
+    if (tid == 0) {
+        unsigned first = (unsigned)vals[0];
+        if (BYTEPIX == 1) first &= 0xffu;
+        if (BYTEPIX == 2) first &= 0xffffu;
+        put_bits(words, 0, first, 8 * BYTEPIX);
+    }
+    for (int b = hw; b < nblk; b += 8) {
+        const int i = 32 * b + l32;
+        const bool in = i < nx;
+        const unsigned d = in ? rice_diff<BYTEPIX>(vals, i) : 0u;
+        const int code = fsv[b];
+        unsigned len = 0;
+        if (in) {
+            if (code == RP::fsmax + 1) len = RP::bbits;
+            else if (code != 0) len = (d >> (code - 1)) + 1u + (unsigned)(code - 1);
+        }
+        const unsigned off = blkbits[b] + RP::fsbits + half_excl_scan_u32(len, l32);
+        if (l32 == 0) put_bits(words, blkbits[b], (unsigned)code, RP::fsbits);
+        if (in && len) {
+            if (code == RP::fsmax + 1) put_bits(words, off, d, RP::bbits);
+            else {
+                const int fs = code - 1;
+                const unsigned top = d >> fs;
+                put_bits(words, off + top, 1u, 1);                 // `top` zeros, then a one
+                if (fs) put_bits(words, off + top + 1u, d & ((1u << fs) - 1u), fs);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned totbits = blkbits[nblk];
+    const unsigned nbytes = (totbits + 7) >> 3;
+    unsigned* dst = reinterpret_cast<unsigned*>(scratch + (size_t)row * tile_stride);
+    for (unsigned w = tid; w < (nbytes + 3) / 4; w += 256) dst[w] = __builtin_bswap32(words[w]);
+    if (tid == 0) out->nbytes = nbytes;
+}
+
+// tile streams -> contiguous heap
+__global__ __launch_bounds__(256) void k_fp_gather(const uint8_t* __restrict__ scratch, size_t tile_stride,
+                                                   const fp_tile* __restrict__ tiles, const long long* __restrict__ offsets,
+                                                   uint8_t* __restrict__ heap) {
+    const int row = blockIdx.x;
+    const unsigned n = tiles[row].nbytes;
+    const uint8_t* s = scratch + (size_t)row * tile_stride;
+    uint8_t* d = heap + offsets[row];
+    for (unsigned i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+
+static size_t fp_tile_stride(int nx, int bytepix) {
+    const size_t nblk = (size_t)(nx + 31) / 32;
+    const size_t bits = 8 * (size_t)bytepix + nblk * 5 + (size_t)nx * 8 * bytepix;
+    return ((bits + 31) / 32 + 2) * 4 + 64 & ~(size_t)63;
+}
+
+extern "C" size_t bbx_fpack_tile_stride(int nx, int bytepix) { return fp_tile_stride(nx, bytepix); }
+
+// d_rnd: the 10000-value random table (float32) on the device.  d_scratch: ny * tile_stride bytes.
+extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed,
+                               const float* d_rnd, uint8_t* d_scratch, void* d_tiles, void* stream) {
+    if (!ctx || !d_img || !d_scratch || !d_tiles || ny < 1 || nx < 1 || nx > FP_MAXNX) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int bytepix = bitpix == -32 ? 4 : bitpix / 8;
+    if (!(bitpix == -32 || bitpix == 8 || bitpix == 16 || bitpix == 32)) return BBX_ERR_ARG;
+    if (bitpix == -32 && (!d_rnd || dither_seed < 1 || dither_seed > 10000)) return BBX_ERR_ARG;
+    const size_t stride = fp_tile_stride(nx, bytepix);
+    const int nblk = (nx + 31) / 32;
+    const int fsbits = bytepix == 1 ? 3 : (bytepix == 2 ? 4 : 5);
+    const size_t maxwords = (8 * (size_t)bytepix + (size_t)nblk * fsbits + (size_t)nx * 8 * bytepix + 31) / 32 + 2;
+    const size_t ldsbytes = (size_t)((nx + 3) & ~3) * 4 + maxwords * 4 + ((size_t)nblk + 1) * 4 + (size_t)nblk + 16;
+    if (ldsbytes > 150 * 1024) return BBX_ERR_ARG;
+    fp_tile* tiles = (fp_tile*)d_tiles;
+#define FP_LAUNCH(BP, FL)                                                                                              \
+    do {                                                                                                               \
+        BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                    (int)ldsbytes));                                                                   \
+        hipLaunchKernelGGL((k_fp_tile<BP, FL>), dim3(ny), dim3(256), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel,    \
+                           dither_seed, d_rnd, d_scratch, stride, tiles);                                              \
+    } while (0)
+    if (bitpix == -32) FP_LAUNCH(4, true);
+    else if (bitpix == 8) FP_LAUNCH(1, false);
+    else if (bitpix == 16) FP_LAUNCH(2, false);
+    else FP_LAUNCH(4, false);
+#undef FP_LAUNCH
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const uint8_t* d_scratch, const void* d_tiles,
+                                const long long* d_offsets, uint8_t* d_heap, void* stream) {
+    if (!ctx || !d_scratch || !d_tiles || !d_offsets || !d_heap || ny < 1) return BBX_ERR_ARG;
+    const int bytepix = bitpix == -32 ? 4 : bitpix / 8;
+    hipLaunchKernelGGL(k_fp_gather, dim3(ny), dim3(256), 0, (hipStream_t)stream, d_scratch, fp_tile_stride(nx, bytepix),
+                       (const fp_tile*)d_tiles, d_offsets, d_heap);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}

@@ -168,6 +168,24 @@ int bbx_rect_clipped_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float
 int bbx_rect_scale(bbx_ctx *ctx, int ny, int nx, int stride, float *d_data, float factor,
                    int divide, void *stream);
 
+/* ---- f2: FITS tile compression (fpack, blackbox.py:812-857) ------------------------
+ * RICE_1, one tile per image row, block size 32; float32 images are quantised like CFITSIO's
+ * fits_quantize_float with SUBTRACTIVE_DITHER_1 (noise from the 2nd/3rd/5th order MAD of the
+ * row, delta = noise / qlevel) -- byte-identical to CFITSIO for the same ZDITHER0.
+ *  bbx_fpack_tiles : d_img [ny][nx] of bitpix -32 (float32) / 8 / 16 / 32, d_rnd = CFITSIO's
+ *    10000-value random table (float32) for bitpix -32, dither_seed = ZDITHER0 in 1..10000.
+ *    d_scratch: ny * bbx_fpack_tile_stride(nx, bytepix) bytes, receives each row's stream at
+ *    its stride; d_tiles [ny] of {u32 nbytes, u32 flag, f64 zscale, f64 zzero} (flag 1: row
+ *    not quantisable, 2: non-finite pixel).
+ *  bbx_fpack_gather: copies the streams to d_heap at d_offsets[row] (int64).              */
+size_t bbx_fpack_tile_stride(int nx, int bytepix);
+int bbx_fpack_tiles(bbx_ctx *ctx, int ny, int nx, const void *d_img, int bitpix, float qlevel,
+                    int dither_seed, const float *d_rnd, uint8_t *d_scratch, void *d_tiles,
+                    void *stream);
+int bbx_fpack_gather(bbx_ctx *ctx, int ny, int nx, int bitpix, const uint8_t *d_scratch,
+                     const void *d_tiles, const long long *d_offsets, uint8_t *d_heap,
+                     void *stream);
+
 /* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
  * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1
  * (sic: uncorrected pixels end up divided by 2, reproduced as written); data /= frac + 1.

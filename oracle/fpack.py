@@ -194,7 +194,7 @@ def quantize_row(row, irow, qlevel):
         return None
     rnd = randoms()
     iseed = (irow - 1) % N_RANDOM
-    nextrand = int(rnd[iseed] * 500.0)
+    nextrand = int(float(rnd[iseed]) * 500.0)
     if (maxval - minval) / delta < 2147483647.0 - N_RESERVED_VALUES:
         zeropt = minval
         iq = int(zeropt / delta + 0.5)                           # (LONGLONG) truncation
@@ -209,7 +209,7 @@ def quantize_row(row, irow, qlevel):
             iseed += 1
             if iseed == N_RANDOM:
                 iseed = 0
-            nextrand = int(rnd[iseed] * 500.0)
+            nextrand = int(float(rnd[iseed]) * 500.0)
     return out, delta, zeropt
 
 
@@ -217,7 +217,7 @@ def unquantize_row(idata, irow, bscale, bzero):
     """the reader's side (unquantize_i4r4, SUBTRACTIVE_DITHER_1): float32 values"""
     rnd = randoms()
     iseed = (irow - 1) % N_RANDOM
-    nextrand = int(rnd[iseed] * 500.0)
+    nextrand = int(float(rnd[iseed]) * 500.0)
     out = np.empty(len(idata), np.float32)
     for i, q in enumerate(idata):
         out[i] = np.float32((float(q) - float(rnd[nextrand]) + 0.5) * bscale + bzero)
@@ -226,7 +226,7 @@ def unquantize_row(idata, irow, bscale, bzero):
             iseed += 1
             if iseed == N_RANDOM:
                 iseed = 0
-            nextrand = int(rnd[iseed] * 500.0)
+            nextrand = int(float(rnd[iseed]) * 500.0)
     return out
 
 
