@@ -111,8 +111,15 @@ class Reducer:
         header['REDFILE'] = (redfile, 'BlackBOX reduced image name')
         header['MASKFILE'] = (redfile.replace('_red', '_mask'), 'BlackBOX mask image name')
         os.makedirs(red_dir, exist_ok=True)
-        fitsio.write_image(fits_out, data.cpu().numpy(), header)
-        fitsio.write_image(fits_out.replace('_red', '_mask'), mask.cpu().numpy(), hm)
+        if self.args.fpack:
+            # products leave the GPU tile-compressed (reference: fpack of the files kept,
+            # copy_files2keep 4033-4035): only the compressed bytes cross PCIe
+            from blackbox_amd import fpack as P
+            fits_out = P.fpack_image(self.ctx, fits_out, data, header)
+            P.fpack_image(self.ctx, fits_out.replace('_red', '_mask'), mask, hm)
+        else:
+            fitsio.write_image(fits_out, data.cpu().numpy(), header)
+            fitsio.write_image(fits_out.replace('_red', '_mask'), mask.cpu().numpy(), hm)
         log.info('reduced %s -> %s in %.2f s', filename, fits_out, time.time() - t0)
         return fits_out
 
@@ -137,6 +144,8 @@ def main(argv=None):
     ap.add_argument('--keep_tmp', type=str2bool, default=None)
     # explicit calibration inputs (the date-based master selection of master_prep is orchestration)
     ap.add_argument('--mflat', type=str, default=None)
+    ap.add_argument('--fpack', type=lambda v: str(v).lower() in ('1', 'true', 'yes'), default=False,
+                    help='write tile-compressed .fits.fz products (compressed on the GPU)')
     ap.add_argument('--mbias', type=str, default=None)
     ap.add_argument('--bpm', type=str, default=None)
     ap.add_argument('--crosstalk', type=str, default=None)

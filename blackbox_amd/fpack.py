@@ -55,10 +55,7 @@ def compress_tiles(ctx, img, qlevel=16, dither_seed=1):
     check(lib.bbx_fpack_tiles(ctx.h, ny, nx, C.c_void_p(img.data_ptr()), bitpix, float(qlevel), int(dither_seed),
                               C.c_void_p(rnd.data_ptr()) if rnd is not None else None, C.c_void_p(scratch.data_ptr()),
                               C.c_void_p(tiles.data_ptr()), ctx.stream()), 'bbx_fpack_tiles', ctx.h)
-    t = tiles.cpu().numpy().view(_TILE_DT)
-    if (t['flag'] != 0).any():
-        bad = int(np.nonzero(t['flag'])[0][0])
-        raise ValueError('row {} cannot be quantised (flag {}): constant or non-finite row'.format(bad, int(t['flag'][bad])))
+    t = tiles.cpu().numpy().view(_TILE_DT).copy()
     offsets = np.concatenate([[0], np.cumsum(t['nbytes'].astype(np.int64))])
     total = int(offsets[-1])
     d_off = torch.from_numpy(offsets[:-1].copy()).to(dev)
@@ -66,26 +63,50 @@ def compress_tiles(ctx, img, qlevel=16, dither_seed=1):
     check(lib.bbx_fpack_gather(ctx.h, ny, nx, bitpix, C.c_void_p(scratch.data_ptr()), C.c_void_p(tiles.data_ptr()),
                                C.c_void_p(d_off.data_ptr()), C.c_void_p(heap.data_ptr()), ctx.stream()),
           'bbx_fpack_gather', ctx.h)
-    return heap[:total].cpu().numpy(), t, offsets[:-1]
+    heap = heap[:total].cpu().numpy()
+    # rows that cannot be quantised (zero noise: constant rows such as the filled edge; or a
+    # non-finite pixel) are stored losslessly, gzip of the big-endian floats, in the
+    # GZIP_COMPRESSED_DATA column with ZSCALE = ZZERO = 0 -- as CFITSIO does
+    gz_nbytes = np.zeros(ny, np.int64)
+    gz_offsets = np.zeros(ny, np.int64)
+    bad = np.nonzero(t['flag'])[0]
+    if bad.size:
+        import gzip
+        rows = img[torch.from_numpy(bad).to(dev)].cpu().numpy().astype('>f4')
+        parts, pos = [], total
+        for k, r in enumerate(bad):
+            g = gzip.compress(rows[k].tobytes(), 6, mtime=0)
+            gz_nbytes[r], gz_offsets[r] = len(g), pos
+            pos += len(g)
+            parts.append(np.frombuffer(g, np.uint8))
+            t['zscale'][r] = t['zzero'][r] = 0.0
+        heap = np.concatenate([heap] + parts)
+    return dict(heap=heap, nbytes=t['nbytes'].astype(np.int64), offsets=offsets[:-1], zscale=t['zscale'], zzero=t['zzero'],
+                flag=t['flag'], gz_nbytes=gz_nbytes, gz_offsets=gz_offsets)
 
 
 def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=None, header=None, qlevel=16,
-                dither_seed=1):
+                dither_seed=1, gz_nbytes=None, gz_offsets=None):
     """write primary HDU + COMPRESSED_IMAGE binary table (FITS 4.0 section 10) around tile
     streams that are already compressed"""
     ny, nx = shape
     quant = bitpix == -32
-    rowlen = 8 + (16 if quant else 0)
+    rowlen = 8 + (24 if quant else 0)
     maxlen = int(np.max(nbytes)) if len(nbytes) else 0
+    if gz_nbytes is None:
+        gz_nbytes, gz_offsets = np.zeros(ny, np.int64), np.zeros(ny, np.int64)
+    maxgz = int(np.max(gz_nbytes)) if len(gz_nbytes) else 0
     cards = [fitsio._card('XTENSION', 'BINTABLE', 'binary table extension'), fitsio._card('BITPIX', 8, 'array data type'),
              fitsio._card('NAXIS', 2, 'number of array dimensions'), fitsio._card('NAXIS1', rowlen, 'width of table in bytes'),
              fitsio._card('NAXIS2', ny, 'number of rows in table'), fitsio._card('PCOUNT', int(len(heap)), 'size of the heap'),
-             fitsio._card('GCOUNT', 1, 'number of groups'), fitsio._card('TFIELDS', 3 if quant else 1, 'number of fields in each row'),
+             fitsio._card('GCOUNT', 1, 'number of groups'), fitsio._card('TFIELDS', 4 if quant else 1, 'number of fields in each row'),
              fitsio._card('TTYPE1', 'COMPRESSED_DATA', 'label for field 1'),
              fitsio._card('TFORM1', '1PB({})'.format(maxlen), 'data format of field: variable length array')]
     if quant:
-        cards += [fitsio._card('TTYPE2', 'ZSCALE', 'label for field 2'), fitsio._card('TFORM2', '1D', 'data format of field: 8-byte DOUBLE'),
-                  fitsio._card('TTYPE3', 'ZZERO', 'label for field 3'), fitsio._card('TFORM3', '1D', 'data format of field: 8-byte DOUBLE')]
+        cards += [fitsio._card('TTYPE2', 'GZIP_COMPRESSED_DATA', 'label for field 2'),
+                  fitsio._card('TFORM2', '1PB({})'.format(maxgz), 'data format of field: variable length array'),
+                  fitsio._card('TTYPE3', 'ZSCALE', 'label for field 3'), fitsio._card('TFORM3', '1D', 'data format of field: 8-byte DOUBLE'),
+                  fitsio._card('TTYPE4', 'ZZERO', 'label for field 4'), fitsio._card('TFORM4', '1D', 'data format of field: 8-byte DOUBLE')]
     cards += [fitsio._card('ZIMAGE', True, 'extension contains compressed image'),
               fitsio._card('ZTENSION', 'IMAGE', 'Image extension'), fitsio._card('ZBITPIX', bitpix, 'data type of original image'),
               fitsio._card('ZNAXIS', 2, 'dimension of original image'), fitsio._card('ZNAXIS1', nx, 'length of original image axis'),
@@ -114,8 +135,10 @@ def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=N
                     'END'.ljust(80)]).encode('ascii')
     prim += b' ' * ((-len(prim)) % fitsio.BLOCK)
     if quant:
-        rows = np.zeros(ny, dtype=[('len', '>i4'), ('off', '>i4'), ('zscale', '>f8'), ('zzero', '>f8')])
+        rows = np.zeros(ny, dtype=[('len', '>i4'), ('off', '>i4'), ('glen', '>i4'), ('goff', '>i4'), ('zscale', '>f8'),
+                                   ('zzero', '>f8')])
         rows['zscale'], rows['zzero'] = zscale, zzero
+        rows['glen'], rows['goff'] = gz_nbytes, gz_offsets
     else:
         rows = np.zeros(ny, dtype=[('len', '>i4'), ('off', '>i4')])
     rows['len'], rows['off'] = nbytes, offsets
@@ -135,7 +158,7 @@ def fpack_image(ctx, path, img, header=None, quant=None, dither_seed=1):
     if quant is None:
         quant = 2 if ('Scorr' in path or 'limmag' in path) else (4 if 'Fpsf' in path else 16)
     out = path if path.endswith('.fz') else path + '.fz'
-    heap, t, offsets = compress_tiles(ctx, img, quant, dither_seed)
+    c = compress_tiles(ctx, img, quant, dither_seed)
     bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32}[img.dtype]
-    return assemble_fz(out, tuple(img.shape), bitpix, heap, t['nbytes'], offsets, t['zscale'], t['zzero'], header, quant,
-                       dither_seed)
+    return assemble_fz(out, tuple(img.shape), bitpix, c['heap'], c['nbytes'], c['offsets'], c['zscale'], c['zzero'], header,
+                       quant, dither_seed, c['gz_nbytes'], c['gz_offsets'])

@@ -37,8 +37,16 @@ def test_container_read_by_astropy(tmp_path):
         nbytes = np.array([len(s[0]) for s in st])
         offsets = np.concatenate([[0], np.cumsum(nbytes)])[:-1]
         heap = np.frombuffer(b''.join(s[0] for s in st), np.uint8)
-        P.assemble_fz(str(tmp_path / name), arr.shape, bitpix, heap, nbytes, offsets, [s[1] for s in st], [s[2] for s in st],
-                      {'OBJECT': ('test', 'field'), 'EXPTIME': 60.0}, 16, 42)
+        gzn, gzo = np.zeros(arr.shape[0], np.int64), np.zeros(arr.shape[0], np.int64)
+        zs, zz = np.array([s[1] for s in st]), np.array([s[2] for s in st])
+        if bitpix == -32:                                  # row 2 stored losslessly
+            import gzip
+            g = np.frombuffer(gzip.compress(arr[2].astype('>f4').tobytes(), 6, mtime=0), np.uint8)
+            gzn[2], gzo[2] = g.size, heap.size
+            heap = np.concatenate([heap, g])
+            nbytes[2], zs[2], zz[2] = 0, 0.0, 0.0
+        P.assemble_fz(str(tmp_path / name), arr.shape, bitpix, heap, nbytes, offsets, zs, zz,
+                      {'OBJECT': ('test', 'field'), 'EXPTIME': 60.0}, 16, 42, gzn, gzo)
     np.save(tmp_path / 'img.npy', img)
     np.save(tmp_path / 'msk.npy', msk)
     code = '''
@@ -51,7 +59,9 @@ a = fits.open(d + '/a_red.fits.fz')[1]
 img = np.load(d + '/img.npy')
 assert a.data.shape == img.shape and a.header['OBJECT'] == 'test' and a.header['EXPTIME'] == 60.0
 t = fits.open(d + '/a_red.fits.fz', disable_image_compression=True)[1].data
-assert np.max(np.abs(a.data - img) / t['ZSCALE'][:, None]) <= 0.5001
+assert np.array_equal(a.data[2], img[2])
+k = [0, 1, 3, 4, 5, 6]
+assert np.max(np.abs(a.data[k] - img[k]) / t['ZSCALE'][k][:, None]) <= 0.5001
 m = fits.open(d + '/a_mask.fits.fz')[1]
 assert np.array_equal(m.data, np.load(d + '/msk.npy')) and m.data.dtype == np.uint8
 print('ok')
@@ -73,8 +83,9 @@ def test_gpu_tiles_equal_cfitsio_and_oracle(tmp_path):
     tdt = {'f32': torch.float32, 'u8': torch.uint8, 'i16': torch.int16, 'i32': torch.int32}
     for k, c in enumerate(cases):
         d = FP.golden_input(c['kind'], c['seed'], c['ny'], c['nx'])
-        heap, t, off = P.compress_tiles(ctx, torch.from_numpy(d).to(ctx.device), c.get('q', 16), c.get('dither_seed', 1))
-        assert t.shape[0] == c['ny'] and tdt[c['kind']] is not None
+        cc = P.compress_tiles(ctx, torch.from_numpy(d).to(ctx.device), c.get('q', 16), c.get('dither_seed', 1))
+        heap, t, off = cc['heap'], cc, cc['offsets']
+        assert t['nbytes'].shape[0] == c['ny'] and tdt[c['kind']] is not None
         for r in range(c['ny']):
             want = g['c%d_row%d' % (k, r)].tobytes()
             assert heap[off[r]:off[r] + t['nbytes'][r]].tobytes() == want, (k, r)
@@ -85,7 +96,8 @@ def test_gpu_tiles_equal_cfitsio_and_oracle(tmp_path):
     for (ny, nx, q, seed) in ((3, 10560, 16, 9990), (5, 1000, 4, 1), (4, 33, 16, 10000), (2, 4097, 2, 123)):
         img = (1000 + 0.01 * np.arange(nx)[None, :] + rs.normal(0, 30, (ny, nx))).astype(np.float32)
         img[rs.randint(0, ny, 6), rs.randint(0, nx, 6)] += 4e4
-        heap, t, off = P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), q, seed)
+        t = P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), q, seed)
+        heap, off = t['heap'], t['offsets']
         for r, (b, zs, zz) in enumerate(FP.compress_float_image(img, q, seed)):
             assert t['zscale'][r] == zs and t['zzero'][r] == zz, (nx, r)
             assert heap[off[r]:off[r] + t['nbytes'][r]].tobytes() == b, (nx, r)
@@ -93,7 +105,8 @@ def test_gpu_tiles_equal_cfitsio_and_oracle(tmp_path):
     msk[rs.rand(6, 10560) < 0.03] = 32
     msk[2, 100:4000] = 4
     msk[4] = 0
-    heap, t, off = P.compress_tiles(ctx, torch.from_numpy(msk).to(ctx.device))
+    t = P.compress_tiles(ctx, torch.from_numpy(msk).to(ctx.device))
+    heap, off = t['heap'], t['offsets']
     for r in range(6):
         b = FP.rice_encode(msk[r], 1)
         assert heap[off[r]:off[r] + t['nbytes'][r]].tobytes() == b, r
@@ -103,8 +116,15 @@ def test_gpu_tiles_equal_cfitsio_and_oracle(tmp_path):
     path = P.fpack_image(ctx, str(tmp_path / 'x_red.fits'), torch.from_numpy(img).to(ctx.device), {'A': 1}, dither_seed=7)
     assert path.endswith('.fits.fz') and os.path.getsize(path) % 2880 == 0
     assert os.path.getsize(path) < img.nbytes / 3
-    # non-finite rows are refused loudly
-    bad = img.copy(); bad[3, 5] = np.nan
-    with pytest.raises(ValueError):
-        P.compress_tiles(ctx, torch.from_numpy(bad).to(ctx.device))
+    # rows that cannot be quantised (constant, or holding a NaN) are stored losslessly (gzip)
+    import gzip
+    bad = img.copy(); bad[3, 5] = np.nan; bad[7] = 12.5
+    c = P.compress_tiles(ctx, torch.from_numpy(bad).to(ctx.device), 16, 3)
+    assert list(np.nonzero(c['flag'])[0]) == [3, 7] and c['nbytes'][3] == 0 and c['nbytes'][7] == 0
+    for r in (3, 7):
+        raw = gzip.decompress(c['heap'][c['gz_offsets'][r]:c['gz_offsets'][r] + c['gz_nbytes'][r]].tobytes())
+        assert np.array_equal(np.frombuffer(raw, '>f4'), bad[r], equal_nan=True)
+        assert c['zscale'][r] == 0.0 and c['zzero'][r] == 0.0
+    P.fpack_image(ctx, str(tmp_path / 'y_red.fits'), torch.from_numpy(bad).to(ctx.device), dither_seed=3)
+    np.save(tmp_path / 'bad.npy', bad)
     ctx.close()
