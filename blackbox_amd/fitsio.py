@@ -83,7 +83,8 @@ def _hv(h, k, default=None):
 
 
 def read_hdus(path):
-    """-> list of (header dict, data ndarray or None)"""
+    """-> list of (header dict, data ndarray or None).  Binary tables come back as their raw
+    row bytes (uint8 [NAXIS2, NAXIS1]) with the heap under header key '__heap__'."""
     out = []
     with open(path, 'rb') as f:
         while True:
@@ -103,7 +104,12 @@ def read_hdus(path):
                 if raw.size != npix:
                     raise EOFError('truncated FITS data in {}'.format(path))
                 data = raw.reshape(shape)
-                f.seek((-(npix * abs(bitpix) // 8)) % BLOCK, 1)       # data units are padded to 2880 bytes
+                nbytes = npix * abs(bitpix) // 8
+                pcount = int(_hv(h, 'PCOUNT', 0) or 0)
+                if pcount and str(_hv(h, 'XTENSION', '')).strip() == 'BINTABLE':
+                    h['__heap__'] = np.fromfile(f, dtype=np.uint8, count=pcount)
+                    nbytes += pcount
+                f.seek((-nbytes) % BLOCK, 1)                          # data units are padded to 2880 bytes
             out.append((h, data))
     return out
 

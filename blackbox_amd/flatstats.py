@@ -19,11 +19,26 @@ from . import reduce as R
 get_par = settings.get_par
 
 
+def _check_section(data, mask, y0, x0, ny, nx, ysz, xsz):
+    """the library addresses the section through offset pointers: everything must lie
+    inside the frame (an out-of-range section would be a device fault, not an error code)"""
+    if data.dim() != 2 or data.dtype != torch.float32 or not data.is_contiguous():
+        raise ValueError('contiguous 2-D float32 frame expected')
+    NY, NX = data.shape
+    if mask is not None and (mask.dtype != torch.uint8 or tuple(mask.shape) != (NY, NX) or not mask.is_contiguous()):
+        raise ValueError('mask: contiguous uint8 of the frame shape expected')
+    if not (0 <= y0 and 0 <= x0 and ny >= 1 and nx >= 1 and y0 + ny <= NY and x0 + nx <= NX):
+        raise ValueError('section [{}:{}, {}:{}] outside the {}x{} frame'.format(y0, y0 + ny, x0, x0 + nx, NY, NX))
+    if ysz < 1 or xsz < 1 or ny % ysz or nx % xsz or (ny // ysz) * (nx // xsz) > 64:
+        raise ValueError('bad segmentation {}x{} of a {}x{} section'.format(ysz, xsz, ny, nx))
+
+
 def rect_stats(ctx, data, mask, y0, x0, ny, nx, ysz, xsz):
     """bbx_rect_stats on the section [y0:y0+ny, x0:x0+nx] of the device frame [data] cut
     into segments of ysz x xsz -> numpy float64 [nseg, 8]
     (n, median, mean, sigma, n_low, sigma_low, 0, 0)"""
     NY, NX = data.shape
+    _check_section(data, mask, y0, x0, ny, nx, ysz, xsz)
     nseg = (ny // ysz) * (nx // xsz)
     out = torch.empty((nseg, 8), dtype=torch.float64, device=data.device)
     off = y0 * NX + x0
@@ -36,6 +51,7 @@ def rect_stats(ctx, data, mask, y0, x0, ny, nx, ysz, xsz):
 def rect_clipped_stats(ctx, data, mask, y0, x0, ny, nx, ysz, xsz, sigma=3.0, maxiters=5, skip_zero=True):
     """sigma_clipped_stats(..., mask_value=0) per segment -> numpy [nseg, 8] (n, median, mean, sigma, ...)"""
     NY, NX = data.shape
+    _check_section(data, mask, y0, x0, ny, nx, ysz, xsz)
     nseg = (ny // ysz) * (nx // xsz)
     out = torch.empty((nseg, 8), dtype=torch.float64, device=data.device)
     off = y0 * NX + x0
@@ -86,6 +102,8 @@ def get_flatstats(ctx, data, header, data_mask, tel=None, statsec=None, subsize=
 
     sub = subsize or settings.subimage_size
     ns = NY // sub
+    if ns < 3 or ns * sub > NX:
+        raise ValueError('frame {}x{} too small for {}-pixel sub-image statistics'.format(NY, NX, sub))
     st = rect_stats(ctx, data, data_mask, 0, 0, ns * sub, ns * sub, sub, sub).reshape(ns, ns, 8)
     mini_median, mini_std = st[:, :, 1], st[:, :, 5]
     mask_cntr = ndimage.binary_erosion(np.ones(mini_median.shape, dtype=bool))

@@ -40,7 +40,9 @@ def master_median(ctx, frames, imgtype, medsec=None, bpm=None):
 
 
 def _rect_scale(ctx, t, y0, x0, ny, nx, factor, divide):
-    NX = t.shape[1]
+    NY, NX = t.shape
+    if not (0 <= y0 and 0 <= x0 and ny >= 1 and nx >= 1 and y0 + ny <= NY and x0 + nx <= NX):
+        raise ValueError('section outside the frame')
     check(lib.bbx_rect_scale(ctx.h, ny, nx, NX, C.c_void_p(t.data_ptr() + 4 * (y0 * NX + x0)), C.c_float(float(factor)),
                              1 if divide else 0, ctx.stream()), 'bbx_rect_scale', ctx.h)
 
@@ -57,6 +59,8 @@ def gain_correction_factors(ctx, master, header, ysize_chan=None, xsize_chan=Non
     from . import flatstats
     NY, NX = master.shape
     ysz, xsz = ysize_chan or NY // 2, xsize_chan or NX // 8
+    if nrows_v > ysz or nrows_h > ysz or ncols > xsz:
+        raise ValueError('statistics strips larger than a channel')
     corr = master.clone()
     med = np.zeros(16)
     for c in range(16):

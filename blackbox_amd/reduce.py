@@ -62,6 +62,14 @@ class Context:
             pass
 
 
+def _expect(t, dtype, shape, name):
+    """device pointers cross the C ABI without their extents: a wrong shape or dtype would be
+    a device fault, so it is refused here"""
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError('{}: expected contiguous {} device tensor of shape {}, got {} {}'.format(
+            name, dtype, tuple(shape), t.dtype, tuple(t.shape)))
+
+
 def raw_type_of(raw):
     if raw.dtype == torch.uint16:
         return BBX_RAW_U16
@@ -222,6 +230,8 @@ def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=N
     flat) in one pass -> (data float32, mask uint8) device tensors"""
     dev = ctx.device
     ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
+    if tuple(raw.shape) != (geom.ny_raw, geom.nx_raw) or not raw.is_contiguous() or not raw.is_cuda:
+        raise ValueError('raw frame: contiguous device tensor of shape {} expected'.format((geom.ny_raw, geom.nx_raw)))
     gain = get_par(settings.gain, tel)
     sat = satlevels(header, tel)
     header_mask['SATURATE'] = header['SATURATE'] = (float(np.mean(sat)), '[e-] mean saturation threshold')
@@ -243,6 +253,7 @@ def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=N
 def mask_init_finish(ctx, mask, header, header_mask, geom, d_n=None):
     """second half of mask_init (blackbox.py:4504-4566) + fill_sat_holes; d_n: optional int32[1]
     device tensor for the NOBJ-SAT count (set by the library)"""
+    _expect(mask, torch.uint8, (2 * geom.ysize_chan, 8 * geom.xsize_chan), 'mask')
     if d_n is None:
         d_n = torch.empty(1, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_mask_finish(ctx.h, C.byref(geom), _ptr(mask), _ptr(d_n), ctx.stream()), 'bbx_mask_finish', ctx.h)
@@ -254,6 +265,8 @@ def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None, d
     [per-iteration counts x6, n objects, n pixels].  readnoise = header RDNOISE, or -- when
     the 16 channel sigmas are still on the device -- their nanmean taken there."""
     ny, nx = data.shape
+    _expect(data, torch.float32, (ny, nx), 'data')
+    _expect(data_mask, torch.uint8, (ny, nx), 'data_mask')
     readnoise = 0.0
     if d_rdn16 is None:
         hv = header['RDNOISE']
@@ -271,6 +284,8 @@ def cosmics_corr(ctx, data, header, data_mask, header_mask, tel, d_rdn16=None, d
 def detect_cosmics(ctx, data, mask, sigclip, sigfrac, objlim, niter, readnoise):
     """astroscrappy-style call on device tensors (in place) -> stats tensor"""
     ny, nx = data.shape
+    _expect(data, torch.float32, (ny, nx), 'data')
+    _expect(mask, torch.uint8, (ny, nx), 'mask')
     d_stats = torch.zeros(16, dtype=torch.int32, device=ctx.device)
     check(lib.bbx_lacosmic(ctx.h, ny, nx, _ptr(data), _ptr(mask), float(sigclip), float(sigfrac), float(objlim),
                            int(niter), float(np.float32(readnoise)), _ptr(None), _ptr(d_stats), ctx.stream()),
@@ -296,6 +311,9 @@ def read_crosstalk(path):
 
 def xtalk_corr(ctx, data, coeffs, data_mask, geom):
     """blackbox.py:7138-7258, in place on the device"""
+    shape = (2 * geom.ysize_chan, 8 * geom.xsize_chan)
+    _expect(data, torch.float32, shape, 'data')
+    _expect(data_mask, torch.uint8, shape, 'data_mask')
     cf = (C.c_double * 256)(*[float(v) for v in np.asarray(coeffs, dtype=np.float64).reshape(-1)])
     check(lib.bbx_xtalk(ctx.h, C.byref(geom), _ptr(data), _ptr(data_mask), cf, ctx.stream()), 'bbx_xtalk', ctx.h)
 
@@ -362,6 +380,8 @@ def sat_detect(ctx, data, header, data_mask, header_mask):
     """blackbox.py:4163-4254 (classical path; deterministic detector, see oracle/sattrail.py):
     adds bit 16 to data_mask in place, sets NSATS.  Returns (nsats tensor, info tensor)."""
     ny, nx = data.shape
+    _expect(data, torch.float32, (ny, nx), 'data')
+    _expect(data_mask, torch.uint8, (ny, nx), 'data_mask')
     th = np.arange(NTHETA_SAT) * (np.pi / NTHETA_SAT)
     cs = np.empty(2 * NTHETA_SAT)
     cs[0::2], cs[1::2] = np.cos(th), np.sin(th)
@@ -374,6 +394,7 @@ def sat_detect(ctx, data, header, data_mask, header_mask):
 
 def mask_header(ctx, data_mask, header_mask):
     """blackbox.py:4601-4620"""
+    _expect(data_mask, torch.uint8, data_mask.shape, 'data_mask')
     d_c = torch.zeros(6, dtype=torch.int64, device=ctx.device)
     check(lib.bbx_mask_counts(ctx.h, data_mask.numel(), _ptr(data_mask), _ptr(d_c), ctx.stream()),
           'bbx_mask_counts', ctx.h)
@@ -389,6 +410,9 @@ def mask_header(ctx, data_mask, header_mask):
 
 def edge_fill(ctx, data, data_mask, geom):
     """blackbox.py:1959-1974"""
+    shape = (2 * geom.ysize_chan, 8 * geom.xsize_chan)
+    _expect(data, torch.float32, shape, 'data')
+    _expect(data_mask, torch.uint8, shape, 'data_mask')
     d_med = torch.empty(16, dtype=torch.float32, device=ctx.device)
     check(lib.bbx_edge_fill(ctx.h, C.byref(geom), _ptr(data), _ptr(data_mask), _ptr(d_med), ctx.stream()),
           'bbx_edge_fill', ctx.h)
