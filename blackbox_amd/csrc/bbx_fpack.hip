@@ -13,6 +13,7 @@
 #include "bbx_common.h"
 
 #define FP_MAXNX 16384
+#define FP_THREADS 1024          // one workgroup per row holds ~100 KB of LDS: one per CU, so make it wide
 #define FP_NRANDOM 10000
 #define FP_NRESERVED 10
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ unsigned rice_diff(const int* vals, int i) {
 // FLOAT_IN: src = float32 rows, quantised first; else src = integer rows of BYTEPIX bytes.
 // dynamic LDS: int vals[nxpad] | unsigned words[maxwords] | unsigned blkbits[nblk+1] | uint8 fsv[nblk] (+ float mode scratch)
 template <int BYTEPIX, bool FLOAT_IN>
-__global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
+__global__ __launch_bounds__(FP_THREADS) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
                                                  float qlevel, int dither_seed, const float* __restrict__ rnd,
                                                  uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles) {
     typedef rice_par<BYTEPIX> RP;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
     uint8_t* fsv = reinterpret_cast<uint8_t*>(blkbits + nblk + 1);
     __shared__ unsigned hist[3][256];
     __shared__ unsigned sel_prefix[3], sel_rank[3];
-    __shared__ float red_min[4], red_max[4];
+    __shared__ float red_min[FP_THREADS / 64], red_max[FP_THREADS / 64];
     __shared__ double s_delta, s_zero;
     __shared__ int s_flag;
     fp_tile* out = &tiles[row];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
         float* fv = reinterpret_cast<float*>(vals);
         float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
         int bad = 0;
-        for (int i = tid; i < nx; i += 256) {
+        for (int i = tid; i < nx; i += FP_THREADS) {
             const float v = f[i];
             fv[i] = v;
             if (!isfinite(v)) bad = 1;
@@ -124,10 +125,10 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
         __syncthreads();
         if (nd > 0) {
             for (int shift = 24; shift >= 0; shift -= 8) {
-                for (int i = tid; i < 3 * 256; i += 256) (&hist[0][0])[i] = 0;
+                for (int i = tid; i < 3 * 256; i += FP_THREADS) (&hist[0][0])[i] = 0;
                 __syncthreads();
                 const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1], p2 = sel_prefix[2];
-                for (int i = tid; i < nd; i += 256) {
+                for (int i = tid; i < nd; i += FP_THREADS) {
                     const float v1 = fv[i], v3 = fv[i + 2], v5 = fv[i + 4], v7 = fv[i + 6], v9 = fv[i + 8];
                     const unsigned k2 = __float_as_uint(fabsf(v5 - v7));
                     const unsigned k3 = __float_as_uint(fabsf((2.f * v5) - v3 - v7));
@@ -137,18 +138,28 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
                     if (shift == 24 || (k5 >> (shift + 8)) == (p2 >> (shift + 8))) atomicAdd(&hist[2][(k5 >> shift) & 255u], 1u);
                 }
                 __syncthreads();
-                if (tid < 3) {
-                    unsigned r = sel_rank[tid], b = 0;
-                    for (; b < 256; b++) { const unsigned c = hist[tid][b]; if (r < c) break; r -= c; }
-                    sel_rank[tid] = r;
-                    sel_prefix[tid] |= b << shift;
+                if (tid < 192) {                                   // one wave per histogram, 4 bins per lane
+                    const int k = tid >> 6;
+                    const unsigned c0 = hist[k][4 * lane], c1 = hist[k][4 * lane + 1], c2 = hist[k][4 * lane + 2],
+                                   c3 = hist[k][4 * lane + 3];
+                    const unsigned mine = c0 + c1 + c2 + c3;
+                    unsigned incl = mine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                    const unsigned excl = incl - mine, r = sel_rank[k];
+                    if (r >= excl && r < incl) {                   // the one lane whose bins hold the rank
+                        unsigned rr = r - excl, b = 4 * lane;
+                        if (rr >= c0) { rr -= c0; b++; if (rr >= c1) { rr -= c1; b++; if (rr >= c2) { rr -= c2; b++; } } }
+                        sel_rank[k] = rr;
+                        sel_prefix[k] |= b << shift;
+                    }
                 }
                 __syncthreads();
             }
         }
         if (tid == 0) {
-            const float minv = fminf(fminf(red_min[0], red_min[1]), fminf(red_min[2], red_min[3]));
-            const float maxv = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+            float minv = red_min[0], maxv = red_max[0];
+            for (int w = 1; w < FP_THREADS / 64; w++) { minv = fminf(minv, red_min[w]); maxv = fmaxf(maxv, red_max[w]); }
             double n2 = 0., n3 = 0., n5 = 0.;
             if (nd > 0) {
                 n2 = 1.0483579 * (double)__uint_as_float(sel_prefix[0]);
@@ -180,27 +191,27 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
         if (iseed < 0) iseed += FP_NRANDOM;
         // the float row is replaced in place by the quantised integers (same LDS words; each
         // element is read and rewritten by one thread, and the medians are done with it)
-        for (int i = tid; i < nx; i += 256)
+        for (int i = tid; i < nx; i += FP_THREADS)
             vals[i] = fp_nint((((double)fv[i] - zeropt) / delta) + (double)rnd[fp_rand_index(rnd, iseed, i)] - 0.5);
     } else {
         if (BYTEPIX == 1) {
             const uint8_t* p = (const uint8_t*)src + (size_t)row * row_stride_elems;
-            for (int i = tid; i < nx; i += 256) vals[i] = (int)(signed char)p[i];
+            for (int i = tid; i < nx; i += FP_THREADS) vals[i] = (int)(signed char)p[i];
         } else if (BYTEPIX == 2) {
             const short* p = (const short*)src + (size_t)row * row_stride_elems;
-            for (int i = tid; i < nx; i += 256) vals[i] = (int)p[i];
+            for (int i = tid; i < nx; i += FP_THREADS) vals[i] = (int)p[i];
         } else {
             const int* p = (const int*)src + (size_t)row * row_stride_elems;
-            for (int i = tid; i < nx; i += 256) vals[i] = p[i];
+            for (int i = tid; i < nx; i += FP_THREADS) vals[i] = p[i];
         }
         if (tid == 0) { out->zscale = 1.0; out->zzero = 0.0; out->flag = 0; }
     }
-    for (int i = tid; i < maxwords; i += 256) words[i] = 0;
+    for (int i = tid; i < maxwords; i += FP_THREADS) words[i] = 0;
     __syncthreads();
 
     // ---- pass 1: per 32-pixel block: split level fs and bit length
-    const int hw = tid >> 5, l32 = tid & 31;                      // 8 half waves, one block each at a time
-    for (int b = hw; b < nblk; b += 8) {
+    const int hw = tid >> 5, l32 = tid & 31;                      // FP_THREADS/32 half waves, one block each at a time
+    for (int b = hw; b < nblk; b += FP_THREADS / 32) {
         const int i = 32 * b + l32;
         const bool in = i < nx;
         const unsigned d = in ? rice_diff<BYTEPIX>(vals, i) : 0u;
@@ -220,11 +231,11 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
         if (l32 == 0) { blkbits[b] = (unsigned)tot + RP::fsbits; fsv[b] = (uint8_t)code; }
     }
     __syncthreads();
-    // ---- exclusive scan of the block lengths (nblk <= 512); the stream starts with the first pixel
+    // ---- exclusive scan of the block lengths (nblk <= 512 <= FP_THREADS); the stream starts
+    // with the first pixel
     {
-        __shared__ unsigned wsum[4];
-        const unsigned a0 = (2 * tid < nblk) ? blkbits[2 * tid] : 0u, a1 = (2 * tid + 1 < nblk) ? blkbits[2 * tid + 1] : 0u;
-        const unsigned mine = a0 + a1;
+        __shared__ unsigned wsum[FP_THREADS / 64];
+        const unsigned mine = (tid < nblk) ? blkbits[tid] : 0u;
         unsigned incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -234,9 +245,8 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
         for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
         const unsigned excl = base + incl - mine;
         __syncthreads();
-        if (2 * tid < nblk) blkbits[2 * tid] = excl;
-        if (2 * tid + 1 < nblk) blkbits[2 * tid + 1] = excl + a0;
-        if (tid == 255) blkbits[nblk] = excl + mine;              // total bits (threads beyond nblk hold zeros)
+        if (tid < nblk) blkbits[tid] = excl;
+        if (tid == FP_THREADS - 1) blkbits[nblk] = excl + mine;   // total bits (threads beyond nblk hold zeros)
     }
     __syncthreads();
     // ---- pass 2: write the codes
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
         if (BYTEPIX == 2) first &= 0xffffu;
         put_bits(words, 0, first, 8 * BYTEPIX);
     }
-    for (int b = hw; b < nblk; b += 8) {
+    for (int b = hw; b < nblk; b += FP_THREADS / 32) {
         const int i = 32 * b + l32;
         const bool in = i < nx;
         const unsigned d = in ? rice_diff<BYTEPIX>(vals, i) : 0u;
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fp_tile(const void* __restrict__ src, i
     const unsigned totbits = blkbits[nblk];
     const unsigned nbytes = (totbits + 7) >> 3;
     unsigned* dst = reinterpret_cast<unsigned*>(scratch + (size_t)row * tile_stride);
-    for (unsigned w = tid; w < (nbytes + 3) / 4; w += 256) dst[w] = __builtin_bswap32(words[w]);
+    for (unsigned w = tid; w < (nbytes + 3) / 4; w += FP_THREADS) dst[w] = __builtin_bswap32(words[w]);
     if (tid == 0) out->nbytes = nbytes;
 }
 
@@ -314,7 +324,7 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
     do {                                                                                                               \
         BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                     (int)ldsbytes));                                                                   \
-        hipLaunchKernelGGL((k_fp_tile<BP, FL>), dim3(ny), dim3(256), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel,    \
+        hipLaunchKernelGGL((k_fp_tile<BP, FL>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel,    \
                            dither_seed, d_rnd, d_scratch, stride, tiles);                                              \
     } while (0)
     if (bitpix == -32) FP_LAUNCH(4, true);
