@@ -77,9 +77,18 @@ class Reducer:
     def blackbox_reduce(self, filename):
         R, torch, fitsio = self.R, self.torch, self.fitsio
         t0 = time.time()
-        raw, hraw = fitsio.read_image(filename, get_header=True)
-        if raw.dtype not in (np.uint16, np.float32):
-            raw = raw.astype(np.float32)
+        d_raw = None
+        if filename.endswith('.fz'):
+            # fpacked raw frame (the reference's usual input): the compressed bytes go to the GPU
+            # and are decoded there
+            from blackbox_amd import fpack as P
+            d_raw, hraw = P.funpack_image(self.ctx, filename)
+            if d_raw.dtype not in (torch.uint16, torch.float32):
+                d_raw = d_raw.to(torch.float32)
+        else:
+            raw, hraw = fitsio.read_image(filename, get_header=True)
+            if raw.dtype not in (np.uint16, np.float32):
+                raw = raw.astype(np.float32)
         header = dict(hraw)
         for k in ('BZERO', 'BSCALE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'SIMPLE', 'EXTEND'):
             header.pop(k, None)
@@ -89,7 +98,8 @@ class Reducer:
                 and not (self.args.img_reduce and self.args.force_reproc_new):
             log.info('%s already reduced; skipping', filename)           # blackbox.py:1336-1390
             return fits_out
-        d_raw = torch.from_numpy(np.ascontiguousarray(raw)).to(self.ctx.device)
+        if d_raw is None:
+            d_raw = torch.from_numpy(np.ascontiguousarray(raw)).to(self.ctx.device)
         exptime = R.hval(header, 'EXPTIME') if 'EXPTIME' in header else 1.0
         imgtype = str(R.hval(header, 'IMAGETYP')).lower() if 'IMAGETYP' in header else 'object'
         if imgtype == 'flat':

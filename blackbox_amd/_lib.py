@@ -55,6 +55,7 @@ SIGNATURES = {
     'bbx_fpack_tile_stride': (C.c_size_t, [_i, _i]),
     'bbx_fpack_tiles': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_fpack_gather': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_funpack_tiles': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     'bbx_psf_model': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'bbx_rect_scale': (_i, [_vp, _i, _i, _i, _vp, _f, _i, _vp]),
     'bbx_nonlin_set': (_i, [_vp, _i, C.POINTER(C.c_int32), _pd, _pd]),

@@ -345,3 +345,106 @@ extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const 
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// funpack: Rice decode of row tiles (+ un-quantisation of float images).  The codes of a
+// tile are sequential (unary prefixes), so one thread walks one tile; the ~10^4 tiles of a
+// frame run side by side.  Decoded values are staged per 32-pixel block in registers and
+// written as whole blocks.
+// ---------------------------------------------------------------------------------
+struct bitreader {
+    const uint8_t* p;
+    unsigned long long buf;      // left-aligned bit buffer
+    int nbits;
+    __device__ __forceinline__ void init(const uint8_t* q) { p = q; buf = 0; nbits = 0; }
+    __device__ __forceinline__ void fill() {
+        while (nbits <= 56) { buf |= (unsigned long long)(*p++) << (56 - nbits); nbits += 8; }
+    }
+    __device__ __forceinline__ unsigned get(int n) {           // n <= 32
+        if (n == 0) return 0u;
+        if (nbits < n) fill();
+        const unsigned v = (unsigned)(buf >> (64 - n));
+        buf <<= n; nbits -= n;
+        return v;
+    }
+    __device__ __forceinline__ unsigned unary() {              // number of zeros before the next one
+        unsigned z = 0;
+        for (;;) {
+            if (nbits == 0) fill();
+            if (buf == 0) { z += nbits; nbits = 0; continue; }
+            const int lz = __clzll((long long)buf);
+            if (lz < nbits) { z += lz; buf <<= (lz + 1); nbits -= lz + 1; return z; }
+            z += nbits; buf = 0; nbits = 0;
+        }
+    }
+};
+
+// desc: per row {int32 len, int32 off} (host order), heap: compressed bytes (padded with 8 readable bytes).
+// out_kind: 0 = uint8, 1 = int16 -> uint16 with +32768 (BZERO), 2 = int16, 3 = int32, 4 = float32 (dequantised)
+template <int BYTEPIX>
+__global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, const uint8_t* __restrict__ heap, int ny, int nx,
+                                                int out_kind, void* __restrict__ out, const double* __restrict__ zscale,
+                                                const double* __restrict__ zzero, int dither_seed,
+                                                const float* __restrict__ rnd, int* __restrict__ err) {
+    typedef rice_par<BYTEPIX> RP;
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= ny) return;
+    const int len = desc[2 * row], off = desc[2 * row + 1];
+    if (len <= 0) return;                                       // stored another way (gzip column): done on the host
+    bitreader br; br.init(heap + off);
+    const uint8_t* end = heap + off + len;
+    int last = (int)br.get(8 * BYTEPIX);
+    if (BYTEPIX == 1) last = (int)(signed char)last;
+    if (BYTEPIX == 2) last = (int)(short)last;
+    double zs = 0., zz = 0.;
+    int iseed = 0, nextrand = 0;
+    if (out_kind == 4) {
+        zs = zscale[row]; zz = zzero[row];
+        iseed = (row + dither_seed - 1) % FP_NRANDOM;
+        nextrand = (int)((double)rnd[iseed] * 500.);
+    }
+    for (int i = 0; i < nx; i += 32) {
+        const int fs = (int)br.get(RP::fsbits) - 1;
+        const int n = min(32, nx - i);
+        for (int j = 0; j < n; j++) {
+            unsigned d;
+            if (fs < 0) d = 0;
+            else if (fs == RP::fsmax) d = br.get(RP::bbits);
+            else { const unsigned top = br.unary(); d = (top << fs) | br.get(fs); }
+            int pd = (int)(d >> 1) ^ -(int)(d & 1u);
+            last += pd;
+            if (BYTEPIX == 1) last = (int)(signed char)last;
+            if (BYTEPIX == 2) last = (int)(short)last;
+            const size_t o = (size_t)row * nx + i + j;
+            if (out_kind == 0) ((uint8_t*)out)[o] = (uint8_t)last;
+            else if (out_kind == 1) ((uint16_t*)out)[o] = (uint16_t)(last + 32768);
+            else if (out_kind == 2) ((short*)out)[o] = (short)last;
+            else if (out_kind == 3) ((int*)out)[o] = last;
+            else {
+                ((float*)out)[o] = (float)(((double)last - (double)rnd[nextrand] + 0.5) * zs + zz);
+                if (++nextrand == FP_NRANDOM) {
+                    iseed = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
+                    nextrand = (int)((double)rnd[iseed] * 500.);
+                }
+            }
+        }
+        if (br.p > end + 8) { atomicOr(err, 1); return; }        // ran past the tile: corrupt stream
+    }
+}
+
+extern "C" int bbx_funpack_tiles(bbx_ctx* ctx, int ny, int nx, int bytepix, const int* d_desc, const uint8_t* d_heap,
+                                 int out_kind, void* d_out, const double* d_zscale, const double* d_zzero, int dither_seed,
+                                 const float* d_rnd, void* stream) {
+    if (!ctx || !d_desc || !d_heap || !d_out || ny < 1 || nx < 1 || out_kind < 0 || out_kind > 4) return BBX_ERR_ARG;
+    if (out_kind == 4 && (!d_zscale || !d_zzero || !d_rnd || bytepix != 4 || dither_seed < 1 || dither_seed > 10000)) return BBX_ERR_ARG;
+    if ((out_kind == 0 && bytepix != 1) || ((out_kind == 1 || out_kind == 2) && bytepix != 2) || (out_kind == 3 && bytepix != 4))
+        return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((ny + 63) / 64);
+    if (bytepix == 1) hipLaunchKernelGGL(k_funpack<1>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    else if (bytepix == 2) hipLaunchKernelGGL(k_funpack<2>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    else if (bytepix == 4) hipLaunchKernelGGL(k_funpack<4>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    else return BBX_ERR_ARG;
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}

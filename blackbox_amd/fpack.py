@@ -55,6 +55,8 @@ def compress_tiles(ctx, img, qlevel=16, dither_seed=1, _view=False):
     flag, zscale, zzero; offsets numpy int64 [ny])"""
     if img.dim() != 2 or not img.is_contiguous():
         raise ValueError('contiguous 2-D image expected')
+    if img.dtype == torch.uint16:                       # FITS stores uint16 as int16 with BZERO = 32768
+        img = (img.to(torch.int32) - 32768).to(torch.int16)
     bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32}[img.dtype]
     bytepix = 4 if bitpix == -32 else bitpix // 8
     ny, nx = img.shape
@@ -100,7 +102,7 @@ def compress_tiles(ctx, img, qlevel=16, dither_seed=1, _view=False):
 
 
 def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=None, header=None, qlevel=16,
-                dither_seed=1, gz_nbytes=None, gz_offsets=None):
+                dither_seed=1, gz_nbytes=None, gz_offsets=None, bzero=None):
     """write primary HDU + COMPRESSED_IMAGE binary table (FITS 4.0 section 10) around tile
     streams that are already compressed"""
     ny, nx = shape
@@ -133,6 +135,8 @@ def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=N
     if quant:
         cards += [fitsio._card('ZQUANTIZ', 'SUBTRACTIVE_DITHER_1', 'Pixel Quantization Algorithm'),
                   fitsio._card('ZDITHER0', int(dither_seed), 'dithering offset when quantizing floats')]
+    if bzero:
+        cards += [fitsio._card('BSCALE', 1, ''), fitsio._card('BZERO', int(bzero), 'offset data range to that of unsigned short')]
     cards.append(fitsio._card('EXTNAME', 'COMPRESSED_IMAGE', 'name of this binary table extension'))
     skip = {'SIMPLE', 'BITPIX', 'NAXIS', 'EXTEND', 'BZERO', 'BSCALE', 'END', 'XTENSION', 'PCOUNT', 'GCOUNT', 'TFIELDS', 'EXTNAME'}
     for k, v in (header or {}).items():
@@ -173,6 +177,106 @@ def fpack_image(ctx, path, img, header=None, quant=None, dither_seed=1):
         quant = 2 if ('Scorr' in path or 'limmag' in path) else (4 if 'Fpsf' in path else 16)
     out = path if path.endswith('.fz') else path + '.fz'
     c = compress_tiles(ctx, img, quant, dither_seed, _view=True)
-    bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32}[img.dtype]
+    bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32, torch.uint16: 16}[img.dtype]
     return assemble_fz(out, tuple(img.shape), bitpix, c['heap'], c['nbytes'], c['offsets'], c['zscale'], c['zzero'], header,
-                       quant, dither_seed, c['gz_nbytes'], c['gz_offsets'])
+                       quant, dither_seed, c['gz_nbytes'], c['gz_offsets'], bzero=32768 if img.dtype == torch.uint16 else None)
+
+
+# --------------------------------------------------------------------------------
+# reading: funpack on the device
+# --------------------------------------------------------------------------------
+_TFORM_BYTES = {'L': 1, 'X': 1, 'B': 1, 'I': 2, 'J': 4, 'K': 8, 'A': 1, 'E': 4, 'D': 8, 'C': 8, 'M': 16}
+
+
+def _table_layout(h):
+    """column name -> (byte offset in the row, TFORM) of a binary table header"""
+    import re
+    hv = fitsio._hv
+    out, off = {}, 0
+    for k in range(1, int(hv(h, 'TFIELDS')) + 1):
+        form = str(hv(h, 'TFORM%d' % k)).strip()
+        name = str(hv(h, 'TTYPE%d' % k, 'COL%d' % k)).strip()
+        m = re.match(r'(\d*)([PQ]?)([A-Z])', form)
+        rep = int(m.group(1)) if m.group(1) else 1
+        if m.group(2) == 'P':
+            size = 8 * rep
+        elif m.group(2) == 'Q':
+            size = 16 * rep
+        else:
+            size = rep * _TFORM_BYTES[m.group(3)]
+        out[name] = (off, form)
+        off += size
+    return out
+
+
+def funpack_image(ctx, path, ext=None):
+    """read a tile-compressed image (what the reference gets from read_hdulist on a .fits.fz
+    file): RICE_1, tiles = whole rows, integer images (BITPIX 8/16/32; 16 with BZERO 32768 ->
+    uint16) and float images quantised with SUBTRACTIVE_DITHER_1; rows in the
+    GZIP_COMPRESSED_DATA column are inflated on the host.  -> (device tensor, header dict)"""
+    import gzip
+    hv = fitsio._hv
+    hdus = fitsio.read_hdus(path)
+    cand = [i for i, (h, d) in enumerate(hdus) if hv(h, 'ZIMAGE', False) is True] if ext is None else [ext]
+    if not cand:
+        raise ValueError('{}: no tile-compressed image extension'.format(path))
+    h, table = hdus[cand[0]]
+    heap = h.pop('__heap__', np.zeros(0, np.uint8))
+    if str(hv(h, 'ZCMPTYPE')).strip() not in ('RICE_1', 'RICE_ONE'):
+        raise ValueError('compression {} not supported (RICE_1 only)'.format(hv(h, 'ZCMPTYPE')))
+    ny, nx, zbitpix = int(hv(h, 'ZNAXIS2')), int(hv(h, 'ZNAXIS1')), int(hv(h, 'ZBITPIX'))
+    if int(hv(h, 'ZNAXIS')) != 2 or int(hv(h, 'ZTILE1', nx)) != nx or int(hv(h, 'ZTILE2', 1)) != 1:
+        raise ValueError('only 2-D images tiled by rows are supported')
+    zpar = {str(hv(h, 'ZNAME%d' % k)).strip(): hv(h, 'ZVAL%d' % k) for k in range(1, 5) if ('ZNAME%d' % k) in h}
+    if int(zpar.get('BLOCKSIZE', 32)) != 32:
+        raise ValueError('Rice block size {} not supported'.format(zpar.get('BLOCKSIZE')))
+    bytepix = int(zpar.get('BYTEPIX', 4))
+    lay = _table_layout(h)
+    if 'COMPRESSED_DATA' not in lay or lay['COMPRESSED_DATA'][1][1] != 'P':
+        raise ValueError('COMPRESSED_DATA column with 32-bit descriptors expected')
+    tb = np.ascontiguousarray(table).reshape(ny, -1)
+    o = lay['COMPRESSED_DATA'][0]
+    desc = np.ascontiguousarray(tb[:, o:o + 8]).view('>i4').astype(np.int32)
+    dev = ctx.device
+    quant = zbitpix == -32
+    bzero = hv(h, 'BZERO', 0)
+    if quant:
+        if str(hv(h, 'ZQUANTIZ', '')).strip() != 'SUBTRACTIVE_DITHER_1':
+            raise ValueError('quantisation method {} not supported'.format(hv(h, 'ZQUANTIZ')))
+        zs = np.ascontiguousarray(tb[:, lay['ZSCALE'][0]:lay['ZSCALE'][0] + 8]).view('>f8').astype(np.float64).reshape(-1)
+        zz = np.ascontiguousarray(tb[:, lay['ZZERO'][0]:lay['ZZERO'][0] + 8]).view('>f8').astype(np.float64).reshape(-1)
+        out = torch.empty((ny, nx), dtype=torch.float32, device=dev)
+        kind, seed = 4, int(hv(h, 'ZDITHER0'))
+        d_zs, d_zz, rnd = torch.from_numpy(zs).to(dev), torch.from_numpy(zz).to(dev), _rnd(dev)
+    else:
+        if zbitpix == 8:
+            out, kind = torch.empty((ny, nx), dtype=torch.uint8, device=dev), 0
+        elif zbitpix == 16 and bzero == 32768:
+            out, kind = torch.empty((ny, nx), dtype=torch.uint16, device=dev), 1
+        elif zbitpix == 16:
+            out, kind = torch.empty((ny, nx), dtype=torch.int16, device=dev), 2
+        elif zbitpix == 32:
+            out, kind = torch.empty((ny, nx), dtype=torch.int32, device=dev), 3
+        else:
+            raise ValueError('ZBITPIX {} not supported'.format(zbitpix))
+        if bytepix != abs(zbitpix) // 8:
+            raise ValueError('BYTEPIX {} with ZBITPIX {} not supported'.format(bytepix, zbitpix))
+        seed, d_zs, d_zz, rnd = 0, None, None, None
+    if (desc < 0).any() or int((desc[:, 0].astype(np.int64) + desc[:, 1]).max(initial=0)) > heap.size:
+        raise ValueError('tile descriptors point outside the heap')
+    d_heap = torch.from_numpy(np.concatenate([heap, np.zeros(16, np.uint8)])).to(dev)
+    d_desc = torch.from_numpy(desc.reshape(-1).copy()).to(dev)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    check(lib.bbx_funpack_tiles(ctx.h, ny, nx, bytepix, vp(d_desc), vp(d_heap), kind, vp(out), vp(d_zs), vp(d_zz), seed,
+                                vp(rnd), ctx.stream()), 'bbx_funpack_tiles', ctx.h)
+    if quant and 'GZIP_COMPRESSED_DATA' in lay:
+        og = lay['GZIP_COMPRESSED_DATA'][0]
+        gd = np.ascontiguousarray(tb[:, og:og + 8]).view('>i4')
+        for r in np.nonzero((desc[:, 0] == 0) & (gd[:, 0] > 0))[0]:
+            raw = gzip.decompress(heap[gd[r, 1]:gd[r, 1] + gd[r, 0]].tobytes())
+            out[r] = torch.from_numpy(np.frombuffer(raw, '>f4').astype(np.float32)).to(dev)
+    ctx.sync()
+    skip = ('ZIMAGE', 'ZCMPTYPE', 'ZBITPIX', 'ZNAXIS', 'ZTILE', 'ZNAME', 'ZVAL', 'ZQUANTIZ', 'ZDITHER0', 'ZTENSION', 'ZPCOUNT',
+            'ZGCOUNT', 'TTYPE', 'TFORM', 'TFIELDS', 'XTENSION', 'PCOUNT', 'GCOUNT', 'NAXIS', 'BITPIX', 'EXTNAME')
+    header = {k: v for k, v in h.items() if not any(k.startswith(p) for p in skip)}
+    return out, header

@@ -186,6 +186,17 @@ int bbx_fpack_gather(bbx_ctx *ctx, int ny, int nx, int bitpix, const uint8_t *d_
                      const void *d_tiles, const long long *d_offsets, uint8_t *d_heap,
                      void *stream);
 
+/* ---- a1 / f2: funpack -- reading tile-compressed images (raw frames arrive as .fits.fz;
+ * read_hdulist, blackbox.py:1451) -------------------------------------------------------
+ * Rice decode of row tiles: d_desc [ny][2] int32 = (length, heap offset) of each row's
+ * stream, d_heap = the table heap (+ 16 readable bytes of padding).  out_kind: 0 uint8,
+ * 1 uint16 = int16 + 32768 (BZERO), 2 int16, 3 int32, 4 float32 = SUBTRACTIVE_DITHER_1
+ * un-quantisation ((q - r + 0.5) * ZSCALE + ZZERO).  Rows with length 0 are left untouched
+ * (losslessly stored rows are filled in by the host).                                     */
+int bbx_funpack_tiles(bbx_ctx *ctx, int ny, int nx, int bytepix, const int *d_desc,
+                      const uint8_t *d_heap, int out_kind, void *d_out, const double *d_zscale,
+                      const double *d_zzero, int dither_seed, const float *d_rnd, void *stream);
+
 /* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
  * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1
  * (sic: uncorrected pixels end up divided by 2, reproduced as written); data /= frac + 1.
