@@ -352,6 +352,9 @@ extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const 
 // frame run side by side.  Decoded values are staged per 32-pixel block in registers and
 // written as whole blocks.
 // ---------------------------------------------------------------------------------
+#ifndef FUNPACK_RPW
+#define FUNPACK_RPW 8
+#endif
 struct bitreader {
     const uint8_t* p;
     unsigned long long buf;      // left-aligned bit buffer
@@ -387,7 +390,11 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
                                                 const double* __restrict__ zzero, int dither_seed,
                                                 const float* __restrict__ rnd, int* __restrict__ err) {
     typedef rice_par<BYTEPIX> RP;
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    // FUNPACK_RPW rows per wave: the lanes of a wave follow different code paths (split levels,
+    // unary runs, refills), so fewer rows per wave means less serialisation, and a frame has
+    // only ~10^4 rows to spread over 1024 SIMDs anyway
+    if ((int)threadIdx.x >= FUNPACK_RPW) return;
+    const int row = blockIdx.x * FUNPACK_RPW + threadIdx.x;
     if (row >= ny) return;
     const int len = desc[2 * row], off = desc[2 * row + 1];
     if (len <= 0) return;                                       // stored another way (gzip column): done on the host
@@ -440,7 +447,7 @@ extern "C" int bbx_funpack_tiles(bbx_ctx* ctx, int ny, int nx, int bytepix, cons
     if ((out_kind == 0 && bytepix != 1) || ((out_kind == 1 || out_kind == 2) && bytepix != 2) || (out_kind == 3 && bytepix != 4))
         return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((ny + 63) / 64);
+    const dim3 grid((ny + FUNPACK_RPW - 1) / FUNPACK_RPW);
     if (bytepix == 1) hipLaunchKernelGGL(k_funpack<1>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
     else if (bytepix == 2) hipLaunchKernelGGL(k_funpack<2>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
     else if (bytepix == 4) hipLaunchKernelGGL(k_funpack<4>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);

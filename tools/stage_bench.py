@@ -113,6 +113,14 @@ def main():
                                         compressed_MB=heap.size / 1e6, ratio=data.numel() * 4 / heap.size,
                                         rows_stored_losslessly=int((cd['flag'] != 0).sum()))
     out['fpack_mask'] = dict(end_to_end_ms_incl_D2H=1e3 * (t3 - t2), compressed_MB=hm.size / 1e6, ratio=mask.numel() / hm.size)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        pz = P.fpack_image(ctx, os.path.join(td, 'raw.fits'), raw)
+        P.funpack_image(ctx, pz)
+        t0 = time.perf_counter(); back, _ = P.funpack_image(ctx, pz); ctx.sync(); t1 = time.perf_counter()
+        assert torch.equal(back, raw)
+        out['funpack_raw_u16_frame'] = dict(end_to_end_ms_incl_file_read_H2D=1e3 * (t1 - t0), file_MB=os.path.getsize(pz) / 1e6,
+                                            raw_MB=raw.numel() * 2 / 1e6)
     print(json.dumps(out, indent=1))
 
 
