@@ -247,11 +247,11 @@ def main():
     if rank == 0:
         b_raw = 2 if args.raw == 'u16' else 4
         # algorithmic bytes per launch: calibration reads the raw data sections, flat,
-        # BPM and writes data + mask; one LA-Cosmic dense pass reads the frame once (+ the mask
-        # in the first pass, which also feeds the background-level select)
+        # BPM and writes data + mask; the dense LA-Cosmic pass reads the frame and the mask once
+        # (iterations 2..n work on the surroundings of the cleaned pixels only)
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
-            'k_lac_cand': (1, 4 * N + N / 3.0),
+            'k_lac_cand': (1, 4 * N + N),        # the one dense LA-Cosmic pass: data + mask (it also feeds the background select)
         }
         # Kernel durations: HIP events recorded by the library around each launch, on the launch
         # stream.  With two stage-C lanes an event pair in the timed region also spans the time the
@@ -262,7 +262,7 @@ def main():
         # figures are given beside them.
         per = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items()}
         live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items()}
-        frame_ms = {k: per[k][0] * (3 if k == 'k_lac_cand' else 1) for k in kern}
+        frame_ms = {k: per[k][0] for k in kern}          # both run once per frame
         dom = max(frame_ms, key=frame_ms.get)
         avg_ms, by, ncall = per[dom]
         roof = dict(bound='hbm', kernel=dom, achieved=by / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
@@ -282,8 +282,7 @@ def main():
                 if dom == 'k_calibrate':
                     roof['traffic'] = next(v for k, v in pmc.items() if k.startswith('k_calibrate_v4'))['traffic_bytes_per_launch']
                 else:
-                    roof['traffic'] = (pmc['k_lac_cand_v4<true>']['traffic_bytes_per_launch'] +
-                                       2 * pmc['k_lac_cand_v4<false>']['traffic_bytes_per_launch']) / 3.0
+                    roof['traffic'] = pmc['k_lac_cand_v4<true>']['traffic_bytes_per_launch']
                 roof['traffic_source'] = 'profiles/r01_pmc_traffic.json'
         except Exception:
             pass
@@ -299,7 +298,7 @@ def main():
                                                        [1e3 * t / max(1, pipe.t_stats[3]) for t in pipe.t_stats[:3]])),
                    single_frame_latency_ms=latency_ms, stage_ms_serial=stage_ms, lacosmic_stats=stats,
                    device_ms_per_frame_serial={'k_calibrate': iso_ms[0] / max(1, iso_calls[0]),
-                                               'k_lac_cand(x3)': 3 * iso_ms[1] / max(1, iso_calls[1]),
+                                               'k_lac_cand': iso_ms[1] / max(1, iso_calls[1]),
                                                'lac_sparse(x3)': 3 * iso_ms[2] / max(1, iso_calls[2])},
                    roofline=roof)
         if not args.no_cpu:

@@ -493,6 +493,50 @@ __device__ __forceinline__ float f_wave(const float* __restrict__ a, int j, int 
 
 __device__ __forceinline__ bool good_px(const uint8_t* mask, size_t o) { return (mask[o] & ~BBX_MASK_COSMIC) == 0; }
 
+// ---- 1a'. candidates of iterations 2..n without another pass over the frame.
+// After the first iteration the image only changes at the cleaned pixels (clean_medmask
+// rewrites exactly the pixels of the cumulative CR list).  A pixel can seed in iteration k
+// only if sp or the fine-structure ratio at it changed -- both read the image within a
+// Chebyshev distance of 4 (5x5 median of s, s from a 5x5 median and a 3x3 stencil; 7x7 median
+// of the 3x3-median image) -- or if it seeded before, in which case it was cleaned itself.
+// First-growth members lie within 1 of a seed.  So every pixel that needs to be on the
+// candidate list of iteration k (L+ > T is still necessary) lies within distance 5 of a CR-list
+// pixel: test the 11x11 neighbourhoods of the list instead of the whole frame.  Duplicates
+// are dropped through a bit of the flag plane; the result is a superset of what matters and
+// a subset of the dense list, so the outcome is identical.
+#define F_QUEUED 32u
+#define SPC_CHUNK 4096
+__global__ __launch_bounds__(256) void k_lac_cand_sparse(const float* __restrict__ a, lac_par p,
+                                                         const uint32_t* __restrict__ crlist, int32_t* counters, uint32_t cap,
+                                                         uint8_t* flags, uint32_t* __restrict__ cand_raw, int32_t* err) {
+    __shared__ uint32_t q[SPC_CHUNK];
+    __shared__ unsigned qn, qbase;
+    const float T = p.rnp[1];
+    const unsigned long long total = (unsigned long long)min((uint32_t)counters[CNT_CRLIST], cap) * 121ull;
+    for (unsigned long long c0 = (unsigned long long)blockIdx.x * SPC_CHUNK; c0 < total; c0 += (unsigned long long)gridDim.x * SPC_CHUNK) {
+        if (threadIdx.x == 0) qn = 0;
+        __syncthreads();
+        const unsigned long long c1 = min(total, c0 + SPC_CHUNK);
+        for (unsigned long long k = c0 + threadIdx.x; k < c1; k += 256) {
+            const uint32_t o = crlist[k / 121ull];
+            const int e = (int)(k % 121ull);
+            const int j = (int)(o / (uint32_t)p.nx) + e / 11 - 5, i = (int)(o % (uint32_t)p.nx) + e % 11 - 5;
+            if (j >= 2 && i >= 2 && j < p.ny - 2 && i < p.nx - 2 && lplus_at(a, j, i, p.ny, p.nx) > T) {
+                const size_t r = (size_t)j * p.nx + i;
+                if (!(atomic_or_u8(flags, r, F_QUEUED) & F_QUEUED)) q[atomicAdd(&qn, 1u)] = (uint32_t)r;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) qbase = qn ? atomicAdd((unsigned*)&counters[CNT_CANDRAW], qn) : 0u;
+        __syncthreads();
+        for (unsigned k = threadIdx.x; k < qn; k += 256) {
+            const unsigned pos = qbase + k;
+            if (pos < cap) cand_raw[pos] = q[k]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- 1b. pre-filter: sp = s - medfilt5(s) <= s (s >= 0 everywhere), so only candidates with
 // s > sigclip (and no mask bit) can seed or join the first growth.  With the true local
 // noise instead of the read noise alone this drops ~80 % of the L+ > T list before the
@@ -647,13 +691,13 @@ __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __re
     }
 }
 
-// the flag plane is only ever written at listed pixels (candidates; 3x3 around stage-2
+// the flag plane is only ever written at listed pixels (raw candidates; 3x3 around stage-2
 // pixels): clearing exactly those keeps it all-zero between iterations without a memset
 __global__ __launch_bounds__(256) void k_lac_unflag(lac_par p, const uint32_t* __restrict__ cand,
                                                     const uint32_t* __restrict__ stage2,
                                                     const int32_t* __restrict__ counters, uint32_t cap,
                                                     uint8_t* __restrict__ flags) {
-    const uint32_t n1 = min((uint32_t)counters[CNT_CAND], cap), n2 = min((uint32_t)counters[CNT_STAGE2], cap);
+    const uint32_t n1 = min((uint32_t)counters[CNT_CANDRAW], cap), n2 = min((uint32_t)counters[CNT_STAGE2], cap);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += stride) flags[cand[k]] = 0;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < 9u * n2; k += stride) {
@@ -747,19 +791,21 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     if (rc) return rc;
     const unsigned gdense = 256u * 16u, gsparse = 256u * 8u;
     for (int it = 0; it < niter; it++) {
-        bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
         if (it == 0) {
+            // the one dense pass: candidates of the first iteration (+ the background-level feed)
+            bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
             if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
+            bbx_prof_stop(ctx, s);
+            if (vec) {
+                const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, ((ntiles + 127) / 128 + 15) / 16 * 16));
+                hipLaunchKernelGGL(k_lac_compact, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(256), 0, s, tile_cnt, tile_seg,
+                                   (int)ntiles, tpb, ovf, (uint32_t)capovf, cnt, cand_raw, (uint32_t)cap, ctx->d_err);
+            }
         } else {
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
-            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
-        }
-        bbx_prof_stop(ctx, s);
-        if (vec) {
-            const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, ((ntiles + 127) / 128 + 15) / 16 * 16));
-            hipLaunchKernelGGL(k_lac_compact, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(256), 0, s, tile_cnt, tile_seg, (int)ntiles,
-                               tpb, ovf, (uint32_t)capovf, cnt, cand_raw, (uint32_t)cap, ctx->d_err);
+            // later iterations: only the surroundings of the pixels cleaned so far can differ
+            hipLaunchKernelGGL(k_lac_cand_sparse, dim3(512), dim3(256), 0, s, d_data, p, crlist, cnt, (uint32_t)cap, flags, cand_raw,
+                               ctx->d_err);
         }
         hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, cand);
         if (it == 0) { rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s); if (rc) return rc; }
@@ -769,7 +815,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         hipLaunchKernelGGL(k_lac_grow2, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
-        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand, stage2, cnt, (uint32_t)cap, flags);
+        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_iter_end, dim3(1), dim3(64), 0, s, cnt, d_stats, it);
         bbx_prof_stop(ctx, s);
     }
