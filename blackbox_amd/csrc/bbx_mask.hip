@@ -95,14 +95,17 @@ __global__ __launch_bounds__(256) void k_bits_erode(const u64* __restrict__ in, 
 //   through empty tiles are resolved wholesale (coarse flood, one workgroup, LDS);
 //   the remaining tiles are flooded at pixel level with word-parallel bit tricks.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_occupancy(const u64* __restrict__ bitsC, uint8_t* __restrict__ occ,
-                                                        int ny, int W, int TH) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W * TH) return;
-    const int ty = t / W, tx = t - ty * W;
+// one wave per 64 consecutive tiles of a tile row: occupancy bytes (for the byte-wise flood)
+// and the row's free-tile bit word (for the run-based kernel)
+__global__ __launch_bounds__(64) void k_tile_occupancy(const u64* __restrict__ bitsC, uint8_t* __restrict__ occ,
+                                                       u64* __restrict__ freebits, int ny, int W, int TH) {
+    const int ty = blockIdx.y, k = blockIdx.x, tx = 64 * k + (int)threadIdx.x;
     u64 any = 0;
-    for (int r = ty * 64; r < ty * 64 + 64 && r < ny; r++) any |= bitsC[(size_t)r * W + tx];
-    occ[t] = any ? 1 : 0;
+    if (tx < W)
+        for (int r = ty * 64; r < ty * 64 + 64 && r < ny; r++) any |= bitsC[(size_t)r * W + tx];
+    if (tx < W) occ[ty * W + tx] = any ? 1 : 0;
+    const u64 fr = __builtin_amdgcn_ballot_w64(tx < W && any == 0);
+    if (threadIdx.x == 0) freebits[(size_t)ty * gridDim.x + k] = fr;
 }
 
 #define COARSE_MAX 49152
@@ -161,14 +164,11 @@ __global__ __launch_bounds__(1024) void k_coarse_flood(const uint8_t* __restrict
     (void)err;
 }
 
-// The same flood on bit rows, for tile grids up to CF_MAX x CF_MAX (a 10560^2 frame has
-// 165 x 165 tiles).  A tile row is CF_WORDS 64-bit words; "reached" spreads along the free
-// runs of a row in O(1) with the carry trick: for seeds X inside free runs F, (F + X) ^ F
-// marks every run from its seed up to the run's end (the carry ripples through the ones).
-// The other direction is the same on bit-reversed words.  Columns are filled the same way on
-// the transposed bit matrix, so one round costs two transposes instead of a serial walk
-// over the tiles, and the number of rounds is the number of turns of the longest free path
-// (1-3 for real frames).
+// Bit-row helpers for tile grids up to CF_MAX x CF_MAX (a 10560^2 frame has 165 x 165
+// tiles; a tile row is CF_WORDS 64-bit words).  "Reached" spreads along the free runs of a
+// row in O(1) with the carry trick: for seeds X inside free runs F, (F + X) ^ F marks every
+// run from its seed up to the run's end (the carry ripples through the ones); the other
+// direction is the same on bit-reversed words.
 #define CF_MAX 256
 #define CF_WORDS 4
 __device__ __forceinline__ bool cf_fill_row(const u64* F, u64* S, int nw) {
@@ -199,63 +199,125 @@ __device__ __forceinline__ bool cf_fill_row(const u64* F, u64* S, int nw) {
     return ch;
 }
 
-// dst[c][*] = transpose of src[r][*] (rows x cols bits); thread c builds column c
-__device__ __forceinline__ void cf_transpose(const u64 (*src)[CF_WORDS], u64 (*dst)[CF_WORDS], int rows, int cols, bool accumulate) {
-    const int c = threadIdx.x;
-    if (c < cols) {
-        const int cw = c >> 6, cb = c & 63;
-#pragma unroll
-        for (int k = 0; k < CF_WORDS; k++) {
-            u64 out = 0;
-            const int rend = min(rows, 64 * k + 64);
-#pragma unroll 8
-            for (int r = 64 * k; r < rend; r++) out |= ((src[r][cw] >> cb) & 1ull) << (r & 63);
-            dst[c][k] = accumulate ? (dst[c][k] | out) : out;
-        }
+// Connected components of the free tiles instead of a flood: the free tiles of a row form
+// runs; runs of adjacent rows that overlap are joined in a lock-free union-find in LDS, runs
+// that touch the frame border are joined to a virtual "outside" node, and a run is reached
+// iff its root is the outside's.  Constant depth whatever the shape of the free space (an
+// iterative flood needs one round per turn of the longest free path, ~10 on a real frame).  parent[] lives in dynamic LDS: (TH * (W/2 + 1) + 1) words.
+__device__ __forceinline__ unsigned cfu_find(unsigned* parent, unsigned i) {
+    unsigned p = *(volatile unsigned*)&parent[i];
+    while (p != i) {
+        const unsigned gp = *(volatile unsigned*)&parent[p];
+        if (gp != p) parent[i] = gp;                  // path halving (benign race)
+        i = p; p = gp;
+    }
+    return i;
+}
+__device__ __forceinline__ void cfu_union(unsigned* parent, unsigned a, unsigned b) {
+    for (;;) {
+        a = cfu_find(parent, a); b = cfu_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const unsigned t = a; a = b; b = t; }      // hang the larger index under the smaller
+        if (atomicCAS(&parent[a], a, b) == a) return;
     }
 }
 
-__global__ __launch_bounds__(CF_MAX) void k_coarse_flood_bits(const uint8_t* __restrict__ occ, uint8_t* __restrict__ state,
-                                                              int W, int TH, uint32_t* __restrict__ tiles, int32_t* counters) {
-    __shared__ u64 F[CF_MAX][CF_WORDS], R[CF_MAX][CF_WORDS], FT[CF_MAX][CF_WORDS], RT[CF_MAX][CF_WORDS];
-    __shared__ int changed;
+__global__ __launch_bounds__(CF_MAX) void k_coarse_cc(const u64* __restrict__ freebits, uint8_t* __restrict__ state, int W, int TH,
+                                                      uint32_t* __restrict__ tiles, int32_t* counters) {
+    extern __shared__ unsigned parent[];
+    __shared__ u64 F[CF_MAX][CF_WORDS], R[CF_MAX][CF_WORDS], ST[CF_MAX][CF_WORDS];
+    __shared__ unsigned rowbase[CF_MAX + 1];
+    __shared__ unsigned wsum[CF_MAX / 64];
     const int t = threadIdx.x;
-    const int WW = (W + 63) >> 6, WH = (TH + 63) >> 6;
-    // occupancy bytes -> free / seed bit rows: a wave reads 64 consecutive tiles of a row
-    // (coalesced) and the ballot of "free" is the bit word
+    const int WW = (W + 63) >> 6;
     const int lane = t & 63, wave = t >> 6, nwave = CF_MAX / 64;
-    for (int idx = wave; idx < TH * WW; idx += nwave) {
-        const int ty = idx / WW, k = idx - ty * WW, tx = 64 * k + lane;
-        const bool fr = tx < W && occ[ty * W + tx] == 0;
-        const u64 m = __builtin_amdgcn_ballot_w64(fr);
-        if (lane == 0) {
-            u64 edge = (ty == 0 || ty == TH - 1) ? ~0ull : 0ull;
-            if (k == 0) edge |= 1ull;
-            if (k == ((W - 1) >> 6)) edge |= 1ull << ((W - 1) & 63);
-            F[ty][k] = m; R[ty][k] = m & edge;
+    // free-tile bit rows, written by k_tile_occupancy
+    for (int idx = t; idx < TH * WW; idx += CF_MAX) {
+        const int ty = idx / WW, k = idx - ty * WW;
+        F[ty][k] = freebits[idx]; R[ty][k] = 0;
+    }
+    __syncthreads();
+    // run starts and the number of runs per row; run id = rowbase[row] + (# starts at or below the bit) - 1
+    unsigned nrun = 0;
+    if (t < TH) {
+        u64 carry = 0;
+        for (int k = 0; k < WW; k++) {
+            const u64 f = F[t][k];
+            const u64 st = f & ~((f << 1) | carry);
+            carry = f >> 63;
+            ST[t][k] = st;
+            nrun += (unsigned)__popcll(st);
+        }
+    }
+    {
+        unsigned incl = nrun;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wave; w++) base += wsum[w];
+        if (t < TH) rowbase[t] = base + incl - nrun;
+        if (t == CF_MAX - 1) rowbase[CF_MAX] = base + incl;         // total number of runs
+    }
+    __syncthreads();
+    const unsigned NR = rowbase[CF_MAX];                            // the virtual outside node
+    for (unsigned i = t; i <= NR; i += CF_MAX) parent[i] = i;
+    __syncthreads();
+    // run id of the free tile (ty, bit pos): starts at or below pos in row ty
+    auto run_of = [&](int ty, int pos) -> unsigned {
+        unsigned c = 0;
+        const int kw = pos >> 6;
+        for (int k = 0; k < kw; k++) c += (unsigned)__popcll(ST[ty][k]);
+        const u64 m = ((pos & 63) == 63) ? ~0ull : ((1ull << ((pos & 63) + 1)) - 1ull);
+        c += (unsigned)__popcll(ST[ty][kw] & m);
+        return rowbase[ty] + c - 1u;
+    };
+    // unions: (a) vertically adjacent free tiles, one union per group of consecutive common bits
+    // in a word; (b) runs holding a border tile with the outside
+    for (int idx = t; idx < TH * WW; idx += CF_MAX) {
+        const int ty = idx / WW, k = idx - ty * WW;
+        const u64 f = F[ty][k];
+        if (ty > 0) {
+            const u64 o = f & F[ty - 1][k];
+            u64 g = o & ~(o << 1);                                   // first bit of every group
+            while (g) {
+                const int b = __ffsll((long long)g) - 1;
+                g &= g - 1;
+                cfu_union(parent, run_of(ty, 64 * k + b), run_of(ty - 1, 64 * k + b));
+            }
+        }
+        u64 edge = (ty == 0 || ty == TH - 1) ? ~0ull : 0ull;
+        if (k == 0) edge |= 1ull;
+        if (k == ((W - 1) >> 6)) edge |= 1ull << ((W - 1) & 63);
+        u64 e = f & edge;
+        e &= ~(e << 1);                                              // one per group is enough
+        while (e) {
+            const int b = __ffsll((long long)e) - 1;
+            e &= e - 1;
+            cfu_union(parent, run_of(ty, 64 * k + b), NR);
         }
     }
     __syncthreads();
-    cf_transpose(F, FT, TH, W, false);
-    __syncthreads();
-    for (int iter = 0; iter < 2 * CF_MAX; iter++) {
-        if (t == 0) changed = 0;
-        __syncthreads();
-        if (t < TH && cf_fill_row(F[t], R[t], WW)) changed = 1;
-        __syncthreads();
-        cf_transpose(R, RT, TH, W, false);
-        __syncthreads();
-        if (t < W && cf_fill_row(FT[t], RT[t], WH)) changed = 1;
-        __syncthreads();
-        cf_transpose(RT, R, W, TH, true);
-        __syncthreads();
-        const int c = changed;
-        __syncthreads();
-        if (!c) break;
+    // seeds: the start tile of every run connected to the outside; the run fill spreads them
+    const unsigned root_out = cfu_find(parent, NR);
+    for (int idx = t; idx < TH * WW; idx += CF_MAX) {
+        const int ty = idx / WW, k = idx - ty * WW;
+        u64 st = ST[ty][k], seed = 0;
+        unsigned r = rowbase[ty];
+        for (int kk = 0; kk < k; kk++) r += (unsigned)__popcll(ST[ty][kk]);
+        while (st) {
+            const int b = __ffsll((long long)st) - 1;
+            st &= st - 1;
+            if (cfu_find(parent, r) == root_out) seed |= 1ull << b;
+            r++;
+        }
+        R[ty][k] = seed;
     }
-    // outputs: state per tile, and the list of unresolved tiles (this kernel is its only
-    // writer: a count pass, a 4-wave prefix, then the writes -- no atomics)
-    __shared__ unsigned wtot[CF_MAX / 64];
+    __syncthreads();
+    if (t < TH) cf_fill_row(F[t], R[t], WW);
+    __syncthreads();
+    // outputs: state per tile, and the list of unresolved tiles (count pass, wave prefix, writes)
     unsigned mycount = 0;
     for (int idx = wave; idx < TH * WW; idx += nwave) {
         const int ty = idx / WW, k = idx - ty * WW;
@@ -263,24 +325,23 @@ __global__ __launch_bounds__(CF_MAX) void k_coarse_flood_bits(const uint8_t* __r
         if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
         mycount += (unsigned)__popcll(~R[ty][k] & valid);
     }
-    if (lane == 0) wtot[wave] = mycount;
+    __syncthreads();
+    if (lane == 0) wsum[wave] = mycount;
     __syncthreads();
     unsigned base = 0, total = 0;
-    for (int w = 0; w < nwave; w++) { if (w < wave) base += wtot[w]; total += wtot[w]; }
+    for (int w = 0; w < nwave; w++) { if (w < wave) base += wsum[w]; total += wsum[w]; }
     for (int idx = wave; idx < TH * WW; idx += nwave) {
         const int ty = idx / WW, k = idx - ty * WW, tx = 64 * k + lane;
         const u64 r = R[ty][k];
+        u64 valid = ~0ull;
+        if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
+        const u64 un = ~r & valid;
         if (tx < W) {
             const bool reached = (r >> lane) & 1ull;
             state[ty * W + tx] = reached ? 1 : 0;
-            u64 valid = ~0ull;
-            if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
-            const u64 un = ~r & valid;
             if (!reached) tiles[base + (unsigned)__popcll(un & ((1ull << lane) - 1ull))] = (uint32_t)(ty * W + tx);
         }
-        u64 valid = ~0ull;
-        if (64 * k + 64 > W) valid = (1ull << (W - 64 * k)) - 1ull;
-        base += (unsigned)__popcll(~r & valid);
+        base += (unsigned)__popcll(un);
     }
     if (t == 0) counters[CNT_TILES] = (int32_t)total;
 }
@@ -608,9 +669,11 @@ int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d
     u64* bitsM = (u64*)bbx_ws(ctx, WS_BITS_M, nwords * 8, &rc); if (rc) return rc;
     u64* bitsC = (u64*)bbx_ws(ctx, WS_BITS_C, nwords * 8, &rc); if (rc) return rc;
     u64* bitsR = (u64*)bbx_ws(ctx, WS_BITS_R, nwords * 8, &rc); if (rc) return rc;
-    char* tws = (char*)bbx_ws(ctx, WS_TILES, (size_t)W * TH * (2 + sizeof(uint32_t)), &rc); if (rc) return rc;
+    const size_t o_tiles = ((size_t)2 * W * TH + 15) & ~(size_t)15, o_free = o_tiles + (size_t)W * TH * sizeof(uint32_t);
+    char* tws = (char*)bbx_ws(ctx, WS_TILES, o_free + (size_t)TH * ((W + 63) / 64) * 8 + 64, &rc); if (rc) return rc;
     uint8_t* occ = (uint8_t*)tws; uint8_t* state = occ + (size_t)W * TH;
-    uint32_t* tiles = (uint32_t*)(tws + (((size_t)2 * W * TH + 15) & ~(size_t)15));
+    uint32_t* tiles = (uint32_t*)(tws + o_tiles);
+    u64* freebits = (u64*)(tws + o_free);
     // (tiles offset may exceed the requested size by the alignment slack; bbx_ws over-allocates by 1/8 + 256)
     BBX_HIP(hipMemsetAsync(bitsM, 0, nwords * 8, s));
     BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_TILES], 0, sizeof(int32_t), s));
@@ -623,9 +686,12 @@ int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d
     const unsigned gw = (unsigned)((nwords + 255) / 256 > 4096 ? 4096 : (nwords + 255) / 256);
     hipLaunchKernelGGL(k_bits_dilate, dim3(gw), dim3(256), 0, s, bitsM, bitsR, d.ny, d.nx, W);   // R as temp
     hipLaunchKernelGGL(k_bits_erode, dim3(gw), dim3(256), 0, s, bitsR, bitsC, d.ny, d.nx, W);
-    hipLaunchKernelGGL(k_tile_occupancy, dim3((W * TH + 255) / 256), dim3(256), 0, s, bitsC, occ, d.ny, W, TH);
-    if (W <= CF_MAX && TH <= CF_MAX)
-        hipLaunchKernelGGL(k_coarse_flood_bits, dim3(1), dim3(CF_MAX), 0, s, occ, state, W, TH, tiles, ctx->d_counters);
+    hipLaunchKernelGGL(k_tile_occupancy, dim3((W + 63) / 64, TH), dim3(64), 0, s, bitsC, occ, freebits, d.ny, W, TH);
+    if (W <= CF_MAX && TH <= CF_MAX) {
+        const size_t lds = ((size_t)TH * (W / 2 + 1) + 2) * sizeof(unsigned);
+        BBX_HIP(hipFuncSetAttribute((const void*)k_coarse_cc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_coarse_cc, dim3(1), dim3(CF_MAX), lds, s, freebits, state, W, TH, tiles, ctx->d_counters);
+    }
     else
         hipLaunchKernelGGL(k_coarse_flood, dim3(1), dim3(1024), 0, s, occ, state, W, TH, tiles, ctx->d_counters, ctx->d_err);
     hipLaunchKernelGGL(k_reach_init, dim3(gw), dim3(256), 0, s, bitsR, state, d.ny, d.nx, W);
