@@ -77,6 +77,82 @@ __global__ __launch_bounds__(256) void k_vos_rowstats(const void* __restrict__ r
     if (lane == 0) mean_out[row_id] = s / (double)cnt;            // 0/0 -> NaN like nanmean of all-NaN
 }
 
+// The same statistics with 16 lanes per row (4 rows per wave): the strip is 180 columns wide,
+// so a 64-lane row leaves most lanes idle, and sums inside a 16-lane DPP row need no
+// cross-row step.
+#define VOS_V16 4       // 4 * VOS_V16 values per lane -> strips up to 256 columns wide
+__device__ __forceinline__ double row16_sum_f64(double v) {
+    v += dpp_mov_f64<BBX_DPP_ROR(1)>(v);
+    v += dpp_mov_f64<BBX_DPP_ROR(2)>(v);
+    v += dpp_mov_f64<BBX_DPP_ROR(4)>(v);
+    v += dpp_mov_f64<BBX_DPP_ROR(8)>(v);
+    return v;
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+    v += dpp_mov_i32<BBX_DPP_ROR(1)>(v);
+    v += dpp_mov_i32<BBX_DPP_ROR(2)>(v);
+    v += dpp_mov_i32<BBX_DPP_ROR(4)>(v);
+    v += dpp_mov_i32<BBX_DPP_ROR(8)>(v);
+    return v;
+}
+
+template <int RAW_T>
+__global__ __launch_bounds__(256) void k_vos_rowstats16(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
+                                                        double* __restrict__ mean_out) {
+    const int l16 = threadIdx.x & 15;
+    const int row_id = (blockIdx.x * 256 + threadIdx.x) >> 4;           // 0 .. 16*dy-1 (+ padding rows)
+    const bool live = row_id < 16 * d.dy;
+    const int rid = live ? row_id : 0;
+    const int c = rid / d.dy, r = rid - c * d.dy;
+    const int iy = c >> 3, ix = c & 7;
+    const size_t base = (size_t)(iy * d.dy + r) * d.nx_raw + (size_t)ix * d.dx + d.vos_x0;
+    const float g = gain.v[c];
+    double v[4 * VOS_V16];
+    unsigned valid = 0;                       // bit per value: finite and != mask_value(0)
+#pragma unroll
+    for (int k = 0; k < 4 * VOS_V16; k++) {
+        const int col = l16 + 16 * k;
+        float x = 0.f;
+        if (col < d.vos_w) x = raw_load<RAW_T>(raw, base + col);
+        if (RAW_T == BBX_RAW_F32 && !isfinite(x)) x = 0.f;             // scrub, blackbox.py:1461-1468
+        x = x * g;                                                     // gain_corr, float32 multiply
+        v[k] = (double)x;
+        if (col < d.vos_w && isfinite(x) && !(fabs((double)x) <= 1e-8)) valid |= 1u << k;
+    }
+    unsigned ok = valid;                                               // still inside the running clip
+    double lo = __longlong_as_double(0x7ff8000000000000LL), hi = lo;   // NaN until computed
+    int n = row16_sum_i32(__popc(ok));
+    bool run = n > 0;
+    for (int it = 0; it < 5; it++) {                                   // rows that are done keep their state
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4 * VOS_V16; k++) if (ok & (1u << k)) s += v[k];
+        s = row16_sum_f64(s);
+        const double mean = s / (double)n;
+        double q2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4 * VOS_V16; k++) if (ok & (1u << k)) { const double t = mean - v[k]; q2 += t * t; }
+        q2 = row16_sum_f64(q2);
+        const double sd = sqrt(q2 / (double)n);
+        const double nlo = mean - 3.0 * sd, nhi = mean + 3.0 * sd;
+        unsigned nok = 0;
+#pragma unroll
+        for (int k = 0; k < 4 * VOS_V16; k++) if ((ok & (1u << k)) && v[k] >= nlo && v[k] <= nhi) nok |= 1u << k;
+        const int m = row16_sum_i32(__popc(nok));
+        if (run) { lo = nlo; hi = nhi; ok = nok; }
+        if (run && m == n) run = false;
+        if (run) { n = m; if (n == 0) run = false; }
+    }
+    // final: every valid value inside the last bounds (NaN bounds reject nothing -- only
+    // reachable with n == 0, where the mean is NaN anyway)
+    double s = 0.0; int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4 * VOS_V16; k++)
+        if ((valid & (1u << k)) && !(v[k] < lo) && !(v[k] > hi)) { s += v[k]; cnt++; }
+    s = row16_sum_f64(s); cnt = row16_sum_i32(cnt);
+    if (live && l16 == 0) mean_out[row_id] = s / (double)cnt;         // 0/0 -> NaN like nanmean of all-NaN
+}
+
 // gain-corrected copy of the horizontal overscan rows (os_sec_hori), all dx columns
 template <int RAW_T>
 __global__ __launch_bounds__(256) void k_hos_copy(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
@@ -275,11 +351,16 @@ int bbx_overscan_stats(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int r
     const int rows = 16 * d.dy;
     dim3 grid((rows + 3) / 4), block(256);
     BBX_HIP(hipMemsetAsync(d_n_infnan, 0, sizeof(int64_t), s));
+    // 16-lane variant for strips up to 256 columns
+    const bool v16 = d.vos_w <= 64 * VOS_V16;
+    const dim3 grid16((rows + 15) / 16);
     if (raw_type == BBX_RAW_U16) {
-        hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_U16>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        if (v16) hipLaunchKernelGGL(k_vos_rowstats16<BBX_RAW_U16>, grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        else hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_U16>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
         hipLaunchKernelGGL(k_hos_copy<BBX_RAW_U16>, dim3(256), block, 0, s, d_raw, d, gain, d_hos);
     } else if (raw_type == BBX_RAW_F32) {
-        hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_F32>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        if (v16) hipLaunchKernelGGL(k_vos_rowstats16<BBX_RAW_F32>, grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        else hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_F32>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
         hipLaunchKernelGGL(k_hos_copy<BBX_RAW_F32>, dim3(256), block, 0, s, d_raw, d, gain, d_hos);
         hipLaunchKernelGGL(k_count_nonfinite, dim3(2048), block, 0, s, (const float*)d_raw,
                            (size_t)d.ny_raw * d.nx_raw, (unsigned long long*)d_n_infnan);
