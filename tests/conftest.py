@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # the ABI / host tests load the in-tree libraries: build them once if a fresh checkout has
+    # none yet (hipcc cross-compiles gfx950 without a GPU); a GPU box gets them with the snapshot
+    lib = os.path.join(ROOT, 'blackbox_amd', 'libbbx_hip.so')
+    if not os.path.isfile(lib) and os.path.isfile(os.path.join(ROOT, 'Makefile')):
+        import subprocess
+        subprocess.run(['make', '-C', ROOT, '-j8', 'all'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
 
 
 @pytest.fixture(scope='session')
