@@ -80,6 +80,7 @@ enum {
     CNT_TMP = 144,
     CNT_CANDOVF = 160,    // LA-Cosmic candidates that did not fit their tile segment
     CNT_CANDRAW = 176,    // LA-Cosmic candidates before the s > sigclip pre-filter
+    CNT_TICKET = 192,     // workgroups of the current kernel that have finished (last one does the epilogue)
     CNT_MAX = 256
 };
 

@@ -694,9 +694,8 @@ __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __re
 // the flag plane is only ever written at listed pixels (raw candidates; 3x3 around stage-2
 // pixels): clearing exactly those keeps it all-zero between iterations without a memset
 __global__ __launch_bounds__(256) void k_lac_unflag(lac_par p, const uint32_t* __restrict__ cand,
-                                                    const uint32_t* __restrict__ stage2,
-                                                    const int32_t* __restrict__ counters, uint32_t cap,
-                                                    uint8_t* __restrict__ flags) {
+                                                    const uint32_t* __restrict__ stage2, int32_t* counters, uint32_t cap,
+                                                    uint8_t* __restrict__ flags, int32_t* __restrict__ stats, int it) {
     const uint32_t n1 = min((uint32_t)counters[CNT_CANDRAW], cap), n2 = min((uint32_t)counters[CNT_STAGE2], cap);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += stride) flags[cand[k]] = 0;
@@ -705,33 +704,30 @@ __global__ __launch_bounds__(256) void k_lac_unflag(lac_par p, const uint32_t* _
         const int e = (int)(k % 9u);
         flags[(size_t)o + (size_t)((e / 3 - 1) * p.nx) + (e % 3 - 1)] = 0;
     }
-}
-
-__global__ void k_lac_iter_end(int32_t* counters, int32_t* stats, int it) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // end of the iteration: the workgroup that finishes last (every other one has read the
+    // counters by then) records the statistics and resets the per-iteration counters
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&counters[CNT_TICKET], 1) == (int)gridDim.x - 1) {
         stats[it] = counters[CNT_NEWCR];
         stats[7] = counters[CNT_CRLIST];
         if (it < 4) { stats[8 + 2 * it] = counters[CNT_CAND]; stats[9 + 2 * it] = counters[CNT_STAGE2]; }
         counters[CNT_NEWCR] = 0; counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CANDOVF] = 0;
-        counters[CNT_CANDRAW] = 0;
+        counters[CNT_CANDRAW] = 0; counters[CNT_TICKET] = 0;
     }
 }
 
-__global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt_pad) {
+// start of a frame: counters and statistics to zero, and readnoise -> {rn2, T, rn} on the
+// device.  With d_rdn16 the read noise is the float32 image of np.nanmean of the 16 channel
+// sigmas (header RDNOISE, blackbox.py:6867) evaluated in numpy's pairwise order for 16
+// elements, so no host round trip is needed between os_corr and here.
+__global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt_pad, float readnoise,
+                            const double* __restrict__ rdn16, float sigclip, float* out) {
     const int t = threadIdx.x;
     if (t < 16) stats[t] = 0;
     if (t < 16 && tile_cnt_pad) tile_cnt_pad[t] = 0;         // k_lac_compact reads the counts sixteen at a time
-    if (t == 0) {
-        counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0;
-        counters[CNT_CANDOVF] = 0; counters[CNT_CANDRAW] = 0;
-    }
-}
-
-// readnoise -> {rn2, T} on the device.  With d_rdn16 the read noise is the float32 image of
-// np.nanmean of the 16 channel sigmas (header RDNOISE, blackbox.py:6867) evaluated in numpy's
-// pairwise order for 16 elements, so no host round trip is needed between os_corr and here.
-__global__ void k_lac_rn(float readnoise, const double* __restrict__ rdn16, float sigclip, float* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (t != 0) return;
+    counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0;
+    counters[CNT_CANDOVF] = 0; counters[CNT_CANDRAW] = 0; counters[CNT_TICKET] = 0;
     float rn = readnoise;
     if (rdn16) {
         double r[8]; int n = 0;
@@ -763,7 +759,6 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     p.ny = ny; p.nx = nx; p.sigclip = sigclip; p.sigcliplow = sigfrac * sigclip; p.objlim = objlim;
     float* rnp = (float*)bbx_ws(ctx, WS_MISC, 64, &rc); if (rc) return rc;
     p.rnp = rnp;
-    hipLaunchKernelGGL(k_lac_rn, dim3(1), dim3(64), 0, s, readnoise, d_rdn16, sigclip, rnp);
     const size_t cap = (npix / 4 + 4096) & ~(size_t)63;
     const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
     const int nwx = (nx + CAND_SPAN - 1) / CAND_SPAN;             // waves along x
@@ -780,7 +775,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     uint32_t* crlist = (uint32_t*)bbx_ws(ctx, WS_CRLIST, cap * 4, &rc); if (rc) return rc;
     uint8_t* flags = (uint8_t*)bbx_ws(ctx, WS_FLAGS, npix + 16, &rc); if (rc) return rc;
     int32_t* cnt = ctx->d_counters;
-    hipLaunchKernelGGL(k_lac_begin, dim3(1), dim3(64), 0, s, cnt, d_stats, tile_cnt + ntiles);
+    hipLaunchKernelGGL(k_lac_begin, dim3(1), dim3(64), 0, s, cnt, d_stats, tile_cnt + ntiles, readnoise, d_rdn16, sigclip, rnp);
     // the flag plane is kept all-zero between calls (k_lac_unflag); zero it when it is new
     if (ctx->flags_clean_ptr != flags || ctx->flags_clean_bytes < npix) BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
     ctx->flags_clean_ptr = nullptr;
@@ -815,8 +810,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         hipLaunchKernelGGL(k_lac_grow2, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
-        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags);
-        hipLaunchKernelGGL(k_lac_iter_end, dim3(1), dim3(64), 0, s, cnt, d_stats, it);
+        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
         bbx_prof_stop(ctx, s);
     }
     ctx->flags_clean_ptr = flags; ctx->flags_clean_bytes = npix;
