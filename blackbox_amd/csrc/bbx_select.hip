@@ -10,6 +10,7 @@
 // on that buffer.  Slow path (exact fallback, taken only when a rank falls outside its
 // bracket) = the same radix select over the whole frame.  Keys are the order-preserving
 // uint32 image of float32.
+#include <algorithm>
 #include "bbx_bsel.h"
 
 #define SEL_BINS 2048
@@ -96,8 +97,11 @@ __device__ void wg_select2(const float* __restrict__ v, uint32_t count, unsigned
 // ---------------------------------------------------------------------------------
 // bracketed select: sample, bracket
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bsel_init(bsel_seg* seg, bsel_shard* shard, int nseg) {
+__global__ __launch_bounds__(256) void k_bsel_init(bsel_seg* seg, bsel_shard* shard, int nseg, uint32_t* hist, int nhist,
+                                                   int* anyfail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = i; k < nhist; k += gridDim.x * blockDim.x) hist[k] = 0;
+    if (i == 0) *anyfail = 0;
     if (i < nseg * BSEL_NSH) { bsel_shard z; memset(&z, 0, sizeof(z)); shard[i] = z; }
     if (i < nseg) {
         bsel_seg s;
@@ -169,6 +173,7 @@ struct sel_args {
     uint32_t* hist;                           // hist[seg][2][SEL_BINS]
     uint32_t* klo;                            // klo[seg]
     int* nbits;                               // B[seg]
+    int* anyfail;                             // != 0: some segment needs the exact select over the frame
 };
 
 // digit of pass p for a segment with B significant bits: false when the pass is not needed
@@ -212,6 +217,7 @@ __global__ void k_sel_plan(sel_args a, int nseg) {
         B = range ? 32 - __clz(range) : 1;
     }
     a.klo[sg] = klo; a.nbits[sg] = B;
+    if (s->fail) atomicOr(a.anyfail, 1);
 }
 
 __device__ __forceinline__ void sel_hist_one(uint32_t* lh0, uint32_t* lh1, uint32_t key, bool in, uint32_t pre0, uint32_t pre1,
@@ -228,63 +234,66 @@ __device__ __forceinline__ void sel_hist_one(uint32_t* lh0, uint32_t* lh1, uint3
     }
 }
 
-// histogram of one key digit over the side buffers (segments that did not fail)
-__global__ __launch_bounds__(256) void k_sel_hist_buf(sel_args a) {
+// histogram of one key digit.  Workgroups [0, bufblocks * nseg): the side buffers of the
+// segments that did not fail (bufblocks = BSEL_NSH * bps: bps workgroups share one shard's
+// region).  The remaining workgroups: the exact path over the frame for segments flagged
+// `fail` -- they return at once when no segment is (the usual case).
+__global__ __launch_bounds__(256) void k_sel_hist(sel_args a, int nseg, int bufblocks, int ny) {
     __shared__ uint32_t lh[2][SEL_BINS];
-    const int sg = blockIdx.y;
-    const bsel_seg* s = &a.b.seg[sg];
-    if (s->fail) return;
-    sel_digit d;
-    if (!sel_digit_of(a.nbits[sg], a.pass, &d)) return;
-    // gridDim.x = BSEL_NSH * bps blocks: bps blocks share one shard's region
-    const int bps = gridDim.x / BSEL_NSH, sh = blockIdx.x / bps;
-    const uint32_t count = min(a.b.shard[sg * BSEL_NSH + sh].nbuf, a.b.capS);
-    const uint32_t per = (count + bps - 1) / bps;
-    const uint32_t i0 = (blockIdx.x % bps) * per, i1 = min(count, i0 + per);
-    if (i0 >= i1) return;
-    const int nb2 = 2 << d.bits;
-    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1], klo = a.klo[sg];
-    const float* v = bsel_region(a.b, sg, sh);
-    const uint32_t span = ((i1 - i0 + 63u) / 64u) * 64u;
-    for (uint32_t k = threadIdx.x; k < span; k += blockDim.x) {
-        const bool in = i0 + k < i1;
-        const uint32_t key = in ? f2key(v[i0 + k]) - klo : 0u;
-        sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
+    const int nbuf = bufblocks * nseg;
+    if ((int)blockIdx.x < nbuf) {
+        const int sg = blockIdx.x / bufblocks, bx = blockIdx.x - sg * bufblocks;
+        const bsel_seg* s = &a.b.seg[sg];
+        if (s->fail) return;
+        sel_digit d;
+        if (!sel_digit_of(a.nbits[sg], a.pass, &d)) return;
+        const int bps = bufblocks / BSEL_NSH, sh = bx / bps;
+        const uint32_t count = min(a.b.shard[sg * BSEL_NSH + sh].nbuf, a.b.capS);
+        const uint32_t per = (count + bps - 1) / bps;
+        const uint32_t i0 = (bx % bps) * per, i1 = min(count, i0 + per);
+        if (i0 >= i1) return;
+        for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1], klo = a.klo[sg];
+        const float* v = bsel_region(a.b, sg, sh);
+        const uint32_t span = ((i1 - i0 + 63u) / 64u) * 64u;
+        for (uint32_t k = threadIdx.x; k < span; k += blockDim.x) {
+            const bool in = i0 + k < i1;
+            const uint32_t key = in ? f2key(v[i0 + k]) - klo : 0u;
+            sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
+            const uint32_t c = (&lh[0][0])[i];
+            if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
+        }
+        return;
     }
-    __syncthreads();
-    (void)nb2;
-    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
-        const uint32_t c = (&lh[0][0])[i];
-        if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
-    }
-}
-
-// the same over the frame, for segments flagged `fail` (every other block exits at once)
-__global__ __launch_bounds__(256) void k_sel_hist_frame(sel_args a) {
-    __shared__ uint32_t lh[2][SEL_BINS];
-    const int Y = blockIdx.x, sx = blockIdx.y;
-    const int sg = (Y / a.ysz) * a.SX + sx;
-    if (!a.b.seg[sg].fail) return;
-    sel_digit d;
-    if (!sel_digit_of(a.nbits[sg], a.pass, &d)) return;
-    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1], klo = a.klo[sg];
-    const size_t row = (size_t)Y * a.nx + (size_t)sx * a.xsz;
-    const int xend = ((a.xsz + 63) / 64) * 64;
-    for (int x = threadIdx.x; x < xend; x += blockDim.x) {
-        bool in = x < a.xsz;
-        if (in && a.mask && (a.mask[row + x] & ~BBX_MASK_COSMIC)) in = false;
-        if (in && !bsel_value_ok(a.data[row + x], a.b.seg[sg].wlo, a.b.seg[sg].whi, a.b.skip_zero)) in = false;
-        const uint32_t key = in ? f2key(a.data[row + x]) - klo : 0u;
-        sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
-        const uint32_t c = (&lh[0][0])[i];
-        if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
+    if (*a.anyfail == 0) return;
+    const int nfb = gridDim.x - nbuf;
+    for (int pair = blockIdx.x - nbuf; pair < ny * a.SX; pair += nfb) {          // (row, segment column)
+        const int Y = pair / a.SX, sx = pair - Y * a.SX;
+        const int sg = (Y / a.ysz) * a.SX + sx;
+        sel_digit d;
+        if (!a.b.seg[sg].fail || !sel_digit_of(a.nbits[sg], a.pass, &d)) continue;   // workgroup-uniform
+        for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t pre0 = a.prefix[sg * 2], pre1 = a.prefix[sg * 2 + 1], klo = a.klo[sg];
+        const size_t row = (size_t)Y * a.nx + (size_t)sx * a.xsz;
+        const int xend = ((a.xsz + 63) / 64) * 64;
+        for (int x = threadIdx.x; x < xend; x += blockDim.x) {
+            bool in = x < a.xsz;
+            if (in && a.mask && (a.mask[row + x] & ~BBX_MASK_COSMIC)) in = false;
+            if (in && !bsel_value_ok(a.data[row + x], a.b.seg[sg].wlo, a.b.seg[sg].whi, a.b.skip_zero)) in = false;
+            const uint32_t key = in ? f2key(a.data[row + x]) - klo : 0u;
+            sel_hist_one(lh[0], lh[1], key, in, pre0, pre1, d);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
+            const uint32_t c = (&lh[0][0])[i];
+            if (c) atomicAdd(&a.hist[(size_t)sg * 2 * SEL_BINS + i], c);
+        }
+        __syncthreads();
     }
 }
 
@@ -310,12 +319,9 @@ __global__ __launch_bounds__(128) void k_sel_scan(sel_args a) {
     for (int k = threadIdx.x; k < 2 * nb; k += 128) h0[(k / nb) * SEL_BINS + (k % nb)] = 0;
 }
 
-__global__ void k_sel_zero(uint32_t* hist, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hist[i] = 0;
-}
-
 static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, bsel_shard** shard, float** samples, float** buf,
-                     uint32_t** prefix, unsigned long long** rank, uint32_t** hist, uint32_t** klo, int** nbits) {
+                     uint32_t** prefix, unsigned long long** rank, uint32_t** hist, uint32_t** klo, int** nbits,
+                     int** anyfail = nullptr) {
     int rc;
     static_assert(sizeof(bsel_shard) == 64, "one cache line per shard");
     const size_t o_shard = 0;
@@ -324,7 +330,8 @@ static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, bsel_
     const size_t o_prefix = o_rank + BSEL_MAXSEG * 2 * sizeof(unsigned long long);
     const size_t o_klo = o_prefix + BSEL_MAXSEG * 2 * sizeof(uint32_t);
     const size_t o_nbits = o_klo + BSEL_MAXSEG * sizeof(uint32_t);
-    const size_t o_hist = o_nbits + BSEL_MAXSEG * sizeof(int);
+    const size_t o_anyfail = o_nbits + BSEL_MAXSEG * sizeof(int);
+    const size_t o_hist = o_anyfail + 64;
     const size_t o_samples = o_hist + (size_t)BSEL_MAXSEG * 2 * SEL_BINS * 4;
     const size_t o_buf = o_samples + (size_t)nseg * BSEL_S * 4;
     const size_t total = o_buf + (size_t)nseg * cap * 4;
@@ -334,6 +341,7 @@ static int ws_layout(bbx_ctx* ctx, int nseg, uint32_t cap, bsel_seg** seg, bsel_
     *seg = (bsel_seg*)(ws + o_seg); *rank = (unsigned long long*)(ws + o_rank);
     *prefix = (uint32_t*)(ws + o_prefix); *hist = (uint32_t*)(ws + o_hist);
     *klo = (uint32_t*)(ws + o_klo); *nbits = (int*)(ws + o_nbits);
+    if (anyfail) *anyfail = (int*)(ws + o_anyfail);
     *samples = (float*)(ws + o_samples); *buf = (float*)(ws + o_buf);
     return BBX_OK;
 }
@@ -351,9 +359,12 @@ int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, i
     const uint32_t capS = (uint32_t)(((segpix / 8 + 65536) / BSEL_NSH + 1023) / 1024 * 1024);
     const uint32_t cap = capS * BSEL_NSH;
     bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
-    int rc = ws_layout(ctx, nseg, cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
+    int* anyfail;
+    int rc = ws_layout(ctx, nseg, cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits, &anyfail);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bsel_init, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg);
+    // (also zeroes the digit histograms: every scan leaves them zero again, so once per select is enough)
+    hipLaunchKernelGGL(k_bsel_init, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg, hist,
+                       nseg * 2 * SEL_BINS, anyfail);
     hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, stride, ysz, xsz, SX, seg, samples, 0);
     hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
     BBX_LAUNCH_CHECK();
@@ -365,19 +376,19 @@ int bbx_bsel_finish(bbx_ctx* ctx, const bsel_dev& b, const float* d_data, const 
                     hipStream_t s) {
     const int SX = b.SX, nseg = SX * (ny / b.ysz);
     bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
-    int rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits);
+    int* anyfail;
+    int rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits, &anyfail);
     if (rc) return rc;
     sel_args a;
     a.data = d_data; a.mask = d_mask; a.nx = b.stride; a.ysz = b.ysz; a.xsz = b.xsz; a.SX = SX;
-    a.b = b; a.prefix = prefix; a.rank = rank; a.hist = hist; a.klo = klo; a.nbits = nbits; a.pass = 0;
-    hipLaunchKernelGGL(k_sel_zero, dim3(32), dim3(256), 0, s, hist, nseg * 2 * SEL_BINS);
+    a.b = b; a.prefix = prefix; a.rank = rank; a.hist = hist; a.klo = klo; a.nbits = nbits; a.pass = 0; a.anyfail = anyfail;
     hipLaunchKernelGGL(k_sel_plan, dim3(1), dim3(64), 0, s, a, nseg);
     const int bufblocks = BSEL_NSH * (nseg == 1 ? 8 : 1);
+    const int framebl = std::min(ny * SX, 4096);               // exact-path workgroups (idle unless a segment failed)
     // up to 3 digits of <= 11 bits; segments whose bracket spans fewer bits skip the later passes
     for (int p = 0; p < 3; p++) {
         a.pass = p;
-        hipLaunchKernelGGL(k_sel_hist_buf, dim3(bufblocks, nseg), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_sel_hist_frame, dim3(ny, SX), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_sel_hist, dim3(bufblocks * nseg + framebl), dim3(256), 0, s, a, nseg, bufblocks, ny);
         hipLaunchKernelGGL(k_sel_scan, dim3(nseg), dim3(128), 0, s, a);
     }
     BBX_LAUNCH_CHECK();
@@ -607,8 +618,9 @@ extern "C" int bbx_rect_stats(bbx_ctx* ctx, int ny, int nx, int stride, const fl
 }
 
 // counters back to zero for another select over the same segments; the clip window stays
-__global__ __launch_bounds__(256) void k_bsel_reset(bsel_seg* seg, bsel_shard* shard, int nseg) {
+__global__ __launch_bounds__(256) void k_bsel_reset(bsel_seg* seg, bsel_shard* shard, int nseg, int* anyfail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *anyfail = 0;
     if (i < nseg * BSEL_NSH) { bsel_shard z; memset(&z, 0, sizeof(z)); shard[i] = z; }
     if (i < nseg) { seg[i].lo = 0.f; seg[i].hi = 0.f; seg[i].nsample = 0; seg[i].nbuf = 0; seg[i].below = 0; seg[i].n = 0; seg[i].fail = 0; }
 }
@@ -630,10 +642,11 @@ extern "C" int bbx_rect_clipped_stats(bbx_ctx* ctx, int ny, int nx, int stride, 
     const int nchunk = (ysz + RS_ROWS - 1) / RS_ROWS;
     double* partial = (double*)bbx_ws(ctx, WS_HIST, (size_t)nseg * nchunk * 5 * sizeof(double), &rc); if (rc) return rc;
     bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
-    rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits); if (rc) return rc;
+    int* anyfail;
+    rc = ws_layout(ctx, nseg, b.cap, &seg, &shard, &samples, &buf, &prefix, &rank, &hist, &klo, &nbits, &anyfail); if (rc) return rc;
     for (int it = 0; it <= maxiters; it++) {
         // (prepare sampled without the mask value rule; sample again with the current window)
-        hipLaunchKernelGGL(k_bsel_reset, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg);
+        hipLaunchKernelGGL(k_bsel_reset, dim3((nseg * BSEL_NSH + 255) / 256), dim3(256), 0, s, seg, shard, nseg, anyfail);
         hipLaunchKernelGGL(k_bsel_sample, dim3(BSEL_S / 256, nseg), dim3(256), 0, s, d_data, d_mask, stride, ysz, xsz, SX, seg,
                            samples, b.skip_zero);
         hipLaunchKernelGGL(k_bsel_bracket, dim3(nseg), dim3(1024), 0, s, seg, samples);
