@@ -208,22 +208,22 @@ __device__ __forceinline__ void vos_pass_finish(double s1, double s2, long long 
     }
 }
 
-// workgroup c (VSTD_BLOCKS threads): fold the channel's partials in fixed order and update the
-// clip state.  Follows SigmaClip._sigmaclip_noaxis: bounds from the survivors' mean/std,
+// Fold of a channel's partials in fixed order (lanes 0..VSTD_BLOCKS-1 of the workgroup) and the
+// clip-state update.  Follows SigmaClip._sigmaclip_noaxis: bounds from the survivors' mean/std,
 // survivors = survivors inside the closed interval, stop when nothing changed or after 5
 // iterations; the pass after the last filter delivers the returned statistics.
-__global__ __launch_bounds__(VSTD_BLOCKS) void k_vos_std_update(vos_state* st, const double* __restrict__ partial, int pass,
-                                                                double* __restrict__ std_out) {
+// `pass` is the index of the pass that produced `partial`; every thread of the workgroup gets
+// the same new state.  Needs blockDim.x >= VSTD_BLOCKS (a multiple of 64).
+__device__ __forceinline__ vos_state vos_fold_update(vos_state s, const double* __restrict__ partial, int c, int pass) {
     __shared__ double sh[3][VSTD_BLOCKS / 64];
-    const int c = blockIdx.x;
-    vos_state s = st[c];
-    if (s.frozen) return;
-    const double* p = partial + ((size_t)c * VSTD_BLOCKS + threadIdx.x) * 3;
-    double a = wave_sum_f64(p[0]), q = wave_sum_f64(p[1]), m = wave_sum_f64(p[2]);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = q; sh[2][threadIdx.x >> 6] = m; }
+    if (s.frozen) return s;                                 // uniform over the workgroup
+    if (threadIdx.x < VSTD_BLOCKS) {
+        const double* p = partial + ((size_t)c * VSTD_BLOCKS + threadIdx.x) * 3;
+        double a = wave_sum_f64(p[0]), q = wave_sum_f64(p[1]), m = wave_sum_f64(p[2]);
+        if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = q; sh[2][threadIdx.x >> 6] = m; }
+    }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    a = q = m = 0.0;
+    double a = 0.0, q = 0.0, m = 0.0;
     for (int w = 0; w < VSTD_BLOCKS / 64; w++) { a += sh[0][w]; q += sh[1][w]; m += sh[2][w]; }
     const long long cnt = (long long)m;
     const double mean = a / m;
@@ -239,8 +239,29 @@ __global__ __launch_bounds__(VSTD_BLOCKS) void k_vos_std_update(vos_state* st, c
         if (lo > s.lo) s.lo = lo;
         if (hi < s.hi) s.hi = hi;
     }
-    st[c] = s;
-    std_out[c] = s.std;
+    return s;
+}
+
+__device__ __forceinline__ vos_state vos_state_init() {
+    vos_state s;
+    s.lo = -__builtin_huge_val(); s.hi = __builtin_huge_val();
+    s.mean = 0; s.std = 0; s.n = -1; s.frozen = 0; s.pad = 0;
+    return s;
+}
+
+// state after the update that follows pass `pass`: st_prev = state before it (ignored for pass 0)
+__device__ __forceinline__ vos_state vos_state_after(const vos_state* __restrict__ st_prev, const double* __restrict__ partial,
+                                                     int c, int pass) {
+    const vos_state s = pass == 0 ? vos_state_init() : st_prev[c];
+    return vos_fold_update(s, partial, c, pass);
+}
+
+// closing launch: the update after pass 5 -> read noise per channel
+__global__ __launch_bounds__(VSTD_BLOCKS) void k_vos_std_final(const vos_state* __restrict__ st_prev,
+                                                               const double* __restrict__ partial, int pass,
+                                                               double* __restrict__ std_out) {
+    const vos_state s = vos_state_after(st_prev, partial, blockIdx.x, pass);
+    if (threadIdx.x == 0) std_out[blockIdx.x] = s.std;
 }
 
 // pass 0: residuals of the vertical overscan after the column fit -> compact float32 strip
@@ -276,12 +297,19 @@ __global__ __launch_bounds__(256) void k_vos_strip(const void* __restrict__ raw,
     vos_pass_finish(s1, s2, n, c, b, partial);
 }
 
-// passes 1..5 over the compact strip; channels whose clip loop has finished return at once
-__global__ __launch_bounds__(256) void k_vos_std_pass(const float* __restrict__ strip, bbx_dims d,
-                                                      const vos_state* __restrict__ st, double* __restrict__ partial) {
+// passes 1..5 over the compact strip.  Each workgroup first derives the clip state from the
+// previous state and the previous pass's partials (the same fold in every workgroup, so all
+// agree bit for bit; workgroup 0 records it for the next launch) - state and partials ping-pong
+// between two buffers, so no launch reads what a concurrent workgroup writes.  Channels whose
+// clip loop has finished return at once.
+__global__ __launch_bounds__(256) void k_vos_std_pass(const float* __restrict__ strip, bbx_dims d, int pass,
+                                                      const vos_state* __restrict__ st_prev, vos_state* __restrict__ st_cur,
+                                                      const double* __restrict__ part_prev, double* __restrict__ part_cur) {
     const int c = blockIdx.y, b = blockIdx.x;
-    if (st[c].frozen) return;
-    const double lo = st[c].lo, hi = st[c].hi;
+    const vos_state s = vos_state_after(st_prev, part_prev, c, pass - 1);
+    if (b == 0 && threadIdx.x == 0) st_cur[c] = s;
+    if (s.frozen) return;
+    const double lo = s.lo, hi = s.hi;
     const size_t total = (size_t)d.dy * d.vos_w;
     const float* x = strip + (size_t)c * total;
     double s1 = 0.0, s2 = 0.0; long long n = 0;
@@ -298,15 +326,7 @@ __global__ __launch_bounds__(256) void k_vos_std_pass(const float* __restrict__ 
     } else {
         for (size_t i = (size_t)b * 256 + threadIdx.x; i < total; i += (size_t)VSTD_BLOCKS * 256) take(x[i]);
     }
-    vos_pass_finish(s1, s2, n, c, b, partial);
-}
-
-__global__ void k_vos_std_init(vos_state* st) {
-    int c = threadIdx.x;
-    if (c < 16) {
-        st[c].lo = -__builtin_huge_val(); st[c].hi = __builtin_huge_val();
-        st[c].mean = 0; st[c].std = 0; st[c].n = -1; st[c].frozen = 0; st[c].pad = 0;
-    }
+    vos_pass_finish(s1, s2, n, c, b, part_cur);
 }
 
 // ---------------------------------------------------------------------------------
@@ -376,13 +396,14 @@ int bbx_vos_std(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type
     hipStream_t s = (hipStream_t)stream;
     f32x16 gain = load16(h_gain), dlev = load16(h_dlevel);
     const size_t nstrip = (size_t)16 * d.dy * d.vos_w;
-    const size_t o_partial = 16 * sizeof(vos_state), o_strip = o_partial + 16 * VSTD_BLOCKS * 3 * sizeof(double);
+    // [2] clip states, [2] partial-sum sets (ping-pong by pass parity), then the strip
+    const size_t npart = (size_t)16 * VSTD_BLOCKS * 3;
+    const size_t o_partial = 2 * 16 * sizeof(vos_state), o_strip = o_partial + 2 * npart * sizeof(double);
     char* ws = (char*)bbx_ws(ctx, WS_STRIP, o_strip + nstrip * sizeof(float), &rc);
     if (rc) return rc;
     vos_state* st = (vos_state*)ws;
     double* partial = (double*)(ws + o_partial);
     float* strip = (float*)(ws + o_strip);
-    hipLaunchKernelGGL(k_vos_std_init, dim3(1), dim3(64), 0, s, st);
     if (raw_type == BBX_RAW_U16)
         hipLaunchKernelGGL(k_vos_strip<BBX_RAW_U16>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain, d_vfit, dlev,
                            strip, partial);
@@ -390,11 +411,13 @@ int bbx_vos_std(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int raw_type
         hipLaunchKernelGGL(k_vos_strip<BBX_RAW_F32>, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, d_raw, d, gain, d_vfit, dlev,
                            strip, partial);
     else return BBX_ERR_ARG;
-    hipLaunchKernelGGL(k_vos_std_update, dim3(16), dim3(VSTD_BLOCKS), 0, s, st, partial, 0, d_std_vos);
-    for (int pass = 1; pass < 6; pass++) {
-        hipLaunchKernelGGL(k_vos_std_pass, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, strip, d, st, partial);
-        hipLaunchKernelGGL(k_vos_std_update, dim3(16), dim3(VSTD_BLOCKS), 0, s, st, partial, pass, d_std_vos);
-    }
+    // pass p writes state p-1 into st[(p-1)&1] and its sums into partial[p&1]
+    for (int pass = 1; pass < 6; pass++)
+        hipLaunchKernelGGL(k_vos_std_pass, dim3(VSTD_BLOCKS, 16), dim3(256), 0, s, strip, d, pass,
+                           st + 16 * (pass & 1), st + 16 * ((pass - 1) & 1),
+                           partial + npart * ((pass - 1) & 1), partial + npart * (pass & 1));
+    hipLaunchKernelGGL(k_vos_std_final, dim3(16), dim3(VSTD_BLOCKS), 0, s, st + 16 * (4 & 1), partial + npart * (5 & 1), 5,
+                       d_std_vos);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
