@@ -616,10 +616,18 @@ __global__ __launch_bounds__(256) void k_lac_grow1(lac_par p, const uint32_t* __
 // s values of "their" neighbour's window with wave shuffles and run the median network in
 // registers.  Neighbours shared by adjacent stage-2 pixels are simply evaluated again (no
 // claim/atomic on the critical path); the F_FINAL bit makes the per-iteration count unique.
+// New CR pixels are queued in LDS and appended to the cumulative list with one reservation per
+// workgroup: a returning atomic per wave on the one list counter retires at ~11 ns each on
+// this part, which made the ~9000 stage-2 pixels of a first iteration cost 80 us.
 #define F_FINAL 8u
+#define G2_QCAP 1024
 __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, uint8_t* mask, lac_par p,
                                                    const uint32_t* __restrict__ stage2, uint32_t cap, uint8_t* flags,
                                                    uint32_t* __restrict__ crlist, int32_t* counters, int32_t* err) {
+    __shared__ uint32_t q[G2_QCAP];
+    __shared__ unsigned qn, nnew, qbase;
+    if (threadIdx.x == 0) { qn = 0; nnew = 0; qbase = 0; }
+    __syncthreads();
     const int n = min((uint32_t)counters[CNT_STAGE2], cap);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -654,15 +662,29 @@ __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, 
                     const unsigned of = atomic_or_u8(flags, r, F_FINAL);
                     if (!(of & F_FINAL)) {
                         const unsigned om = atomic_or_u8(mask, r, BBX_MASK_COSMIC);
-                        atomicAdd(&counters[CNT_NEWCR], 1);
+                        atomicAdd(&nnew, 1u);
                         if (!(om & BBX_MASK_COSMIC)) {
-                            const unsigned q = atomicAdd((unsigned*)&counters[CNT_CRLIST], 1u);
-                            if (q < cap) crlist[q] = (uint32_t)r; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                            const unsigned k = atomicAdd(&qn, 1u);
+                            if (k < G2_QCAP) q[k] = (uint32_t)r;
+                            else {                                              // queue full: append directly
+                                const unsigned g = atomicAdd((unsigned*)&counters[CNT_CRLIST], 1u);
+                                if (g < cap) crlist[g] = (uint32_t)r; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                            }
                         }
                     }
                 }
             }
         }
+    }
+    __syncthreads();
+    const unsigned nq = min(qn, (unsigned)G2_QCAP);
+    if (threadIdx.x == 0) {
+        if (nq) qbase = atomicAdd((unsigned*)&counters[CNT_CRLIST], nq);
+        if (nnew) atomicAdd(&counters[CNT_NEWCR], (int)nnew);
+    }
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < nq; k += blockDim.x) {
+        if (qbase + k < cap) crlist[qbase + k] = q[k]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
     }
 }
 
@@ -807,7 +829,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
-        hipLaunchKernelGGL(k_lac_grow2, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
+        hipLaunchKernelGGL(k_lac_grow2, dim3(512), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
         hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
