@@ -689,9 +689,13 @@ __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, 
 }
 
 // ---- 4. clean_medmask on the cumulative CR list -------------------------------------------------
+// A CR pixel without any good neighbour takes the background level (median of the good input
+// pixels).  That is rare, and the level costs a select to finish, so such pixels are only
+// listed here; k_lac_bg, right after this kernel, produces the level on demand and fills them
+// (nothing else reads a CR pixel's value in between: the windows take mask == 0 pixels only).
 __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __restrict__ mask, lac_par p,
-                                                   const uint32_t* __restrict__ crlist, const int32_t* __restrict__ counters,
-                                                   uint32_t cap, const bsel_seg* __restrict__ bg) {
+                                                   const uint32_t* __restrict__ crlist, int32_t* counters,
+                                                   uint32_t cap, uint32_t* __restrict__ bglist, uint32_t capbg, int32_t* err) {
     const int n = min((uint32_t)counters[CNT_CRLIST], cap);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -709,8 +713,117 @@ __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __re
         const int cnt = __popcll(__ballot(ok));
         // +inf padding sorts last; a genuine +inf pixel would too, and is then picked in order
         const float med = wave_sort_pick(v, 32, cnt > 0 ? (cnt - 1) / 2 : 0);
-        if (lane == 0) a[o] = (cnt > 0) ? med : bg->result[0];
+        if (lane == 0) {
+            if (cnt > 0) a[o] = med;
+            else {
+                const unsigned q = atomicAdd((unsigned*)&counters[CNT_BGNEED], 1u);
+                if (q < capbg) bglist[q] = o; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+            }
+        }
     }
+}
+
+// ---- 4b. background level on demand ------------------------------------------------------------
+// One workgroup: lower-middle element (rank (n-1)/2, astroscrappy's quick-select median) of the
+// values picked by [from_frame]: the good pixels of the frame, or the side buffer of the
+// bracketed select (then [rank] counts inside the buffer).  Three digit passes over the float
+// keys with an LDS histogram; slow next to the multi-workgroup select, but it only runs when a
+// frame needs the level at all.
+__device__ float wg_lower_median(const bsel_dev& b, const float* __restrict__ a, const uint8_t* __restrict__ mask,
+                                 size_t npix, bool from_frame, unsigned long long rank) {
+    __shared__ uint32_t lh[2048];
+    __shared__ uint32_t s_prefix;
+    __shared__ unsigned long long s_rank;
+    __shared__ int s_empty;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_prefix = 0; s_rank = rank; s_empty = 0; }
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    uint32_t himask = 0;
+    for (int ps = 0; ps < 3; ps++) {
+        for (int i = tid; i < 2048; i += blockDim.x) lh[i] = 0;
+        __syncthreads();
+        const uint32_t pre = s_prefix, dmask = (1u << nbits[ps]) - 1u;
+        const int shift = shifts[ps];
+        if (from_frame) {
+            for (size_t i = tid; i < npix; i += blockDim.x) {
+                if (mask[i] & ~BBX_MASK_COSMIC) continue;
+                const uint32_t key = f2key(a[i]);
+                if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+            }
+        } else {
+            for (unsigned sh = 0; sh < BSEL_NSH; sh++) {
+                const uint32_t cnt = min(b.shard[sh].nbuf, b.capS);
+                const float* v = bsel_region(b, 0, sh);
+                for (uint32_t i = tid; i < cnt; i += blockDim.x) {
+                    const uint32_t key = f2key(v[i]);
+                    if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (ps == 0 && from_frame) {
+                unsigned long long total = 0;
+                for (int bin = 0; bin < 2048; bin++) total += lh[bin];
+                if (total == 0) s_empty = 1; else s_rank = (total - 1) / 2;
+            }
+            unsigned long long r = s_rank, acc = 0;
+            for (int bin = 0; bin <= (int)dmask; bin++) {
+                if (acc + lh[bin] > r) { s_rank = r - acc; s_prefix = pre | ((uint32_t)bin << shift); break; }
+                acc += lh[bin];
+            }
+        }
+        __syncthreads();
+        if (s_empty) return 0.f;                                // no good pixel at all: level 0
+        himask |= dmask << shift;
+    }
+    return key2f(s_prefix);
+}
+
+// mode 0, after the pass that fed the bracketed select and before the frame is modified: sums
+// of the shards; if the bracket cannot deliver the rank (see bbx_bsel.h) the exact select over
+// the frame runs now.  mode 1, after k_lac_clean: nothing to do unless pixels were listed; then
+// the level comes from the side buffer (unless it is known already) and the listed pixels get it.
+// seg->pad marks "result[0] holds the level".
+__global__ __launch_bounds__(1024) void k_lac_bg(float* a, const uint8_t* __restrict__ mask, lac_par p, bsel_dev b,
+                                                 int32_t* counters, const uint32_t* __restrict__ bglist, uint32_t capbg, int mode) {
+    __shared__ float s_bg;
+    __shared__ int s_fail;
+    bsel_seg* sg = b.seg;
+    const size_t npix = (size_t)p.ny * p.nx;
+    if (mode == 0) {
+        if (threadIdx.x < 64) {
+            const bsel_shard* q = &b.shard[threadIdx.x];
+            const long long n = wave_sum_i64((long long)q->n), below = wave_sum_i64((long long)q->below);
+            const long long nbuf = wave_sum_i64((long long)q->nbuf);
+            const bool over = __ballot(q->nbuf > b.capS) != 0ull;
+            if (threadIdx.x == 0) {
+                sg->n = (unsigned long long)n; sg->below = (unsigned long long)below; sg->nbuf = (uint32_t)nbuf;
+                const long long k0 = n ? (n - 1) / 2 : 0;
+                const int fail = (sg->fail || over || k0 < below || k0 >= below + nbuf) ? 1 : 0;
+                sg->fail = fail; sg->pad = 0;
+                s_fail = fail;
+            }
+        }
+        __syncthreads();
+        if (!s_fail) return;
+        const float r = wg_lower_median(b, a, mask, npix, true, 0ull);
+        if (threadIdx.x == 0) { sg->result[0] = r; sg->result[1] = r; sg->pad = 1; }
+        return;
+    }
+    const uint32_t n = min((uint32_t)counters[CNT_BGNEED], capbg);
+    if (n == 0) return;
+    float bg;
+    if (!sg->pad) {                                             // workgroup-uniform
+        const unsigned long long k0 = sg->n ? (sg->n - 1) / 2 : 0;
+        bg = wg_lower_median(b, a, mask, npix, false, k0 - sg->below);
+    } else bg = sg->result[0];
+    if (threadIdx.x == 0) s_bg = bg;
+    __syncthreads();
+    bg = s_bg;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) a[bglist[k]] = bg;
+    __syncthreads();
+    if (threadIdx.x == 0) { sg->result[0] = bg; sg->result[1] = bg; sg->pad = 1; counters[CNT_BGNEED] = 0; }
 }
 
 // the flag plane is only ever written at listed pixels (raw candidates; 3x3 around stage-2
@@ -749,7 +862,7 @@ __global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt
     if (t < 16 && tile_cnt_pad) tile_cnt_pad[t] = 0;         // k_lac_compact reads the counts sixteen at a time
     if (t != 0) return;
     counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CRLIST] = 0; counters[CNT_NEWCR] = 0;
-    counters[CNT_CANDOVF] = 0; counters[CNT_CANDRAW] = 0; counters[CNT_TICKET] = 0;
+    counters[CNT_CANDOVF] = 0; counters[CNT_CANDRAW] = 0; counters[CNT_TICKET] = 0; counters[CNT_BGNEED] = 0;
     float rn = readnoise;
     if (rdn16) {
         double r[8]; int n = 0;
@@ -825,13 +938,16 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
                                ctx->d_err);
         }
         hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, cand);
-        if (it == 0) { rc = bbx_bsel_finish(ctx, bs, d_data, d_mask, ny, nx, s); if (rc) return rc; }
+        if (it == 0) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(1024), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 0);
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_grow2, dim3(512), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
                            cnt, ctx->d_err);
-        hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, bs.seg);
+        // (the overflow list of the dense pass is free again after k_lac_compact: pixels waiting for the level)
+        hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, ovf,
+                           (uint32_t)capovf, ctx->d_err);
+        hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(1024), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1);
         hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
         bbx_prof_stop(ctx, s);
     }

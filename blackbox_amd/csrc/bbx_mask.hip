@@ -157,6 +157,9 @@ __global__ __launch_bounds__(1024) void k_coarse_flood(const uint8_t* __restrict
         __syncthreads();
         if (!c) break;
     }
+    // (single workgroup: the tile counter starts from zero here, no memset before the launch)
+    if (threadIdx.x == 0) counters[CNT_TILES] = 0;
+    __syncthreads();
     for (int t = threadIdx.x; t < nt; t += blockDim.x) {
         state[t] = st[t] & 1;
         if (!(st[t] & 1)) { int k = atomicAdd(&counters[CNT_TILES], 1); tiles[k] = (uint32_t)t; }
@@ -437,11 +440,23 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
     k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k;
 }
 
+// The table is allocated for the list capacity (hundreds of MB for a full frame), but a list
+// of n pixels only uses the first pow2(>= 4 n) slots of it: a typical CR / saturation list then
+// hashes into a few hundred KB that stay in L2 instead of one HBM (and TLB) miss per probe.
+__device__ __forceinline__ uint32_t cc_hmask(int n, uint32_t hmask_max) {
+    const unsigned long long want = 4ull * (unsigned long long)(n > 0 ? n : 0);
+    unsigned long long m = 1024ull;
+    while (m < want) m <<= 1;
+    return (uint32_t)min(m - 1ull, (unsigned long long)hmask_max);
+}
+
 __global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                    uint32_t* keys, uint32_t* vals, uint32_t hmask, uint32_t* parent,
-                                                   uint32_t* __restrict__ slot, int cap, int32_t* err) {
+                                                   uint32_t* __restrict__ slot, int cap, int32_t* err, int32_t* out) {
     int n = *cnt;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = 0;                 // summed into by k_cc_count
     if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
+    hmask = cc_hmask(n, hmask);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
         uint32_t h = hash_u32(p) & hmask;
@@ -478,6 +493,7 @@ __global__ __launch_bounds__(256) void k_cc_union(const uint32_t* __restrict__ l
                                                   const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                   uint32_t hmask, uint32_t* parent, int ny, int nx, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
+    hmask = cc_hmask(n, hmask);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
         const int Y = p / nx, X = p - Y * nx;
@@ -546,10 +562,9 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
         BBX_HIP(hipMemsetAsync(keys, 0xff, hsize * sizeof(uint32_t), s));
         ctx->hash_clean_ptr = (void*)hash; ctx->hash_clean_n = hsize;
     }
-    BBX_HIP(hipMemsetAsync(d_out, 0, sizeof(int32_t), s));
     const unsigned grid = 1024;
     hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent,
-                       slot, (int)cap, ctx->d_err);
+                       slot, (int)cap, ctx->d_err, d_out);
     hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent, ny, nx,
                        (int)cap);
     hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, d_cnt, parent, slot, keys, d_out, (int)cap);
@@ -676,7 +691,6 @@ int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d
     u64* freebits = (u64*)(tws + o_free);
     // (tiles offset may exceed the requested size by the alignment slack; bbx_ws over-allocates by 1/8 + 256)
     BBX_HIP(hipMemsetAsync(bitsM, 0, nwords * 8, s));
-    BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_TILES], 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_sat_scatter, dim3(512), dim3(256), 0, s, ctx->d_satlist, ctx->d_counters, d, d_mask, bitsM, W);
     // NOBJ-SAT: objects of the saturated pixels themselves (blackbox.py:4544-4550)
     rc = bbx_cc_count_list(ctx, ctx->d_satlist, &ctx->d_counters[CNT_SAT],

@@ -264,3 +264,38 @@ def test_select_exact_fallback(ctx):
     for k in range(64):
         by, bx = divmod(k, 8)
         assert np.float32(st[k, 1]) == np.median(small[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8]), k
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('constant_sky', [False, True])
+def test_lacosmic_background_level(ctx, constant_sky):
+    """CR pixels without a single good neighbour take the background level (lower median of the
+    good pixels): produced on demand from the select's side buffer; with a constant sky the
+    bracket cannot hold the rank and the exact select over the frame has to deliver it"""
+    ys, xs = 256, 384
+    rs = np.random.RandomState(5)
+    if constant_sky:
+        img = np.full((ys, xs), 100.0, np.float32)
+        img[::7, ::5] = 101.0
+    else:
+        img = (100.0 + 8.0 * synth._gauss(rs, (ys, xs))).astype(np.float32)
+    mask = np.zeros((ys, xs), np.uint8)
+    spikes = [(40, 50), (41, 200), (130, 17), (200, 300), (100, 100)]
+    for (j, i) in spikes:
+        img[j, i] = 5000.0
+        mask[j - 2:j + 3, i - 2:i + 3] = 1
+        mask[j, i] = 0
+    img[100, 101] = 4000.0; mask[100, 101] = 0                      # a pair: both wait for the level
+    img[150, 150] = 3000.0                                          # and an ordinary one
+    cr_o, clean_o, ncr_o = L.detect_cosmics(img, mask != 0, 4.5, 0.3, 3.0, 3, 8.2, return_iters=True)
+    for (j, i) in spikes:
+        assert cr_o[j, i]
+    level = np.sort(img[mask == 0])[((mask == 0).sum() - 1) // 2]
+    assert clean_o[40, 50] == level
+    d = torch.from_numpy(img.copy()).to(ctx.device)
+    m = torch.from_numpy(mask.copy()).to(ctx.device)
+    st = R.detect_cosmics(ctx, d, m, 4.5, 0.3, 3.0, 3, 8.2)
+    ctx.sync()
+    assert np.array_equal((m.cpu().numpy() & 2) != 0, cr_o)
+    assert np.array_equal(d.cpu().numpy(), clean_o)
+    assert list(st.cpu().numpy()[:len(ncr_o)]) == ncr_o
+
