@@ -465,7 +465,6 @@ __global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ 
             if (old == HEMPTY || old == p) { vals[h] = (uint32_t)i; slot[i] = h; break; }
             h = (h + 1) & hmask;
         }
-        parent[i] = (uint32_t)i;
     }
 }
 
@@ -479,38 +478,76 @@ __device__ __forceinline__ int cc_lookup(const uint32_t* keys, const uint32_t* v
     }
 }
 
+// (device-scope relaxed loads: served by the L2 the atomics go to; `volatile` would make them
+// system-scope accesses)
+__device__ __forceinline__ uint32_t cc_load(const uint32_t* q) {
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t cc_find(uint32_t* parent, uint32_t i) {
-    uint32_t p = *(volatile uint32_t*)&parent[i];
+    uint32_t p = cc_load(&parent[i]);
     while (p != i) {
-        const uint32_t gp = *(volatile uint32_t*)&parent[p];
-        if (gp != p) parent[i] = gp;          // path halving (benign race)
+        const uint32_t gp = cc_load(&parent[p]);
+        if (gp != p) __hip_atomic_store(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving (benign race)
         i = p; p = gp;
     }
     return i;
 }
 
-__global__ __launch_bounds__(256) void k_cc_union(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
-                                                  const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                  uint32_t hmask, uint32_t* parent, int ny, int nx, int cap) {
+// Links in two steps (the decision tree of raster-scan labelling).  With a = NW, b = N, c = NE,
+// d = W of pixel e, every pixel only has to make sure that e and its earlier neighbours end up
+// in one tree, given that each of those does the same for its own earlier neighbours:
+//   b present                -> e - b            (a, c, d all touch b)
+//   b absent, c present      -> e - c, and c - a (or c - d when a is absent; d touches a)
+//   b, c absent              -> e - a, else e - d (d touches a)
+// The first link of each pixel is a plain store into its own parent slot (every pixel points
+// at an earlier pixel of the raster: a forest), done by k_cc_link for all pixels before any
+// tree is searched.  Only the pixels of the middle case need a real union afterwards
+// (k_cc_union) -- a few per object instead of four contended compare-and-swap loops per pixel.
+__global__ __launch_bounds__(256) void k_cc_link(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                 const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                 uint32_t hmask, uint32_t* __restrict__ parent, int32_t* __restrict__ pend,
+                                                 int ny, int nx, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
     hmask = cc_hmask(n, hmask);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
         const int Y = p / nx, X = p - Y * nx;
-        const int ox[4] = {1, -1, 0, 1}, oy[4] = {0, 1, 1, 1};
-        for (int k = 0; k < 4; k++) {
-            const int Xn = X + ox[k], Yn = Y + oy[k];
-            if (Xn < 0 || Xn >= nx || Yn >= ny) continue;
-            const int j = cc_lookup(keys, vals, hmask, (uint32_t)(Yn * nx + Xn));
-            if (j < 0) continue;
-            uint32_t a = (uint32_t)i, b = (uint32_t)j;
-            for (;;) {
-                a = cc_find(parent, a); b = cc_find(parent, b);
-                if (a == b) break;
-                if (a < b) { uint32_t t = a; a = b; b = t; }      // a > b: hang a under b
-                const uint32_t old = atomicCAS(&parent[a], a, b);
-                if (old == a) break;
+        int link = i, other = -1;
+        if (Y > 0) {
+            const uint32_t up = p - (uint32_t)nx;
+            const int jb = cc_lookup(keys, vals, hmask, up);
+            if (jb >= 0) link = jb;
+            else {
+                const int jc = (X + 1 < nx) ? cc_lookup(keys, vals, hmask, up + 1u) : -1;
+                const int ja = (X > 0) ? cc_lookup(keys, vals, hmask, up - 1u) : -1;
+                if (jc >= 0) {
+                    link = jc;
+                    other = ja >= 0 ? ja : ((X > 0) ? cc_lookup(keys, vals, hmask, p - 1u) : -1);
+                } else if (ja >= 0) link = ja;
             }
+        }
+        if (link == i && X > 0) {                                 // nothing in the row above
+            const int jd = cc_lookup(keys, vals, hmask, p - 1u);
+            if (jd >= 0) link = jd;
+        }
+        parent[i] = (uint32_t)link;
+        pend[i] = other;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_union(const int32_t* __restrict__ cnt, uint32_t* parent,
+                                                  const int32_t* __restrict__ pend, int cap) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = pend[i];
+        if (j < 0) continue;
+        uint32_t a = (uint32_t)i, b = (uint32_t)j;
+        for (;;) {
+            a = cc_find(parent, a); b = cc_find(parent, b);
+            if (a == b) break;
+            if (a < b) { uint32_t t = a; a = b; b = t; }      // a > b: hang a under b
+            const uint32_t old = atomicCAS(&parent[a], a, b);
+            if (old == a) break;
         }
     }
 }
@@ -552,8 +589,9 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
     // of a call with a different table size
     uint32_t* hash = (uint32_t*)bbx_ws(ctx, WS_HASH, hsize * sizeof(uint32_t), &rc); if (rc) return rc;
     uint32_t* vals = (uint32_t*)bbx_ws(ctx, WS_HVALS, hsize * sizeof(uint32_t), &rc); if (rc) return rc;
-    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, 2 * cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
+    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, 3 * cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
     uint32_t* slot = parent + cap;
+    int32_t* pend = (int32_t*)(slot + cap);
     uint32_t* keys = hash;
     // the key table is kept all-HEMPTY between calls (k_cc_count empties what it used); it is
     // filled once when the workspace block is new or grew.  Slots of a smaller earlier table
@@ -565,8 +603,9 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
     const unsigned grid = 1024;
     hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent,
                        slot, (int)cap, ctx->d_err, d_out);
-    hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent, ny, nx,
-                       (int)cap);
+    hipLaunchKernelGGL(k_cc_link, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent, pend,
+                       ny, nx, (int)cap);
+    hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_cnt, parent, pend, (int)cap);
     hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, d_cnt, parent, slot, keys, d_out, (int)cap);
     BBX_LAUNCH_CHECK();
     return BBX_OK;

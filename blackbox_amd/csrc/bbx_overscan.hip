@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_vos_rowstats(const void* __restrict__ r
 // The same statistics with 16 lanes per row (4 rows per wave): the strip is 180 columns wide,
 // so a 64-lane row leaves most lanes idle, and sums inside a 16-lane DPP row need no
 // cross-row step.
-#define VOS_V16 4       // 4 * VOS_V16 values per lane -> strips up to 256 columns wide
+#define VOS_V16 4       // up to 4 * VOS_V16 values per lane -> strips up to 256 columns wide
 __device__ __forceinline__ double row16_sum_f64(double v) {
     v += dpp_mov_f64<BBX_DPP_ROR(1)>(v);
     v += dpp_mov_f64<BBX_DPP_ROR(2)>(v);
@@ -96,7 +96,9 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
     return v;
 }
 
-template <int RAW_T>
+// NV = values per lane (16 NV >= strip width): the loop is ALU-bound (float64 sums, 5 clip rounds),
+// so the production strip (174 columns) gets an 11-value instance instead of the generic 16.
+template <int RAW_T, int NV>
 __global__ __launch_bounds__(256) void k_vos_rowstats16(const void* __restrict__ raw, bbx_dims d, f32x16 gain,
                                                         double* __restrict__ mean_out) {
     const int l16 = threadIdx.x & 15;
@@ -107,10 +109,10 @@ __global__ __launch_bounds__(256) void k_vos_rowstats16(const void* __restrict__
     const int iy = c >> 3, ix = c & 7;
     const size_t base = (size_t)(iy * d.dy + r) * d.nx_raw + (size_t)ix * d.dx + d.vos_x0;
     const float g = gain.v[c];
-    double v[4 * VOS_V16];
+    double v[NV];
     unsigned valid = 0;                       // bit per value: finite and != mask_value(0)
 #pragma unroll
-    for (int k = 0; k < 4 * VOS_V16; k++) {
+    for (int k = 0; k < NV; k++) {
         const int col = l16 + 16 * k;
         float x = 0.f;
         if (col < d.vos_w) x = raw_load<RAW_T>(raw, base + col);
@@ -126,28 +128,29 @@ __global__ __launch_bounds__(256) void k_vos_rowstats16(const void* __restrict__
     for (int it = 0; it < 5; it++) {                                   // rows that are done keep their state
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4 * VOS_V16; k++) if (ok & (1u << k)) s += v[k];
+        for (int k = 0; k < NV; k++) if (ok & (1u << k)) s += v[k];
         s = row16_sum_f64(s);
         const double mean = s / (double)n;
         double q2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4 * VOS_V16; k++) if (ok & (1u << k)) { const double t = mean - v[k]; q2 += t * t; }
+        for (int k = 0; k < NV; k++) if (ok & (1u << k)) { const double t = mean - v[k]; q2 += t * t; }
         q2 = row16_sum_f64(q2);
         const double sd = sqrt(q2 / (double)n);
         const double nlo = mean - 3.0 * sd, nhi = mean + 3.0 * sd;
         unsigned nok = 0;
 #pragma unroll
-        for (int k = 0; k < 4 * VOS_V16; k++) if ((ok & (1u << k)) && v[k] >= nlo && v[k] <= nhi) nok |= 1u << k;
+        for (int k = 0; k < NV; k++) if ((ok & (1u << k)) && v[k] >= nlo && v[k] <= nhi) nok |= 1u << k;
         const int m = row16_sum_i32(__popc(nok));
         if (run) { lo = nlo; hi = nhi; ok = nok; }
         if (run && m == n) run = false;
         if (run) { n = m; if (n == 0) run = false; }
+        if (!__any(run)) break;                                        // every row of the wave has converged
     }
     // final: every valid value inside the last bounds (NaN bounds reject nothing -- only
     // reachable with n == 0, where the mean is NaN anyway)
     double s = 0.0; int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4 * VOS_V16; k++)
+    for (int k = 0; k < NV; k++)
         if ((valid & (1u << k)) && !(v[k] < lo) && !(v[k] > hi)) { s += v[k]; cnt++; }
     s = row16_sum_f64(s); cnt = row16_sum_i32(cnt);
     if (live && l16 == 0) mean_out[row_id] = s / (double)cnt;         // 0/0 -> NaN like nanmean of all-NaN
@@ -375,11 +378,13 @@ int bbx_overscan_stats(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw, int r
     const bool v16 = d.vos_w <= 64 * VOS_V16;
     const dim3 grid16((rows + 15) / 16);
     if (raw_type == BBX_RAW_U16) {
-        if (v16) hipLaunchKernelGGL(k_vos_rowstats16<BBX_RAW_U16>, grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        if (v16 && d.vos_w <= 176) hipLaunchKernelGGL((k_vos_rowstats16<BBX_RAW_U16, 11>), grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        else if (v16) hipLaunchKernelGGL((k_vos_rowstats16<BBX_RAW_U16, 4 * VOS_V16>), grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
         else hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_U16>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
         hipLaunchKernelGGL(k_hos_copy<BBX_RAW_U16>, dim3(256), block, 0, s, d_raw, d, gain, d_hos);
     } else if (raw_type == BBX_RAW_F32) {
-        if (v16) hipLaunchKernelGGL(k_vos_rowstats16<BBX_RAW_F32>, grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        if (v16 && d.vos_w <= 176) hipLaunchKernelGGL((k_vos_rowstats16<BBX_RAW_F32, 11>), grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
+        else if (v16) hipLaunchKernelGGL((k_vos_rowstats16<BBX_RAW_F32, 4 * VOS_V16>), grid16, block, 0, s, d_raw, d, gain, d_mean_vos_col);
         else hipLaunchKernelGGL(k_vos_rowstats<BBX_RAW_F32>, grid, block, 0, s, d_raw, d, gain, d_mean_vos_col);
         hipLaunchKernelGGL(k_hos_copy<BBX_RAW_F32>, dim3(256), block, 0, s, d_raw, d, gain, d_hos);
         hipLaunchKernelGGL(k_count_nonfinite, dim3(2048), block, 0, s, (const float*)d_raw,
