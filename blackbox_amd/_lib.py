@@ -44,6 +44,12 @@ SIGNATURES = {
     'bbx_last_hip_error': (C.c_char_p, [_vp]),
     'bbx_version': (_i, []),
     'bbx_sync': (_i, [_vp, _vp]),
+    'bbx_event_create': (_i, [C.POINTER(C.c_void_p)]),
+    'bbx_event_destroy': (None, [_vp]),
+    'bbx_event_record': (_i, [_vp, _vp]),
+    'bbx_event_query': (_i, [_vp]),
+    'bbx_stream_wait_event': (_i, [_vp, _vp]),
+    'bbx_copy_async': (_i, [_vp, _vp, C.c_size_t, _i, _vp]),
     'bbx_profile_enable': (_i, [_vp, _i]),
     'bbx_profile_read': (_i, [_vp, _pd, C.POINTER(C.c_int32), _i]),
     'bbx_overscan_stats': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp]),

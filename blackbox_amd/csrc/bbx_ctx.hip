@@ -129,4 +129,47 @@ int bbx_sync(bbx_ctx* ctx, void* stream) {
     return BBX_OK;
 }
 
+// ---- stream plumbing (see bbx.h) ---------------------------------------------------------
+#define BBX_HIP0(call) do { if ((call) != hipSuccess) return BBX_ERR_HIP; } while (0)
+
+int bbx_event_create(void** out_event) {
+    if (!out_event) return BBX_ERR_ARG;
+    hipEvent_t ev;
+    BBX_HIP0(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *out_event = (void*)ev;
+    return BBX_OK;
+}
+
+void bbx_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
+int bbx_event_record(void* event, void* stream) {
+    if (!event) return BBX_ERR_ARG;
+    BBX_HIP0(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return BBX_OK;
+}
+
+int bbx_event_query(void* event) {
+    if (!event) return BBX_ERR_ARG;
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return BBX_ERR_HIP;
+}
+
+int bbx_stream_wait_event(void* stream, void* event) {
+    if (!event) return BBX_ERR_ARG;
+    BBX_HIP0(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return BBX_OK;
+}
+
+int bbx_copy_async(void* dst, const void* src, size_t nbytes, int kind, void* stream) {
+    if (!dst || !src || kind < 0 || kind > 2) return BBX_ERR_ARG;
+    if (nbytes == 0) return BBX_OK;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    BBX_HIP0(hipMemcpyAsync(dst, src, nbytes, k, (hipStream_t)stream));
+    return BBX_OK;
+}
+
 }  // extern "C"

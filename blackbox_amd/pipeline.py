@@ -18,6 +18,8 @@ No collective, no inter-GPU traffic: one FramePipeline per GPU / process.
 import ctypes as C
 import multiprocessing as mp
 import os
+import queue
+import threading
 import time
 
 import numpy as np
@@ -193,7 +195,52 @@ def _shm_phase2(args):
 
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
-                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane')
+                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane', 'err')
+
+
+class _LaneCtx:
+    """a library context bound to one stream (what the stage functions of reduce.py ask of a
+    Context: .h, .device, .stream(), .sync()) -- the stream handle is looked up once, not per call"""
+
+    def __init__(self, ctx, stream):
+        self.h, self.device, self.owner = ctx.h, ctx.device, ctx
+        self.torch_stream = stream
+        self.sp = C.c_void_p(stream.cuda_stream)
+
+    def stream(self):
+        return self.sp
+
+    def sync(self):
+        check(lib.bbx_sync(self.h, self.sp), 'bbx_sync', self.h)
+
+
+class _LaneThread(threading.Thread):
+    """issues the device stage of one lane: the launches of a frame take ~0.6 ms of host time,
+    most of it inside the library (ctypes drops the GIL there), so the lanes and the
+    orchestrating thread overlap.  Work items: (method, frame, results)."""
+
+    def __init__(self, pipe, device):
+        super().__init__(daemon=True)
+        self.pipe, self.device, self.q = pipe, device, queue.SimpleQueue()
+
+    def run(self):
+        torch.cuda.set_device(self.device)              # the current HIP device is per thread
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            fn, f, results = item
+            try:
+                fn(f, results)
+            except BaseException as e:                  # handed to the orchestrating thread
+                f.err = e
+                f.state = 'err'
+
+
+def _new_event():
+    ev = C.c_void_p()
+    check(lib.bbx_event_create(C.byref(ev)), 'bbx_event_create')
+    return ev
 
 
 class FramePipeline:
@@ -201,8 +248,9 @@ class FramePipeline:
                  pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=2):
         self.ctx, self.tel, self.geom = ctx, tel, geom
         # stage-C lanes: (context, stream); lane 0 is the caller's context
-        self.lane_ctx = [ctx] + [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
-        self.lane_stream = [torch.cuda.Stream(device=ctx.device) for _ in self.lane_ctx]
+        self.own_ctx = [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
+        self.lane_stream = [torch.cuda.Stream(device=ctx.device) for _ in range(max(1, lanes))]
+        self.lane_ctx = [_LaneCtx(c, st) for c, st in zip([ctx] + self.own_ctx, self.lane_stream)]
         self.mflat, self.bpm = mflat, bpm
         self.mbias = mbias if (mbias is not None and get_par(settings.subtract_mbias, tel)) else None
         self.xtalk = xtalk_coeffs
@@ -213,6 +261,19 @@ class FramePipeline:
         self.do_cosmics, self.do_finish, self.accum = do_cosmics, do_finish, accum
         self.keep_outputs = keep_outputs
         self.sA = torch.cuda.Stream(device=ctx.device)
+        # stage A has a library context of its own: it is driven from the orchestrating thread
+        # while lane 0 (the caller's context) is driven from a lane thread
+        self.own_ctx.append(R.Context(ctx.device.index))
+        self.ctxA = _LaneCtx(self.own_ctx[-1], self.sA)
+        self.lane_thread = [_LaneThread(self, ctx.device) for _ in self.lane_ctx]
+        for t in self.lane_thread:
+            t.start()
+        # outputs: one (data, mask) pair per lane unless the caller keeps them (frames of a lane
+        # are ordered on its stream, so the pair is free again when the next one starts)
+        ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
+        self.lane_out = None if keep_outputs else [
+            (torch.empty((ny, nx), dtype=torch.float32, device=ctx.device),
+             torch.empty((ny, nx), dtype=torch.uint8, device=ctx.device)) for _ in self.lane_ctx]
         self.gain = get_par(settings.gain, tel)
         self.g32 = _lib.f32x16(self.gain)
         g = geom
@@ -245,7 +306,16 @@ class FramePipeline:
                 return t.view(shape) if shape else t
             d_res = torch.zeros(256, dtype=torch.uint8, device=dev)      # std[16] f64 | nobj i32 | stats[16] i32 | cnt[6] i64
             h_res = torch.zeros(256, dtype=torch.uint8, pin_memory=True)
+            h_in_np, h_vo_np = ar.span(i, 'mean', 'ninf'), ar.span(i, 'vfit', 'oscan')
+            h_cnt = torch.empty((2, 16, self.xsz), dtype=torch.int32, pin_memory=True)
+            d_cnt = torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev)
             self.slots.append(dict(
+                evA=_new_event(), evS=_new_event(), evC=_new_event(),
+                # (dst, src, nbytes, kind) of the packed copies, for bbx_copy_async
+                cp_in=(C.c_void_p(h_in_np.ctypes.data), R._ptr(d_in), n_in, 1),
+                cp_vo=(R._ptr(d_vo), C.c_void_p(h_vo_np.ctypes.data), n_vo, 0),
+                cp_res=(R._ptr(h_res), R._ptr(d_res), 256, 1),
+                cp_cnt=(R._ptr(h_cnt), R._ptr(d_cnt), h_cnt.numel() * 4, 1),
                 d_in=d_in, h_in=torch.from_numpy(ar.span(i, 'mean', 'ninf')),
                 d_mean=dv(d_in, 'mean', 'mean', torch.float64),
                 d_hos=dv(d_in, 'mean', 'hos', torch.float32, (16, self.hos_rows, self.dx)),
@@ -258,8 +328,7 @@ class FramePipeline:
                 d_stats=d_res[132:196].view(torch.int32), d_cnt6=d_res[200:248].view(torch.int64),
                 h_std=h_res[0:128].view(torch.float64), h_nobj=h_res[128:132].view(torch.int32),
                 h_stats=h_res[132:196].view(torch.int32), h_cnt6=h_res[200:248].view(torch.int64),
-                h_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, pin_memory=True),
-                d_cnt=torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev)))
+                h_cnt=h_cnt, d_cnt=d_cnt))
         # header keys / comments are the same for every frame
         self._k_bias = [[('BIAS{}A{}'.format(c + 1, k), '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
                          for k in range(settings.voscan_poldeg + 1)] for c in range(16)]
@@ -271,29 +340,38 @@ class FramePipeline:
     def close(self):
         if self.own_pool:
             self.pool.close()
+        for t in self.lane_thread:
+            t.q.put(None)
+        for t in self.lane_thread:
+            t.join()
+        self.lane_thread = []
+        for sl in self.slots:
+            for k in ('evA', 'evS', 'evC'):
+                lib.bbx_event_destroy(sl[k])
         self.slots = []
+        self.lane_out = None
         self.arena.close()
-        for c in self.lane_ctx[1:]:
+        for c in self.own_ctx:
             c.close()
 
     # ---- stage A ------------------------------------------------------------------
     def _start(self, idx, raw, header):
-        ctx, dev = self.ctx, self.ctx.device
+        ctx = self.ctxA
         f = _Frame()
-        f.idx, f.raw, f.header, f.hm, f.t0 = idx, raw, header, {}, time.perf_counter()
+        f.idx, f.raw, f.header, f.hm, f.t0, f.err = idx, raw, header, {}, time.perf_counter(), None
         R.gain_corr(header, self.tel)
         f.slot = self.free_slots.pop()
         f.lane = idx % len(self.lane_ctx)
         sl = self.slots[f.slot]
-        with torch.cuda.stream(self.sA):
-            d_mean, d_hos, d_ninf = sl['d_mean'], sl['d_hos'], sl['d_ninf']
-            check(lib.bbx_overscan_stats(ctx.h, C.byref(self.geom), R._ptr(raw), R.raw_type_of(raw), self.g32,
-                                         R._ptr(d_mean), R._ptr(d_hos), R._ptr(d_ninf), ctx.stream()),
-                  'bbx_overscan_stats', ctx.h)
-            f.h_ninf = sl['h_ninf']
-            sl['h_in'].copy_(sl['d_in'], non_blocking=True)          # mean | hos | ninf in one copy
-            f.evA = torch.cuda.Event()
-            f.evA.record()
+        sA = self.ctxA.sp
+        d_mean, d_hos, d_ninf = sl['d_mean'], sl['d_hos'], sl['d_ninf']
+        check(lib.bbx_overscan_stats(ctx.h, C.byref(self.geom), R._ptr(raw), R.raw_type_of(raw), self.g32,
+                                     R._ptr(d_mean), R._ptr(d_hos), R._ptr(d_ninf), sA),
+              'bbx_overscan_stats', ctx.h)
+        f.h_ninf = sl['h_ninf']
+        check(lib.bbx_copy_async(*sl['cp_in'], sA), 'bbx_copy_async')     # mean | hos | ninf in one copy
+        f.evA = sl['evA']
+        check(lib.bbx_event_record(f.evA, sA), 'bbx_event_record')
         f.state = 'A'
         return f
 
@@ -328,20 +406,20 @@ class FramePipeline:
         f.p1 = results
         lim = settings.os_ypix_lim[self.tel]
         satl = np.array(get_par(settings.satlevel, self.tel)) * np.array(self.gain)
-        with torch.cuda.stream(self.lane_stream[f.lane]):
-            self.lane_stream[f.lane].wait_event(f.evA)
-            sl = self.slots[f.slot]
-            d_vfit = sl['d_vfit']
-            sl['d_vo'].copy_(sl['h_vo'], non_blocking=True)            # vfit (| oscan, not final yet)
-            d_cnt = sl['d_cnt']
-            check(lib.bbx_satcol_counts(ctx.h, C.byref(self.geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
-                                        R._ptr(d_vfit), _lib.f32x16(np.float32(0.9 * satl)), int(lim[0]), int(lim[1]),
-                                        R._ptr(d_cnt), ctx.stream()), 'bbx_satcol_counts', ctx.h)
-            f.h_cnt = sl['h_cnt']
-            f.h_cnt.copy_(d_cnt, non_blocking=True)
-            f.evS = torch.cuda.Event()
-            f.evS.record()
-            f.d_keep = (d_vfit, d_cnt)
+        sp = ctx.sp
+        check(lib.bbx_stream_wait_event(sp, f.evA), 'bbx_stream_wait_event')
+        sl = self.slots[f.slot]
+        d_vfit = sl['d_vfit']
+        check(lib.bbx_copy_async(*sl['cp_vo'], sp), 'bbx_copy_async')     # vfit (| oscan, not final yet)
+        d_cnt = sl['d_cnt']
+        check(lib.bbx_satcol_counts(ctx.h, C.byref(self.geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
+                                    R._ptr(d_vfit), _lib.f32x16(np.float32(0.9 * satl)), int(lim[0]), int(lim[1]),
+                                    R._ptr(d_cnt), sp), 'bbx_satcol_counts', ctx.h)
+        f.h_cnt = sl['h_cnt']
+        check(lib.bbx_copy_async(*sl['cp_cnt'], sp), 'bbx_copy_async')
+        f.evS = sl['evS']
+        check(lib.bbx_event_record(f.evS, sp), 'bbx_event_record')
+        f.d_keep = (d_vfit, d_cnt)
         f.state = 'S'
 
     def _submit_phase2(self, f):
@@ -353,45 +431,48 @@ class FramePipeline:
 
     # ---- stage C ------------------------------------------------------------------
     def _device_stage(self, f, results):
-        ctx, dev, geom, tel = self.lane_ctx[f.lane], self.ctx.device, self.geom, self.tel
-        sC = self.lane_stream[f.lane]
+        ctx, geom, tel = self.lane_ctx[f.lane], self.geom, self.tel
+        sp = ctx.sp
         self._fill_header_vos(f, results)
         dlevel = np.float32([r['dlevel'] for r in results])
         h, hm = f.header, f.hm
-        with torch.cuda.stream(sC):
-            sC.wait_event(f.evA)
-            sol = R.OverscanSolution()
-            sl = self.slots[f.slot]
-            sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
-            sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
-            sl['d_vo'].copy_(sl['h_vo'], non_blocking=True)            # vfit | oscan in one copy
-            d_std = sl['d_std']
-            check(lib.bbx_vos_std(ctx.h, C.byref(geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
-                                  R._ptr(sol.d_vfit), _lib.f32x16(dlevel), R._ptr(d_std), ctx.stream()),
-                  'bbx_vos_std', ctx.h)
+        check(lib.bbx_stream_wait_event(sp, f.evA), 'bbx_stream_wait_event')
+        sol = R.OverscanSolution()
+        sl = self.slots[f.slot]
+        sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
+        sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
+        check(lib.bbx_copy_async(*sl['cp_vo'], sp), 'bbx_copy_async')     # vfit | oscan in one copy
+        d_std = sl['d_std']
+        check(lib.bbx_vos_std(ctx.h, C.byref(geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
+                              R._ptr(sol.d_vfit), _lib.f32x16(dlevel), R._ptr(d_std), sp),
+              'bbx_vos_std', ctx.h)
+        if self.lane_out is not None:
+            out = self.lane_out[f.lane]
             data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat,
-                                     bpm=self.bpm)
-            d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom, d_n=sl['d_nobj'])
-            d_stats = None
-            if self.do_cosmics:
-                # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
-                d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std, d_stats=sl['d_stats'])
-            if self.do_finish:
-                if self.xtalk is not None:
-                    R.xtalk_corr(ctx, data, self.xtalk, mask, geom)
-                d_cnt = sl['d_cnt6']
-                check(lib.bbx_mask_counts(ctx.h, mask.numel(), R._ptr(mask), R._ptr(d_cnt), ctx.stream()),
-                      'bbx_mask_counts', ctx.h)
-                R.edge_fill(ctx, data, mask, geom)
-            else:
-                d_cnt = sl['d_cnt6']
-            # scalar results: one small pinned D2H of the packed record
-            f.h_out = (sl['h_std'], sl['h_nobj'], sl['h_stats'], sl['h_cnt6'])
-            sl['h_res'].copy_(sl['d_res'], non_blocking=True)
-            f.evC = torch.cuda.Event()
-            f.evC.record()
-            f.d_keep = (sol, d_std, d_nobj, d_stats, d_cnt)
-            f.data, f.mask = (data, mask) if self.keep_outputs else (None, None)
+                                     bpm=self.bpm, out=out)
+        else:
+            with torch.cuda.stream(ctx.torch_stream):                 # the allocations belong to the lane's stream
+                data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat,
+                                         bpm=self.bpm)
+        d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom, d_n=sl['d_nobj'])
+        d_stats = None
+        if self.do_cosmics:
+            # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
+            d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std, d_stats=sl['d_stats'])
+        d_cnt = sl['d_cnt6']
+        if self.do_finish:
+            if self.xtalk is not None:
+                R.xtalk_corr(ctx, data, self.xtalk, mask, geom)
+            check(lib.bbx_mask_counts(ctx.h, mask.numel(), R._ptr(mask), R._ptr(d_cnt), sp),
+                  'bbx_mask_counts', ctx.h)
+            R.edge_fill(ctx, data, mask, geom)
+        # scalar results: one small pinned D2H of the packed record
+        f.h_out = (sl['h_std'], sl['h_nobj'], sl['h_stats'], sl['h_cnt6'])
+        check(lib.bbx_copy_async(*sl['cp_res'], sp), 'bbx_copy_async')
+        f.evC = sl['evC']
+        check(lib.bbx_event_record(f.evC, sp), 'bbx_event_record')
+        f.d_keep = (sol, d_std, d_nobj, d_stats, d_cnt)
+        f.data, f.mask = (data, mask) if self.keep_outputs else (None, None)
         f.state = 'C'
 
     def _finalize(self, f):
@@ -426,26 +507,27 @@ class FramePipeline:
                 live.append(self._start(idx, raw, header))
                 progressed = True
             for f in live:
-                if f.state == 'A' and f.evA.query():
+                if f.state == 'A' and lib.bbx_event_query(f.evA) == 1:
                     f.tA = time.perf_counter()
                     self._submit_fits(f)
                     progressed = True
                 elif f.state == 'B' and f.res.ready():
                     f.tB = time.perf_counter()
                     results = f.res.get()
-                    if self.two_phase:
-                        self._satcol(f, results)
-                    else:
-                        self._device_stage(f, results)
+                    f.state = 'Q'                                  # queued at its lane
+                    self.lane_thread[f.lane].q.put((self._satcol if self.two_phase else self._device_stage, f, results))
                     progressed = True
-                elif f.state == 'S' and f.evS.query():
+                elif f.state == 'S' and lib.bbx_event_query(f.evS) == 1:
                     self._submit_phase2(f)
                     progressed = True
                 elif f.state == 'B2' and f.res2.ready():
                     f.res2.get()
-                    self._device_stage(f, f.p1)
+                    f.state = 'Q'
+                    self.lane_thread[f.lane].q.put((self._device_stage, f, f.p1))
                     progressed = True
-                elif f.state == 'C' and f.evC.query():
+                elif f.state == 'err':
+                    raise f.err
+                elif f.state == 'C' and lib.bbx_event_query(f.evC) == 1:
                     f.tC = time.perf_counter()
                     self.t_stats[0] += f.tA - f.t0
                     self.t_stats[1] += f.tB - f.tA
@@ -463,6 +545,6 @@ class FramePipeline:
                 break
             if not progressed:
                 time.sleep(0.0002)
-        for c, st in zip(self.lane_ctx, self.lane_stream):
-            check(lib.bbx_sync(c.h, C.c_void_p(st.cuda_stream)), 'bbx_sync', c.h)
+        for c in self.lane_ctx:
+            c.sync()
         return ndone

@@ -225,9 +225,10 @@ def satlevels(header, tel):
 _SATLEV_KEYS = [('SATLEV{}'.format(c + 1), '[e-] channel {} saturation threshold'.format(c + 1)) for c in range(16)]
 
 
-def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=None, bpm=None):
+def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=None, bpm=None, out=None):
     """gain + overscan + crop (+ master bias) + first half of mask_init (+ master
-    flat) in one pass -> (data float32, mask uint8) device tensors"""
+    flat) in one pass -> (data float32, mask uint8) device tensors; out: optional
+    (data, mask) pair to write into instead of allocating"""
     dev = ctx.device
     ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
     if tuple(raw.shape) != (geom.ny_raw, geom.nx_raw) or not raw.is_contiguous() or not raw.is_cuda:
@@ -237,8 +238,13 @@ def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=N
     header_mask['SATURATE'] = header['SATURATE'] = (float(np.mean(sat)), '[e-] mean saturation threshold')
     for c, (key, comment) in enumerate(_SATLEV_KEYS):
         header[key] = header_mask[key] = (round(float(sat[c]), 1), comment)
-    data = torch.empty((ny, nx), dtype=torch.float32, device=dev)
-    mask = torch.empty((ny, nx), dtype=torch.uint8, device=dev)
+    if out is not None:
+        data, mask = out
+        _expect(data, torch.float32, (ny, nx), 'out data')
+        _expect(mask, torch.uint8, (ny, nx), 'out mask')
+    else:
+        data = torch.empty((ny, nx), dtype=torch.float32, device=dev)
+        mask = torch.empty((ny, nx), dtype=torch.uint8, device=dev)
     for t, name, dt in ((mbias, 'master bias', torch.float32), (mflat, 'master flat', torch.float32),
                         (bpm, 'bad pixel mask', torch.uint8)):
         if t is not None and (t.dtype != dt or tuple(t.shape) != (ny, nx) or not t.is_contiguous()):

@@ -73,6 +73,20 @@ int  bbx_version(void);
  * (list overflow, non-convergence).  Call before trusting host copies. */
 int  bbx_sync(bbx_ctx *ctx, void *stream);
 
+/* Stream plumbing for a host that pipelines frames (the reference runs one frame per worker
+ * process, blackbox.py:640-700 pool_func; here one process keeps several frames in flight on
+ * HIP streams).  Thin wrappers -- hipEvent without timing, hipStreamWaitEvent,
+ * hipMemcpyAsync -- so the per-frame loop does not pay an ML runtime's bookkeeping per call.
+ * bbx_event_query: 1 = complete, 0 = not yet, < 0 = BBX_ERR_*.
+ * bbx_copy_async kind: 0 host->device, 1 device->host, 2 device->device; host memory should be
+ * pinned (hipHostMalloc / hipHostRegister) for the copy to be asynchronous. */
+int  bbx_event_create(void **out_event);
+void bbx_event_destroy(void *event);
+int  bbx_event_record(void *event, void *stream);
+int  bbx_event_query(void *event);
+int  bbx_stream_wait_event(void *stream, void *event);
+int  bbx_copy_async(void *dst, const void *src, size_t nbytes, int kind, void *stream);
+
 /* per-kernel timing: when enabled, the library brackets its main kernels with hipEvents
  * on the launch stream (the reference logs wall time per stage with log_timing_memory,
  * e.g. blackbox.py:4366-4367).  Slots: */
