@@ -15,7 +15,7 @@ all: $(LIB) $(HOSTLIB)
 
 # host-side C helpers of the overscan solve (same float operations as the numpy code)
 $(HOSTLIB): blackbox_amd/chost/bbx_host.c
-	gcc -O2 -fPIC -shared -ffp-contract=off -o $@ $< -lm
+	gcc -O3 -fPIC -shared -ffp-contract=off -fno-trapping-math -fno-math-errno -o $@ $< -lm
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h $(CSRC)/bbx_bsel.h include/bbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -11,61 +11,106 @@
 /* overscan.hos_column_stats(data_hos, mask_hos, accum='f32seq'):
  * data [nrow][ncol] float32, mask [nrow][ncol] uint8 (non-zero = masked)
  * -> n [ncol] int64, mean [ncol] float32, std [ncol] float32 */
-int bbx_hos_column_stats_f32seq(const float *data, const uint8_t *mask, int nrow, int ncol, int64_t *n_out,
-                                float *mean_out, float *std_out) {
-    if (nrow < 1 || nrow > 4096) return -1;
-    uint8_t *ok = (uint8_t *)malloc((size_t)nrow), *cur = (uint8_t *)malloc((size_t)nrow);
-    if (!ok || !cur) { free(ok); free(cur); return -3; }
-    for (int x = 0; x < ncol; x++) {
-        double lo = NAN, hi = NAN;
-        for (int i = 0; i < nrow; i++) {
-            const double d = (double)data[(size_t)i * ncol + x];
-            ok[i] = (uint8_t)(isfinite(d) && !mask[(size_t)i * ncol + x]);
-            cur[i] = ok[i];
-        }
-        for (int it = 0; it < 5; it++) {
-            int64_t n = 0;
-            double s = 0.0;
-            for (int i = 0; i < nrow; i++) {
-                const double d = (double)data[(size_t)i * ncol + x];
-                const double t = cur[i] ? d : 0.0;
-                s = (i == 0) ? t : s + t;                      /* add.reduce over axis 0: row 0 first */
-                n += cur[i];
-            }
-            const double mean = s / (double)n;
-            double q = 0.0;
-            for (int i = 0; i < nrow; i++) {
-                const double d = (double)data[(size_t)i * ncol + x];
-                const double dev = cur[i] ? (mean - d) : 0.0;
-                const double t = dev * dev;
-                q = (i == 0) ? t : q + t;
-            }
-            const double sd = sqrt(q / (double)n);
-            if (n > 0) { lo = mean - 2.5 * sd; hi = mean + 2.5 * sd; }
-            for (int i = 0; i < nrow; i++) {
-                const double d = (double)data[(size_t)i * ncol + x];
-                cur[i] = (uint8_t)(cur[i] && d >= lo && d <= hi);
-            }
-        }
-        int64_t n = 0;
-        for (int i = 0; i < nrow; i++) {
-            const double d = (double)data[(size_t)i * ncol + x];
-            ok[i] = (uint8_t)(ok[i] && !(d < lo) && !(d > hi));
-            n += ok[i];
-        }
-        float tot = 0.0f;
-        for (int i = 0; i < nrow; i++) tot = tot + (ok[i] ? data[(size_t)i * ncol + x] : 0.0f);
-        const float mean = tot / (float)n;
-        float tot2 = 0.0f;
-        for (int i = 0; i < nrow; i++) {
-            const float dev = ok[i] ? (data[(size_t)i * ncol + x] - mean) : 0.0f;
-            tot2 = tot2 + dev * dev;
-        }
-        n_out[x] = n;
-        mean_out[x] = mean;
-        std_out[x] = sqrtf(tot2 / (float)(n - 1));
+/* (loads are unconditional and the selects written on values, so that gcc if-converts and
+ * vectorises the column loops; the clones pick AVX2 at load time where the CPU has it) */
+__attribute__((target_clones("avx2", "default")))
+int bbx_hos_column_stats_f32seq(const float *restrict data, const uint8_t *restrict mask, int nrow, int ncol,
+                                int64_t *restrict n_out, float *restrict mean_out, float *restrict std_out) {
+    if (nrow < 1 || nrow > 4096 || ncol < 1) return -1;
+    /* Rows outside, columns inside: every column still sees its rows in order 0..nrow-1 (the
+     * order of numpy's reduction over axis 0), and the inner loops run along memory.
+     * Masks are kept as 0.0 / 1.0 doubles (cur, ok) next to the data converted once. */
+    const size_t nc = (size_t)ncol, np_ = (size_t)nrow * nc;
+    /* scratch kept per thread between calls (a few hundred KB: malloc would mmap and fault it in every time) */
+    static __thread void *scratch = 0;
+    static __thread size_t scratch_bytes = 0;
+    const size_t wbytes = (3 * np_ + 6 * nc) * sizeof(double), fbytes = (3 * nc + np_) * sizeof(float);
+    if (scratch_bytes < wbytes + fbytes) {
+        free(scratch);
+        scratch = malloc(wbytes + fbytes);
+        scratch_bytes = scratch ? wbytes + fbytes : 0;
+        if (!scratch) return -3;
     }
-    free(ok); free(cur);
+    double *restrict w = (double *)scratch;
+    float *restrict fw = (float *)((char *)scratch + wbytes);
+    double *restrict dd = w, *restrict cur = w + np_, *restrict ok = w + 2 * np_;
+    double *restrict lo = w + 3 * np_, *restrict hi = lo + nc, *restrict s = lo + 2 * nc, *restrict q = lo + 3 * nc,
+           *restrict mean = lo + 4 * nc, *restrict cnt = lo + 5 * nc;
+    for (size_t x = 0; x < nc; x++) { lo[x] = NAN; hi[x] = NAN; }
+    for (size_t k = 0; k < np_; k++) {
+        const double d = (double)data[k];
+        const double fin = (d - d == 0.0) ? 1.0 : 0.0;             /* finite <=> d - d == 0 */
+        const double v = mask[k] ? 0.0 : fin;
+        dd[k] = d; ok[k] = v; cur[k] = v;
+    }
+    for (int it = 0; it < 5; it++) {
+        for (size_t x = 0; x < nc; x++) { const double c = cur[x], d = dd[x]; s[x] = (c != 0.0) ? d : 0.0; cnt[x] = c; }
+        for (int i = 1; i < nrow; i++) {
+            const double *restrict dr = dd + (size_t)i * nc; const double *restrict cr = cur + (size_t)i * nc;
+            for (size_t x = 0; x < nc; x++) {
+                const double c = cr[x], d = dr[x];
+                const double t = (c != 0.0) ? d : 0.0;
+                s[x] = s[x] + t; cnt[x] = cnt[x] + c;
+            }
+        }
+        for (size_t x = 0; x < nc; x++) mean[x] = s[x] / cnt[x];
+        for (size_t x = 0; x < nc; x++) {
+            const double c = cur[x], d = dd[x];
+            const double dev0 = mean[x] - d, dev = (c != 0.0) ? dev0 : 0.0;
+            q[x] = dev * dev;
+        }
+        for (int i = 1; i < nrow; i++) {
+            const double *restrict dr = dd + (size_t)i * nc; const double *restrict cr = cur + (size_t)i * nc;
+            for (size_t x = 0; x < nc; x++) {
+                const double c = cr[x], d = dr[x];
+                const double dev0 = mean[x] - d, dev = (c != 0.0) ? dev0 : 0.0;
+                q[x] = q[x] + dev * dev;
+            }
+        }
+        for (size_t x = 0; x < nc; x++) {
+            const double sd = sqrt(q[x] / cnt[x]);
+            const double nlo = mean[x] - 2.5 * sd, nhi = mean[x] + 2.5 * sd;
+            const int upd = cnt[x] > 0.0;
+            lo[x] = upd ? nlo : lo[x]; hi[x] = upd ? nhi : hi[x];
+        }
+        for (int i = 0; i < nrow; i++) {
+            const double *restrict dr = dd + (size_t)i * nc; double *restrict cr = cur + (size_t)i * nc;
+            for (size_t x = 0; x < nc; x++) {
+                const double d = dr[x];
+                const int in = (d >= lo[x]) & (d <= hi[x]);
+                cr[x] = in ? cr[x] : 0.0;
+            }
+        }
+    }
+    /* final statistics in float32, rows in order */
+    float *restrict tot = fw, *restrict tot2 = fw + nc, *restrict fm = fw + 2 * nc, *restrict okf = fw + 3 * nc;
+    for (size_t x = 0; x < nc; x++) { tot[x] = 0.0f; tot2[x] = 0.0f; cnt[x] = 0.0; }
+    for (int i = 0; i < nrow; i++) {
+        const double *restrict dr = dd + (size_t)i * nc; const double *restrict orow = ok + (size_t)i * nc;
+        const float *restrict fr = data + (size_t)i * nc; float *restrict of = okf + (size_t)i * nc;
+        for (size_t x = 0; x < nc; x++) {
+            const double d = dr[x];
+            const int out = (d < lo[x]) | (d > hi[x]);
+            const double o = out ? 0.0 : orow[x];
+            const float f = fr[x];
+            cnt[x] = cnt[x] + o;
+            tot[x] = tot[x] + ((o != 0.0) ? f : 0.0f);
+            of[x] = (float)o;
+        }
+    }
+    for (size_t x = 0; x < nc; x++) fm[x] = tot[x] / (float)cnt[x];
+    for (int i = 0; i < nrow; i++) {
+        const float *restrict fr = data + (size_t)i * nc; const float *restrict of = okf + (size_t)i * nc;
+        for (size_t x = 0; x < nc; x++) {
+            const float dev0 = fr[x] - fm[x], dev = (of[x] != 0.0f) ? dev0 : 0.0f;
+            tot2[x] = tot2[x] + dev * dev;
+        }
+    }
+    for (size_t x = 0; x < nc; x++) {
+        n_out[x] = (int64_t)cnt[x];
+        mean_out[x] = fm[x];
+        std_out[x] = sqrtf(tot2[x] / (float)(cnt[x] - 1.0));
+    }
     return 0;
 }
 
@@ -103,5 +148,30 @@ int64_t bbx_clipped_stats_flat_f32seq(const float *values, int64_t n, double sig
     }
     out[0] = (double)mean; out[1] = (double)sd;
     free(v);
+    return m;
+}
+
+/* overscan.polyfit_exact, the part before LAPACK: rows of the cached Vandermonde matrix V
+ * [n][order] picked by mask -> lhs [m][order] with every column divided by its Euclidean norm
+ * (scale[order]; squares summed row by row like numpy's sum over axis 0).  Returns m. */
+int64_t bbx_polyfit_prep(const double *restrict V, const uint8_t *restrict mask, int64_t n, int order,
+                         double *restrict lhs, double *restrict scale) {
+    if (order < 1 || order > 16 || n < 0) return -1;
+    double acc[16];
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (!mask[i]) continue;
+        const double *restrict r = V + i * order;
+        double *restrict o = lhs + m * order;
+        if (m == 0) for (int j = 0; j < order; j++) { o[j] = r[j]; acc[j] = r[j] * r[j]; }
+        else for (int j = 0; j < order; j++) { o[j] = r[j]; acc[j] = acc[j] + r[j] * r[j]; }
+        m++;
+    }
+    if (m == 0) { for (int j = 0; j < order; j++) scale[j] = 0.0; return 0; }
+    for (int j = 0; j < order; j++) scale[j] = sqrt(acc[j]);
+    for (int64_t i = 0; i < m; i++) {
+        double *restrict o = lhs + i * order;
+        for (int j = 0; j < order; j++) o[j] = o[j] / scale[j];
+    }
     return m;
 }

@@ -32,6 +32,8 @@ try:
                                                   _C.c_void_p]
     _HOST.bbx_clipped_stats_flat_f32seq.restype = _C.c_int64
     _HOST.bbx_clipped_stats_flat_f32seq.argtypes = [_C.c_void_p, _C.c_int64, _C.c_double, _C.c_int, _C.c_void_p]
+    _HOST.bbx_polyfit_prep.restype = _C.c_int64
+    _HOST.bbx_polyfit_prep.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_int, _C.c_void_p, _C.c_void_p]
 except OSError:
     _HOST = None
 
@@ -110,11 +112,20 @@ def polyfit_exact(start, n, mask, y, deg):
     the Vandermonde matrix and without np.polyfit's argument handling.
     -> (coefficients high -> low order, rank)"""
     order = deg + 1
-    lhs = _vander_full(start, n, order)[mask]
+    V = _vander_full(start, n, order)
     rhs = np.asarray(y) + 0.0
+    if _HOST is not None and rhs.size > 0:
+        mk = np.ascontiguousarray(mask, dtype=np.uint8)
+        lhs = np.empty((rhs.size, order))
+        scale = np.empty(order)
+        m = _HOST.bbx_polyfit_prep(V.ctypes.data, mk.ctypes.data, n, order, lhs.ctypes.data, scale.ctypes.data)
+        if m != rhs.size:
+            raise ValueError('polyfit_exact: {} ordinates for {} selected abscissae'.format(rhs.size, m))
+    else:
+        lhs = V[mask]
+        scale = np.sqrt((lhs * lhs).sum(axis=0))
+        lhs /= scale
     rcond = lhs.shape[0] * np.finfo(np.float64).eps
-    scale = np.sqrt((lhs * lhs).sum(axis=0))
-    lhs /= scale
     c, _, rank, _ = np.linalg.lstsq(lhs, rhs, rcond)
     c = (c.T / scale).T
     return c, rank
@@ -326,7 +337,10 @@ def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
             p, _ = polyfit_exact(1, ncols, mask_fit, mean_hos[mask_fit], deg)
             fit = np.polyval(p, xcol)
             with np.errstate(invalid='ignore'):
-                mask_fit &= np.abs(fit - mean_hos) <= err3
+                new_mask = mask_fit & (np.abs(fit - mean_hos) <= err3)
+            if np.array_equal(new_mask, mask_fit):
+                break                       # the same points again: the next fit would be this one
+            mask_fit[:] = new_mask
         return fit
 
     if not bg2_chan9:

@@ -49,12 +49,13 @@ def cpu_budget():
 
 def default_workers():
     """fit workers per GPU process: the host fits are the CPU-side cost of a frame
-    (~20 ms of one core), so take the budget minus the orchestrating thread and the HIP
-    runtime's helper thread; BBX_HOST_WORKERS overrides"""
+    (~11 ms of one core) and, next to the GPU, what bounds the frame rate, so take the budget
+    minus two (orchestrating and lane threads spend most of their time inside HIP calls; 14 of
+    16 cores measured best on a one-GPU box); BBX_HOST_WORKERS overrides"""
     if 'BBX_HOST_WORKERS' in os.environ:
         return max(1, int(os.environ['BBX_HOST_WORKERS']))
     world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
-    return max(2, min(12, cpu_budget() // max(1, world) - 2))
+    return max(2, min(14, cpu_budget() // max(1, world) - 2))
 
 
 class HostPool:
@@ -63,6 +64,7 @@ class HostPool:
 
     def __init__(self, nworkers=None):
         self.n = nworkers or default_workers()
+        self.chunk = max(1, int(os.environ.get('BBX_HOST_CHUNK', '4')))
         # one BLAS/OpenMP thread per worker: the fits are tiny, thread pools only fight each other
         saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
         for k in saved:
@@ -79,7 +81,10 @@ class HostPool:
         self.pool.map(_noop, range(self.n * 2))
 
     def submit(self, fn, tasks):
-        return self.pool.map_async(fn, tasks, chunksize=1)
+        # several channels per message: with one task per message the pool's feeder / result
+        # threads in this process (pickling, pipe I/O, all under the GIL) become the limit at
+        # ~14k tasks/s; BBX_HOST_CHUNK overrides
+        return self.pool.map_async(fn, tasks, chunksize=self.chunk)
 
     def close(self):
         self.pool.close()                   # workers exit after their queue drains (no SIGTERM)
