@@ -49,13 +49,13 @@ def cpu_budget():
 
 def default_workers():
     """fit workers per GPU process: the host fits are the CPU-side cost of a frame
-    (~11 ms of one core) and, next to the GPU, what bounds the frame rate, so take the budget
-    minus two (orchestrating and lane threads spend most of their time inside HIP calls; 14 of
-    16 cores measured best on a one-GPU box); BBX_HOST_WORKERS overrides"""
+    (~7 ms of one core), the orchestrating and lane threads need the rest of the budget for
+    their HIP calls (12 of 16 cores measured best on a one-GPU box: 12/13/14 workers gave
+    1160/1120/1030 frames/s); BBX_HOST_WORKERS overrides"""
     if 'BBX_HOST_WORKERS' in os.environ:
         return max(1, int(os.environ['BBX_HOST_WORKERS']))
     world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
-    return max(2, min(14, cpu_budget() // max(1, world) - 2))
+    return max(2, min(12, cpu_budget() // max(1, world) - 2))
 
 
 class HostPool:
