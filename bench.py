@@ -135,14 +135,14 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=120)
-    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=240)
+    ap.add_argument('--warmup', type=int, default=12)
     ap.add_argument('--raw', default='u16', choices=['u16', 'f32'])
     ap.add_argument('--small', action='store_true', help='reduced geometry (debug)')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--depth', type=int, default=12, help='frames in flight')
+    ap.add_argument('--depth', type=int, default=18, help='frames in flight')
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
-    ap.add_argument('--lanes', type=int, default=2, help='stage-C lanes (context + stream) per GPU')
+    ap.add_argument('--lanes', type=int, default=6, help='stage-C lanes (context + stream + issuing thread) per GPU')
     args = ap.parse_args()
 
     import torch
@@ -254,8 +254,8 @@ def main():
             'k_lac_cand': (1, 4 * N + N),        # the one dense LA-Cosmic pass: data + mask (it also feeds the background select)
         }
         # Kernel durations: HIP events recorded by the library around each launch, on the launch
-        # stream.  With two stage-C lanes an event pair in the timed region also spans the time the
-        # kernel waits behind the other lane's kernel (rocprofv3 shows the execution time itself
+        # stream.  With several stage-C lanes an event pair in the timed region also spans the time the
+        # kernel waits behind the other lanes' kernels (rocprofv3 shows the execution time itself
         # is unchanged), so the roofline uses the event pairs of the serial frames run in this
         # process just before the timed region (one lane, nothing else in flight) -- those agree
         # with the rocprofv3 --kernel-trace average of this command -- and the timed-region
@@ -273,7 +273,7 @@ def main():
         roof['timing'] = 'HIP events around each launch, serial frames in this process (kernels alone on the GPU)'
         roof['timed_region'] = {k: dict(avg_event_interval_ms=live[k][0], launches=int(live[k][2]),
                                         frac=live[k][1] / (live[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        note='includes queueing behind the other stage-C lane') for k in live}
+                                        note='lane 0 only; includes queueing behind the other stage-C lanes') for k in live}
         # HBM traffic per launch from the committed rocprofv3 --pmc passes of this command
         # (profiles/r01_pmc_traffic.json: FETCH_SIZE/WRITE_SIZE, gfx950 correction applied)
         try:
