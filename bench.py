@@ -254,26 +254,29 @@ def main():
             'k_lac_cand': (1, 4 * N + N),        # the one dense LA-Cosmic pass: data + mask (it also feeds the background select)
         }
         # Kernel durations: HIP events recorded by the library around each launch, on the launch
-        # stream.  With several stage-C lanes an event pair in the timed region also spans the time the
-        # kernel waits behind the other lanes' kernels (rocprofv3 shows the execution time itself
-        # is unchanged), so the roofline uses the event pairs of the serial frames run in this
-        # process just before the timed region (one lane, nothing else in flight) -- those agree
-        # with the rocprofv3 --kernel-trace average of this command -- and the timed-region
-        # figures are given beside them.
-        per = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items()}
+        # stream (lane 0's context carries the timers, so one frame in [lanes] is sampled).  The
+        # roofline uses the event pairs of the timed region: the kernel shares the GPU with the
+        # other lanes' kernels there, and the rocprofv3 --kernel-trace average of this command
+        # shows the same duration.  `isolated` gives the same kernels from the serial frames run
+        # in this process just before the timed region (one stream, nothing else in flight):
+        # that is the kernel's own efficiency, the timed-region figure its share of a busy GPU.
+        iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items()}
         live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items()}
-        frame_ms = {k: per[k][0] for k in kern}          # both run once per frame
-        dom = max(frame_ms, key=frame_ms.get)
-        avg_ms, by, ncall = per[dom]
-        roof = dict(bound='hbm', kernel=dom, achieved=by / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+        dom = max(live, key=lambda k: live[k][0])          # both run once per frame
+        avg_ms, by, ncall = live[dom]
+
+        def gbs(t):
+            return t[1] / (t[0] * 1e-3) / 1e9
+        roof = dict(bound='hbm', kernel=dom, achieved=gbs(live[dom]), peak=HBM_PEAK_GBS, unit='GB/s',
                     avg_launch_ms=avg_ms, launches=int(ncall), bytes_per_launch=by, traffic=None,
-                    others={k: dict(avg_launch_ms=per[k][0], achieved=per[k][1] / (per[k][0] * 1e-3) / 1e9,
-                                    frac=per[k][1] / (per[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) for k in per if k != dom})
+                    others={k: dict(avg_launch_ms=live[k][0], achieved=gbs(live[k]), frac=gbs(live[k]) / HBM_PEAK_GBS)
+                            for k in live if k != dom})
         roof['frac'] = roof['achieved'] / roof['peak']
-        roof['timing'] = 'HIP events around each launch, serial frames in this process (kernels alone on the GPU)'
-        roof['timed_region'] = {k: dict(avg_event_interval_ms=live[k][0], launches=int(live[k][2]),
-                                        frac=live[k][1] / (live[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        note='lane 0 only; includes queueing behind the other stage-C lanes') for k in live}
+        roof['timing'] = ('HIP events around each launch on the launch stream, timed region, lane 0 of %d '
+                          '(other lanes\' kernels run concurrently)' % args.lanes)
+        roof['isolated'] = {k: dict(avg_launch_ms=iso[k][0], launches=int(iso[k][2]), achieved=gbs(iso[k]),
+                                    frac=gbs(iso[k]) / HBM_PEAK_GBS,
+                                    note='serial frames, kernel alone on the GPU') for k in iso}
         # HBM traffic per launch from the committed rocprofv3 --pmc passes of this command
         # (profiles/r01_pmc_traffic.json: FETCH_SIZE/WRITE_SIZE, gfx950 correction applied)
         try:
