@@ -62,6 +62,9 @@ SIGNATURES = {
     'bbx_fpack_tiles': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_fpack_gather': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_funpack_tiles': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    'bbx_coadd_prep': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'bbx_resample_lanczos3': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    'bbx_coadd_combine': (_i, [_vp, _i, C.c_int64, _vp, _vp, C.c_int64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_model': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'bbx_rect_scale': (_i, [_vp, _i, _i, _i, _vp, _f, _i, _vp]),
     'bbx_nonlin_set': (_i, [_vp, _i, C.POINTER(C.c_int32), _pd, _pd]),

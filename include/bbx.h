@@ -182,6 +182,47 @@ int bbx_rect_clipped_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float
 int bbx_rect_scale(bbx_ctx *ctx, int ny, int nx, int stride, float *d_data, float factor,
                    int divide, void *stream);
 
+/* ---- f3: reference co-add (buildref.py) ----------------------------------------------
+ * bbx_coadd_prep replaces the array arithmetic of prep_inputimages (buildref.py:2602-2624,
+ * 2709-2733): d_data -= d_bkg (d_bkg may be NULL: image already background-subtracted);
+ * d_data[mask == edge_value] = 0; d_weights = 1 / d_bkg_std**2 where d_bkg_std != 0, else 0,
+ * and 0 where (mask & discard_bits) != 0 (pass discard_bits = 0 for a single image, as the
+ * reference only discards when len(imtable) > 1).  float32 throughout, bit-identical to numpy.
+ *
+ * bbx_resample_lanczos3 replaces SWarp's resampling step (-RESAMPLING_TYPE LANCZOS3,
+ * buildref.py:1748): for each output pixel the input position comes from the bilinear
+ * interpolation (float64) of d_grid [gny][gnx][2] = exact (x, y) input coordinates (0-based
+ * pixel centres) at output pixels (j*gstep, i*gstep) -- SWarp evaluates the projection on such
+ * a lattice too; the grid must extend one node past the last output pixel.  Data: 6x6
+ * normalised LANCZOS3 taps times fscale (-FSCALE_KEYWORD); weights travel as variances through
+ * the same kernel (x fscale^2); a footprint that leaves the input or holds a zero-weight pixel
+ * gives weight 0.
+ *
+ * bbx_coadd_combine replaces SWarp's -COMBINE_TYPE step (buildref.py:1733, 1815) over n <= 32
+ * resampled planes d_cube / d_wcube [n][plane_stride]: pixels with weight > 0 take part;
+ * float64 sums in plane order.  CLIPPED (Gruen et al. 2014, -CLIP_SIGMA / -CLIP_AMPFRAC,
+ * buildref.py:1780-1788): values further than clip_sigma*sqrt(1/w) + clip_ampfrac*|median|
+ * from the median of the valid values are dropped, then WEIGHTED; d_clipmask [n][npix] (1 =
+ * dropped) and d_nclip [n] take SWarp's clip log (-CLIP_WRITELOG), both optional.           */
+#define BBX_COMBINE_WEIGHTED 0
+#define BBX_COMBINE_AVERAGE  1
+#define BBX_COMBINE_MEDIAN   2
+#define BBX_COMBINE_CLIPPED  3
+#define BBX_COMBINE_MIN      4
+#define BBX_COMBINE_MAX      5
+#define BBX_COMBINE_SUM      6
+int bbx_coadd_prep(bbx_ctx *ctx, int64_t npix, float *d_data, const float *d_bkg,
+                   const float *d_bkg_std, const uint8_t *d_mask, int discard_bits,
+                   int edge_value, float *d_weights, void *stream);
+int bbx_resample_lanczos3(bbx_ctx *ctx, int in_ny, int in_nx, const float *d_in,
+                          const float *d_win, int out_ny, int out_nx, const double *d_grid,
+                          int gny, int gnx, int gstep, float fscale, float *d_out,
+                          float *d_wout, void *stream);
+int bbx_coadd_combine(bbx_ctx *ctx, int n, int64_t npix, const float *d_cube,
+                      const float *d_wcube, int64_t plane_stride, int combine_type,
+                      float clip_sigma, float clip_ampfrac, float *d_out, float *d_wout,
+                      uint8_t *d_clipmask, int64_t *d_nclip, void *stream);
+
 /* ---- f2: FITS tile compression (fpack, blackbox.py:812-857) ------------------------
  * RICE_1, one tile per image row, block size 32; float32 images are quantised like CFITSIO's
  * fits_quantize_float with SUBTRACTIVE_DITHER_1 (noise from the 2nd/3rd/5th order MAD of the
