@@ -51,27 +51,33 @@ __global__ __launch_bounds__(256) void k_coadd_prep(float* __restrict__ data, co
 // ---------------------------------------------------------------------------------
 // LANCZOS3 resampling
 // ---------------------------------------------------------------------------------
-// taps ix-2 .. ix+3 for a position ix + f: k(t) = sinc(t) sinc(t/3), t = f - i, normalised to
-// unit sum; float64, rounded to float32 at the end (oracle/coadd.py lanczos3_taps)
-__device__ __forceinline__ void l3_taps(double f, float* k) {
-    double v[6], sum = 0.0;
+// taps ix-2 .. ix+3 for a position ix + f (0 <= f < 1): k(t) = sinc(t) sinc(t/3), t = f - i,
+// normalised to unit sum (oracle/coadd.py lanczos3_taps).  sin(pi t) = +-sin(pi f) and
+// sin(pi t/3) = sin(pi f/3 - i pi/3) by the addition theorem: three sinpi/cospi calls per axis
+// instead of twelve sines.  Single precision like SWarp's kernels: the taps agree with the
+// float64 oracle to a few 1e-7, which is the tolerance of the resampling tests.
+__device__ __forceinline__ void l3_taps(float f, float* k) {
+    const float s1 = sinpif(f), s3 = sinpif(f * (1.0f / 3.0f)), c3 = cospif(f * (1.0f / 3.0f));
+    const float H = 0.86602540378443864676f;                 // sin(pi/3)
+    const float ci[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};   // cos(i pi/3), i = -2..3
+    const float si[6] = {-H, -H, 0.0f, H, H, 0.0f};                // sin(i pi/3)
+    float v[6], sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double t = f - (double)(i - 2);
-        double val;
-        if (t == 0.0) val = 1.0;
-        else if (fabs(t) >= 3.0) val = 0.0;
-        else {
-            const double a = M_PI * t, b = M_PI * (t / 3.0);
-            val = (sin(a) / a) * (sin(b) / b);
-        }
-        v[i] = val; sum += val;
+    for (int q = 0; q < 6; q++) {
+        const int i = q - 2;
+        const float t = f - (float)i;
+        const float sa = (i & 1) ? -s1 : s1;                  // sin(pi t)
+        const float sb = s3 * ci[q] - c3 * si[q];             // sin(pi t / 3)
+        const float val = (t == 0.f) ? 1.0f : (3.0f * sa * sb) / ((float)(M_PI * M_PI) * (t * t));
+        v[q] = val; sum += val;
     }
+    const float rs = 1.0f / sum;
 #pragma unroll
-    for (int i = 0; i < 6; i++) k[i] = (float)(v[i] / sum);
+    for (int q = 0; q < 6; q++) k[q] = v[q] * rs;
 }
 
 #define RS_BIG 1e30f
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct rs_args {
     const float* in; const float* win;
     int in_ny, in_nx, out_ny, out_nx;
@@ -80,56 +86,134 @@ struct rs_args {
     float* out; float* wout;
 };
 
-__global__ __launch_bounds__(256) void k_resample_l3(rs_args a) {
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (X >= a.out_nx || Y >= a.out_ny) return;
-    // input position: bilinear interpolation (float64) of the coarse grid
+// input position of output pixel (X, Y): bilinear interpolation (float64) of the coarse grid
+__device__ __forceinline__ void rs_position(const rs_args& a, int X, int Y, double* pos) {
     const int gj = Y / a.gstep, gi = X / a.gstep;
     const double fy = (double)(Y - gj * a.gstep) / (double)a.gstep, fx = (double)(X - gi * a.gstep) / (double)a.gstep;
     const double* g00 = a.grid + ((size_t)gj * a.gnx + gi) * 2;
     const double* g10 = g00 + (size_t)a.gnx * 2;
-    double pos[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const double p = g00[k] + (g00[2 + k] - g00[k]) * fx;
         const double q = g10[k] + (g10[2 + k] - g10[k]) * fx;
         pos[k] = p + (q - p) * fy;
     }
-    const double xf = floor(pos[0]), yf = floor(pos[1]);
-    const size_t o = (size_t)Y * a.out_nx + X;
-    // footprint inside the input image?  (also rejects NaN positions)
-    if (!(xf - 2.0 >= 0.0 && xf + 3.0 < (double)a.in_nx && yf - 2.0 >= 0.0 && yf + 3.0 < (double)a.in_ny)) {
-        a.out[o] = 0.f; a.wout[o] = 0.f;
-        return;
-    }
-    const int ix = (int)xf, iy = (int)yf;
-    float kx[6], ky[6];
-    l3_taps(pos[0] - xf, kx);
-    l3_taps(pos[1] - yf, ky);
-    float acc = 0.f, vacc = 0.f;
-    bool bad = false;
-    const float* p = a.in + (size_t)(iy - 2) * a.in_nx + (ix - 2);
-    const float* pw = a.win + (size_t)(iy - 2) * a.in_nx + (ix - 2);
+}
+
+// Output tile of RT_W x RT_H pixels per workgroup.  The input pixels its 6x6 footprints touch
+// form a box a little larger than the tile (same pixel scale, small rotation): the workgroup
+// stages that box in LDS once -- data and variance, the reciprocal taken once per input pixel
+// instead of 36 times -- and every output pixel reads its 36 taps from there.  A box that does
+// not fit (strong rotation / magnification) falls back to gathering from global memory.
+#define RT_W 64
+#define RT_H 16
+#define RT_LW 96
+#define RT_LH 48
+__global__ __launch_bounds__(256) void k_resample_l3(rs_args a) {
+    __shared__ float2 tile[RT_LW * RT_LH];                     // (data, variance)
+    __shared__ int red[4][4];
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, wave = threadIdx.x >> 6;
+    const int X = blockIdx.x * RT_W + lx;
+    double px[4], py[4];
+    int fxi[4], fyi[4];
+    bool ok[4];                                                // footprint inside the input image
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -0x7fffffff, mxy = -0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        float row = 0.f, vrow = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const float f = p[i], w = pw[i];
-            const float v = (w > 0.f) ? 1.0f / w : RS_BIG;
-            bad |= !(w > 0.f);
-            row = row + kx[i] * f;
-            vrow = vrow + kx[i] * v;
+    for (int k = 0; k < 4; k++) {
+        const int Y = blockIdx.y * RT_H + ly + 4 * k;
+        ok[k] = false; fxi[k] = 0; fyi[k] = 0; px[k] = 0.0; py[k] = 0.0;
+        if (X < a.out_nx && Y < a.out_ny) {
+            double pos[2];
+            rs_position(a, X, Y, pos);
+            const double xf = floor(pos[0]), yf = floor(pos[1]);
+            // (the comparison also rejects NaN positions)
+            if (xf - 2.0 >= 0.0 && xf + 3.0 < (double)a.in_nx && yf - 2.0 >= 0.0 && yf + 3.0 < (double)a.in_ny) {
+                ok[k] = true; fxi[k] = (int)xf; fyi[k] = (int)yf; px[k] = pos[0] - xf; py[k] = pos[1] - yf;
+                mnx = min(mnx, fxi[k]); mxx = max(mxx, fxi[k]); mny = min(mny, fyi[k]); mxy = max(mxy, fyi[k]);
+            }
         }
-        acc = acc + ky[j] * row;
-        vacc = vacc + ky[j] * vrow;
-        p += a.in_nx; pw += a.in_nx;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64));
+        mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64));
+    }
+    if (lx == 0) { red[wave][0] = mnx; red[wave][1] = mny; red[wave][2] = mxx; red[wave][3] = mxy; }
+    __syncthreads();
+    mnx = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    mny = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+    mxx = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+    mxy = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    const bool any = mxx >= mnx;
+    const int x0 = mnx - 2, y0 = mny - 2;
+    const int W = any ? mxx - mnx + 6 : 0, Hh = any ? mxy - mny + 6 : 0;
+    const bool staged = any && W <= RT_LW && Hh <= RT_LH;      // workgroup-uniform
+    if (staged) {
+        // every pixel of the box lies inside the image (each contributing footprint does)
+        for (int idx = threadIdx.x; idx < W * Hh; idx += 256) {
+            const int r = idx / W, c = idx - r * W;
+            const size_t g = (size_t)(y0 + r) * a.in_nx + (x0 + c);
+            const float f = a.in[g], w = a.win[g];
+            tile[r * RT_LW + c] = make_float2(f, (w > 0.f) ? 1.0f / w : RS_BIG);
+        }
+    }
+    __syncthreads();
     const float fs = a.fscale;
-    const float vout = (fs * fs) * vacc;
-    a.out[o] = fs * acc;
-    a.wout[o] = (!bad && vout > 0.f) ? 1.0f / vout : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int Y = blockIdx.y * RT_H + ly + 4 * k;
+        if (!(X < a.out_nx && Y < a.out_ny)) continue;
+        const size_t o = (size_t)Y * a.out_nx + X;
+        if (!ok[k]) { a.out[o] = 0.f; a.wout[o] = 0.f; continue; }
+        float kx[6], ky[6];
+        l3_taps((float)px[k], kx);
+        l3_taps((float)py[k], ky);
+        float acc = 0.f, vacc = 0.f;
+        bool bad = false;
+        if (staged) {
+            const float2* p = tile + (fyi[k] - 2 - y0) * RT_LW + (fxi[k] - 2 - x0);
+            // (data, variance) pairs through packed fused multiply-adds
+            f32x2 acc2 = {0.f, 0.f};
+            float vmax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                f32x2 row2 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const float2 fv = p[i];
+                    const f32x2 v2 = {fv.x, fv.y}, k2 = {kx[i], kx[i]};
+                    vmax = fmaxf(vmax, fv.y);
+                    row2 = __builtin_elementwise_fma(k2, v2, row2);
+                }
+                const f32x2 ky2 = {ky[j], ky[j]};
+                acc2 = __builtin_elementwise_fma(ky2, row2, acc2);
+                p += RT_LW;
+            }
+            acc = acc2.x; vacc = acc2.y;
+            bad = vmax >= RS_BIG;
+        } else {
+            const float* p = a.in + (size_t)(fyi[k] - 2) * a.in_nx + (fxi[k] - 2);
+            const float* pw = a.win + (size_t)(fyi[k] - 2) * a.in_nx + (fxi[k] - 2);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                float row = 0.f, vrow = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const float f = p[i], w = pw[i];
+                    const float v = (w > 0.f) ? 1.0f / w : RS_BIG;
+                    bad |= !(w > 0.f);
+                    row = row + kx[i] * f;
+                    vrow = vrow + kx[i] * v;
+                }
+                acc = acc + ky[j] * row;
+                vacc = vacc + ky[j] * vrow;
+                p += a.in_nx; pw += a.in_nx;
+            }
+        }
+        const float vout = (fs * fs) * vacc;
+        a.out[o] = fs * acc;
+        a.wout[o] = (!bad && vout > 0.f) ? 1.0f / vout : 0.f;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -146,21 +230,34 @@ struct cb_args {
     unsigned long long* nclip;       // [n] or null
 };
 
-// element of 0-based rank r among the valid values (ties by index): rank counting, no
-// data-dependent register indexing
+// ascending bitonic sort of CAP (power of two) register values: fully unrolled compare-exchange
+// network, no data-dependent indexing (invalid entries are +inf and sort last)
 template <int CAP>
-__device__ __forceinline__ float rank_pick(const float (&f)[CAP], unsigned valid, int n, int r) {
-    float res = 0.f;
+__device__ __forceinline__ void sort_regs(float (&v)[CAP]) {
 #pragma unroll
-    for (int i = 0; i < CAP; i++) {
-        if (i < n && (valid >> i & 1u)) {
-            int rk = 0;
+    for (int k = 2; k <= CAP; k <<= 1) {
 #pragma unroll
-            for (int j = 0; j < CAP; j++)
-                if (j < n && (valid >> j & 1u)) rk += (f[j] < f[i] || (f[j] == f[i] && j < i)) ? 1 : 0;
-            if (rk == r) res = f[i];
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < CAP; i++) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const float a = v[i], b = v[l];
+                    const float lo = fminf(a, b), hi = fmaxf(a, b);
+                    v[i] = up ? lo : hi;
+                    v[l] = up ? hi : lo;
+                }
+            }
         }
     }
+}
+// v[r] for a run-time r (select chain)
+template <int CAP>
+__device__ __forceinline__ float pick_reg(const float (&v)[CAP], int r) {
+    float res = v[0];
+#pragma unroll
+    for (int i = 1; i < CAP; i++) res = (i == r) ? v[i] : res;
     return res;
 }
 
@@ -184,11 +281,15 @@ __global__ __launch_bounds__(256) void k_combine(cb_args a) {
     unsigned drop = 0;
     if (m > 0) {
         double sw = 0.0, swf = 0.0, sf = 0.0, sinv = 0.0;
+        const bool need_inv = (TYPE == CB_AVERAGE || TYPE == CB_SUM || TYPE == CB_MEDIAN);
+        const bool need_w = (TYPE == CB_WEIGHTED || TYPE == CB_CLIPPED);
 #pragma unroll
         for (int i = 0; i < CAP; i++)
             if (valid >> i & 1u) {
                 const double wd = (double)w[i], fd = (double)f[i];
-                sw += wd; swf += wd * fd; sf += fd; sinv += 1.0 / wd;
+                if (need_w) { sw += wd; swf += wd * fd; }
+                if (TYPE == CB_AVERAGE || TYPE == CB_SUM) sf += fd;
+                if (need_inv) sinv += 1.0 / wd;
             }
         if (TYPE == CB_WEIGHTED) { out = swf / sw; wout = sw; }
         else if (TYPE == CB_AVERAGE) { out = sf / (double)m; wout = (double)m * (double)m / sinv; }
@@ -202,20 +303,26 @@ __global__ __launch_bounds__(256) void k_combine(cb_args a) {
                     if (better) { out = (double)f[i]; wout = (double)w[i]; first = false; }
                 }
         } else {
-            const double lo = (double)rank_pick<CAP>(f, valid, a.n, (m - 1) / 2);
-            const double hi = (double)rank_pick<CAP>(f, valid, a.n, m / 2);
+            float srt[CAP];
+#pragma unroll
+            for (int i = 0; i < CAP; i++) srt[i] = (valid >> i & 1u) ? f[i] : __builtin_huge_valf();
+            sort_regs<CAP>(srt);
+            const double lo = (double)pick_reg<CAP>(srt, (m - 1) / 2);
+            const double hi = (double)pick_reg<CAP>(srt, m / 2);
             const double med = 0.5 * (lo + hi);
             if (TYPE == CB_MEDIAN) { out = med; wout = (2.0 / M_PI) * (double)m * (double)m / sinv; }
             else {
+                // the clip test runs in float32 (SWarp's pixel type): |f - med| > sigma*sqrt(1/w) + A*|med|
+                const float med32 = (float)med, amed = a.clip_ampfrac * fabsf(med32);
                 double sw2 = 0.0, swf2 = 0.0;
                 int nk = 0;
 #pragma unroll
                 for (int i = 0; i < CAP; i++)
                     if (valid >> i & 1u) {
-                        const double wd = (double)w[i], fd = (double)f[i];
-                        const bool d = fabs(fd - med) > (double)a.clip_sigma * sqrt(1.0 / wd) + (double)a.clip_ampfrac * fabs(med);
+                        const float thr = a.clip_sigma * sqrtf(1.0f / w[i]) + amed;
+                        const bool d = fabsf(f[i] - med32) > thr;
                         if (d) drop |= 1u << i;
-                        else { sw2 += wd; swf2 += wd * fd; nk++; }
+                        else { const double wd = (double)w[i]; sw2 += wd; swf2 += wd * (double)f[i]; nk++; }
                     }
                 if (nk > 0) { out = swf2 / sw2; wout = sw2; }
                 else { out = swf / sw; wout = sw; drop = 0; }
@@ -271,7 +378,7 @@ int bbx_resample_lanczos3(bbx_ctx* ctx, int in_ny, int in_nx, const float* d_in,
     rs_args a;
     a.in = d_in; a.win = d_win; a.in_ny = in_ny; a.in_nx = in_nx; a.out_ny = out_ny; a.out_nx = out_nx;
     a.grid = d_grid; a.gny = gny; a.gnx = gnx; a.gstep = gstep; a.fscale = fscale; a.out = d_out; a.wout = d_wout;
-    hipLaunchKernelGGL(k_resample_l3, dim3((out_nx + 63) / 64, (out_ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_resample_l3, dim3((out_nx + RT_W - 1) / RT_W, (out_ny + RT_H - 1) / RT_H), dim3(256), 0, (hipStream_t)stream, a);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

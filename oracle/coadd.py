@@ -154,7 +154,7 @@ def combine(cube, wcube, combine_type='weighted', clip_sigma=4.0, clip_ampfrac=0
     min/max  : extreme value,                weight of that pixel
     sum      : sum(f),                       weight 1 / sum(1/w)
     clipped  : reference value = median of the valid values; a value is dropped when
-               |f - med| > clip_sigma * sqrt(1/w) + clip_ampfrac * |med|; then `weighted`
+               |f - med| > clip_sigma * sqrt(1/w) + clip_ampfrac * |med| (float32); then `weighted`
                over the rest (never drops everything: the median itself survives for odd m;
                if nothing survives the unclipped weighted mean is used)
     float64 accumulation over the images in order, results rounded to float32."""
@@ -191,8 +191,11 @@ def combine(cube, wcube, combine_type='weighted', clip_sigma=4.0, clip_ampfrac=0
                 out = med
                 wout = np.where(m > 0, (2.0 / np.pi) * m * m / sinv, 0.0)
             else:
-                sig = np.sqrt(1.0 / np.where(valid, w, 1.0))
-                drop = valid & (np.abs(c - med[None]) > clip_sigma * sig + clip_ampfrac * np.abs(med)[None])
+                # the clip test in float32 (SWarp's pixel type), operations in this order
+                med32 = med.astype(F)
+                sig = np.sqrt(F(1) / np.where(valid, wcube, F(1)).astype(F))
+                thr = F(clip_sigma) * sig + (F(clip_ampfrac) * np.abs(med32))[None]
+                drop = valid & (np.abs(cube.astype(F) - med32[None]) > thr)
                 keep = valid & ~drop
                 nk = keep.sum(axis=0)
                 sw2 = np.where(keep, w, 0.0).sum(axis=0)

@@ -80,15 +80,18 @@ def test_resample_vs_oracle(ctx):
     def f(yy, xx):
         return (130 + 1.02 * ((xx - 120) * np.cos(th) - (yy - 90) * np.sin(th)) + 0.3,
                 100 + 1.02 * ((xx - 120) * np.sin(th) + (yy - 90) * np.cos(th)) - 0.45)
+    # the third map has 0.97 input px per output px (fits the staged box), the fourth 1.6 (a 64-pixel
+    # tile row spans 102 input pixels, more than the stage holds): the gather path runs
     out_shape, step = (190, 250), 32
-    grid = OC.coarse_grid(f, out_shape[0], out_shape[1], step)
-    xin, yin = OC.grid_positions(grid, out_shape[0], out_shape[1], step)
-    for fscale in (1.0, 1.7):
+    for fun, fscale in ((f, 1.0), (f, 1.7), (lambda yy, xx: (3.0 + 2.55 * xx * 0.38, 4.0 + 2.55 * yy * 0.38), 1.0),
+                        (lambda yy, xx: (2.5 + 1.6 * xx + 0.05 * yy, 3.5 - 0.04 * xx + 1.6 * yy), 1.0)):
+        grid = OC.coarse_grid(fun, out_shape[0], out_shape[1], step)
+        xin, yin = OC.grid_positions(grid, out_shape[0], out_shape[1], step)
         o_ref, w_ref = OC.lanczos3_resample(img, w, xin, yin, fscale)
         o, wo = PC.resample(ctx, dev(ctx, img), dev(ctx, w), grid, out_shape, fscale, step)
         ctx.sync()
         o, wo = o.cpu().numpy(), wo.cpu().numpy()
-        assert (w_ref == 0).sum() > 500 and (w_ref > 0).sum() > 30000
+        assert (w_ref == 0).sum() > 500 and (w_ref > 0).sum() > 10000
         assert np.array_equal(wo == 0, w_ref == 0)                 # same footprint decisions
         # float32 accumulation in the same order; the taps may differ in their last bit
         # (device sin vs numpy sin): 2e-6 of the image scale
