@@ -20,6 +20,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+KEYWORDS_VERSION = '1.2.2'      # header keywords version this product follows (blackbox.py:123)
 log = logging.getLogger('blackbox')
 
 
@@ -117,9 +118,35 @@ class Reducer:
                 xtalk_coeffs=self.xtalk, exptime=exptime, ysize_chan=self.args.ysize_chan,
                 xsize_chan=self.args.xsize_chan)
         header['BUNIT'] = ('e-', 'pixel values are in electrons')
+        # bookkeeping keywords of the header contract (blackbox.py:1110-1112, 1520, 1607, 1669-1690,
+        # 1817-1855; verify_header 2893-3255)
+        from blackbox_amd import __version__ as bbx_version
+        base = lambda p: os.path.basename(p) if p else 'None'                  # noqa: E731
+        stem = lambda p: os.path.basename(p).split('.fits')[0] if p else 'None'  # noqa: E731
+        header['BB-V'] = ('amd-' + bbx_version, 'BlackBOX version used')
+        header['KW-V'] = (KEYWORDS_VERSION, 'header keywords version used')
+        header['BB-START'] = (time.strftime('%Y-%m-%dT%H:%M:%S', time.gmtime(t0)), 'start UTC date of BlackBOX image run')
+        header['XTALK-F'] = (base(self.args.crosstalk), 'name crosstalk coefficients file')
+        header['NONLIN-F'] = ('None', 'name non-linearity correction file')
+        header['MBIAS-F'] = (stem(self.args.mbias) if R.hval(header, 'MBIAS-P') else 'None', 'name of master bias applied')
+        header['MFLAT-F'] = (stem(self.args.mflat) if R.hval(header, 'MFLAT-P') else 'None', 'name of master flat applied')
+        for k, c in (('XTALK-P', 'corrected for crosstalk?'), ('COSMIC-P', 'corrected for cosmic rays?'),
+                     ('SAT-P', 'processed for satellite trails?')):
+            header.setdefault(k, (False, c))                                     # steps that did not run
+        header.setdefault('NCOSMICS', ('None', '[/s] number of cosmic rays identified'))
+        header.setdefault('NSATS', ('None', 'number of satellite trails identified'))
+        header['MFRING-P'] = (False, 'corrected for master fringe map?')
+        header['MFRING-F'] = ('None', 'name of master fringe map applied')
+        header['FRRATIO'] = ('None', 'fringe ratio (science/fringe map) applied')
+        # QC flags on the reduction keywords (blackbox.py:2000; qc.py)
+        from blackbox_amd import qc
+        qc_flag = qc.run_qc_check(header, self.tel, check_key_type='full')      # flags go into the image header
+        if qc_flag == 'red':
+            log.error('red QC flag for %s', filename)
         redfile = os.path.basename(fits_out).split('.fits')[0]
         header['REDFILE'] = (redfile, 'BlackBOX reduced image name')
         header['MASKFILE'] = (redfile.replace('_red', '_mask'), 'BlackBOX mask image name')
+        qc.verify_header(header, ['full'], name=fits_out)                     # blackbox.py:2062 (raises on a DB keyword)
         os.makedirs(red_dir, exist_ok=True)
         if self.args.fpack:
             # products leave the GPU tile-compressed (reference: fpack of the files kept,
