@@ -352,90 +352,225 @@ extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const 
 // frame run side by side.  Decoded values are staged per 32-pixel block in registers and
 // written as whole blocks.
 // ---------------------------------------------------------------------------------
-#ifndef FUNPACK_RPW
-#define FUNPACK_RPW 8
-#endif
-struct bitreader {
-    const uint8_t* p;
-    unsigned long long buf;      // left-aligned bit buffer
+// desc: per row {int32 len, int32 off} (host order), heap: compressed bytes (padded with 8 readable bytes).
+// out_kind: 0 = uint8, 1 = int16 -> uint16 with +32768 (BZERO), 2 = int16, 3 = int32, 4 = float32 (dequantised)
+//
+// A Rice stream is sequential within its tile (a row), so the time of the kernel is the time of
+// one row: what matters is that nothing but ALU work sits on that chain.  One wave handles
+// FU_ROWS rows: lanes 0..FU_ROWS-1 each decode one row in bursts of FU_OUT pixels (two Rice
+// blocks), reading the stream from a ring in LDS and leaving the pixels in LDS; between bursts
+// all 64 lanes refill every row's ring with coalesced 256-byte loads and write the decoded
+// pixels out with coalesced stores.  (Reading the stream straight from global memory puts one
+// ~1 us load per byte on the chain: 8 ms for a 10600-row frame.)
+#define FU_ROWS 16
+#define FU_IN 1024           // ring bytes per row (power of two; a burst needs <= 266)
+#define FU_OUT 64            // pixels per burst
+// Bit reader over the row's ring, written without branches: the 16 decoding lanes of a wave
+// must follow one instruction stream, and a pixel must not wait for memory.  After refill() the
+// left-aligned buffer holds more than 32 valid bits.  `nxt` is the ring word after the buffer
+// and `ahead` the one after that, whose LDS read was issued at the previous refill site -- by
+// the time it is consumed it has arrived.
+struct ringreader {
+    const uint32_t* ring;        // this row's ring (FU_IN / 4 words)
+    unsigned idx;                // ring word index of `nxt`
+    unsigned long long buf;      // left-aligned bit buffer, zero below the valid bits
     int nbits;
-    __device__ __forceinline__ void init(const uint8_t* q) { p = q; buf = 0; nbits = 0; }
-    __device__ __forceinline__ void fill() {
-        while (nbits <= 56) { buf |= (unsigned long long)(*p++) << (56 - nbits); nbits += 8; }
+    unsigned nxt, ahead;         // raw (big-endian) words idx and idx + 1
+    __device__ __forceinline__ unsigned bytes_taken() const { return 4u * idx; }
+    __device__ __forceinline__ void start() {
+        idx = 0; buf = 0; nbits = 0;
+        nxt = ring[0]; ahead = ring[1];
+        refill(); refill();
     }
-    __device__ __forceinline__ unsigned get(int n) {           // n <= 32
-        if (n == 0) return 0u;
-        if (nbits < n) fill();
-        const unsigned v = (unsigned)(buf >> (64 - n));
+    __device__ __forceinline__ void refill() {                 // -> nbits >= 33
+        const bool c = nbits <= 32;
+        const unsigned long long add = (unsigned long long)__builtin_bswap32(nxt) << ((32 - nbits) & 63);
+        buf |= c ? add : 0ull;
+        nbits += c ? 32 : 0;
+        nxt = c ? ahead : nxt;
+        idx += c ? 1u : 0u;
+        ahead = ring[(idx + 1u) & (FU_IN / 4 - 1)];            // (the same word again when nothing moved)
+    }
+    __device__ __forceinline__ unsigned take(int n) {           // n <= 32 <= nbits
+        const unsigned v = (unsigned)((buf >> 1) >> (63 - n));  // (n == 0 -> 0 without a 64-bit shift by 64)
         buf <<= n; nbits -= n;
         return v;
     }
+    __device__ __forceinline__ unsigned get(int n) { refill(); return take(n); }
     __device__ __forceinline__ unsigned unary() {              // number of zeros before the next one
+        refill();
         unsigned z = 0;
-        for (;;) {
-            if (nbits == 0) fill();
-            if (buf == 0) { z += nbits; nbits = 0; continue; }
-            const int lz = __clzll((long long)buf);
-            if (lz < nbits) { z += lz; buf <<= (lz + 1); nbits -= lz + 1; return z; }
-            z += nbits; buf = 0; nbits = 0;
+        while ((unsigned)(buf >> 32) == 0u) {                   // 32 zeros: rare (a code longer than 32 bits)
+            z += 32; buf <<= 32; nbits -= 32;
+            refill();
+            if (z > 0x100000u) return z;                        // (bounded: a corrupt stream ends)
         }
+        const int lz = __clzll((long long)buf);                 // < 32
+        z += lz; buf <<= (lz + 1); nbits -= lz + 1;
+        return z;
     }
 };
 
-// desc: per row {int32 len, int32 off} (host order), heap: compressed bytes (padded with 8 readable bytes).
-// out_kind: 0 = uint8, 1 = int16 -> uint16 with +32768 (BZERO), 2 = int16, 3 = int32, 4 = float32 (dequantised)
 template <int BYTEPIX>
 __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, const uint8_t* __restrict__ heap, int ny, int nx,
                                                 int out_kind, void* __restrict__ out, const double* __restrict__ zscale,
                                                 const double* __restrict__ zzero, int dither_seed,
                                                 const float* __restrict__ rnd, int* __restrict__ err) {
     typedef rice_par<BYTEPIX> RP;
-    // FUNPACK_RPW rows per wave: the lanes of a wave follow different code paths (split levels,
-    // unary runs, refills), so fewer rows per wave means less serialisation, and a frame has
-    // only ~10^4 rows to spread over 1024 SIMDs anyway
-    if ((int)threadIdx.x >= FUNPACK_RPW) return;
-    const int row = blockIdx.x * FUNPACK_RPW + threadIdx.x;
-    if (row >= ny) return;
-    const int len = desc[2 * row], off = desc[2 * row + 1];
-    if (len <= 0) return;                                       // stored another way (gzip column): done on the host
-    bitreader br; br.init(heap + off);
-    const uint8_t* end = heap + off + len;
-    int last = (int)br.get(8 * BYTEPIX);
-    if (BYTEPIX == 1) last = (int)(signed char)last;
-    if (BYTEPIX == 2) last = (int)(short)last;
+    __shared__ uint32_t ring[FU_ROWS][FU_IN / 4 + 1];           // (+1: rows on different banks)
+    __shared__ int obuf[FU_ROWS][FU_OUT + 1];
+    __shared__ unsigned s_fill[FU_ROWS], s_rd[FU_ROWS], s_total[FU_ROWS];   // bytes from the row's aligned base
+    __shared__ size_t s_base[FU_ROWS];
+    __shared__ int s_cnt[FU_ROWS], s_pix[FU_ROWS], s_live;
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x * FU_ROWS + lane;
+    const bool dec = lane < FU_ROWS;
+    bool active = false;
+    ringreader br; br.ring = ring[dec ? lane : 0]; br.idx = 0; br.buf = 0; br.nbits = 0; br.nxt = 0; br.ahead = 0;
+    int last = 0, pix = 0, mis = 0;
     double zs = 0., zz = 0.;
     int iseed = 0, nextrand = 0;
-    if (out_kind == 4) {
-        zs = zscale[row]; zz = zzero[row];
-        iseed = (row + dither_seed - 1) % FP_NRANDOM;
-        nextrand = (int)((double)rnd[iseed] * 500.);
-    }
-    for (int i = 0; i < nx; i += 32) {
-        const int fs = (int)br.get(RP::fsbits) - 1;
-        const int n = min(32, nx - i);
-        for (int j = 0; j < n; j++) {
-            unsigned d;
-            if (fs < 0) d = 0;
-            else if (fs == RP::fsmax) d = br.get(RP::bbits);
-            else { const unsigned top = br.unary(); d = (top << fs) | br.get(fs); }
-            int pd = (int)(d >> 1) ^ -(int)(d & 1u);
-            last += pd;
-            if (BYTEPIX == 1) last = (int)(signed char)last;
-            if (BYTEPIX == 2) last = (int)(short)last;
-            const size_t o = (size_t)row * nx + i + j;
-            if (out_kind == 0) ((uint8_t*)out)[o] = (uint8_t)last;
-            else if (out_kind == 1) ((uint16_t*)out)[o] = (uint16_t)(last + 32768);
-            else if (out_kind == 2) ((short*)out)[o] = (short)last;
-            else if (out_kind == 3) ((int*)out)[o] = last;
-            else {
-                ((float*)out)[o] = (float)(((double)last - (double)rnd[nextrand] + 0.5) * zs + zz);
-                if (++nextrand == FP_NRANDOM) {
-                    iseed = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
+    if (dec) {
+        unsigned total = 0; size_t base = 0;
+        if (row < ny) {
+            const int len = desc[2 * row], off = desc[2 * row + 1];
+            if (len > 0) {                                      // len <= 0: stored another way (gzip column), done on the host
+                active = true;
+                mis = off & 3;
+                base = (size_t)(off - mis);
+                total = (unsigned)((mis + len + 3) & ~3);
+                if (out_kind == 4) {
+                    zs = zscale[row]; zz = zzero[row];
+                    iseed = (row + dither_seed - 1) % FP_NRANDOM;
                     nextrand = (int)((double)rnd[iseed] * 500.);
                 }
             }
         }
-        if (br.p > end + 8) { atomicOr(err, 1); return; }        // ran past the tile: corrupt stream
+        s_base[lane] = base; s_total[lane] = total; s_fill[lane] = 0; s_rd[lane] = 0; s_cnt[lane] = 0; s_pix[lane] = 0;
+    }
+    // value stored for a decoded pixel: the integer, or the un-quantised float's bits
+    auto emit = [&](int v) -> int {
+        if (out_kind != 4) return v;
+        const int r = __float_as_int((float)(((double)v - (double)rnd[nextrand] + 0.5) * zs + zz));
+        if (++nextrand == FP_NRANDOM) {
+            iseed = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
+            nextrand = (int)((double)rnd[iseed] * 500.);
+        }
+        return r;
+    };
+    bool first = true;
+    // prime the rings (up to 768 bytes each) before the first burst
+    __syncthreads();
+    for (int rr = 0; rr < FU_ROWS; rr++) {
+        const unsigned total = s_total[rr];
+        const uint8_t* src = heap + s_base[rr];
+        unsigned fill = 0;
+        for (int c = 0; c < 3 && fill < total; c++, fill += 256) {
+            const unsigned bo = fill + 4 * lane;
+            if (bo < total) ring[rr][(bo >> 2) & (FU_IN / 4 - 1)] = *(const uint32_t*)(src + bo);
+        }
+        if (lane == 0) s_fill[rr] = fill < total ? fill : total;
+    }
+    for (;;) {
+        __syncthreads();
+        // ---- refill, first half: issue the loads of every row that has room for them (all lanes).
+        // They land in registers and go into the rings after the burst, so their latency runs beside
+        // the decode instead of in front of it; a ring always holds >= 500 bytes ahead of its reader
+        // (or the rest of the stream), a burst needs <= 266.
+        uint32_t pre[FU_ROWS][2];
+        unsigned pre_fill[FU_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < FU_ROWS; rr++) {
+            const unsigned fill = s_fill[rr], rd = s_rd[rr], total = s_total[rr];
+            const uint8_t* src = heap + s_base[rr];
+            pre_fill[rr] = fill;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const unsigned f = fill + 256u * c, bo = f + 4 * lane;
+                pre[rr][c] = 0;
+                if (f < total && f - rd <= FU_IN - 256) {       // uniform
+                    if (bo < total) pre[rr][c] = *(const uint32_t*)(src + bo);
+                    pre_fill[rr] = f + 256u;
+                }
+            }
+        }
+        // ---- decode a burst ----
+        if (dec) {
+            s_cnt[lane] = 0;
+            if (active) {
+                if (first) {
+                    br.start();
+                    if (mis) br.get(8 * mis);                   // bytes before the stream in its first aligned word
+                    last = (int)br.get(8 * BYTEPIX);
+                    if (BYTEPIX == 1) last = (int)(signed char)last;
+                    if (BYTEPIX == 2) last = (int)(short)last;
+                }
+                const int n_burst = min(FU_OUT, nx - pix);
+                for (int i = 0; i < n_burst; i += 32) {
+                    const int fs = (int)br.get(RP::fsbits) - 1;
+                    const int n = min(32, n_burst - i);
+                    // the three kinds of block; a lane stays in one of them for 32 pixels
+                    if (fs < 0) {
+                        for (int j = 0; j < n; j++) obuf[lane][i + j] = emit(last);
+                    } else if (fs == RP::fsmax) {
+                        for (int j = 0; j < n; j++) {
+                            const unsigned d = br.get(RP::bbits);
+                            last += (int)(d >> 1) ^ -(int)(d & 1u);
+                            if (BYTEPIX == 1) last = (int)(signed char)last;
+                            if (BYTEPIX == 2) last = (int)(short)last;
+                            obuf[lane][i + j] = emit(last);
+                        }
+                    } else {
+                        for (int j = 0; j < n; j++) {
+                            const unsigned top = br.unary();
+                            const unsigned d = (top << fs) | br.get(fs);
+                            last += (int)(d >> 1) ^ -(int)(d & 1u);
+                            if (BYTEPIX == 1) last = (int)(signed char)last;
+                            if (BYTEPIX == 2) last = (int)(short)last;
+                            obuf[lane][i + j] = emit(last);
+                        }
+                    }
+                }
+                s_cnt[lane] = n_burst; s_pix[lane] = pix;
+                pix += n_burst;
+                s_rd[lane] = br.bytes_taken();
+                if (br.bytes_taken() > s_total[lane] + 8) { atomicOr(err, 1); active = false; }    // ran past the tile: corrupt stream
+                if (pix >= nx) active = false;
+            }
+        }
+        first = false;
+        __syncthreads();
+        // ---- refill, second half: the loaded words into the rings ----
+#pragma unroll
+        for (int rr = 0; rr < FU_ROWS; rr++) {
+            const unsigned fill = s_fill[rr], total = s_total[rr];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const unsigned f = fill + 256u * c, bo = f + 4 * lane;
+                if (f < pre_fill[rr] && bo < total) ring[rr][(bo >> 2) & (FU_IN / 4 - 1)] = pre[rr][c];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < FU_ROWS; rr++)
+            if (lane == 0) s_fill[rr] = pre_fill[rr] < s_total[rr] ? pre_fill[rr] : s_total[rr];
+        // ---- write the bursts out (all lanes, one coalesced store per row) ----
+        for (int rr = 0; rr < FU_ROWS; rr++) {
+            const int n = s_cnt[rr];
+            if (lane < n) {
+                const size_t o = (size_t)(blockIdx.x * FU_ROWS + rr) * nx + s_pix[rr] + lane;
+                const int v = obuf[rr][lane];
+                if (out_kind == 0) ((uint8_t*)out)[o] = (uint8_t)v;
+                else if (out_kind == 1) ((uint16_t*)out)[o] = (uint16_t)(v + 32768);
+                else if (out_kind == 2) ((short*)out)[o] = (short)v;
+                else ((int*)out)[o] = v;                         // int32 or float bits
+            }
+        }
+        if (lane == 0) s_live = 0;
+        __syncthreads();
+        if (active) s_live = 1;
+        __syncthreads();
+        if (!s_live) break;
     }
 }
 
@@ -447,7 +582,7 @@ extern "C" int bbx_funpack_tiles(bbx_ctx* ctx, int ny, int nx, int bytepix, cons
     if ((out_kind == 0 && bytepix != 1) || ((out_kind == 1 || out_kind == 2) && bytepix != 2) || (out_kind == 3 && bytepix != 4))
         return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((ny + FUNPACK_RPW - 1) / FUNPACK_RPW);
+    const dim3 grid((ny + FU_ROWS - 1) / FU_ROWS);
     if (bytepix == 1) hipLaunchKernelGGL(k_funpack<1>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
     else if (bytepix == 2) hipLaunchKernelGGL(k_funpack<2>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
     else if (bytepix == 4) hipLaunchKernelGGL(k_funpack<4>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
