@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 /* overscan.hos_column_stats(data_hos, mask_hos, accum='f32seq'):
  * data [nrow][ncol] float32, mask [nrow][ncol] uint8 (non-zero = masked)
@@ -174,4 +175,196 @@ int64_t bbx_polyfit_prep(const double *restrict V, const uint8_t *restrict mask,
         for (int j = 0; j < order; j++) o[j] = o[j] / scale[j];
     }
     return m;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * overscan.channel_solve (telescope ML1, accum='f32seq') in one call: the numpy glue between the
+ * LAPACK fits, operation by operation as in blackbox_amd/overscan.py (channel_phase1,
+ * vos_polyfit, channel_phase2, hos_fit), which follows blackbox.py:6497-6814.  The least-squares
+ * solves themselves stay with numpy (np.linalg.lstsq = LAPACK gelsd, what np.polyfit calls):
+ * [lstsq] is a callback into Python.  Situations the numpy code handles in other ways (failed or
+ * rank-deficient vertical fit, non-finite fit, overscan pixels above data_limit, columns that
+ * need the spline, too few points) return a positive code and the caller runs the numpy path.
+ * tests/test_host_overscan.py holds both paths against each other bit for bit. */
+typedef int (*bbx_lstsq_fn)(const double *lhs, int64_t m, int order, const double *rhs, double rcond, double *coef,
+                            int *rank);
+
+/* numpy's pairwise summation of a contiguous float64 vector (np.add.reduce: blocks of 128 with
+ * eight accumulators, halves split at a multiple of 8) */
+static double pairwise_sum(const double *a, int64_t n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int64_t i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+
+/* overscan._mean_std_flat(v, 'f64') */
+static void mean_std_f64(const double *v, int64_t n, double *tmp, double *mean, double *sd) {
+    const double m = pairwise_sum(v, n) / (double)n;
+    for (int64_t i = 0; i < n; i++) { const double d = v[i] - m; tmp[i] = d * d; }
+    *mean = m;
+    *sd = sqrt(pairwise_sum(tmp, n) / (double)n);
+}
+
+/* np.polyval(p, start + arange(n)) with p high -> low order */
+static void polyval_arange(const double *p, int order, int start, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; i++) {
+        const double x = (double)(start + i);
+        double y = 0.0;                                       /* zeros_like(x) (integers), then y * x + pv */
+        for (int k = 0; k < order; k++) y = y * x + p[k];
+        out[i] = y;
+    }
+}
+
+/* polyfit_exact(start, n, mask, y[mask], order - 1) -> coefficients high -> low; 0 ok */
+static int polyfit_masked(const double *V, const uint8_t *mask, int64_t n, int order, const double *yfull,
+                          bbx_lstsq_fn lstsq, double *lhs, double *rhs, double *coef, int *rank) {
+    double scale[16];
+    const int64_t m = bbx_polyfit_prep(V, mask, n, order, lhs, scale);
+    if (m < order) return 1;
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++) if (mask[i]) rhs[k++] = yfull[i] + 0.0;
+    const double rcond = (double)m * 2.220446049250313e-16;
+    if (lstsq(lhs, m, order, rhs, rcond, coef, rank) != 0) return 2;
+    for (int j = 0; j < order; j++) coef[j] = coef[j] / scale[j];
+    return 0;
+}
+
+#define IDX_SWITCH 150
+#define OVERLAP 30
+int bbx_channel_solve_ml1(int c, const double *mean_vos_col, int dy, const float *hos, int hos_rows, int dx, int ysz,
+                          int xsz, int poldeg, double data_limit, const double *V_vos, const double *V_hos,
+                          bbx_lstsq_fn lstsq, double *fit_out, double *coeffs_out, double *level_out,
+                          double *dlevel_out, double *oscan_out) {
+    const int order_v = poldeg + 1, order_h = 8;
+    if (dy < 8 || xsz < 300 || xsz > dx || hos_rows < 1 || hos_rows > 4096 || order_v > 16) return 100;
+    const size_t nmax = (size_t)(dy > xsz ? dy : xsz);
+    static __thread void *scratch = 0;
+    static __thread size_t scratch_bytes = 0;
+    const size_t n_strip = (size_t)hos_rows * dx, n_blk = (size_t)hos_rows * (xsz + 300);
+    const size_t need = (nmax * 21 + (size_t)xsz) * sizeof(double) + (n_strip + n_blk + 3 * (size_t)xsz + 4) * sizeof(float)
+                        + 2 * nmax + (size_t)hos_rows * xsz + 64;
+    if (scratch_bytes < need) {
+        free(scratch);
+        scratch = malloc(need);
+        scratch_bytes = scratch ? need : 0;
+        if (!scratch) return -3;
+    }
+    double *v = (double *)scratch, *tmp = v + nmax, *rhs = tmp + nmax, *lhs = rhs + nmax;   /* lhs: nmax * 16 */
+    double *yd = lhs + nmax * 16;                                                            /* nmax */
+    int64_t *ncol = (int64_t *)(yd + nmax);                                                  /* xsz */
+    float *strip = (float *)(ncol + xsz);                                                    /* hos_rows * dx */
+    float *blk = strip + n_strip;                                                            /* hos_rows * (xsz + 300) */
+    float *mean_hos = blk + n_blk, *std_hos = mean_hos + xsz, *err_hos = std_hos + xsz;
+    uint8_t *mask = (uint8_t *)(err_hos + xsz + 4), *mask2 = mask + nmax, *zero_mask = mask2 + nmax;
+
+    /* ---- vos_polyfit ---------------------------------------------------------------- */
+    int64_t m = 0;
+    for (int i = 0; i < dy; i++) if (isfinite(mean_vos_col[i])) v[m++] = mean_vos_col[i];
+    double mean = NAN, sd = NAN;
+    for (int it = 0; it < 5; it++) {
+        if (m == 0) break;
+        mean_std_f64(v, m, tmp, &mean, &sd);
+        const double lo = mean - sd * 5.0, hi = mean + sd * 5.0;
+        int64_t k = 0;
+        for (int64_t i = 0; i < m; i++) if (v[i] >= lo && v[i] <= hi) v[k++] = v[i];
+        if (k == m) break;
+        m = k;
+    }
+    if (m == 0) return 1;                                     /* statistics undefined: numpy path */
+    mean_std_f64(v, m, tmp, &mean, &sd);
+    for (int i = 0; i < dy; i++)
+        mask[i] = (sd == 0.0) ? 1 : (uint8_t)(fabs(mean_vos_col[i] - mean) / sd <= 5.0);
+    if (c < 8) { for (int i = ysz; i < dy; i++) mask[i] = 0; }
+    else { for (int i = 0; i < dy - ysz; i++) mask[i] = 0; }
+    double p[16];
+    int rank = 0;
+    if (polyfit_masked(V_vos, mask, dy, order_v, mean_vos_col, lstsq, lhs, rhs, p, &rank) != 0) return 2;
+    if (rank != order_v) return 3;
+    polyval_arange(p, order_v, 0, dy, fit_out);
+    for (int i = 0; i < dy; i++) if (!isfinite(fit_out[i])) return 4;
+    *level_out = pairwise_sum(fit_out, dy) / (double)dy;      /* np.mean(fit) */
+    for (int k = 0; k < order_v; k++) coeffs_out[k] = p[order_v - 1 - k];
+
+    /* ---- horizontal strip after the vertical fit; its level ------------------------ */
+    const int rl0 = (c < 8) ? (dy - hos_rows) : 0;
+    for (int r = 0; r < hos_rows; r++) {
+        const double f = fit_out[rl0 + r];
+        for (int x = 0; x < dx; x++) strip[(size_t)r * dx + x] = (float)((double)hos[(size_t)r * dx + x] - f);
+    }
+    float *lvl = blk;
+    for (int r = 0; r < hos_rows; r++)
+        for (int x = 0; x < 300; x++) lvl[(size_t)r * 300 + x] = strip[(size_t)r * dx + (xsz - 300) + x];
+    double st[2];
+    const int64_t ml = bbx_clipped_stats_flat_f32seq(lvl, (int64_t)hos_rows * 300, 3.0, 5, st);
+    if (ml <= 0) return 5;
+    const float dlevel = (float)st[0];
+    *dlevel_out = (double)dlevel;
+    float *data_hos = blk;                                    /* [hos_rows][xsz], contiguous */
+    for (int r = 0; r < hos_rows; r++)
+        for (int x = 0; x < xsz; x++) {
+            const float s = strip[(size_t)r * dx + x] - dlevel;
+            if (s > (float)data_limit) return 6;              /* hos_mask_ml1 would mask something */
+            data_hos[(size_t)r * xsz + x] = s;
+        }
+    memset(zero_mask, 0, (size_t)hos_rows * xsz);
+    if (bbx_hos_column_stats_f32seq(data_hos, zero_mask, hos_rows, xsz, ncol, mean_hos, std_hos) != 0) return -3;
+
+    /* ---- hos_fit --------------------------------------------------------------------- */
+    for (int x = 0; x < xsz; x++) {
+        err_hos[x] = 0.0f;
+        if (ncol[x] > 1) err_hos[x] = (float)((double)std_hos[x] / sqrt((double)ncol[x]));
+    }
+    /* columns below IDX_SWITCH that do not take their own mean need the spline: numpy path */
+    for (int x = 0; x < IDX_SWITCH; x++) {
+        const int valid = ncol[x] > 1;
+        int keeps_spline = !valid;
+        if (x < 3) keeps_spline = keeps_spline && !valid;
+        if (keeps_spline) return 7;
+    }
+    int64_t nm = 0;
+    for (int x = 0; x < xsz; x++) {
+        mask[x] = (uint8_t)(ncol[x] > 1 && x >= IDX_SWITCH - OVERLAP);
+        if (mask[x]) blk[nm++] = mean_hos[x];                 /* mhp (data_hos is not needed any more) */
+    }
+    const int64_t mk = bbx_clipped_stats_flat_f32seq(blk, nm, 5.0, 5, st);
+    if (mk <= 0) return 8;
+    const float cm = (float)st[0], cs = (float)st[1];
+    if (!(cs == 0.0f)) {
+        for (int x = 0; x < xsz; x++)
+            if (mask[x]) mask[x] = (uint8_t)(fabsf(mean_hos[x] - cm) / cs <= 5.0f);
+    }
+    for (int x = 0; x < xsz; x++) yd[x] = (double)mean_hos[x];
+    double ph[16];
+    for (int it = 0; it < 3; it++) {
+        int rk;
+        if (polyfit_masked(V_hos, mask, xsz, order_h, yd, lstsq, lhs, rhs, ph, &rk) != 0) return 9;
+        polyval_arange(ph, order_h, 1, xsz, oscan_out);
+        int same = 1;
+        for (int x = 0; x < xsz; x++) {
+            const double e3 = (double)(3.0f * err_hos[x]);
+            const uint8_t nmk = (uint8_t)(mask[x] && (fabs(oscan_out[x] - yd[x]) <= e3));
+            if (nmk != mask[x]) same = 0;
+            mask2[x] = nmk;
+        }
+        if (same) break;
+        memcpy(mask, mask2, (size_t)xsz);
+    }
+    for (int x = 0; x < IDX_SWITCH; x++)                       /* mask_usemean (and the first three columns) */
+        if (ncol[x] > 1) oscan_out[x] = (double)mean_hos[x];
+    return 0;
 }

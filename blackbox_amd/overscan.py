@@ -32,11 +32,16 @@ try:
                                                   _C.c_void_p]
     _HOST.bbx_clipped_stats_flat_f32seq.restype = _C.c_int64
     _HOST.bbx_clipped_stats_flat_f32seq.argtypes = [_C.c_void_p, _C.c_int64, _C.c_double, _C.c_int, _C.c_void_p]
+    _HOST.bbx_channel_solve_ml1.restype = _C.c_int
+    _HOST.bbx_channel_solve_ml1.argtypes = ([_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_int, _C.c_int,
+                                             _C.c_int, _C.c_int, _C.c_double, _C.c_void_p, _C.c_void_p, _C.c_void_p]
+                                            + [_C.c_void_p] * 5)
     _HOST.bbx_polyfit_prep.restype = _C.c_int64
     _HOST.bbx_polyfit_prep.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_int, _C.c_void_p, _C.c_void_p]
 except OSError:
     _HOST = None
 
+USE_C_DRIVER = True   # channel_solve through libbbx_host.so (bit-identical; tests switch it off to compare)
 IDX_SWITCH = 150      # blackbox.py:6683
 OVERLAP = 30          # blackbox.py:6684
 
@@ -393,9 +398,50 @@ def channel_phase2(c, strip, xsz, tel, data_limit=2000, mask_sat_row=None, accum
     return hos_fit(n, mean_hos, std_hos, mask_sat_row, bg2_chan9=(tel == 'BG2' and c == 8), accum=accum)
 
 
+def _lstsq_cb(lhs_p, m, order, rhs_p, rcond, coef_p, rank_p):
+    """np.linalg.lstsq for the C driver (bbx_channel_solve_ml1): views on its buffers, no copies"""
+    try:
+        lhs = np.frombuffer((_C.c_char * (8 * m * order)).from_address(lhs_p), np.float64).reshape(m, order)
+        rhs = np.frombuffer((_C.c_char * (8 * m)).from_address(rhs_p), np.float64)
+        c, _, rank, _ = np.linalg.lstsq(lhs, rhs, rcond)
+        np.frombuffer((_C.c_char * (8 * order)).from_address(coef_p), np.float64)[:] = c
+        _C.c_int.from_address(rank_p).value = int(rank)
+        return 0
+    except Exception:
+        return 1
+
+
+_LSTSQ_CB = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int64, _C.c_int, _C.c_void_p, _C.c_double, _C.c_void_p,
+                         _C.c_void_p)(_lstsq_cb)
+
+
+def _channel_solve_c(c, mean_vos_col, hos, ysz, xsz, poldeg, data_limit):
+    """the whole channel in the C helper (LAPACK through the callback); None when a situation
+    turns up that only the numpy path handles (the helper says which)"""
+    col = np.ascontiguousarray(mean_vos_col, np.float64)
+    h = np.ascontiguousarray(hos, np.float32)
+    dy, (hos_rows, dx) = col.size, h.shape
+    fit, coeffs, oscan = np.empty(dy), np.empty(poldeg + 1), np.empty(xsz)
+    level, dlevel = _C.c_double(), _C.c_double()
+    rc = _HOST.bbx_channel_solve_ml1(c, col.ctypes.data, dy, h.ctypes.data, hos_rows, dx, ysz, xsz, poldeg, float(data_limit),
+                                     _vander_full(0, dy, poldeg + 1).ctypes.data, _vander_full(1, xsz, 8).ctypes.data,
+                                     _LSTSQ_CB, fit.ctypes.data, coeffs.ctypes.data, _C.addressof(level),
+                                     _C.addressof(dlevel), oscan.ctypes.data)
+    if rc < 0:
+        raise MemoryError('bbx_channel_solve_ml1')
+    if rc != 0:
+        return None
+    return dict(fit=fit, coeffs=coeffs, ok=True, level=level.value, dlevel=dlevel.value, oscan=oscan)
+
+
 def channel_solve(args):
     """both phases for telescopes without the saturated-column step (ML1)"""
     c, mean_vos_col, hos, ysz, xsz, poldeg, tel, data_limit, accum = args
+    if (_HOST is not None and USE_C_DRIVER and tel == 'ML1' and accum == 'f32seq' and hos.dtype == np.float32
+            and not (tel == 'BG2' and c == 8)):
+        r = _channel_solve_c(c, mean_vos_col, hos, ysz, xsz, poldeg, data_limit)
+        if r is not None:
+            return r
     r = channel_phase1(c, mean_vos_col, hos, ysz, xsz, poldeg, accum)
     r['oscan'] = channel_phase2(c, r.pop('strip'), xsz, tel, data_limit, None, accum)
     return r

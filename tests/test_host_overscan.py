@@ -124,3 +124,54 @@ def test_c_helpers_equal_numpy():
                 assert type(a[0]) == type(b[0])
     finally:
         ov._HOST = host
+
+
+def _channel_case(seed, c, dy=1340, dx=450, ysz=1320, xsz=330, hos_rows=10):
+    rs = np.random.RandomState(seed)
+    col = (1000 + 0.002 * np.arange(dy) + rs.normal(0, 0.8, dy)).astype(np.float64)
+    col[rs.randint(0, dy, 4)] += rs.choice([40.0, -35.0], 4)            # outliers the 5-sigma clip removes
+    hos = (1000 + rs.normal(0, 8, (hos_rows, dx))).astype(np.float32)
+    hos[:, :30] += np.linspace(20, 0, 30).astype(np.float32)[None, :]
+    hos[rs.randint(0, hos_rows, 6), rs.randint(0, xsz, 6)] += 70.0       # clipped by the column statistics
+    return [c, col, hos, ysz, xsz, 3, 'ML1', 2000, 'f32seq']
+
+
+@pytest.mark.skipif(overscan._HOST is None, reason='libbbx_host.so not built')
+def test_c_driver_equals_numpy_path():
+    """channel_solve through bbx_channel_solve_ml1 (numpy only for LAPACK) == the numpy path, bit for
+    bit; situations the helper hands back (spline columns, masked overscan pixels, NaN columns)
+    give the numpy result too"""
+    def both(a):
+        overscan.USE_C_DRIVER = True
+        try:
+            r1 = overscan.channel_solve(tuple(a))
+        finally:
+            overscan.USE_C_DRIVER = False
+        try:
+            r2 = overscan.channel_solve(tuple(a))
+        finally:
+            overscan.USE_C_DRIVER = True
+        assert set(r1) == set(r2)
+        for k in r2:
+            assert np.array_equal(np.asarray(r1[k]), np.asarray(r2[k]), equal_nan=True), k
+            assert type(r1[k]) is type(r2[k]) or isinstance(r1[k], (bool, float, np.floating, np.bool_)), k
+        return r1
+    for seed in range(10):
+        both(_channel_case(seed, (5 * seed) % 16))
+    for sz in ((5300, 1500, 5280, 1320), (700, 380, 680, 300)):
+        both(_channel_case(99, 11, dy=sz[0], dx=sz[1], ysz=sz[2], xsz=sz[3]))
+    # the helper really ran (not the fall-back) for an ordinary case
+    a = _channel_case(1, 2)
+    assert overscan._channel_solve_c(a[0], a[1], a[2], a[3], a[4], a[5], a[7]) is not None
+    # handed back: a column below IDX_SWITCH without valid pixels (spline), a bright overscan pixel,
+    # NaN in the vertical strip means, a constant strip
+    a = _channel_case(2, 3); a[2][:, 40] = np.nan
+    assert overscan._channel_solve_c(a[0], a[1], a[2], a[3], a[4], a[5], a[7]) is None
+    both(a)
+    a = _channel_case(3, 12); a[2][4, 200] += 5000.0
+    assert overscan._channel_solve_c(a[0], a[1], a[2], a[3], a[4], a[5], a[7]) is None
+    both(a)
+    a = _channel_case(4, 7); a[1][100:110] = np.nan
+    both(a)
+    a = _channel_case(5, 0); a[1][:] = 1000.0
+    both(a)
