@@ -785,7 +785,7 @@ __device__ float wg_lower_median(const bsel_dev& b, const float* __restrict__ a,
 // the frame runs now.  mode 1, after k_lac_clean: nothing to do unless pixels were listed; then
 // the level comes from the side buffer (unless it is known already) and the listed pixels get it.
 // seg->pad marks "result[0] holds the level".
-__global__ __launch_bounds__(1024) void k_lac_bg(float* a, const uint8_t* __restrict__ mask, lac_par p, bsel_dev b,
+__global__ __launch_bounds__(256) void k_lac_bg(float* a, const uint8_t* __restrict__ mask, lac_par p, bsel_dev b,
                                                  int32_t* counters, const uint32_t* __restrict__ bglist, uint32_t capbg, int mode) {
     __shared__ float s_bg;
     __shared__ int s_fail;
@@ -938,7 +938,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
                                ctx->d_err);
         }
         hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, cand);
-        if (it == 0) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(1024), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 0);
+        if (it == 0) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 0);
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
@@ -947,7 +947,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         // (the overflow list of the dense pass is free again after k_lac_compact: pixels waiting for the level)
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, ovf,
                            (uint32_t)capovf, ctx->d_err);
-        hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(1024), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1);
+        hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1);
         hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
         bbx_prof_stop(ctx, s);
     }
