@@ -251,7 +251,9 @@ def main():
         # (iterations 2..n work on the surroundings of the cleaned pixels only)
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
-            'k_lac_cand': (1, 4 * N + N),        # the one dense LA-Cosmic pass: data + mask (it also feeds the background select)
+            # the one dense LA-Cosmic pass reads the frame (the mask plane too only while the
+            # background-level feed is on, i.e. after a frame needed the level: not in this workload)
+            'k_lac_cand': (1, 4 * N),
         }
         # Kernel durations: HIP events recorded by the library around each launch, on the launch
         # stream (lane 0's context carries the timers, so one frame in [lanes] is sampled).  The

@@ -44,6 +44,7 @@ SIGNATURES = {
     'bbx_last_hip_error': (C.c_char_p, [_vp]),
     'bbx_version': (_i, []),
     'bbx_sync': (_i, [_vp, _vp]),
+    'bbx_set_option': (_i, [_vp, _i, _i]),
     'bbx_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'bbx_event_destroy': (None, [_vp]),
     'bbx_event_record': (_i, [_vp, _vp]),

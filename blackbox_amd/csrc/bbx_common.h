@@ -55,8 +55,9 @@ struct bbx_ctx {
     size_t    hash_clean_n;
     int32_t*  d_counters;      // [CNT_MAX] device counters (see enum below)
     // --- scratch, (re)allocated on demand by bbx_ws()
-    void*  d_ws[16];
-    size_t ws_bytes[16];
+    void*  d_ws[24];
+    size_t ws_bytes[24];
+    int    lac_feed;           // BBX_OPT_LAC_LEVEL_FEED (bbx_set_option)
     // --- optional per-kernel timing (bbx_profile_enable): hipEvent pairs on the launch stream
     int prof_on, prof_n;
     hipEvent_t* prof_ev;       // [2 * BBX_PROF_MAX]
@@ -87,7 +88,7 @@ enum {
 // workspace slots
 enum {
     WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
-    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG,
     WS_MAX
 };
 

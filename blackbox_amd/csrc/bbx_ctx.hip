@@ -129,6 +129,12 @@ int bbx_sync(bbx_ctx* ctx, void* stream) {
     return BBX_OK;
 }
 
+int bbx_set_option(bbx_ctx* ctx, int option, int value) {
+    if (!ctx) return BBX_ERR_ARG;
+    if (option == BBX_OPT_LAC_LEVEL_FEED) { ctx->lac_feed = value ? 1 : 0; return BBX_OK; }
+    return BBX_ERR_ARG;
+}
+
 // ---- stream plumbing (see bbx.h) ---------------------------------------------------------
 #define BBX_HIP0(call) do { if ((call) != hipSuccess) return BBX_ERR_HIP; } while (0)
 

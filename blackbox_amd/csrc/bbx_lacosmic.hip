@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256) void k_lac_grow1(lac_par p, const uint32_t* __
 #define G2_QCAP 1024
 __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, uint8_t* mask, lac_par p,
                                                    const uint32_t* __restrict__ stage2, uint32_t cap, uint8_t* flags,
-                                                   uint32_t* __restrict__ crlist, int32_t* counters, int32_t* err) {
+                                                   uint32_t* __restrict__ crlist, int32_t* counters, int32_t* err,
+                                                   float* __restrict__ orig, uint32_t caporig) {
     __shared__ uint32_t q[G2_QCAP];
     __shared__ unsigned qn, nnew, qbase;
     if (threadIdx.x == 0) { qn = 0; nnew = 0; qbase = 0; }
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, 
                             else {                                              // queue full: append directly
                                 const unsigned g = atomicAdd((unsigned*)&counters[CNT_CRLIST], 1u);
                                 if (g < cap) crlist[g] = (uint32_t)r; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                                if (orig) { if (g < caporig) orig[g] = a[r]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
                             }
                         }
                     }
@@ -683,8 +685,11 @@ __global__ __launch_bounds__(256) void k_lac_grow2(const float* __restrict__ a, 
         if (nnew) atomicAdd(&counters[CNT_NEWCR], (int)nnew);
     }
     __syncthreads();
+    // (a pixel enters the list once and is cleaned only afterwards: a[] still holds its input value,
+    // kept in orig[] for the exact background level on demand)
     for (unsigned k = threadIdx.x; k < nq; k += blockDim.x) {
         if (qbase + k < cap) crlist[qbase + k] = q[k]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        if (orig) { if (qbase + k < caporig) orig[qbase + k] = a[q[k]]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
     }
 }
 
@@ -729,8 +734,11 @@ __global__ __launch_bounds__(256) void k_lac_clean(float* a, const uint8_t* __re
 // bracketed select (then [rank] counts inside the buffer).  Three digit passes over the float
 // keys with an LDS histogram; slow next to the multi-workgroup select, but it only runs when a
 // frame needs the level at all.
+// [orig, norig]: with from_frame, pixels carrying the COSMIC bit are skipped (their values were
+// replaced) and the saved input values of the CR list stand in for them.
 __device__ float wg_lower_median(const bsel_dev& b, const float* __restrict__ a, const uint8_t* __restrict__ mask,
-                                 size_t npix, bool from_frame, unsigned long long rank) {
+                                 size_t npix, bool from_frame, unsigned long long rank,
+                                 const float* __restrict__ orig = nullptr, uint32_t norig = 0) {
     __shared__ uint32_t lh[2048];
     __shared__ uint32_t s_prefix;
     __shared__ unsigned long long s_rank;
@@ -745,9 +753,14 @@ __device__ float wg_lower_median(const bsel_dev& b, const float* __restrict__ a,
         const uint32_t pre = s_prefix, dmask = (1u << nbits[ps]) - 1u;
         const int shift = shifts[ps];
         if (from_frame) {
+            const unsigned skipbits = orig ? 0xffu : (0xffu & ~BBX_MASK_COSMIC);
             for (size_t i = tid; i < npix; i += blockDim.x) {
-                if (mask[i] & ~BBX_MASK_COSMIC) continue;
+                if (mask[i] & skipbits) continue;
                 const uint32_t key = f2key(a[i]);
+                if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+            }
+            for (uint32_t i = tid; i < norig; i += blockDim.x) {
+                const uint32_t key = f2key(orig[i]);
                 if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
             }
         } else {
@@ -786,7 +799,8 @@ __device__ float wg_lower_median(const bsel_dev& b, const float* __restrict__ a,
 // the level comes from the side buffer (unless it is known already) and the listed pixels get it.
 // seg->pad marks "result[0] holds the level".
 __global__ __launch_bounds__(256) void k_lac_bg(float* a, const uint8_t* __restrict__ mask, lac_par p, bsel_dev b,
-                                                 int32_t* counters, const uint32_t* __restrict__ bglist, uint32_t capbg, int mode) {
+                                                 int32_t* counters, const uint32_t* __restrict__ bglist, uint32_t capbg, int mode,
+                                                 int32_t* __restrict__ stats) {
     __shared__ float s_bg;
     __shared__ int s_fail;
     bsel_seg* sg = b.seg;
@@ -823,7 +837,31 @@ __global__ __launch_bounds__(256) void k_lac_bg(float* a, const uint8_t* __restr
     bg = s_bg;
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) a[bglist[k]] = bg;
     __syncthreads();
-    if (threadIdx.x == 0) { sg->result[0] = bg; sg->result[1] = bg; sg->pad = 1; counters[CNT_BGNEED] = 0; }
+    if (threadIdx.x == 0) { sg->result[0] = bg; sg->result[1] = bg; sg->pad = 1; counters[CNT_BGNEED] = 0; stats[15] = 1; }
+}
+
+// The same step when nothing was prepared (BBX_OPT_LAC_LEVEL_FEED = 0): pixels listed by
+// k_lac_clean get the level, selected exactly by this one workgroup over the good pixels of the
+// frame -- those the run has flagged and cleaned so far are taken with their input values from
+// orig[] (saved by k_lac_grow2).  lvl[0] = level, lvl[1] = known? (zeroed by k_lac_begin).
+__global__ __launch_bounds__(256) void k_lac_bg_frame(float* a, const uint8_t* __restrict__ mask, lac_par p,
+                                                      int32_t* counters, const uint32_t* __restrict__ bglist, uint32_t capbg,
+                                                      const float* __restrict__ orig, uint32_t caporig, float* lvl,
+                                                      int32_t* __restrict__ stats) {
+    __shared__ float s_bg;
+    const uint32_t n = min((uint32_t)counters[CNT_BGNEED], capbg);
+    if (n == 0) return;
+    float bg;
+    if (lvl[1] == 0.f) {                                        // workgroup-uniform
+        bsel_dev none; none.seg = nullptr; none.shard = nullptr; none.buf = nullptr; none.cap = 0; none.capS = 0;
+        bg = wg_lower_median(none, a, mask, (size_t)p.ny * p.nx, true, 0ull, orig, min((uint32_t)counters[CNT_CRLIST], caporig));
+    } else bg = lvl[0];
+    if (threadIdx.x == 0) s_bg = bg;
+    __syncthreads();
+    bg = s_bg;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) a[bglist[k]] = bg;
+    __syncthreads();
+    if (threadIdx.x == 0) { lvl[0] = bg; lvl[1] = 1.f; counters[CNT_BGNEED] = 0; stats[15] = 1; }
 }
 
 // the flag plane is only ever written at listed pixels (raw candidates; 3x3 around stage-2
@@ -845,7 +883,7 @@ __global__ __launch_bounds__(256) void k_lac_unflag(lac_par p, const uint32_t* _
     if (threadIdx.x == 0 && atomicAdd(&counters[CNT_TICKET], 1) == (int)gridDim.x - 1) {
         stats[it] = counters[CNT_NEWCR];
         stats[7] = counters[CNT_CRLIST];
-        if (it < 4) { stats[8 + 2 * it] = counters[CNT_CAND]; stats[9 + 2 * it] = counters[CNT_STAGE2]; }
+        if (it < 3) { stats[8 + 2 * it] = counters[CNT_CAND]; stats[9 + 2 * it] = counters[CNT_STAGE2]; }
         counters[CNT_NEWCR] = 0; counters[CNT_CAND] = 0; counters[CNT_STAGE2] = 0; counters[CNT_CANDOVF] = 0;
         counters[CNT_CANDRAW] = 0; counters[CNT_TICKET] = 0;
     }
@@ -880,6 +918,7 @@ __global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt
     // roundings of the division and of 2*noise (LA-Cosmic)
     out[1] = 2.0f * sigclip * sqrtf(rn2) * (1.0f - 1e-5f);
     out[2] = rn;
+    out[8] = 0.f; out[9] = 0.f;                                // background level (k_lac_bg_frame): value, known?
 }
 
 extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t* d_mask, float sigclip,
@@ -916,16 +955,22 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     ctx->flags_clean_ptr = nullptr;
     // background level of the unmasked input pixels (needed when a CR pixel has no good
     // neighbour): bracketed select fed by the first candidate pass, no extra read of the frame
+    const bool feed = ctx->lac_feed != 0;
     bsel_dev bs;
-    rc = bbx_bsel_prepare(ctx, d_data, d_mask, ny, nx, ny, nx, &bs, s);
-    if (rc) return rc;
+    memset(&bs, 0, sizeof(bs));
+    float* orig = nullptr;
+    const size_t caporig = std::min<size_t>(cap, (size_t)1 << 23);
+    if (feed) { rc = bbx_bsel_prepare(ctx, d_data, d_mask, ny, nx, ny, nx, &bs, s); if (rc) return rc; }
+    else { orig = (float*)bbx_ws(ctx, WS_CRORIG, caporig * sizeof(float), &rc); if (rc) return rc; }
     const unsigned gdense = 256u * 16u, gsparse = 256u * 8u;
     for (int it = 0; it < niter; it++) {
         if (it == 0) {
             // the one dense pass: candidates of the first iteration (+ the background-level feed)
             bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
-            if (vec) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
-            else hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
+            if (vec && feed) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            else if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            else if (feed) hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
+            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
             bbx_prof_stop(ctx, s);
             if (vec) {
                 const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, ((ntiles + 127) / 128 + 15) / 16 * 16));
@@ -938,16 +983,18 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
                                ctx->d_err);
         }
         hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, cand);
-        if (it == 0) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 0);
+        if (it == 0 && feed) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 0, d_stats);
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
         hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
         hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
         hipLaunchKernelGGL(k_lac_grow2, dim3(512), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
-                           cnt, ctx->d_err);
+                           cnt, ctx->d_err, orig, (uint32_t)caporig);
         // (the overflow list of the dense pass is free again after k_lac_compact: pixels waiting for the level)
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, ovf,
                            (uint32_t)capovf, ctx->d_err);
-        hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1);
+        if (feed) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1, d_stats);
+        else hipLaunchKernelGGL(k_lac_bg_frame, dim3(1), dim3(256), 0, s, d_data, d_mask, p, cnt, ovf, (uint32_t)capovf, orig,
+                                (uint32_t)caporig, rnp + 8, d_stats);
         hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
         bbx_prof_stop(ctx, s);
     }

@@ -341,6 +341,9 @@ class FramePipeline:
         self._k_biasm = [('BIASM{}'.format(c + 1), '[e-] channel {} mean vertical overscan'.format(c + 1)) for c in range(16)]
         self._k_rdn = [('RDN{}'.format(c + 1), '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1)) for c in range(16)]
         self.free_slots = list(range(depth))
+        # frames still to run with LA-Cosmic's background level prepared in advance (include/bbx.h,
+        # BBX_OPT_LAC_LEVEL_FEED); BBX_LAC_FEED_FRAMES sets the start value (0: only after a frame needed it)
+        self.level_feed_left = int(os.environ.get('BBX_LAC_FEED_FRAMES', '0'))
 
     def close(self):
         if self.own_pool:
@@ -462,6 +465,8 @@ class FramePipeline:
         d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom, d_n=sl['d_nobj'])
         d_stats = None
         if self.do_cosmics:
+            # background level: prepared in advance only while recent frames needed it (st[15])
+            check(lib.bbx_set_option(ctx.h, 1, 1 if self.level_feed_left > 0 else 0), 'bbx_set_option', ctx.h)
             # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
             d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std, d_stats=sl['d_stats'])
         d_cnt = sl['d_cnt6']
@@ -492,6 +497,10 @@ class FramePipeline:
             st = f.h_out[2].numpy()
             h['NCOSMICS'] = hm['NCOSMICS'] = (st[6] / float(self.exptime), '[/s] number of cosmic rays identified')
             h['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
+            if st[15]:
+                self.level_feed_left = 64             # a frame needed the level: feed it for the next frames
+            elif self.level_feed_left > 0:
+                self.level_feed_left -= 1
         f.d_keep = None
         f.state = 'done'
 

@@ -47,6 +47,11 @@ class Context:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_lac_level_feed(self, on):
+        """BBX_OPT_LAC_LEVEL_FEED (include/bbx.h): prepare LA-Cosmic's background level during the
+        dense pass (True) or select it over the frame only when a frame needs it (False, default)"""
+        check(lib.bbx_set_option(self.h, 1, 1 if on else 0), 'bbx_set_option', self.h)
+
     def sync(self):
         check(lib.bbx_sync(self.h, self.stream()), 'bbx_sync', self.h)
 

@@ -73,6 +73,18 @@ int  bbx_version(void);
  * (list overflow, non-convergence).  Call before trusting host copies. */
 int  bbx_sync(bbx_ctx *ctx, void *stream);
 
+/* Options of a context.
+ * BBX_OPT_LAC_LEVEL_FEED (default 0): how bbx_lacosmic obtains astroscrappy's background_level
+ * (the median of the good input pixels; only CR pixels without a single good 5x5 neighbour take
+ * it, which real frames rarely contain).  0: nothing is prepared; when a frame needs the level,
+ * one workgroup selects it exactly over the frame (tens of ms for 10^8 pixels, that frame
+ * only).  1: the dense candidate pass also feeds a bracketed select (reads the mask plane too,
+ * +45 % on that kernel, plus the sample / bracket kernels) and the level costs microseconds
+ * when needed.  Results are identical; a host that sees the level being needed
+ * (d_stats[15] != 0) can switch the feed on for a while (pipeline.FramePipeline does). */
+#define BBX_OPT_LAC_LEVEL_FEED 1
+int  bbx_set_option(bbx_ctx *ctx, int option, int value);
+
 /* Stream plumbing for a host that pipelines frames (the reference runs one frame per worker
  * process, blackbox.py:640-700 pool_func; here one process keeps several frames in flight on
  * HIP streams).  Thin wrappers -- hipEvent without timing, hipStreamWaitEvent,

@@ -153,8 +153,12 @@ def test_lacosmic_vs_oracle(ctx, seed, shape):
                                                 return_iters=True)
         d = torch.from_numpy(img.copy()).to(ctx.device)
         m = torch.from_numpy(mask.copy()).to(ctx.device)
-        st = R.detect_cosmics(ctx, d, m, sigclip, 0.01 if sigclip > 10 else 0.3, 3.0, 3, 8.2)
-        ctx.sync()
+        ctx.set_lac_level_feed(sigclip > 10)                        # both ways of getting the background level
+        try:
+            st = R.detect_cosmics(ctx, d, m, sigclip, 0.01 if sigclip > 10 else 0.3, 3.0, 3, 8.2)
+            ctx.sync()
+        finally:
+            ctx.set_lac_level_feed(False)
         st = st.cpu().numpy()
         m = m.cpu().numpy()
         assert cr_o.sum() > 0
@@ -266,8 +270,9 @@ def test_select_exact_fallback(ctx):
         assert np.float32(st[k, 1]) == np.median(small[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8]), k
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('feed', [False, True])
 @pytest.mark.parametrize('constant_sky', [False, True])
-def test_lacosmic_background_level(ctx, constant_sky):
+def test_lacosmic_background_level(ctx, constant_sky, feed):
     """CR pixels without a single good neighbour take the background level (lower median of the
     good pixels): produced on demand from the select's side buffer; with a constant sky the
     bracket cannot hold the rank and the exact select over the frame has to deliver it"""
@@ -293,9 +298,15 @@ def test_lacosmic_background_level(ctx, constant_sky):
     assert clean_o[40, 50] == level
     d = torch.from_numpy(img.copy()).to(ctx.device)
     m = torch.from_numpy(mask.copy()).to(ctx.device)
-    st = R.detect_cosmics(ctx, d, m, 4.5, 0.3, 3.0, 3, 8.2)
-    ctx.sync()
+    ctx.set_lac_level_feed(feed)                                    # prepared in advance / selected over the frame on demand
+    try:
+        st = R.detect_cosmics(ctx, d, m, 4.5, 0.3, 3.0, 3, 8.2)
+        ctx.sync()
+    finally:
+        ctx.set_lac_level_feed(False)
     assert np.array_equal((m.cpu().numpy() & 2) != 0, cr_o)
     assert np.array_equal(d.cpu().numpy(), clean_o)
-    assert list(st.cpu().numpy()[:len(ncr_o)]) == ncr_o
+    st = st.cpu().numpy()
+    assert list(st[:len(ncr_o)]) == ncr_o
+    assert st[15] == 1                                              # "the level was needed"
 
