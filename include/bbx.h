@@ -77,8 +77,8 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * BBX_OPT_LAC_LEVEL_FEED (default 0): how bbx_lacosmic obtains astroscrappy's background_level
  * (the median of the good input pixels; only CR pixels without a single good 5x5 neighbour take
  * it, which real frames rarely contain).  0: nothing is prepared; when a frame needs the level,
- * one workgroup selects it exactly over the frame (tens of ms for 10^8 pixels, that frame
- * only).  1: the dense candidate pass also feeds a bracketed select (reads the mask plane too,
+ * 256 workgroups select it exactly over the frame together (about 1 ms for 10^8 pixels, that
+ * frame only).  1: the dense candidate pass also feeds a bracketed select (reads the mask plane too,
  * +45 % on that kernel, plus the sample / bracket kernels) and the level costs microseconds
  * when needed.  Results are identical; a host that sees the level being needed
  * (d_stats[15] != 0) can switch the feed on for a while (pipeline.FramePipeline does). */

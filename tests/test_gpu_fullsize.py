@@ -172,3 +172,36 @@ def test_xtalk_and_edge_fill_fullsize(frame):
         edge = (hm[sl] & 32) == 32
         assert edge.any() and (host[sl][edge] == med[c]).all()
         assert np.array_equal(host[sl][~edge], pre[sl][~edge])
+
+
+def test_lacosmic_background_level_fullsize(frame):
+    """a CR pixel without a good neighbour on the full frame: the level selected over the frame on
+    demand == the level from the fed bracketed select == the (n-1)//2-th smallest good pixel"""
+    import time
+    f = frame
+    ctx = f['ctx']
+    base_d, base_m = f['data'].clone(), f['mask'].clone()
+    spots = [(3000, 4000), (7001, 123), (9000, 10000)]
+    for (j, i) in spots:
+        base_m[j - 2:j + 3, i - 2:i + 3] |= 1
+        base_m[j, i] = 0
+        base_d[j, i] = 40000.0
+    good = base_m == 0
+    vals = base_d[good]
+    level = torch.kthvalue(vals, (vals.numel() - 1) // 2 + 1).values.item()
+    out = {}
+    for feed in (False, True):
+        d, m = base_d.clone(), base_m.clone()
+        ctx.set_lac_level_feed(feed)
+        try:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            st = R.cosmics_corr(ctx, d, dict(f['header']), m, {}, 'ML1')
+            ctx.sync(); dt = time.perf_counter() - t0
+        finally:
+            ctx.set_lac_level_feed(False)
+        assert int(st.cpu().numpy()[15]) == 1
+        for (j, i) in spots:
+            assert (int(m[j, i].item()) & 2) and d[j, i].item() == level
+        out[feed] = (d, m)
+        print('background level needed, feed=%s: %.1f ms' % (feed, 1e3 * dt))
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])

@@ -30,8 +30,22 @@ def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
     dev = ctx.device
     cases = [synth.make_case(ys, xs, 100 + k, tel=tel, os_y=os_y, os_x=os_x, n_stars=60, n_sat=4, n_cr=60)
              for k in range(4)]
+    # frames 1 and 3 hold a hot pixel inside a fully masked 5x5 block: the cleaned value is LA-Cosmic's
+    # background level -- selected over the frame on demand in the serial runs and in the pipeline's
+    # first such frame, prepared in advance (BBX_OPT_LAC_LEVEL_FEED) in the pipeline's later ones
+    bpm_np = cases[0]['bpm'].copy()
+    hot = [(ys // 2 + 7, xs + 13), (ys + 5, 3 * xs + 40)]
+    for (j, i) in hot:
+        bpm_np[j - 2:j + 3, i - 2:i + 3] |= 1
+        bpm_np[j, i] = 0
+    dy, dx = ys + os_y, xs + os_x
+    for k in (1, 3):
+        for (j, i) in hot:
+            iy, ix = j // ys, i // xs
+            rj = iy * dy + (j - iy * ys) + (0 if iy == 0 else os_y)
+            cases[k]['raw'][rj, ix * dx + (i - ix * xs)] = 15000       # well below saturation
     flat = torch.from_numpy(cases[0]['flat']).to(dev)
-    bpm = torch.from_numpy(cases[0]['bpm']).to(dev)
+    bpm = torch.from_numpy(bpm_np).to(dev)
     coeffs = O.xtalk_coeffs(cases[0]['xtalk'])
     raws = [torch.from_numpy(c['raw']).to(dev) for c in cases]
     geom = R.geometry(raws[0].shape, ys, xs)
@@ -49,7 +63,9 @@ def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
     def done(idx, f):
         got[idx] = (f.data.cpu().numpy(), f.mask.cpu().numpy(), f.header)
     n = pipe.run([(r, {}) for r in raws], on_done=done)
+    fed = pipe.level_feed_left
     pipe.close()
+    assert fed > 0                                                # a frame needed the level: the feed is on now
     assert n == len(raws) and sorted(got) == list(range(len(raws)))
     for k in range(len(raws)):
         d0, m0, h0 = serial[k]
