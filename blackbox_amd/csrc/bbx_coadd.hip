@@ -57,7 +57,23 @@ __global__ __launch_bounds__(256) void k_coadd_prep(float* __restrict__ data, co
 // instead of twelve sines.  Single precision like SWarp's kernels: the taps agree with the
 // float64 oracle to a few 1e-7, which is the tolerance of the resampling tests.
 __device__ __forceinline__ void l3_taps(float f, float* k) {
-    const float s1 = sinpif(f), s3 = sinpif(f * (1.0f / 3.0f)), c3 = cospif(f * (1.0f / 3.0f));
+    // sin and cos of y = pi f / 3 (0 <= y < 1.05) from their Taylor polynomials (through y^11 / y^12:
+    // below float32 resolution on this interval); sin(pi f) follows from the triple-angle identity
+    const float y = f * 1.04719755119659774615f, y2 = y * y;
+    float ps = -2.50521083854417187751e-8f;                   // -1/11!
+    ps = __builtin_fmaf(ps, y2, 2.75573192239858906526e-6f);  //  1/9!
+    ps = __builtin_fmaf(ps, y2, -1.98412698412698412698e-4f); // -1/7!
+    ps = __builtin_fmaf(ps, y2, 8.33333333333333333333e-3f);  //  1/5!
+    ps = __builtin_fmaf(ps, y2, -1.66666666666666666667e-1f); // -1/3!
+    const float s3 = __builtin_fmaf(ps * y2, y, y);
+    float pc = 2.08767569878680989792e-9f;                    //  1/12!
+    pc = __builtin_fmaf(pc, y2, -2.75573192239858906526e-7f); // -1/10!
+    pc = __builtin_fmaf(pc, y2, 2.48015873015873015873e-5f);  //  1/8!
+    pc = __builtin_fmaf(pc, y2, -1.38888888888888888889e-3f); // -1/6!
+    pc = __builtin_fmaf(pc, y2, 4.16666666666666666667e-2f);  //  1/4!
+    pc = __builtin_fmaf(pc, y2, -0.5f);
+    const float c3 = __builtin_fmaf(pc, y2, 1.0f);
+    const float s1 = s3 * (3.0f - 4.0f * s3 * s3);
     const float H = 0.86602540378443864676f;                 // sin(pi/3)
     const float ci[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};   // cos(i pi/3), i = -2..3
     const float si[6] = {-H, -H, 0.0f, H, H, 0.0f};                // sin(i pi/3)
@@ -68,10 +84,11 @@ __device__ __forceinline__ void l3_taps(float f, float* k) {
         const float t = f - (float)i;
         const float sa = (i & 1) ? -s1 : s1;                  // sin(pi t)
         const float sb = s3 * ci[q] - c3 * si[q];             // sin(pi t / 3)
-        const float val = (t == 0.f) ? 1.0f : (3.0f * sa * sb) / ((float)(M_PI * M_PI) * (t * t));
+        // (hardware reciprocal, 1 ulp: the taps are normalised afterwards)
+        const float val = (t == 0.f) ? 1.0f : (3.0f * sa * sb) * __builtin_amdgcn_rcpf((float)(M_PI * M_PI) * (t * t));
         v[q] = val; sum += val;
     }
-    const float rs = 1.0f / sum;
+    const float rs = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int q = 0; q < 6; q++) k[q] = v[q] * rs;
 }
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(256) void k_resample_l3(rs_args a) {
             const int r = idx / W, c = idx - r * W;
             const size_t g = (size_t)(y0 + r) * a.in_nx + (x0 + c);
             const float f = a.in[g], w = a.win[g];
-            tile[r * RT_LW + c] = make_float2(f, (w > 0.f) ? 1.0f / w : RS_BIG);
+            tile[r * RT_LW + c] = make_float2(f, (w > 0.f) ? 1.0f / w : __builtin_huge_valf());   // inf poisons the sum
         }
     }
     __syncthreads();
@@ -173,8 +190,9 @@ __global__ __launch_bounds__(256) void k_resample_l3(rs_args a) {
         if (staged) {
             const float2* p = tile + (fyi[k] - 2 - y0) * RT_LW + (fxi[k] - 2 - x0);
             // (data, variance) pairs through packed fused multiply-adds
+            // a zero-weight input pixel carries an infinite variance: any tap touching it (even
+            // with a zero kernel value: 0 * inf = NaN) leaves the interpolated variance non-finite
             f32x2 acc2 = {0.f, 0.f};
-            float vmax = 0.f;
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 f32x2 row2 = {0.f, 0.f};
@@ -182,7 +200,6 @@ __global__ __launch_bounds__(256) void k_resample_l3(rs_args a) {
                 for (int i = 0; i < 6; i++) {
                     const float2 fv = p[i];
                     const f32x2 v2 = {fv.x, fv.y}, k2 = {kx[i], kx[i]};
-                    vmax = fmaxf(vmax, fv.y);
                     row2 = __builtin_elementwise_fma(k2, v2, row2);
                 }
                 const f32x2 ky2 = {ky[j], ky[j]};
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(256) void k_resample_l3(rs_args a) {
                 p += RT_LW;
             }
             acc = acc2.x; vacc = acc2.y;
-            bad = vmax >= RS_BIG;
+            bad = !(fabsf(vacc) < __builtin_huge_valf());
         } else {
             const float* p = a.in + (size_t)(fyi[k] - 2) * a.in_nx + (fxi[k] - 2);
             const float* pw = a.win + (size_t)(fyi[k] - 2) * a.in_nx + (fxi[k] - 2);
