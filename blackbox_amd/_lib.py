@@ -65,7 +65,9 @@ SIGNATURES = {
     'bbx_funpack_tiles': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     'bbx_coadd_prep': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'bbx_resample_lanczos3': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
-    'bbx_coadd_combine': (_i, [_vp, _i, C.c_int64, _vp, _vp, C.c_int64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_coadd_combine': (_i, [_vp, _i, C.c_int64, _vp, _vp, C.c_int64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_clipped2mask': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, C.POINTER(C.c_int),
+                          C.POINTER(C.c_float), C.POINTER(C.c_int), _vp, _vp, _vp, _vp]),
     'bbx_psf_model': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'bbx_rect_scale': (_i, [_vp, _i, _i, _i, _vp, _f, _i, _vp]),
     'bbx_nonlin_set': (_i, [_vp, _i, C.POINTER(C.c_int32), _pd, _pd]),

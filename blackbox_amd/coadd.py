@@ -7,6 +7,7 @@ Host-side mirror of the data path of the reference's buildref.py:
   scale_chan_zps    buildref.py:3019-3047
   resample          SWarp's -RESAMPLING_TYPE LANCZOS3 step (buildref.py:1748)
   combine           SWarp's -COMBINE_TYPE step (buildref.py:1733, 1815; CLIPPED 1780-1788)
+  clipped2mask      clipped2mask_loop + pass_filters (buildref.py:3686-3873): clip log -> input-frame masks
   imcombine         resample every prepared image onto the output frame and combine them: the
                     data path of imcombine_mp (buildref.py:1425-2000) between reading the inputs
                     and writing the co-add
@@ -168,21 +169,66 @@ def combine(ctx, cube, wcube, combine_type='weighted', nsigma_clip=4.0, A_swarp=
     wout = torch.empty((ny, nx), dtype=torch.float32, device=ctx.device)
     nclip = torch.zeros(n, dtype=torch.int64, device=ctx.device)
     cm = torch.empty((n, ny, nx), dtype=torch.uint8, device=ctx.device) if (clipmask and t == 'clipped') else None
+    ns = torch.empty((n, ny, nx), dtype=torch.float32, device=ctx.device) if cm is not None else None
     check(lib.bbx_coadd_combine(ctx.h, n, ny * nx, _ptr(cube), _ptr(wcube), ny * nx, COMBINE_TYPES[t],
-                                float(nsigma_clip), float(A_swarp), _ptr(out), _ptr(wout), _ptr(cm), _ptr(nclip),
+                                float(nsigma_clip), float(A_swarp), _ptr(out), _ptr(wout), _ptr(cm), _ptr(ns), _ptr(nclip),
                                 ctx.stream()), 'bbx_coadd_combine', ctx.h)
-    return out, wout, nclip, cm
+    if cm is not None:
+        return out, wout, nclip, (cm, ns)
+    return out, wout, nclip, None
+
+
+def clipped2mask(ctx, clip, nsig, grid, in_shape, data_mask, weights, nsigma_clip, fwhm, step=GRID_STEP,
+                 sat_bits=None, fsize=(5, 1), fmax=(4, 1)):
+    """clipped2mask_loop (buildref.py:3686-3783) for one input image: clip / nsig = that image's
+    planes of the clip log (combine(..., 'clipped', clipmask=True)), grid = its projection lattice;
+    zeroes [weights] (in place) where the filtered clipped pixels fall -> (mask uint8, number)"""
+    out_ny, out_nx = clip.shape
+    in_ny, in_nx = in_shape
+    _expect(clip, torch.uint8, (out_ny, out_nx), 'clip')
+    _expect(nsig, torch.float32, (out_ny, out_nx), 'nsig')
+    _expect(data_mask, torch.uint8, (in_ny, in_nx), 'data_mask')
+    _expect(weights, torch.float32, (in_ny, in_nx), 'weights')
+    if not torch.is_tensor(grid):
+        grid = torch.from_numpy(np.ascontiguousarray(grid, np.float64)).to(ctx.device)
+    gny, gnx = int(grid.shape[0]), int(grid.shape[1])
+    _expect(grid, torch.float64, (gny, gnx, 2), 'grid')
+    if sat_bits is None:
+        sat_bits = 0
+        for key, val in settings.mask_value.items():
+            if 'saturated' in key:
+                sat_bits |= val
+    nf = len(fsize)
+    fsigma = [float(nsigma_clip), 4.0][:nf] if nf <= 2 else [float(nsigma_clip)] + [4.0] * (nf - 1)
+    mask_im = torch.empty((in_ny, in_nx), dtype=torch.uint8, device=ctx.device)
+    nmasked = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    check(lib.bbx_clipped2mask(ctx.h, out_ny, out_nx, _ptr(clip), _ptr(nsig), _ptr(grid), gny, gnx, int(step), in_ny, in_nx,
+                               _ptr(data_mask), int(sat_bits), float((5 * fwhm) ** 2), nf, (C.c_int * nf)(*[int(v) for v in fsize]),
+                               (C.c_float * nf)(*fsigma), (C.c_int * nf)(*[int(v) for v in fmax]), _ptr(weights), _ptr(mask_im),
+                               _ptr(nmasked), ctx.stream()), 'bbx_clipped2mask', ctx.h)
+    return mask_im, nmasked
 
 
 def imcombine(ctx, images, weights, wcs_list, wcs_out, out_shape, combine_type='weighted', fscale=None,
-              nsigma_clip=4.0, A_swarp=0.3, step=GRID_STEP, clipmask=False):
+              nsigma_clip=4.0, A_swarp=0.3, step=GRID_STEP, clipmask=False, masks=None, fwhm=None):
     """images / weights: prepared device tensors (prep_inputimage); wcs_list: TanWCS per image.
-    -> (co-add, weights, nclip, clip mask)"""
+    -> (co-add, weights, nclip, clip log).  With combine_type 'clipped' and masks + fwhm given, the
+    reference's two passes run (buildref.py:1773-1833): CLIPPED with the clip log, clipped2mask on
+    every input image (its weights are changed in place), then WEIGHTED."""
     n = len(images)
     fscale = [1.0] * n if fscale is None else list(fscale)
     cube = torch.empty((n,) + tuple(out_shape), dtype=torch.float32, device=ctx.device)
     wcube = torch.empty_like(cube)
+    grids = [torch.from_numpy(projection_grid(wcs_list[k], wcs_out, out_shape, step)).to(ctx.device) for k in range(n)]
     for k in range(n):
-        grid = projection_grid(wcs_list[k], wcs_out, out_shape, step)
-        resample(ctx, images[k], weights[k], grid, out_shape, fscale[k], step, out=cube[k], wout=wcube[k])
-    return combine(ctx, cube, wcube, combine_type, nsigma_clip, A_swarp, clipmask)
+        resample(ctx, images[k], weights[k], grids[k], out_shape, fscale[k], step, out=cube[k], wout=wcube[k])
+    two_pass = combine_type.lower() == 'clipped' and masks is not None and fwhm is not None
+    res = combine(ctx, cube, wcube, combine_type, nsigma_clip, A_swarp, clipmask or two_pass)
+    if not two_pass:
+        return res
+    cm, ns = res[3]
+    for k in range(n):
+        clipped2mask(ctx, cm[k], ns[k], grids[k], tuple(images[k].shape), masks[k], weights[k], nsigma_clip, fwhm[k], step)
+        resample(ctx, images[k], weights[k], grids[k], out_shape, fscale[k], step, out=cube[k], wout=wcube[k])
+    out, wout, _, _ = combine(ctx, cube, wcube, 'weighted')
+    return out, wout, res[2], res[3]

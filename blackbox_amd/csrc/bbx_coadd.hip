@@ -244,6 +244,7 @@ struct cb_args {
     float clip_sigma, clip_ampfrac;
     float* out; float* wout;
     uint8_t* clipmask;               // [n][npix] or null
+    float* nsigma;                   // [n][npix] or null: deviation of the dropped pixels in sigma
     unsigned long long* nclip;       // [n] or null
 };
 
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256) void k_combine(cb_args a) {
     const int m = __popc(valid);
     double out = 0.0, wout = 0.0;
     unsigned drop = 0;
+    float med_keep = 0.f;
     if (m > 0) {
         double sw = 0.0, swf = 0.0, sf = 0.0, sinv = 0.0;
         const bool need_inv = (TYPE == CB_AVERAGE || TYPE == CB_SUM || TYPE == CB_MEDIAN);
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(256) void k_combine(cb_args a) {
             else {
                 // the clip test runs in float32 (SWarp's pixel type): |f - med| > sigma*sqrt(1/w) + A*|med|
                 const float med32 = (float)med, amed = a.clip_ampfrac * fabsf(med32);
+                med_keep = med32;
                 double sw2 = 0.0, swf2 = 0.0;
                 int nk = 0;
 #pragma unroll
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256) void k_combine(cb_args a) {
             if (i < a.n) {                                      // uniform
                 const bool d = live && (drop >> i & 1u);
                 if (a.clipmask && live) a.clipmask[(size_t)i * a.npix + p] = d ? 1 : 0;
+                if (a.nsigma && live) a.nsigma[(size_t)i * a.npix + p] = d ? (f[i] - med_keep) / sqrtf(1.0f / w[i]) : 0.f;
                 if (a.nclip) {
                     const unsigned long long bal = __ballot(d);
                     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&a.nclip[i], (unsigned long long)__popcll(bal));
@@ -371,7 +375,147 @@ static void launch_combine(const cb_args& a, hipStream_t s) {
     else hipLaunchKernelGGL((k_combine<TYPE, 32>), grid, block, 0, s, a);
 }
 
+// ---------------------------------------------------------------------------------
+// clipped pixels of the first CLIPPED pass -> mask in the frame of an input image
+// (buildref.py clipped2mask_loop 3686-3783, pass_filters 3784-3873)
+// ---------------------------------------------------------------------------------
+struct c2m_point { uint32_t xy; float nsigma; };          // (y0 << 16) | x0, 0-based input pixel
+
+__global__ __launch_bounds__(256) void k_c2m_points(rs_args g, const uint8_t* __restrict__ clip, const float* __restrict__ nsig,
+                                                    float min_sigma, c2m_point* __restrict__ pts, unsigned* __restrict__ npts,
+                                                    unsigned cap, int32_t* err) {
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool keep = false;
+    c2m_point pt = {0u, 0.f};
+    if (X < g.out_nx && Y < g.out_ny) {
+        const size_t o = (size_t)Y * g.out_nx + X;
+        if (clip[o] && fabsf(nsig[o]) > min_sigma) {
+            double pos[2];
+            rs_position(g, X, Y, pos);
+            // (x_im + 0.5).astype(uint16) on 1-based positions; kept when 1 <= x <= xsize
+            const double x1 = pos[0] + 1.0 + 0.5, y1 = pos[1] + 1.0 + 0.5;
+            if (x1 >= 1.0 && y1 >= 1.0 && x1 < 60000.0 && y1 < 60000.0) {
+                const int xi = (int)x1, yi = (int)y1;
+                if (xi <= g.in_nx && yi <= g.in_ny) { keep = true; pt.xy = ((uint32_t)(yi - 1) << 16) | (uint32_t)(xi - 1); pt.nsigma = nsig[o]; }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(npts, (unsigned)__popcll(m));
+        base = __shfl(base, leader, 64);
+        const unsigned k = base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        if (keep) { if (k < cap) pts[k] = pt; else atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
+    }
+}
+
+__device__ __forceinline__ void add_u8(uint8_t* plane, size_t idx) {
+    atomicAdd((unsigned*)(plane + (idx & ~(size_t)3)), 1u << (8 * (idx & 3)));      // (counts stay far below 256)
+}
+
+// mode 0: count the boxes of the selected points; 1: mark the back-boxes of box pixels whose count
+// reached fmax; 2: clear the boxes; 3: fsize == 1, mark the pixels themselves
+__global__ __launch_bounds__(256) void k_c2m_filter(const c2m_point* __restrict__ pts, const unsigned* __restrict__ npts, unsigned cap,
+                                                    int ny, int nx, int fsize, float fsigma, int fmax, uint8_t* cnt0, uint8_t* cnt1,
+                                                    uint8_t* mask_im, int mode) {
+    const unsigned n = min(*npts, cap);
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const c2m_point pt = pts[k];
+        if (!(fabsf(pt.nsigma) > fsigma)) continue;
+        const int i0 = (int)(pt.xy & 0xffffu), j0 = (int)(pt.xy >> 16);
+        if (mode == 3) { mask_im[(size_t)j0 * nx + i0] = 1; continue; }
+        if (mode == 0 && mask_im[(size_t)j0 * nx + i0]) continue;          // masked by an earlier filter
+        const int i1 = min(i0 + fsize, nx), j1 = min(j0 + fsize, ny);
+        uint8_t* cnt = (pt.nsigma > 0.f) ? cnt1 : cnt0;
+        for (int j = j0; j < j1; j++)
+            for (int i = i0; i < i1; i++) {
+                const size_t q = (size_t)j * nx + i;
+                if (mode == 0) add_u8(cnt, q);
+                else if (mode == 2) { cnt0[q] = 0; cnt1[q] = 0; }
+                else if (cnt0[q] >= fmax || cnt1[q] >= fmax) {
+                    const int ib = max(i + 1 - fsize, 0), jb = max(j + 1 - fsize, 0);
+                    for (int jj = jb; jj <= j; jj++)
+                        for (int ii = ib; ii <= i; ii++) mask_im[(size_t)jj * nx + ii] = 1;
+                }
+            }
+    }
+}
+
+// masked pixels within sqrt(dist2) of a saturated pixel are released; the weights of the others go to zero
+__global__ __launch_bounds__(256) void k_c2m_apply(uint8_t* __restrict__ mask_im, const uint8_t* __restrict__ data_mask, int ny, int nx,
+                                                   int sat_bits, float dist2, float* __restrict__ weights,
+                                                   unsigned long long* __restrict__ nmasked) {
+    const int R = (int)floorf(sqrtf(dist2));
+    unsigned long long cnt = 0;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)ny * nx; o += (size_t)gridDim.x * blockDim.x) {
+        if (!mask_im[o]) continue;
+        const int j = (int)(o / nx), i = (int)(o - (size_t)j * nx);
+        bool near = false;
+        for (int dj = -R; dj <= R && !near; dj++) {
+            const int jj = j + dj;
+            if (jj < 0 || jj >= ny) continue;
+            for (int di = -R; di <= R; di++) {
+                const int ii = i + di;
+                if (ii < 0 || ii >= nx) continue;
+                if ((float)(di * di + dj * dj) <= dist2 && (data_mask[(size_t)jj * nx + ii] & sat_bits)) { near = true; break; }
+            }
+        }
+        if (near) mask_im[o] = 0;
+        else { weights[o] = 0.f; cnt++; }
+    }
+    cnt = (unsigned long long)wave_sum_i64((long long)cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nmasked, cnt);
+}
+
 extern "C" {
+
+int bbx_clipped2mask(bbx_ctx* ctx, int out_ny, int out_nx, const uint8_t* d_clip, const float* d_nsigma, const double* d_grid,
+                     int gny, int gnx, int gstep, int in_ny, int in_nx, const uint8_t* d_data_mask, int sat_bits,
+                     float dist2_limit, int nfilt, const int* h_fsize, const float* h_fsigma, const int* h_fmax,
+                     float* d_weights, uint8_t* d_mask_im, int64_t* d_nmasked, void* stream) {
+    if (!ctx || !d_clip || !d_nsigma || !d_grid || !d_data_mask || !d_weights || !d_mask_im || !d_nmasked || !h_fsize || !h_fsigma || !h_fmax)
+        return BBX_ERR_ARG;
+    if (out_ny < 1 || out_nx < 1 || in_ny < 1 || in_nx < 1 || in_ny > 60000 || in_nx > 60000 || gstep < 1 || nfilt < 1 || nfilt > 8)
+        return BBX_ERR_ARG;
+    if ((out_ny - 1) / gstep + 1 >= gny || (out_nx - 1) / gstep + 1 >= gnx || !(dist2_limit >= 0.f) || dist2_limit > 1.0e4f) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t in_npix = (size_t)in_ny * in_nx, in_pad = (in_npix + 3) & ~(size_t)3;
+    const size_t cap = (size_t)out_ny * out_nx / 8 + 4096;
+    int rc;
+    // 2 count planes | point count | points
+    char* w = (char*)bbx_ws(ctx, WS_HIST, 2 * in_pad + 64 + cap * sizeof(c2m_point), &rc); if (rc) return rc;
+    uint8_t* cnt0 = (uint8_t*)w; uint8_t* cnt1 = cnt0 + in_pad;
+    unsigned* npts = (unsigned*)(w + 2 * in_pad);
+    c2m_point* pts = (c2m_point*)(w + 2 * in_pad + 64);
+    BBX_HIP(hipMemsetAsync(w, 0, 2 * in_pad + 64, s));
+    BBX_HIP(hipMemsetAsync(d_mask_im, 0, in_npix, s));
+    BBX_HIP(hipMemsetAsync(d_nmasked, 0, sizeof(int64_t), s));
+    float min_sigma = h_fsigma[0];
+    for (int k = 1; k < nfilt; k++) min_sigma = h_fsigma[k] < min_sigma ? h_fsigma[k] : min_sigma;
+    for (int k = 0; k < nfilt; k++)
+        if (h_fsize[k] < 1 || h_fsize[k] > 64 || h_fmax[k] < 1 || h_fmax[k] > 255) return BBX_ERR_ARG;
+    rs_args g;
+    memset(&g, 0, sizeof(g));
+    g.in_ny = in_ny; g.in_nx = in_nx; g.out_ny = out_ny; g.out_nx = out_nx; g.grid = d_grid; g.gny = gny; g.gnx = gnx; g.gstep = gstep;
+    hipLaunchKernelGGL(k_c2m_points, dim3((out_nx + 63) / 64, (out_ny + 3) / 4), dim3(256), 0, s, g, d_clip, d_nsigma, min_sigma, pts,
+                       npts, (unsigned)cap, ctx->d_err);
+    for (int k = 0; k < nfilt; k++) {
+        if (h_fsize[k] == 1) {
+            hipLaunchKernelGGL(k_c2m_filter, dim3(512), dim3(256), 0, s, pts, npts, (unsigned)cap, in_ny, in_nx, 1, h_fsigma[k], h_fmax[k],
+                               cnt0, cnt1, d_mask_im, 3);
+        } else {
+            for (int mode = 0; mode < 3; mode++)
+                hipLaunchKernelGGL(k_c2m_filter, dim3(512), dim3(256), 0, s, pts, npts, (unsigned)cap, in_ny, in_nx, h_fsize[k], h_fsigma[k],
+                                   h_fmax[k], cnt0, cnt1, d_mask_im, mode);
+        }
+    }
+    hipLaunchKernelGGL(k_c2m_apply, dim3(2048), dim3(256), 0, s, d_mask_im, d_data_mask, in_ny, in_nx, sat_bits & 255, dist2_limit,
+                       d_weights, (unsigned long long*)d_nmasked);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
 
 int bbx_coadd_prep(bbx_ctx* ctx, int64_t npix, float* d_data, const float* d_bkg, const float* d_bkg_std,
                    const uint8_t* d_mask, int discard_bits, int edge_value, float* d_weights, void* stream) {
@@ -402,7 +546,7 @@ int bbx_resample_lanczos3(bbx_ctx* ctx, int in_ny, int in_nx, const float* d_in,
 
 int bbx_coadd_combine(bbx_ctx* ctx, int n, int64_t npix, const float* d_cube, const float* d_wcube, int64_t plane_stride,
                       int combine_type, float clip_sigma, float clip_ampfrac, float* d_out, float* d_wout,
-                      uint8_t* d_clipmask, int64_t* d_nclip, void* stream) {
+                      uint8_t* d_clipmask, float* d_nsigma, int64_t* d_nclip, void* stream) {
     if (!ctx || !d_cube || !d_wcube || !d_out || !d_wout || n < 1 || n > 32 || npix <= 0 || plane_stride < npix)
         return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -410,6 +554,7 @@ int bbx_coadd_combine(bbx_ctx* ctx, int n, int64_t npix, const float* d_cube, co
     a.cube = d_cube; a.wcube = d_wcube; a.stride = plane_stride; a.npix = (size_t)npix; a.n = n;
     a.clip_sigma = clip_sigma; a.clip_ampfrac = clip_ampfrac; a.out = d_out; a.wout = d_wout;
     a.clipmask = combine_type == CB_CLIPPED ? d_clipmask : nullptr;
+    a.nsigma = combine_type == CB_CLIPPED ? d_nsigma : nullptr;
     a.nclip = combine_type == CB_CLIPPED ? (unsigned long long*)d_nclip : nullptr;
     if (d_nclip) BBX_HIP(hipMemsetAsync(d_nclip, 0, (size_t)n * sizeof(int64_t), s));
     switch (combine_type) {

@@ -215,7 +215,8 @@ int bbx_rect_scale(bbx_ctx *ctx, int ny, int nx, int stride, float *d_data, floa
  * float64 sums in plane order.  CLIPPED (Gruen et al. 2014, -CLIP_SIGMA / -CLIP_AMPFRAC,
  * buildref.py:1780-1788): values further than clip_sigma*sqrt(1/w) + clip_ampfrac*|median|
  * from the median of the valid values are dropped, then WEIGHTED; d_clipmask [n][npix] (1 =
- * dropped) and d_nclip [n] take SWarp's clip log (-CLIP_WRITELOG), both optional.           */
+ * dropped), d_nsigma [n][npix] (deviation of the dropped values in sigma, 0 elsewhere) and
+ * d_nclip [n] take SWarp's clip log (-CLIP_WRITELOG); all three optional.                    */
 #define BBX_COMBINE_WEIGHTED 0
 #define BBX_COMBINE_AVERAGE  1
 #define BBX_COMBINE_MEDIAN   2
@@ -233,7 +234,26 @@ int bbx_resample_lanczos3(bbx_ctx *ctx, int in_ny, int in_nx, const float *d_in,
 int bbx_coadd_combine(bbx_ctx *ctx, int n, int64_t npix, const float *d_cube,
                       const float *d_wcube, int64_t plane_stride, int combine_type,
                       float clip_sigma, float clip_ampfrac, float *d_out, float *d_wout,
-                      uint8_t *d_clipmask, int64_t *d_nclip, void *stream);
+                      uint8_t *d_clipmask, float *d_nsigma, int64_t *d_nclip, void *stream);
+/* bbx_clipped2mask replaces clipped2mask_loop + pass_filters (buildref.py:3686-3873) for one
+ * input image: d_clip / d_nsigma = that image's plane of bbx_coadd_combine's clip mask and
+ * deviations (the clip log, output frame); every clipped pixel with |nsigma| > min(fsigma) is
+ * carried to the input frame through the same lattice d_grid as the resampling (rounding
+ * `(x + 0.5).astype(uint16)` on 1-based positions), then the filters run in order: points with
+ * |nsigma| > fsigma[k] that are not masked yet add 1 to an fsize x fsize box of a count image
+ * (positive and negative deviations apart); where a count reaches fmax, the fsize x fsize box
+ * ending at that pixel is masked; fsize == 1 masks the points themselves (the reference uses
+ * fsize = [5, 1], fsigma = [nsigma_clip, 4], fmax = [4, 1]).  Masked pixels within
+ * sqrt(dist2_limit) = 5 S-FWHM of a pixel with (data_mask & sat_bits) are released; d_weights
+ * of the others are set to 0 (the second, WEIGHTED pass then ignores them).  d_mask_im
+ * [in_ny][in_nx] receives the mask, d_nmasked the number of zeroed weights.  Integer work:
+ * identical to the numpy code. */
+int bbx_clipped2mask(bbx_ctx *ctx, int out_ny, int out_nx, const uint8_t *d_clip,
+                     const float *d_nsigma, const double *d_grid, int gny, int gnx, int gstep,
+                     int in_ny, int in_nx, const uint8_t *d_data_mask, int sat_bits,
+                     float dist2_limit, int nfilt, const int *h_fsize, const float *h_fsigma,
+                     const int *h_fmax, float *d_weights, uint8_t *d_mask_im,
+                     int64_t *d_nmasked, void *stream);
 
 /* ---- f2: FITS tile compression (fpack, blackbox.py:812-857) ------------------------
  * RICE_1, one tile per image row, block size 32; float32 images are quantised like CFITSIO's

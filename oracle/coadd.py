@@ -216,3 +216,87 @@ def coadd(images, weights, positions, fscales, combine_type='weighted', **kw):
         o, wo = lanczos3_resample(img, w, xin, yin, fs)
         cube.append(o); wcube.append(wo)
     return combine(np.stack(cube), np.stack(wcube), combine_type, **kw)
+
+
+# ---------------------------------------------------------------------------------------
+# in-reference: clipped pixels of the first CLIPPED pass -> masks in the input frames
+# (buildref.py clipped2mask_loop 3686-3783, pass_filters 3784-3873)
+# ---------------------------------------------------------------------------------------
+def clip_nsigma(cube, wcube, clip_sigma=4.0, clip_ampfrac=0.3):
+    """what the clip log holds per dropped pixel [EXT SWarp -CLIP_WRITELOG: image, x, y, deviation in
+    sigma]: (f - median) / sqrt(1/w) in float32 where `combine(..., 'clipped')` drops a pixel, else 0"""
+    valid = wcube > 0
+    m = valid.sum(axis=0)
+    cs = np.sort(np.where(valid, cube.astype(np.float64), np.inf), axis=0)
+    lo = np.take_along_axis(cs, np.maximum((m - 1) // 2, 0)[None], 0)[0]
+    hi = np.take_along_axis(cs, np.maximum(m // 2, 0)[None], 0)[0]
+    med32 = np.where(m > 0, 0.5 * (lo + hi), 0.0).astype(F)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        sig = np.sqrt(F(1) / np.where(valid, wcube, F(1)).astype(F))
+        thr = F(clip_sigma) * sig + (F(clip_ampfrac) * np.abs(med32))[None]
+        dev = cube.astype(F) - med32[None]
+        drop = valid & (np.abs(dev) > thr)
+        nk = (valid & ~drop).sum(axis=0)
+        drop &= (nk > 0)[None]
+        return np.where(drop, dev / sig, F(0)).astype(F), drop
+
+
+def pass_filters(x, y, nsigma, fsize, fsigma, fmax, mask_shape):
+    """buildref.py:3784-3873 written out (x, y 1-based integer pixel positions of the clipped pixels
+    of one image, nsigma their deviations) -> bool mask"""
+    x = np.asarray(x, np.int64); y = np.asarray(y, np.int64); nsigma = np.asarray(nsigma, np.float32)
+    mask_im = np.zeros(mask_shape, dtype=bool)
+    for nf in range(len(fsize)):
+        sel = np.abs(nsigma) > fsigma[nf]
+        xs, ys, ns = x[sel], y[sel], nsigma[sel]
+        keep = ~mask_im[ys - 1, xs - 1]
+        xs, ys, ns = xs[keep], ys[keep], ns[keep]
+        x_index, y_index = xs - 1, ys - 1
+        if fsize[nf] == 1:
+            mask_im[y_index, x_index] = True
+        else:
+            ysize, xsize = mask_shape
+            count_im = np.zeros((2, ysize, xsize), dtype='uint16')
+            count_index = (ns > 0).astype(np.int64)
+            for it in range(xs.size):
+                i0, j0 = x_index[it], y_index[it]
+                i1, j1 = min(i0 + fsize[nf], xsize), min(j0 + fsize[nf], ysize)
+                count_im[count_index[it], j0:j1, i0:i1] += 1
+            mask_count = (count_im[0] >= fmax[nf]) | (count_im[1] >= fmax[nf])
+            for y1, x1 in zip(*np.nonzero(mask_count)):
+                i1, j1 = x1 + 1, y1 + 1
+                i0, j0 = max(i1 - fsize[nf], 0), max(j1 - fsize[nf], 0)
+                mask_im[j0:j1, i0:i1] = True
+    return mask_im
+
+
+def clipped2mask(clip_out, nsig_out, xin, yin, in_shape, data_mask, weights, nsigma_clip, fwhm,
+                 sat_bits=12, fsize=(5, 1), fmax=(4, 1)):
+    """clipped2mask_loop (buildref.py:3686-3783) for one input image: the clipped pixels of the
+    output frame (clip_out bool, nsig_out float32) are carried to the input frame -- (xin, yin) =
+    input position of every output pixel, 0-based; the reference goes through sky coordinates, the
+    rounding `(x_im + 0.5).astype(uint16)` on 1-based positions is the same -- filtered
+    (fsigma = [nsigma_clip, 4]), those within 5 FWHM of a saturated / saturated-connected pixel are
+    released, and the weights of the rest are set to zero.  -> (mask bool, weights)"""
+    ysize, xsize = in_shape
+    jj, ii = np.nonzero(clip_out)
+    ns = nsig_out[jj, ii]
+    keep0 = np.abs(ns) > min(nsigma_clip, 4)
+    jj, ii, ns = jj[keep0], ii[keep0], ns[keep0]
+    x1 = xin[jj, ii] + 1.0; y1 = yin[jj, ii] + 1.0
+    ok = np.isfinite(x1) & np.isfinite(y1) & (x1 + 0.5 >= 0) & (y1 + 0.5 >= 0) & (x1 < 60000) & (y1 < 60000)
+    xi = np.zeros(x1.shape, np.int64); yi = np.zeros(x1.shape, np.int64)
+    xi[ok] = (x1[ok] + 0.5).astype(np.int64); yi[ok] = (y1[ok] + 0.5).astype(np.int64)
+    keep = ok & (xi >= 1) & (xi <= xsize) & (yi >= 1) & (yi <= ysize)
+    mask_im = pass_filters(xi[keep], yi[keep], ns[keep], list(fsize), [nsigma_clip, 4], list(fmax), in_shape)
+    mask_sat = (data_mask & np.uint8(sat_bits)) != 0
+    y_sat, x_sat = np.nonzero(mask_sat)
+    y_im, x_im = np.nonzero(mask_im)
+    dist2_limit = (5 * fwhm) ** 2
+    for i in range(y_sat.size):
+        near = (x_im - x_sat[i]) ** 2 + (y_im - y_sat[i]) ** 2 <= dist2_limit
+        if near.any():
+            mask_im[y_im[near], x_im[near]] = False
+    w = weights.copy()
+    w[mask_im] = 0
+    return mask_im, w

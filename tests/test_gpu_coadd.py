@@ -133,7 +133,10 @@ def test_combine_vs_oracle(ctx, n):
         if t == 'clipped':
             assert np.array_equal(nclip.cpu().numpy(), nclip_ref)
             assert nclip_ref.sum() > 0
-            assert np.array_equal(cm.cpu().numpy().reshape(n, -1).sum(axis=1), nclip_ref)
+            nsig_ref, drop_ref = OC.clip_nsigma(cube, wc, sig, amp)
+            assert np.array_equal(cm[0].cpu().numpy() != 0, drop_ref)
+            assert np.array_equal(cm[1].cpu().numpy(), nsig_ref)
+            assert np.array_equal(cm[0].cpu().numpy().reshape(n, -1).sum(axis=1), nclip_ref)
         else:
             assert cm is None and int(nclip.sum()) == 0
     with pytest.raises(ValueError):
@@ -181,3 +184,50 @@ def test_imcombine_dithered_clipped(ctx):
     assert out[95:110, 85:96].max() < ref[95:110, 85:96].max() + 1e-3 * scale
     inner = (slice(20, 200), slice(20, 220))
     assert (wout[inner] > 0).all()
+    # the reference's two passes: the clip log goes back to the input frames (clipped2mask), the
+    # weights of the filtered pixels are zeroed, the second pass is a plain weighted mean
+    dws = [dev(ctx, a) for a in weights]
+    masks = [dev(ctx, np.zeros(a.shape, np.uint8)) for a in images]
+    out2, wout2, nclip2, _ = PC.imcombine(ctx, [dev(ctx, a) for a in images], dws, wcss, sky_wcs, (ny, nx), 'clipped', fs,
+                                          sig, amp, masks=masks, fwhm=[3.0, 3.0, 3.0])
+    ctx.sync()
+    out2 = out2.cpu().numpy()
+    w1 = dws[1].cpu().numpy()
+    assert (w1[100:104, 90] == 0).all() and (w1 == 0).sum() < 200          # the cosmic ray, little else
+    assert (dws[0].cpu().numpy() == 0).sum() < 100
+    assert out2[95:110, 85:96].max() < ref[95:110, 85:96].max() + 0.05 * scale   # gone from the second pass too
+    assert np.isfinite(out2).all()
+
+
+def test_clipped2mask_vs_oracle(ctx):
+    """the clip log carried to an input frame, filtered like pass_filters, saturated neighbourhoods
+    released, weights zeroed: integer work, identical to the numpy restatement"""
+    rs = np.random.RandomState(31)
+    out_shape, in_shape, step = (150, 180), (140, 170), 32
+    th = np.deg2rad(2.0)
+
+    def f(yy, xx):
+        return (3.0 + 0.97 * (xx * np.cos(th) - yy * np.sin(th)), 6.0 + 0.97 * (xx * np.sin(th) + yy * np.cos(th)) - 4.0)
+    grid = OC.coarse_grid(f, out_shape[0], out_shape[1], step)
+    xin, yin = OC.grid_positions(grid, out_shape[0], out_shape[1], step)
+    clip = rs.random_sample(out_shape) < 0.004
+    nsig = (rs.normal(0, 3.0, out_shape) + np.where(rs.random_sample(out_shape) < 0.5, 4.5, -4.5)).astype('float32')
+    # a satellite-trail like streak and a blob: clusters that the 5x5 box filter picks up
+    for t in range(60):
+        clip[40 + t // 3, 20 + t] = True; nsig[40 + t // 3, 20 + t] = 3.2
+    clip[90:96, 100:107] = True; nsig[90:96, 100:107] = -3.5
+    nsig[~clip] = 0
+    data_mask = np.zeros(in_shape, np.uint8)
+    data_mask[60:64, 60:64] = 4; data_mask[59:65, 59:65] |= 8          # a saturated star near part of the streak
+    data_mask[rs.random_sample(in_shape) < 0.01] |= 1
+    weights = rs.uniform(0.5, 2.0, in_shape).astype('float32')
+    for nsigma_clip, fwhm in ((3.0, 2.0), (2.5, 4.0)):
+        m_ref, w_ref = OC.clipped2mask(clip, nsig, xin, yin, in_shape, data_mask, weights, nsigma_clip, fwhm)
+        dw = dev(ctx, weights)
+        m, nm = PC.clipped2mask(ctx, dev(ctx, clip.astype(np.uint8)), dev(ctx, nsig), grid, in_shape, dev(ctx, data_mask), dw,
+                                nsigma_clip, fwhm, step)
+        ctx.sync()
+        assert m_ref.sum() > 50
+        assert np.array_equal(m.cpu().numpy() != 0, m_ref)
+        assert np.array_equal(dw.cpu().numpy(), w_ref)
+        assert int(nm.item()) == int(m_ref.sum())
