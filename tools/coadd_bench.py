@@ -72,9 +72,15 @@ def main():
         t = timed(torch, lambda: PC.combine(ctx, cube, wcube, tname, 4.0, 0.3), 3)
         out['coadd_combine_%s_%d' % (tname, nimg)] = dict(ms=t, algorithmic_GB=(8 * nimg + 8) * N * GB,
                                                            GBps=(8 * nimg + 8) * N * GB / (t * 1e-3))
-    o, w, nclip, _ = PC.combine(ctx, cube, wcube, 'clipped', 4.0, 0.3)
+    o, w, nclip, log = PC.combine(ctx, cube, wcube, 'clipped', 2.5, 0.0, clipmask=True)
     ctx.sync()
-    out['clipped_pixels_per_image'] = nclip.cpu().numpy().tolist()
+    out['clipped_pixels_per_image(nsigma 2.5, A 0)'] = nclip.cpu().numpy().tolist()
+    cm, ns = log
+    wts2 = torch.ones((ny, nx), dtype=torch.float32, device=dev)
+    t = timed(torch, lambda: PC.clipped2mask(ctx, cm[3], ns[3], grid, (ny, nx), mask, wts2, 2.5, 3.0), 3)
+    _, nm = PC.clipped2mask(ctx, cm[3], ns[3], grid, (ny, nx), mask, wts2, 2.5, 3.0)
+    ctx.sync()
+    out['clipped2mask(one image)'] = dict(ms=t, clip_log_pixels=int(cm[3].sum().item()), weights_zeroed=int(nm.item()))
     print(json.dumps(out, indent=1))
 
 
