@@ -365,6 +365,11 @@ class FramePipeline:
     # ---- stage A ------------------------------------------------------------------
     def _start(self, idx, raw, header):
         ctx = self.ctxA
+        # device pointers cross the C ABI without their extents: refuse a frame of another shape here
+        if (not torch.is_tensor(raw) or not raw.is_cuda or not raw.is_contiguous()
+                or tuple(raw.shape) != (self.geom.ny_raw, self.geom.nx_raw)):
+            raise ValueError('frame {}: contiguous device tensor of shape {} expected'.format(
+                idx, (self.geom.ny_raw, self.geom.nx_raw)))
         f = _Frame()
         f.idx, f.raw, f.header, f.hm, f.t0, f.err = idx, raw, header, {}, time.perf_counter(), None
         R.gain_corr(header, self.tel)

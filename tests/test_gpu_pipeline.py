@@ -78,3 +78,24 @@ def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
         for key in keys:
             assert R.hval(h0, key) == R.hval(h1, key), (k, key)
     ctx.close()
+
+
+def test_pipeline_refuses_bad_input_and_reports_lane_errors(pool):
+    """a frame of the wrong shape is refused before anything is launched; an exception raised while a
+    lane thread issues the device stage comes out of run()"""
+    ctx = R.Context(0)
+    ys, xs = 96, 330
+    case = synth.make_case(ys, xs, 7, tel='ML1', os_y=20, os_x=45, n_stars=10, n_sat=1, n_cr=5)
+    raw = torch.from_numpy(case['raw']).to(ctx.device)
+    geom = R.geometry(raw.shape, ys, xs)
+    pipe = FramePipeline(ctx, 'ML1', geom, pool=pool, depth=2, lanes=2)
+    with pytest.raises(ValueError):
+        pipe.run([(raw[:-1].contiguous(), {})])
+    assert pipe.run([(raw, {})]) == 1                              # still usable afterwards
+    pipe.close()
+    bad_flat = torch.ones((2 * ys, 8 * xs - 1), dtype=torch.float32, device=ctx.device)
+    pipe = FramePipeline(ctx, 'ML1', geom, mflat=bad_flat, pool=pool, depth=2, lanes=2)
+    with pytest.raises(ValueError):
+        pipe.run([(raw, {}), (raw, {})])
+    pipe.close()
+    ctx.close()
