@@ -515,6 +515,34 @@ class FramePipeline:
         up to [depth] in flight; calls on_done(idx, frame) in completion order."""
         it = iter(enumerate(frames))
         live, ndone, exhausted = [], 0, False
+        try:
+            return self._run(it, live, ndone, exhausted, on_done)
+        except BaseException:
+            self._abort(live)
+            raise
+
+    def _abort(self, live):
+        """after an error: let the fit workers and the lanes finish what was queued, drain the streams
+        and take all slots back"""
+        for f in live:
+            for r in (getattr(f, 'res', None), getattr(f, 'res2', None)):
+                try:
+                    if r is not None:
+                        r.wait(30.0)
+                except Exception:
+                    pass
+        done = [threading.Event() for _ in self.lane_thread]
+        for t, ev in zip(self.lane_thread, done):
+            t.q.put((lambda f, r, ev=ev: ev.set(), None, None))
+        for ev in done:
+            ev.wait(30.0)
+        try:
+            torch.cuda.synchronize(self.ctx.device)
+        except Exception:
+            pass
+        self.free_slots = list(range(self.depth))
+
+    def _run(self, it, live, ndone, exhausted, on_done):
         while True:
             progressed = False
             while not exhausted and len(live) < self.depth:

@@ -97,5 +97,6 @@ def test_pipeline_refuses_bad_input_and_reports_lane_errors(pool):
     pipe = FramePipeline(ctx, 'ML1', geom, mflat=bad_flat, pool=pool, depth=2, lanes=2)
     with pytest.raises(ValueError):
         pipe.run([(raw, {}), (raw, {})])
+    assert sorted(pipe.free_slots) == [0, 1]                       # nothing leaked by the aborted run
     pipe.close()
     ctx.close()
