@@ -356,7 +356,11 @@ int bbx_bsel_prepare(bbx_ctx* ctx, const float* d_data, const uint8_t* d_mask, i
     // side buffer: 1/8 of the segment (the bracket holds ~5 %), at least 64k values
     const size_t segpix = (size_t)ysz * xsz;
     // split over BSEL_NSH shards (workgroups pick shards round-robin; 2x headroom per shard)
-    const uint32_t capS = (uint32_t)(((segpix / 8 + 65536) / BSEL_NSH + 1023) / 1024 * 1024);
+    uint32_t capS = (uint32_t)(((segpix / 8 + 65536) / BSEL_NSH + 1023) / 1024 * 1024);
+    // ... and room for one feeding workgroup whose strip lies entirely inside the bracket (an already
+    // edge-filled frame: whole rows equal to the median) on top of the shard's usual share
+    const uint32_t strip = (uint32_t)((size_t)16 * xsz + capS / 2 + 1023) / 1024 * 1024;
+    if (strip > capS) capS = strip;
     const uint32_t cap = capS * BSEL_NSH;
     bsel_seg* seg; bsel_shard* shard; float *samples, *buf; uint32_t *prefix, *hist, *klo; int* nbits; unsigned long long* rank;
     int* anyfail;
