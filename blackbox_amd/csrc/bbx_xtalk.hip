@@ -9,6 +9,7 @@
 // once: 4N + N (mask) + 4N bytes, HBM-bound (16 float64 FMAs per output pixel are
 // far below the vector rate, so no MFMA reshaping).
 #include "bbx_common.h"
+#include <stdlib.h>
 
 // VEC pixels per thread and channel (4 when xsize_chan % 4 == 0: float4 / uchar4 accesses)
 template <int VEC>
@@ -32,6 +33,10 @@ __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __res
                 const uchar4 b = *(const uchar4*)(mask + off[c]);
                 v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
                 m[0] = b.x; m[1] = b.y; m[2] = b.z; m[3] = b.w;
+            } else if (VEC == 2) {
+                const float2 f = *(const float2*)(data + off[c]);
+                const uchar2 b = *(const uchar2*)(mask + off[c]);
+                v[0] = f.x; v[1] = f.y; m[0] = b.x; m[1] = b.y;
             } else {
                 v[0] = data[off[c]]; m[0] = mask[off[c]];
             }
@@ -58,6 +63,7 @@ __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __res
                 o[q] = (float)((double)val[v][q] - (victim_ok[v][q] ? corr : corr * 0.0));
             }
             if (VEC == 4) *(float4*)(data + off[v]) = make_float4(o[0], o[1], o[2], o[3]);
+            else if (VEC == 2) *(float2*)(data + off[v]) = make_float2(o[0], o[VEC - 1]);
             else data[off[v]] = o[0];
         }
     }
@@ -69,12 +75,17 @@ extern "C" int bbx_xtalk(bbx_ctx* ctx, const bbx_geom* g, float* d_data, const u
     bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
     f64x256 cf;
     for (int i = 0; i < 256; i++) cf.v[i] = h_coeffs[i];
-    const bool vec = false;          // measured on MI355X: the 4-wide variant is register-bound and slower
-    const size_t total = (size_t)d.ysz * (d.xsz / (vec ? 4 : 1));
+    // measured on MI355X: the 4-wide variant is register-bound and slower than one pixel per thread;
+    // two pixels per thread (8-byte loads, 2-byte mask loads) is the fastest of the three
+    const int vw = (getenv("BBX_XTALK_VEC") ? atoi(getenv("BBX_XTALK_VEC")) : 2);
+    const bool vec2 = vw == 2 && d.xsz % 2 == 0 && ((uintptr_t)d_data) % 8 == 0 && ((uintptr_t)d_mask) % 2 == 0 && d.nx % 2 == 0;
+    const bool vec = vw == 4 && d.xsz % 4 == 0 && d.nx % 4 == 0;
+    const size_t total = (size_t)d.ysz * (d.xsz / (vec ? 4 : vec2 ? 2 : 1));
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 256u * 16u) grid = 256u * 16u;
     bbx_prof_start(ctx, BBX_PROF_XTALK, (hipStream_t)stream);
     if (vec) hipLaunchKernelGGL(k_xtalk<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    else if (vec2) hipLaunchKernelGGL(k_xtalk<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
     else hipLaunchKernelGGL(k_xtalk<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
     bbx_prof_stop(ctx, (hipStream_t)stream);
     BBX_LAUNCH_CHECK();
