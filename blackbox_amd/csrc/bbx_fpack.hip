@@ -365,53 +365,64 @@ extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const 
 #define FU_ROWS 16
 #define FU_IN 1024           // ring bytes per row (power of two; a burst needs <= 266)
 #define FU_OUT 64            // pixels per burst
-// Bit reader over the row's ring, written without branches: the 16 decoding lanes of a wave
-// must follow one instruction stream, and a pixel must not wait for memory.  After refill() the
-// left-aligned buffer holds more than 32 valid bits.  `nxt` is the ring word after the buffer
-// and `ahead` the one after that, whose LDS read was issued at the previous refill site -- by
-// the time it is consumed it has arrived.
+// Bit reader over the row's ring, written without branches (the 16 decoding lanes of a wave must
+// follow one instruction stream) and in 32-bit operations: the window is three byte-swapped ring
+// words w0 w1 w2 and the number of bits of w0 already taken; the next 32 bits of the stream are
+// one funnel shift of (w0, w1).  The word read from LDS when the window advances is w2's
+// successor, needed two advances later: its latency never shows.
 struct ringreader {
     const uint32_t* ring;        // this row's ring (FU_IN / 4 words)
-    unsigned idx;                // ring word index of `nxt`
-    unsigned long long buf;      // left-aligned bit buffer, zero below the valid bits
-    int nbits;
-    unsigned nxt, ahead;         // raw (big-endian) words idx and idx + 1
+    unsigned idx;                // ring word index of w0
+    unsigned w0, w1, w2;
+    unsigned pos;                // bits of w0 consumed (< 32 after norm())
     __device__ __forceinline__ unsigned bytes_taken() const { return 4u * idx; }
-    __device__ __forceinline__ void start() {
-        idx = 0; buf = 0; nbits = 0;
-        nxt = ring[0]; ahead = ring[1];
-        refill(); refill();
+    __device__ __forceinline__ unsigned word(unsigned i) const { return __builtin_bswap32(ring[i & (FU_IN / 4 - 1)]); }
+    __device__ __forceinline__ void start() { idx = 0; pos = 0; w0 = word(0); w1 = word(1); w2 = word(2); }
+    __device__ __forceinline__ void norm() {
+        const bool c = pos >= 32u;
+        w0 = c ? w1 : w0; w1 = c ? w2 : w1;
+        idx += c ? 1u : 0u; pos -= c ? 32u : 0u;
+        w2 = word(idx + 2u);                                    // (the same word again when nothing moved)
     }
-    __device__ __forceinline__ void refill() {                 // -> nbits >= 33
-        const bool c = nbits <= 32;
-        const unsigned long long add = (unsigned long long)__builtin_bswap32(nxt) << ((32 - nbits) & 63);
-        buf |= c ? add : 0ull;
-        nbits += c ? 32 : 0;
-        nxt = c ? ahead : nxt;
-        idx += c ? 1u : 0u;
-        ahead = ring[(idx + 1u) & (FU_IN / 4 - 1)];            // (the same word again when nothing moved)
+    __device__ __forceinline__ unsigned peek() const {          // the next 32 bits
+        const unsigned f = __builtin_amdgcn_alignbit(w0, w1, (32u - pos) & 31u);
+        return pos ? f : w0;
     }
-    __device__ __forceinline__ unsigned take(int n) {           // n <= 32 <= nbits
-        const unsigned v = (unsigned)((buf >> 1) >> (63 - n));  // (n == 0 -> 0 without a 64-bit shift by 64)
-        buf <<= n; nbits -= n;
+    __device__ __forceinline__ unsigned get(int n) {            // n <= 32
+        norm();
+        const unsigned p = peek();
+        const unsigned v = n ? (p >> (32 - n)) : 0u;
+        pos += (unsigned)n;
         return v;
     }
-    __device__ __forceinline__ unsigned get(int n) { refill(); return take(n); }
+    // unary part without a branch: valid when the run of zeros is shorter than 32 (else [viol] is
+    // raised and the caller decodes the block again with unary())
+    __device__ __forceinline__ unsigned unary_fast(bool& viol) {
+        norm();
+        const unsigned p = peek();
+        viol |= p == 0u;
+        const unsigned lz = p ? (unsigned)__clz((int)p) : 31u;
+        pos += lz + 1u;
+        return lz;
+    }
     __device__ __forceinline__ unsigned unary() {              // number of zeros before the next one
-        refill();
         unsigned z = 0;
-        while ((unsigned)(buf >> 32) == 0u) {                   // 32 zeros: rare (a code longer than 32 bits)
-            z += 32; buf <<= 32; nbits -= 32;
-            refill();
-            if (z > 0x100000u) return z;                        // (bounded: a corrupt stream ends)
+        for (;;) {
+            norm();
+            const unsigned p = peek();
+            if (p == 0u) {                                      // 32 zeros: rare (a code longer than 32 bits)
+                z += 32u; pos += 32u;
+                if (z > 0x100000u) return z;                    // (bounded: a corrupt stream ends)
+                continue;
+            }
+            const unsigned lz = (unsigned)__clz((int)p);
+            pos += lz + 1u;
+            return z + lz;
         }
-        const int lz = __clzll((long long)buf);                 // < 32
-        z += lz; buf <<= (lz + 1); nbits -= lz + 1;
-        return z;
     }
 };
 
-template <int BYTEPIX>
+template <int BYTEPIX, bool FLOATOUT>
 __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, const uint8_t* __restrict__ heap, int ny, int nx,
                                                 int out_kind, void* __restrict__ out, const double* __restrict__ zscale,
                                                 const double* __restrict__ zzero, int dither_seed,
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
     const int row = blockIdx.x * FU_ROWS + lane;
     const bool dec = lane < FU_ROWS;
     bool active = false;
-    ringreader br; br.ring = ring[dec ? lane : 0]; br.idx = 0; br.buf = 0; br.nbits = 0; br.nxt = 0; br.ahead = 0;
+    ringreader br; br.ring = ring[dec ? lane : 0]; br.idx = 0; br.pos = 0; br.w0 = 0; br.w1 = 0; br.w2 = 0;
     int last = 0, pix = 0, mis = 0;
     double zs = 0., zz = 0.;
     int iseed = 0, nextrand = 0;
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
     }
     // value stored for a decoded pixel: the integer, or the un-quantised float's bits
     auto emit = [&](int v) -> int {
-        if (out_kind != 4) return v;
+        if (!FLOATOUT) return v;
         const int r = __float_as_int((float)(((double)v - (double)rnd[nextrand] + 0.5) * zs + zz));
         if (++nextrand == FP_NRANDOM) {
             iseed = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
@@ -521,13 +532,30 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
                             obuf[lane][i + j] = emit(last);
                         }
                     } else {
+                        // straight-line decode of the block; a code with 32 or more leading zeros (rare)
+                        // makes the lane decode the block again with the general reader
+                        const ringreader br0 = br;
+                        const int last0 = last, iseed0 = iseed, nextrand0 = nextrand;
+                        bool viol = false;
+#pragma unroll 4
                         for (int j = 0; j < n; j++) {
-                            const unsigned top = br.unary();
+                            const unsigned top = br.unary_fast(viol);
                             const unsigned d = (top << fs) | br.get(fs);
                             last += (int)(d >> 1) ^ -(int)(d & 1u);
                             if (BYTEPIX == 1) last = (int)(signed char)last;
                             if (BYTEPIX == 2) last = (int)(short)last;
                             obuf[lane][i + j] = emit(last);
+                        }
+                        if (viol) {
+                            br = br0; last = last0; iseed = iseed0; nextrand = nextrand0;
+                            for (int j = 0; j < n; j++) {
+                                const unsigned top = br.unary();
+                                const unsigned d = (top << fs) | br.get(fs);
+                                last += (int)(d >> 1) ^ -(int)(d & 1u);
+                                if (BYTEPIX == 1) last = (int)(signed char)last;
+                                if (BYTEPIX == 2) last = (int)(short)last;
+                                obuf[lane][i + j] = emit(last);
+                            }
                         }
                     }
                 }
@@ -583,9 +611,10 @@ extern "C" int bbx_funpack_tiles(bbx_ctx* ctx, int ny, int nx, int bytepix, cons
         return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((ny + FU_ROWS - 1) / FU_ROWS);
-    if (bytepix == 1) hipLaunchKernelGGL(k_funpack<1>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
-    else if (bytepix == 2) hipLaunchKernelGGL(k_funpack<2>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
-    else if (bytepix == 4) hipLaunchKernelGGL(k_funpack<4>, grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    if (bytepix == 1) hipLaunchKernelGGL((k_funpack<1, false>), grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    else if (bytepix == 2) hipLaunchKernelGGL((k_funpack<2, false>), grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    else if (bytepix == 4 && out_kind == 4) hipLaunchKernelGGL((k_funpack<4, true>), grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
+    else if (bytepix == 4) hipLaunchKernelGGL((k_funpack<4, false>), grid, dim3(64), 0, s, d_desc, d_heap, ny, nx, out_kind, d_out, d_zscale, d_zzero, dither_seed, d_rnd, ctx->d_err);
     else return BBX_ERR_ARG;
     BBX_LAUNCH_CHECK();
     return BBX_OK;
