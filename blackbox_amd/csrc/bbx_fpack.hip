@@ -359,8 +359,8 @@ extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const 
 // one row: what matters is that nothing but ALU work sits on that chain.  One wave handles
 // FU_ROWS rows: lanes 0..FU_ROWS-1 each decode one row in bursts of FU_OUT pixels (two Rice
 // blocks), reading the stream from a ring in LDS and leaving the pixels in LDS; between bursts
-// all 64 lanes refill every row's ring with coalesced 256-byte loads and write the decoded
-// pixels out with coalesced stores.  (Reading the stream straight from global memory puts one
+// all 64 lanes stage -- four per row, all rows at once -- refilling the rings with 16-byte loads
+// and writing the decoded pixels out.  (Reading the stream straight from global memory puts one
 // ~1 us load per byte on the chain: 8 ms for a 10600-row frame.)
 #define FU_ROWS 16
 #define FU_IN 1024           // ring bytes per row (power of two; a burst needs <= 266)
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
                                                 const double* __restrict__ zzero, int dither_seed,
                                                 const float* __restrict__ rnd, int* __restrict__ err) {
     typedef rice_par<BYTEPIX> RP;
-    __shared__ uint32_t ring[FU_ROWS][FU_IN / 4 + 1];           // (+1: rows on different banks)
+    __shared__ __align__(16) uint32_t ring[FU_ROWS][FU_IN / 4 + 4];   // (+4 words: rows on different banks, 16-byte aligned)
     __shared__ int obuf[FU_ROWS][FU_OUT + 1];
     __shared__ unsigned s_fill[FU_ROWS], s_rd[FU_ROWS], s_total[FU_ROWS];   // bytes from the row's aligned base
     __shared__ size_t s_base[FU_ROWS];
@@ -470,39 +470,48 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
         return r;
     };
     bool first = true;
+    // staging role of a lane: FU_LPR lanes per row, each moving 64 bytes of a 256-byte chunk
+    constexpr int FU_LPR = 64 / FU_ROWS;
+    static_assert(FU_LPR == 4 && FU_OUT == 64, "staging layout: 4 lanes per row, 4 x 16 bytes per lane and chunk");
+    const int srow = lane / FU_LPR, ssub = lane % FU_LPR;
     // prime the rings (up to 768 bytes each) before the first burst
     __syncthreads();
-    for (int rr = 0; rr < FU_ROWS; rr++) {
-        const unsigned total = s_total[rr];
-        const uint8_t* src = heap + s_base[rr];
+    {
+        const unsigned total = s_total[srow];
+        const uint8_t* src = heap + s_base[srow];
         unsigned fill = 0;
         for (int c = 0; c < 3 && fill < total; c++, fill += 256) {
-            const unsigned bo = fill + 4 * lane;
-            if (bo < total) ring[rr][(bo >> 2) & (FU_IN / 4 - 1)] = *(const uint32_t*)(src + bo);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned bo = fill + 64u * ssub + 16u * k;
+                if (bo < total) *(uint4*)&ring[srow][(bo >> 2) & (FU_IN / 4 - 1)] = *(const uint4*)(src + bo);
+            }
         }
-        if (lane == 0) s_fill[rr] = fill < total ? fill : total;
+        if (ssub == 0) s_fill[srow] = fill < total ? fill : total;
     }
     for (;;) {
         __syncthreads();
-        // ---- refill, first half: issue the loads of every row that has room for them (all lanes).
-        // They land in registers and go into the rings after the burst, so their latency runs beside
-        // the decode instead of in front of it; a ring always holds >= 500 bytes ahead of its reader
-        // (or the rest of the stream), a burst needs <= 266.
-        uint32_t pre[FU_ROWS][2];
-        unsigned pre_fill[FU_ROWS];
-#pragma unroll
-        for (int rr = 0; rr < FU_ROWS; rr++) {
-            const unsigned fill = s_fill[rr], rd = s_rd[rr], total = s_total[rr];
-            const uint8_t* src = heap + s_base[rr];
-            pre_fill[rr] = fill;
+        // ---- refill, first half: the lanes of a row issue the loads of up to two chunks if its ring
+        // has room.  They land in registers and go into the ring after the burst, so their latency runs
+        // beside the decode; a ring always holds >= 500 bytes ahead of its reader (or the rest of the
+        // stream), a burst needs <= 266.  (All rows at once: no loop over the rows.)
+        uint4 pre[2][4];
+        unsigned pre_fill;
+        {
+            const unsigned fill = s_fill[srow], rd = s_rd[srow], total = s_total[srow];
+            const uint8_t* src = heap + s_base[srow];
+            pre_fill = fill;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const unsigned f = fill + 256u * c, bo = f + 4 * lane;
-                pre[rr][c] = 0;
-                if (f < total && f - rd <= FU_IN - 256) {       // uniform
-                    if (bo < total) pre[rr][c] = *(const uint32_t*)(src + bo);
-                    pre_fill[rr] = f + 256u;
+                const unsigned f = fill + 256u * c;
+                const bool go = f < total && f - rd <= FU_IN - 256;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned bo = f + 64u * ssub + 16u * k;
+                    pre[c][k] = make_uint4(0, 0, 0, 0);
+                    if (go && bo < total) pre[c][k] = *(const uint4*)(src + bo);
                 }
+                if (go) pre_fill = f + 256u;
             }
         }
         // ---- decode a burst ----
@@ -569,29 +578,32 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
         first = false;
         __syncthreads();
         // ---- refill, second half: the loaded words into the rings ----
+        {
+            const unsigned fill = s_fill[srow], total = s_total[srow];
 #pragma unroll
-        for (int rr = 0; rr < FU_ROWS; rr++) {
-            const unsigned fill = s_fill[rr], total = s_total[rr];
+            for (int c = 0; c < 2; c++)
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const unsigned f = fill + 256u * c, bo = f + 4 * lane;
-                if (f < pre_fill[rr] && bo < total) ring[rr][(bo >> 2) & (FU_IN / 4 - 1)] = pre[rr][c];
-            }
+                for (int k = 0; k < 4; k++) {
+                    const unsigned f = fill + 256u * c, bo = f + 64u * ssub + 16u * k;
+                    if (f < pre_fill && bo < total) *(uint4*)&ring[srow][(bo >> 2) & (FU_IN / 4 - 1)] = pre[c][k];
+                }
+            __syncthreads();
+            if (ssub == 0) s_fill[srow] = pre_fill < total ? pre_fill : total;
         }
-        __syncthreads();
+        // ---- write the bursts out: the lanes of a row take its pixels interleaved ----
+        {
+            const int n = s_cnt[srow];
+            const size_t o0 = (size_t)(blockIdx.x * FU_ROWS + srow) * nx + s_pix[srow];
 #pragma unroll
-        for (int rr = 0; rr < FU_ROWS; rr++)
-            if (lane == 0) s_fill[rr] = pre_fill[rr] < s_total[rr] ? pre_fill[rr] : s_total[rr];
-        // ---- write the bursts out (all lanes, one coalesced store per row) ----
-        for (int rr = 0; rr < FU_ROWS; rr++) {
-            const int n = s_cnt[rr];
-            if (lane < n) {
-                const size_t o = (size_t)(blockIdx.x * FU_ROWS + rr) * nx + s_pix[rr] + lane;
-                const int v = obuf[rr][lane];
-                if (out_kind == 0) ((uint8_t*)out)[o] = (uint8_t)v;
-                else if (out_kind == 1) ((uint16_t*)out)[o] = (uint16_t)(v + 32768);
-                else if (out_kind == 2) ((short*)out)[o] = (short)v;
-                else ((int*)out)[o] = v;                         // int32 or float bits
+            for (int k = 0; k < FU_OUT / FU_LPR; k++) {
+                const int i = k * FU_LPR + ssub;
+                if (i < n) {
+                    const int v = obuf[srow][i];
+                    if (out_kind == 0) ((uint8_t*)out)[o0 + i] = (uint8_t)v;
+                    else if (out_kind == 1) ((uint16_t*)out)[o0 + i] = (uint16_t)(v + 32768);
+                    else if (out_kind == 2) ((short*)out)[o0 + i] = (short)v;
+                    else ((int*)out)[o0 + i] = v;                  // int32 or float bits
+                }
             }
         }
         if (lane == 0) s_live = 0;
