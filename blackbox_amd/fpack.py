@@ -264,7 +264,11 @@ def funpack_image(ctx, path, ext=None):
         seed, d_zs, d_zz, rnd = 0, None, None, None
     if (desc < 0).any() or int((desc[:, 0].astype(np.int64) + desc[:, 1]).max(initial=0)) > heap.size:
         raise ValueError('tile descriptors point outside the heap')
-    d_heap = torch.from_numpy(np.concatenate([heap, np.zeros(16, np.uint8)])).to(dev)
+    # compressed bytes + 16 readable pad bytes (no host-side copy of the heap for the padding)
+    d_heap = torch.empty(heap.size + 16, dtype=torch.uint8, device=dev)
+    d_heap[heap.size:].zero_()
+    if heap.size:
+        d_heap[:heap.size].copy_(torch.from_numpy(np.ascontiguousarray(heap)))
     d_desc = torch.from_numpy(desc.reshape(-1).copy()).to(dev)
     vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     check(lib.bbx_funpack_tiles(ctx.h, ny, nx, bytepix, vp(d_desc), vp(d_heap), kind, vp(out), vp(d_zs), vp(d_zz), seed,
