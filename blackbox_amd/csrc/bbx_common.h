@@ -58,6 +58,7 @@ struct bbx_ctx {
     void*  d_ws[24];
     size_t ws_bytes[24];
     int    lac_feed;           // BBX_OPT_LAC_LEVEL_FEED (bbx_set_option)
+    int    num_cus;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     // --- optional per-kernel timing (bbx_profile_enable): hipEvent pairs on the launch stream
     int prof_on, prof_n;
     hipEvent_t* prof_ev;       // [2 * BBX_PROF_MAX]

@@ -94,6 +94,8 @@ int bbx_ctx_create(int device, bbx_ctx** out) {
     if (e == hipSuccess) e = hipMemset(ctx->d_err, 0, 4 * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, CNT_MAX * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, CNT_MAX * sizeof(int32_t));
+    ctx->num_cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) {
         fprintf(stderr, "bbx_ctx_create: %s\n", hipGetErrorString(e));
         free(ctx);

@@ -844,10 +844,10 @@ __global__ __launch_bounds__(256) void k_lac_bg(float* a, const uint8_t* __restr
 // k_lac_clean get the level, selected exactly over the good pixels of the frame -- those the run
 // has flagged and cleaned so far are taken with their input values from orig[] (saved by
 // k_lac_grow2).  lvl[0] = level, lvl[1] = known? (zeroed by k_lac_begin).
-// Launched after every k_lac_clean with BGF_WGS workgroups that return at once unless pixels are
+// Launched after every k_lac_clean with one workgroup per compute unit; they return at once unless pixels are
 // listed (the usual frame).  When the level has to be produced, the workgroups run the three
 // digit passes of a radix select together: LDS histograms added to a global one, a grid barrier
-// (all BGF_WGS workgroups are resident: one per CU; the spin is bounded), every workgroup scans
+// (the workgroups -- one per compute unit, at most BGF_WGS -- are all resident; the spin is bounded), every workgroup scans
 // the global histogram itself.  ~0.6 ms instead of the ~1 s of a single workgroup.
 #define BGF_WGS 256
 __device__ __forceinline__ bool bgf_barrier(unsigned* bar, unsigned target, int32_t* err) {
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256) void k_lac_bg_frame(float* a, const uint8_t* _
         const uint32_t norig = min((uint32_t)counters[CNT_CRLIST], caporig);
         unsigned phase = 0;
         if (blockIdx.x == 0) for (int i = tid; i < 3 * 2048; i += 256) ghist[i] = 0;
-        if (!bgf_barrier(gbar, ++phase * BGF_WGS, err)) return;
+        if (!bgf_barrier(gbar, ++phase * gridDim.x, err)) return;
         if (tid == 0) { s_prefix = 0; s_rank = 0; s_empty = 0; }
         const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
         uint32_t himask = 0;
@@ -899,19 +899,19 @@ __global__ __launch_bounds__(256) void k_lac_bg_frame(float* a, const uint8_t* _
             __syncthreads();
             const uint32_t pre = s_prefix, dmask = (1u << nbits[ps]) - 1u;
             const int shift = shifts[ps];
-            for (size_t i = (size_t)blockIdx.x * 256 + tid; i < npix; i += (size_t)BGF_WGS * 256) {
+            for (size_t i = (size_t)blockIdx.x * 256 + tid; i < npix; i += (size_t)gridDim.x * 256) {
                 if (mask[i]) continue;                          // masked, or flagged (and cleaned) by this run
                 const uint32_t key = f2key(a[i]);
                 if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
             }
-            for (uint32_t i = blockIdx.x * 256 + tid; i < norig; i += BGF_WGS * 256) {
+            for (uint32_t i = blockIdx.x * 256 + tid; i < norig; i += gridDim.x * 256) {
                 const uint32_t key = f2key(orig[i]);
                 if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
             }
             __syncthreads();
             uint32_t* gh = ghist + ps * 2048;
             for (int i = tid; i < 2048; i += 256) if (lh[i]) atomicAdd(&gh[i], lh[i]);
-            if (!bgf_barrier(gbar, ++phase * BGF_WGS, err)) return;
+            if (!bgf_barrier(gbar, ++phase * gridDim.x, err)) return;
             // every workgroup finds the bin of the wanted rank in the global histogram
             unsigned long long part = 0;
             uint32_t mine[8];
@@ -1060,6 +1060,8 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     // background level of the unmasked input pixels (needed when a CR pixel has no good
     // neighbour): bracketed select fed by the first candidate pass, no extra read of the frame
     const unsigned gdense = 256u * 16u, gsparse = 256u * 8u;
+    // workgroups of the cooperative level select: one per compute unit (they must all be resident)
+    const unsigned bgf_wgs = (unsigned)std::min(BGF_WGS, std::max(8, ctx->num_cus));
     for (int it = 0; it < niter; it++) {
         if (it == 0) {
             // the one dense pass: candidates of the first iteration (+ the background-level feed)
@@ -1090,7 +1092,7 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, ovf,
                            (uint32_t)capovf, ctx->d_err);
         if (feed) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1, d_stats);
-        else hipLaunchKernelGGL(k_lac_bg_frame, dim3(BGF_WGS), dim3(256), 0, s, d_data, d_mask, p, cnt, ovf, (uint32_t)capovf, orig,
+        else hipLaunchKernelGGL(k_lac_bg_frame, dim3(bgf_wgs), dim3(256), 0, s, d_data, d_mask, p, cnt, ovf, (uint32_t)capovf, orig,
                                 (uint32_t)caporig, rnp + 8, d_stats, ghist, (unsigned*)(ghist + 3 * 2048), ctx->d_err);
         hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
         bbx_prof_stop(ctx, s);
