@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: throughput against lanes / depth / workers
 cd "$GRAFT_REPO_ROOT" || exit 1
-for cfg in "6 18 12" "6 24 12" "8 24 12" "6 18 10" "8 32 12" "5 15 12"; do
+for cfg in "6 18 12" "8 24 12" "10 32 12" "6 18 10" "6 24 12"; do
   set -- $cfg
   timeout -k 10 200 python bench.py --no-cpu --steps 240 --warmup 12 --lanes $1 --depth $2 --workers $3 2>/dev/null | python -c "
 import json,sys
