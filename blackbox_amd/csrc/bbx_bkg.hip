@@ -158,45 +158,83 @@ __global__ __launch_bounds__(1024) void k_mini_fill_filter(float* mini, float* t
     (void)err;
 }
 
+// One workgroup = 256 columns x ZOOM_ROWS rows: the column taps (index + 4 float64 weights per
+// pixel, 36 bytes) are read once per thread and reused down the rows -- with a workgroup per row
+// they came through the L2 again for every row, 4.5x the bytes of the image itself.
+#define ZOOM_ROWS 16
 __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const double* __restrict__ coef, int cnx,
                                                      const int32_t* __restrict__ fy, const double* __restrict__ wy,
                                                      const int32_t* __restrict__ fx, const double* __restrict__ wx,
                                                      float* data, float* bkg) {
-    // the 4 coefficient rows of this output row are first folded with the row weights into a
+    // the 4 coefficient rows of an output row are first folded with the row weights into a
     // short LDS vector (a 256-pixel span touches only a handful of coefficient columns); each
     // pixel then needs 4 taps instead of 16 strided float64 loads
-    __shared__ double rowc[512];
-    const int X0 = blockIdx.x * blockDim.x, X = X0 + threadIdx.x, Y = blockIdx.y;
-    const int iy = fy[Y];
+    __shared__ double rowc[2][512];
+    const int X0 = blockIdx.x * blockDim.x, X = X0 + threadIdx.x;
     const int j0 = fx[X0] - 1, j1 = fx[min(X0 + (int)blockDim.x - 1, nx - 1)] + 2;      // fx is non-decreasing
     const int span = j1 - j0 + 1;
-    double t = 0.0;
-    if (span <= 512) {
-        const double w0 = wy[Y * 4], w1 = wy[Y * 4 + 1], w2 = wy[Y * 4 + 2], w3 = wy[Y * 4 + 3];
-        for (int j = threadIdx.x; j < span; j += blockDim.x) {
-            const double* c0 = coef + (size_t)(iy - 1) * cnx + (j0 + j);
-            rowc[j] = ((c0[0] * w0 + c0[cnx] * w1) + c0[2 * (size_t)cnx] * w2) + c0[3 * (size_t)cnx] * w3;
+    const bool live = X < nx;
+    const int ix = live ? fx[X] : 0;
+    double wxr[4] = {0, 0, 0, 0};
+    if (live) { wxr[0] = wx[X * 4]; wxr[1] = wx[X * 4 + 1]; wxr[2] = wx[X * 4 + 2]; wxr[3] = wx[X * 4 + 3]; }
+    const int k = ix - 1 - j0;
+    const int Y0 = blockIdx.y * ZOOM_ROWS, Y1 = min(ny, Y0 + ZOOM_ROWS);
+    if (span <= 32) {
+        // the usual case (zoom factor >> 1: a 256-pixel span touches ~10 coefficient columns): the folded
+        // coefficient vectors of all ZOOM_ROWS rows at once, one barrier, then 4 taps per pixel and row
+        double* rc = &rowc[0][0];                               // [ZOOM_ROWS][32]
+        for (int e = threadIdx.x; e < ZOOM_ROWS * 32; e += blockDim.x) {
+            const int r = e >> 5, j = e & 31, Y = Y0 + r;
+            if (Y < Y1 && j < span) {
+                const double* c0 = coef + (size_t)(fy[Y] - 1) * cnx + (j0 + j);
+                rc[e] = ((c0[0] * wy[Y * 4] + c0[cnx] * wy[Y * 4 + 1]) + c0[2 * (size_t)cnx] * wy[Y * 4 + 2]) + c0[3 * (size_t)cnx] * wy[Y * 4 + 3];
+            }
         }
         __syncthreads();
-        if (X >= nx) return;
-        const int k = fx[X] - 1 - j0;
+        if (!live) return;
+        for (int Y = Y0; Y < Y1; Y++) {
+            const double* r4 = rc + ((Y - Y0) << 5) + k;
+            double t = 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) t += rowc[k + b] * wx[X * 4 + b];
-    } else {
-        if (X >= nx) return;
-        const int ix = fx[X];
+            for (int b = 0; b < 4; b++) t += r4[b] * wxr[b];
+            const float v = (float)t;
+            const size_t o = (size_t)Y * nx + X;
+            if (bkg) bkg[o] = v;
+            if (data) data[o] = data[o] - v;
+        }
+        return;
+    }
+    for (int Y = Y0; Y < Y1; Y++) {
+        const int iy = fy[Y];
+        double t = 0.0;
+        if (span <= 512) {
+            double* rc = rowc[(Y - Y0) & 1];
+            const double w0 = wy[Y * 4], w1 = wy[Y * 4 + 1], w2 = wy[Y * 4 + 2], w3 = wy[Y * 4 + 3];
+            for (int j = threadIdx.x; j < span; j += blockDim.x) {
+                const double* c0 = coef + (size_t)(iy - 1) * cnx + (j0 + j);
+                rc[j] = ((c0[0] * w0 + c0[cnx] * w1) + c0[2 * (size_t)cnx] * w2) + c0[3 * (size_t)cnx] * w3;
+            }
+            __syncthreads();                                     // (the other buffer is free again after the next barrier)
+            if (live) {
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const double wa = wy[Y * 4 + a];
-            const double* row = coef + (size_t)(iy - 1 + a) * cnx + (ix - 1);
+                for (int b = 0; b < 4; b++) t += rc[k + b] * wxr[b];
+            }
+        } else if (live) {
 #pragma unroll
-            for (int b = 0; b < 4; b++) t += row[b] * (wa * wx[X * 4 + b]);
+            for (int a = 0; a < 4; a++) {
+                const double wa = wy[Y * 4 + a];
+                const double* row = coef + (size_t)(iy - 1 + a) * cnx + (ix - 1);
+#pragma unroll
+                for (int b = 0; b < 4; b++) t += row[b] * (wa * wxr[b]);
+            }
+        }
+        if (live) {
+            const float v = (float)t;
+            const size_t o = (size_t)Y * nx + X;
+            if (bkg) bkg[o] = v;
+            if (data) data[o] = data[o] - v;
         }
     }
-    const float v = (float)t;
-    const size_t o = (size_t)Y * nx + X;
-    if (bkg) bkg[o] = v;
-    if (data) data[o] = data[o] - v;
 }
 
 extern "C" {
@@ -226,7 +264,7 @@ int bbx_spline_zoom(bbx_ctx* ctx, int ny, int nx, const double* d_coef, int cny,
                     void* stream) {
     if (!ctx || !d_coef || !d_fy || !d_wy || !d_fx || !d_wx || (!d_data && !d_bkg) || ny < 1 || nx < 1 || cny < 4 || cnx < 4)
         return BBX_ERR_ARG;
-    hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, ny), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
+    hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
                        d_fy, d_wy, d_fx, d_wx, d_data, d_bkg);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
