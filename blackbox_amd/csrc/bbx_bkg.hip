@@ -15,96 +15,168 @@
 //                    subtraction from the frame (read 4N + write 4N).
 #include "bbx_common.h"
 #include "bbx_mednet.h"
-#include <rocprim/block/block_radix_sort.hpp>
 
-#define BOX_NS 4096
+#define BOX_NS 4096                 // 64 lanes x 64 registers: boxes up to 64 x 64 pixels
+#define BOX_PAD 0xffffffffu         // key of a slot without usable pixel (above the key of +inf)
 
-__global__ __launch_bounds__(256) void k_bkg_boxstats(const float* __restrict__ data, const uint8_t* __restrict__ mask,
-                                                      const uint8_t* __restrict__ objmask, int ny, int nx, int box,
-                                                      int nbx, float limfrac, float* __restrict__ mini_med,
-                                                      float* __restrict__ mini_std) {
-    // rocPRIM's block radix sort (256 threads x 16 keys, blocked arrangement) shares its LDS
-    // with the sorted array that the clip loop walks afterwards
-    using sort_t = rocprim::block_radix_sort<float, 256, BOX_NS / 256>;
-    __shared__ union { typename sort_t::storage_type sort; float v[BOX_NS]; } sh;
-    float* v = sh.v;
-    __shared__ double red[4];
-    __shared__ int redi[4];
-    __shared__ int s_a, s_b;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int by = blockIdx.x / nbx, bx = blockIdx.x - by * nbx;
-    const int npx = box * box;
-    int cnt = 0;
-    float keys[BOX_NS / 256];
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t o;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ float box_key_value(uint32_t u) { return __uint_as_float((u >> 31) ? (u ^ 0x80000000u) : ~u); }
+
+// compare-exchange stage between registers r and r^J of every lane, directions fixed by the
+// element index (levels of 2..32 elements of the bitonic network)
+template <int K, int J> __device__ __forceinline__ void box_stage_static(uint32_t (&k)[64]) {
 #pragma unroll
-    for (int k = 0; k < BOX_NS / 256; k++) {
-        const int i = tid * (BOX_NS / 256) + k;
-        float val = __builtin_huge_valf();
-        if (i < npx) {
-            const int y = by * box + i / box, x = bx * box + i % box;
-            const size_t o = (size_t)y * nx + x;
-            const float d = data[o];
-            const bool rej = (mask[o] != 0) || (objmask && objmask[o] != 0) || (d == 0.f) || !(d == d);
-            if (!rej) { val = d; cnt++; }
+    for (int r = 0; r < 64; r++) {
+        const int q = r ^ J;
+        if (q > r) {
+            const uint32_t a = k[r], b = k[q];
+            const uint32_t lo = min(a, b), hi = max(a, b);
+            if ((r & K) == 0) { k[r] = lo; k[q] = hi; } else { k[r] = hi; k[q] = lo; }
         }
-        keys[k] = val;
     }
-    cnt = wave_sum_i32(cnt);
-    if (lane == 0) redi[wid] = cnt;
-    __syncthreads();
-    const int n0 = redi[0] + redi[1] + redi[2] + redi[3];
-    __syncthreads();
+}
+// the same with the direction of the lane: clo = 0 sorts ascending (med3(a,b,0) = min), ~0 descending
+template <int J> __device__ __forceinline__ void box_stage_lane(uint32_t (&k)[64], uint32_t clo) {
+    const uint32_t chi = ~clo;
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const int q = r ^ J;
+        if (q > r) {
+            const uint32_t a = k[r], b = k[q];
+            k[r] = umed3(a, b, clo); k[q] = umed3(a, b, chi);
+        }
+    }
+}
+
+// index of sorted element i in LDS: one word of padding per lane's 64 so that the lanes'
+// stores fall in different banks
+__device__ __forceinline__ int box_slot(int i) { return i + (i >> 6); }
+
+// number of entries of the ascending v[a, b) that are < lim (UPPER = false) or <= lim (true):
+// a 64-way search over the blocks of 64, then inside the block that holds the boundary
+template <bool UPPER> __device__ __forceinline__ int box_count_below(const float* v, int a, int b, double lim, int lane) {
+    const int nblk = (b - a + 63) >> 6;                   // <= 64
+    bool below = false;
+    if (lane < nblk) { const double x = (double)v[box_slot(a + lane * 64)]; below = UPPER ? (x <= lim) : (x < lim); }
+    const int nb = __popcll(__ballot(below));             // blocks whose first entry is below: the boundary is in block nb-1
+    if (nb == 0) return 0;
+    const int base = a + (nb - 1) * 64;
+    bool in = false;
+    if (base + lane < b) { const double x = (double)v[box_slot(base + lane)]; in = UPPER ? (x <= lim) : (x < lim); }
+    return (nb - 1) * 64 + __popcll(__ballot(in));
+}
+
+__global__ __launch_bounds__(64) void k_bkg_boxstats(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                     const uint8_t* __restrict__ objmask, int ny, int nx, int box,
+                                                     int nbx, int nboxes, float limfrac, float* __restrict__ mini_med,
+                                                     float* __restrict__ mini_std) {
+    // one wave per box.  The usable pixels become order-preserving integer keys, 64 per lane
+    // in registers, and are sorted once by a bitonic network: stages between registers of a
+    // lane are v_min/v_max (or v_med3 against a per-lane 0 / ~0 when the direction depends on
+    // the lane), the 21 stages between lanes fetch the partner through ds_bpermute.  The sorted
+    // pixels go to LDS; the clip iterations then only move the two ends of the index range.
+    __shared__ float v[BOX_NS + 64];
+    const int lane = threadIdx.x;
+    // workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of boxes, so that
+    // the cache lines which neighbouring boxes share are fetched into one L2 only
+    const int per = (nboxes + 7) >> 3;
+    const int ibox = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (ibox >= nboxes) return;
+    const int by = ibox / nbx, bx = ibox - by * nbx;
+    const int npx = box * box;
+    const int q64 = 64 / box, r64 = 64 - q64 * box;
+    uint32_t k[64];
+    int cnt = 0;
+    {
+        // element c*64 + lane: consecutive lanes read along a box row.  All loads of the box are
+        // issued before the first use and without branches (slots beyond the box re-read its
+        // first pixel and are discarded): the kernel runs few waves per CU (LDS) and needs the
+        // memory parallelism
+        int yy = lane / box, xx = lane - yy * box;
+        const size_t o0 = (size_t)(by * box) * nx + (size_t)bx * box;
+        const float* pd = data + o0; const uint8_t* pm = mask + o0; const uint8_t* po = objmask + o0;
+        unsigned mk[64];
+#pragma unroll
+        for (int c = 0; c < 64; c++) {
+            const uint32_t o = (c * 64 + lane < npx) ? (uint32_t)(yy * nx + xx) : 0u;   // < 64 nx: the host checks that it fits
+            k[c] = __float_as_uint(pd[o]);
+            mk[c] = pm[o];
+            if (objmask) mk[c] |= po[o];
+            yy += q64; xx += r64;
+            if (xx >= box) { xx -= box; yy++; }
+        }
+#pragma unroll
+        for (int c = 0; c < 64; c++) {
+            const uint32_t u = k[c];
+            const float d = __uint_as_float(u);
+            const bool ok = (c * 64 + lane < npx) & (mk[c] == 0) & (d != 0.f) & (d == d);
+            k[c] = ok ? (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) : BOX_PAD;
+            cnt += ok;
+        }
+    }
+    const int n0 = wave_sum_i32(cnt);
     if ((float)n0 < limfrac * (float)npx || n0 == 0) {
-        if (tid == 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[blockIdx.x] = nanv; mini_std[blockIdx.x] = nanv; }
+        if (lane == 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[ibox] = nanv; mini_std[ibox] = nanv; }
         return;
     }
-    sort_t().sort(keys, sh.sort);                        // ascending; +inf padding ends up last
-    __syncthreads();
+    // sorted position of element (lane, r) is lane*64 + r
+    box_stage_static<2, 1>(k);
+    box_stage_static<4, 2>(k); box_stage_static<4, 1>(k);
+    box_stage_static<8, 4>(k); box_stage_static<8, 2>(k); box_stage_static<8, 1>(k);
+    box_stage_static<16, 8>(k); box_stage_static<16, 4>(k); box_stage_static<16, 2>(k); box_stage_static<16, 1>(k);
+    box_stage_static<32, 16>(k); box_stage_static<32, 8>(k); box_stage_static<32, 4>(k); box_stage_static<32, 2>(k);
+    box_stage_static<32, 1>(k);
+    for (int ll = 0; ll <= 6; ll++) {                     // runs of 64 << ll elements
+        const bool asc = (lane & (1 << ll)) == 0;         // ll = 6: one ascending run
+        for (int m = (1 << ll) >> 1; m > 0; m >>= 1) {
+            const uint32_t c = (((lane & m) == 0) == asc) ? 0u : 0xffffffffu;   // keep the smaller / the larger
 #pragma unroll
-    for (int k = 0; k < BOX_NS / 256; k++) v[tid * (BOX_NS / 256) + k] = keys[k];
+            for (int r = 0; r < 64; r++) k[r] = umed3(k[r], (uint32_t)__shfl_xor((int)k[r], m), c);
+        }
+        const uint32_t clo = asc ? 0u : 0xffffffffu;
+        box_stage_lane<32>(k, clo); box_stage_lane<16>(k, clo); box_stage_lane<8>(k, clo);
+        box_stage_lane<4>(k, clo); box_stage_lane<2>(k, clo); box_stage_lane<1>(k, clo);
+    }
+#pragma unroll
+    for (int r = 0; r < 64; r++) v[lane * 65 + r] = box_key_value(k[r]);
     __syncthreads();
-    if (tid == 0) { s_a = 0; s_b = n0; }
-    __syncthreads();
-    double mean = 0.0, sd = 0.0, med = 0.0;
+    // sums about a pivot close to the final mean (the median of all usable pixels); the clip
+    // iterations subtract what they remove
+    const double piv = (double)v[box_slot(n0 >> 1)];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const double t = (k[r] != BOX_PAD) ? (double)box_key_value(k[r]) - piv : 0.0;
+        s1 += t; s2 += t * t;
+    }
+    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+    int a = 0, b = n0;
+    double sd = 0.0, med = 0.0;
     for (int it = 0; it <= 5; it++) {
-        const int a = s_a, b = s_b, n = b - a;
-        // mean and std (about the mean, ddof 0) of the survivors
-        double s = 0.0;
-        for (int i = a + tid; i < b; i += 256) s += (double)v[i];
-        s = wave_sum_f64(s);
-        if (lane == 0) red[wid] = s;
-        __syncthreads();
-        mean = ((red[0] + red[1]) + (red[2] + red[3])) / (double)n;
-        __syncthreads();
-        double q = 0.0;
-        for (int i = a + tid; i < b; i += 256) { const double t = mean - (double)v[i]; q += t * t; }
-        q = wave_sum_f64(q);
-        if (lane == 0) red[wid] = q;
-        __syncthreads();
-        sd = sqrt(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
-        med = (n & 1) ? (double)v[a + n / 2] : ((double)v[a + n / 2 - 1] + (double)v[a + n / 2]) * 0.5;
-        __syncthreads();
+        const int n = b - a;
+        const double m1 = s1 / (double)n;
+        const double var = s2 / (double)n - m1 * m1;      // std about the mean, ddof 0
+        sd = sqrt(var > 0.0 ? var : 0.0);
+        med = (n & 1) ? (double)v[box_slot(a + n / 2)] : ((double)v[box_slot(a + n / 2 - 1)] + (double)v[box_slot(a + n / 2)]) * 0.5;
         if (it == 5) break;                               // statistics of the survivors after 5 clips
         const double lo = med - 3.0 * sd, hi = med + 3.0 * sd;
-        int nlo = 0, nhi = 0;
-        for (int i = a + tid; i < b; i += 256) { const double x = (double)v[i]; nlo += (x < lo); nhi += (x > hi); }
-        nlo = wave_sum_i32(nlo); nhi = wave_sum_i32(nhi);
-        if (lane == 0) { redi[wid] = nlo; }
-        __syncthreads();
-        const int tlo = redi[0] + redi[1] + redi[2] + redi[3];
-        __syncthreads();
-        if (lane == 0) { redi[wid] = nhi; }
-        __syncthreads();
-        const int thi = redi[0] + redi[1] + redi[2] + redi[3];
-        __syncthreads();
+        const int tlo = box_count_below<false>(v, a, b, lo, lane);
+        const int thi = n - box_count_below<true>(v, a, b, hi, lane);
         if (tlo == 0 && thi == 0) break;                  // nothing clipped: these are the final statistics
-        if (tid == 0) { s_a = a + tlo; s_b = b - thi; }
-        __syncthreads();
-        if (s_b - s_a <= 0) break;
+        double d1 = 0.0, d2 = 0.0;
+        for (int i = a + lane; i < a + tlo; i += 64) { const double t = (double)v[box_slot(i)] - piv; d1 += t; d2 += t * t; }
+        for (int i = b - thi + lane; i < b; i += 64) { const double t = (double)v[box_slot(i)] - piv; d1 += t; d2 += t * t; }
+        s1 -= wave_sum_f64(d1); s2 -= wave_sum_f64(d2);
+        a += tlo; b -= thi;
+        if (b - a <= 0) break;
     }
-    if (tid == 0) {
-        if (s_b - s_a <= 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[blockIdx.x] = nanv; mini_std[blockIdx.x] = nanv; }
-        else { mini_med[blockIdx.x] = (float)med; mini_std[blockIdx.x] = (float)sd; }
+    if (lane == 0) {
+        if (b - a <= 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[ibox] = nanv; mini_std[ibox] = nanv; }
+        else { mini_med[ibox] = (float)med; mini_std[ibox] = (float)sd; }
     }
 }
 
@@ -242,10 +314,11 @@ extern "C" {
 int bbx_bkg_boxstats(bbx_ctx* ctx, int ny, int nx, int box, const float* d_data, const uint8_t* d_mask,
                      const uint8_t* d_objmask, float limfrac, float* d_mini_med, float* d_mini_std, void* stream) {
     if (!ctx || !d_data || !d_mask || !d_mini_med || !d_mini_std) return BBX_ERR_ARG;
-    if (box < 2 || box > 64 || ny % box || nx % box) return BBX_ERR_ARG;
+    if (box < 2 || box > 64 || ny % box || nx % box || (size_t)nx * 64 > 0x7fffffffu) return BBX_ERR_ARG;
     const int nby = ny / box, nbx = nx / box;
-    hipLaunchKernelGGL(k_bkg_boxstats, dim3(nby * nbx), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d_objmask,
-                       ny, nx, box, nbx, limfrac, d_mini_med, d_mini_std);
+    const int nboxes = nby * nbx;
+    hipLaunchKernelGGL(k_bkg_boxstats, dim3(((nboxes + 7) / 8) * 8), dim3(64), 0, (hipStream_t)stream, d_data, d_mask, d_objmask,
+                       ny, nx, box, nbx, nboxes, limfrac, d_mini_med, d_mini_std);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -29,6 +29,44 @@ def dev(ctx, a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
 
 
+@pytest.mark.parametrize('box', [2, 5, 33, 60, 64])
+def test_box_statistics_box_sizes(ctx, box):
+    """k_bkg_boxstats sorts a box in the registers of one wave (64 x 64 slots): box sizes that
+    fill them partly, exactly and barely; negative and tied values; constant boxes (std 0);
+    boxes below limfrac; outliers on both sides."""
+    from blackbox_amd._lib import lib, check
+    import ctypes as C
+    rs = np.random.RandomState(box)
+    nby, nbx = (9, 11) if box > 8 else (40, 37)
+    ny, nx = nby * box, nbx * box
+    data = np.round(rs.normal(-3, 20, (ny, nx)) * 4) / 4          # quarter-ADU grid: many ties, both signs
+    data[rs.random_sample((ny, nx)) < 0.02] += 5000
+    data[rs.random_sample((ny, nx)) < 0.02] -= 7000
+    data = data.astype(F)
+    data[0:box, 0:box] = 17.25                                     # constant box
+    data[box:2 * box, 0:box] = np.where(rs.random_sample((box, box)) < 0.5, F(1), F(2))   # two values
+    mask = np.zeros((ny, nx), np.uint8)
+    mask[rs.random_sample((ny, nx)) < 0.1] = 2
+    mask[2 * box:3 * box, box:2 * box][rs.random_sample((box, box)) < 0.6] = 1            # below limfrac
+    mask[3 * box:4 * box, 0:box] = 8                               # nothing usable
+    objmask = (rs.random_sample((ny, nx)) < 0.05).astype(np.uint8)
+    for om, od in ((objmask, dev(ctx, objmask)), (None, None)):
+        med_o, std_o = Z.get_back_mini(data, mask, om, box=box)
+        m = torch.full((nby, nbx), -1.0, dtype=torch.float32, device=ctx.device)
+        s = torch.full((nby, nbx), -1.0, dtype=torch.float32, device=ctx.device)
+        t_data, t_mask = dev(ctx, data), dev(ctx, mask)
+        check(lib.bbx_bkg_boxstats(ctx.h, ny, nx, box, C.c_void_p(t_data.data_ptr()), C.c_void_p(t_mask.data_ptr()),
+                                   C.c_void_p(od.data_ptr() if od is not None else None), 0.5,
+                                   C.c_void_p(m.data_ptr()), C.c_void_p(s.data_ptr()), ctx.stream()), 'boxstats')
+        ctx.sync()
+        mh, sh = m.cpu().numpy(), s.cpu().numpy()
+        assert np.array_equal(np.isnan(mh), np.isnan(med_o)) and np.isnan(med_o).any()
+        ok = ~np.isnan(med_o)
+        assert np.array_equal(mh[ok], med_o[ok])
+        np.testing.assert_allclose(sh[ok], std_o[ok], rtol=2e-6, atol=1e-7)
+        assert sh[0, 0] == 0 and mh[0, 0] == F(17.25)
+
+
 def test_background_mesh(ctx):
     rs = np.random.RandomState(1)
     box, nby, nbx = 20, 12, 16
