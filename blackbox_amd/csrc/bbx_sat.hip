@@ -11,7 +11,7 @@
 
 #define SAT_PROF_HALF 40
 #define SAT_NPROF (2 * SAT_PROF_HALF + 1)
-#define SAT_BLOCKS 512
+#define SAT_BLOCKS 1024
 
 struct sat_state {
     double lo, hi, mean, std;             // clipped statistics of the binned frame
@@ -41,17 +41,38 @@ __global__ void k_sat_init(sat_state* st) {
     if (threadIdx.x < SAT_NPROF) { st->prof_sum[threadIdx.x] = 0.0; st->prof_n[threadIdx.x] = 0; }
 }
 
+__device__ __forceinline__ void clip_acc(float f, double lo, double hi, double& s1, double& s2, int& cnt) {
+    const double x = (double)f;
+    if (isfinite(f) && x >= lo && x <= hi) { s1 += x; s2 += x * x; cnt++; }
+}
+
+// sums of the binned pixels inside the current clip range: 16-byte loads, four in flight per
+// thread; one partial triple per workgroup (fixed launch shape -> the same sums in every run)
 __global__ __launch_bounds__(256) void k_clip_pass(const float* __restrict__ b, size_t n, const sat_state* __restrict__ st,
                                                    double* __restrict__ partial) {
     const double lo = st->lo, hi = st->hi;
-    double s1 = 0.0, s2 = 0.0; long long cnt = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float f = b[i];
-        const double x = (double)f;
-        if (isfinite(f) && x >= lo && x <= hi) { s1 += x; s2 += x * x; cnt++; }
+    double s1 = 0.0, s2 = 0.0; int cnt = 0;
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    const float4* b4 = (const float4*)b;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = b4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            clip_acc(q[u].x, lo, hi, s1, s2, cnt); clip_acc(q[u].y, lo, hi, s1, s2, cnt);
+            clip_acc(q[u].z, lo, hi, s1, s2, cnt); clip_acc(q[u].w, lo, hi, s1, s2, cnt);
+        }
     }
-    __shared__ double sh1[4], sh2[4]; __shared__ long long shn[4];
-    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2); cnt = wave_sum_i64(cnt);
+    for (; i < n4; i += stride) {
+        const float4 q = b4[i];
+        clip_acc(q.x, lo, hi, s1, s2, cnt); clip_acc(q.y, lo, hi, s1, s2, cnt);
+        clip_acc(q.z, lo, hi, s1, s2, cnt); clip_acc(q.w, lo, hi, s1, s2, cnt);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) clip_acc(b[(n4 << 2) + threadIdx.x], lo, hi, s1, s2, cnt);
+    __shared__ double sh1[4], sh2[4]; __shared__ int shn[4];
+    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2); cnt = wave_sum_i32(cnt);
     if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = s1; sh2[threadIdx.x >> 6] = s2; shn[threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -61,10 +82,18 @@ __global__ __launch_bounds__(256) void k_clip_pass(const float* __restrict__ b, 
     }
 }
 
-__global__ void k_clip_update(sat_state* st, const double* __restrict__ partial, int nblocks) {
-    if (threadIdx.x != 0) return;
+// one workgroup of 256 folds the partial triples (thread t takes blocks t, t+256, ...; then a
+// fixed tree) and narrows the clip range
+__global__ __launch_bounds__(256) void k_clip_update(sat_state* st, const double* __restrict__ partial, int nblocks) {
+    __shared__ double sh[3][4];
     double a = 0, q = 0, m = 0;
-    for (int b = 0; b < nblocks; b++) { a += partial[3 * b]; q += partial[3 * b + 1]; m += partial[3 * b + 2]; }
+    for (int b = threadIdx.x; b < nblocks; b += 256) { a += partial[3 * b]; q += partial[3 * b + 1]; m += partial[3 * b + 2]; }
+    a = wave_sum_f64(a); q = wave_sum_f64(q); m = wave_sum_f64(m);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = q; sh[2][threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]); q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    m = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
     const double mean = a / m;
     double var = q / m - mean * mean; if (var < 0) var = 0;
     const double sd = sqrt(var);
@@ -246,7 +275,7 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin);
     for (int pass = 0; pass < 4; pass++) {
         hipLaunchKernelGGL(k_clip_pass, dim3(SAT_BLOCKS), dim3(256), 0, s, bin, nb, st, partial);
-        hipLaunchKernelGGL(k_clip_update, dim3(1), dim3(64), 0, s, st, partial, SAT_BLOCKS);
+        hipLaunchKernelGGL(k_clip_update, dim3(1), dim3(256), 0, s, st, partial, SAT_BLOCKS);
     }
     hipLaunchKernelGGL(k_edge_compact, dim3(2048), dim3(256), 0, s, bin, nb, st, list, cnt, (uint32_t)cap, ctx->d_err);
     if ((size_t)nrho * 4 <= 150 * 1024) {
