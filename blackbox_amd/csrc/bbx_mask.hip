@@ -568,9 +568,52 @@ __global__ __launch_bounds__(256) void k_cc_count(const int32_t* __restrict__ cn
 }
 
 // compaction of (mask & bit) pixels into a list
-__global__ __launch_bounds__(256) void k_compact_bit(const uint8_t* __restrict__ mask, size_t npix, int bit,
+// pixels whose mask byte holds all of [bit] -> list (any order).  16 mask bytes per thread and
+// load; a wave that found something reserves its entries with one atomic.  from16/to16 are in
+// units of 16 bytes ([mask] 16-byte aligned); k_compact_bit_bytes takes what is left.
+__global__ __launch_bounds__(256) void k_compact_bit(const uint8_t* __restrict__ mask, size_t n16, int bit,
                                                      uint32_t* list, int32_t* cnt, uint32_t cap, int32_t* err) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4* m16 = (const uint4*)mask;
+    const unsigned B = (unsigned)bit * 0x01010101u;
+    const int lane = threadIdx.x & 63;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nend = ((n16 + stride - 1) / stride) * stride;          // every wave runs the same number of rounds
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nend; i += stride) {
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (i < n16) w = m16[i];
+        unsigned h[4]; int c = 0;
+        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned t = (ww[k] & B) ^ B;                          // byte == 0 <=> all bits of [bit] set
+            const unsigned nz = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+            h[k] = (i < n16) ? (~nz & 0x80808080u) : 0u;
+            c += __popc(h[k]);
+        }
+        if (__ballot(c > 0) == 0) continue;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int total = __shfl(incl, 63);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd((unsigned*)cnt, (unsigned)total);
+        base = (unsigned)__shfl((int)base, 0) + (unsigned)(incl - c);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned hk = h[k];
+            while (hk) {
+                const int by = (__ffs((int)hk) - 1) >> 3;
+                hk &= hk - 1;
+                if (base < cap) list[base] = (uint32_t)(i * 16 + k * 4 + by); else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+                base++;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_bit_bytes(const uint8_t* __restrict__ mask, size_t from, size_t npix, int bit,
+                                                           uint32_t* list, int32_t* cnt, uint32_t cap, int32_t* err) {
+    for (size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         if ((mask[i] & bit) == bit) {
             unsigned k = atomicAdd((unsigned*)cnt, 1u);
             if (k < cap) list[k] = (uint32_t)i; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
@@ -795,8 +838,13 @@ int bbx_count_objects(bbx_ctx* ctx, int ny, int nx, const uint8_t* d_mask, int b
     const size_t cap = npix / 8 + 1024;
     uint32_t* list = (uint32_t*)bbx_ws(ctx, WS_CCLIST, cap * sizeof(uint32_t), &rc); if (rc) return rc;
     BBX_HIP(hipMemsetAsync(&ctx->d_counters[CNT_CC_N], 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_compact_bit, dim3(2048), dim3(256), 0, s, d_mask, npix, bit, list, &ctx->d_counters[CNT_CC_N],
-                       (uint32_t)cap, ctx->d_err);
+    const size_t n16 = (((uintptr_t)d_mask) & 15) ? 0 : (size_t)npix / 16;
+    if (n16)
+        hipLaunchKernelGGL(k_compact_bit, dim3(2048), dim3(256), 0, s, d_mask, n16, bit, list, &ctx->d_counters[CNT_CC_N],
+                           (uint32_t)cap, ctx->d_err);
+    if (n16 * 16 < (size_t)npix)
+        hipLaunchKernelGGL(k_compact_bit_bytes, dim3(n16 ? 1 : 2048), dim3(256), 0, s, d_mask, n16 * 16, (size_t)npix, bit, list,
+                           &ctx->d_counters[CNT_CC_N], (uint32_t)cap, ctx->d_err);
     BBX_LAUNCH_CHECK();
     return bbx_cc_count_list(ctx, list, &ctx->d_counters[CNT_CC_N], cap, ny, nx, d_count, s);
 }

@@ -178,6 +178,24 @@ def test_count_objects(ctx):
     n = R.count_objects(ctx, torch.from_numpy(m).to(ctx.device), 16)
     ctx.sync()
     assert int(n.item()) == ndimage.label(m == 16, structure=np.ones((3, 3), bool))[1]
+    # other bits around, a two-bit pattern, a pixel count that is no multiple of 16 and a mask
+    # that does not start on a 16-byte boundary (the compaction reads 16 bytes per thread)
+    m2 = (rs.randint(0, 256, (301, 517)) & ~12).astype(np.uint8)           # lists hold at most 1/8 of the frame
+    m2[rs.random_sample(m2.shape) < 0.05] |= 4
+    m2[rs.random_sample(m2.shape) < 0.05] |= 8
+    m2[200:203, 7:9] = 255
+    m2[50:60, 100:300] |= 12
+    m2[-1, -5:] |= 12
+    m2[0, :3] |= 12
+    for bit in (4, 12, 255):
+        want = ndimage.label((m2 & bit) == bit, structure=np.ones((3, 3), bool))[1]
+        for off in (0, 3):
+            buf = torch.zeros(m2.size + 16, dtype=torch.uint8, device=ctx.device)
+            view = buf[off:off + m2.size].view(m2.shape)
+            view.copy_(torch.from_numpy(m2).to(ctx.device))
+            n = R.count_objects(ctx, view, bit)
+            ctx.sync()
+            assert int(n.item()) == want, (bit, off)
 
 
 def test_fill_holes_shapes(ctx):
