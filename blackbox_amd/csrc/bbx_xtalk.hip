@@ -4,67 +4,82 @@
 // float64 matmuls with K = 8.  Here one thread owns one pixel position (y, x) of
 // the channel grid: it reads the 16 source values that couple to each other -- the
 // 8 lower-row channels at row y and the 8 upper-row channels at the mirrored row
-// ysize-1-y -- applies the 16x16 coefficient matrix in float64 registers and writes
-// the 16 corrected victims back in place.  Every pixel is read once and written
-// once: 4N + N (mask) + 4N bytes, HBM-bound (16 float64 FMAs per output pixel are
-// far below the vector rate, so no MFMA reshaping).
+// ysize-1-y -- keeps them in float64 registers, and then takes the 16 victims in turn:
+// the victim's 16 coefficients arrive by scalar loads, its own value is read again
+// (L2) and the corrected value written back in place.  From HBM every pixel is read
+// once and written once: 4N + N (mask) + 4N bytes (16 float64 FMAs per output pixel
+// are far below the vector rate, so no MFMA reshaping).
 #include "bbx_common.h"
 #include <stdlib.h>
 
-// VEC pixels per thread and channel (4 when xsize_chan % 4 == 0: float4 / uchar4 accesses)
+template <int VEC> __device__ __forceinline__ void xtalk_fetch(const float* data, const uint8_t* mask, size_t off, float (&v)[VEC], uint8_t (&m)[VEC]) {
+    if (VEC == 4) {
+        const float4 f = *(const float4*)(data + off);
+        const uchar4 b = *(const uchar4*)(mask + off);
+        v[0] = f.x; v[1 % VEC] = f.y; v[2 % VEC] = f.z; v[3 % VEC] = f.w;
+        m[0] = b.x; m[1 % VEC] = b.y; m[2 % VEC] = b.z; m[3 % VEC] = b.w;
+    } else if (VEC == 2) {
+        const float2 f = *(const float2*)(data + off);
+        const uchar2 b = *(const uchar2*)(mask + off);
+        v[0] = f.x; v[VEC - 1] = f.y; m[0] = b.x; m[VEC - 1] = b.y;
+    } else {
+        v[0] = data[off]; m[0] = mask[off];
+    }
+}
+
+// VEC pixels per thread and channel (float4 / uchar4 accesses when VEC == 4).
+// [cf] is the transposed matrix: cf.v[v * 16 + s] = coefficient of source channel s on victim v.
+// The loop over the victims is a real loop: the 16 coefficients of a victim are fetched by scalar
+// loads from the kernel-argument segment when its turn comes.  (Unrolled, the 256 coefficients
+// are loop invariants that the compiler keeps in 512 SGPRs it does not have: it spilled them to
+// VGPR lanes and the kernel spent its time in v_readlane, 0.72 ms per frame.)  The victim's own
+// value and mask byte are read again (L2 hits) rather than kept in registers for the same reason.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __restrict__ mask, bbx_dims d, f64x256 cf) {
     const int ngx = d.xsz / VEC;
     const size_t total = (size_t)d.ysz * ngx;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(t / ngx), x = (int)(t - (size_t)y * ngx) * VEC;
-        size_t off[16];
+        const size_t off_lo = (size_t)y * d.nx + x, off_hi = (size_t)(d.ysz + (d.ysz - 1 - y)) * d.nx + x;
         double src[16][VEC];
-        float val[16][VEC];
-        bool victim_ok[16][VEC];
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            const int iy = c >> 3, ix = c & 7;
-            const int Y = (iy == 0) ? y : (d.ysz + (d.ysz - 1 - y));
-            off[c] = (size_t)Y * d.nx + (size_t)ix * d.xsz + x;
+            const size_t off = ((c >> 3) ? off_hi : off_lo) + (size_t)(c & 7) * d.xsz;
             float v[VEC]; uint8_t m[VEC];
-            if (VEC == 4) {
-                const float4 f = *(const float4*)(data + off[c]);
-                const uchar4 b = *(const uchar4*)(mask + off[c]);
-                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-                m[0] = b.x; m[1] = b.y; m[2] = b.z; m[3] = b.w;
-            } else if (VEC == 2) {
-                const float2 f = *(const float2*)(data + off[c]);
-                const uchar2 b = *(const uchar2*)(mask + off[c]);
-                v[0] = f.x; v[1] = f.y; m[0] = b.x; m[1] = b.y;
-            } else {
-                v[0] = data[off[c]]; m[0] = mask[off[c]];
-            }
+            xtalk_fetch<VEC>(data, mask, off, v, m);
 #pragma unroll
             for (int q = 0; q < VEC; q++) {
-                val[c][q] = v[q];
-                // mask_source: positive, not bad, not cosmic (7178-7180); mask_victim: not edge (7184)
+                // mask_source: positive, not bad, not cosmic (7178-7180)
                 const bool use = (v[q] > 0.f) && !(m[q] & BBX_MASK_BAD) && !(m[q] & BBX_MASK_COSMIC);
                 src[c][q] = use ? (double)v[q] : 0.0;
-                victim_ok[c][q] = !(m[q] & BBX_MASK_EDGE);
             }
         }
-#pragma unroll
+        // the victim's value and mask byte are fetched one turn ahead
+        float nval[VEC]; uint8_t nm[VEC];
+        xtalk_fetch<VEC>(data, mask, off_lo, nval, nm);
+#pragma unroll 1
         for (int v = 0; v < 16; v++) {
+            const size_t off = ((v >> 3) ? off_hi : off_lo) + (size_t)(v & 7) * d.xsz;
+            float val[VEC]; uint8_t m[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; q++) { val[q] = nval[q]; m[q] = nm[q]; }
+            if (v < 15) xtalk_fetch<VEC>(data, mask, (((v + 1) >> 3) ? off_hi : off_lo) + (size_t)((v + 1) & 7) * d.xsz, nval, nm);
+            const double* cv = &cf.v[v * 16];
             float o[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; q++) {
                 double q_lo = 0.0, q_hi = 0.0;                 // the two K=8 quadrant products
 #pragma unroll
-                for (int s = 0; s < 8; s++) q_lo = fma(src[s][q], cf.v[s * 16 + v], q_lo);
+                for (int s = 0; s < 8; s++) q_lo = fma(src[s][q], cv[s], q_lo);
 #pragma unroll
-                for (int s = 8; s < 16; s++) q_hi = fma(src[s][q], cf.v[s * 16 + v], q_hi);
+                for (int s = 8; s < 16; s++) q_hi = fma(src[s][q], cv[s], q_hi);
                 const double corr = (0.0 + q_lo) + q_hi;
-                o[q] = (float)((double)val[v][q] - (victim_ok[v][q] ? corr : corr * 0.0));
+                // mask_victim: not edge (7184)
+                o[q] = (float)((double)val[q] - (!(m[q] & BBX_MASK_EDGE) ? corr : corr * 0.0));
             }
-            if (VEC == 4) *(float4*)(data + off[v]) = make_float4(o[0], o[1], o[2], o[3]);
-            else if (VEC == 2) *(float2*)(data + off[v]) = make_float2(o[0], o[VEC - 1]);
-            else data[off[v]] = o[0];
+            if (VEC == 4) *(float4*)(data + off) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+            else if (VEC == 2) *(float2*)(data + off) = make_float2(o[0], o[VEC - 1]);
+            else data[off] = o[0];
         }
     }
 }
@@ -73,19 +88,23 @@ extern "C" int bbx_xtalk(bbx_ctx* ctx, const bbx_geom* g, float* d_data, const u
                          const double* h_coeffs, void* stream) {
     if (!ctx || !d_data || !d_mask || !h_coeffs) return BBX_ERR_ARG;
     bbx_dims d; int rc = bbx_make_dims(g, &d); if (rc) return rc;
-    f64x256 cf;
-    for (int i = 0; i < 256; i++) cf.v[i] = h_coeffs[i];
-    // measured on MI355X: the 4-wide variant is register-bound and slower than one pixel per thread;
-    // two pixels per thread (8-byte loads, 2-byte mask loads) is the fastest of the three
-    const int vw = (getenv("BBX_XTALK_VEC") ? atoi(getenv("BBX_XTALK_VEC")) : 2);
-    const bool vec2 = vw == 2 && d.xsz % 2 == 0 && ((uintptr_t)d_data) % 8 == 0 && ((uintptr_t)d_mask) % 2 == 0 && d.nx % 2 == 0;
-    const bool vec = vw == 4 && d.xsz % 4 == 0 && d.nx % 4 == 0;
-    const size_t total = (size_t)d.ysz * (d.xsz / (vec ? 4 : vec2 ? 2 : 1));
+    f64x256 cf;                                             // transposed: the coefficients of a victim are contiguous
+    for (int sc = 0; sc < 16; sc++) for (int v = 0; v < 16; v++) cf.v[v * 16 + sc] = h_coeffs[sc * 16 + v];
+    // measured on MI355X (full frame): one pixel per thread 0.26 ms, two 0.40, four 0.32 -- the
+    // narrow variant needs 52 VGPRs and runs 8 waves per SIMD, which hides the 16 channel streams'
+    // latency best.  BBX_XTALK_VEC=2|4 selects the wider ones where geometry and pointers allow.
+    int vw = 1;
+    if (getenv("BBX_XTALK_VEC")) {
+        const int w = atoi(getenv("BBX_XTALK_VEC"));
+        if (w == 2 && d.xsz % 2 == 0 && d.nx % 2 == 0 && ((uintptr_t)d_data) % 8 == 0 && ((uintptr_t)d_mask) % 2 == 0) vw = 2;
+        if (w == 4 && d.xsz % 4 == 0 && d.nx % 4 == 0 && ((uintptr_t)d_data) % 16 == 0 && ((uintptr_t)d_mask) % 4 == 0) vw = 4;
+    }
+    const size_t total = (size_t)d.ysz * (d.xsz / vw);
     unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 256u * 16u) grid = 256u * 16u;
+    if (grid > 256u * 16u) grid = 256u * 16u;                // 2k ... 1M workgroups measure the same
     bbx_prof_start(ctx, BBX_PROF_XTALK, (hipStream_t)stream);
-    if (vec) hipLaunchKernelGGL(k_xtalk<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
-    else if (vec2) hipLaunchKernelGGL(k_xtalk<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    if (vw == 4) hipLaunchKernelGGL(k_xtalk<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
+    else if (vw == 2) hipLaunchKernelGGL(k_xtalk<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
     else hipLaunchKernelGGL(k_xtalk<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_data, d_mask, d, cf);
     bbx_prof_stop(ctx, (hipStream_t)stream);
     BBX_LAUNCH_CHECK();

@@ -12,11 +12,12 @@ sol = R.os_solve(ctx, raw, h, 'ML1', geom)
 data, mask = R.calibrate(ctx, raw, sol, h, hm, 'ML1', geom, mflat=flat, bpm=bpm)
 rs = np.random.RandomState(0)
 coeffs = np.zeros((16, 16)); coeffs[~np.eye(16, dtype=bool)] = rs.uniform(0, 2e-4, 240)
-for vw in ('1', '2', '4'):
+for vw, grid in (('1', 0), ('2', 0), ('4', 0)):
     os.environ['BBX_XTALK_VEC'] = vw
+    os.environ['BBX_XTALK_GRID'] = str(grid)
     R.xtalk_corr(ctx, data, coeffs, mask, geom); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10): R.xtalk_corr(ctx, data, coeffs, mask, geom)
     e1.record(); torch.cuda.synchronize()
-    print('xtalk VEC', vw, round(e0.elapsed_time(e1) / 10, 3), 'ms')
+    print('xtalk VEC', vw, 'grid', grid, round(e0.elapsed_time(e1) / 10, 3), 'ms')
