@@ -94,15 +94,16 @@ __global__ __launch_bounds__(64) void k_bkg_boxstats(const float* __restrict__ d
     {
         // element c*64 + lane: consecutive lanes read along a box row.  All loads of the box are
         // issued before the first use and without branches (slots beyond the box re-read its
-        // first pixel and are discarded): the kernel runs few waves per CU (LDS) and needs the
+        // last pixel and are discarded): the kernel runs few waves per CU (LDS) and needs the
         // memory parallelism
         int yy = lane / box, xx = lane - yy * box;
         const size_t o0 = (size_t)(by * box) * nx + (size_t)bx * box;
         const float* pd = data + o0; const uint8_t* pm = mask + o0; const uint8_t* po = objmask + o0;
+        const uint32_t omax = (uint32_t)((box - 1) * nx + box - 1);
         unsigned mk[64];
 #pragma unroll
         for (int c = 0; c < 64; c++) {
-            const uint32_t o = (c * 64 + lane < npx) ? (uint32_t)(yy * nx + xx) : 0u;   // < 64 nx: the host checks that it fits
+            const uint32_t o = min((uint32_t)(yy * nx + xx), omax);    // < 64 nx: the host checks that it fits
             k[c] = __float_as_uint(pd[o]);
             mk[c] = pm[o];
             if (objmask) mk[c] |= po[o];
