@@ -47,42 +47,44 @@ __global__ __launch_bounds__(256) void k_sat_scatter(const uint32_t* __restrict_
 // ---------------------------------------------------------------------------------
 // 3x3 binary closing on the bit plane (ndimage.binary_closing, border_value 0)
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ u64 row3(const u64* __restrict__ b, int r, int w, int ny, int W, bool outside_one) {
-    // OR (dilate) helper input: word w of rows r-1..r+1 combined with OR
-    u64 v = 0;
-    for (int k = -1; k <= 1; k++) {
-        int rr = r + k;
-        if (rr < 0 || rr >= ny) { if (outside_one) v = ~0ull; continue; }
-        v |= b[(size_t)rr * W + w];
-    }
-    return v;
-}
-
-__global__ __launch_bounds__(256) void k_bits_dilate(const u64* __restrict__ in, u64* __restrict__ out, int ny, int nx, int W) {
+// closing in one pass: word w of row r of erode(dilate(in)).  The dilation of rows r-1..r+1 is
+// rebuilt from the words w-1, w, w+1 of rows r-2..r+2 (15 loads that hit the caches; the
+// saturated pixels are sparse, so almost every thread finds 15 zeros and stores a zero).
+__global__ __launch_bounds__(256) void k_bits_close(const u64* __restrict__ in, u64* __restrict__ out, int ny, int nx, int W) {
     const size_t total = (size_t)ny * W;
+    const u64 lastmask = (nx & 63) ? ((1ull << (nx & 63)) - 1) : ~0ull;      // dilation stays inside the image
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
-        u64 n = row3(in, r, w, ny, W, false);
-        u64 nl = (w > 0) ? row3(in, r, w - 1, ny, W, false) : 0ull;
-        u64 nr = (w < W - 1) ? row3(in, r, w + 1, ny, W, false) : 0ull;
-        u64 h = n | (n << 1) | (n >> 1) | (nl >> 63) | (nr << 63);
-        if (w == W - 1 && (nx & 63)) h &= (1ull << (nx & 63)) - 1;        // stay inside the image
-        out[i] = h;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_bits_erode(const u64* __restrict__ in, u64* __restrict__ out, int ny, int nx, int W) {
-    const size_t total = (size_t)ny * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
-        u64 res = ~0ull;
-        for (int k = -1; k <= 1; k++) {
-            const int rr = r + k;
-            if (rr < 0 || rr >= ny) { res = 0; break; }                    // border_value = 0
-            const u64 c = in[(size_t)rr * W + w];
-            const u64 l = (w > 0) ? in[(size_t)rr * W + w - 1] : 0ull;
-            const u64 rt = (w < W - 1) ? in[(size_t)rr * W + w + 1] : 0ull;
-            res &= c & ((c << 1) | (l >> 63)) & ((c >> 1) | (rt << 63));
+        u64 m[5][3]; u64 any = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int rr = r + k - 2;
+            const bool in_r = rr >= 0 && rr < ny;
+            m[k][0] = (in_r && w > 0) ? in[(size_t)rr * W + w - 1] : 0ull;
+            m[k][1] = in_r ? in[(size_t)rr * W + w] : 0ull;
+            m[k][2] = (in_r && w < W - 1) ? in[(size_t)rr * W + w + 1] : 0ull;
+            any |= m[k][0] | m[k][1] | m[k][2];
+        }
+        u64 res = 0;
+        if (any && r > 0 && r < ny - 1) {                                    // erosion: border_value = 0
+            res = ~0ull;
+#pragma unroll
+            for (int k = 1; k <= 3; k++) {                                   // dilated row r + k - 2
+                const u64 nl = m[k - 1][0] | m[k][0] | m[k + 1][0];          // OR of the three rows, per word
+                const u64 n = m[k - 1][1] | m[k][1] | m[k + 1][1];
+                const u64 nr = m[k - 1][2] | m[k][2] | m[k + 1][2];
+                u64 c = n | (n << 1) | (n >> 1) | (nl >> 63) | (nr << 63);
+                if (w == W - 1) c &= lastmask;
+                // the two bits of the neighbouring words' dilation that the erosion looks at
+                u64 l63 = (w > 0) ? (((nl | (nl << 1)) >> 63) | (n & 1ull)) & 1ull : 0ull;
+                u64 r0 = 0ull;
+                if (w < W - 1) {
+                    u64 d = (nr | (nr >> 1) | (n >> 63)) & 1ull;
+                    if (w + 1 == W - 1) d &= lastmask;
+                    r0 = d;
+                }
+                res &= c & ((c << 1) | l63) & ((c >> 1) | (r0 << 63));
+            }
         }
         out[i] = res;
     }
@@ -810,8 +812,7 @@ int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d
                            d.ny, d.nx, d_nobj_sat, s);
     if (rc) return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256 > 4096 ? 4096 : (nwords + 255) / 256);
-    hipLaunchKernelGGL(k_bits_dilate, dim3(gw), dim3(256), 0, s, bitsM, bitsR, d.ny, d.nx, W);   // R as temp
-    hipLaunchKernelGGL(k_bits_erode, dim3(gw), dim3(256), 0, s, bitsR, bitsC, d.ny, d.nx, W);
+    hipLaunchKernelGGL(k_bits_close, dim3(gw), dim3(256), 0, s, bitsM, bitsC, d.ny, d.nx, W);
     hipLaunchKernelGGL(k_tile_occupancy, dim3((W + 63) / 64, TH), dim3(64), 0, s, bitsC, occ, freebits, d.ny, W, TH);
     if (W <= CF_MAX && TH <= CF_MAX) {
         const size_t lds = ((size_t)TH * (W / 2 + 1) + 2) * sizeof(unsigned);
