@@ -99,15 +99,25 @@ __global__ __launch_bounds__(256) void k_bits_close(const u64* __restrict__ in, 
 // ---------------------------------------------------------------------------------
 // one wave per 64 consecutive tiles of a tile row: occupancy bytes (for the byte-wise flood)
 // and the row's free-tile bit word (for the run-based kernel)
-__global__ __launch_bounds__(64) void k_tile_occupancy(const u64* __restrict__ bitsC, uint8_t* __restrict__ occ,
-                                                       u64* __restrict__ freebits, int ny, int W, int TH) {
-    const int ty = blockIdx.y, k = blockIdx.x, tx = 64 * k + (int)threadIdx.x;
+__global__ __launch_bounds__(256) void k_tile_occupancy(const u64* __restrict__ bitsC, uint8_t* __restrict__ occ,
+                                                        u64* __restrict__ freebits, int ny, int W, int TH) {
+    // four waves share the 64 rows of a tile row (16 independent loads per lane)
+    __shared__ u64 part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ty = blockIdx.y, k = blockIdx.x, tx = 64 * k + lane;
     u64 any = 0;
-    if (tx < W)
-        for (int r = ty * 64; r < ty * 64 + 64 && r < ny; r++) any |= bitsC[(size_t)r * W + tx];
+    if (tx < W) {
+        const int r0 = ty * 64 + wv * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const int r = r0 + j; if (r < ny) any |= bitsC[(size_t)r * W + tx]; }
+    }
+    part[wv][lane] = any;
+    __syncthreads();
+    if (wv) return;
+    any = (part[0][lane] | part[1][lane]) | (part[2][lane] | part[3][lane]);
     if (tx < W) occ[ty * W + tx] = any ? 1 : 0;
     const u64 fr = __builtin_amdgcn_ballot_w64(tx < W && any == 0);
-    if (threadIdx.x == 0) freebits[(size_t)ty * gridDim.x + k] = fr;
+    if (lane == 0) freebits[(size_t)ty * gridDim.x + k] = fr;
 }
 
 #define COARSE_MAX 49152
@@ -813,7 +823,7 @@ int bbx_mask_finish(bbx_ctx* ctx, const bbx_geom* g, uint8_t* d_mask, int32_t* d
     if (rc) return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256 > 4096 ? 4096 : (nwords + 255) / 256);
     hipLaunchKernelGGL(k_bits_close, dim3(gw), dim3(256), 0, s, bitsM, bitsC, d.ny, d.nx, W);
-    hipLaunchKernelGGL(k_tile_occupancy, dim3((W + 63) / 64, TH), dim3(64), 0, s, bitsC, occ, freebits, d.ny, W, TH);
+    hipLaunchKernelGGL(k_tile_occupancy, dim3((W + 63) / 64, TH), dim3(256), 0, s, bitsC, occ, freebits, d.ny, W, TH);
     if (W <= CF_MAX && TH <= CF_MAX) {
         const size_t lds = ((size_t)TH * (W / 2 + 1) + 2) * sizeof(unsigned);
         BBX_HIP(hipFuncSetAttribute((const void*)k_coarse_cc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
