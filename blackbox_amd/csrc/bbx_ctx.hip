@@ -131,13 +131,6 @@ int bbx_sync(bbx_ctx* ctx, void* stream) {
     return BBX_OK;
 }
 
-// (experiments only, not part of bbx.h: device address and size of a workspace block)
-int bbx_debug_ws_ptr(bbx_ctx* ctx, int slot, void** ptr, size_t* bytes) {
-    if (!ctx || slot < 0 || slot >= WS_MAX || !ptr || !bytes) return BBX_ERR_ARG;
-    *ptr = ctx->d_ws[slot]; *bytes = ctx->ws_bytes[slot];
-    return BBX_OK;
-}
-
 int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (!ctx) return BBX_ERR_ARG;
     if (option == BBX_OPT_LAC_LEVEL_FEED) { ctx->lac_feed = value ? 1 : 0; return BBX_OK; }
