@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_bits_close(const u64* __restrict__ in, 
     const size_t total = (size_t)ny * W;
     const u64 lastmask = (nx & 63) ? ((1ull << (nx & 63)) - 1) : ~0ull;      // dilation stays inside the image
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
+        const int r = (int)((unsigned)i / (unsigned)W), w = (int)((unsigned)i - (unsigned)r * (unsigned)W);   // ny * W < 2^22 (COARSE_MAX tiles)
         u64 m[5][3]; u64 any = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_reach_init(u64* __restrict__ R, const u
     const size_t total = (size_t)ny * W;
     const u64 pad = (nx & 63) ? ~((1ull << (nx & 63)) - 1) : 0ull;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / W), w = (int)(i - (size_t)r * W);
+        const int r = (int)((unsigned)i / (unsigned)W), w = (int)((unsigned)i - (unsigned)r * (unsigned)W);   // ny * W < 2^22 (COARSE_MAX tiles)
         u64 v = state[(r >> 6) * W + w] ? ~0ull : 0ull;
         if (w == W - 1) v |= pad;
         R[i] = v;
