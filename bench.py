@@ -1,20 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- frames/sec of the per-image reduction hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): one 10600x12000 raw MeerLICHT frame ->
-gain/overscan/flat calibration + initial mask (saturation, crosstalk flags,
-closing, hole fill) + LA-Cosmic (niter=3), i.e. blackbox_reduce up to and
-including cosmics_corr (blackbox.py:1451-1878).  A "step" = one frame.  Inputs
-(raw frame, master flat, bad-pixel mask) are synthetic and resident in HBM when
-the timed region starts; every step includes the host-side overscan fits and the
-two small device<->host hops they need.
+Headline workload (BASELINE.json metric "end-to-end reduce+ZOGY", the per-frame work of
+configs[4] on one GPU): one 10600x12000 raw MeerLICHT frame -> gain / overscan / flat
+calibration + initial mask + LA-Cosmic (niter=3) + crosstalk + satellite trail + mask counts +
+edge fill (blackbox_reduce, blackbox.py:1451-1974), then zogy.optimal_subtraction against a
+co-added reference of the field (call site 2460-2465): background mesh + subtraction, variance
+images, 64 sub-images of 1400^2 through the ZOGY FFT subtraction, D / Scorr / Fpsf / Fpsferr,
+transient candidates, and the full-source catalogue by PSF-weighted optimal photometry.
+A "step" = one frame.  Inputs (raw frames, master flat, bad-pixel mask, crosstalk
+coefficients, reference image, PSFs) are synthetic and resident in HBM when the timed
+region starts; every step includes the host-side overscan fits and the small device<->host
+hops of the path.  --workload selects configs[1] (calibration + LA-Cosmic) or configs[2]
+(full calibration + background mesh + satellite trail) as the timed workload instead; their
+rates are also measured briefly and attached to the headline line (other_workloads).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--raw u16|f32] [--small]
-  N > 1: launched by torch.distributed.run, one rank per GPU; every rank reduces its
-  own frames (frames are independent, no data-path collective) -> weak scaling.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload zogy|full|calib] [--small]
+  N > 1: one rank per GPU (torch.distributed.run; `--gpus N` alone spawns it); every rank
+  reduces its own frames (independent, no data-path collective) -> weak scaling.
 
-Prints ONE JSON line (rank 0) with the roofline of the dominant kernel and a CPU
-baseline (the oracle restatement timed on a bounded sub-frame of the same scene).
+Timing: W + K frames go through the frames-in-flight pipeline in one run.  The clock starts
+when the W-th frame completes (pipeline full, no drain in between) and stops after the last
+frame completed and the device is idle: exactly K frames, steady state plus the drain.
+`fill_inclusive` is the rate of all W + K frames including the pipeline fill.
+
+Prints ONE JSON line (rank 0) with the roofline of the dominant kernel and a CPU baseline.
 """
 import argparse
 import json
@@ -30,9 +40,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
-def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype):
+def moffat_stamp(S, fwhm, beta=2.5):
+    """unit-sum Moffat PSF stamp [S, S] (float32), centre at S // 2"""
+    a = fwhm / (2 * np.sqrt(2 ** (1 / beta) - 1))
+    y, x = np.mgrid[0:S, 0:S] - S // 2
+    p = (1 + (y * y + x * x) / (a * a)) ** -beta
+    return (p / p.sum()).astype(np.float32)
+
+
+def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras=False, ntrans=0, trail=None):
     """full-size synthetic raw frame + flat + BPM, generated on the GPU (SURVEY 8d recipe:
-    per-channel bias/read noise, sky, stars incl. saturated ones, cosmic-ray tracks)"""
+    per-channel bias/read noise, sky, stars incl. saturated ones, cosmic-ray tracks).
+    extras: also return dict(scene0 = the noiseless sky + stars scene in e- (what a deep reference
+    image of the field shows), transients = [(y, x, flux)] of [ntrans] point sources (Moffat FWHM 4)
+    added to this frame only, S/N 6-100); trail = (xa, ya, xb, yb, amp, fwhm): a satellite trail."""
     from blackbox_amd import settings
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -65,6 +86,27 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype):
         ok = (px >= 0) & (px < nx) & (py >= 0) & (py < ny)
         idx = (py.long() * nx + px.long())[ok]
         scene.view(-1).index_add_(0, idx, val[ok])
+    scene0 = scene.clone() if extras else None
+    transients = []
+    if ntrans:
+        rt = np.random.RandomState(seed + 77)
+        S = 25
+        st = torch.tensor(moffat_stamp(S, 4.0), device=dev).reshape(-1)
+        oyx = np.mgrid[-(S // 2):S // 2 + 1, -(S // 2):S // 2 + 1]
+        for _ in range(ntrans):
+            ty, tx = int(rt.randint(40, ny - 40)), int(rt.randint(40, nx - 40))
+            fl = float(110.0 * 10 ** rt.uniform(np.log10(6), 2))               # S/N 6 .. 100 for ~110 e- of noise per PSF
+            idx = torch.tensor(((ty + oyx[0]) * nx + (tx + oyx[1])).ravel(), device=dev)
+            scene.view(-1).index_add_(0, idx, st * fl)
+            transients.append((ty, tx, fl))
+    if trail is not None:
+        xa, ya, xb, yb, amp, width = trail
+        norm = float(np.hypot(xb - xa, yb - ya))
+        for y0 in range(0, ny, 1024):                                          # in row bands: one distance plane at a time
+            yb_ = min(ny, y0 + 1024)
+            d = ((xx - xa) * (yb - ya) - (yy[y0:yb_] - ya) * (xb - xa)) / norm
+            scene[y0:yb_] += amp * torch.exp(-0.5 * (d / (width / 2.355)) ** 2)
+        del d
     # cosmic rays: 600 straight tracks (10/s x 60 s), 1 px wide, length 1-30
     ncr = max(10, int(600 * (ny * nx) / 111513600.0))
     cr_idx, cr_val = [], []
@@ -105,18 +147,37 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype):
     del scene
     if raw_dtype == 'u16':
         raw = raw.to(torch.int32).to(torch.uint16)
+    if extras:
+        return raw.contiguous(), flat, bpm, dict(scene0=scene0, transients=transients)
     return raw.contiguous(), flat, bpm
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """oracle (numpy/scipy restatement, single core) on a bounded sub-frame of the same
-    kind of scene: 2x8 channels of 660x330 px (1/32 of the frame), scaled by area"""
+def synth_reference(torch, dev, scene0, seed, depth=4.0, sky_ref=120.0):
+    """the co-added reference image of the field: the same scene without
+    cosmic rays / trails / transients at [depth] x the exposure (noise / sqrt(depth) in the
+    new frame's units), another sky level; mask all zero"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed + 4242)
+    sky = 250.0                                                   # mean sky of synth_frame_device's scene
+    ref = scene0 - sky + sky_ref
+    ref = ref + torch.sqrt((scene0 / depth).clamp(min=0)) * torch.randn(scene0.shape, device=dev, generator=g)
+    return ref.contiguous(), torch.zeros(scene0.shape, dtype=torch.uint8, device=dev)
+
+
+def _cpu_sample(args):
+    """one worker's bounded sample of the CPU path: the oracle restatement (numpy/scipy) of the
+    reduction on a 1320x2640 sub-frame (1/32 of a frame), the background mesh on it, and run_zogy
+    (numpy FFTs) on one 1400^2 sub-image; returns the seconds of each part"""
+    seed, with_zogy = args
+    for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[k] = '1'
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bbx_oracle as O
     import lacosmic as L
+    import zogy_core as Z
     from blackbox_amd import settings, synth
     ys, xs = 660, 330
-    case = synth.make_case(ys, xs, 4242, tel='ML1', os_y=20, os_x=45, n_stars=200, n_sat=2, n_cr=6)
+    case = synth.make_case(ys, xs, 4242 + seed, tel='ML1', os_y=20, os_x=45, n_stars=200, n_sat=2, n_cr=6)
     t0 = time.perf_counter()
     data = case['raw'].astype('float32')
     gain, sat = settings.gain['ML1'], settings.satlevel['ML1']
@@ -125,29 +186,127 @@ def cpu_baseline(seconds_budget=30.0):
     mask, hm = O.mask_init(out, h, case['bpm'], gain, sat, ys, xs)
     out /= case['flat']
     L.detect_cosmics(out, mask != 0, 15, 0.01, 3, 3, h['RDNOISE'])
-    dt = time.perf_counter() - t0
-    frac = (2 * ys * 8 * xs) / 111513600.0
-    return dict(value=frac / dt, unit='frames/s', cores=1, kind='port',
-                sample='oracle (numpy/scipy) on a 1320x2640 px sub-frame (1/%.0f of a frame) in %.1f s, scaled by area'
-                       % (1 / frac, dt))
+    t1 = time.perf_counter()
+    t_bkg = t_zogy = 0.0
+    if with_zogy:
+        med, std = Z.get_back_mini(out, mask, None, box=60)
+        med, std = Z.fill_filter_mini(med), Z.fill_filter_mini(std)
+        Z.mini2back(med, out.shape, 60)
+        Z.mini2back(std, out.shape, 60)
+        t2 = time.perf_counter()
+        rs = np.random.RandomState(seed)
+        Ls = 1400
+        img = rs.normal(0, 20, (Ls, Ls)).astype('float32')
+        psf = np.zeros((Ls, Ls), 'float32'); st = moffat_stamp(25, 4.0)
+        for j in range(25):
+            for i in range(25):
+                psf[(j - 12) % Ls, (i - 12) % Ls] = st[j, i]
+        V = np.full((Ls, Ls), 400.0, 'float32')
+        Z.run_zogy(img, img[::-1].copy(), psf, psf, 20.0, 10.0, 1.0, 1.0, V, V, 0.03, 0.03)
+        t3 = time.perf_counter()
+        t_bkg, t_zogy = t2 - t1, t3 - t2
+    return (t1 - t0, t_bkg, t_zogy)
+
+
+def cpu_baseline(workload):
+    """the CPU restatement (oracle: numpy / scipy, kind "port") timed on the host cores of this
+    box the way the reference farms frames (blackbox.py:363-379: one process per frame, each
+    single-threaded): N_proc = min(cores, RAM / 6 GB) workers run the same bounded sample
+    concurrently; frames/s = N_proc / (per-frame seconds extrapolated from the sample by area)."""
+    import multiprocessing as mp
+    from blackbox_amd.pipeline import cpu_budget
+    cores = cpu_budget()
+    try:
+        ram_gb = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES') / 2 ** 30
+    except (ValueError, OSError):
+        ram_gb = 64.0
+    nproc = int(max(1, min(cores, ram_gb // 6)))
+    with_zogy = workload == 'zogy'
+    frac = (2 * 660 * 8 * 330) / 111513600.0
+
+    def frame_seconds(t):
+        # reduction and mesh scale with the area; ZOGY with the 64 sub-images; the mesh runs on both frames
+        return t[0] / frac + (2 * t[1] / frac if workload != 'calib' else 0.0) + (64 * t[2] if with_zogy else 0.0)
+    t1 = _cpu_sample((0, with_zogy))
+    with mp.get_context('spawn').Pool(nproc) as pool:
+        ts = pool.map(_cpu_sample, [(k, with_zogy) for k in range(nproc)])
+    per_frame_all = float(np.mean([frame_seconds(t) for t in ts]))
+    return dict(value=nproc / per_frame_all, unit='frames/s', cores=nproc, kind='port',
+                one_core_frames_per_s=1.0 / frame_seconds(t1),
+                sample='oracle (numpy/scipy) per worker: reduction%s on a 1320x2640 px sub-frame (1/%.0f of a frame, scaled by '
+                       'area)%s; %d single-threaded worker processes at once (cpu budget %d cores, %.0f GB RAM); mean '
+                       'seconds per part %s' % (' + background mesh' if workload != 'calib' else '', 1 / frac,
+                                                ' + run_zogy on one 1400^2 sub-image (x64)' if with_zogy else '', nproc, cores,
+                                                ram_gb, [round(float(np.mean([t[i] for t in ts])), 2) for i in range(3)]),
+                reference_own_code_anchor='SURVEY.md section 6 / BASELINE.md section 2: the reference\'s own gain+os_corr+flat+'
+                                          'mask_init+xtalk+mask_header+edge fill take ~50 s per frame on one process '
+                                          '(no LA-Cosmic, no ZOGY: packages absent)')
+
+
+def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None):
+    """W + K frames through a FramePipeline; -> dict(dt timed region, dt_all, stats of the pipeline)"""
+    from blackbox_amd import _lib
+    from blackbox_amd.pipeline import FramePipeline
+    pipe = FramePipeline(ctx, tel, geom, pool=pool, depth=depth, lanes=lanes, **kw)
+    # untimed: first-use allocations, rocFFT plans, workspace growth of every lane
+    pipe.run([(raws[i % len(raws)], {}) for i in range(max(lanes, 2))])
+    pipe.t_stats = [0.0, 0.0, 0.0, 0]
+    mark = {}
+    n_all = warmup + steps
+
+    def on_done(idx, f):
+        mark.setdefault('n', 0)
+        mark['n'] += 1
+        if mark['n'] == warmup:
+            mark['t0'] = time.perf_counter()
+            if prof_ctx is not None:
+                _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
+        mark['last'] = f
+    barrier()
+    t_all0 = time.perf_counter()
+    if warmup == 0:
+        mark['t0'] = t_all0
+        if prof_ctx is not None:
+            _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
+    pipe.run([(raws[i % len(raws)], {}) for i in range(n_all)], on_done=on_done)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    out = dict(dt=t1 - mark['t0'], dt_all=t1 - t_all0, t_stats=list(pipe.t_stats), last=mark.get('last'), nworkers=pipe.pool.n)
+    pipe.close()
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child
+    launcher (fresh processes; nothing in this process has touched the GPU) and pass its exit code on"""
+    import subprocess
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=240)
-    ap.add_argument('--warmup', type=int, default=12)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='zogy', choices=['zogy', 'full', 'calib'],
+                    help='zogy: reduce + ZOGY + photometry (headline, configs[4] per frame); full: configs[2]; calib: configs[1]')
     ap.add_argument('--raw', default='u16', choices=['u16', 'f32'])
     ap.add_argument('--small', action='store_true', help='reduced geometry (debug)')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--depth', type=int, default=18, help='frames in flight')
+    ap.add_argument('--no-extras', action='store_true', help='skip the other workloads and the I/O-inclusive figures')
+    ap.add_argument('--depth', type=int, default=None, help='frames in flight')
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
-    ap.add_argument('--lanes', type=int, default=6, help='stage-C lanes (context + stream + issuing thread) per GPU')
+    ap.add_argument('--lanes', type=int, default=None, help='stage-C lanes (context + stream + issuing thread) per GPU')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     from blackbox_amd import reduce as R
-    from blackbox_amd import settings
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -162,155 +321,244 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
+    # the fit workers are started before this process makes its first GPU call
+    from blackbox_amd.pipeline import HostPool
+    pool = HostPool(args.workers)
     ctx = R.Context(local)
     dev = ctx.device
     if args.small:
         ysz, xsz, os_y, os_x = 660, 330, 20, 45
+        size, border, box = 330, 20, 30
     else:
         ysz, xsz, os_y, os_x = 5280, 1320, 20, 180
-    raw, flat, bpm = synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, 1000 * 2 + rank, args.raw)
+        size, border, box = 1320, 40, 60
+    wl = args.workload
+    lanes = args.lanes or {'zogy': 3, 'full': 6, 'calib': 6}[wl]
+    depth = args.depth or {'zogy': 8, 'full': 18, 'calib': 18}[wl]
+    seed = 1000 * 4 + rank
+    raw, flat, bpm, ex = synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, args.raw, extras=True, ntrans=50)
+    ref, ref_mask = synth_reference(torch, dev, ex.pop('scene0'), seed)
     geom = R.geometry(raw.shape, ysz, xsz)
     tel = 'ML1'
     N = 2 * ysz * 8 * xsz
-    nraw = raw.numel()
+    # distinct raw buffers for the frames in flight (same scene, fresh read noise): the working set
+    # of consecutive frames must not sit in the 256 MB Infinity Cache
+    nbuf = max(depth, 4)
+    g = torch.Generator(device=dev); g.manual_seed(seed + 1)
+    raws = [raw]
+    for _ in range(nbuf - 1):
+        r = (raw.to(torch.float32) + 2.0 * torch.randn(raw.shape, device=dev, generator=g)).round().clamp(0, 65535)
+        raws.append(r.to(torch.int32).to(torch.uint16).contiguous() if args.raw == 'u16' else r.contiguous())
+    rs = np.random.RandomState(0)
+    coeffs = np.zeros((16, 16)); coeffs[~np.eye(16, dtype=bool)] = rs.uniform(0, 2e-4, 240)
+    S = 25
+    psf_n = torch.from_numpy(moffat_stamp(S, 4.0)).to(dev)
+    psf_r = torch.from_numpy(moffat_stamp(S, 4.0)).to(dev)
+    sub_kw = dict(ref=ref, ref_mask=ref_mask, psf_new=psf_n, psf_ref=psf_r, fratio=1.0, dx=0.03, dy=0.03, ref_is_bkgsub=False,
+                  cat_extract=True, trans_extract=True, subimage_size=size, subimage_border=border, bkg_boxsize=box)
+    base_kw = dict(mflat=flat, bpm=bpm)
+    kws = {
+        'calib': dict(base_kw),
+        'full': dict(base_kw, xtalk_coeffs=coeffs, do_finish=True, detect_sats=True,
+                     subtract=dict(psf_new=None, psf_ref=None, ref=None, ref_mask=None, trans_extract=False,
+                                   subimage_size=size, subimage_border=border, bkg_boxsize=box)),
+        'zogy': dict(base_kw, xtalk_coeffs=coeffs, do_finish=True, detect_sats=True, subtract=sub_kw),
+    }
 
     import ctypes as C
     from blackbox_amd import _lib
-    from blackbox_amd.pipeline import FramePipeline, HostPool
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ---- serial reference run of one frame (stage breakdown, not the timed region) -----------
+    # ---- serial reference run of one frame (stage breakdown + isolated kernel timings; untimed) --
+    from blackbox_amd import zogy as G
     stage_ms = {}
 
-    def frame_serial():
+    def frame_serial(with_sub):
         header, hm = {}, {}
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         ev[0].record()
         R.gain_corr(header, tel)
         sol = R.os_solve(ctx, raw, header, tel, geom)
         ev[1].record()
         data, mask = R.calibrate(ctx, raw, sol, header, hm, tel, geom, mflat=flat, bpm=bpm)
         ev[2].record()
-        d_nobj = R.mask_init_finish(ctx, mask, header, hm, geom)
+        R.mask_init_finish(ctx, mask, header, hm, geom)
         ev[3].record()
         st = R.cosmics_corr(ctx, data, header, mask, hm, tel)
         ev[4].record()
+        R.xtalk_corr(ctx, data, coeffs, mask, geom)
+        R.sat_detect(ctx, data, header, mask, hm)
+        R.mask_header(ctx, mask, hm)
+        R.edge_fill(ctx, data, mask, geom)
+        ev[5].record()
+        res = None
+        if with_sub:
+            res = G.optimal_subtraction(ctx, data, new_mask=mask, **sub_kw)
+        ev[6].record()
         ctx.sync()
-        return ev, st
+        return ev, st, res
 
-    frame_serial()
-    # kernels alone on the GPU (no second lane, no other frame in flight): isolated timings of
-    # the two dense kernels, reported next to the live ones of the timed region
+    frame_serial(wl == 'zogy')
     _lib.check(_lib.lib.bbx_profile_enable(ctx.h, 1), 'bbx_profile_enable')
-    for _ in range(10):
-        frame_serial()
+    nser = 3
+    for _ in range(nser):
+        frame_serial(wl == 'zogy')
     iso_ms = (C.c_double * 8)()
     iso_calls = (C.c_int32 * 8)()
     _lib.check(_lib.lib.bbx_profile_read(ctx.h, iso_ms, iso_calls, 8), 'bbx_profile_read', ctx.h)
     _lib.check(_lib.lib.bbx_profile_enable(ctx.h, 0), 'bbx_profile_enable')
     t0 = time.perf_counter()
-    ev, st = frame_serial()
+    ev, st, res = frame_serial(wl == 'zogy')
     latency_ms = 1e3 * (time.perf_counter() - t0)
-    for i, n in enumerate(['overscan(stats+host fits)', 'calibrate', 'mask_finish', 'lacosmic']):
+    for i, n in enumerate(['overscan(stats+host fits)', 'calibrate', 'mask_finish', 'lacosmic', 'xtalk+sat+counts+edge_fill',
+                           'optimal_subtraction']):
         stage_ms[n] = ev[i].elapsed_time(ev[i + 1])
     stats = st.cpu().numpy().tolist()
+    sub_info = None
+    if res is not None:
+        sub_info = dict(ntransients=len(res['transients']), ncatalog=int(len(res['catalog']['X_POS'])) if res['catalog'] else 0,
+                        scorr_median=res['header_trans']['Z-SCMED'][0], scorr_std=res['header_trans']['Z-SCSTD'][0],
+                        injected=len(ex['transients']))
+    del res
+    torch.cuda.empty_cache()
 
-    # ---- timed region: K frames through the pipelined path -------------------------------------
-    pool = HostPool(args.workers)
-    pipe = FramePipeline(ctx, tel, geom, mflat=flat, bpm=bpm, pool=pool, depth=args.depth, lanes=args.lanes)
-    pipe.run([(raw, {}) for _ in range(max(args.warmup, 1))])
-    pipe.t_stats = [0.0, 0.0, 0.0, 0]
-    check = _lib.check
-    check(_lib.lib.bbx_profile_enable(ctx.h, 1), 'bbx_profile_enable')
-    barrier()
-    t0 = time.perf_counter()
-    pipe.run([(raw, {}) for _ in range(args.steps)])
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---- timed region ----------------------------------------------------------------------------
+    r = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], args.steps, args.warmup, depth, lanes, pool, barrier, prof_ctx=ctx)
+    dt, dt_all = r['dt'], r['dt_all']
     nsl = 8
     ms_tot = (C.c_double * nsl)()
     calls = (C.c_int32 * nsl)()
-    check(_lib.lib.bbx_profile_read(ctx.h, ms_tot, calls, nsl), 'bbx_profile_read', ctx.h)
-    check(_lib.lib.bbx_profile_enable(ctx.h, 0), 'bbx_profile_enable')
-    pipe.close()
-    pool.close()
+    _lib.check(_lib.lib.bbx_profile_read(ctx.h, ms_tot, calls, nsl), 'bbx_profile_read', ctx.h)
+    _lib.check(_lib.lib.bbx_profile_enable(ctx.h, 0), 'bbx_profile_enable')
     if world > 1:
-        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        t = torch.tensor([dt, dt_all], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_all = float(t[0].item()), float(t[1].item())
 
+    out = None
     if rank == 0:
         b_raw = 2 if args.raw == 'u16' else 4
-        # algorithmic bytes per launch: calibration reads the raw data sections, flat,
-        # BPM and writes data + mask; the dense LA-Cosmic pass reads the frame and the mask once
-        # (iterations 2..n work on the surroundings of the cleaned pixels only)
+        L = size + 2 * border
+        nsub = (2 * ysz // size) * (8 * xsz // size)
+        # algorithmic bytes per launch
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
-            # the one dense LA-Cosmic pass reads the frame (the mask plane too only while the
-            # background-level feed is on, i.e. after a frame needed the level: not in this workload)
             'k_lac_cand': (1, 4 * N),
+            # ZOGY: I/O-only model -- 4 input images read with the tile overlap (L/size)^2, 4 output images written
+            'zogy_subimages': (6, int(4 * 4 * nsub * L * L + 4 * 4 * N)),
         }
-        # Kernel durations: HIP events recorded by the library around each launch, on the launch
-        # stream (lane 0's context carries the timers, so one frame in [lanes] is sampled).  The
-        # roofline uses the event pairs of the timed region: the kernel shares the GPU with the
-        # other lanes' kernels there, and the rocprofv3 --kernel-trace average of this command
-        # shows the same duration.  `isolated` gives the same kernels from the serial frames run
-        # in this process just before the timed region (one stream, nothing else in flight):
-        # that is the kernel's own efficiency, the timed-region figure its share of a busy GPU.
-        iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items()}
-        live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items()}
-        dom = max(live, key=lambda k: live[k][0])          # both run once per frame
-        avg_ms, by, ncall = live[dom]
+        iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items() if iso_calls[sl]}
+        live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items() if calls[sl]}
+        dom = max(live, key=lambda k: live[k][0])          # each runs once per frame
 
         def gbs(t):
             return t[1] / (t[0] * 1e-3) / 1e9
         roof = dict(bound='hbm', kernel=dom, achieved=gbs(live[dom]), peak=HBM_PEAK_GBS, unit='GB/s',
-                    avg_launch_ms=avg_ms, launches=int(ncall), bytes_per_launch=by, traffic=None,
+                    avg_launch_ms=live[dom][0], launches=int(live[dom][2]), bytes_per_launch=live[dom][1], traffic=None,
                     others={k: dict(avg_launch_ms=live[k][0], achieved=gbs(live[k]), frac=gbs(live[k]) / HBM_PEAK_GBS)
                             for k in live if k != dom})
         roof['frac'] = roof['achieved'] / roof['peak']
-        roof['timing'] = ('HIP events around each launch on the launch stream, timed region, lane 0 of %d '
-                          '(other lanes\' kernels run concurrently)' % args.lanes)
+        roof['timing'] = ('HIP events around each launch (group) on the launch stream, timed region, lane 0 of %d '
+                          '(other lanes\' kernels run concurrently)' % lanes)
         roof['isolated'] = {k: dict(avg_launch_ms=iso[k][0], launches=int(iso[k][2]), achieved=gbs(iso[k]),
-                                    frac=gbs(iso[k]) / HBM_PEAK_GBS,
-                                    note='serial frames, kernel alone on the GPU') for k in iso}
-        # HBM traffic per launch from the committed rocprofv3 --pmc passes of this command
-        # (profiles/r01_pmc_traffic.json: FETCH_SIZE/WRITE_SIZE, gfx950 correction applied)
+                                    frac=gbs(iso[k]) / HBM_PEAK_GBS, note='serial frames, kernel alone on the GPU') for k in iso}
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
-            if not args.small and args.raw == 'u16':
-                if dom == 'k_calibrate':
-                    roof['traffic'] = next(v for k, v in pmc.items() if k.startswith('k_calibrate_v4'))['traffic_bytes_per_launch']
-                else:
-                    roof['traffic'] = pmc['k_lac_cand_v4<true>']['traffic_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))['kernels']
+            if not args.small and args.raw == 'u16' and dom in pmc:
+                roof['traffic'] = pmc[dom]['traffic_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r02_pmc_traffic.json'
         except Exception:
             pass
-        out = dict(metric='10560x10560 fp32 frames/sec end-to-end reduce (calibration + LA-Cosmic)',
+        shape = '%dx%d raw (%s)' % (raw.shape[0], raw.shape[1], args.raw)
+        names = {'zogy': 'configs[4] per frame on one GPU: one %s -> reduce (gain+overscan+flat+mask+LA-Cosmic(niter=3)+xtalk+'
+                         'sat trail+counts+edge fill) + optimal_subtraction vs a co-added reference (bkg mesh x2, variance, %d '
+                         'sub-images of %d^2 ZOGY, D/Scorr/Fpsf/Fpsferr, transients, PSF-photometry catalogue), ML1'
+                         % (shape, nsub, L),
+                 'full': 'configs[2]: one %s -> full calibration + LA-Cosmic + xtalk + sat trail + counts + edge fill + '
+                         'background mesh and subtraction, ML1' % shape,
+                 'calib': 'configs[1]: one %s -> gain+overscan+flat+mask_init+LA-Cosmic(niter=3), ML1' % shape}
+        out = dict(metric='10560x10560 fp32 frames/sec end-to-end reduce+ZOGY; % HBM roofline' if wl == 'zogy' else
+                   '10560x10560 fp32 frames/sec end-to-end reduce (%s)' % wl,
                    value=args.steps * world / dt, unit='frames/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload='configs[1]: one %dx%d raw (%s) -> %dx%d frame, gain+overscan+flat+mask_init+LA-Cosmic(niter=3), ML1'
-                               % (raw.shape[0], raw.shape[1], args.raw, 2 * ysz, 8 * xsz),
-                               frames_per_gpu=args.steps, frames_in_flight=args.depth, stageC_lanes=args.lanes, host_fit_workers=pool.n,
-                               parallelism='frame-per-gpu x%d (no collective)' % world),
+                   config=dict(workload=names[wl],
+                               frames_per_gpu=args.steps, frames_in_flight=depth, stageC_lanes=lanes, host_fit_workers=r['nworkers'],
+                               distinct_raw_buffers=nbuf, parallelism='frame-per-gpu x%d (no collective)' % world),
+                   timing='clock from the completion of warm-up frame %d (pipeline full) to device idle after the last of the %d '
+                          'timed frames' % (args.warmup, args.steps),
+                   fill_inclusive=dict(frames=args.warmup + args.steps, frames_per_s=(args.warmup + args.steps) * world / dt_all,
+                                       note='all frames incl. the pipeline fill from an idle device'),
                    pipeline_wall_ms_per_frame=dict(zip(['stageA_stats', 'stageB_host_fits', 'stageC_device'],
-                                                       [1e3 * t / max(1, pipe.t_stats[3]) for t in pipe.t_stats[:3]])),
-                   single_frame_latency_ms=latency_ms, stage_ms_serial=stage_ms, lacosmic_stats=stats,
-                   device_ms_per_frame_serial={'k_calibrate': iso_ms[0] / max(1, iso_calls[0]),
-                                               'k_lac_cand': iso_ms[1] / max(1, iso_calls[1]),
-                                               'lac_sparse(x3)': 3 * iso_ms[2] / max(1, iso_calls[2])},
+                                                       [1e3 * t / max(1, r['t_stats'][3]) for t in r['t_stats'][:3]])),
+                   single_frame_latency_ms=latency_ms, stage_ms_serial=stage_ms, lacosmic_stats=stats, subtraction=sub_info,
                    roofline=roof)
+    # ---- the other workloads, briefly, and the I/O-inclusive figures (not part of `value`) ---------
+    if world == 1 and not args.no_extras:
+        others = {}
+        for w2 in ('calib', 'full'):
+            if w2 == wl:
+                continue
+            l2, d2 = (6, 18)
+            r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 18, d2, l2, pool, barrier)
+            others[w2] = dict(frames_per_s=60 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 60, frames_in_flight=d2, lanes=l2)
+        out['other_workloads'] = others
+        out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
+    pool.close()
+    if rank == 0:
         if not args.no_cpu:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(wl)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def io_inclusive(torch, ctx, raw, N, ms_compute, wl):
+    """SURVEY 8d timing items (ii) and (iii) as bounds from measured parts: PCIe copies of what a
+    frame moves (pinned memory, H2D and D2H on their own streams) and, with the products
+    tile-compressed on the device (bbx_fpack_tiles), the compressed bytes instead"""
+    from blackbox_amd import fpack as P
+    dev = ctx.device
+    nprod = 5 if wl == 'zogy' else 1                            # float32 images leaving: red (+ D, Scorr, Fpsf, Fpsferr)
+    h_raw = torch.empty(raw.shape, dtype=raw.dtype, pin_memory=True)
+    h_img = torch.empty(N, dtype=torch.float32, pin_memory=True)
+    h_msk = torch.empty(N, dtype=torch.uint8, pin_memory=True)
+    d_img = torch.randn(N, device=dev)
+    d_msk = torch.zeros(N, dtype=torch.uint8, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        with torch.cuda.stream(s1):
+            raw.copy_(h_raw, non_blocking=True)
+        with torch.cuda.stream(s2):
+            for _ in range(nprod):
+                h_img.copy_(d_img, non_blocking=True)
+            h_msk.copy_(d_msk, non_blocking=True)
+    torch.cuda.synchronize()
+    ms_pcie = 1e3 * (time.perf_counter() - t0) / reps
+    out = dict(pcie_ms_per_frame=ms_pcie, bytes_h2d=raw.numel() * raw.element_size(), bytes_d2h=nprod * 4 * N + N,
+               frames_per_s_pcie_bound=1e3 / max(ms_pcie, ms_compute),
+               note='raw H2D + products D2H through pinned memory on two streams, overlapped with compute: '
+                    'rate = 1 / max(compute, copies)')
+    try:
+        img = (250 + 20 * torch.randn(int(np.sqrt(N)), int(np.sqrt(N)), device=dev)).contiguous()
+        P.compress_tiles(ctx, img, 16, 1, _view=True); ctx.sync()
+        t0 = time.perf_counter()
+        cd = P.compress_tiles(ctx, img, 16, 1, _view=True); ctx.sync()
+        ms_fp = 1e3 * (time.perf_counter() - t0)
+        out['with_fpack'] = dict(ms_per_float_image_incl_D2H=ms_fp, compressed_MB=cd['heap'].size / 1e6,
+                                 frames_per_s_bound=1e3 / max(ms_compute, nprod * ms_fp, ms_pcie * (raw.numel() * raw.element_size()) /
+                                                              (raw.numel() * raw.element_size() + nprod * 4 * N + N)),
+                                 note='products quantised (q=16) + Rice-compressed on the device, only the streams cross PCIe')
+    except Exception as e:                                         # the figure is informative only
+        out['with_fpack'] = dict(error=str(e))
+    return out
 
 
 if __name__ == '__main__':

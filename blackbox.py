@@ -1,13 +1,20 @@
 #!/usr/bin/env python
 """blackbox.py -- per-file entry point of the MI355X reduction, same command line as the
-reference's `python blackbox.py --telescope T --img_reduce True ... --image FILE`
-(blackbox.py:8128-8213, blackbox_slurm_google.py:305-309).
+reference's `python blackbox.py --telescope T --img_reduce True --cat_extract True
+--trans_extract True --force_reproc_new True --image FILE` (blackbox.py:8128-8213,
+blackbox_slurm_google.py:305-309).
 
-FITS in -> `{tel}_{yyyymmdd}_{hhmmss}_red.fits` (float32, e-) + `..._mask.fits` (uint8) out.
-Flags of the reference that concern orchestration (night mode, dates, master creation,
-catalogues) are accepted and ignored with a warning: only the per-image reduction hot
-path lives here.  With WORLD_SIZE > 1 (torch.distributed.run) every rank takes every
-world-th file of --image_list on its own GPU.
+FITS in -> `{tel}_{yyyymmdd}_{hhmmss}_red.fits` (float32, e-), `..._mask.fits` (uint8),
+`..._red_hdr.fits`, `..._red.log`; with --cat_extract / --trans_extract the products of
+zogy.optimal_subtraction that the hot path covers (set_blackbox.py:157-164): `_red_bkg_mini`,
+`_red_bkg_std_mini`, `_red_cat` (+ `_red_cat_hdr`), `_red_D`, `_red_Scorr`, `_red_Fpsf`,
+`_red_trans` (+ `_red_trans_hdr`).  The reference image, its mask and the PSFs are explicit
+inputs (--ref, --ref_mask, --psf_new, --psf_ref), like the masters (--mflat, --mbias, --bpm):
+their selection / creation (reference building, PSFEx, astrometry) is orchestration.
+Flags of the reference that concern orchestration only (night mode, dates, master creation)
+are accepted and ignored with a warning.  With WORLD_SIZE > 1 (torch.distributed.run) every
+rank takes every world-th file of --image_list on its own GPU; an --image_list of object
+frames runs through the frames-in-flight pipeline (blackbox_amd.pipeline.FramePipeline).
 """
 import argparse
 import logging
@@ -43,8 +50,16 @@ def outname(header, tel, red_dir):
     return os.path.join(red_dir, '{}_{}_{}_red.fits'.format(tel, d, t))
 
 
+def _base(p):
+    return os.path.basename(p) if p else 'None'
+
+
+def _stem(p):
+    return os.path.basename(p).split('.fits')[0] if p else 'None'
+
+
 class Reducer:
-    """per-process state: GPU context + masters resident in HBM"""
+    """per-process state: GPU context + masters / reference / PSFs resident in HBM"""
 
     def __init__(self, tel, args):
         import torch
@@ -53,20 +68,88 @@ class Reducer:
         _, _, local = __import__('blackbox_amd.farm', fromlist=['rank_world']).rank_world()
         self.ctx = R.Context(local)
         self.tel = tel
+        self.args = args
         dev = self.ctx.device
 
-        def load(path, dtype):
+        def load(path, dtype, what):
+            """a master that cannot be read is not applied: <X>-P False (blackbox.py:1674-1699, 1820-1846)"""
             if not path:
                 return None
-            return torch.from_numpy(np.ascontiguousarray(fitsio.read_image(path, dtype=dtype))).to(dev)
-        self.mflat = load(args.mflat, np.float32)
-        self.mbias = load(args.mbias, np.float32)
-        self.bpm = load(args.bpm, np.uint8)
+            try:
+                return torch.from_numpy(np.ascontiguousarray(fitsio.read_image(path, dtype=dtype))).to(dev)
+            except Exception:
+                log.exception('exception was raised while reading the %s %s', what, path)
+                return None
+        self.mflat = load(args.mflat, np.float32, 'master flat')
+        self.mbias = load(args.mbias, np.float32, 'master bias')
+        self.bpm = load(args.bpm, np.uint8, 'bad pixel mask')
         if self.bpm is not None and bool((self.bpm & 12).any()):
             raise ValueError('bad-pixel mask carries saturated(4)/saturated-connected(8) bits; expected 1 and 32 only')
-        self.xtalk = R.read_crosstalk(args.crosstalk) if args.crosstalk else None
-        self.args = args
+        self.xtalk = None
+        if args.crosstalk:
+            try:
+                self.xtalk = R.read_crosstalk(args.crosstalk)
+            except Exception:
+                log.exception('exception was raised while reading the crosstalk file %s', args.crosstalk)
+        self.nonlin = None
+        if args.nonlin:
+            try:
+                self.nonlin = R.read_nonlin_splines(args.nonlin)
+            except Exception:
+                log.exception('exception was raised while reading the non-linearity splines %s', args.nonlin)
+        # inputs of the subtraction stage
+        self.sub = None
+        if args.cat_extract or args.trans_extract:
+            self.sub = self._load_subtraction_inputs(load)
 
+    def _load_psf(self, path):
+        """PSF input: a PSFEx .psf table (model evaluated on the GPU) or a FITS image / cube of
+        unit-sum stamps ([S, S] or [nsub, S, S])"""
+        if not path:
+            return None
+        torch, fitsio = self.torch, self.fitsio
+        try:
+            if path.endswith('.psf') or path.endswith('_psf.fits'):
+                m = fitsio.read_psfex(path)
+                if m['psf_samp'] != 1.0:
+                    log.warning('PSF_SAMP %.3f != 1: the model is used on its own sampling grid', m['psf_samp'])
+                m['basis'] = torch.from_numpy(np.ascontiguousarray(m['basis'])).to(self.ctx.device)
+                return m
+            st = np.ascontiguousarray(fitsio.read_image(path, dtype=np.float32))
+            st = st / st.sum(axis=(-2, -1), keepdims=True)
+            return torch.from_numpy(st).to(self.ctx.device)
+        except Exception:
+            log.exception('exception was raised while reading the PSF %s', path)
+            return None
+
+    def _load_subtraction_inputs(self, load):
+        a = self.args
+        sub = dict(psf_new=self._load_psf(a.psf_new), psf_ref=None, ref=None, ref_mask=None,
+                   cat_extract=bool(a.cat_extract), trans_extract=bool(a.trans_extract),
+                   fratio=a.fratio, dx=a.zogy_dx, dy=a.zogy_dy, ref_is_bkgsub=bool(a.ref_bkgsub))
+        if a.subimage_size:
+            sub['subimage_size'] = a.subimage_size
+        if a.subimage_border is not None:
+            sub['subimage_border'] = a.subimage_border
+        if a.bkg_boxsize:
+            sub['bkg_boxsize'] = a.bkg_boxsize
+        if a.trans_extract and a.ref:
+            sub['ref'] = load(a.ref, np.float32, 'reference image')
+            sub['ref_mask'] = load(a.ref_mask, np.uint8, 'reference mask') if a.ref_mask else None
+            if sub['ref'] is not None and sub['ref_mask'] is None:
+                sub['ref_mask'] = self.torch.zeros(sub['ref'].shape, dtype=self.torch.uint8, device=self.ctx.device)
+            sub['psf_ref'] = self._load_psf(a.psf_ref)
+            if a.ref_bkg_std_mini:
+                sub['ref_bkg_std_mini'] = self.fitsio.read_image(a.ref_bkg_std_mini, dtype=np.float32)
+            if sub['ref'] is None or sub['psf_ref'] is None or sub['psf_new'] is None:
+                log.error('reference image or PSFs missing: processing the new image only')
+                sub['ref'] = None
+        elif a.trans_extract:
+            log.info('no reference image given: processing the new image only, without comparison to a reference '
+                     '(blackbox.py:2338-2354)')
+        return sub
+
+    # ------------------------------------------------------------------------------------
     def try_blackbox_reduce(self, filename):
         """blackbox.py:948-999: returns the reduced file name or None; never raises"""
         try:
@@ -75,10 +158,9 @@ class Reducer:
             log.exception('exception was raised during [blackbox_reduce] of %s', filename)
             return None
 
-    def blackbox_reduce(self, filename):
+    def read_raw(self, filename):
+        """-> (raw device tensor, header dict)"""
         R, torch, fitsio = self.R, self.torch, self.fitsio
-        t0 = time.time()
-        d_raw = None
         if filename.endswith('.fz'):
             # fpacked raw frame (the reference's usual input): the compressed bytes go to the GPU
             # and are decoded there
@@ -90,75 +172,242 @@ class Reducer:
             raw, hraw = fitsio.read_image(filename, get_header=True)
             if raw.dtype not in (np.uint16, np.float32):
                 raw = raw.astype(np.float32)
+            d_raw = torch.from_numpy(np.ascontiguousarray(raw)).to(self.ctx.device)
         header = dict(hraw)
         for k in ('BZERO', 'BSCALE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'SIMPLE', 'EXTEND'):
             header.pop(k, None)
-        red_dir = self.args.red_dir or os.path.dirname(os.path.abspath(filename))
+        return d_raw, header
+
+    def names(self, header):
+        red_dir = self.args.red_dir or '.'
         fits_out = outname(header, self.tel, red_dir)
-        if os.path.isfile(fits_out) and os.path.isfile(fits_out.replace('_red', '_mask')) \
-                and not (self.args.img_reduce and self.args.force_reproc_new):
+        return red_dir, fits_out
+
+    def already_done(self, fits_out):
+        return os.path.isfile(fits_out) and os.path.isfile(fits_out.replace('_red', '_mask')) \
+            and not (self.args.img_reduce and self.args.force_reproc_new)
+
+    def blackbox_reduce(self, filename):
+        R = self.R
+        t0 = time.time()
+        d_raw, header = self.read_raw(filename)
+        if not self.args.red_dir:
+            self.args.red_dir = os.path.dirname(os.path.abspath(filename))
+        red_dir, fits_out = self.names(header)
+        if self.already_done(fits_out):
             log.info('%s already reduced; skipping', filename)           # blackbox.py:1336-1390
             return fits_out
-        if d_raw is None:
-            d_raw = torch.from_numpy(np.ascontiguousarray(raw)).to(self.ctx.device)
-        exptime = R.hval(header, 'EXPTIME') if 'EXPTIME' in header else 1.0
-        imgtype = str(R.hval(header, 'IMAGETYP')).lower() if 'IMAGETYP' in header else 'object'
-        if imgtype == 'flat':
-            # flat frames (blackbox.py:1826-1850): overscan, master bias, mask; no flat division,
-            # cosmics, crosstalk or trails; header statistics from get_flatstats
-            from blackbox_amd import flatstats
-            data, mask, header, hm = R.reduce_object(
-                self.ctx, d_raw, header, self.tel, mflat=None, mbias=self.mbias, bpm=self.bpm, exptime=exptime,
-                ysize_chan=self.args.ysize_chan, xsize_chan=self.args.xsize_chan, do_cosmics=False, detect_sats=False)
-            flatstats.get_flatstats(self.ctx, data, header, mask, self.tel, ysize_chan=self.args.ysize_chan,
-                                    xsize_chan=self.args.xsize_chan)
-        else:
+        os.makedirs(red_dir, exist_ok=True)
+        fh = self.open_image_log(fits_out)
+        try:
+            exptime = R.hval(header, 'EXPTIME') if 'EXPTIME' in header else 1.0
+            imgtype = str(R.hval(header, 'IMAGETYP')).lower() if 'IMAGETYP' in header else 'object'
             data, mask, header, hm = R.reduce_object(
                 self.ctx, d_raw, header, self.tel, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
                 xtalk_coeffs=self.xtalk, exptime=exptime, ysize_chan=self.args.ysize_chan,
-                xsize_chan=self.args.xsize_chan)
+                xsize_chan=self.args.xsize_chan, nonlin_splines=self.nonlin, imgtype=imgtype, log=log)
+            if imgtype != 'object':
+                return self.finish_calibration_frame(data, mask, header, imgtype, fits_out)
+            return self.finish_object(filename, data, mask, header, hm, fits_out, t0)
+        finally:
+            self.close_image_log(fh)
+
+    # ---- per-image log (blackbox.py:1311-1318: {base}_red.log next to the product) ----------
+    def open_image_log(self, fits_out):
+        try:
+            fh = logging.FileHandler(fits_out.replace('.fits', '.log'), mode='w')
+            fh.setFormatter(logging.Formatter('%(asctime)s [%(levelname)s, %(process)s] %(message)s'))
+            log.addHandler(fh)
+            return fh
+        except OSError:
+            return None
+
+    def close_image_log(self, fh):
+        if fh is not None:
+            log.removeHandler(fh)
+            fh.close()
+
+    # ---- bias / dark / flat frames -------------------------------------------------------------
+    def finish_calibration_frame(self, data, mask, header, imgtype, fits_out):
+        """blackbox.py:1627-1637 (bias), 1764-1784 (flat): statistics, QC flags, write the frame
+        (no mask product)"""
+        R, fitsio = self.R, self.fitsio
+        from blackbox_amd import qc
         header['BUNIT'] = ('e-', 'pixel values are in electrons')
-        # bookkeeping keywords of the header contract (blackbox.py:1110-1112, 1520, 1607, 1669-1690,
-        # 1817-1855; verify_header 2893-3255)
+        if imgtype == 'flat' and R.hval(header, 'OS-P'):
+            from blackbox_amd import flatstats
+            flatstats.get_flatstats(self.ctx, data, header, mask, self.tel, ysize_chan=self.args.ysize_chan,
+                                    xsize_chan=self.args.xsize_chan)
+        self.bookkeeping(header, time.time())
+        qc.run_qc_check(header, self.tel)
+        fits_out = fits_out.replace('_red.fits', '.fits')       # calibration frames keep their plain name
+        fitsio.write_image(fits_out, data.cpu().numpy(), header)
+        return fits_out
+
+    def bookkeeping(self, header, t0):
+        """bookkeeping keywords of the header contract (blackbox.py:1110-1112, 1520, 1607, 1669-1690,
+        1817-1855; verify_header 2893-3255)"""
+        R = self.R
         from blackbox_amd import __version__ as bbx_version
-        base = lambda p: os.path.basename(p) if p else 'None'                  # noqa: E731
-        stem = lambda p: os.path.basename(p).split('.fits')[0] if p else 'None'  # noqa: E731
+        a = self.args
         header['BB-V'] = ('amd-' + bbx_version, 'BlackBOX version used')
         header['KW-V'] = (KEYWORDS_VERSION, 'header keywords version used')
         header['BB-START'] = (time.strftime('%Y-%m-%dT%H:%M:%S', time.gmtime(t0)), 'start UTC date of BlackBOX image run')
-        header['XTALK-F'] = (base(self.args.crosstalk), 'name crosstalk coefficients file')
-        header['NONLIN-F'] = ('None', 'name non-linearity correction file')
-        header['MBIAS-F'] = (stem(self.args.mbias) if R.hval(header, 'MBIAS-P') else 'None', 'name of master bias applied')
-        header['MFLAT-F'] = (stem(self.args.mflat) if R.hval(header, 'MFLAT-P') else 'None', 'name of master flat applied')
+        header['XTALK-F'] = (_base(a.crosstalk), 'name crosstalk coefficients file')
+        header['NONLIN-F'] = (_base(a.nonlin) if R.hval(header, 'NONLIN-P') else 'None', 'name non-linearity correction file')
+        header['MBIAS-F'] = (_stem(a.mbias) if header.get('MBIAS-P') and R.hval(header, 'MBIAS-P') else 'None',
+                             'name of master bias applied')
+        header['MFLAT-F'] = (_stem(a.mflat) if header.get('MFLAT-P') and R.hval(header, 'MFLAT-P') else 'None',
+                             'name of master flat applied')
         for k, c in (('XTALK-P', 'corrected for crosstalk?'), ('COSMIC-P', 'corrected for cosmic rays?'),
-                     ('SAT-P', 'processed for satellite trails?')):
+                     ('SAT-P', 'processed for satellite trails?'), ('MBIAS-P', 'corrected for master bias?'),
+                     ('MFLAT-P', 'corrected for master flat?'), ('MASK-P', 'mask image created?')):
             header.setdefault(k, (False, c))                                     # steps that did not run
         header.setdefault('NCOSMICS', ('None', '[/s] number of cosmic rays identified'))
         header.setdefault('NSATS', ('None', 'number of satellite trails identified'))
         header['MFRING-P'] = (False, 'corrected for master fringe map?')
         header['MFRING-F'] = ('None', 'name of master fringe map applied')
         header['FRRATIO'] = ('None', 'fringe ratio (science/fringe map) applied')
-        # QC flags on the reduction keywords (blackbox.py:2000; qc.py)
+
+    # ---- object frames -------------------------------------------------------------------------
+    def finish_object(self, filename, data, mask, header, hm, fits_out, t0, sub_result=None):
+        R, fitsio = self.R, self.fitsio
         from blackbox_amd import qc
-        qc_flag = qc.run_qc_check(header, self.tel, check_key_type='full')      # flags go into the image header
-        if qc_flag == 'red':
-            log.error('red QC flag for %s', filename)
+        header['BUNIT'] = ('e-', 'pixel values are in electrons')
+        self.bookkeeping(header, t0)
         redfile = os.path.basename(fits_out).split('.fits')[0]
         header['REDFILE'] = (redfile, 'BlackBOX reduced image name')
         header['MASKFILE'] = (redfile.replace('_red', '_mask'), 'BlackBOX mask image name')
+        # QC flags on the reduction keywords (blackbox.py:2000; qc.py)
+        qc_flag = qc.run_qc_check(header, self.tel, check_key_type='full')      # flags go into the image header
         qc.verify_header(header, ['full'], name=fits_out)                     # blackbox.py:2062 (raises on a DB keyword)
-        os.makedirs(red_dir, exist_ok=True)
+        base = fits_out.replace('.fits', '')
+        if qc_flag == 'red':
+            # red flag: dummy catalogues, no subtraction (blackbox.py:2015-2046)
+            log.error('red QC flag in image %s; making dummy catalogs and returning', fits_out)
+            written = self.write_image(fits_out, data, header)
+            self.write_image(fits_out.replace('_red', '_mask'), mask, hm)
+            fitsio.write_header(base + '_hdr.fits', header)
+            if self.sub is not None:
+                qc.run_qc_check(header, self.tel, cat_type='new', cat_dummy=base + '_cat.fits', check_key_type='full')
+                htrans = dict(header)
+                qc.run_qc_check(htrans, self.tel, cat_type='trans', cat_dummy=base + '_trans.fits', check_key_type='trans')
+            return written
+        if self.sub is not None:
+            self.subtract_and_write(data, mask, header, base, sub_result)
+        written = self.write_image(fits_out, data, header)
+        self.write_image(fits_out.replace('_red', '_mask'), mask, hm)
+        fitsio.write_header(base + '_hdr.fits', header)                       # update_imcathead(create_hdrfile=True), 2011
+        log.info('reduced %s -> %s in %.2f s', filename, written, time.time() - t0)
+        return written
+
+    def write_image(self, path, img, header):
         if self.args.fpack:
             # products leave the GPU tile-compressed (reference: fpack of the files kept,
             # copy_files2keep 4033-4035): only the compressed bytes cross PCIe
             from blackbox_amd import fpack as P
-            fits_out = P.fpack_image(self.ctx, fits_out, data, header)
-            P.fpack_image(self.ctx, fits_out.replace('_red', '_mask'), mask, hm)
-        else:
-            fitsio.write_image(fits_out, data.cpu().numpy(), header)
-            fitsio.write_image(fits_out.replace('_red', '_mask'), mask.cpu().numpy(), hm)
-        log.info('reduced %s -> %s in %.2f s', filename, fits_out, time.time() - t0)
-        return fits_out
+            if self.torch.is_tensor(img):
+                P.fpack_image(self.ctx, path, img, header)
+                return path + '.fz'
+        self.fitsio.write_image(path, img.cpu().numpy() if self.torch.is_tensor(img) else img, header)
+        return path
+
+    def subtract_and_write(self, data, mask, header, base, res=None):
+        """zogy.optimal_subtraction + the products it leaves (set_blackbox.py:157-164); a failure
+        keeps the reduction products (blackbox.py:2364-2382)"""
+        from blackbox_amd import zogy as G, qc
+        fitsio = self.fitsio
+        try:
+            if res is None:
+                kw = {k: v for k, v in self.sub.items() if k not in ('ref', 'ref_mask', 'psf_new', 'psf_ref')}
+                res = G.optimal_subtraction(self.ctx, data, self.sub['ref'], mask, self.sub['ref_mask'],
+                                            self.sub['psf_new'], self.sub['psf_ref'], **kw)
+                self.ctx.sync()
+        except Exception:
+            log.exception('exception was raised during [optimal_subtraction]; saving just the image reduction products')
+            header['Z-P'] = (False, 'successfully processed by ZOGY?')
+            return
+        hnew, htrans = res['header_new'], res['header_trans']
+        header.update(hnew)
+        bkg_hdr = {'BKG-SIZE': hnew['BKG-SIZE']}
+        fitsio.write_image(base + '_bkg_mini.fits', res['bkg_mini_new'], bkg_hdr)
+        fitsio.write_image(base + '_bkg_std_mini.fits', res['bkg_std_mini_new'], bkg_hdr)
+        qc_flag = qc.run_qc_check(header, self.tel, check_key_type='full')
+        if res.get('catalog') is not None:
+            if qc_flag == 'red':
+                qc.run_qc_check(header, self.tel, cat_type='new', cat_dummy=base + '_cat.fits', check_key_type='full')
+            else:
+                G.format_cat(res['catalog'], base + '_cat.fits', cat_type='new', header2add=header)
+            fitsio.write_header(base + '_cat_hdr.fits', header)
+        if res.get('D') is not None:
+            full_t = dict(header)
+            full_t.update(htrans)
+            tqc = qc.run_qc_check(full_t, self.tel, check_key_type='trans')
+            for ext in ('D', 'Scorr', 'Fpsf'):
+                self.write_image('{}_{}.fits'.format(base, ext), res[ext], full_t)
+            if tqc == 'red' or qc_flag == 'red':
+                qc.run_qc_check(full_t, self.tel, cat_type='trans', cat_dummy=base + '_trans.fits', check_key_type='trans')
+            else:
+                G.format_cat(G.transient_table(res['transients']), base + '_trans.fits', cat_type='trans', header2add=full_t)
+            fitsio.write_header(base + '_trans_hdr.fits', full_t)
+
+    # ---- many object frames: frames-in-flight pipeline ------------------------------------------
+    def reduce_list(self, files):
+        """object frames of one geometry through FramePipeline (several frames in flight on this
+        GPU); anything else goes through blackbox_reduce one by one.  -> list of output names"""
+        R, torch = self.R, self.torch
+        from blackbox_amd.pipeline import FramePipeline
+        out = {}
+        todo = []
+        for fn in files:
+            try:
+                d_raw, header = self.read_raw(fn)
+                imgtype = str(R.hval(header, 'IMAGETYP')).lower() if 'IMAGETYP' in header else 'object'
+                if not self.args.red_dir:
+                    self.args.red_dir = os.path.dirname(os.path.abspath(fn))
+                _, fits_out = self.names(header)
+                if imgtype != 'object' or self.nonlin is not None:
+                    out[fn] = self.try_blackbox_reduce(fn)
+                elif self.already_done(fits_out):
+                    out[fn] = fits_out
+                else:
+                    todo.append((fn, d_raw, header, fits_out))
+            except Exception:
+                log.exception('exception was raised while reading %s', fn)
+                out[fn] = None
+        if todo:
+            shapes = {tuple(t[1].shape) for t in todo}
+            if len(shapes) > 1:
+                raise ValueError('frames of different shapes in one --image_list: {}'.format(sorted(shapes)))
+            geom = R.geometry(todo[0][1].shape, self.args.ysize_chan, self.args.xsize_chan)
+            exptime = R.hval(todo[0][2], 'EXPTIME') if 'EXPTIME' in todo[0][2] else 1.0
+            sub = None
+            if self.sub is not None:
+                sub = dict(self.sub)
+            pipe = FramePipeline(self.ctx, self.tel, geom, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
+                                 xtalk_coeffs=self.xtalk, exptime=exptime, depth=max(2, min(8, len(todo))), lanes=2,
+                                 do_finish=True, detect_sats=True, keep_outputs=True, subtract=sub, log=log)
+            os.makedirs(self.args.red_dir, exist_ok=True)
+            t0 = time.time()
+
+            def on_done(idx, f):
+                fn, _, header, fits_out = todo[idx]
+                try:
+                    # the pipeline works with one exposure time; NCOSMICS follows the frame's own
+                    et = R.hval(header, 'EXPTIME') if 'EXPTIME' in header else 1.0
+                    if et != exptime and not isinstance(R.hval(header, 'NCOSMICS'), str):
+                        header['NCOSMICS'] = (R.hval(header, 'NCOSMICS') * float(exptime) / float(et), header['NCOSMICS'][1])
+                    if 'zogy' in f.failed:
+                        header['Z-P'] = (False, 'successfully processed by ZOGY?')
+                    out[fn] = self.finish_object(fn, f.data, f.mask, header, f.hm, fits_out, t0, sub_result=f.sub)
+                except Exception:
+                    log.exception('exception was raised during [blackbox_reduce] of %s', fn)
+                    out[fn] = None
+            try:
+                pipe.run([(t[1], t[2]) for t in todo], on_done=on_done)
+            finally:
+                pipe.close()
+        return [out.get(fn) for fn in files]
 
 
 def main(argv=None):
@@ -186,9 +435,23 @@ def main(argv=None):
     ap.add_argument('--mbias', type=str, default=None)
     ap.add_argument('--bpm', type=str, default=None)
     ap.add_argument('--crosstalk', type=str, default=None)
+    ap.add_argument('--nonlin', type=str, default=None, help='pickle of 16 scipy splines (set_bb.nonlin_corr_file)')
     ap.add_argument('--red_dir', type=str, default=None)
     ap.add_argument('--ysize_chan', type=int, default=None)
     ap.add_argument('--xsize_chan', type=int, default=None)
+    # explicit inputs of zogy.optimal_subtraction (reference selection / PSFEx are orchestration)
+    ap.add_argument('--ref', type=str, default=None, help='reference image on the new frame\'s pixel grid (_red.fits)')
+    ap.add_argument('--ref_mask', type=str, default=None)
+    ap.add_argument('--ref_bkg_std_mini', type=str, default=None, help='the reference\'s _bkg_std_mini.fits')
+    ap.add_argument('--ref_bkgsub', type=str2bool, default=False, help='reference is background-subtracted (BKG-SUB)')
+    ap.add_argument('--psf_new', type=str, default=None, help='PSFEx .psf model or FITS stamp / cube of the new image')
+    ap.add_argument('--psf_ref', type=str, default=None)
+    ap.add_argument('--fratio', type=float, default=1.0, help='flux ratio new / ref (Z-FNR)')
+    ap.add_argument('--zogy_dx', type=float, default=0.0, help='[pix] astrometric scatter in x (Z-DXSTD)')
+    ap.add_argument('--zogy_dy', type=float, default=0.0)
+    ap.add_argument('--subimage_size', type=int, default=None)
+    ap.add_argument('--subimage_border', type=int, default=None)
+    ap.add_argument('--bkg_boxsize', type=int, default=None)
     args = ap.parse_args(argv)
     logging.basicConfig(level='INFO', format='%(asctime)s [%(levelname)s, %(process)s] %(message)s')
     for flag in ('date', 'read_path', 'imgtypes', 'filters', 'master_date', 'name_genlog'):
@@ -196,8 +459,6 @@ def main(argv=None):
             log.warning('--%s concerns orchestration and is ignored by the hot-path build', flag)
     if args.mode != 'day':
         log.warning('night mode (watchdog) is out of scope; running the given files once')
-    if args.cat_extract or args.trans_extract:
-        log.warning('catalogue / transient extraction (ZOGY) is not part of this round; reduction only')
     files = []
     if args.image:
         files.append(args.image)
@@ -214,7 +475,14 @@ def main(argv=None):
     from blackbox_amd import farm
     mine = farm.shard(files)
     red = Reducer(tel, args)
-    out = [red.try_blackbox_reduce(f) for f in mine]
+    if args.image_list and len(mine) > 1:
+        try:
+            out = red.reduce_list(mine)
+        except Exception:
+            log.exception('pipelined run failed; reducing the files one by one')
+            out = [red.try_blackbox_reduce(f) for f in mine]
+    else:
+        out = [red.try_blackbox_reduce(f) for f in mine]
     for o in out:
         print(o)
     return out

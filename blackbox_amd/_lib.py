@@ -45,6 +45,7 @@ SIGNATURES = {
     'bbx_version': (_i, []),
     'bbx_sync': (_i, [_vp, _vp]),
     'bbx_set_option': (_i, [_vp, _i, _i]),
+    'bbx_step_mark': (_i, [_vp, _vp, _vp]),
     'bbx_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'bbx_event_destroy': (None, [_vp]),
     'bbx_event_record': (_i, [_vp, _vp]),

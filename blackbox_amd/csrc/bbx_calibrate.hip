@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
     const double os0 = a.oscan[c * d.xsz + x], os1 = a.oscan[c * d.xsz + x + 1],
                  os2 = a.oscan[c * d.xsz + x + 2], os3 = a.oscan[c * d.xsz + x + 3];
     const float g = a.gain.v[c], sat = a.sat.v[c];
+    unsigned satbits = 0;                                        // bit 4*k + q: pixel q of row k is saturated
 #pragma unroll
     for (int k = 0; k < CAL_ROWS; k++) {
         const int Y = Y0 + k;
@@ -146,16 +147,34 @@ __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
             if (NONLIN) v = nl_apply(a.nonlin, c, v, g);
             if (a.bias) v = v - bi[q];
             if (!isfinite(v)) { v = 0.f; if (m[q] == 0) m[q] |= BBX_MASK_BAD; }
-            if (v >= sat) {
-                m[q] |= BBX_MASK_SAT;
-                const unsigned kk = atomicAdd((unsigned*)&a.counters[CNT_SAT], 1u);
-                if (kk < a.satcap) a.satlist[kk] = (uint32_t)(o + q); else atomicOr(a.err, BBX_DERR_LIST_OVERFLOW);
-            }
+            if (v >= sat) { m[q] |= BBX_MASK_SAT; satbits |= 1u << (4 * k + q); }
             if (a.flat) v = v / fl[q];
             ov[q] = v;
         }
         *(float4*)(a.data + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
         *(uchar4*)(a.mask + o) = make_uchar4(m[0], m[1], m[2], m[3]);
+    }
+    // saturated-pixel queue: one reservation per wave for all the rows of the block (a returning
+    // atomic per pixel on one counter retires at ~11 ns each: a frame with 1 % saturated pixels
+    // would spend 12 ms there).  Waves without a saturated pixel -- nearly all -- skip this.
+    if (__builtin_amdgcn_ballot_w64(satbits != 0u) != 0ull) {
+        const int lane = threadIdx.x & 63;
+        const unsigned cnt = (unsigned)__popc(satbits);
+        unsigned incl = cnt;                                     // inclusive prefix sum over the wave
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const unsigned t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
+        const unsigned total = __shfl(incl, 63, 64);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd((unsigned*)&a.counters[CNT_SAT], total);
+        base = __shfl(base, 0, 64) + incl - cnt;
+        if (base + cnt > a.satcap) { if (cnt) atomicOr(a.err, BBX_DERR_LIST_OVERFLOW); }
+        else {
+            unsigned b = satbits;
+            while (b) {
+                const int bit = __ffs(b) - 1; b &= b - 1;
+                a.satlist[base++] = (uint32_t)((size_t)(Y0 + (bit >> 2)) * d.nx + X + (bit & 3));
+            }
+        }
     }
 }
 
@@ -188,11 +207,13 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)a.d.ny * a.d.nx;
     if (npix >= 0xffffffffull) return BBX_ERR_ARG;
-    // saturated-pixel queue: worst case every pixel
-    if (!ctx->d_satlist || ctx->cap_satlist < (int64_t)npix) {
+    // saturated-pixel queue: an eighth of the frame (a frame with more saturated pixels than that
+    // raises the overflow flag -> MASK-P False; the consumers clamp to the capacity)
+    const int64_t satcap = (int64_t)(npix / 8 + 4096);
+    if (!ctx->d_satlist || ctx->cap_satlist < satcap) {
         if (ctx->d_satlist) { BBX_HIP(hipDeviceSynchronize()); BBX_HIP(hipFree(ctx->d_satlist)); ctx->d_satlist = nullptr; }
-        BBX_HIP(hipMalloc((void**)&ctx->d_satlist, npix * sizeof(uint32_t)));
-        ctx->cap_satlist = (int64_t)npix;
+        BBX_HIP(hipMalloc((void**)&ctx->d_satlist, (size_t)satcap * sizeof(uint32_t)));
+        ctx->cap_satlist = satcap;
     }
     a.nonlin = ctx->nonlin_on ? (const nonlin_tab*)ctx->d_nonlin : nullptr;
     a.raw = d_raw; a.vfit = d_vfit; a.oscan = d_oscan; a.bias = d_bias; a.flat = d_flat; a.bpm = d_bpm;

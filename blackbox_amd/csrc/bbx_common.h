@@ -58,9 +58,13 @@ struct bbx_ctx {
     void*  d_ws[24];
     size_t ws_bytes[24];
     int    lac_feed;           // BBX_OPT_LAC_LEVEL_FEED (bbx_set_option)
+    int    debug_listcap;      // BBX_OPT_DEBUG_LISTCAP: capacity the LA-Cosmic kernels see (0 = the allocated one)
+    void*  zogy_state;         // per-context FFT plans / work buffer of bbx_zogy.hip (NULL until first use)
     int    num_cus;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     // --- optional per-kernel timing (bbx_profile_enable): hipEvent pairs on the launch stream
     int prof_on, prof_n;
+    volatile int prof_gen;     // bumped by bbx_profile_enable / _read
+    int prof_open, prof_open_gen, prof_open_idx;
     hipEvent_t* prof_ev;       // [2 * BBX_PROF_MAX]
     int* prof_slot;            // [BBX_PROF_MAX]
 };
@@ -94,6 +98,7 @@ enum {
 };
 
 int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line);
+void bbx_zogy_release(bbx_ctx* ctx);      // bbx_zogy.hip: frees ctx->zogy_state (called by bbx_ctx_destroy)
 void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc);
 
 // small per-channel parameter vectors travel as by-value kernel arguments

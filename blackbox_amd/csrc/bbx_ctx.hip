@@ -27,13 +27,22 @@ void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc) {
     return ctx->d_ws[slot];
 }
 
+// bbx_profile_enable may be called by another thread than the one launching on this context (a
+// bench switches the timers on at the start of its timed region): a pair is kept only if no
+// enable / read came between its start and its stop (generation counter)
 void bbx_prof_start(bbx_ctx* ctx, int slot, hipStream_t s) {
+    ctx->prof_open = 0;
     if (!ctx->prof_on || ctx->prof_n >= BBX_PROF_MAX) return;
-    ctx->prof_slot[ctx->prof_n] = slot;
-    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], s);
+    const int n = ctx->prof_n;
+    ctx->prof_open_gen = ctx->prof_gen;
+    ctx->prof_slot[n] = slot;
+    (void)hipEventRecord(ctx->prof_ev[2 * n], s);
+    ctx->prof_open = 1; ctx->prof_open_idx = n;
 }
 void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s) {
-    if (!ctx->prof_on || ctx->prof_n >= BBX_PROF_MAX) return;
+    if (!ctx->prof_open) return;
+    ctx->prof_open = 0;
+    if (!ctx->prof_on || ctx->prof_open_gen != ctx->prof_gen || ctx->prof_open_idx != ctx->prof_n) return;
     (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], s);
     ctx->prof_n++;
 }
@@ -50,8 +59,10 @@ int bbx_profile_enable(bbx_ctx* ctx, int on) {
         if (!ctx->prof_ev || !ctx->prof_slot) return BBX_ERR_NOMEM;
         for (int i = 0; i < 2 * BBX_PROF_MAX; i++) BBX_HIP(hipEventCreate(&ctx->prof_ev[i]));
     }
-    ctx->prof_on = on ? 1 : 0;
+    ctx->prof_on = 0;
+    ctx->prof_gen++;
     ctx->prof_n = 0;
+    ctx->prof_on = on ? 1 : 0;
     return BBX_OK;
 }
 
@@ -65,6 +76,7 @@ int bbx_profile_read(bbx_ctx* ctx, double* ms_total, int32_t* calls, int nslots)
         const int sl = ctx->prof_slot[k];
         if (sl >= 0 && sl < nslots) { ms_total[sl] += ms; calls[sl]++; }
     }
+    ctx->prof_gen++;
     ctx->prof_n = 0;
     return BBX_OK;
 }
@@ -109,6 +121,7 @@ void bbx_ctx_destroy(bbx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    bbx_zogy_release(ctx);
     for (int i = 0; i < WS_MAX; i++) if (ctx->d_ws[i]) (void)hipFree(ctx->d_ws[i]);
     if (ctx->d_satlist) (void)hipFree(ctx->d_satlist);
     if (ctx->d_nonlin) (void)hipFree(ctx->d_nonlin);
@@ -131,9 +144,20 @@ int bbx_sync(bbx_ctx* ctx, void* stream) {
     return BBX_OK;
 }
 
+// *slot = device error flags accumulated since the last mark; flags <- 0 (one thread)
+__global__ void k_step_mark(int32_t* err, int32_t* slot) { *slot = err[0]; err[0] = 0; }
+
+int bbx_step_mark(bbx_ctx* ctx, int32_t* d_slot, void* stream) {
+    if (!ctx || !d_slot) return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_step_mark, dim3(1), dim3(1), 0, (hipStream_t)stream, ctx->d_err, d_slot);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
 int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (!ctx) return BBX_ERR_ARG;
     if (option == BBX_OPT_LAC_LEVEL_FEED) { ctx->lac_feed = value ? 1 : 0; return BBX_OK; }
+    if (option == BBX_OPT_DEBUG_LISTCAP) { ctx->debug_listcap = value > 0 ? value : 0; return BBX_OK; }
     return BBX_ERR_ARG;
 }
 

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) void k_lac_compact(const uint8_t* __restrict__
     before = (unsigned)wave_sum_i32((int)before); all = (unsigned)wave_sum_i32((int)all);
     if (lane == 0) { red[0][wid] = before; red[1][wid] = all; }
     const int t = t0 + tid;
-    const unsigned mine = (t < t1) ? tile_cnt[t] : 0u;
+    // a count above the segment size can only come from a producer bug: never index past the segment
+    unsigned mine = (t < t1) ? tile_cnt[t] : 0u;
+    if (mine > (unsigned)CAND_TILECAP) { mine = CAND_TILECAP; atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
     unsigned ltot;
     const unsigned excl = block_excl_scan256(mine, wsum, &ltot);         // contains the barriers for red[]
     const unsigned base = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -543,8 +545,9 @@ __global__ __launch_bounds__(256) void k_lac_cand_sparse(const float* __restrict
 // wave-per-candidate stage.  One thread per candidate; survivors are appended wave by wave.
 __global__ __launch_bounds__(256) void k_lac_prefilter(const float* __restrict__ a, const uint8_t* __restrict__ mask, lac_par p,
                                                        const uint32_t* __restrict__ raw, int32_t* counters, uint32_t cap,
-                                                       uint32_t* __restrict__ cand) {
+                                                       uint32_t* __restrict__ cand, int32_t* err) {
     const uint32_t n = min((uint32_t)counters[CNT_CANDRAW], cap);
+    const uint32_t npix = (uint32_t)p.ny * (uint32_t)p.nx;
     const uint32_t nround = ((n + 63u) / 64u) * 64u;
     const int lane = threadIdx.x & 63;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += gridDim.x * blockDim.x) {
@@ -552,7 +555,10 @@ __global__ __launch_bounds__(256) void k_lac_prefilter(const float* __restrict__
         uint32_t o = 0;
         if (k < n) {
             o = raw[k];
-            if (good_px(mask, o)) {
+            // every later consumer dereferences the indices this kernel lets through: an index off
+            // the frame (a producer bug) becomes an error code here, never a device fault
+            if (o >= npix) atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+            else if (good_px(mask, o)) {
                 const int j = (int)(o / p.nx), i = (int)(o - (uint32_t)j * p.nx);
                 float noise;
                 keep = s_at(a, j, i, p, &noise) > p.sigclip;
@@ -844,110 +850,109 @@ __global__ __launch_bounds__(256) void k_lac_bg(float* a, const uint8_t* __restr
 // k_lac_clean get the level, selected exactly over the good pixels of the frame -- those the run
 // has flagged and cleaned so far are taken with their input values from orig[] (saved by
 // k_lac_grow2).  lvl[0] = level, lvl[1] = known? (zeroed by k_lac_begin).
-// Launched after every k_lac_clean with one workgroup per compute unit; they return at once unless pixels are
-// listed (the usual frame).  When the level has to be produced, the workgroups run the three
-// digit passes of a radix select together: LDS histograms added to a global one, a grid barrier
-// (the workgroups -- one per compute unit, at most BGF_WGS -- are all resident; the spin is bounded), every workgroup scans
-// the global histogram itself.  ~0.6 ms instead of the ~1 s of a single workgroup.
+// Three digit passes of a radix select (11 + 11 + 10 bits of the order-preserving key), each its
+// own launch: k_lac_bgf_hist<ps> adds the LDS histogram of every workgroup to ghist[ps]; the
+// kernel boundary is the grid-wide synchronisation (no assumption about which workgroups are
+// resident together); the next launch's workgroups each re-derive the prefix and rank from the
+// finished histograms.  k_lac_bgf_final resolves the last digit and fills the listed pixels.
+// All four return at once unless pixels are listed (the usual frame).
 #define BGF_WGS 256
-__device__ __forceinline__ bool bgf_barrier(unsigned* bar, unsigned target, int32_t* err) {
+struct bgf_sh {
+    unsigned long long part[256];
+    unsigned long long rank;
+    uint32_t prefix;
+    int empty;
+};
+// prefix / rank after the first [nps] digits, from the global histograms (workgroup-uniform result)
+__device__ __forceinline__ void bgf_resolve(const uint32_t* __restrict__ ghist, int nps, bgf_sh& sh, uint32_t& himask) {
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh.prefix = 0; sh.rank = 0; sh.empty = 0; }
+    himask = 0;
     __syncthreads();
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(bar, 1u);
-        int good = 0;
-        for (unsigned spin = 0; spin < (1u << 21); spin++) {       // ~2 s at most
-            if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
+    for (int ps = 0; ps < nps; ps++) {
+        const uint32_t* gh = ghist + ps * 2048;
+        const uint32_t pre = sh.prefix, dmask = (1u << nbits[ps]) - 1u;
+        const int shift = shifts[ps];
+        unsigned long long part = 0;
+        uint32_t mine[8];
+        for (int k = 0; k < 8; k++) { mine[k] = gh[tid * 8 + k]; part += mine[k]; }
+        sh.part[tid] = part;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long total = 0;
+            for (int t = 0; t < 256; t++) total += sh.part[t];
+            if (ps == 0) { if (total == 0) sh.empty = 1; else sh.rank = (total - 1) / 2; }
+            unsigned long long r = sh.rank, acc = 0;
+            int t = 0;
+            while (t < 255 && acc + sh.part[t] <= r) { acc += sh.part[t]; t++; }
+            sh.part[0] = acc;                                // counts below group t
+            sh.prefix = (uint32_t)t;                         // group index, replaced below
         }
-        if (!good) atomicOr(err, BBX_DERR_NOTCONV);
-        __threadfence();
-        ok = good;
+        __syncthreads();
+        if (sh.empty) return;
+        const int grp = (int)sh.prefix;
+        const unsigned long long below = sh.part[0];
+        __syncthreads();
+        if (tid == grp) {
+            unsigned long long acc = below;
+            int k = 0;
+            while (k < 7 && acc + mine[k] <= sh.rank) { acc += mine[k]; k++; }
+            sh.rank = sh.rank - acc;
+            sh.prefix = pre | ((uint32_t)(grp * 8 + k) << shift);
+        }
+        __syncthreads();
+        himask |= dmask << shift;
     }
-    __syncthreads();
-    return ok != 0;
 }
 
-__global__ __launch_bounds__(256) void k_lac_bg_frame(float* a, const uint8_t* __restrict__ mask, lac_par p,
-                                                      int32_t* counters, const uint32_t* __restrict__ bglist, uint32_t capbg,
-                                                      const float* __restrict__ orig, uint32_t caporig, float* lvl,
-                                                      int32_t* __restrict__ stats, uint32_t* ghist, unsigned* gbar, int32_t* err) {
+__global__ __launch_bounds__(256) void k_lac_bgf_hist(const float* __restrict__ a, const uint8_t* __restrict__ mask, lac_par p,
+                                                      const int32_t* __restrict__ counters, uint32_t capbg,
+                                                      const float* __restrict__ orig, uint32_t caporig,
+                                                      const float* __restrict__ lvl, uint32_t* ghist, int ps) {
     __shared__ uint32_t lh[2048];
-    __shared__ unsigned long long s_part[256];
-    __shared__ uint32_t s_prefix;
-    __shared__ unsigned long long s_rank;
-    __shared__ int s_empty;
+    __shared__ bgf_sh sh;
+    const uint32_t n = min((uint32_t)counters[CNT_BGNEED], capbg);
+    if (n == 0 || lvl[1] != 0.f) return;                       // nothing listed, or level known (grid-uniform)
+    const int tid = threadIdx.x;
+    uint32_t himask;
+    bgf_resolve(ghist, ps, sh, himask);
+    if (sh.empty) return;
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    const uint32_t pre = sh.prefix, dmask = (1u << nbits[ps]) - 1u;
+    const int shift = shifts[ps];
+    for (int i = tid; i < 2048; i += 256) lh[i] = 0;
+    __syncthreads();
+    const size_t npix = (size_t)p.ny * p.nx;
+    const uint32_t norig = min((uint32_t)counters[CNT_CRLIST], caporig);
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < npix; i += (size_t)gridDim.x * 256) {
+        if (mask[i]) continue;                                  // masked, or flagged (and cleaned) by this run
+        const uint32_t key = f2key(a[i]);
+        if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+    }
+    for (uint32_t i = blockIdx.x * 256 + tid; i < norig; i += gridDim.x * 256) {
+        const uint32_t key = f2key(orig[i]);
+        if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    uint32_t* gh = ghist + ps * 2048;
+    for (int i = tid; i < 2048; i += 256) if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+__global__ __launch_bounds__(256) void k_lac_bgf_final(float* a, lac_par p, int32_t* counters,
+                                                       const uint32_t* __restrict__ bglist, uint32_t capbg, float* lvl,
+                                                       int32_t* __restrict__ stats, uint32_t* ghist) {
+    __shared__ bgf_sh sh;
     const uint32_t n = min((uint32_t)counters[CNT_BGNEED], capbg);
     if (n == 0) return;
     const int tid = threadIdx.x;
-    float bg = 0.f;
-    if (lvl[1] != 0.f) {                                        // level known from an earlier iteration (grid-uniform)
-        if (blockIdx.x != 0) return;
-        bg = lvl[0];
-    } else {
-        const size_t npix = (size_t)p.ny * p.nx;
-        const uint32_t norig = min((uint32_t)counters[CNT_CRLIST], caporig);
-        unsigned phase = 0;
-        if (blockIdx.x == 0) for (int i = tid; i < 3 * 2048; i += 256) ghist[i] = 0;
-        if (!bgf_barrier(gbar, ++phase * gridDim.x, err)) return;
-        if (tid == 0) { s_prefix = 0; s_rank = 0; s_empty = 0; }
-        const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
-        uint32_t himask = 0;
-        for (int ps = 0; ps < 3; ps++) {
-            for (int i = tid; i < 2048; i += 256) lh[i] = 0;
-            __syncthreads();
-            const uint32_t pre = s_prefix, dmask = (1u << nbits[ps]) - 1u;
-            const int shift = shifts[ps];
-            for (size_t i = (size_t)blockIdx.x * 256 + tid; i < npix; i += (size_t)gridDim.x * 256) {
-                if (mask[i]) continue;                          // masked, or flagged (and cleaned) by this run
-                const uint32_t key = f2key(a[i]);
-                if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
-            }
-            for (uint32_t i = blockIdx.x * 256 + tid; i < norig; i += gridDim.x * 256) {
-                const uint32_t key = f2key(orig[i]);
-                if ((key & himask) == pre) atomicAdd(&lh[(key >> shift) & dmask], 1u);
-            }
-            __syncthreads();
-            uint32_t* gh = ghist + ps * 2048;
-            for (int i = tid; i < 2048; i += 256) if (lh[i]) atomicAdd(&gh[i], lh[i]);
-            if (!bgf_barrier(gbar, ++phase * gridDim.x, err)) return;
-            // every workgroup finds the bin of the wanted rank in the global histogram
-            unsigned long long part = 0;
-            uint32_t mine[8];
-            for (int k = 0; k < 8; k++) { mine[k] = __hip_atomic_load(&gh[tid * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); part += mine[k]; }
-            s_part[tid] = part;
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long total = 0;
-                for (int t = 0; t < 256; t++) total += s_part[t];
-                if (ps == 0) { if (total == 0) s_empty = 1; else s_rank = (total - 1) / 2; }
-                unsigned long long r = s_rank, acc = 0;
-                int t = 0;
-                while (t < 255 && acc + s_part[t] <= r) { acc += s_part[t]; t++; }
-                s_part[0] = acc;                                 // counts below group t
-                s_prefix = (uint32_t)t;                          // (group index, replaced below)
-            }
-            __syncthreads();
-            if (s_empty) break;
-            const int grp = (int)s_prefix;
-            const unsigned long long below = s_part[0];
-            __syncthreads();
-            if (tid == grp) {
-                unsigned long long acc = below;
-                int k = 0;
-                while (k < 7 && acc + mine[k] <= s_rank) { acc += mine[k]; k++; }
-                s_rank = s_rank - acc;
-                s_prefix = pre | ((uint32_t)(grp * 8 + k) << shift);
-            }
-            __syncthreads();
-            himask |= dmask << shift;
-        }
-        __syncthreads();
-        bg = s_empty ? 0.f : key2f(s_prefix);
-        if (blockIdx.x != 0) return;
+    float bg;
+    if (lvl[1] != 0.f) bg = lvl[0];                             // level known from an earlier iteration
+    else {
+        uint32_t himask;
+        bgf_resolve(ghist, 3, sh, himask);
+        bg = sh.empty ? 0.f : key2f(sh.prefix);                 // no good pixel at all: level 0
     }
-    // workgroup 0: the listed pixels, the record, the counter
     for (uint32_t k = tid; k < n; k += blockDim.x) a[bglist[k]] = bg;
     __syncthreads();
     if (tid == 0) { lvl[0] = bg; lvl[1] = 1.f; counters[CNT_BGNEED] = 0; stats[15] = 1; }
@@ -985,7 +990,7 @@ __global__ __launch_bounds__(256) void k_lac_unflag(lac_par p, const uint32_t* _
 __global__ void k_lac_begin(int32_t* counters, int32_t* stats, uint8_t* tile_cnt_pad, float readnoise,
                             const double* __restrict__ rdn16, float sigclip, float* out, unsigned* gbar) {
     const int t = threadIdx.x;
-    if (t == 0 && gbar) *gbar = 0;                               // grid-barrier counter of k_lac_bg_frame
+    if (gbar) for (int i = t; i < 3 * 2048; i += blockDim.x) gbar[i] = 0;   // digit histograms of k_lac_bgf_hist
     if (t < 16) stats[t] = 0;
     if (t < 16 && tile_cnt_pad) tile_cnt_pad[t] = 0;         // k_lac_compact reads the counts sixteen at a time
     if (t != 0) return;
@@ -1024,6 +1029,8 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     float* rnp = (float*)bbx_ws(ctx, WS_MISC, 64, &rc); if (rc) return rc;
     p.rnp = rnp;
     const size_t cap = (npix / 4 + 4096) & ~(size_t)63;
+    // BBX_OPT_DEBUG_LISTCAP: the kernels see a smaller capacity than what is allocated (tests of the overflow path)
+    const size_t capk = (ctx->debug_listcap > 0 && (size_t)ctx->debug_listcap < cap) ? (size_t)ctx->debug_listcap : cap;
     const bool vec = (nx % 4 == 0) && (((uintptr_t)d_data) % 16 == 0);
     const int nwx = (nx + CAND_SPAN - 1) / CAND_SPAN;             // waves along x
     const size_t ntiles = (size_t)nwx * ((ny + CAND_ROWS - 1) / CAND_ROWS), capovf = cap / 4 + 4096;
@@ -1053,14 +1060,14 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
         ghist = (uint32_t*)(w + caporig * sizeof(float));
     }
     hipLaunchKernelGGL(k_lac_begin, dim3(1), dim3(64), 0, s, cnt, d_stats, tile_cnt + ntiles, readnoise, d_rdn16, sigclip, rnp,
-                       ghist ? (unsigned*)(ghist + 3 * 2048) : nullptr);
+                       (unsigned*)ghist);
     // the flag plane is kept all-zero between calls (k_lac_unflag); zero it when it is new
     if (ctx->flags_clean_ptr != flags || ctx->flags_clean_bytes < npix) BBX_HIP(hipMemsetAsync(flags, 0, npix, s));
     ctx->flags_clean_ptr = nullptr;
     // background level of the unmasked input pixels (needed when a CR pixel has no good
     // neighbour): bracketed select fed by the first candidate pass, no extra read of the frame
     const unsigned gdense = 256u * 16u, gsparse = 256u * 8u;
-    // workgroups of the cooperative level select: one per compute unit (they must all be resident)
+    // workgroups of the level select's digit passes
     const unsigned bgf_wgs = (unsigned)std::min(BGF_WGS, std::max(8, ctx->num_cus));
     for (int it = 0; it < niter; it++) {
         if (it == 0) {
@@ -1068,33 +1075,37 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
             bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
             if (vec && feed) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
             else if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
-            else if (feed) hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
-            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, ctx->d_err, bs);
+            else if (feed) hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)capk, ctx->d_err, bs);
+            else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)capk, ctx->d_err, bs);
             bbx_prof_stop(ctx, s);
             if (vec) {
                 const int tpb = (int)std::min<size_t>(256, std::max<size_t>(16, ((ntiles + 127) / 128 + 15) / 16 * 16));
                 hipLaunchKernelGGL(k_lac_compact, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(256), 0, s, tile_cnt, tile_seg,
-                                   (int)ntiles, tpb, ovf, (uint32_t)capovf, cnt, cand_raw, (uint32_t)cap, ctx->d_err);
+                                   (int)ntiles, tpb, ovf, (uint32_t)capovf, cnt, cand_raw, (uint32_t)capk, ctx->d_err);
             }
         } else {
             // later iterations: only the surroundings of the pixels cleaned so far can differ
-            hipLaunchKernelGGL(k_lac_cand_sparse, dim3(512), dim3(256), 0, s, d_data, p, crlist, cnt, (uint32_t)cap, flags, cand_raw,
+            hipLaunchKernelGGL(k_lac_cand_sparse, dim3(512), dim3(256), 0, s, d_data, p, crlist, cnt, (uint32_t)capk, flags, cand_raw,
                                ctx->d_err);
         }
-        hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)cap, cand);
+        hipLaunchKernelGGL(k_lac_prefilter, dim3(256), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)capk, cand, ctx->d_err);
         if (it == 0 && feed) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 0, d_stats);
         bbx_prof_start(ctx, BBX_PROF_LAC_SPARSE, s);
-        hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)cap, flags);
-        hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)cap, flags, stage2, cnt, ctx->d_err);
-        hipLaunchKernelGGL(k_lac_grow2, dim3(512), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)cap, flags, crlist,
+        hipLaunchKernelGGL(k_lac_seed, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, cand, cnt, (uint32_t)capk, flags);
+        hipLaunchKernelGGL(k_lac_grow1, dim3(gsparse), dim3(256), 0, s, p, cand, cnt, (uint32_t)capk, flags, stage2, cnt, ctx->d_err);
+        hipLaunchKernelGGL(k_lac_grow2, dim3(512), dim3(256), 0, s, d_data, d_mask, p, stage2, (uint32_t)capk, flags, crlist,
                            cnt, ctx->d_err, orig, (uint32_t)caporig);
         // (the overflow list of the dense pass is free again after k_lac_compact: pixels waiting for the level)
-        hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)cap, ovf,
+        hipLaunchKernelGGL(k_lac_clean, dim3(gsparse), dim3(256), 0, s, d_data, d_mask, p, crlist, cnt, (uint32_t)capk, ovf,
                            (uint32_t)capovf, ctx->d_err);
         if (feed) hipLaunchKernelGGL(k_lac_bg, dim3(1), dim3(256), 0, s, d_data, d_mask, p, bs, cnt, ovf, (uint32_t)capovf, 1, d_stats);
-        else hipLaunchKernelGGL(k_lac_bg_frame, dim3(bgf_wgs), dim3(256), 0, s, d_data, d_mask, p, cnt, ovf, (uint32_t)capovf, orig,
-                                (uint32_t)caporig, rnp + 8, d_stats, ghist, (unsigned*)(ghist + 3 * 2048), ctx->d_err);
-        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)cap, flags, d_stats, it);
+        else {
+            for (int ps = 0; ps < 3; ps++)
+                hipLaunchKernelGGL(k_lac_bgf_hist, dim3(bgf_wgs), dim3(256), 0, s, d_data, d_mask, p, cnt, (uint32_t)capovf, orig,
+                                   (uint32_t)caporig, rnp + 8, ghist, ps);
+            hipLaunchKernelGGL(k_lac_bgf_final, dim3(1), dim3(256), 0, s, d_data, p, cnt, ovf, (uint32_t)capovf, rnp + 8, d_stats, ghist);
+        }
+        hipLaunchKernelGGL(k_lac_unflag, dim3(256), dim3(256), 0, s, p, cand_raw, stage2, cnt, (uint32_t)capk, flags, d_stats, it);
         bbx_prof_stop(ctx, s);
     }
     ctx->flags_clean_ptr = flags; ctx->flags_clean_bytes = npix;

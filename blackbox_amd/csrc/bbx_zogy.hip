@@ -14,6 +14,7 @@
 #include "bbx_common.h"
 #include <rocfft/rocfft.h>
 #include <stdlib.h>
+#include <mutex>
 
 struct zogy_scal { float sn, sr, fn, fr, dx, dy; };
 
@@ -23,44 +24,70 @@ struct zogy_plans {
     rocfft_execution_info info;
     void* work; size_t work_bytes;
 };
-static zogy_plans g_plans = {0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+// rocfft_setup() is the only process-wide step (once, under a lock); plans, the work buffer and the
+// execution info (which carries the stream) belong to the context: two lanes never share them
+static std::mutex g_rocfft_lock;
 static int g_rocfft_ready = 0;
 
 #define RFFT(call) do { rocfft_status _s = (call); if (_s != rocfft_status_success) { \
     snprintf(ctx->hip_err, sizeof(ctx->hip_err), "rocFFT: %s -> %d (line %d)", #call, (int)_s, __LINE__); return BBX_ERR_HIP; } } while (0)
 
-static int get_plans(bbx_ctx* ctx, int L, int batch, hipStream_t s) {
-    if (!g_rocfft_ready) { RFFT(rocfft_setup()); g_rocfft_ready = 1; }
-    if (g_plans.L != L || g_plans.batch != batch) {
-        if (g_plans.fwd) { rocfft_plan_destroy(g_plans.fwd); rocfft_plan_destroy(g_plans.inv); g_plans.fwd = g_plans.inv = nullptr; }
-        if (g_plans.info) { rocfft_execution_info_destroy(g_plans.info); g_plans.info = nullptr; }
-        if (g_plans.work) { (void)hipDeviceSynchronize(); (void)hipFree(g_plans.work); g_plans.work = nullptr; }
+static void drop_plans(zogy_plans* P) {
+    if (P->fwd) { rocfft_plan_destroy(P->fwd); P->fwd = nullptr; }
+    if (P->inv) { rocfft_plan_destroy(P->inv); P->inv = nullptr; }
+    if (P->info) { rocfft_execution_info_destroy(P->info); P->info = nullptr; }
+    if (P->work) { (void)hipDeviceSynchronize(); (void)hipFree(P->work); P->work = nullptr; }
+    P->L = P->batch = 0; P->work_bytes = 0;
+}
+
+void bbx_zogy_release(bbx_ctx* ctx) {
+    if (!ctx || !ctx->zogy_state) return;
+    zogy_plans* P = (zogy_plans*)ctx->zogy_state;
+    drop_plans(P);
+    free(P);
+    ctx->zogy_state = nullptr;
+}
+
+static int get_plans(bbx_ctx* ctx, int L, int batch, hipStream_t s, zogy_plans** out) {
+    {
+        std::lock_guard<std::mutex> lk(g_rocfft_lock);
+        if (!g_rocfft_ready) { RFFT(rocfft_setup()); g_rocfft_ready = 1; }
+    }
+    if (!ctx->zogy_state) {
+        ctx->zogy_state = calloc(1, sizeof(zogy_plans));
+        if (!ctx->zogy_state) return BBX_ERR_NOMEM;
+    }
+    zogy_plans* P = (zogy_plans*)ctx->zogy_state;
+    if (P->L != L || P->batch != batch) {
+        drop_plans(P);
         const size_t len[2] = {(size_t)L, (size_t)L};
-        RFFT(rocfft_plan_create(&g_plans.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+        std::lock_guard<std::mutex> lk(g_rocfft_lock);          // plan creation touches rocFFT's kernel cache
+        RFFT(rocfft_plan_create(&P->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                                 rocfft_precision_single, 2, len, (size_t)batch, nullptr));
-        RFFT(rocfft_plan_create(&g_plans.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+        RFFT(rocfft_plan_create(&P->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
                                 rocfft_precision_single, 2, len, (size_t)batch, nullptr));
         size_t w1 = 0, w2 = 0;
-        RFFT(rocfft_plan_get_work_buffer_size(g_plans.fwd, &w1));
-        RFFT(rocfft_plan_get_work_buffer_size(g_plans.inv, &w2));
-        g_plans.work_bytes = w1 > w2 ? w1 : w2;
-        if (g_plans.work_bytes) BBX_HIP(hipMalloc(&g_plans.work, g_plans.work_bytes));
-        RFFT(rocfft_execution_info_create(&g_plans.info));
-        if (g_plans.work_bytes) RFFT(rocfft_execution_info_set_work_buffer(g_plans.info, g_plans.work, g_plans.work_bytes));
-        g_plans.L = L; g_plans.batch = batch;
+        RFFT(rocfft_plan_get_work_buffer_size(P->fwd, &w1));
+        RFFT(rocfft_plan_get_work_buffer_size(P->inv, &w2));
+        P->work_bytes = w1 > w2 ? w1 : w2;
+        if (P->work_bytes) BBX_HIP(hipMalloc(&P->work, P->work_bytes));
+        RFFT(rocfft_execution_info_create(&P->info));
+        if (P->work_bytes) RFFT(rocfft_execution_info_set_work_buffer(P->info, P->work, P->work_bytes));
+        P->L = L; P->batch = batch;
     }
-    RFFT(rocfft_execution_info_set_stream(g_plans.info, s));
+    RFFT(rocfft_execution_info_set_stream(P->info, s));
+    *out = P;
     return BBX_OK;
 }
 
-static int fft_fwd(bbx_ctx* ctx, float* in, float2* out) {
+static int fft_fwd(bbx_ctx* ctx, zogy_plans* P, float* in, float2* out) {
     void* i[1] = {in}; void* o[1] = {out};
-    RFFT(rocfft_execute(g_plans.fwd, i, o, g_plans.info));
+    RFFT(rocfft_execute(P->fwd, i, o, P->info));
     return BBX_OK;
 }
-static int fft_inv(bbx_ctx* ctx, float2* in, float* out) {       // destroys [in]
+static int fft_inv(bbx_ctx* ctx, zogy_plans* P, float2* in, float* out) {       // destroys [in]
     void* i[1] = {in}; void* o[1] = {out};
-    RFFT(rocfft_execute(g_plans.inv, i, o, g_plans.info));
+    RFFT(rocfft_execute(P->inv, i, o, P->info));
     return BBX_OK;
 }
 
@@ -288,7 +315,8 @@ int bbx_zogy_subimages(bbx_ctx* ctx, int L, int nsub, float* d_new, float* d_ref
         return BBX_ERR_ARG;
     if (L < 8 || nsub < 1 || nsub > 4096) return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rc = get_plans(ctx, L, nsub, s); if (rc) return rc;
+    zogy_plans* P = nullptr;
+    int rc = get_plans(ctx, L, nsub, s, &P); if (rc) return rc;
     const int H = L / 2 + 1;
     const size_t nreal = (size_t)nsub * L * L, nspec = (size_t)nsub * L * H;
     const int NB = 64;                                      // partial-sum blocks per sub-image
@@ -307,19 +335,21 @@ int bbx_zogy_subimages(bbx_ctx* ctx, int L, int nsub, float* d_new, float* d_ref
     float2 *Nh = spec[0], *Rh = spec[1], *Pnh = spec[2], *Prh = spec[3], *Dh = spec[4], *Sh = spec[5], *krh = spec[6],
            *knh = spec[7], *SnH = spec[8], *SrH = spec[9];
     float *Draw = real[0], *Sraw = real[1], *kr = real[2], *kn = real[3], *Sn = real[4], *Sr = real[5], *t0 = real[6], *t1 = real[7];
-    if ((rc = fft_fwd(ctx, d_new, Nh)) || (rc = fft_fwd(ctx, d_ref, Rh)) || (rc = fft_fwd(ctx, d_pn, Pnh)) || (rc = fft_fwd(ctx, d_pr, Prh))) return rc;
+    bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
+    if ((rc = fft_fwd(ctx, P, d_new, Nh)) || (rc = fft_fwd(ctx, P, d_ref, Rh)) || (rc = fft_fwd(ctx, P, d_pn, Pnh)) || (rc = fft_fwd(ctx, P, d_pr, Prh))) return rc;
     hipLaunchKernelGGL(k_zogy_spec1, dim3(NB, nsub), dim3(256), 0, s, L, H, Nh, Rh, Pnh, Prh, d_sc, Dh, Sh, krh, knh, SnH, SrH, fs_partial);
     hipLaunchKernelGGL(k_zogy_fs, dim3(nsub), dim3(64), 0, s, NB, L, fs_partial, FS);
-    if ((rc = fft_inv(ctx, Dh, Draw)) || (rc = fft_inv(ctx, Sh, Sraw)) || (rc = fft_inv(ctx, krh, kr)) || (rc = fft_inv(ctx, knh, kn)) ||
-        (rc = fft_inv(ctx, SnH, Sn)) || (rc = fft_inv(ctx, SrH, Sr))) return rc;
+    if ((rc = fft_inv(ctx, P, Dh, Draw)) || (rc = fft_inv(ctx, P, Sh, Sraw)) || (rc = fft_inv(ctx, P, krh, kr)) || (rc = fft_inv(ctx, P, knh, kn)) ||
+        (rc = fft_inv(ctx, P, SnH, Sn)) || (rc = fft_inv(ctx, P, SrH, Sr))) return rc;
     const float inv_n2 = 1.0f / ((float)L * (float)L);
     hipLaunchKernelGGL(k_zogy_sq, dim3(2048), dim3(256), 0, s, nreal, inv_n2, kr, kn, t0, t1);
     // reuse spectra: Vr^ -> Nh, kr2^ -> Rh, Vn^ -> Pnh, kn2^ -> Prh, products -> Dh, Sh
-    if ((rc = fft_fwd(ctx, d_vr, Nh)) || (rc = fft_fwd(ctx, t0, Rh)) || (rc = fft_fwd(ctx, d_vn, Pnh)) || (rc = fft_fwd(ctx, t1, Prh))) return rc;
+    if ((rc = fft_fwd(ctx, P, d_vr, Nh)) || (rc = fft_fwd(ctx, P, t0, Rh)) || (rc = fft_fwd(ctx, P, d_vn, Pnh)) || (rc = fft_fwd(ctx, P, t1, Prh))) return rc;
     hipLaunchKernelGGL(k_zogy_spec2, dim3(2048), dim3(256), 0, s, nspec, Nh, Rh, Pnh, Prh, Dh, Sh);
-    if ((rc = fft_inv(ctx, Dh, t0)) || (rc = fft_inv(ctx, Sh, t1))) return rc;           // VSr, VSn
+    if ((rc = fft_inv(ctx, P, Dh, t0)) || (rc = fft_inv(ctx, P, Sh, t1))) return rc;           // VSr, VSn
     hipLaunchKernelGGL(k_zogy_final, dim3(256, nsub), dim3(256), 0, s, L, inv_n2, d_sc, FS, Draw, Sraw, Sn, Sr, t0, t1, d_D, d_S,
                        d_Scorr, d_Fpsf, d_Fpsferr);
+    bbx_prof_stop(ctx, s);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

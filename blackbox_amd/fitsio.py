@@ -199,3 +199,119 @@ def write_image(path, data, header=None):
         buf = out.tobytes()
         f.write(buf)
         f.write(b'\0' * ((-len(buf)) % BLOCK))
+
+
+def _header_bytes(cards):
+    hdr = ''.join(cards + ['END'.ljust(80)]).encode('ascii', 'replace')
+    return hdr + b' ' * ((-len(hdr)) % BLOCK)
+
+
+def _user_cards(header, skip=()):
+    skip = set(skip) | {'SIMPLE', 'BITPIX', 'NAXIS', 'EXTEND', 'BZERO', 'BSCALE', 'END', 'XTENSION', 'PCOUNT', 'GCOUNT',
+                        'TFIELDS'}
+    cards = []
+    for k, v in (header or {}).items():
+        ku = str(k).upper()
+        if ku in skip or ku.startswith('NAXIS') or ku.startswith('TFORM') or ku.startswith('TTYPE') or len(ku) > 8 \
+                or ku.startswith('__'):
+            continue
+        cards.append(_card(ku, v))
+    return cards
+
+
+def write_header(path, header):
+    """header-only FITS file: what update_imcathead(..., create_hdrfile=True) leaves next to the
+    product (`_red_hdr.fits`, `_trans_hdr.fits`; blackbox.py:2011, zogy.update_imcathead)"""
+    cards = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', 8, 'array data type'),
+             _card('NAXIS', 0, 'number of array dimensions')] + _user_cards(header)
+    with open(path, 'wb') as f:
+        f.write(_header_bytes(cards))
+
+
+_TFORM = {'f4': 'E', 'f8': 'D', 'i2': 'I', 'i4': 'J', 'i8': 'K', 'u1': 'B', 'b1': 'L'}
+
+
+def write_table(path, columns, header=None, units=None):
+    """binary-table FITS file (empty primary HDU + one BINTABLE): columns = {name: 1-D or 2-D
+    array}; what zogy.format_cat writes for `_cat.fits` / `_trans.fits`.  Zero rows is valid
+    (the dummy catalogues of qc.py:451-503)."""
+    names = list(columns)
+    arrs = [np.asarray(columns[n]) for n in names]
+    nrow = arrs[0].shape[0] if arrs else 0
+    fields, forms = [], []
+    for n, a in zip(names, arrs):
+        if a.shape[0] != nrow:
+            raise ValueError('column {} has {} rows, expected {}'.format(n, a.shape[0], nrow))
+        code = a.dtype.str[1:]
+        if code not in _TFORM:
+            raise TypeError('column {}: dtype {} not supported'.format(n, a.dtype))
+        rep = int(np.prod(a.shape[1:])) if a.ndim > 1 else 1
+        fields.append((n, '>' + code if code != 'b1' else 'u1', (rep,) if rep > 1 else ()))
+        forms.append(('%d' % rep if rep > 1 else '') + _TFORM[code])
+    rec = np.zeros(nrow, dtype=[(n, t, s) for n, t, s in fields]) if fields else np.zeros(0, 'u1')
+    for (n, _, _), a in zip(fields, arrs):
+        if a.dtype == np.bool_:
+            rec[n] = np.where(a.reshape(rec[n].shape), ord('T'), ord('F'))
+        else:
+            rec[n] = a.reshape(rec[n].shape)
+    rowbytes = rec.dtype.itemsize if fields else 0
+    cards = [_card('XTENSION', 'BINTABLE', 'binary table extension'), _card('BITPIX', 8), _card('NAXIS', 2),
+             _card('NAXIS1', rowbytes, 'width of table in bytes'), _card('NAXIS2', nrow, 'number of rows'),
+             _card('PCOUNT', 0), _card('GCOUNT', 1), _card('TFIELDS', len(names), 'number of columns')]
+    for i, (n, form) in enumerate(zip(names, forms)):
+        cards.append(_card('TTYPE%d' % (i + 1), n))
+        cards.append(_card('TFORM%d' % (i + 1), form))
+        if units and units.get(n):
+            cards.append(_card('TUNIT%d' % (i + 1), units[n]))
+    cards += _user_cards(header)
+    prim = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', 8), _card('NAXIS', 0),
+            _card('EXTEND', True)]
+    with open(path, 'wb') as f:
+        f.write(_header_bytes(prim))
+        f.write(_header_bytes(cards))
+        buf = rec.tobytes()
+        f.write(buf)
+        f.write(b'\0' * ((-len(buf)) % BLOCK))
+
+
+def read_table(path, ext=1):
+    """-> (columns dict name -> native-endian array, header) of a BINTABLE HDU written with
+    fixed-width columns (L B I J K E D with repeat counts)"""
+    h, data = read_hdus(path)[ext]
+    nf = int(_hv(h, 'TFIELDS', 0))
+    nrow = int(_hv(h, 'NAXIS2', 0))
+    code = {v: k for k, v in _TFORM.items()}
+    fields = []
+    for i in range(1, nf + 1):
+        form = str(_hv(h, 'TFORM%d' % i)).strip()
+        rep = int(form[:-1]) if form[:-1] else 1
+        t = code[form[-1]]
+        fields.append((str(_hv(h, 'TTYPE%d' % i)).strip(), ('>' + t) if t != 'b1' else 'u1', (rep,) if rep > 1 else ()))
+    rec = np.frombuffer(data.tobytes() if data is not None else b'', dtype=fields, count=nrow) if fields else None
+    cols = {}
+    for n, t, s in fields:
+        a = rec[n]
+        cols[n] = (a == ord('T')) if t == 'u1' and str(_hv(h, 'TFORM%d' % (1 + [f[0] for f in fields].index(n)))).strip().endswith('L') \
+            else a.astype(a.dtype.newbyteorder('='))
+    return cols, h
+
+
+def read_psfex(path):
+    """PSFEx `.psf` file (binary table with one PSF_MASK cell; zogy.extract_psf_datapars,
+    signature seen at buildref.py:3357-3366) -> dict(basis float32 [ncoef, S, S], polzero,
+    polscal, poldeg, psf_samp, psf_fwhm)"""
+    for h, data in read_hdus(path)[1:]:
+        if str(_hv(h, 'XTENSION', '')).strip() != 'BINTABLE':
+            continue
+        form = str(_hv(h, 'TFORM1')).strip()
+        n = int(form[:-1])
+        dims = str(_hv(h, 'TDIM1', '')).strip('() ').split(',')
+        shape = tuple(int(d) for d in reversed(dims)) if dims != [''] else (n,)
+        basis = np.frombuffer(data.tobytes(), dtype='>f4', count=n).astype(np.float32).reshape(shape)
+        ngroup = int(_hv(h, 'POLNGRP', 1) or 0)
+        poldeg = int(_hv(h, 'POLDEG1', 0) or 0) if ngroup else 0
+        return dict(basis=basis, poldeg=poldeg,
+                    polzero=(float(_hv(h, 'POLZERO1', 0.0) or 0.0), float(_hv(h, 'POLZERO2', 0.0) or 0.0)),
+                    polscal=(float(_hv(h, 'POLSCAL1', 1.0) or 1.0), float(_hv(h, 'POLSCAL2', 1.0) or 1.0)),
+                    psf_samp=float(_hv(h, 'PSF_SAMP', 1.0) or 1.0), psf_fwhm=float(_hv(h, 'PSF_FWHM', 0.0) or 0.0))
+    raise ValueError('no PSF_MASK table in {}'.format(path))

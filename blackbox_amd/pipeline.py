@@ -200,7 +200,8 @@ def _shm_phase2(args):
 
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
-                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane', 'err')
+                 'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane', 'err',
+                 'sub', 'failed', 'os_ok')
 
 
 class _LaneCtx:
@@ -250,7 +251,13 @@ def _new_event():
 
 class FramePipeline:
     def __init__(self, ctx, tel, geom, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None, exptime=60.0,
-                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=2):
+                 pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=2,
+                 detect_sats=False, subtract=None, log=None):
+        """do_finish: crosstalk, mask counts, edge fill (the tail of blackbox_reduce);
+        detect_sats: satellite trails before them (blackbox.py:1919-1952);
+        subtract: dict of keyword arguments for zogy.optimal_subtraction (ref=, ref_mask=, psf_new=,
+        psf_ref=, ...) -- the frame then continues into the background mesh / ZOGY / photometry
+        stage on the same lane (blackbox.py:2350-2354, 2460-2465), results in frame.sub"""
         self.ctx, self.tel, self.geom = ctx, tel, geom
         # stage-C lanes: (context, stream); lane 0 is the caller's context
         self.own_ctx = [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
@@ -264,6 +271,10 @@ class FramePipeline:
         self.own_pool = pool is None
         self.depth = depth
         self.do_cosmics, self.do_finish, self.accum = do_cosmics, do_finish, accum
+        self.detect_sats = detect_sats and bool(get_par(settings.detect_sats, tel))
+        self.subtract = dict(subtract) if subtract else None
+        self.keep_sub = ('D', 'Scorr', 'Fpsf', 'Fpsferr')        # device products kept on the frame when keep_outputs
+        self.log = log
         self.keep_outputs = keep_outputs
         self.sA = torch.cuda.Stream(device=ctx.device)
         # stage A has a library context of its own: it is driven from the orchestrating thread
@@ -309,8 +320,9 @@ class FramePipeline:
                 o = ar.off[k] - ar.off[base]
                 t = buf[o:o + ar.sizes[k]].view(dt)
                 return t.view(shape) if shape else t
-            d_res = torch.zeros(256, dtype=torch.uint8, device=dev)      # std[16] f64 | nobj i32 | stats[16] i32 | cnt[6] i64
-            h_res = torch.zeros(256, dtype=torch.uint8, pin_memory=True)
+            # std[16] f64 | nobj i32 | stats[16] i32 | nsats i32 | cnt[6] i64 | step error flags [8] i32 (248..280)
+            d_res = torch.zeros(288, dtype=torch.uint8, device=dev)
+            h_res = torch.zeros(288, dtype=torch.uint8, pin_memory=True)
             h_in_np, h_vo_np = ar.span(i, 'mean', 'ninf'), ar.span(i, 'vfit', 'oscan')
             h_cnt = torch.empty((2, 16, self.xsz), dtype=torch.int32, pin_memory=True)
             d_cnt = torch.empty((2, 16, self.xsz), dtype=torch.int32, device=dev)
@@ -319,7 +331,7 @@ class FramePipeline:
                 # (dst, src, nbytes, kind) of the packed copies, for bbx_copy_async
                 cp_in=(C.c_void_p(h_in_np.ctypes.data), R._ptr(d_in), n_in, 1),
                 cp_vo=(R._ptr(d_vo), C.c_void_p(h_vo_np.ctypes.data), n_vo, 0),
-                cp_res=(R._ptr(h_res), R._ptr(d_res), 256, 1),
+                cp_res=(R._ptr(h_res), R._ptr(d_res), 288, 1),
                 cp_cnt=(R._ptr(h_cnt), R._ptr(d_cnt), h_cnt.numel() * 4, 1),
                 d_in=d_in, h_in=torch.from_numpy(ar.span(i, 'mean', 'ninf')),
                 d_mean=dv(d_in, 'mean', 'mean', torch.float64),
@@ -330,9 +342,12 @@ class FramePipeline:
                 d_vfit=dv(d_vo, 'vfit', 'vfit', torch.float64), d_oscan=dv(d_vo, 'vfit', 'oscan', torch.float64),
                 d_res=d_res, h_res=h_res,
                 d_std=d_res[0:128].view(torch.float64), d_nobj=d_res[128:132].view(torch.int32),
-                d_stats=d_res[132:196].view(torch.int32), d_cnt6=d_res[200:248].view(torch.int64),
+                d_stats=d_res[132:196].view(torch.int32), d_nsats=d_res[196:200].view(torch.int32),
+                d_cnt6=d_res[200:248].view(torch.int64), d_steps=d_res[248:280].view(torch.int32),
+                d_info=torch.zeros(8, dtype=torch.float32, device=dev), d_med=torch.empty(16, dtype=torch.float32, device=dev),
                 h_std=h_res[0:128].view(torch.float64), h_nobj=h_res[128:132].view(torch.int32),
-                h_stats=h_res[132:196].view(torch.int32), h_cnt6=h_res[200:248].view(torch.int64),
+                h_stats=h_res[132:196].view(torch.int32), h_nsats=h_res[196:200].view(torch.int32),
+                h_cnt6=h_res[200:248].view(torch.int64), h_steps=h_res[248:280].view(torch.int32),
                 h_cnt=h_cnt, d_cnt=d_cnt))
         # header keys / comments are the same for every frame
         self._k_bias = [[('BIAS{}A{}'.format(c + 1, k), '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
@@ -444,45 +459,105 @@ class FramePipeline:
 
     # ---- stage C ------------------------------------------------------------------
     def _device_stage(self, f, results):
-        ctx, geom, tel = self.lane_ctx[f.lane], self.geom, self.tel
+        ctx = self.lane_ctx[f.lane]
+        # every torch allocation / operation of the stage belongs to the lane's stream (the caching
+        # allocator hands a freed block only to work queued behind it on the same stream)
+        with torch.cuda.stream(ctx.torch_stream):
+            self._device_stage_on_lane(f, results, ctx)
+
+    def _device_stage_on_lane(self, f, results, ctx):
+        geom, tel = self.geom, self.tel
         sp = ctx.sp
-        self._fill_header_vos(f, results)
-        dlevel = np.float32([r['dlevel'] for r in results])
         h, hm = f.header, f.hm
+        sl = self.slots[f.slot]
+        d_steps = sl['d_steps']
+        f.failed, f.sub = [], None
         check(lib.bbx_stream_wait_event(sp, f.evA), 'bbx_stream_wait_event')
         sol = R.OverscanSolution()
-        sl = self.slots[f.slot]
-        sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
-        sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
-        check(lib.bbx_copy_async(*sl['cp_vo'], sp), 'bbx_copy_async')     # vfit | oscan in one copy
         d_std = sl['d_std']
-        check(lib.bbx_vos_std(ctx.h, C.byref(geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
-                              R._ptr(sol.d_vfit), _lib.f32x16(dlevel), R._ptr(d_std), sp),
-              'bbx_vos_std', ctx.h)
-        if self.lane_out is not None:
-            out = self.lane_out[f.lane]
-            data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat,
-                                     bpm=self.bpm, out=out)
+        if results is None:
+            # the host fits failed: overscan of zero, RDN = 10 (blackbox.py:1537-1585)
+            zs = R.zero_overscan_solution(ctx, h, geom)
+            sol.vfit, sol.oscan, sol.d_vfit, sol.d_oscan = zs.vfit, zs.oscan, zs.d_vfit, zs.d_oscan
+            h['N-INFNAN'] = (int(f.h_ninf.item()), 'number of pixels with infinite/nan values')
+            d_std.fill_(10.0)
+            f.os_ok = False
         else:
-            with torch.cuda.stream(ctx.torch_stream):                 # the allocations belong to the lane's stream
-                data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat,
-                                         bpm=self.bpm)
-        d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom, d_n=sl['d_nobj'])
+            self._fill_header_vos(f, results)
+            dlevel = np.float32([r['dlevel'] for r in results])
+            sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
+            sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
+            check(lib.bbx_copy_async(*sl['cp_vo'], sp), 'bbx_copy_async')     # vfit | oscan in one copy
+            check(lib.bbx_vos_std(ctx.h, C.byref(geom), R._ptr(f.raw), R.raw_type_of(f.raw), self.g32,
+                                  R._ptr(sol.d_vfit), _lib.f32x16(dlevel), R._ptr(d_std), sp),
+                  'bbx_vos_std', ctx.h)
+            f.os_ok = True
+        h['OS-P'] = (f.os_ok, 'corrected for overscan?')
+        out = self.lane_out[f.lane] if self.lane_out is not None else None
+        data, mask = R.calibrate(ctx, f.raw, sol, h, hm, tel, geom, mbias=self.mbias, mflat=self.mflat, bpm=self.bpm, out=out)
+        h['MBIAS-P'] = (self.mbias is not None, 'corrected for master bias?')
+        h['MFLAT-P'] = (self.mflat is not None, 'corrected for master flat?')
+        R.step_mark(ctx, d_steps, 'calibrate')
+        try:
+            d_nobj = R.mask_init_finish(ctx, mask, h, hm, geom, d_n=sl['d_nobj'])
+            h['MASK-P'] = (True, 'mask image created?')
+        except _lib.BBXError:
+            d_nobj = None
+            h['MASK-P'] = (False, 'mask image created?')
+        R.step_mark(ctx, d_steps, 'mask')
         d_stats = None
         if self.do_cosmics:
-            # background level: prepared in advance only while recent frames needed it (st[15])
-            check(lib.bbx_set_option(ctx.h, 1, 1 if self.level_feed_left > 0 else 0), 'bbx_set_option', ctx.h)
-            # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
-            d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std, d_stats=sl['d_stats'])
+            try:
+                # background level: prepared in advance only while recent frames needed it (st[15])
+                check(lib.bbx_set_option(ctx.h, 1, 1 if self.level_feed_left > 0 else 0), 'bbx_set_option', ctx.h)
+                # RDNOISE = nanmean of the 16 channel sigmas is formed on the device
+                d_stats = R.cosmics_corr(ctx, data, h, mask, hm, tel, d_rdn16=d_std, d_stats=sl['d_stats'])
+                h['COSMIC-P'] = (True, 'corrected for cosmic rays?')
+            except _lib.BBXError:
+                d_stats = None
+                f.failed.append('cosmics')
+        R.step_mark(ctx, d_steps, 'cosmics')
         d_cnt = sl['d_cnt6']
-        if self.do_finish:
-            if self.xtalk is not None:
+        if self.do_finish and self.xtalk is not None:
+            try:
                 R.xtalk_corr(ctx, data, self.xtalk, mask, geom)
-            check(lib.bbx_mask_counts(ctx.h, mask.numel(), R._ptr(mask), R._ptr(d_cnt), sp),
-                  'bbx_mask_counts', ctx.h)
-            R.edge_fill(ctx, data, mask, geom)
+                h['XTALK-P'] = (True, 'corrected for crosstalk?')
+            except _lib.BBXError:
+                h['XTALK-P'] = (False, 'corrected for crosstalk?')
+        R.step_mark(ctx, d_steps, 'xtalk')
+        d_nsats = None
+        if self.detect_sats:
+            try:
+                d_nsats = sl['d_nsats']
+                check(lib.bbx_sat_trails(ctx.h, data.shape[0], data.shape[1], R._ptr(data), R._ptr(mask), R.sat_cos_sin(),
+                                         R.NTHETA_SAT, R._ptr(d_nsats), R._ptr(sl['d_info']), sp), 'bbx_sat_trails', ctx.h)
+                h['SAT-P'] = (True, 'processed for satellite trails?')
+            except _lib.BBXError:
+                d_nsats = None
+                f.failed.append('sat')
+        R.step_mark(ctx, d_steps, 'sat')
+        if self.do_finish:
+            check(lib.bbx_mask_counts(ctx.h, mask.numel(), R._ptr(mask), R._ptr(d_cnt), sp), 'bbx_mask_counts', ctx.h)
+            check(lib.bbx_edge_fill(ctx.h, C.byref(geom), R._ptr(data), R._ptr(mask), R._ptr(sl['d_med']), sp),
+                  'bbx_edge_fill', ctx.h)
+        R.step_mark(ctx, d_steps, 'finish')
+        if self.subtract is not None:
+            from . import zogy as G
+            try:
+                sub = G.optimal_subtraction(ctx, data, new_mask=mask, **self.subtract)
+                if not self.keep_outputs:
+                    for k in list(sub):
+                        if torch.is_tensor(sub[k]):
+                            del sub[k]                                # device products stay only on request
+                f.sub = sub
+            except (_lib.BBXError, ValueError) as e:
+                f.failed.append('zogy')
+                if self.log is not None:
+                    self.log.error('frame %d: [optimal_subtraction] failed: %s', f.idx, e)
+            R.step_mark(ctx, d_steps, 'zogy')
         # scalar results: one small pinned D2H of the packed record
-        f.h_out = (sl['h_std'], sl['h_nobj'], sl['h_stats'], sl['h_cnt6'])
+        f.h_out = (sl['h_std'], sl['h_nobj'] if d_nobj is not None else None, sl['h_stats'] if d_stats is not None else None,
+                   sl['h_cnt6'], sl['h_nsats'] if d_nsats is not None else None, sl['h_steps'])
         check(lib.bbx_copy_async(*sl['cp_res'], sp), 'bbx_copy_async')
         f.evC = sl['evC']
         check(lib.bbx_event_record(f.evC, sp), 'bbx_event_record')
@@ -492,13 +567,15 @@ class FramePipeline:
 
     def _finalize(self, f):
         h, hm = f.header, f.hm
-        std = f.h_out[0].numpy()
-        for c in range(16):
-            h[self._k_rdn[c][0]] = (float(std[c]), self._k_rdn[c][1])
-        h['RDNOISE'] = (float(np.nanmean(std)), '[e-] average all channel sigmas vert. overscan')
-        nobj = int(f.h_out[1].item())
-        h['NOBJ-SAT'] = hm['NOBJ-SAT'] = (nobj, 'number of saturated objects')
-        if self.do_cosmics:
+        if f.os_ok:
+            std = f.h_out[0].numpy()
+            for c in range(16):
+                h[self._k_rdn[c][0]] = (float(std[c]), self._k_rdn[c][1])
+            h['RDNOISE'] = (float(np.nanmean(std)), '[e-] average all channel sigmas vert. overscan')
+        if f.h_out[1] is not None:
+            nobj = int(f.h_out[1].item())
+            h['NOBJ-SAT'] = hm['NOBJ-SAT'] = (nobj, 'number of saturated objects')
+        if f.h_out[2] is not None:
             st = f.h_out[2].numpy()
             h['NCOSMICS'] = hm['NCOSMICS'] = (st[6] / float(self.exptime), '[/s] number of cosmic rays identified')
             h['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
@@ -506,6 +583,19 @@ class FramePipeline:
                 self.level_feed_left = 64             # a frame needed the level: feed it for the next frames
             elif self.level_feed_left > 0:
                 self.level_feed_left -= 1
+        if f.h_out[4] is not None:
+            h['NSATS'] = hm['NSATS'] = (int(f.h_out[4].item()), 'number of satellite trails identified')
+        if self.do_finish:
+            R.fill_mask_header(hm, f.h_out[3].numpy())
+        for step in f.failed:                                    # host-side failures of a step's launch
+            if step == 'cosmics':
+                h['COSMIC-P'] = (False, 'corrected for cosmic rays?')
+                h['NCOSMICS'] = hm['NCOSMICS'] = ('None', '[/s] number of cosmic rays identified')
+            elif step == 'sat':
+                h['SAT-P'] = (False, 'processed for satellite trails?')
+                h['NSATS'] = hm['NSATS'] = ('None', 'number of satellite trails identified')
+        # device-side error flags per step (bbx_step_mark) -> <STEP>-P False for this frame only
+        f.failed += R.apply_step_errors(h, hm, f.h_out[5].numpy(), self.log)
         f.d_keep = None
         f.state = 'done'
 
@@ -560,15 +650,26 @@ class FramePipeline:
                     progressed = True
                 elif f.state == 'B' and f.res.ready():
                     f.tB = time.perf_counter()
-                    results = f.res.get()
+                    try:
+                        results = f.res.get()
+                    except Exception as e:                         # os_corr failed on the host: zero overscan
+                        if self.log is not None:
+                            self.log.error('frame %d: overscan fits failed (%s); adopting an overscan of zero', f.idx, e)
+                        results = None
                     f.state = 'Q'                                  # queued at its lane
-                    self.lane_thread[f.lane].q.put((self._satcol if self.two_phase else self._device_stage, f, results))
+                    second = self.two_phase and results is not None
+                    self.lane_thread[f.lane].q.put((self._satcol if second else self._device_stage, f, results))
                     progressed = True
                 elif f.state == 'S' and lib.bbx_event_query(f.evS) == 1:
                     self._submit_phase2(f)
                     progressed = True
                 elif f.state == 'B2' and f.res2.ready():
-                    f.res2.get()
+                    try:
+                        f.res2.get()
+                    except Exception as e:
+                        if self.log is not None:
+                            self.log.error('frame %d: overscan fits failed (%s); adopting an overscan of zero', f.idx, e)
+                        f.p1 = None
                     f.state = 'Q'
                     self.lane_thread[f.lane].q.put((self._device_stage, f, f.p1))
                     progressed = True
@@ -592,6 +693,7 @@ class FramePipeline:
                 break
             if not progressed:
                 time.sleep(0.0002)
-        for c in self.lane_ctx:
-            c.sync()
+        # device-side error flags were moved into each frame's record (bbx_step_mark): a failing
+        # frame is flagged in its own header and does not abort the run
+        torch.cuda.synchronize(self.ctx.device)
         return ndone

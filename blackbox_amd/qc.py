@@ -188,6 +188,15 @@ def qc_check(header, telescope='ML1', keywords=None, check_key_type=None, cat_du
         if COLORS.index(qc_flag) < COLORS.index(main):
             _set(header, 'TQC-FLAG', main, 'transient QC flag (green|yellow|orange|red)')
             _set(header, 'TQC{}1'.format(main[0:3].upper()), 'QC-FLAG', 'flag inherited from QC-FLAG', after='TQC-FLAG')
+    if cat_dummy is not None:
+        # dummy catalogue of type [cat_type] (qc.py:451-503): an empty table whose header carries
+        # the image header plus the defaults of the keywords a catalogue of that type would hold
+        from .catalogs import format_cat
+        header_dummy = dict(header)
+        for key, e in table.items():
+            if key not in header_dummy and e['key_type'] in (cat_type, 'full'):
+                header_dummy[key] = (e['default'], e['comment'])
+        format_cat(None, cat_dummy, cat_type=cat_type or 'new', header2add=header_dummy)
     prev = prefix + 'QC-FLAG'
     kw = np.array([k.upper() for k in keywords])
     for col in ('red', 'orange', 'yellow'):

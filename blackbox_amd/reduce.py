@@ -230,7 +230,8 @@ def satlevels(header, tel):
 _SATLEV_KEYS = [('SATLEV{}'.format(c + 1), '[e-] channel {} saturation threshold'.format(c + 1)) for c in range(16)]
 
 
-def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=None, bpm=None, out=None):
+def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=None, bpm=None, out=None,
+              satlevel_override=None):
     """gain + overscan + crop (+ master bias) + first half of mask_init (+ master
     flat) in one pass -> (data float32, mask uint8) device tensors; out: optional
     (data, mask) pair to write into instead of allocating"""
@@ -239,10 +240,13 @@ def calibrate(ctx, raw, sol, header, header_mask, tel, geom, mbias=None, mflat=N
     if tuple(raw.shape) != (geom.ny_raw, geom.nx_raw) or not raw.is_contiguous() or not raw.is_cuda:
         raise ValueError('raw frame: contiguous device tensor of shape {} expected'.format((geom.ny_raw, geom.nx_raw)))
     gain = get_par(settings.gain, tel)
-    sat = satlevels(header, tel)
-    header_mask['SATURATE'] = header['SATURATE'] = (float(np.mean(sat)), '[e-] mean saturation threshold')
-    for c, (key, comment) in enumerate(_SATLEV_KEYS):
-        header[key] = header_mask[key] = (round(float(sat[c]), 1), comment)
+    if satlevel_override is not None:
+        sat = np.full(16, satlevel_override, dtype=np.float64)         # calibration frames: no saturation marking
+    else:
+        sat = satlevels(header, tel)
+        header_mask['SATURATE'] = header['SATURATE'] = (float(np.mean(sat)), '[e-] mean saturation threshold')
+        for c, (key, comment) in enumerate(_SATLEV_KEYS):
+            header[key] = header_mask[key] = (round(float(sat[c]), 1), comment)
     if out is not None:
         data, mask = out
         _expect(data, torch.float32, (ny, nx), 'out data')
@@ -387,18 +391,29 @@ def nonlin_corr(ctx, data, geom, tel, splines=None):
 NTHETA_SAT = 720
 
 
+_SAT_CS = None
+
+
+def sat_cos_sin():
+    """cos / sin table of the Hough angles (float64), shared by the device code and the oracle"""
+    global _SAT_CS
+    if _SAT_CS is None:
+        th = np.arange(NTHETA_SAT) * (np.pi / NTHETA_SAT)
+        cs = np.empty(2 * NTHETA_SAT)
+        cs[0::2], cs[1::2] = np.cos(th), np.sin(th)
+        _SAT_CS = (cs, cs.ctypes.data_as(C.POINTER(C.c_double)))
+    return _SAT_CS[1]
+
+
 def sat_detect(ctx, data, header, data_mask, header_mask):
     """blackbox.py:4163-4254 (classical path; deterministic detector, see oracle/sattrail.py):
     adds bit 16 to data_mask in place, sets NSATS.  Returns (nsats tensor, info tensor)."""
     ny, nx = data.shape
     _expect(data, torch.float32, (ny, nx), 'data')
     _expect(data_mask, torch.uint8, (ny, nx), 'data_mask')
-    th = np.arange(NTHETA_SAT) * (np.pi / NTHETA_SAT)
-    cs = np.empty(2 * NTHETA_SAT)
-    cs[0::2], cs[1::2] = np.cos(th), np.sin(th)
     d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
     d_info = torch.zeros(8, dtype=torch.float32, device=ctx.device)
-    check(lib.bbx_sat_trails(ctx.h, ny, nx, _ptr(data), _ptr(data_mask), cs.ctypes.data_as(C.POINTER(C.c_double)),
+    check(lib.bbx_sat_trails(ctx.h, ny, nx, _ptr(data), _ptr(data_mask), sat_cos_sin(),
                              NTHETA_SAT, _ptr(d_n), _ptr(d_info), ctx.stream()), 'bbx_sat_trails', ctx.h)
     return d_n, d_info
 
@@ -409,7 +424,12 @@ def mask_header(ctx, data_mask, header_mask):
     d_c = torch.zeros(6, dtype=torch.int64, device=ctx.device)
     check(lib.bbx_mask_counts(ctx.h, data_mask.numel(), _ptr(data_mask), _ptr(d_c), ctx.stream()),
           'bbx_mask_counts', ctx.h)
-    counts = d_c.cpu().numpy()
+    fill_mask_header(header_mask, d_c.cpu().numpy())
+
+
+def fill_mask_header(header_mask, counts):
+    """the M-* keywords of mask_header from the six pixel counts (bad, edge, saturated,
+    saturated-connected, satellite trail, cosmic ray)"""
     text = (('bad', 'BP'), ('edge', 'EP'), ('saturated', 'SP'), ('saturated-connected', 'SCP'),
             ('satellite trail', 'STP'), ('cosmic ray', 'CRP'))
     for (mask_type, t), n in zip(text, counts):
@@ -443,30 +463,132 @@ def hval(header, key):
     return v[0] if isinstance(v, tuple) else v
 
 
+# ---- error attribution per step --------------------------------------------------------------
+STEP_SLOTS = ('calibrate', 'mask', 'cosmics', 'xtalk', 'sat', 'finish', 'bkg', 'zogy')
+
+
+def step_mark(ctx, d_steps, step):
+    """enqueue: d_steps[slot of step] <- device error flags raised since the previous mark (bbx_step_mark)"""
+    k = STEP_SLOTS.index(step)
+    check(lib.bbx_step_mark(ctx.h, C.c_void_p(d_steps.data_ptr() + 4 * k), ctx.stream()), 'bbx_step_mark', ctx.h)
+
+
+def zero_overscan_solution(ctx, header, geom):
+    """the reference's fallback when os_corr raises (blackbox.py:1546-1585): adopt an overscan of
+    zero for all channels -- the data sections are only cropped -- with BIASM{c} = 0, RDN{c} = 10,
+    BIASMEAN = 0, RDNOISE = 10"""
+    dy = geom.ny_raw // 2
+    for c in range(16):
+        header['BIASM{}'.format(c + 1)] = (0.0, '[e-] channel {} mean vertical overscan'.format(c + 1))
+    for c in range(16):
+        header['RDN{}'.format(c + 1)] = (10.0, '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1))
+    header['BIASMEAN'] = (0.0, '[e-] average all channel means vert. overscan')
+    header['RDNOISE'] = (10.0, '[e-] average all channel sigmas vert. overscan')
+    sol = OverscanSolution()
+    sol.vfit, sol.oscan = np.zeros((16, dy)), np.zeros((16, geom.xsize_chan))
+    sol.d_vfit = torch.zeros(16 * dy, dtype=torch.float64, device=ctx.device)
+    sol.d_oscan = torch.zeros(16 * geom.xsize_chan, dtype=torch.float64, device=ctx.device)
+    sol.aux = None
+    return sol
+
+
+def apply_step_errors(header, header_mask, errs, log=None):
+    """device-side failures of the asynchronous stages (list overflow, non-convergence), read
+    per step after the frame's synchronisation -> the reference's convention (blackbox.py:
+    1750-1761, 1866-1878, 1897-1912, 1919-1952): flag the step, keep going with what there is"""
+    def bad(step):
+        return int(errs[STEP_SLOTS.index(step)]) != 0
+    if bad('calibrate') or bad('mask'):
+        header['MASK-P'] = (False, 'mask image created?')
+    if bad('cosmics'):
+        header['COSMIC-P'] = (False, 'corrected for cosmic rays?')
+        header['NCOSMICS'] = header_mask['NCOSMICS'] = ('None', '[/s] number of cosmic rays identified')
+    if bad('xtalk'):
+        header['XTALK-P'] = (False, 'corrected for crosstalk?')
+    if bad('sat'):
+        header['SAT-P'] = (False, 'processed for satellite trails?')
+        header['NSATS'] = header_mask['NSATS'] = ('None', 'number of satellite trails identified')
+    failed = [s for s in STEP_SLOTS if bad(s)]
+    if failed and log is not None:
+        log.error('device-side error flags %s in step(s) %s', [int(e) for e in errs], failed)
+    return failed
+
+
 def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None,
                   exptime=None, ysize_chan=None, xsize_chan=None, do_cosmics=True, crmask_override=None,
-                  accum='f32seq', stages=None, detect_sats=True, nonlin_splines=None):
-    """The hot path of blackbox_reduce for an 'object' frame (blackbox.py:1451-1974):
-    raw device tensor -> (data, mask, header, header_mask).  Failures of a stage
-    follow the reference convention: flag <STEP>-P False and carry on."""
+                  accum='f32seq', stages=None, detect_sats=True, nonlin_splines=None, imgtype='object', log=None):
+    """The hot path of blackbox_reduce (blackbox.py:1451-1974): raw device tensor ->
+    (data, mask, header, header_mask).  imgtype 'object' runs every step; 'flat' stops after the
+    master-bias step with the bad-pixel mask as its mask (mask_init with imgtype 'flat' copies the
+    BPM only, 4386-4405; no saturation marking, flat division, cosmics, crosstalk, trails, edge
+    fill); 'bias' / 'dark' stop after the overscan step (1627-1637).
+    Failures of a step -- an exception of its host part or a device-side error flag -- follow the
+    reference convention: `<STEP>-P = False`, log, carry on with what there is."""
     header_mask = {}
     geom = geometry(raw.shape, ysize_chan, xsize_chan)
-    gain_corr(header, tel)
+    d_steps = torch.zeros(len(STEP_SLOTS), dtype=torch.int32, device=ctx.device)
+
+    def logexc(what):
+        if log is not None:
+            log.exception('exception was raised during [%s]', what)
+
+    try:
+        gain_ok = False
+        gain_corr(header, tel)
+        gain_ok = True
+    except Exception:
+        logexc('gain_corr')
     header['GAIN'] = (1.0, '[e-/ADU] effective gain all channels')
-    header['GAIN-P'] = (True, 'corrected for gain?')
-    sol = os_solve(ctx, raw, header, tel, geom, accum=accum)
-    header['OS-P'] = (True, 'corrected for overscan?')
+    header['GAIN-P'] = (gain_ok, 'corrected for gain?')
+    try:
+        sol = os_solve(ctx, raw, header, tel, geom, accum=accum)
+        os_ok = True
+    except Exception:
+        # os_corr failed: adopt an overscan of zero for all channels (blackbox.py:1537-1585)
+        logexc('os_corr; adopting an overscan of zero for all channels')
+        sol = zero_overscan_solution(ctx, header, geom)
+        os_ok = False
+    header['OS-P'] = (os_ok, 'corrected for overscan?')
     # non-linearity correction (off upstream: set_bb.correct_nonlin False): done inside the fused
     # calibration pass when splines are given
-    set_nonlin(ctx, nonlin_splines)
-    header['NONLIN-P'] = (nonlin_splines is not None, 'corrected for non-linearity?')
-    use_bias = mbias is not None and get_par(settings.subtract_mbias, tel)
-    data, mask = calibrate(ctx, raw, sol, header, header_mask, tel, geom,
-                           mbias=mbias if use_bias else None, mflat=mflat, bpm=bpm)
+    header['NONLIN-P'] = (False, 'corrected for non-linearity?')
+    if imgtype != 'bias' and nonlin_splines is not None:
+        try:
+            set_nonlin(ctx, nonlin_splines)
+            header['NONLIN-P'] = (True, 'corrected for non-linearity?')
+        except Exception:
+            logexc('nonlin_corr')
+            set_nonlin(ctx, None)
+    else:
+        set_nonlin(ctx, None)
+    is_object = imgtype == 'object'
+    use_bias = imgtype in ('object', 'flat') and mbias is not None and bool(get_par(settings.subtract_mbias, tel))
+    use_flat = is_object and mflat is not None
+    if is_object:
+        data, mask = calibrate(ctx, raw, sol, header, header_mask, tel, geom,
+                               mbias=mbias if use_bias else None, mflat=mflat if use_flat else None, bpm=bpm)
+    else:
+        # calibration frames: no saturation marking (mask_init marks saturated pixels for object
+        # frames only), mask = the bad-pixel mask as it is
+        data, _ = calibrate(ctx, raw, sol, {k: v for k, v in header.items()}, {}, tel, geom,
+                            mbias=mbias if use_bias else None, mflat=None, bpm=None, satlevel_override=np.inf)
+        mask = bpm.clone() if bpm is not None else torch.zeros(data.shape, dtype=torch.uint8, device=ctx.device)
+    step_mark(ctx, d_steps, 'calibrate')
     header['MBIAS-P'] = (bool(use_bias), 'corrected for master bias?')
-    header['MFLAT-P'] = (mflat is not None, 'corrected for master flat?')
-    d_nobj = mask_init_finish(ctx, mask, header, header_mask, geom)
-    header['MASK-P'] = (True, 'mask image created?')
+    if not is_object:
+        ctx.sync()
+        if imgtype == 'flat':
+            header['MASK-P'] = (True, 'mask image created?')
+        return data, mask, header, header_mask
+    header['MFLAT-P'] = (bool(use_flat), 'corrected for master flat?')
+    d_nobj = None
+    try:
+        d_nobj = mask_init_finish(ctx, mask, header, header_mask, geom)
+        header['MASK-P'] = (True, 'mask image created?')
+    except _lib.BBXError:
+        logexc('mask_init')
+        header['MASK-P'] = (False, 'mask image created?')
+    step_mark(ctx, d_steps, 'mask')
     d_stats = None
     if crmask_override is not None:
         # test hook: take the cosmic-ray pixels as given instead of detecting them
@@ -476,11 +598,19 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
             d_stats = cosmics_corr(ctx, data, header, mask, header_mask, tel)
             header['COSMIC-P'] = (True, 'corrected for cosmic rays?')
         except _lib.BBXError:
+            logexc('cosmics_corr')
+            d_stats = None
             header['NCOSMICS'] = ('None', '[/s] number of cosmic rays identified')
             header['COSMIC-P'] = (False, 'corrected for cosmic rays?')
+    step_mark(ctx, d_steps, 'cosmics')
     if xtalk_coeffs is not None:
-        xtalk_corr(ctx, data, xtalk_coeffs, mask, geom)
-        header['XTALK-P'] = (True, 'corrected for crosstalk?')
+        try:
+            xtalk_corr(ctx, data, xtalk_coeffs, mask, geom)
+            header['XTALK-P'] = (True, 'corrected for crosstalk?')
+        except (_lib.BBXError, ValueError):
+            logexc('xtalk_corr')
+            header['XTALK-P'] = (False, 'corrected for crosstalk?')
+    step_mark(ctx, d_steps, 'xtalk')
     if stages is not None:
         stages['data_xtalk'] = data.clone()
     d_nsats = None
@@ -489,13 +619,18 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
             d_nsats, _ = sat_detect(ctx, data, header, mask, header_mask)
             header['SAT-P'] = (True, 'processed for satellite trails?')
         except _lib.BBXError:
+            logexc('sat_detect')
+            d_nsats = None
             header['NSATS'] = ('None', 'number of satellite trails identified')
             header['SAT-P'] = (False, 'processed for satellite trails?')
+    step_mark(ctx, d_steps, 'sat')
     mask_header(ctx, mask, header_mask)
     edge_fill(ctx, data, mask, geom)
+    step_mark(ctx, d_steps, 'finish')
     ctx.sync()
-    nobj = int(d_nobj.item())
-    header_mask['NOBJ-SAT'] = header['NOBJ-SAT'] = (nobj, 'number of saturated objects')
+    if d_nobj is not None:
+        nobj = int(d_nobj.item())
+        header_mask['NOBJ-SAT'] = header['NOBJ-SAT'] = (nobj, 'number of saturated objects')
     if d_nsats is not None:
         header['NSATS'] = header_mask['NSATS'] = (int(d_nsats.item()), 'number of satellite trails identified')
     if d_stats is not None:
@@ -503,4 +638,5 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
         t = float(exptime) if exptime else 1.0
         header['NCOSMICS'] = header_mask['NCOSMICS'] = (st[6] / t, '[/s] number of cosmic rays identified')
         header['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
+    apply_step_errors(header, header_mask, d_steps.cpu().numpy(), log)
     return data, mask, header, header_mask

@@ -15,6 +15,7 @@ from scipy import ndimage
 
 from . import settings
 from ._lib import lib, check
+from .catalogs import format_cat, transient_table         # noqa: F401  (zogy.format_cat)
 
 NPAD = 12          # scipy.ndimage.zoom pads 'nearest' inputs by 12 samples before prefiltering
 
@@ -207,34 +208,171 @@ def variance(ctx, data_bkgsub, bkg_std):
     return v
 
 
+def remap_mini(mini, grid, shape_in, box, step):
+    """a mini (per-box) image of the reference frame sampled on the new frame's box centres:
+    bilinear interpolation of [mini] at the reference-frame positions that the projection
+    lattice [grid] (coadd.projection_grid: [gny][gnx][2] = x, y input position of the output
+    pixels (j*step, i*step)) assigns to the centres of the new frame's boxes.  Host, float64:
+    176 x 176 values."""
+    mini = np.asarray(mini, np.float64)
+    nby, nbx = mini.shape
+    cy = (np.arange(nby) + 0.5) * box - 0.5
+    cx = (np.arange(nbx) + 0.5) * box - 0.5
+    gy, gx = cy / step, cx / step
+    j0 = np.clip(np.floor(gy).astype(int), 0, grid.shape[0] - 2); fy = (gy - j0)[:, None]
+    i0 = np.clip(np.floor(gx).astype(int), 0, grid.shape[1] - 2); fx = (gx - i0)[None, :]
+    g00, g01 = grid[j0][:, i0], grid[j0][:, i0 + 1]
+    g10, g11 = grid[j0 + 1][:, i0], grid[j0 + 1][:, i0 + 1]
+    pos = ((1 - fy) * (1 - fx))[..., None] * g00 + ((1 - fy) * fx)[..., None] * g01 + \
+          (fy * (1 - fx))[..., None] * g10 + (fy * fx)[..., None] * g11
+    # position in box units of the reference frame's mini image (box centres at k + 0.5)
+    by = np.clip((pos[..., 1] + 0.5) / box - 0.5, 0, shape_in[0] // box - 1)
+    bx = np.clip((pos[..., 0] + 0.5) / box - 0.5, 0, shape_in[1] // box - 1)
+    y0 = np.clip(np.floor(by).astype(int), 0, mini.shape[0] - 2); wy = by - y0
+    x0 = np.clip(np.floor(bx).astype(int), 0, mini.shape[1] - 2); wx = bx - x0
+    out = (1 - wy) * (1 - wx) * mini[y0, x0] + (1 - wy) * wx * mini[y0, x0 + 1] + \
+          wy * (1 - wx) * mini[y0 + 1, x0] + wy * wx * mini[y0 + 1, x0 + 1]
+    return out.astype(np.float32)
+
+
+def subimage_psfs(ctx, psf, nsy, nsx, size):
+    """PSF stamps of the sub-images [nsub, S, S] (unit sum) from either such a tensor, a single
+    stamp [S, S], or a PSFEx model dict(basis=[ncoef,S,S] device tensor, polzero, polscal, poldeg)
+    evaluated at the sub-image centres on the f32 MFMA (zogy.get_psf_ima at the tile centre)"""
+    nsub = nsy * nsx
+    if isinstance(psf, dict):
+        yc = (np.arange(nsy) + 0.5) * size + 0.5          # FITS pixel coordinates of the tile centres
+        xc = (np.arange(nsx) + 0.5) * size + 0.5
+        yy, xx = np.meshgrid(yc, xc, indexing='ij')
+        return psf_model_stamps(ctx, psf['basis'], xx.ravel(), yy.ravel(), psf['polzero'], psf['polscal'], psf['poldeg'])
+    if psf.dim() == 2:
+        return psf.unsqueeze(0).expand(nsub, -1, -1).contiguous()
+    if psf.shape[0] != nsub:
+        raise ValueError('need one PSF stamp per sub-image ({}), got {}'.format(nsub, psf.shape[0]))
+    return psf.contiguous()
+
+
+def source_psfs(ctx, psf, sub_psfs, ys, xs, nsx, size):
+    """unit-sum PSF stamp of every source: the PSFEx model at the source position, or the stamp
+    of the sub-image the source falls in"""
+    if isinstance(psf, dict):
+        return psf_model_stamps(ctx, psf['basis'], np.asarray(xs) + 1.0, np.asarray(ys) + 1.0, psf['polzero'],
+                                psf['polscal'], psf['poldeg'])
+    k = torch.as_tensor((np.asarray(ys) // size) * nsx + (np.asarray(xs) // size), device=ctx.device, dtype=torch.long)
+    return sub_psfs.index_select(0, k).contiguous()
+
+
+def frame_clipped_stats(ctx, img, mask=None):
+    """sigma_clipped_stats over a whole frame (3 sigma, 5 iterations, centre = exact median)
+    -> (median, std) as zogy reports them in Z-SCMED / Z-SCSTD / Z-FPEMED / Z-FPESTD"""
+    from . import flatstats
+    ny, nx = img.shape
+    st = flatstats.rect_clipped_stats(ctx, img, mask, 0, 0, ny, nx, ny, nx, skip_zero=True)[0]
+    return float(st[1]), float(st[3])
+
+
 def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fratio=1.0, dx=0.0, dy=0.0,
-                        subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None):
-    """The numerical core of zogy.optimal_subtraction(new_fits, ref_fits, ...) (call site
-    blackbox.py:2460-2465) on device tensors: background mesh + subtraction of both frames,
-    variance images, sub-image ZOGY, stitching, transient candidates with PSF fluxes.
-      new, ref   : reduced frames (float32, e-), ref already remapped to the new frame's grid
-      psf_new/ref: PSF stamps per sub-image [nsub, S, S] (unit sum) -- PSFEx is out of scope
-    -> dict(D, Scorr, Fpsf, Fpsferr, bkg_mini, bkg_std_mini, transients, header)"""
+                        subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None,
+                        ref_is_bkgsub=False, ref_bkg_std_mini=None, ref_grid=None, ref_grid_step=32,
+                        cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000):
+    """The numerical core of zogy.optimal_subtraction(new_fits, ref_fits, ...) (call sites
+    blackbox.py:2350-2354 new-only, 2460-2465 new + ref) on device tensors: background mesh +
+    subtraction, variance images, [remapping of the reference to the new frame's grid],
+    sub-image ZOGY, stitching, transient candidates with PSF fluxes, [full-source catalogue by
+    PSF-weighted optimal photometry].
+      new, new_mask : reduced frame (float32, e-) and its mask
+      ref, ref_mask : reference frame or None (new-only mode, trans_extract False or no ref:
+                      the 2350-2354 branch): then only the background products and the catalogue
+      ref_is_bkgsub : the reference is a background-subtracted co-add (buildref product);
+                      ref_bkg_std_mini: its `_bkg_std_mini` image (else measured here)
+      ref_grid      : projection lattice (coadd.projection_grid) when the reference lives on
+                      another pixel grid: it is remapped with the LANCZOS3 kernel (zogy runs SWarp)
+      psf_new/ref   : PSF stamps [nsub, S, S] / [S, S] (unit sum) or a PSFEx model dict
+                      (subimage_psfs) -- running PSFEx itself is out of scope
+    -> dict(D, Scorr, Fpsf, Fpsferr, bkg_mini_new, bkg_std_mini_new, ..., transients, catalog,
+            header (= header_new additions), header_trans)"""
     size = subimage_size or settings.subimage_size
     border = settings.subimage_border if subimage_border is None else subimage_border
     box = bkg_boxsize or settings.bkg_boxsize
     ny, nx = new.shape
     L = size + 2 * border
-    res, hdr = {}, {}
-    prepared = []
-    for name, img, msk in (('new', new, new_mask), ('ref', ref, ref_mask)):
-        mini, mini_std = get_back(ctx, img, msk, bkg_boxsize=box)
-        work = img.clone()
-        mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=work, want_bkg=False)
-        bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
-        prepared.append((work, variance(ctx, work, bstd), mini.cpu().numpy(), mini_std.cpu().numpy()))
-        res['bkg_mini_' + name], res['bkg_std_mini_' + name] = prepared[-1][2], prepared[-1][3]
-        hdr['S-BKG' if name == 'new' else 'S-BKG-R'] = float(np.median(prepared[-1][2]))
-        hdr['S-BKGSTD' if name == 'new' else 'S-BKGSTDR'] = float(np.median(prepared[-1][3]))
-    (N, Vn, _, sdn), (Rr, Vr, _, sdr) = prepared
+    res, hdr, hdr_t = {}, {}, {}
     nsy, nsx = ny // size, nx // size
     nsub = nsy * nsx
-    # per sub-image noise level = median of the mini std image inside the tile
+    have_ref = ref is not None and trans_extract
+
+    # ---- new frame: mesh, subtraction, sigma image, variance
+    mini, mini_std = get_back(ctx, new, new_mask, bkg_boxsize=box)
+    work = new.clone()
+    mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=work, want_bkg=False)
+    bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
+    Vn = variance(ctx, work, bstd)
+    sdn = mini_std.cpu().numpy()
+    res['bkg_mini_new'], res['bkg_std_mini_new'] = mini.cpu().numpy(), sdn
+    hdr['BKG-SIZE'] = (box, '[pix] background boxsize used')
+    hdr['BKG-SUB'] = (False, 'sky background was subtracted?')          # the _red product keeps its sky
+    hdr['S-BKG'] = (float(np.median(res['bkg_mini_new'])), '[e-] median background full-frame image')
+    hdr['S-BKGSTD'] = (float(np.median(sdn)), '[e-] sigma (STD) background full-frame image')
+    res['data_bkgsub'], res['bkg_std'], res['var_new'] = work, bstd, Vn
+
+    sub_pn = subimage_psfs(ctx, psf_new, nsy, nsx, size) if psf_new is not None else None
+
+    # ---- full-source catalogue (a17): peaks of the background-subtracted frame above
+    # cat_nsigma x S-BKGSTD, PSF-weighted optimal flux at each (zogy.get_psfoptflux)
+    res['catalog'] = None
+    if cat_extract and sub_pn is not None:
+        thr = float(cat_nsigma) * hdr['S-BKGSTD'][0]
+        peaks = [p for p in find_transients(ctx, work, thr, max_out=max_sources) if p[2] > 0]
+        ok = new_mask[torch.as_tensor([p[0] for p in peaks], device=ctx.device, dtype=torch.long),
+                      torch.as_tensor([p[1] for p in peaks], device=ctx.device, dtype=torch.long)].cpu().numpy() == 0 \
+            if peaks else np.zeros(0, bool)
+        peaks = [p for p, k in zip(peaks, ok) if k]
+        ys, xs = [p[0] for p in peaks], [p[1] for p in peaks]
+        if peaks:
+            stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
+            f, e = psf_optflux(ctx, work, Vn, stamps, ys, xs)
+            f, e = f.cpu().numpy(), e.cpu().numpy()
+        else:
+            f = e = np.zeros(0, np.float32)
+        res['catalog'] = dict(Y_POS=np.asarray(ys, np.float32) + 1, X_POS=np.asarray(xs, np.float32) + 1,
+                              E_FLUX_PEAK=np.asarray([p[2] for p in peaks], np.float32), E_FLUX_OPT=f, E_FLUXERR_OPT=e,
+                              SNR_OPT=np.where(e > 0, f / np.where(e > 0, e, 1), 0).astype(np.float32))
+        hdr['NOBJECTS'] = (len(peaks), 'number of objects detected')
+    if not have_ref:
+        hdr['Z-P'] = (False, 'successfully processed by ZOGY?')
+        res['header'], res['header_new'], res['header_trans'], res['transients'] = _HeaderView(hdr, hdr_t), hdr, hdr_t, []
+        return res
+
+    # ---- reference frame on the new frame's grid: background-subtracted image + sigma image
+    rny, rnx = ref.shape
+    if ref_is_bkgsub:
+        rwork = ref
+        if ref_bkg_std_mini is None:
+            _, rstd_mini = get_back(ctx, ref, ref_mask, bkg_boxsize=box)
+            sdr = rstd_mini.cpu().numpy()
+        else:
+            sdr = np.asarray(ref_bkg_std_mini, np.float32)
+    else:
+        rmini, rstd_mini = get_back(ctx, ref, ref_mask, bkg_boxsize=box)
+        rwork = ref.clone()
+        mini2back(ctx, rmini, (rny, rnx), bkg_boxsize=box, interp_Xchan=True, subtract_from=rwork, want_bkg=False)
+        sdr = rstd_mini.cpu().numpy() if ref_bkg_std_mini is None else np.asarray(ref_bkg_std_mini, np.float32)
+        res['bkg_mini_ref'] = rmini.cpu().numpy()
+    res['bkg_std_mini_ref'] = sdr
+    if ref_grid is not None:
+        from . import coadd
+        ones = torch.ones_like(rwork)
+        rwork, _ = coadd.resample(ctx, rwork, ones, ref_grid, (ny, nx), 1.0, ref_grid_step)
+        sdr = remap_mini(sdr, np.asarray(ref_grid), (rny, rnx), box, ref_grid_step)
+    elif (rny, rnx) != (ny, nx):
+        raise ValueError('reference frame of another shape needs ref_grid')
+    # co-added reference: no channel structure in its noise -> interpolation across the frame
+    rbstd = mini2back(ctx, sdr, (ny, nx), bkg_boxsize=box, interp_Xchan=True)
+    Vr = variance(ctx, rwork, rbstd)
+    res['ref_bkgsub'], res['var_ref'] = rwork, Vr
+    hdr_t['S-BKGSTDR'] = (float(np.median(sdr)), '[e-] sigma (STD) background reference image')
+
+    # ---- sub-images
     bs = size // box if size % box == 0 else None
     scal = np.zeros((nsub, 6), np.float32)
     for k in range(nsub):
@@ -245,12 +383,18 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         else:
             tn, tr = sdn, sdr
         scal[k] = [np.median(tn), np.median(tr), 1.0, 1.0 / fratio if fratio else 1.0, dx, dy]
-    subs = [cut_subimages(ctx, a, size, border) for a in (N, Rr, Vn, Vr)]
-    Pn, Pr = embed_psfs(ctx, psf_new, L), embed_psfs(ctx, psf_ref, L)
+    sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
+    subs = [cut_subimages(ctx, a, size, border) for a in (work, rwork, Vn, Vr)]
+    Pn, Pr = embed_psfs(ctx, sub_pn, L), embed_psfs(ctx, sub_pr, L)
     D, S, Scorr, Fpsf, Fpsferr = run_zogy(ctx, subs[0], subs[1], Pn, Pr, subs[2], subs[3], scal)
+    del subs, Pn, Pr, S
     for name, a in (('D', D), ('Scorr', Scorr), ('Fpsf', Fpsf), ('Fpsferr', Fpsferr)):
         res[name] = stitch_subimages(ctx, a, (ny, nx), size, border)
-    trans = find_transients(ctx, res['Scorr'], nsigma)
+    del D, Scorr, Fpsf, Fpsferr
+
+    # ---- transient candidates: regions of |Scorr| >= T-NSIGMA, flux = Fpsf at the peak
+    nsig = settings.transient_nsigma if nsigma is None else nsigma
+    trans = find_transients(ctx, res['Scorr'], nsig)
     if trans:
         ys = torch.as_tensor([t[0] for t in trans], device=ctx.device)
         xs = torch.as_tensor([t[1] for t in trans], device=ctx.device)
@@ -258,9 +402,37 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         res['transients'] = [dict(y=t[0], x=t[1], scorr=t[2], fpsf=float(f[i]), fpsferr=float(e[i])) for i, t in enumerate(trans)]
     else:
         res['transients'] = []
-    sc = res['Scorr']
-    hdr['Z-SIZE'], hdr['Z-BSIZE'] = size, border
-    hdr['T-NTRANS'] = len(res['transients'])
-    res['header'] = hdr
+    hdr['Z-P'] = (True, 'successfully processed by ZOGY?')
+    for h in (hdr, hdr_t):
+        h['Z-SIZE'] = (size, '[pix] size of (square) ZOGY subimages')
+        h['Z-BSIZE'] = (border, '[pix] size of ZOGY subimage borders')
+    hdr_t['Z-DX'] = (float(dx), '[pix] dx median offset full image')
+    hdr_t['Z-DY'] = (float(dy), '[pix] dy median offset full image')
+    hdr_t['Z-FNR'] = (float(fratio), 'median flux ratio (Fnew/Fref) full image')
+    if frame_stats:
+        # statistics over the unmasked pixels (new frame's mask), clipped like zogy's header values
+        med, std = frame_clipped_stats(ctx, res['Scorr'], new_mask)
+        hdr_t['Z-SCMED'] = (med, 'median Scorr full image')
+        hdr_t['Z-SCSTD'] = (std, 'sigma (STD) Scorr full image')
+        med, std = frame_clipped_stats(ctx, res['Fpsferr'], new_mask)
+        hdr_t['Z-FPEMED'] = (med, '[e-] median Fpsferr full image')
+        hdr_t['Z-FPESTD'] = (std, '[e-] sigma (STD) Fpsferr full image')
+    hdr_t['T-NSIGMA'] = (float(nsig), '[sigma] transient detection threshold')
+    hdr_t['T-NTRANS'] = (len(res['transients']), 'number of transient candidates')
+    res['header'] = _HeaderView(hdr, hdr_t)
+    res['header_new'], res['header_trans'] = hdr, hdr_t
     res['scal'] = scal
     return res
+
+
+class _HeaderView(dict):
+    """header_new additions as {KEY: (value, comment)}; item access also finds header_trans
+    keys and returns plain values (what the callers of the tensor-level function read)"""
+
+    def __init__(self, hdr, hdr_t):
+        dict.__init__(self, hdr)
+        self._t = hdr_t
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k) if dict.__contains__(self, k) else self._t[k]
+        return v[0] if isinstance(v, tuple) else v

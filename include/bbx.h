@@ -83,7 +83,20 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * when needed.  Results are identical; a host that sees the level being needed
  * (d_stats[15] != 0) can switch the feed on for a while (pipeline.FramePipeline does). */
 #define BBX_OPT_LAC_LEVEL_FEED 1
+/* BBX_OPT_DEBUG_LISTCAP (default 0 = off): capacity of the LA-Cosmic work lists as the kernels see
+ * it, below the allocated one -- lets a test drive the list-overflow path (BBX_ERR_OVERFLOW ->
+ * COSMIC-P = False) with an ordinary frame. */
+#define BBX_OPT_DEBUG_LISTCAP 2
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
+
+/* Per-step attribution of device-side errors.  Kernels report list overflow / non-convergence by
+ * setting bits in a flag word of the context; the calls are asynchronous, so the host cannot see
+ * them when a stage function returns.  bbx_step_mark enqueues, on [stream], a move of the flags
+ * accumulated so far into *d_slot (device int32, caller-owned; e.g. one slot per stage inside the
+ * frame's packed result record) and clears them.  A host that marks after every stage reads, with
+ * the frame's scalars, which stage failed (bit 1 = BBX_ERR_OVERFLOW, bit 2 = BBX_ERR_NOTCONV) and
+ * applies the reference's convention: `<STEP>-P = False` and carry on (blackbox.py:1866-1878). */
+int  bbx_step_mark(bbx_ctx *ctx, int32_t *d_slot, void *stream);
 
 /* Stream plumbing for a host that pipelines frames (the reference runs one frame per worker
  * process, blackbox.py:640-700 pool_func; here one process keeps several frames in flight on
@@ -108,6 +121,7 @@ int  bbx_copy_async(void *dst, const void *src, size_t nbytes, int kind, void *s
 #define BBX_PROF_XTALK 3       /* k_xtalk                                     */
 #define BBX_PROF_VOS_STD 4     /* read-noise passes      (1 group / frame)   */
 #define BBX_PROF_MASK_FINISH 5 /* mask_init tail + fill  (1 group / frame)   */
+#define BBX_PROF_ZOGY 6        /* bbx_zogy_subimages     (1 group / frame)   */
 #define BBX_PROF_NSLOTS 8
 int  bbx_profile_enable(bbx_ctx *ctx, int on);
 /* synchronises on the recorded events; ms_total/calls have nslots entries; resets */
