@@ -254,6 +254,9 @@ class Reducer:
         header['KW-V'] = (KEYWORDS_VERSION, 'header keywords version used')
         header['BB-START'] = (time.strftime('%Y-%m-%dT%H:%M:%S', time.gmtime(t0)), 'start UTC date of BlackBOX image run')
         header['XTALK-F'] = (_base(a.crosstalk), 'name crosstalk coefficients file')
+        header.setdefault('GAIN', (1.0, '[e-/ADU] effective gain all channels'))
+        header.setdefault('GAIN-P', (True, 'corrected for gain?'))
+        header.setdefault('NONLIN-P', (False, 'corrected for non-linearity?'))
         header['NONLIN-F'] = (_base(a.nonlin) if R.hval(header, 'NONLIN-P') else 'None', 'name non-linearity correction file')
         header['MBIAS-F'] = (_stem(a.mbias) if header.get('MBIAS-P') and R.hval(header, 'MBIAS-P') else 'None',
                              'name of master bias applied')

@@ -14,7 +14,7 @@ import torch
 from scipy import ndimage
 
 from . import settings
-from ._lib import lib, check
+from ._lib import lib, check, BBXError as _lib_BBXError
 from .catalogs import format_cat, transient_table         # noqa: F401  (zogy.format_cat)
 
 NPAD = 12          # scipy.ndimage.zoom pads 'nearest' inputs by 12 samples before prefiltering
@@ -85,6 +85,9 @@ def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_fr
     mini_h = mini.cpu().numpy() if torch.is_tensor(mini) else np.asarray(mini)
     channels = None
     if not interp_Xchan:
+        if mini_h.shape[0] % settings.ny or mini_h.shape[1] % settings.nx:
+            raise ValueError('interp_Xchan=False needs a whole number of boxes per channel: mini image {}x{} over {}x{} channels'
+                             .format(mini_h.shape[0], mini_h.shape[1], settings.ny, settings.nx))
         channels = (mini_h.shape[0] // settings.ny, mini_h.shape[1] // settings.nx)
     coef, fy, wy, fx, wx = zoom_plan(mini_h, box, channels)
     dev = ctx.device
@@ -394,7 +397,13 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
 
     # ---- transient candidates: regions of |Scorr| >= T-NSIGMA, flux = Fpsf at the peak
     nsig = settings.transient_nsigma if nsigma is None else nsigma
-    trans = find_transients(ctx, res['Scorr'], nsig)
+    try:
+        trans = find_transients(ctx, res['Scorr'], nsig)
+        ntrans = len(trans)
+    except _lib_BBXError:
+        # more significant pixels than the candidate list holds (a failed subtraction: wrong
+        # reference, gross misalignment): the images stand, the candidate table stays empty
+        trans, ntrans = [], 'None'
     if trans:
         ys = torch.as_tensor([t[0] for t in trans], device=ctx.device)
         xs = torch.as_tensor([t[1] for t in trans], device=ctx.device)
@@ -418,7 +427,7 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         hdr_t['Z-FPEMED'] = (med, '[e-] median Fpsferr full image')
         hdr_t['Z-FPESTD'] = (std, '[e-] sigma (STD) Fpsferr full image')
     hdr_t['T-NSIGMA'] = (float(nsig), '[sigma] transient detection threshold')
-    hdr_t['T-NTRANS'] = (len(res['transients']), 'number of transient candidates')
+    hdr_t['T-NTRANS'] = (ntrans, 'number of transient candidates')
     res['header'] = _HeaderView(hdr, hdr_t)
     res['header_new'], res['header_trans'] = hdr, hdr_t
     res['scal'] = scal

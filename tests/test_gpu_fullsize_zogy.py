@@ -155,17 +155,33 @@ def test_zogy_fullsize(scene):
                                        cut(Vr, sy, sx), dx, dy)
         inner = (slice(BORDER, BORDER + SIZE), slice(BORDER, BORDER + SIZE))
         tile = (slice(sy * SIZE, (sy + 1) * SIZE), slice(sx * SIZE, (sx + 1) * SIZE))
+        # float32 rounding of a 2-D FFT spreads along the row and the column of a bright pixel (the
+        # row pass and the column pass each round at ~1e-7 of the largest value in their line): the
+        # images carry errors of ~2e-6 of the brightest input pixel of their row / column, on both
+        # sides (tools/dbg/zogy_dbg.py: HIP and numpy complex64 are equally far from a float64
+        # evaluation, 0.22 / 0.24 e- on the rows of a saturated star with 1.4e5 e- pixels)
+        a = np.abs(cut(Nw, sy, sx)) + np.abs(cut(Rw, sy, sx))
+        big = np.maximum(a.max(axis=1)[:, None], a.max(axis=0)[None, :])[inner]
+        fe = Fe[inner]
         for key, want in (('D', D), ('Scorr', Sc), ('Fpsf', Fp), ('Fpsferr', Fe)):
             got = res[key][tile].cpu().numpy()
             want = want[inner]
             # local noise of the image: 1.4826 * MAD of the oracle tile (Fpsferr: its median level)
             noise = np.median(want) if key == 'Fpsferr' else 1.4826 * np.median(np.abs(want - np.median(want)))
             ok = np.isfinite(want)
-            err = np.abs(got[ok] - want[ok]).max() / noise
-            worst[(key, k)] = err
             assert np.array_equal(np.isfinite(got), ok)
-            assert err <= 5e-3, (key, (sy, sx), err, noise)
-    print('ZOGY full size, max |HIP - oracle| / local noise:', {k: float('%.2e' % v) for k, v in worst.items()})
+            # per-pixel tolerance: 5e-3 of the local noise + 4e-6 of the brightest input pixel of the row /
+            # column, in the image's own units (the matched filter sums ~ N_eff = 36 pixels of D for
+            # Fpsf: x 6; Scorr = S / sigma_S with sigma_S / F_S = Fpsferr)
+            unit = {'D': 1.0, 'Fpsf': 6.0, 'Fpsferr': 6.0, 'Scorr': 6.0 / np.maximum(fe, 1e-3)}[key]
+            tol = 5e-3 * noise + 4e-6 * big * unit
+            err = np.abs(got - want)
+            worst[(key, k)] = (float((err[ok] / noise).max()), float((err[ok] / tol[ok]).max()))
+            assert (err[ok] <= tol[ok]).all(), (key, (sy, sx), worst[(key, k)], noise)
+            # on lines without a bright star (nothing above 2000 e-) the local-noise term alone holds
+            sky = ok & (big < 2e3)
+            assert sky.sum() > 0.3 * sky.size and (err[sky] <= 6e-3 * noise).all(), (key, (sy, sx), float((err[sky] / noise).max()))
+    print('ZOGY full size, max |HIP - oracle| (/ local noise, / tolerance):', worst)
     # Scorr of the unmasked frame ~ N(0, 1) (QC ranges set_qc.py:382-383)
     assert abs(hdr['Z-SCMED'][0]) < 0.3 and abs(hdr['Z-SCSTD'][0] - 1) < 0.15
     # injected transients: found within a pixel, flux within 3 sigma + 5 %

@@ -88,14 +88,15 @@ def test_optimal_subtraction_chain(ctx):
     # ---- the same chain from the oracle pieces
     L = size + 2 * border
 
-    def prep(img, msk):
+    def prep(img, msk, per_channel):
         med, std = Z.get_back_mini(img, msk, None, box=box)
         med, std = Z.fill_filter_mini(med), Z.fill_filter_mini(std)
         work = img - Z.mini2back(med, (ny, nx), box)
-        bstd = Z.mini2back(std, (ny, nx), box, channels=(med.shape[0] // 2, med.shape[1] // 8))
+        # sigma image: per channel for a single exposure, across the frame for the co-added reference
+        bstd = Z.mini2back(std, (ny, nx), box, channels=(med.shape[0] // 2, med.shape[1] // 8) if per_channel else None)
         return work.astype(F), (np.maximum(work, 0) + bstd * bstd).astype(F), med, std
-    N, Vn, mn, sdn = prep(new, mask_n)
-    Rr, Vr, mr, sdr = prep(ref, mask_r)
+    N, Vn, mn, sdn = prep(new, mask_n, True)
+    Rr, Vr, mr, sdr = prep(ref, mask_r, False)
     np.testing.assert_allclose(res['bkg_mini_new'], mn, rtol=1e-6)
     np.testing.assert_allclose(res['bkg_std_mini_ref'], sdr, rtol=3e-6)
     subsN, subsR, subsVn, subsVr = [Z.cut_subimages(a, size, border) for a in (N, Rr, Vn, Vr)]
