@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := blackbox_amd/csrc
 SRCS  := $(CSRC)/bbx_ctx.hip $(CSRC)/bbx_overscan.hip $(CSRC)/bbx_calibrate.hip \
          $(CSRC)/bbx_mask.hip $(CSRC)/bbx_select.hip $(CSRC)/bbx_lacosmic.hip $(CSRC)/bbx_xtalk.hip \
-         $(CSRC)/bbx_stack.hip $(CSRC)/bbx_bkg.hip $(CSRC)/bbx_zogy.hip $(CSRC)/bbx_sat.hip $(CSRC)/bbx_psf.hip $(CSRC)/bbx_fpack.hip $(CSRC)/bbx_coadd.hip
+         $(CSRC)/bbx_stack.hip $(CSRC)/bbx_bkg.hip $(CSRC)/bbx_zogy.hip $(CSRC)/bbx_zogy2.hip $(CSRC)/bbx_sat.hip $(CSRC)/bbx_psf.hip $(CSRC)/bbx_fpack.hip $(CSRC)/bbx_coadd.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := blackbox_amd/libbbx_hip.so
 HOSTLIB := blackbox_amd/libbbx_host.so
@@ -17,7 +17,10 @@ all: $(LIB) $(HOSTLIB)
 $(HOSTLIB): blackbox_amd/chost/bbx_host.c
 	gcc -O3 -fPIC -shared -ffp-contract=off -fno-trapping-math -fno-math-errno -o $@ $< -lm
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h $(CSRC)/bbx_bsel.h include/bbx.h
+$(CSRC)/bbx_fft_gen.h: tools/gen_fft.py
+	python3 tools/gen_fft.py
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/bbx_common.h $(CSRC)/bbx_mednet.h $(CSRC)/bbx_bsel.h $(CSRC)/bbx_fft_gen.h include/bbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

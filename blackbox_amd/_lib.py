@@ -88,6 +88,8 @@ SIGNATURES = {
     'bbx_cut_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_stitch_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_zogy_subimages': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_zogy_frame_supported': (_i, [_i]),
+    'bbx_zogy_frame': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_find_peaks': (_i, [_vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_count_objects': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

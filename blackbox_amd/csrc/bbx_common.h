@@ -60,6 +60,7 @@ struct bbx_ctx {
     int    lac_feed;           // BBX_OPT_LAC_LEVEL_FEED (bbx_set_option)
     int    debug_listcap;      // BBX_OPT_DEBUG_LISTCAP: capacity the LA-Cosmic kernels see (0 = the allocated one)
     void*  zogy_state;         // per-context FFT plans / work buffer of bbx_zogy.hip (NULL until first use)
+    void*  zogy2_state;        // twiddle table of bbx_zogy2.hip
     int    num_cus;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     // --- optional per-kernel timing (bbx_profile_enable): hipEvent pairs on the launch stream
     int prof_on, prof_n;
@@ -98,6 +99,7 @@ enum {
 };
 
 int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line);
+void bbx_zogy2_release(bbx_ctx* ctx);     // bbx_zogy2.hip
 void bbx_zogy_release(bbx_ctx* ctx);      // bbx_zogy.hip: frees ctx->zogy_state (called by bbx_ctx_destroy)
 void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc);
 

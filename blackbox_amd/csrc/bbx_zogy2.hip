@@ -1,0 +1,659 @@
+// bbx_zogy2.hip -- ZOGY on whole frames with a hand-written 2-D FFT (gfx950).
+// (zogy.optimal_subtraction -> run_ZOGY, called at blackbox.py:2350-2354 / 2460-2465; Zackay,
+// Ofek & Gal-Yam 2016.  [EXT: parity unpinned, conventions = oracle/zogy_core.py])
+//
+// Why not rocFFT: a batched 2-D real transform of 1400 x 1400 runs as four kernels (two 1-D
+// passes and two transposes) that each move the whole batch through HBM, and the element-wise
+// ZOGY algebra needs four more passes: 17.4 ms per frame for 3.8 GB of algorithmic I/O
+// (profiles/r01_stage_bench.json).  Here every kernel is "load NL lines -> 1-D FFTs in LDS ->
+// point-wise algebra in registers -> (more FFTs) -> store", and the transposition between the
+// row and the column pass is the store pattern of the producing kernel (NL x 8-byte runs):
+//
+//   sub-image side L = N1 * N2 (1400 = 35 * 40).  One line of L complex values lives in LDS; a
+//   1-D FFT is two steps of register DFTs (tools/gen_fft.py), thread-private in both steps:
+//     forward : step 1, thread n2: DFT_N1 over x[N2 n1 + n2], times W_L^(n2 k1), in place;
+//               barrier; step 2, thread k1: DFT_N2 over n2 -> X[k1 + N1 k2] in registers,
+//               i.e. the spectrum in the digit-swapped order pos(k) = N2 (k mod N1) + k div N1
+//     inverse : the same backwards from that order (no reordering pass anywhere: the
+//               point-wise algebra between a forward and an inverse transform does not care)
+//   Real rows are transformed in pairs (a + i b), the two half spectra come out of the
+//   Hermitian split; the inverse row pass packs two half spectra the same way.
+//
+// Launch sequence for one frame of nsub sub-images (layouts: T = [sub][kx][y], U = [sub][y][kx],
+// C = [sub][kx group][k2][k1][line] -- the register order of the column kernels):
+//   k_psf_cols   PSF stamps -> Pn^, Pr^ (the row DFT of the few non-zero rows is summed directly)
+//                -> coefficient arrays A, B, kn^, kr^ (C) + F_S partial sums; kn^, kr^ back
+//                through the inverse column pass (U)
+//   k_psf_rows   inverse row pass -> kr, kn (real) -> squares -> forward row pass (T)
+//   k_k2_cols    forward column pass of (kr^2)^, (kn^2)^ (C)
+//   k_img_rows   cut of the frames + forward row pass of (N, R) and (Vn, Vr); V = max(d,0)+sigma^2
+//   k_img_cols   column pass: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^, inverse column pass (U)
+//   k_var_cols   column pass: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^, inverse column pass (U)
+//   k_final_rows inverse row pass of (D, V_S) and (Sn, Sr); S = Sn - Sr; S_corr with the
+//                astrometric variance from the finite differences of Sn, Sr; F_psf, F_psf_err;
+//                written straight into the full-frame outputs (borders dropped)
+// HBM traffic: ~44 passes of nsub * L * (L/2+1) * 8 bytes = 22 GB per frame of 64 x 1400^2.
+#include "bbx_common.h"
+#include "bbx_fft_gen.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace z2 {
+
+// compiler-level fence: keeps the scheduler from hoisting every load of an unrolled loop to its top
+#define FENCE() asm volatile("" ::: "memory")
+
+struct zscal { float sn, sr, fn, fr, dx, dy; };
+
+constexpr int floor_pow2(int v) { int p = 1; while (2 * p <= v) p *= 2; return p; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+// line stride in float2: >= lp, and 2 * stride = 8 (mod 64) dwords so that the NL lines of one
+// wave-instruction start on different banks
+constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; return s; }
+
+template <int N1_, int N2_> struct Plan {
+    static constexpr int N1 = N1_, N2 = N2_, L = N1_ * N2_, H = L / 2 + 1;
+    static constexpr int NT = cmax(N1_, N2_);                       // thread tasks per line
+    static constexpr int NL = cmin(16, floor_pow2(320 / NT));       // lines per workgroup
+    static constexpr int THREADS = ((NL * NT + 63) / 64) * 64;
+    static constexpr int G = (H + NL - 1) / NL, HP = G * NL;        // column groups, padded half-spectrum width
+    static constexpr int LP = N1_ * (N2_ + 1);                      // padded line: one pad per N2 entries
+    static constexpr int LS = line_stride(LP);
+    static constexpr int CT = NL * N1_;                             // step-2 thread tasks per workgroup
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+template <int N> __device__ __forceinline__ void idft(float2 (&x)[N]) {      // inverse = forward on swapped pairs
+#pragma unroll
+    for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
+    bbx_dft<N>::run(x);
+#pragma unroll
+    for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
+}
+
+template <class P> __device__ __forceinline__ int ppos(int k) { return (P::N2 + 1) * (k % P::N1) + k / P::N1; }   // spectrum order
+template <class P> __device__ __forceinline__ int npos(int n) { return n + n / P::N2; }                              // natural order
+
+// ---- the two steps (line = this thread's line in LDS, t = task index) ------------------------
+// forward step 1 on values already in registers (x[n1] = sample N2 n1 + t), result to LDS
+template <class P> __device__ __forceinline__ void fwd_step1_regs(float2 (&x)[P::N1], float2* line, int t, const float2* __restrict__ tw) {
+    bbx_dft<P::N1>::run(x);
+#pragma unroll
+    for (int k1 = 0; k1 < P::N1; k1++) line[(P::N2 + 1) * k1 + t] = cmul(x[k1], tw[t * k1]);
+}
+template <class P> __device__ __forceinline__ void fwd_step1(float2* line, int t, const float2* __restrict__ tw) {
+    float2 x[P::N1];
+#pragma unroll
+    for (int n1 = 0; n1 < P::N1; n1++) x[n1] = line[(P::N2 + 1) * n1 + t];
+    fwd_step1_regs<P>(x, line, t, tw);
+}
+// forward step 2: thread t = k1 -> X[k1 + N1 k2] in x[k2]
+template <class P> __device__ __forceinline__ void fwd_step2(const float2* line, int t, float2 (&x)[P::N2]) {
+#pragma unroll
+    for (int n2 = 0; n2 < P::N2; n2++) x[n2] = line[(P::N2 + 1) * t + n2];
+    bbx_dft<P::N2>::run(x);
+}
+// inverse step 2 from registers (x[k2] of thread t = k1), result to LDS
+template <class P> __device__ __forceinline__ void inv_step2(float2 (&x)[P::N2], float2* line, int t, const float2* __restrict__ tw) {
+    idft<P::N2>(x);
+#pragma unroll
+    for (int n2 = 0; n2 < P::N2; n2++) line[(P::N2 + 1) * t + n2] = cmulc(x[n2], tw[n2 * t]);
+}
+// inverse step 1: thread t = n2 -> x[n1] = (unnormalised) sample N2 n1 + t
+template <class P> __device__ __forceinline__ void inv_step1(const float2* line, int t, float2 (&x)[P::N1]) {
+#pragma unroll
+    for (int k1 = 0; k1 < P::N1; k1++) x[k1] = line[(P::N2 + 1) * k1 + t];
+    idft<P::N1>(x);
+}
+// whole transforms for all lines of the workgroup (barriers inside; every thread must call)
+template <class P> __device__ __forceinline__ void fwd_lines(float2* s, int l, int t, const float2* tw, float2 (&X)[P::N2]) {
+    if (t < P::N2) fwd_step1<P>(s + l * P::LS, t, tw);
+    __syncthreads();
+    if (t < P::N1) fwd_step2<P>(s + l * P::LS, t, X);
+}
+template <class P> __device__ __forceinline__ void inv_lines(float2 (&X)[P::N2], float2* s, int l, int t, const float2* tw, float2 (&x)[P::N1]) {
+    if (t < P::N1) inv_step2<P>(X, s + l * P::LS, t, tw);
+    __syncthreads();
+    if (t < P::N2) inv_step1<P>(s + l * P::LS, t, x);
+}
+
+// store the inverse column pass (thread t = n2 holds y = N2 n1 + t of column g NL + l) to the U layout
+template <class P> __device__ __forceinline__ void store_u(float2* __restrict__ U, int sub, int g, int l, int t, const float2 (&x)[P::N1]) {
+    float2* base = U + ((size_t)sub * P::L) * P::HP + (size_t)g * P::NL + l;
+#pragma unroll
+    for (int n1 = 0; n1 < P::N1; n1++) base[(size_t)(P::N2 * n1 + t) * P::HP] = x[n1];
+}
+// load NL lines of a T-layout array ([sub][kx][y], kx = g NL + l) into LDS, natural order
+template <class P> __device__ __forceinline__ void load_t_lines(const float2* __restrict__ T, int sub, int g, float2* s) {
+    const float2* src = T + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L;      // NL contiguous lines
+    for (int e = threadIdx.x; e < P::NL * P::L; e += P::THREADS) {
+        const int l = e / P::L, y = e - l * P::L;
+        s[l * P::LS + npos<P>(y)] = src[e];
+    }
+}
+// Hermitian packing of two U-layout half spectra (rows y0 .. y0+NL-1) into full complex lines in
+// spectrum order: Z[k] = a[k] + i b[k]
+template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int y0,
+                                                               float2* s) {
+    for (int e = threadIdx.x; e < P::NL * P::HP; e += P::THREADS) {
+        const int l = e / P::HP, kx = e - l * P::HP;
+        const int y = y0 + l;
+        if (kx >= P::H) continue;
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (y >= 0 && y < P::L) {
+            const size_t o = ((size_t)sub * P::L + y) * P::HP + kx;
+            a = Ua[o]; b = Ub[o];
+        }
+        float2* line = s + l * P::LS;
+        line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
+        if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
+    }
+}
+// Hermitian split of a packed transform Z (LDS, spectrum order) -> two half spectra, T layout
+template <class P> __device__ __forceinline__ void store_t_split(const float2* s, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub, int y0) {
+    for (int e = threadIdx.x; e < P::NL * P::H; e += P::THREADS) {
+        const int kx = e / P::NL, l = e - kx * P::NL;
+        const int y = y0 + l;
+        if (y >= P::L) continue;
+        const float2* line = s + l * P::LS;
+        const float2 zk = line[ppos<P>(kx)], zm = line[ppos<P>(kx ? P::L - kx : 0)];
+        const size_t o = ((size_t)sub * P::HP + kx) * P::L + y;
+        Ta[o] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        Tb[o] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+    }
+}
+
+// ---- PSF side ---------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
+                                                         const zscal* __restrict__ sc, const float2* __restrict__ tw,
+                                                         float2* __restrict__ cA, float2* __restrict__ cB, float2* __restrict__ cKn,
+                                                         float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
+                                                         double* __restrict__ fs_partial) {
+    extern __shared__ float2 s[];
+    __shared__ double red[P::THREADS / 64];
+    const int g = blockIdx.x, sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    const int kx = g * P::NL + l, h = S / 2;
+    float2 X[P::N2];
+    const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
+    for (int pass = 0; pass < 2; pass++) {
+        const float* st = (pass ? psf_r : psf_n) + (size_t)sub * S * S;
+        for (int e = threadIdx.x; e < P::NL * P::LS; e += P::THREADS) s[e] = make_float2(0.f, 0.f);
+        __syncthreads();
+        // row DFT of the S non-zero rows, summed directly: line[y] = sum_x p[y][x] W^(kx x)
+        for (int e = threadIdx.x; e < P::NL * S; e += P::THREADS) {
+            const int ll = e % P::NL, j = e / P::NL;
+            const int kk = g * P::NL + ll;
+            if (kk >= P::H) continue;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int i = 0; i < S; i++) {
+                const int xw = ((i - h) % P::L + P::L) % P::L;
+                const float2 w = tw[(int)(((long long)kk * xw) % P::L)];
+                const float p = st[j * S + i];
+                acc.x += p * w.x; acc.y += p * w.y;
+            }
+            const int y = ((j - h) % P::L + P::L) % P::L;
+            s[ll * P::LS + npos<P>(y)] = acc;
+        }
+        __syncthreads();
+        fwd_lines<P>(s, l, t, tw, X);
+        if (pass == 0 && t < P::N1) {
+            // Pn^ waits in the (not yet written) A array while Pr^ is transformed: one spectrum in registers at a time
+#pragma unroll
+            for (int k2 = 0; k2 < P::N2; k2++) cA[cbase + (size_t)k2 * P::CT] = X[k2];
+        }
+        __syncthreads();
+    }
+    const zscal z = sc[sub];
+    const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
+    double fs = 0.0;
+    if (t < P::N1) {
+        const bool live = kx < P::H;
+        const double wgt = (kx == 0 || (P::L % 2 == 0 && kx == P::L / 2)) ? 1.0 : 2.0;
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) {
+            const size_t o = cbase + (size_t)k2 * P::CT;
+            float2 a = make_float2(0.f, 0.f), b = a, kn = a, kr = a;
+            if (live) {
+                const float2 pn = cA[o], pr = X[k2];
+                const float pn2 = pn.x * pn.x + pn.y * pn.y, pr2 = pr.x * pr.x + pr.y * pr.y;
+                const float den = (sn2 * fr2) * pr2 + (sr2 * fn2) * pn2;
+                const float isd = 1.0f / sqrtf(den);
+                a = cscale(pr, z.fr * isd);                                   // D^ = A N^ - B R^
+                b = cscale(pn, z.fn * isd);
+                kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 / den);
+                kn = cscale(make_float2(pn.x, -pn.y), z.fn * fr2 * pr2 / den);
+                fs += wgt * (double)(fn2 * pn2 * fr2 * pr2 / den);
+            }
+            cA[o] = a; cB[o] = b; cKn[o] = kn; cKr[o] = kr;
+            X[k2] = kr;
+        }
+    }
+    float2 x[P::N1];
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) store_u<P>(Ukr, sub, g, l, t, x);
+    __syncthreads();
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = cKn[cbase + (size_t)k2 * P::CT];       // written by this thread above
+    }
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) store_u<P>(Ukn, sub, g, l, t, x);
+    fs = wave_sum_f64(fs);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = fs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < P::THREADS / 64; i++) tot += red[i];
+        fs_partial[(size_t)sub * P::G + g] = tot;
+    }
+}
+
+// inverse row pass of kr^, kn^ -> kr, kn -> squares -> forward row pass, T layout
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
+                                                         const float2* __restrict__ tw, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2) {
+    extern __shared__ float2 s[];
+    const int y0 = blockIdx.x * P::NL, sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    load_u_pair<P>(Ukr, Ukn, sub, y0, s);
+    __syncthreads();
+    float2 X[P::N2], x[P::N1];
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
+    }
+    inv_lines<P>(X, s, l, t, tw, x);
+    __syncthreads();
+    if (t < P::N2) {
+#pragma unroll
+        for (int n1 = 0; n1 < P::N1; n1++) { const float a = x[n1].x * inv_n2, b = x[n1].y * inv_n2; x[n1] = make_float2(a * a, b * b); }
+        fwd_step1_regs<P>(x, s + l * P::LS, t, tw);
+    }
+    __syncthreads();
+    if (t < P::N1) {
+        fwd_step2<P>(s + l * P::LS, t, X);
+    }
+    __syncthreads();
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) s[l * P::LS + (P::N2 + 1) * t + k2] = X[k2];
+    }
+    __syncthreads();
+    store_t_split<P>(s, Tkr2, Tkn2, sub, y0);
+}
+
+// forward column pass of one T-layout array -> C layout
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ tw, float2* __restrict__ Cout) {
+    extern __shared__ float2 s[];
+    const int g = blockIdx.x, sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    load_t_lines<P>(T, sub, g, s);
+    __syncthreads();
+    float2 X[P::N2];
+    fwd_lines<P>(s, l, t, tw, X);
+    if (t < P::N1) {
+        const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) Cout[cbase + (size_t)k2 * P::CT] = X[k2];
+    }
+}
+
+// ---- image side -------------------------------------------------------------------------------
+struct frame_args {
+    const float* a; const float* b;          // the two frames of a pair (new, ref) or their sigma images
+    const float* sa; const float* sb;        // sigma images (variance pair) or NULL
+    int ny, nx, size, border, nsx;
+};
+
+// cut + forward row pass of a pair of real frames: (N, R) or, with sigma images, (Vn, Vr)
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_img_rows(frame_args f, const float2* __restrict__ tw, float2* __restrict__ Ta,
+                                                         float2* __restrict__ Tb) {
+    extern __shared__ float2 s[];
+    const int y0 = blockIdx.x * P::NL, sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    const int sy = sub / f.nsx, sx = sub - sy * f.nsx;
+    const int Y0 = sy * f.size - f.border, X0 = sx * f.size - f.border;
+    for (int e = threadIdx.x; e < P::NL * P::L; e += P::THREADS) {
+        const int ll = e / P::L, x = e - ll * P::L;
+        const int Y = Y0 + y0 + ll, X = X0 + x;
+        float2 v = make_float2(0.f, 0.f);
+        if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
+            const size_t o = (size_t)Y * f.nx + X;
+            v.x = f.a[o]; v.y = f.b[o];
+            if (f.sa) { const float p = f.sa[o], q = f.sb[o]; v.x = fmaxf(v.x, 0.f) + p * p; v.y = fmaxf(v.y, 0.f) + q * q; }
+        }
+        s[ll * P::LS + npos<P>(x)] = v;
+    }
+    __syncthreads();
+    float2 X[P::N2];
+    fwd_lines<P>(s, l, t, tw, X);
+    __syncthreads();
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) s[l * P::LS + (P::N2 + 1) * t + k2] = X[k2];
+    }
+    __syncthreads();
+    store_t_split<P>(s, Ta, Tb, sub, y0);
+}
+
+// column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U layout)
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_img_cols(float2* TN, const float2* __restrict__ TR,
+                                                         const float2* __restrict__ cA, const float2* __restrict__ cB,
+                                                         const float2* __restrict__ cKn, const float2* __restrict__ cKr,
+                                                         const float2* __restrict__ tw, float2* __restrict__ UD, float2* __restrict__ USn,
+                                                         float2* __restrict__ USr) {
+    extern __shared__ float2 s[];
+    const int g = blockIdx.x, sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
+    float2 X[P::N2], x[P::N1];
+    // the partial D^ = A N^ waits in this workgroup's own (already consumed) lines of T_N, in the
+    // register order of the C layout (coalesced; it stays in the XCD's L2 for the few microseconds)
+    float2* park = TN + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L + (size_t)t * P::NL + l;
+    load_t_lines<P>(TN, sub, g, s);
+    __syncthreads();
+    fwd_lines<P>(s, l, t, tw, X);
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) {
+            const size_t o = cbase + (size_t)k2 * P::CT;
+            park[(size_t)k2 * P::CT] = cmul(cA[o], X[k2]);
+            X[k2] = cmul(cKn[o], X[k2]);
+        }
+    }
+    __syncthreads();
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) store_u<P>(USn, sub, g, l, t, x);
+    __syncthreads();
+    load_t_lines<P>(TR, sub, g, s);
+    __syncthreads();
+    fwd_lines<P>(s, l, t, tw, X);
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) {
+            const size_t o = cbase + (size_t)k2 * P::CT;
+            const float2 br = cmul(cB[o], X[k2]), da = park[(size_t)k2 * P::CT];
+            park[(size_t)k2 * P::CT] = make_float2(da.x - br.x, da.y - br.y);
+            X[k2] = cmul(cKr[o], X[k2]);
+        }
+    }
+    __syncthreads();
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) store_u<P>(USr, sub, g, l, t, x);
+    __syncthreads();
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = park[(size_t)k2 * P::CT];
+    }
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) store_u<P>(UD, sub, g, l, t, x);
+}
+
+// column pass of the variance pair: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^ and back (U layout)
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_var_cols(float2* TVn, const float2* __restrict__ TVr,
+                                                         const float2* __restrict__ cK2n, const float2* __restrict__ cK2r,
+                                                         const float2* __restrict__ tw, float2* __restrict__ UVS) {
+    extern __shared__ float2 s[];
+    const int g = blockIdx.x, sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
+    float2 X[P::N2], x[P::N1];
+    float2* park = TVn + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L + (size_t)t * P::NL + l;
+    load_t_lines<P>(TVn, sub, g, s);
+    __syncthreads();
+    fwd_lines<P>(s, l, t, tw, X);
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) park[(size_t)k2 * P::CT] = cmul(cK2n[cbase + (size_t)k2 * P::CT], X[k2]);
+    }
+    __syncthreads();
+    load_t_lines<P>(TVr, sub, g, s);
+    __syncthreads();
+    fwd_lines<P>(s, l, t, tw, X);
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) {
+            const float2 v = cmul(cK2r[cbase + (size_t)k2 * P::CT], X[k2]), a = park[(size_t)k2 * P::CT];
+            X[k2] = make_float2(a.x + v.x, a.y + v.y);
+        }
+    }
+    __syncthreads();
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) store_u<P>(UVS, sub, g, l, t, x);
+}
+
+struct out_args {
+    float* D; float* S; float* Scorr; float* Fpsf; float* Fpsferr;      // full frames [ny][nx]; S may be NULL
+    int ny, nx, size, border, nsx;
+};
+
+// inverse row pass of (D, V_S) and (Sn, Sr) + the final algebra, written into the full frames.
+// A workgroup takes NL rows of a sub-image: row 0 is the halo (y - 1) of the NL - 1 output rows.
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void k_final_rows(const float2* __restrict__ UD, const float2* __restrict__ UVS,
+                                                           const float2* __restrict__ USn, const float2* __restrict__ USr,
+                                                           const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
+                                                           float inv_n2, const float2* __restrict__ tw, out_args o) {
+    extern __shared__ float2 s[];
+    float* stage = (float*)(s + P::NL * P::LS);                     // [NL][L] output staging
+    __shared__ float s_fs;
+    const int sub = blockIdx.y;
+    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
+    const int yfirst = o.border + blockIdx.x * (P::NL - 1) - 1;     // sub-image row of line 0 (may be -1: wraps)
+    const zscal z = sc[sub];
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int g = 0; g < P::G; g++) tot += fs_partial[(size_t)sub * P::G + g];
+        s_fs = (float)(tot / ((double)P::L * (double)P::L));
+    }
+    const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
+    const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
+    const int sy = sub / o.nsx, sx = sub - sy * o.nsx;
+    // rows are taken modulo L (np.roll semantics of the finite differences at y = 0)
+    const int ybase = ((yfirst % P::L) + P::L) % P::L;
+    auto load_pair = [&](const float2* __restrict__ Ua, const float2* __restrict__ Ub) {
+        if (ybase + P::NL <= P::L) { load_u_pair<P>(Ua, Ub, sub, ybase, s); return; }
+        for (int e = threadIdx.x; e < P::NL * P::HP; e += P::THREADS) {       // the block straddles the wrap: row by row
+            const int ll = e / P::HP, kx = e - ll * P::HP;
+            if (kx >= P::H) continue;
+            const int y = (ybase + ll) % P::L;
+            const size_t q = ((size_t)sub * P::L + y) * P::HP + kx;
+            const float2 a = Ua[q], b = Ub[q];
+            float2* line = s + ll * P::LS;
+            line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
+            if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
+        }
+    };
+    auto write_rows = [&](float* dst) {                           // staging rows 1 .. NL-1 -> the frame
+        __syncthreads();
+        for (int e = threadIdx.x; e < (P::NL - 1) * o.size; e += P::THREADS) {
+            const int ll = 1 + e / o.size, xi = e - (ll - 1) * o.size;
+            const int y = yfirst + ll;                               // sub-image row
+            if (y >= o.border + o.size) continue;
+            const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
+            if (Y < o.ny && Xf < o.nx) dst[(size_t)Y * o.nx + Xf] = stage[ll * P::L + o.border + xi];
+        }
+        __syncthreads();
+    };
+    float2 X[P::N2], x[P::N1];
+    float vs[P::N1];
+    // (D, V_S): D goes out at once, V_S stays in registers
+    load_pair(UD, UVS);
+    __syncthreads();
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
+    }
+    inv_lines<P>(X, s, l, t, tw, x);
+    if (t < P::N2) {
+#pragma unroll
+        for (int n1 = 0; n1 < P::N1; n1++) { stage[l * P::L + P::N2 * n1 + t] = x[n1].x * inv_n2 / fD; vs[n1] = x[n1].y * inv_n2; }
+    }
+    write_rows(o.D);
+    // (Sn, Sr)
+    load_pair(USn, USr);
+    __syncthreads();
+    if (t < P::N1) {
+#pragma unroll
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
+    }
+    inv_lines<P>(X, s, l, t, tw, x);
+    __syncthreads();
+    // Sn, Sr (scaled) in natural order for the neighbour reads
+    if (t < P::N2) {
+#pragma unroll
+        for (int n1 = 0; n1 < P::N1; n1++) s[l * P::LS + npos<P>(P::N2 * n1 + t)] = cscale(x[n1], inv_n2);
+    }
+    __syncthreads();
+    const float fs = s_fs;
+    // the other four outputs, one at a time through the staging rows
+    for (int which = 1; which < 5; which++) {
+        float* dst = which == 1 ? o.S : which == 2 ? o.Scorr : which == 3 ? o.Fpsf : o.Fpsferr;
+        if (!dst) continue;                                       // workgroup-uniform
+        if (t < P::N2 && l >= 1) {
+#pragma unroll
+            for (int n1 = 0; n1 < P::N1; n1++) {
+                const int xx = P::N2 * n1 + t;
+                const float2 c = s[l * P::LS + npos<P>(xx)];                   // (Sn, Sr) here
+                const float sval = c.x - c.y;                                   // S = Sn - Sr
+                float v;
+                if (which == 1) v = sval;
+                else if (which == 2) {
+                    const int xm = xx == 0 ? P::L - 1 : xx - 1;
+                    const float2 up = s[(l - 1) * P::LS + npos<P>(xx)], lf = s[l * P::LS + npos<P>(xm)];
+                    const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
+                    const float vast = z.dx * z.dx * (dSndx * dSndx + dSrdx * dSrdx) + z.dy * z.dy * (dSndy * dSndy + dSrdy * dSrdy);
+                    v = sval / sqrtf(vs[n1] + vast);
+                } else if (which == 3) v = sval / fs;
+                else v = sqrtf(fmaxf(vs[n1], 0.f)) / fs;
+                stage[l * P::L + xx] = v;
+            }
+        }
+        write_rows(dst);
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+struct state {
+    int L; float2* d_tw;
+};
+
+template <class P>
+static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+               const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
+               float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
+    const int nsy = ny / size, nsx = nx / size, nsub = nsy * nsx;
+    int rc;
+    const size_t unit = (size_t)nsub * P::HP * P::L;                  // elements of one T / U / C array
+    // 4 T + 4 U + 6 C arrays + scalars + F_S partial sums
+    const size_t bytes = 14 * unit * sizeof(float2) + (size_t)nsub * sizeof(zscal) + (size_t)nsub * P::G * sizeof(double) + 4096;
+    char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
+    float2* arr[14]; for (int i = 0; i < 14; i++) arr[i] = (float2*)ws + (size_t)i * unit;
+    char* p = ws + 14 * unit * sizeof(float2);
+    zscal* d_sc = (zscal*)p; p += (size_t)nsub * sizeof(zscal);
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    double* fs_partial = (double*)p;
+    float2 *T0 = arr[0], *T1 = arr[1], *T2 = arr[2], *T3 = arr[3], *U0 = arr[4], *U1 = arr[5], *U2 = arr[6], *U3 = arr[7];
+    float2 *cA = arr[8], *cB = arr[9], *cKn = arr[10], *cKr = arr[11], *cK2n = arr[12], *cK2r = arr[13];
+    // (pageable host source: the runtime stages it before the call returns)
+    BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));
+    const float2* tw = st->d_tw;
+    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2), lds_fin = lds + (size_t)P::NL * P::L * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BBX_HIP(hipFuncSetAttribute((const void*)k_psf_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_psf_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_cols_fwd<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_var_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_final_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
+        attr_set = true;
+    }
+    const float inv_n2 = 1.0f / ((float)P::L * (float)P::L);
+    const dim3 gcol(P::G, nsub), grow((P::L + P::NL - 1) / P::NL, nsub), blk(P::THREADS);
+    bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
+    // PSF side: U0 = kn (cols^-1), U1 = kr; T0 = (kr^2)^ rows, T1 = (kn^2)^ rows
+    hipLaunchKernelGGL(k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial);
+    hipLaunchKernelGGL(k_psf_rows<P>, grow, blk, lds, s, U1, U0, inv_n2, tw, T0, T1);
+    hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T0, tw, cK2r);
+    hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T1, tw, cK2n);
+    // image side
+    frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
+    hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T0, T1);
+    fa.sa = d_sig_new; fa.sb = d_sig_ref;
+    hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3);
+    hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2);      // D, Sn, Sr
+    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3);                    // V_S
+    out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
+    oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx;
+    const dim3 gfin((size + P::NL - 2) / (P::NL - 1), nsub);
+    hipLaunchKernelGGL(k_final_rows<P>, gfin, blk, lds_fin, s, U0, U3, U1, U2, d_sc, fs_partial, inv_n2, tw, oa);
+    bbx_prof_stop(ctx, s);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+}  // namespace z2
+
+void bbx_zogy2_release(bbx_ctx* ctx) {
+    if (!ctx || !ctx->zogy2_state) return;
+    z2::state* st = (z2::state*)ctx->zogy2_state;
+    if (st->d_tw) (void)hipFree(st->d_tw);
+    free(st);
+    ctx->zogy2_state = nullptr;
+}
+
+extern "C" int bbx_zogy_frame_supported(int L) {
+    return (L == 1400 || L == 140 || L == 128 || L == 64) ? 1 : 0;
+}
+
+extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+                              const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S,
+                              const float* h_scal, float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr,
+                              void* stream) {
+    if (!ctx || !d_new || !d_ref || !d_sig_new || !d_sig_ref || !d_psf_n || !d_psf_r || !h_scal || !d_D || !d_Scorr || !d_Fpsf || !d_Fpsferr)
+        return BBX_ERR_ARG;
+    if (size < 1 || border < 0 || ny < size || nx < size || ny % size || nx % size || S < 1) return BBX_ERR_ARG;
+    const int L = size + 2 * border;
+    if (!bbx_zogy_frame_supported(L) || S > L || (ny / size) * (nx / size) > 4096) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->zogy2_state) {
+        ctx->zogy2_state = calloc(1, sizeof(z2::state));
+        if (!ctx->zogy2_state) return BBX_ERR_NOMEM;
+    }
+    z2::state* st = (z2::state*)ctx->zogy2_state;
+    if (st->L != L) {
+        if (st->d_tw) { BBX_HIP(hipDeviceSynchronize()); BBX_HIP(hipFree(st->d_tw)); st->d_tw = nullptr; }
+        float2* h = (float2*)malloc((size_t)L * sizeof(float2));
+        if (!h) return BBX_ERR_NOMEM;
+        for (int m = 0; m < L; m++) {
+            const double a = -2.0 * M_PI * (double)m / (double)L;
+            h[m] = make_float2((float)cos(a), (float)sin(a));
+        }
+        hipError_t e = hipMalloc((void**)&st->d_tw, (size_t)L * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(st->d_tw, h, (size_t)L * sizeof(float2), hipMemcpyHostToDevice);
+        free(h);
+        if (e != hipSuccess) return bbx_hip_fail(ctx, e, "twiddle table", __LINE__);
+        st->L = L;
+    }
+#define Z2_RUN(N1, N2) return z2::run<z2::Plan<N1, N2>>(ctx, st, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, \
+                                                        h_scal, d_D, d_S, d_Scorr, d_Fpsf, d_Fpsferr, s)
+    switch (L) {
+        case 1400: Z2_RUN(35, 40);
+        case 140: Z2_RUN(10, 14);
+        case 128: Z2_RUN(8, 16);
+        case 64: Z2_RUN(8, 8);
+    }
+    return BBX_ERR_ARG;
+}

@@ -135,6 +135,28 @@ def run_zogy(ctx, N, R, Pn, Pr, Vn, Vr, scal):
     return outs
 
 
+def frame_path_supported(L):
+    """sub-image sides the hand-written FFT path (bbx_zogy_frame) is built for; BBX_ZOGY_ROCFFT=1
+    forces the rocFFT path (bbx_zogy_subimages) everywhere"""
+    import os
+    return bool(lib.bbx_zogy_frame_supported(int(L))) and not os.environ.get('BBX_ZOGY_ROCFFT')
+
+
+def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, border, want_S=False):
+    """ZOGY of whole frames (bbx_zogy_frame): background-subtracted frames + sigma images + PSF
+    stamps [nsub, S, S] -> D, S (or None), Scorr, Fpsf, Fpsferr full frames"""
+    ny, nx = new.shape
+    nsub = (ny // size) * (nx // size)
+    scal = np.ascontiguousarray(scal, dtype=np.float32)
+    assert scal.shape == (nsub, 6) and psf_n.shape[0] == nsub and psf_r.shape[0] == nsub
+    S = int(psf_n.shape[1])
+    outs = [torch.empty_like(new) if (k != 1 or want_S) else None for k in range(5)]
+    check(lib.bbx_zogy_frame(ctx.h, ny, nx, int(size), int(border), _p(new), _p(ref), _p(sig_new), _p(sig_ref),
+                             _p(psf_n.contiguous()), _p(psf_r.contiguous()), S, scal.ctypes.data_as(C.POINTER(C.c_float)),
+                             *[_p(o) for o in outs], ctx.stream()), 'bbx_zogy_frame', ctx.h)
+    return outs
+
+
 def psf_optflux(ctx, D, V, psfs, ys, xs):
     """zogy.get_psfoptflux at integer positions -> (flux, fluxerr) float32 device tensors"""
     nsrc, S, _ = psfs.shape
@@ -313,14 +335,14 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     work = new.clone()
     mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=work, want_bkg=False)
     bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
-    Vn = variance(ctx, work, bstd)
+    Vn = None                                                        # variance image: only where a consumer needs it
     sdn = mini_std.cpu().numpy()
     res['bkg_mini_new'], res['bkg_std_mini_new'] = mini.cpu().numpy(), sdn
     hdr['BKG-SIZE'] = (box, '[pix] background boxsize used')
     hdr['BKG-SUB'] = (False, 'sky background was subtracted?')          # the _red product keeps its sky
     hdr['S-BKG'] = (float(np.median(res['bkg_mini_new'])), '[e-] median background full-frame image')
     hdr['S-BKGSTD'] = (float(np.median(sdn)), '[e-] sigma (STD) background full-frame image')
-    res['data_bkgsub'], res['bkg_std'], res['var_new'] = work, bstd, Vn
+    res['data_bkgsub'], res['bkg_std'] = work, bstd
 
     sub_pn = subimage_psfs(ctx, psf_new, nsy, nsx, size) if psf_new is not None else None
 
@@ -337,6 +359,7 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         ys, xs = [p[0] for p in peaks], [p[1] for p in peaks]
         if peaks:
             stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
+            Vn = variance(ctx, work, bstd)
             f, e = psf_optflux(ctx, work, Vn, stamps, ys, xs)
             f, e = f.cpu().numpy(), e.cpu().numpy()
         else:
@@ -375,8 +398,7 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         raise ValueError('reference frame of another shape needs ref_grid')
     # co-added reference: no channel structure in its noise -> interpolation across the frame
     rbstd = mini2back(ctx, sdr, (ny, nx), bkg_boxsize=box, interp_Xchan=True)
-    Vr = variance(ctx, rwork, rbstd)
-    res['ref_bkgsub'], res['var_ref'] = rwork, Vr
+    res['ref_bkgsub'], res['bkg_std_ref'] = rwork, rbstd
     hdr_t['S-BKGSTDR'] = (float(np.median(sdr)), '[e-] sigma (STD) background reference image')
 
     # ---- sub-images
@@ -391,12 +413,19 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
             tn, tr = sdn, sdr
         scal[k] = [np.median(tn), np.median(tr), 1.0, 1.0 / fratio if fratio else 1.0, dx, dy]
     sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
-    subs = [cut_subimages(ctx, a, size, border) for a in (work, rwork, Vn, Vr)]
-    Pn, Pr = embed_psfs(ctx, sub_pn, L), embed_psfs(ctx, sub_pr, L)
-    D, S, Scorr, Fpsf, Fpsferr = run_zogy(ctx, subs[0], subs[1], Pn, Pr, subs[2], subs[3], scal)
-    del subs, Pn, Pr, S
-    for name, a in (('D', D), ('Scorr', Scorr), ('Fpsf', Fpsf), ('Fpsferr', Fpsferr)):
-        res[name] = stitch_subimages(ctx, a, (ny, nx), size, border)
+    if frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]:
+        # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
+        D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border)
+        res['D'], res['Scorr'], res['Fpsf'], res['Fpsferr'] = D, Scorr, Fpsf, Fpsferr
+    else:
+        Vn = Vn if Vn is not None else variance(ctx, work, bstd)
+        Vr = variance(ctx, rwork, rbstd)
+        subs = [cut_subimages(ctx, a, size, border) for a in (work, rwork, Vn, Vr)]
+        Pn, Pr = embed_psfs(ctx, sub_pn, L), embed_psfs(ctx, sub_pr, L)
+        D, S, Scorr, Fpsf, Fpsferr = run_zogy(ctx, subs[0], subs[1], Pn, Pr, subs[2], subs[3], scal)
+        del subs, Pn, Pr, S, Vr
+        for name, a in (('D', D), ('Scorr', Scorr), ('Fpsf', Fpsf), ('Fpsferr', Fpsferr)):
+            res[name] = stitch_subimages(ctx, a, (ny, nx), size, border)
     del D, Scorr, Fpsf, Fpsferr
 
     # ---- transient candidates: regions of |Scorr| >= T-NSIGMA, flux = Fpsf at the peak

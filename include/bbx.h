@@ -416,6 +416,28 @@ int bbx_zogy_subimages(bbx_ctx *ctx, int L, int nsub, float *d_new, float *d_ref
                        const float *h_scal, float *d_D, float *d_S, float *d_Scorr,
                        float *d_Fpsf, float *d_Fpsferr, void *stream);
 
+/* bbx_zogy_frame: the same subtraction for a whole frame in one call, with the library's own 2-D
+ * FFT (bbx_zogy2.hip: 1-D transforms in LDS, transposition folded into the store patterns, the
+ * ZOGY algebra in the registers of the column passes) instead of rocFFT + separate element-wise
+ * kernels; the cut into (ny/size)*(nx/size) sub-images of side L = size + 2*border (zero-padded
+ * at the frame edge), the variance images V = max(d, 0) + sigma^2 and the stitching of the
+ * results are part of its kernels.
+ *   d_new, d_ref         : background-subtracted frames [ny][nx] (ref on the new frame's grid)
+ *   d_sig_new, d_sig_ref : background sigma images [ny][nx]
+ *   d_psf_n, d_psf_r     : unit-sum PSF stamps [nsub][S][S] (centre at S/2)
+ *   h_scal [nsub][6]     : sigma_n, sigma_r, f_n, f_r, dx, dy
+ *   d_D, d_Scorr, d_Fpsf, d_Fpsferr (and d_S, may be NULL) : full frames [ny][nx]
+ * Supported sub-image sides: bbx_zogy_frame_supported(L) != 0 (1400 = the reference's
+ * 1320 + 2*40, and 64 / 128 / 140 for tests); other sizes go through bbx_zogy_subimages.
+ * S = S_n - S_r is formed in real space (identical in exact arithmetic to the inverse transform
+ * of S^ that bbx_zogy_subimages takes). */
+int bbx_zogy_frame_supported(int L);
+int bbx_zogy_frame(bbx_ctx *ctx, int ny, int nx, int size, int border, const float *d_new,
+                   const float *d_ref, const float *d_sig_new, const float *d_sig_ref,
+                   const float *d_psf_n, const float *d_psf_r, int S, const float *h_scal,
+                   float *d_D, float *d_S, float *d_Scorr, float *d_Fpsf, float *d_Fpsferr,
+                   void *stream);
+
 /* ---- a17: PSFEx model evaluation [EXT: zogy.get_psf / psfex poly] ----------------------
  * stamp[s][p] = sum_k terms[s][k] * basis[k][p]: terms [nsrc][ncoef] f32 = the polynomial
  * terms x'^i y'^j (i + j <= poldeg, PSFEx order) of each source position, basis

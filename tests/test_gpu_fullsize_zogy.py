@@ -130,7 +130,8 @@ def test_zogy_fullsize(scene):
     hdr = res['header_trans']
     assert res['header_new']['Z-P'][0] is True and hdr['Z-SIZE'][0] == SIZE and hdr['Z-BSIZE'][0] == BORDER
     nsx = NX // SIZE
-    Nw, Rw, Vn, Vr = res['data_bkgsub'], res['ref_bkgsub'], res['var_new'], res['var_ref']
+    Nw, Rw = res['data_bkgsub'], res['ref_bkgsub']
+    Vn, Vr = G.variance(ctx, Nw, res['bkg_std']), G.variance(ctx, Rw, res['bkg_std_ref'])
 
     def embed(p):
         k = np.zeros((L, L), F); h = p.shape[0] // 2

@@ -1,0 +1,135 @@
+"""GPU: bbx_zogy_frame -- the hand-written 2-D FFT path of the ZOGY stage (bbx_zogy2.hip) -- against
+the oracle's run_zogy on every sub-image (cut with zero padding, per-sub-image PSFs and
+scalars, stitched), for each sub-image side the path is built for (64 = 8*8, 128 = 8*16,
+140 = 10*14; 1400 = 35*40 is covered at full size in test_gpu_fullsize_zogy.py), with and
+without a border (the finite differences then wrap around like np.roll), and against the
+rocFFT path (bbx_zogy_subimages) on the same inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+if not torch.cuda.is_available():
+    pytest.skip('no GPU', allow_module_level=True)
+
+import zogy_core as Z                       # noqa: E402
+from blackbox_amd import reduce as R       # noqa: E402
+from blackbox_amd import zogy as G          # noqa: E402
+from blackbox_amd._lib import lib          # noqa: E402
+
+F = np.float32
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = R.Context(0)
+    yield c
+    c.close()
+
+
+def dev(ctx, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+
+
+def moffat(S, fwhm, dy=0.0, dx=0.0):
+    a = fwhm / (2 * np.sqrt(2 ** (1 / 2.5) - 1))
+    y, x = np.mgrid[0:S, 0:S] - S // 2
+    p = (1 + ((y - dy) ** 2 + (x - dx) ** 2) / (a * a)) ** -2.5
+    return (p / p.sum()).astype(F)
+
+
+def embed(p, L):
+    k = np.zeros((L, L), F); S = p.shape[0]; h = S // 2
+    for j in range(S):
+        for i in range(S):
+            k[(j - h) % L, (i - h) % L] = p[j, i]
+    return k
+
+
+def make(size, border, nsy, nsx, S, seed):
+    rs = np.random.RandomState(seed)
+    ny, nx = nsy * size, nsx * size
+    truth = np.zeros((ny, nx))
+    for _ in range(6 * nsy * nsx):
+        truth[rs.randint(0, ny), rs.randint(0, nx)] += 10 ** rs.uniform(3, 5)
+    from scipy import ndimage
+    new = (ndimage.gaussian_filter(truth, 1.6) + rs.normal(0, 14, (ny, nx))).astype(F)
+    ref = (ndimage.gaussian_filter(truth, 1.3) + rs.normal(0, 6, (ny, nx))).astype(F)
+    new[rs.randint(0, ny), rs.randint(0, nx)] += 4000.0                      # a transient
+    sig_n = (14 + 2 * rs.random_sample((ny, nx))).astype(F)
+    sig_r = (6 + rs.random_sample((ny, nx))).astype(F)
+    nsub = nsy * nsx
+    pn = np.stack([moffat(S, 3.4 + 0.1 * k, 0.1 * k, -0.05 * k) for k in range(nsub)])
+    pr = np.stack([moffat(S, 2.9 + 0.05 * k) for k in range(nsub)])
+    scal = np.stack([[14 + 0.3 * k, 6 + 0.1 * k, 1.0, 0.9 + 0.02 * k, 0.03, 0.02] for k in range(nsub)]).astype(F)
+    return new, ref, sig_n, sig_r, pn, pr, scal
+
+
+def oracle(new, ref, sig_n, sig_r, pn, pr, scal, size, border):
+    ny, nx = new.shape
+    L = size + 2 * border
+    Vn = (np.maximum(new, 0) + sig_n * sig_n).astype(F)
+    Vr = (np.maximum(ref, 0) + sig_r * sig_r).astype(F)
+    subs = [Z.cut_subimages(a, size, border) for a in (new, ref, Vn, Vr)]
+    outs = [[] for _ in range(5)]
+    for k in range(subs[0].shape[0]):
+        sn, sr, fn, fr, dx, dy = scal[k]
+        r = Z.run_zogy(subs[0][k], subs[1][k], embed(pn[k], L), embed(pr[k], L), sn, sr, fn, fr, subs[2][k], subs[3][k], dx, dy)
+        for o, a in zip(outs, r):
+            o.append(a)
+    return [Z.stitch_subimages(np.stack(o), ny, nx, size, border) for o in outs]
+
+
+@pytest.mark.parametrize('size,border,nsy,nsx,S', [(48, 8, 2, 3, 11), (64, 0, 2, 2, 9), (100, 14, 2, 3, 15), (120, 10, 2, 4, 15),
+                                                  (128, 0, 1, 2, 13)])
+def test_frame_path_vs_oracle(ctx, size, border, nsy, nsx, S):
+    L = size + 2 * border
+    assert lib.bbx_zogy_frame_supported(L)
+    new, ref, sig_n, sig_r, pn, pr, scal = make(size, border, nsy, nsx, S, seed=L + border)
+    want = oracle(new, ref, sig_n, sig_r, pn, pr, scal, size, border)
+    got = G.run_zogy_frame(ctx, dev(ctx, new), dev(ctx, ref), dev(ctx, sig_n), dev(ctx, sig_r), dev(ctx, pn), dev(ctx, pr), scal,
+                           size, border, want_S=True)
+    ctx.sync()
+    for name, g, w in zip(('D', 'S', 'Scorr', 'Fpsf', 'Fpsferr'), got, want):
+        g = g.cpu().numpy()
+        ok = np.isfinite(w)
+        assert np.array_equal(np.isfinite(g), ok), name
+        # toy frames (a few 10^4 e- peaks over 15 e- of noise): 2e-5 of the image scale, i.e. ~1e-3 of the noise
+        scale = np.abs(w[ok]).max()
+        assert np.abs(g[ok] - w[ok]).max() <= 2e-5 * scale, (name, np.abs(g[ok] - w[ok]).max(), scale)
+
+
+def test_frame_path_vs_rocfft_path(ctx):
+    """the two device implementations on the same inputs (L = 140: radices 2, 5, 7 like 1400)"""
+    size, border, nsy, nsx, S = 120, 10, 2, 4, 15
+    L = size + 2 * border
+    new, ref, sig_n, sig_r, pn, pr, scal = make(size, border, nsy, nsx, S, seed=5)
+    a = G.run_zogy_frame(ctx, dev(ctx, new), dev(ctx, ref), dev(ctx, sig_n), dev(ctx, sig_r), dev(ctx, pn), dev(ctx, pr), scal,
+                         size, border, want_S=True)
+    dn, dr = dev(ctx, new), dev(ctx, ref)
+    Vn, Vr = G.variance(ctx, dn, dev(ctx, sig_n)), G.variance(ctx, dr, dev(ctx, sig_r))
+    subs = [G.cut_subimages(ctx, t, size, border) for t in (dn, dr, Vn, Vr)]
+    b = G.run_zogy(ctx, subs[0], subs[1], G.embed_psfs(ctx, dev(ctx, pn), L), G.embed_psfs(ctx, dev(ctx, pr), L), subs[2], subs[3], scal)
+    b = [G.stitch_subimages(ctx, t, new.shape, size, border) for t in b]
+    ctx.sync()
+    for name, x, y in zip(('D', 'S', 'Scorr', 'Fpsf', 'Fpsferr'), a, b):
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        assert np.abs(x - y).max() <= 2e-5 * np.abs(y).max(), name
+
+
+def test_frame_path_rejects_bad_arguments(ctx):
+    z = torch.zeros((96, 96), dtype=torch.float32, device=ctx.device)
+    p = torch.zeros((4, 9, 9), dtype=torch.float32, device=ctx.device)
+    sc = (C.c_float * 24)()
+    args = [z.data_ptr()] * 4 + [p.data_ptr()] * 2
+
+    def call(ny, nx, size, border, S=9):
+        return lib.bbx_zogy_frame(ctx.h, ny, nx, size, border, *[C.c_void_p(a) for a in args], S, sc,
+                                  *[C.c_void_p(z.data_ptr())] * 5, ctx.stream())
+    assert call(96, 96, 50, 7) != 0          # frame not a multiple of the sub-image size
+    assert call(96, 96, 48, 9) != 0          # L = 66: not a supported side
+    assert call(96, 96, 48, 8, S=0) != 0
+    assert not lib.bbx_zogy_frame_supported(66) and lib.bbx_zogy_frame_supported(1400)
