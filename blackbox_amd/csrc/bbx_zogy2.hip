@@ -175,7 +175,7 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
                                                          float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
                                                          double* __restrict__ fs_partial) {
     extern __shared__ float2 s[];
-    __shared__ double red[P::THREADS / 64];
+    __shared__ double red[3][P::THREADS / 64];
     const int g = blockIdx.x, sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const int kx = g * P::NL + l, h = S / 2;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
     }
     const zscal z = sc[sub];
     const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
-    double fs = 0.0;
+    double fs = 0.0, sk2n = 0.0, sk2r = 0.0;                      // F_S and the Parseval sums of kn^2, kr^2
     if (t < P::N1) {
         const bool live = kx < P::H;
         const double wgt = (kx == 0 || (P::L % 2 == 0 && kx == P::L / 2)) ? 1.0 : 2.0;
@@ -229,6 +229,8 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
                 kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 / den);
                 kn = cscale(make_float2(pn.x, -pn.y), z.fn * fr2 * pr2 / den);
                 fs += wgt * (double)(fn2 * pn2 * fr2 * pr2 / den);
+                sk2n += wgt * (double)(kn.x * kn.x + kn.y * kn.y);
+                sk2r += wgt * (double)(kr.x * kr.x + kr.y * kr.y);
             }
             cA[o] = a; cB[o] = b; cKn[o] = kn; cKr[o] = kr;
             X[k2] = kr;
@@ -244,13 +246,13 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
     }
     inv_lines<P>(X, s, l, t, tw, x);
     if (t < P::N2) store_u<P>(Ukn, sub, g, l, t, x);
-    fs = wave_sum_f64(fs);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = fs;
+    fs = wave_sum_f64(fs); sk2n = wave_sum_f64(sk2n); sk2r = wave_sum_f64(sk2r);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = fs; red[1][threadIdx.x >> 6] = sk2n; red[2][threadIdx.x >> 6] = sk2r; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 3) {
         double tot = 0.0;
-        for (int i = 0; i < P::THREADS / 64; i++) tot += red[i];
-        fs_partial[(size_t)sub * P::G + g] = tot;
+        for (int i = 0; i < P::THREADS / 64; i++) tot += red[threadIdx.x][i];
+        fs_partial[((size_t)threadIdx.x * gridDim.y + sub) * P::G + g] = tot;      // [3][nsub][G]
     }
 }
 
@@ -303,6 +305,23 @@ __global__ __launch_bounds__(P::THREADS) void k_cols_fwd(const float2* __restric
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) Cout[cbase + (size_t)k2 * P::CT] = X[k2];
     }
+}
+
+// V(S) is ~1e-4 of D in the units both leave the column pass in, and the final inverse row pass
+// transforms them as one complex signal (D + i V_S): float32 rounding of the larger part would
+// leak into the smaller one (0.1 % of V_S typically, 10 % next to bright residuals).  V(S)^ is
+// therefore scaled by a power of two (exact) that brings its sky level -- sigma_n^2 sum(kn^2) +
+// sigma_r^2 sum(kr^2), from the Parseval sums of k_psf_cols -- to ~1, and unscaled at the end.
+template <class P> __device__ __forceinline__ float vs_scale(const double* __restrict__ fs_partial, int nsub, int sub, const zscal& z) {
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < P::G; g++) {
+        a += fs_partial[((size_t)1 * nsub + sub) * P::G + g];
+        b += fs_partial[((size_t)2 * nsub + sub) * P::G + g];
+    }
+    const double n2 = (double)P::L * (double)P::L;
+    const float level = (float)(((double)z.sn * z.sn * a + (double)z.sr * z.sr * b) / n2);            // Parseval: sum_x k^2 = sum_k |k^|^2 / L^2
+    if (!(level > 0.f) || !isfinite(level)) return 1.f;
+    return exp2f(-rintf(log2f(level)));
 }
 
 // ---- image side -------------------------------------------------------------------------------
@@ -402,9 +421,12 @@ __global__ __launch_bounds__(P::THREADS) void k_img_cols(float2* TN, const float
 template <class P>
 __global__ __launch_bounds__(P::THREADS) void k_var_cols(float2* TVn, const float2* __restrict__ TVr,
                                                          const float2* __restrict__ cK2n, const float2* __restrict__ cK2r,
-                                                         const float2* __restrict__ tw, float2* __restrict__ UVS) {
+                                                         const float2* __restrict__ tw, float2* __restrict__ UVS,
+                                                         const zscal* __restrict__ sc, const double* __restrict__ fs_partial) {
     extern __shared__ float2 s[];
+    __shared__ float s_beta;
     const int g = blockIdx.x, sub = blockIdx.y;
+    if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, gridDim.y, sub, sc[sub]);
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
     float2 X[P::N2], x[P::N1];
@@ -419,12 +441,13 @@ __global__ __launch_bounds__(P::THREADS) void k_var_cols(float2* TVn, const floa
     __syncthreads();
     load_t_lines<P>(TVr, sub, g, s);
     __syncthreads();
+    const float beta = s_beta;
     fwd_lines<P>(s, l, t, tw, X);
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) {
             const float2 v = cmul(cK2r[cbase + (size_t)k2 * P::CT], X[k2]), a = park[(size_t)k2 * P::CT];
-            X[k2] = make_float2(a.x + v.x, a.y + v.y);
+            X[k2] = make_float2((a.x + v.x) * beta, (a.y + v.y) * beta);
         }
     }
     __syncthreads();
@@ -451,10 +474,12 @@ __global__ __launch_bounds__(P::THREADS) void k_final_rows(const float2* __restr
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const int yfirst = o.border + blockIdx.x * (P::NL - 1) - 1;     // sub-image row of line 0 (may be -1: wraps)
     const zscal z = sc[sub];
+    __shared__ float s_ibeta;
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int g = 0; g < P::G; g++) tot += fs_partial[(size_t)sub * P::G + g];
         s_fs = (float)(tot / ((double)P::L * (double)P::L));
+        s_ibeta = 1.0f / vs_scale<P>(fs_partial, gridDim.y, sub, z);
     }
     const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
     const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
@@ -495,9 +520,10 @@ __global__ __launch_bounds__(P::THREADS) void k_final_rows(const float2* __restr
         for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
     }
     inv_lines<P>(X, s, l, t, tw, x);
+    const float ibeta = s_ibeta;
     if (t < P::N2) {
 #pragma unroll
-        for (int n1 = 0; n1 < P::N1; n1++) { stage[l * P::L + P::N2 * n1 + t] = x[n1].x * inv_n2 / fD; vs[n1] = x[n1].y * inv_n2; }
+        for (int n1 = 0; n1 < P::N1; n1++) { stage[l * P::L + P::N2 * n1 + t] = x[n1].x * inv_n2 / fD; vs[n1] = x[n1].y * inv_n2 * ibeta; }
     }
     write_rows(o.D);
     // (Sn, Sr)
@@ -556,7 +582,7 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     int rc;
     const size_t unit = (size_t)nsub * P::HP * P::L;                  // elements of one T / U / C array
     // 4 T + 4 U + 6 C arrays + scalars + F_S partial sums
-    const size_t bytes = 14 * unit * sizeof(float2) + (size_t)nsub * sizeof(zscal) + (size_t)nsub * P::G * sizeof(double) + 4096;
+    const size_t bytes = 14 * unit * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 3 * (size_t)nsub * P::G * sizeof(double) + 4096;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
     float2* arr[14]; for (int i = 0; i < 14; i++) arr[i] = (float2*)ws + (size_t)i * unit;
     char* p = ws + 14 * unit * sizeof(float2);
@@ -594,7 +620,7 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3);
     hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2);      // D, Sn, Sr
-    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3);                    // V_S
+    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3, d_sc, fs_partial);                    // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx;
     const dim3 gfin((size + P::NL - 2) / (P::NL - 1), nsub);
