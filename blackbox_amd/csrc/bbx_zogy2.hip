@@ -52,10 +52,13 @@ constexpr int cmin(int a, int b) { return a < b ? a : b; }
 // wave-instruction start on different banks
 constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; return s; }
 
+#ifndef Z2_NL_BIG
+#define Z2_NL_BIG 8
+#endif
 template <int N1_, int N2_> struct Plan {
     static constexpr int N1 = N1_, N2 = N2_, L = N1_ * N2_, H = L / 2 + 1;
     static constexpr int NT = cmax(N1_, N2_);                       // thread tasks per line
-    static constexpr int NL = cmin(16, floor_pow2(320 / NT));       // lines per workgroup
+    static constexpr int NL = cmin(NT >= 32 ? Z2_NL_BIG : 16, floor_pow2(320 / NT));       // lines per workgroup
     static constexpr int THREADS = ((NL * NT + 63) / 64) * 64;
     static constexpr int G = (H + NL - 1) / NL, HP = G * NL;        // column groups, padded half-spectrum width
     static constexpr int LP = N1_ * (N2_ + 1);                      // padded line: one pad per N2 entries
@@ -67,10 +70,21 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
 
+// knock-out switches for timing experiments (tools/dbg/z2_variants.sh); never set in the product build
+#ifdef Z2_SKIP_DFT
+#define DFT_RUN(N, x) ((void)0)
+#else
+#define DFT_RUN(N, x) bbx_dft<N>::run(x)
+#endif
+#ifdef Z2_SKIP_TW
+#define TW(i) make_float2(1.f, 0.f)
+#else
+#define TW(i) tw[i]
+#endif
 template <int N> __device__ __forceinline__ void idft(float2 (&x)[N]) {      // inverse = forward on swapped pairs
 #pragma unroll
     for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
-    bbx_dft<N>::run(x);
+    DFT_RUN(N, x);
 #pragma unroll
     for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
 }
@@ -81,9 +95,9 @@ template <class P> __device__ __forceinline__ int npos(int n) { return n + n / P
 // ---- the two steps (line = this thread's line in LDS, t = task index) ------------------------
 // forward step 1 on values already in registers (x[n1] = sample N2 n1 + t), result to LDS
 template <class P> __device__ __forceinline__ void fwd_step1_regs(float2 (&x)[P::N1], float2* line, int t, const float2* __restrict__ tw) {
-    bbx_dft<P::N1>::run(x);
+    DFT_RUN(P::N1, x);
 #pragma unroll
-    for (int k1 = 0; k1 < P::N1; k1++) line[(P::N2 + 1) * k1 + t] = cmul(x[k1], tw[t * k1]);
+    for (int k1 = 0; k1 < P::N1; k1++) line[(P::N2 + 1) * k1 + t] = cmul(x[k1], TW(t * k1));
 }
 template <class P> __device__ __forceinline__ void fwd_step1(float2* line, int t, const float2* __restrict__ tw) {
     float2 x[P::N1];
@@ -95,13 +109,13 @@ template <class P> __device__ __forceinline__ void fwd_step1(float2* line, int t
 template <class P> __device__ __forceinline__ void fwd_step2(const float2* line, int t, float2 (&x)[P::N2]) {
 #pragma unroll
     for (int n2 = 0; n2 < P::N2; n2++) x[n2] = line[(P::N2 + 1) * t + n2];
-    bbx_dft<P::N2>::run(x);
+    DFT_RUN(P::N2, x);
 }
 // inverse step 2 from registers (x[k2] of thread t = k1), result to LDS
 template <class P> __device__ __forceinline__ void inv_step2(float2 (&x)[P::N2], float2* line, int t, const float2* __restrict__ tw) {
     idft<P::N2>(x);
 #pragma unroll
-    for (int n2 = 0; n2 < P::N2; n2++) line[(P::N2 + 1) * t + n2] = cmulc(x[n2], tw[n2 * t]);
+    for (int n2 = 0; n2 < P::N2; n2++) line[(P::N2 + 1) * t + n2] = cmulc(x[n2], TW(n2 * t));
 }
 // inverse step 1: thread t = n2 -> x[n1] = (unnormalised) sample N2 n1 + t
 template <class P> __device__ __forceinline__ void inv_step1(const float2* line, int t, float2 (&x)[P::N1]) {
@@ -127,35 +141,69 @@ template <class P> __device__ __forceinline__ void store_u(float2* __restrict__ 
 #pragma unroll
     for (int n1 = 0; n1 < P::N1; n1++) base[(size_t)(P::N2 * n1 + t) * P::HP] = x[n1];
 }
-// load NL lines of a T-layout array ([sub][kx][y], kx = g NL + l) into LDS, natural order
-template <class P> __device__ __forceinline__ void load_t_lines(const float2* __restrict__ T, int sub, int g, float2* s) {
-    const float2* src = T + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L;      // NL contiguous lines
-    for (int e = threadIdx.x; e < P::NL * P::L; e += P::THREADS) {
-        const int l = e / P::L, y = e - l * P::L;
-        s[l * P::LS + npos<P>(y)] = src[e];
+// load NL lines of a T-layout array ([sub][kx][y], kx = g NL + l) into LDS, natural order.  All loads
+// of a thread are issued before its first LDS write (one wave per SIMD: nothing else hides the latency).
+template <class P> __device__ __forceinline__ void load_t_lines(const float2* T, int sub, int g, float2* s) {
+    static_assert(P::L % 2 == 0, "even sub-image side");
+    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L);      // NL contiguous lines
+    constexpr int NV = P::NL * P::L / 2, IT = (NV + P::THREADS - 1) / P::THREADS;
+    float4 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; i++) { const int e = threadIdx.x + i * P::THREADS; if (e < NV) v[i] = src[e]; }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+        const int e = threadIdx.x + i * P::THREADS;
+        if (e < NV) {
+            const int q = 2 * e, l = q / P::L, y = q - l * P::L;
+            float2* d = s + l * P::LS + npos<P>(y);                 // y even: y and y + 1 share their pad group
+            d[0] = make_float2(v[i].x, v[i].y); d[1] = make_float2(v[i].z, v[i].w);
+        }
     }
 }
 // Hermitian packing of two U-layout half spectra (rows y0 .. y0+NL-1) into full complex lines in
 // spectrum order: Z[k] = a[k] + i b[k]
+template <class P> __device__ __forceinline__ void pack_store(float2* line, int kx, float2 a, float2 b) {
+    if (kx >= P::H) return;
+    line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
+    if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
+}
 template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int y0,
                                                                float2* s) {
-    for (int e = threadIdx.x; e < P::NL * P::HP; e += P::THREADS) {
-        const int l = e / P::HP, kx = e - l * P::HP;
-        const int y = y0 + l;
-        if (kx >= P::H) continue;
-        float2 a = make_float2(0.f, 0.f), b = a;
-        if (y >= 0 && y < P::L) {
-            const size_t o = ((size_t)sub * P::L + y) * P::HP + kx;
-            a = Ua[o]; b = Ub[o];
+    static_assert(P::HP % 2 == 0, "even padded width");
+    constexpr int NV = P::NL * P::HP / 2, IT = (NV + P::THREADS - 1) / P::THREADS;
+    float4 va[IT], vb[IT];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+        const int e = threadIdx.x + i * P::THREADS;
+        va[i] = zero; vb[i] = zero;
+        if (e < NV) {
+            const int q = 2 * e, l = q / P::HP, kx = q - l * P::HP, y = y0 + l;
+            if (y >= 0 && y < P::L && kx < P::H) {
+                const size_t o = ((size_t)sub * P::L + y) * P::HP + kx;
+                va[i] = *reinterpret_cast<const float4*>(Ua + o);
+                vb[i] = *reinterpret_cast<const float4*>(Ub + o);
+            }
         }
-        float2* line = s + l * P::LS;
-        line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
-        if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+        const int e = threadIdx.x + i * P::THREADS;
+        if (e < NV) {
+            const int q = 2 * e, l = q / P::HP, kx = q - l * P::HP;
+            float2* line = s + l * P::LS;
+            pack_store<P>(line, kx, make_float2(va[i].x, va[i].y), make_float2(vb[i].x, vb[i].y));
+            pack_store<P>(line, kx + 1, make_float2(va[i].z, va[i].w), make_float2(vb[i].z, vb[i].w));
+        }
     }
 }
 // Hermitian split of a packed transform Z (LDS, spectrum order) -> two half spectra, T layout
 template <class P> __device__ __forceinline__ void store_t_split(const float2* s, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub, int y0) {
-    for (int e = threadIdx.x; e < P::NL * P::H; e += P::THREADS) {
+    constexpr int NE = P::NL * P::H, IT = (NE + P::THREADS - 1) / P::THREADS;
+#pragma unroll 6
+    for (int i = 0; i < IT; i++) {
+        const int e = threadIdx.x + i * P::THREADS;
+        if (e >= NE) break;
         const int kx = e / P::NL, l = e - kx * P::NL;
         const int y = y0 + l;
         if (y >= P::L) continue;
@@ -328,7 +376,7 @@ template <class P> __device__ __forceinline__ float vs_scale(const double* __res
 struct frame_args {
     const float* a; const float* b;          // the two frames of a pair (new, ref) or their sigma images
     const float* sa; const float* sb;        // sigma images (variance pair) or NULL
-    int ny, nx, size, border, nsx;
+    int ny, nx, size, border, nsx, vec4;
 };
 
 // cut + forward row pass of a pair of real frames: (N, R) or, with sigma images, (Vn, Vr)
@@ -340,6 +388,49 @@ __global__ __launch_bounds__(P::THREADS) void k_img_rows(frame_args f, const flo
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const int sy = sub / f.nsx, sx = sub - sy * f.nsx;
     const int Y0 = sy * f.size - f.border, X0 = sx * f.size - f.border;
+    if (f.vec4) {
+        // groups of four pixels never straddle the frame edge or a pad group (size, border, nx multiples of 4)
+        constexpr int NV = P::NL * P::L / 4, IT = (NV + P::THREADS - 1) / P::THREADS;
+        float4 va[IT], vb[IT];
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        size_t off[IT];
+#pragma unroll
+        for (int i = 0; i < IT; i++) {
+            const int e = threadIdx.x + i * P::THREADS;
+            va[i] = zero; vb[i] = zero; off[i] = (size_t)-1;
+            if (e < NV) {
+                const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                const int Y = Y0 + y0 + ll, X = X0 + x;
+                if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
+                    off[i] = (size_t)Y * f.nx + X;
+                    va[i] = *reinterpret_cast<const float4*>(f.a + off[i]);
+                    vb[i] = *reinterpret_cast<const float4*>(f.b + off[i]);
+                }
+            }
+        }
+        if (f.sa) {
+#pragma unroll
+            for (int i = 0; i < IT; i++) {
+                if (off[i] != (size_t)-1) {
+                    const float4 p = *reinterpret_cast<const float4*>(f.sa + off[i]), q = *reinterpret_cast<const float4*>(f.sb + off[i]);
+                    va[i] = make_float4(fmaxf(va[i].x, 0.f) + p.x * p.x, fmaxf(va[i].y, 0.f) + p.y * p.y, fmaxf(va[i].z, 0.f) + p.z * p.z,
+                                        fmaxf(va[i].w, 0.f) + p.w * p.w);
+                    vb[i] = make_float4(fmaxf(vb[i].x, 0.f) + q.x * q.x, fmaxf(vb[i].y, 0.f) + q.y * q.y, fmaxf(vb[i].z, 0.f) + q.z * q.z,
+                                        fmaxf(vb[i].w, 0.f) + q.w * q.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; i++) {
+            const int e = threadIdx.x + i * P::THREADS;
+            if (e < NV) {
+                const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                float2* d = s + ll * P::LS + npos<P>(x);
+                d[0] = make_float2(va[i].x, vb[i].x); d[1] = make_float2(va[i].y, vb[i].y);
+                d[2] = make_float2(va[i].z, vb[i].z); d[3] = make_float2(va[i].w, vb[i].w);
+            }
+        }
+    } else
     for (int e = threadIdx.x; e < P::NL * P::L; e += P::THREADS) {
         const int ll = e / P::L, x = e - ll * P::L;
         const int Y = Y0 + y0 + ll, X = X0 + x;
@@ -457,7 +548,7 @@ __global__ __launch_bounds__(P::THREADS) void k_var_cols(float2* TVn, const floa
 
 struct out_args {
     float* D; float* S; float* Scorr; float* Fpsf; float* Fpsferr;      // full frames [ny][nx]; S may be NULL
-    int ny, nx, size, border, nsx;
+    int ny, nx, size, border, nsx, vec4;
 };
 
 // inverse row pass of (D, V_S) and (Sn, Sr) + the final algebra, written into the full frames.
@@ -501,12 +592,23 @@ __global__ __launch_bounds__(P::THREADS) void k_final_rows(const float2* __restr
     };
     auto write_rows = [&](float* dst) {                           // staging rows 1 .. NL-1 -> the frame
         __syncthreads();
-        for (int e = threadIdx.x; e < (P::NL - 1) * o.size; e += P::THREADS) {
-            const int ll = 1 + e / o.size, xi = e - (ll - 1) * o.size;
-            const int y = yfirst + ll;                               // sub-image row
-            if (y >= o.border + o.size) continue;
-            const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
-            if (Y < o.ny && Xf < o.nx) dst[(size_t)Y * o.nx + Xf] = stage[ll * P::L + o.border + xi];
+        if (o.vec4) {
+            const int nq = o.size / 4;
+            for (int e = threadIdx.x; e < (P::NL - 1) * nq; e += P::THREADS) {
+                const int ll = 1 + e / nq, xi = 4 * (e - (ll - 1) * nq);
+                const int y = yfirst + ll;                           // sub-image row
+                if (y >= o.border + o.size) continue;
+                const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
+                *reinterpret_cast<float4*>(dst + (size_t)Y * o.nx + Xf) = *reinterpret_cast<const float4*>(stage + ll * P::L + o.border + xi);
+            }
+        } else {
+            for (int e = threadIdx.x; e < (P::NL - 1) * o.size; e += P::THREADS) {
+                const int ll = 1 + e / o.size, xi = e - (ll - 1) * o.size;
+                const int y = yfirst + ll;
+                if (y >= o.border + o.size) continue;
+                const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
+                if (Y < o.ny && Xf < o.nx) dst[(size_t)Y * o.nx + Xf] = stage[ll * P::L + o.border + xi];
+            }
         }
         __syncthreads();
     };
@@ -616,6 +718,7 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T1, tw, cK2n);
     // image side
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
+    fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::N2 % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T0, T1);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3);
@@ -623,6 +726,8 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3, d_sc, fs_partial);                    // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx;
+    oa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 &&
+               ((uintptr_t)d_D | (uintptr_t)d_S | (uintptr_t)d_Scorr | (uintptr_t)d_Fpsf | (uintptr_t)d_Fpsferr) % 16 == 0) ? 1 : 0;
     const dim3 gfin((size + P::NL - 2) / (P::NL - 1), nsub);
     hipLaunchKernelGGL(k_final_rows<P>, gfin, blk, lds_fin, s, U0, U3, U1, U2, d_sc, fs_partial, inv_n2, tw, oa);
     bbx_prof_stop(ctx, s);
