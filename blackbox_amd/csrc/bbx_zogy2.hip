@@ -53,17 +53,25 @@ constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; return s; }
 
 #ifndef Z2_NL_BIG
-#define Z2_NL_BIG 8
+#define Z2_NL_BIG 6           // 6 lines of 1400: 69 KB of LDS, two workgroups per CU (NL = 8: one)
 #endif
 template <int N1_, int N2_> struct Plan {
     static constexpr int N1 = N1_, N2 = N2_, L = N1_ * N2_, H = L / 2 + 1;
     static constexpr int NT = cmax(N1_, N2_);                       // thread tasks per line
     static constexpr int NL = cmin(NT >= 32 ? Z2_NL_BIG : 16, floor_pow2(320 / NT));       // lines per workgroup
     static constexpr int THREADS = ((NL * NT + 63) / 64) * 64;
+#ifndef Z2_MINW
+#define Z2_MINW 2
+#endif
+    static constexpr int MINW = Z2_MINW;                            // minimum waves per SIMD the register allocation must allow
     static constexpr int G = (H + NL - 1) / NL, HP = G * NL;        // column groups, padded half-spectrum width
     static constexpr int LP = N1_ * (N2_ + 1);                      // padded line: one pad per N2 entries
     static constexpr int LS = line_stride(LP);
     static constexpr int CT = NL * N1_;                             // step-2 thread tasks per workgroup
+    static constexpr int LB = (L + NL - 1) / NL;                    // row blocks of NL rows
+    // T and U are stored in NL x NL tiles: T[sub][yb][kx][yi] (row kernels write one contiguous
+    // block per workgroup, column kernels read 8 NL^2-byte tiles), U[sub][g][y][l] (the reverse)
+    static constexpr size_t UNIT = (size_t)LB * NL * HP;            // elements of one T / U / C array per sub-image
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -135,30 +143,51 @@ template <class P> __device__ __forceinline__ void inv_lines(float2 (&X)[P::N2],
     if (t < P::N2) inv_step1<P>(s + l * P::LS, t, x);
 }
 
-// store the inverse column pass (thread t = n2 holds y = N2 n1 + t of column g NL + l) to the U layout
-template <class P> __device__ __forceinline__ void store_u(float2* __restrict__ U, int sub, int g, int l, int t, const float2 (&x)[P::N1]) {
-    float2* base = U + ((size_t)sub * P::L) * P::HP + (size_t)g * P::NL + l;
+// store the inverse column pass (thread t = n2 holds y = N2 n1 + t of column g NL + l) to the U layout:
+// U[sub][g][y][l], a wave-instruction writes 64 consecutive entries.  halo != NULL: the last row of
+// every row block (and row L - 1) also goes to halo[sub][yb][kx] for the finite differences across blocks.
+template <class P> __device__ __forceinline__ void store_u(float2* __restrict__ U, int sub, int g, int l, int t, const float2 (&x)[P::N1],
+                                                           float2* __restrict__ halo = nullptr) {
+    float2* base = U + (size_t)sub * P::UNIT + (size_t)g * P::L * P::NL + l;
 #pragma unroll
-    for (int n1 = 0; n1 < P::N1; n1++) base[(size_t)(P::N2 * n1 + t) * P::HP] = x[n1];
+    for (int n1 = 0; n1 < P::N1; n1++) base[(size_t)(P::N2 * n1 + t) * P::NL] = x[n1];
+    if (halo) {
+#pragma unroll
+        for (int n1 = 0; n1 < P::N1; n1++) {
+            const int y = P::N2 * n1 + t;
+            if (y % P::NL == P::NL - 1 || y == P::L - 1) halo[((size_t)sub * P::LB + y / P::NL) * P::HP + g * P::NL + l] = x[n1];
+        }
+    }
 }
 // load NL lines of a T-layout array ([sub][kx][y], kx = g NL + l) into LDS, natural order.  All loads
 // of a thread are issued before its first LDS write (one wave per SIMD: nothing else hides the latency).
 template <class P> __device__ __forceinline__ void load_t_lines(const float2* T, int sub, int g, float2* s) {
-    static_assert(P::L % 2 == 0, "even sub-image side");
-    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L);      // NL contiguous lines
-    constexpr int NV = P::NL * P::L / 2, IT = (NV + P::THREADS - 1) / P::THREADS;
+    static_assert(P::NL % 2 == 0, "even tile side");
+    const float2* src = T + (size_t)sub * P::UNIT + (size_t)g * P::NL * P::NL;
+    constexpr int TV = P::NL * P::NL / 2;                           // float4 per tile
+    constexpr int NV = P::LB * TV, IT = (NV + P::THREADS - 1) / P::THREADS;
     float4 v[IT];
 #pragma unroll
-    for (int i = 0; i < IT; i++) { const int e = threadIdx.x + i * P::THREADS; if (e < NV) v[i] = src[e]; }
+    for (int i = 0; i < IT; i++) {
+        const int e = threadIdx.x + i * P::THREADS;
+        if (e < NV) { const int yb = e / TV, j = e - yb * TV; v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
+    }
 #pragma unroll
     for (int i = 0; i < IT; i++) {
         const int e = threadIdx.x + i * P::THREADS;
         if (e < NV) {
-            const int q = 2 * e, l = q / P::L, y = q - l * P::L;
-            float2* d = s + l * P::LS + npos<P>(y);                 // y even: y and y + 1 share their pad group
-            d[0] = make_float2(v[i].x, v[i].y); d[1] = make_float2(v[i].z, v[i].w);
+            const int yb = e / TV, j = e - yb * TV, l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
+            if (y < P::L) {
+                float2* d = s + l * P::LS + npos<P>(y);             // y even: y and y + 1 share their pad group
+                d[0] = make_float2(v[i].x, v[i].y); d[1] = make_float2(v[i].z, v[i].w);
+            }
         }
     }
+}
+// the same tiles as the workgroup's scratch: entry p of its NL * L values
+template <class P> __device__ __forceinline__ float2* park_ptr(float2* T, int sub, int g, int p) {
+    constexpr int TS = P::NL * P::NL;
+    return T + (size_t)sub * P::UNIT + (size_t)(p / TS) * P::HP * P::NL + (size_t)g * TS + p % TS;
 }
 // Hermitian packing of two U-layout half spectra (rows y0 .. y0+NL-1) into full complex lines in
 // spectrum order: Z[k] = a[k] + i b[k]
@@ -167,62 +196,66 @@ template <class P> __device__ __forceinline__ void pack_store(float2* line, int 
     line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
     if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
 }
-template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int y0,
+template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb,
                                                                float2* s) {
-    static_assert(P::HP % 2 == 0, "even padded width");
-    constexpr int NV = P::NL * P::HP / 2, IT = (NV + P::THREADS - 1) / P::THREADS;
+    constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV, IT = (NV + P::THREADS - 1) / P::THREADS;
     float4 va[IT], vb[IT];
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::NL * P::NL;
 #pragma unroll
     for (int i = 0; i < IT; i++) {
         const int e = threadIdx.x + i * P::THREADS;
-        va[i] = zero; vb[i] = zero;
         if (e < NV) {
-            const int q = 2 * e, l = q / P::HP, kx = q - l * P::HP, y = y0 + l;
-            if (y >= 0 && y < P::L && kx < P::H) {
-                const size_t o = ((size_t)sub * P::L + y) * P::HP + kx;
-                va[i] = *reinterpret_cast<const float4*>(Ua + o);
-                vb[i] = *reinterpret_cast<const float4*>(Ub + o);
+            const int g = e / TV, j = e - g * TV;
+            const size_t o = base + (size_t)g * P::L * P::NL + 2 * j;
+            va[i] = *reinterpret_cast<const float4*>(Ua + o);
+            vb[i] = *reinterpret_cast<const float4*>(Ub + o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+        const int e = threadIdx.x + i * P::THREADS;
+        if (e < NV) {
+            const int g = e / TV, j = e - g * TV, row = (2 * j) / P::NL, l = (2 * j) % P::NL;      // tile entry [row][l], l even
+            if (yb * P::NL + row < P::L) {
+                float2* line = s + row * P::LS;
+                pack_store<P>(line, g * P::NL + l, make_float2(va[i].x, va[i].y), make_float2(vb[i].x, vb[i].y));
+                pack_store<P>(line, g * P::NL + l + 1, make_float2(va[i].z, va[i].w), make_float2(vb[i].z, vb[i].w));
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < IT; i++) {
-        const int e = threadIdx.x + i * P::THREADS;
-        if (e < NV) {
-            const int q = 2 * e, l = q / P::HP, kx = q - l * P::HP;
-            float2* line = s + l * P::LS;
-            pack_store<P>(line, kx, make_float2(va[i].x, va[i].y), make_float2(vb[i].x, vb[i].y));
-            pack_store<P>(line, kx + 1, make_float2(va[i].z, va[i].w), make_float2(vb[i].z, vb[i].w));
-        }
-    }
+}
+// one extra line from the halo arrays (row-major over kx)
+template <class P> __device__ __forceinline__ void load_halo_pair(const float2* __restrict__ Ha, const float2* __restrict__ Hb, int sub, int yb,
+                                                                  float2* line, int tid, int nthreads) {
+    const size_t base = ((size_t)sub * P::LB + yb) * P::HP;
+    for (int kx = tid; kx < P::H; kx += nthreads) pack_store<P>(line, kx, Ha[base + kx], Hb[base + kx]);
 }
 // Hermitian split of a packed transform Z (LDS, spectrum order) -> two half spectra, T layout
-template <class P> __device__ __forceinline__ void store_t_split(const float2* s, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub, int y0) {
+template <class P> __device__ __forceinline__ void store_t_split(const float2* s, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub, int yb) {
     constexpr int NE = P::NL * P::H, IT = (NE + P::THREADS - 1) / P::THREADS;
+    const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::HP * P::NL;         // the block's entries (kx, row) are contiguous
 #pragma unroll 6
     for (int i = 0; i < IT; i++) {
         const int e = threadIdx.x + i * P::THREADS;
         if (e >= NE) break;
-        const int kx = e / P::NL, l = e - kx * P::NL;
-        const int y = y0 + l;
-        if (y >= P::L) continue;
-        const float2* line = s + l * P::LS;
+        const int kx = e / P::NL, row = e - kx * P::NL;
+        const float2* line = s + row * P::LS;
         const float2 zk = line[ppos<P>(kx)], zm = line[ppos<P>(kx ? P::L - kx : 0)];
-        const size_t o = ((size_t)sub * P::HP + kx) * P::L + y;
-        Ta[o] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        Tb[o] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        Ta[base + e] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        Tb[base + e] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
     }
 }
 
 // ---- PSF side ---------------------------------------------------------------------------------
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
                                                          const zscal* __restrict__ sc, const float2* __restrict__ tw,
                                                          float2* __restrict__ cA, float2* __restrict__ cB, float2* __restrict__ cKn,
                                                          float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
                                                          double* __restrict__ fs_partial) {
     extern __shared__ float2 s[];
+    float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
     __shared__ double red[3][P::THREADS / 64];
     const int g = blockIdx.x, sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
@@ -249,7 +282,7 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
             s[ll * P::LS + npos<P>(y)] = acc;
         }
         __syncthreads();
-        fwd_lines<P>(s, l, t, tw, X);
+        fwd_lines<P>(s, l, t, twl, X);
         if (pass == 0 && t < P::N1) {
             // Pn^ waits in the (not yet written) A array while Pr^ is transformed: one spectrum in registers at a time
 #pragma unroll
@@ -285,14 +318,14 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
         }
     }
     float2 x[P::N1];
-    inv_lines<P>(X, s, l, t, tw, x);
+    inv_lines<P>(X, s, l, t, twl, x);
     if (t < P::N2) store_u<P>(Ukr, sub, g, l, t, x);
     __syncthreads();
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) X[k2] = cKn[cbase + (size_t)k2 * P::CT];       // written by this thread above
     }
-    inv_lines<P>(X, s, l, t, tw, x);
+    inv_lines<P>(X, s, l, t, twl, x);
     if (t < P::N2) store_u<P>(Ukn, sub, g, l, t, x);
     fs = wave_sum_f64(fs); sk2n = wave_sum_f64(sk2n); sk2r = wave_sum_f64(sk2r);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = fs; red[1][threadIdx.x >> 6] = sk2n; red[2][threadIdx.x >> 6] = sk2r; }
@@ -306,24 +339,26 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_cols(const float* __restrict
 
 // inverse row pass of kr^, kn^ -> kr, kn -> squares -> forward row pass, T layout
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
                                                          const float2* __restrict__ tw, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2) {
     extern __shared__ float2 s[];
+    float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
     const int y0 = blockIdx.x * P::NL, sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
-    load_u_pair<P>(Ukr, Ukn, sub, y0, s);
+    load_u_pair<P>(Ukr, Ukn, sub, blockIdx.x, s);
     __syncthreads();
     float2 X[P::N2], x[P::N1];
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
     }
-    inv_lines<P>(X, s, l, t, tw, x);
+    inv_lines<P>(X, s, l, t, twl, x);
     __syncthreads();
     if (t < P::N2) {
 #pragma unroll
         for (int n1 = 0; n1 < P::N1; n1++) { const float a = x[n1].x * inv_n2, b = x[n1].y * inv_n2; x[n1] = make_float2(a * a, b * b); }
-        fwd_step1_regs<P>(x, s + l * P::LS, t, tw);
+        fwd_step1_regs<P>(x, s + l * P::LS, t, twl);
     }
     __syncthreads();
     if (t < P::N1) {
@@ -335,19 +370,21 @@ __global__ __launch_bounds__(P::THREADS) void k_psf_rows(const float2* __restric
         for (int k2 = 0; k2 < P::N2; k2++) s[l * P::LS + (P::N2 + 1) * t + k2] = X[k2];
     }
     __syncthreads();
-    store_t_split<P>(s, Tkr2, Tkn2, sub, y0);
+    store_t_split<P>(s, Tkr2, Tkn2, sub, blockIdx.x);
 }
 
 // forward column pass of one T-layout array -> C layout
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ tw, float2* __restrict__ Cout) {
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ tw, float2* __restrict__ Cout) {
     extern __shared__ float2 s[];
+    float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
     const int g = blockIdx.x, sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     load_t_lines<P>(T, sub, g, s);
     __syncthreads();
     float2 X[P::N2];
-    fwd_lines<P>(s, l, t, tw, X);
+    fwd_lines<P>(s, l, t, twl, X);
     if (t < P::N1) {
         const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
 #pragma unroll
@@ -381,9 +418,11 @@ struct frame_args {
 
 // cut + forward row pass of a pair of real frames: (N, R) or, with sigma images, (Vn, Vr)
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_img_rows(frame_args f, const float2* __restrict__ tw, float2* __restrict__ Ta,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_rows(frame_args f, const float2* __restrict__ tw, float2* __restrict__ Ta,
                                                          float2* __restrict__ Tb) {
     extern __shared__ float2 s[];
+    float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
     const int y0 = blockIdx.x * P::NL, sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const int sy = sub / f.nsx, sx = sub - sy * f.nsx;
@@ -444,105 +483,109 @@ __global__ __launch_bounds__(P::THREADS) void k_img_rows(frame_args f, const flo
     }
     __syncthreads();
     float2 X[P::N2];
-    fwd_lines<P>(s, l, t, tw, X);
+    fwd_lines<P>(s, l, t, twl, X);
     __syncthreads();
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) s[l * P::LS + (P::N2 + 1) * t + k2] = X[k2];
     }
     __syncthreads();
-    store_t_split<P>(s, Ta, Tb, sub, y0);
+    store_t_split<P>(s, Ta, Tb, sub, blockIdx.x);
 }
 
 // column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U layout)
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_img_cols(float2* TN, const float2* __restrict__ TR,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(float2* TN, const float2* __restrict__ TR,
                                                          const float2* __restrict__ cA, const float2* __restrict__ cB,
                                                          const float2* __restrict__ cKn, const float2* __restrict__ cKr,
                                                          const float2* __restrict__ tw, float2* __restrict__ UD, float2* __restrict__ USn,
-                                                         float2* __restrict__ USr) {
+                                                         float2* __restrict__ USr, float2* __restrict__ HSn, float2* __restrict__ HSr) {
     extern __shared__ float2 s[];
+    float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
     const int g = blockIdx.x, sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
     float2 X[P::N2], x[P::N1];
     // the partial D^ = A N^ waits in this workgroup's own (already consumed) lines of T_N, in the
     // register order of the C layout (coalesced; it stays in the XCD's L2 for the few microseconds)
-    float2* park = TN + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L + (size_t)t * P::NL + l;
+#define PARK(k2) (*park_ptr<P>(TN, sub, g, (k2) * P::CT + t * P::NL + l))
     load_t_lines<P>(TN, sub, g, s);
     __syncthreads();
-    fwd_lines<P>(s, l, t, tw, X);
+    fwd_lines<P>(s, l, t, twl, X);
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) {
             const size_t o = cbase + (size_t)k2 * P::CT;
-            park[(size_t)k2 * P::CT] = cmul(cA[o], X[k2]);
+            PARK(k2) = cmul(cA[o], X[k2]);
             X[k2] = cmul(cKn[o], X[k2]);
         }
     }
     __syncthreads();
-    inv_lines<P>(X, s, l, t, tw, x);
-    if (t < P::N2) store_u<P>(USn, sub, g, l, t, x);
+    inv_lines<P>(X, s, l, t, twl, x);
+    if (t < P::N2) store_u<P>(USn, sub, g, l, t, x, HSn);
     __syncthreads();
     load_t_lines<P>(TR, sub, g, s);
     __syncthreads();
-    fwd_lines<P>(s, l, t, tw, X);
+    fwd_lines<P>(s, l, t, twl, X);
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) {
             const size_t o = cbase + (size_t)k2 * P::CT;
-            const float2 br = cmul(cB[o], X[k2]), da = park[(size_t)k2 * P::CT];
-            park[(size_t)k2 * P::CT] = make_float2(da.x - br.x, da.y - br.y);
+            const float2 br = cmul(cB[o], X[k2]), da = PARK(k2);
+            PARK(k2) = make_float2(da.x - br.x, da.y - br.y);
             X[k2] = cmul(cKr[o], X[k2]);
         }
     }
     __syncthreads();
-    inv_lines<P>(X, s, l, t, tw, x);
-    if (t < P::N2) store_u<P>(USr, sub, g, l, t, x);
+    inv_lines<P>(X, s, l, t, twl, x);
+    if (t < P::N2) store_u<P>(USr, sub, g, l, t, x, HSr);
     __syncthreads();
     if (t < P::N1) {
 #pragma unroll
-        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = park[(size_t)k2 * P::CT];
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = PARK(k2);
     }
-    inv_lines<P>(X, s, l, t, tw, x);
+    inv_lines<P>(X, s, l, t, twl, x);
     if (t < P::N2) store_u<P>(UD, sub, g, l, t, x);
 }
 
 // column pass of the variance pair: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^ and back (U layout)
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_var_cols(float2* TVn, const float2* __restrict__ TVr,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(float2* TVn, const float2* __restrict__ TVr,
                                                          const float2* __restrict__ cK2n, const float2* __restrict__ cK2r,
                                                          const float2* __restrict__ tw, float2* __restrict__ UVS,
                                                          const zscal* __restrict__ sc, const double* __restrict__ fs_partial) {
     extern __shared__ float2 s[];
+    float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
     __shared__ float s_beta;
     const int g = blockIdx.x, sub = blockIdx.y;
     if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, gridDim.y, sub, sc[sub]);
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     const size_t cbase = ((size_t)(sub * P::G + g) * P::N2) * P::CT + (size_t)t * P::NL + l;
     float2 X[P::N2], x[P::N1];
-    float2* park = TVn + ((size_t)sub * P::HP + (size_t)g * P::NL) * P::L + (size_t)t * P::NL + l;
+#define PARKV(k2) (*park_ptr<P>(TVn, sub, g, (k2) * P::CT + t * P::NL + l))
     load_t_lines<P>(TVn, sub, g, s);
     __syncthreads();
-    fwd_lines<P>(s, l, t, tw, X);
+    fwd_lines<P>(s, l, t, twl, X);
     if (t < P::N1) {
 #pragma unroll
-        for (int k2 = 0; k2 < P::N2; k2++) park[(size_t)k2 * P::CT] = cmul(cK2n[cbase + (size_t)k2 * P::CT], X[k2]);
+        for (int k2 = 0; k2 < P::N2; k2++) PARKV(k2) = cmul(cK2n[cbase + (size_t)k2 * P::CT], X[k2]);
     }
     __syncthreads();
     load_t_lines<P>(TVr, sub, g, s);
     __syncthreads();
     const float beta = s_beta;
-    fwd_lines<P>(s, l, t, tw, X);
+    fwd_lines<P>(s, l, t, twl, X);
     if (t < P::N1) {
 #pragma unroll
         for (int k2 = 0; k2 < P::N2; k2++) {
-            const float2 v = cmul(cK2r[cbase + (size_t)k2 * P::CT], X[k2]), a = park[(size_t)k2 * P::CT];
+            const float2 v = cmul(cK2r[cbase + (size_t)k2 * P::CT], X[k2]), a = PARKV(k2);
             X[k2] = make_float2((a.x + v.x) * beta, (a.y + v.y) * beta);
         }
     }
     __syncthreads();
-    inv_lines<P>(X, s, l, t, tw, x);
+    inv_lines<P>(X, s, l, t, twl, x);
     if (t < P::N2) store_u<P>(UVS, sub, g, l, t, x);
 }
 
@@ -552,20 +595,26 @@ struct out_args {
 };
 
 // inverse row pass of (D, V_S) and (Sn, Sr) + the final algebra, written into the full frames.
-// A workgroup takes NL rows of a sub-image: row 0 is the halo (y - 1) of the NL - 1 output rows.
+// A workgroup takes one block of NL rows.  The row above the block (for the y finite difference)
+// comes from the halo arrays as one more line, transformed by the 64 extra threads of the workgroup.
+// Thread mapping: task index fastest (unlike the other kernels): after the inverse transform a
+// thread holds x = N2 n1 + t of its row, so the lanes of a wave-instruction hold up to N2
+// consecutive pixels of a row and the five outputs go from registers straight to the frames.
 template <class P>
-__global__ __launch_bounds__(P::THREADS) void k_final_rows(const float2* __restrict__ UD, const float2* __restrict__ UVS,
-                                                           const float2* __restrict__ USn, const float2* __restrict__ USr,
-                                                           const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
-                                                           float inv_n2, const float2* __restrict__ tw, out_args o) {
+__global__ __launch_bounds__(P::THREADS + 64, P::MINW) void k_final_rows(const float2* __restrict__ UD, const float2* __restrict__ UVS,
+                                                                         const float2* __restrict__ USn, const float2* __restrict__ USr,
+                                                                         const float2* __restrict__ HSn, const float2* __restrict__ HSr,
+                                                                         const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
+                                                                         float inv_n2, const float2* __restrict__ tw, out_args o, int yb0) {
     extern __shared__ float2 s[];
-    float* stage = (float*)(s + P::NL * P::LS);                     // [NL][L] output staging
-    __shared__ float s_fs;
-    const int sub = blockIdx.y;
-    const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
-    const int yfirst = o.border + blockIdx.x * (P::NL - 1) - 1;     // sub-image row of line 0 (may be -1: wraps)
+    float2* hline = s + P::NL * P::LS;                              // the halo line
+    __shared__ float s_fs, s_ibeta;
+    const int sub = blockIdx.y, yb = yb0 + blockIdx.x, y0 = yb * P::NL;
+    const bool main_thread = threadIdx.x < P::NL * P::NT;
+    const int l = main_thread ? threadIdx.x / P::NT : P::NL;       // threads beyond the NL * NT tasks: the halo line (64 of them at least)
+    const int t = main_thread ? threadIdx.x % P::NT : threadIdx.x - P::NL * P::NT;
+    float2* myline = s + l * P::LS;
     const zscal z = sc[sub];
-    __shared__ float s_ibeta;
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int g = 0; g < P::G; g++) tot += fs_partial[(size_t)sub * P::G + g];
@@ -575,99 +624,68 @@ __global__ __launch_bounds__(P::THREADS) void k_final_rows(const float2* __restr
     const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
     const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
     const int sy = sub / o.nsx, sx = sub - sy * o.nsx;
-    // rows are taken modulo L (np.roll semantics of the finite differences at y = 0)
-    const int ybase = ((yfirst % P::L) + P::L) % P::L;
-    auto load_pair = [&](const float2* __restrict__ Ua, const float2* __restrict__ Ub) {
-        if (ybase + P::NL <= P::L) { load_u_pair<P>(Ua, Ub, sub, ybase, s); return; }
-        for (int e = threadIdx.x; e < P::NL * P::HP; e += P::THREADS) {       // the block straddles the wrap: row by row
-            const int ll = e / P::HP, kx = e - ll * P::HP;
-            if (kx >= P::H) continue;
-            const int y = (ybase + ll) % P::L;
-            const size_t q = ((size_t)sub * P::L + y) * P::HP + kx;
-            const float2 a = Ua[q], b = Ub[q];
-            float2* line = s + ll * P::LS;
-            line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
-            if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
-        }
-    };
-    auto write_rows = [&](float* dst) {                           // staging rows 1 .. NL-1 -> the frame
-        __syncthreads();
-        if (o.vec4) {
-            const int nq = o.size / 4;
-            for (int e = threadIdx.x; e < (P::NL - 1) * nq; e += P::THREADS) {
-                const int ll = 1 + e / nq, xi = 4 * (e - (ll - 1) * nq);
-                const int y = yfirst + ll;                           // sub-image row
-                if (y >= o.border + o.size) continue;
-                const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
-                *reinterpret_cast<float4*>(dst + (size_t)Y * o.nx + Xf) = *reinterpret_cast<const float4*>(stage + ll * P::L + o.border + xi);
-            }
-        } else {
-            for (int e = threadIdx.x; e < (P::NL - 1) * o.size; e += P::THREADS) {
-                const int ll = 1 + e / o.size, xi = e - (ll - 1) * o.size;
-                const int y = yfirst + ll;
-                if (y >= o.border + o.size) continue;
-                const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
-                if (Y < o.ny && Xf < o.nx) dst[(size_t)Y * o.nx + Xf] = stage[ll * P::L + o.border + xi];
-            }
-        }
-        __syncthreads();
-    };
+    // this thread's row in the frame (or none)
+    const int y = y0 + l;
+    const bool row_out = main_thread && y >= o.border && y < o.border + o.size && sy * o.size + (y - o.border) < o.ny;
+    const size_t rowbase = row_out ? (size_t)(sy * o.size + (y - o.border)) * o.nx + (size_t)sx * o.size : 0;
     float2 X[P::N2], x[P::N1];
     float vs[P::N1];
     // (D, V_S): D goes out at once, V_S stays in registers
-    load_pair(UD, UVS);
+    if (threadIdx.x < P::THREADS) load_u_pair<P>(UD, UVS, sub, yb, s);
     __syncthreads();
-    if (t < P::N1) {
+    if (main_thread && t < P::N1) {
 #pragma unroll
-        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = myline[(P::N2 + 1) * t + k2];
+        inv_step2<P>(X, myline, t, tw);
     }
-    inv_lines<P>(X, s, l, t, tw, x);
+    __syncthreads();
     const float ibeta = s_ibeta;
-    if (t < P::N2) {
+    if (main_thread && t < P::N2) {
+        inv_step1<P>(myline, t, x);
 #pragma unroll
-        for (int n1 = 0; n1 < P::N1; n1++) { stage[l * P::L + P::N2 * n1 + t] = x[n1].x * inv_n2 / fD; vs[n1] = x[n1].y * inv_n2 * ibeta; }
+        for (int n1 = 0; n1 < P::N1; n1++) {
+            const int xi = P::N2 * n1 + t - o.border;
+            vs[n1] = x[n1].y * inv_n2 * ibeta;
+            if (row_out && xi >= 0 && xi < o.size && sx * o.size + xi < o.nx) o.D[rowbase + xi] = x[n1].x * inv_n2 / fD;
+        }
     }
-    write_rows(o.D);
-    // (Sn, Sr)
-    load_pair(USn, USr);
     __syncthreads();
-    if (t < P::N1) {
+    // (Sn, Sr): the block's rows + the row above it (row L - 1 above row 0: np.roll)
+    if (threadIdx.x < P::THREADS) load_u_pair<P>(USn, USr, sub, yb, s);
+    if (!main_thread) load_halo_pair<P>(HSn, HSr, sub, yb ? yb - 1 : P::LB - 1, hline, threadIdx.x - P::NL * P::NT, (int)blockDim.x - P::NL * P::NT);
+    __syncthreads();
+    if (t < P::N1) {                                              // the extra threads take part with the halo line
 #pragma unroll
-        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = s[l * P::LS + (P::N2 + 1) * t + k2];
+        for (int k2 = 0; k2 < P::N2; k2++) X[k2] = myline[(P::N2 + 1) * t + k2];
+        inv_step2<P>(X, myline, t, tw);
     }
-    inv_lines<P>(X, s, l, t, tw, x);
+    __syncthreads();
+    if (t < P::N2) inv_step1<P>(myline, t, x);
     __syncthreads();
     // Sn, Sr (scaled) in natural order for the neighbour reads
     if (t < P::N2) {
 #pragma unroll
-        for (int n1 = 0; n1 < P::N1; n1++) s[l * P::LS + npos<P>(P::N2 * n1 + t)] = cscale(x[n1], inv_n2);
+        for (int n1 = 0; n1 < P::N1; n1++) { x[n1] = cscale(x[n1], inv_n2); myline[npos<P>(P::N2 * n1 + t)] = x[n1]; }
     }
     __syncthreads();
     const float fs = s_fs;
-    // the other four outputs, one at a time through the staging rows
-    for (int which = 1; which < 5; which++) {
-        float* dst = which == 1 ? o.S : which == 2 ? o.Scorr : which == 3 ? o.Fpsf : o.Fpsferr;
-        if (!dst) continue;                                       // workgroup-uniform
-        if (t < P::N2 && l >= 1) {
+    if (row_out && t < P::N2) {
+        const float2* upline = l ? s + (l - 1) * P::LS : hline;
 #pragma unroll
-            for (int n1 = 0; n1 < P::N1; n1++) {
-                const int xx = P::N2 * n1 + t;
-                const float2 c = s[l * P::LS + npos<P>(xx)];                   // (Sn, Sr) here
-                const float sval = c.x - c.y;                                   // S = Sn - Sr
-                float v;
-                if (which == 1) v = sval;
-                else if (which == 2) {
-                    const int xm = xx == 0 ? P::L - 1 : xx - 1;
-                    const float2 up = s[(l - 1) * P::LS + npos<P>(xx)], lf = s[l * P::LS + npos<P>(xm)];
-                    const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
-                    const float vast = z.dx * z.dx * (dSndx * dSndx + dSrdx * dSrdx) + z.dy * z.dy * (dSndy * dSndy + dSrdy * dSrdy);
-                    v = sval / sqrtf(vs[n1] + vast);
-                } else if (which == 3) v = sval / fs;
-                else v = sqrtf(fmaxf(vs[n1], 0.f)) / fs;
-                stage[l * P::L + xx] = v;
-            }
+        for (int n1 = 0; n1 < P::N1; n1++) {
+            const int xx = P::N2 * n1 + t, xi = xx - o.border;
+            if (xi < 0 || xi >= o.size || sx * o.size + xi >= o.nx) continue;
+            const float2 c = x[n1];                                         // (Sn, Sr) here
+            const float sval = c.x - c.y;                                   // S = Sn - Sr
+            const int xm = xx == 0 ? P::L - 1 : xx - 1;
+            const float2 up = upline[npos<P>(xx)], lf = myline[npos<P>(xm)];
+            const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
+            const float vast = z.dx * z.dx * (dSndx * dSndx + dSrdx * dSrdx) + z.dy * z.dy * (dSndy * dSndy + dSrdy * dSrdy);
+            if (o.S) o.S[rowbase + xi] = sval;
+            o.Scorr[rowbase + xi] = sval / sqrtf(vs[n1] + vast);
+            o.Fpsf[rowbase + xi] = sval / fs;
+            o.Fpsferr[rowbase + xi] = sqrtf(fmaxf(vs[n1], 0.f)) / fs;
         }
-        write_rows(dst);
     }
 }
 
@@ -682,12 +700,14 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
                float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
     const int nsy = ny / size, nsx = nx / size, nsub = nsy * nsx;
     int rc;
-    const size_t unit = (size_t)nsub * P::HP * P::L;                  // elements of one T / U / C array
+    const size_t unit = (size_t)nsub * P::UNIT;                       // elements of one T / U / C array
+    const size_t hunit = (size_t)nsub * P::LB * P::HP;                // elements of one halo array
     // 4 T + 4 U + 6 C arrays + scalars + F_S partial sums
-    const size_t bytes = 14 * unit * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 3 * (size_t)nsub * P::G * sizeof(double) + 4096;
+    const size_t bytes = (14 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 3 * (size_t)nsub * P::G * sizeof(double) + 4096;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
     float2* arr[14]; for (int i = 0; i < 14; i++) arr[i] = (float2*)ws + (size_t)i * unit;
-    char* p = ws + 14 * unit * sizeof(float2);
+    float2 *HSn = (float2*)ws + 14 * unit, *HSr = HSn + hunit;
+    char* p = ws + (14 * unit + 2 * hunit) * sizeof(float2);
     zscal* d_sc = (zscal*)p; p += (size_t)nsub * sizeof(zscal);
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     double* fs_partial = (double*)p;
@@ -696,7 +716,9 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     // (pageable host source: the runtime stages it before the call returns)
     BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));
     const float2* tw = st->d_tw;
-    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2), lds_fin = lds + (size_t)P::NL * P::L * sizeof(float);
+    const size_t lds_tw = (size_t)P::L * sizeof(float2);
+    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + lds_tw,
+                 lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2);
     static bool attr_set = false;
     if (!attr_set) {
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -709,7 +731,7 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
         attr_set = true;
     }
     const float inv_n2 = 1.0f / ((float)P::L * (float)P::L);
-    const dim3 gcol(P::G, nsub), grow((P::L + P::NL - 1) / P::NL, nsub), blk(P::THREADS);
+    const dim3 gcol(P::G, nsub), grow(P::LB, nsub), blk(P::THREADS);
     bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
     // PSF side: U0 = kn (cols^-1), U1 = kr; T0 = (kr^2)^ rows, T1 = (kn^2)^ rows
     hipLaunchKernelGGL(k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial);
@@ -722,14 +744,16 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T0, T1);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3);
-    hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2);      // D, Sn, Sr
+    hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr);      // D, Sn, Sr
     hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3, d_sc, fs_partial);                    // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx;
     oa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 &&
                ((uintptr_t)d_D | (uintptr_t)d_S | (uintptr_t)d_Scorr | (uintptr_t)d_Fpsf | (uintptr_t)d_Fpsferr) % 16 == 0) ? 1 : 0;
-    const dim3 gfin((size + P::NL - 2) / (P::NL - 1), nsub);
-    hipLaunchKernelGGL(k_final_rows<P>, gfin, blk, lds_fin, s, U0, U3, U1, U2, d_sc, fs_partial, inv_n2, tw, oa);
+    // row blocks that hold output rows: border .. border + size - 1
+    const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
+    const dim3 gfin(yb1 - yb0 + 1, nsub);
+    hipLaunchKernelGGL(k_final_rows<P>, gfin, dim3(((P::NL * P::NT + 64 + 63) / 64) * 64), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial, inv_n2, tw, oa, yb0);
     bbx_prof_stop(ctx, s);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
