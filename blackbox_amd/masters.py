@@ -59,22 +59,28 @@ def gain_correction_factors(ctx, master, header, ysize_chan=None, xsize_chan=Non
     from . import flatstats
     NY, NX = master.shape
     ysz, xsz = ysize_chan or NY // 2, xsize_chan or NX // 8
-    if nrows_v > ysz or nrows_h > ysz or ncols > xsz:
-        raise ValueError('statistics strips larger than a channel')
+    def pyslice(start, stop, n):
+        """[start:stop] of an axis of length n with Python's rules (the reference slices numpy arrays
+        with these numbers; strips larger than the frame are clamped, a negative start wraps once)"""
+        a, b, _ = slice(start, stop).indices(n)
+        if b <= a:
+            raise ValueError('empty statistics strip [{}:{}] on an axis of {}'.format(start, stop, n))
+        return a, b - a
     corr = master.clone()
     med = np.zeros(16)
     for c in range(16):
         iy, ix = divmod(c, 8)
-        y0 = (ysz - nrows_v) if iy == 0 else ysz
-        med[c] = np.float32(flatstats.rect_stats(ctx, corr, None, y0, ix * xsz, nrows_v, xsz, nrows_v, xsz)[0, 1])
+        ya, nr = pyslice(-nrows_v, None, ysz) if iy == 0 else pyslice(0, nrows_v, ysz)      # data_chan[-nrows:, :] / [0:nrows, :]
+        med[c] = np.float32(flatstats.rect_stats(ctx, corr, None, iy * ysz + ya, ix * xsz, nr, xsz, nr, xsz)[0, 1])
         _rect_scale(ctx, corr, iy * ysz, ix * xsz, ysz, xsz, med[c], True)
     factor = 1.0 / med
     for i in range(1, 8):
         x_index = i * xsz
-        m1 = np.float32(flatstats.rect_stats(ctx, corr, None, ysz - nrows_h, x_index - ncols, 2 * nrows_h, ncols,
-                                             2 * nrows_h, ncols)[0, 1])
-        m2 = np.float32(flatstats.rect_stats(ctx, corr, None, ysz - nrows_h, x_index, 2 * nrows_h, ncols,
-                                             2 * nrows_h, ncols)[0, 1])
+        ya, nr = pyslice(ysz - nrows_h, ysz + nrows_h, NY)
+        xa, nc1 = pyslice(x_index - ncols, x_index, NX)
+        xb, nc2 = pyslice(x_index, x_index + ncols, NX)
+        m1 = np.float32(flatstats.rect_stats(ctx, corr, None, ya, xa, nr, nc1, nr, nc1)[0, 1])
+        m2 = np.float32(flatstats.rect_stats(ctx, corr, None, ya, xb, nr, nc2, nr, nc2)[0, 1])
         ratio = np.float32(m1) / np.float32(m2)
         _rect_scale(ctx, corr, 0, i * xsz, ysz, xsz, ratio, False)
         _rect_scale(ctx, corr, ysz, i * xsz, ysz, xsz, ratio, False)

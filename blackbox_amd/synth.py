@@ -210,3 +210,95 @@ def make_case(ysize_chan, xsize_chan, seed, tel='ML1', os_y=20, os_x=45,
     return dict(raw=raw, flat=flat, bias=bias,
                 bpm=make_bpm(ysize_chan, xsize_chan, seed),
                 xtalk=make_xtalk(seed), scene=scene, cr=cr)
+
+
+# ---- inputs of the round-2 reference-run fixtures (oracle/gen_golden_r02.py, tests) -----------
+# master frames: channels wider than 200 px (master_prep's boundary strips are 200 columns)
+MASTER_GEOM = (64, 210)
+MASTER_NORM_SEC = (slice(32, 96), slice(400, 800))
+
+
+def master_bpm():
+    ys, xs = MASTER_GEOM
+    bpm = np.zeros((2 * ys, 8 * xs), np.uint8)
+    bpm[:3] = 32; bpm[-3:] = 32; bpm[:, :3] = 32; bpm[:, -3:] = 32
+    bpm[40, 500] = 1
+    return bpm
+
+
+def master_frames(imgtype, n=6, seed=5):
+    """-> (list of float32 frames, MEDSEC per frame or None): reduced flats with a level step per
+    channel and a few non-positive pixels, or bias frames with zeros (sigma_clipped_stats(mask_value=0))"""
+    ys, xs = MASTER_GEOM
+    ny, nx = 2 * ys, 8 * xs
+    rs = np.random.RandomState(seed + (0 if imgtype == 'flat' else 100))
+    chan = (np.arange(nx) // xs)[None, :] + 8 * (np.arange(ny) // ys)[:, None]
+    frames, medsec = [], []
+    for k in range(n):
+        if imgtype == 'flat':
+            lev = 20000.0 + 1500.0 * k
+            img = lev * (1.0 + 0.02 * _gauss(rs, (ny, nx))) * (1.0 + 0.004 * chan)
+            img[10, 20 + k] = -5.0
+            img = img.astype(np.float32)
+            medsec.append(np.median(img[MASTER_NORM_SEC]))
+        else:
+            img = (3.0 * _gauss(rs, (ny, nx)) + 0.2 * chan).astype(np.float32)
+            img[rs.random_sample((ny, nx)) < 0.001] = 0.0
+        frames.append(img)
+    return frames, (medsec if imgtype == 'flat' else None)
+
+
+# get_flatstats: a square frame (the reference reshapes into nsubs x nsubs sub-images)
+FLATSTAT_GEOM = (120, 30)
+FLATSTAT_SUB = 60
+FLATSTAT_SEC = (slice(60, 180), slice(30, 150))
+
+
+def flatstat_frame(seed=9):
+    ys, xs = FLATSTAT_GEOM
+    ny, nx = 2 * ys, 8 * xs
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    data = (30000.0 * (1.0 - 0.1 * ((yy - 120.0) ** 2 + (xx - 120.0) ** 2) / 28800.0) * (1.0 + 0.01 * _gauss(rs, (ny, nx)))).astype(np.float32)
+    mask = np.zeros((ny, nx), np.uint8)
+    mask[:4] = 32; mask[-4:] = 32; mask[:, :4] = 32; mask[:, -4:] = 32
+    mask[rs.random_sample((ny, nx)) < 0.01] |= 1
+    data[100, 100] = 250000.0
+    return data, mask
+
+
+NONLIN_GEOM = (32, 40)
+
+
+def nonlin_frame(seed=13):
+    """overscan-corrected frame in e-: counts from ~0 to above the 50000-count limit of nonlin_corr"""
+    ys, xs = NONLIN_GEOM
+    rs = np.random.RandomState(seed)
+    return (rs.random_sample((2 * ys, 8 * xs)) * 130000.0).astype(np.float32)
+
+
+def nonlin_splines():
+    """inputs of 16 scipy UnivariateSpline fits (x, y, w, k, s): fractional non-linearity vs counts"""
+    out = []
+    for c in range(16):
+        x = np.arange(0.0, 66000.0, 3000.0)
+        y = 1e-3 * (1.0 + 0.1 * c) * ((x / 30000.0) * (x / 30000.0) - x / 30000.0)
+        out.append((x, y, None, 3, 0.0))
+    return out
+
+
+def qc_headers():
+    """header dicts for the qc_check pins: (name, telescope, check_key_type, header)"""
+    base = {'IMAGETYP': 'object', 'FILTER': 'q', 'RA': 120.0, 'DEC': -30.0, 'XTALK-P': True, 'NONLIN-P': False, 'GAIN-P': True, 'OS-P': True, 'MBIAS-P': False,
+            'MFLAT-P': True, 'COSMIC-P': True, 'SAT-P': True, 'BIASMEAN': 6460.0, 'RDNOISE': 9.0, 'N-INFNAN': 0, 'NCOSMICS': 10.0,
+            'NSATS': 1}
+    cases = [('all_green', 'ML1', 'full', dict(base))]
+    h = dict(base); h['XTALK-P'] = False; h['RDNOISE'] = 12.0
+    cases.append(('red_flag_and_yellow', 'ML1', 'full', h))
+    h = dict(base); h['BIASMEAN'] = 6900.0; h['NCOSMICS'] = 80.0; h['N-INFNAN'] = 5
+    cases.append(('orange_sigma', 'ML1', 'full', h))
+    h = dict(base); h['NCOSMICS'] = 'None'; h['COSMIC-P'] = False; h['NSATS'] = 150
+    cases.append(('none_value_and_red', 'ML1', 'full', h))
+    h = dict(base); h['MBIAS-P'] = True; h['BIASMEAN'] = 3300.0; h['RDNOISE'] = 16.0
+    cases.append(('blackgem', 'BG3', 'full', h))
+    return cases

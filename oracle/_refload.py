@@ -95,7 +95,15 @@ def load(cal_dir='/tmp/bbx_cal'):
             return data, header
         return data if get_data else header
 
-    _stub('zogy', np=np, fits=fits, Table=Table, vstack=vstack, unique=unique,
+    def list_files(path, search_str='', end_str='', start_str=None, recursive=False):
+        # restatement of the zogy helper: files whose path starts with [path], contains
+        # [search_str] and ends with [end_str]
+        import glob
+        names = glob.glob(path + '*') + (glob.glob(path + '/**/*', recursive=True) if recursive else [])
+        return sorted(f for f in set(names) if os.path.isfile(f) and search_str in f and f.endswith(end_str)
+                      and (start_str is None or os.path.basename(f).startswith(start_str)))
+
+    _stub('zogy', np=np, fits=fits, list_files=list_files, Table=Table, vstack=vstack, unique=unique,
           sigma_clip=sigma_clip, ndimage=ndimage, interpolate=interpolate,
           subprocess=subprocess, traceback=traceback, argparse=argparse,
           get_par=get_par, get_rand_indices=get_rand_indices,
