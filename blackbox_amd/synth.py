@@ -302,3 +302,28 @@ def qc_headers():
     h = dict(base); h['MBIAS-P'] = True; h['BIASMEAN'] = 3300.0; h['RDNOISE'] = 16.0
     cases.append(('blackgem', 'BG3', 'full', h))
     return cases
+
+
+CLIP_FILTERS = {'default': ((5, 1), (3.5, 4.0), (4, 1)), 'wide': ((7, 3, 1), (3.0, 3.5, 5.0), (6, 3, 1))}
+
+
+def clip_points(seed=21):
+    """clipped-pixel table of one input image for the pass_filters pin: isolated points, clusters
+    (cosmic-ray / satellite residuals), both signs, points at the frame corners -> (x, y 1-based, nsigma, shape)"""
+    rs = np.random.RandomState(seed)
+    ny, nx = 120, 160
+    xs, ys, ns = [], [], []
+    for _ in range(150):
+        xs.append(1 + int(rs.random_sample() * nx)); ys.append(1 + int(rs.random_sample() * ny)); ns.append(3.0 + 4.0 * rs.random_sample())
+    for _ in range(8):
+        cx, cy = 5 + int(rs.random_sample() * (nx - 10)), 5 + int(rs.random_sample() * (ny - 10))
+        sign = 1.0 if rs.random_sample() < 0.7 else -1.0
+        for _ in range(3 + int(rs.random_sample() * 12)):
+            xs.append(cx + int(rs.random_sample() * 5)); ys.append(cy + int(rs.random_sample() * 5)); ns.append(sign * (3.2 + 6.0 * rs.random_sample()))
+    for (x, y) in ((1, 1), (nx, ny), (nx, 1), (1, ny), (nx - 1, ny - 1), (nx, ny - 2), (nx - 2, ny)):
+        xs.append(x); ys.append(y); ns.append(6.0)
+    x, y, n = np.array(xs), np.array(ys), np.array(ns, np.float32)
+    key = y * 100000 + x                                        # one entry per pixel
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    return x[first], y[first], n[first], (ny, nx)

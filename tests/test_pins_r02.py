@@ -188,3 +188,58 @@ def test_qc_check_vs_reference():
         assert added == want['added'], name
         for k, c in want['added_comments'].items():
             assert (h2[k][1] if isinstance(h2[k], tuple) else '') == c, (name, k)
+
+
+# ---- f3: clip log -> input-frame masks (in-reference integer code) ------------------------------------
+def test_oracle_pass_filters_vs_reference():
+    """oracle/coadd.pass_filters == the reference's own buildref.pass_filters on the same table; the HIP
+    kernel (bbx_clipped2mask) is held to that oracle in tests/test_gpu_coadd.py"""
+    import coadd as OC
+    x, y, ns, shape = synth.clip_points()
+    assert META['pass_filters']['npoints'] == x.size and tuple(META['pass_filters']['shape']) == shape
+    for name, (fsize, fsigma, fmax) in synth.CLIP_FILTERS.items():
+        m = OC.pass_filters(x, y, ns, list(fsize), list(fsigma), list(fmax), shape)
+        want = np.unpackbits(NPZ['passfilt_' + name])[:shape[0] * shape[1]].reshape(shape).astype(bool)
+        assert META['pass_filters']['cases'][name]['n'] == int(want.sum()) > 0
+        assert np.array_equal(m, want), name
+
+
+# ---- f4: verify_header ------------------------------------------------------------------------------------
+def test_verify_header_vs_reference_behaviour():
+    """for every keyword of the product's contract that the reference's verify_header knows ('full'
+    headers; per-channel families: channels 1 and 16 there), the same reaction to the keyword missing
+    (KeyError / warning), to 'None' (ValueError / accepted) and to values of each basic type (dtype warning)"""
+    probe = META['verify_header']['probe']
+    known = {k: e for k, e in probe.items() if e['known']}
+    assert len(known) >= 40 and 'RDNOISE' in known and 'COSMIC-P' in known
+    sample = {'bool': True, 'int': 3, 'float': 2.5, 'str': 'x'}
+    base = {}
+    for k, e in qc.REDUCTION_CONTRACT.items():
+        base[k] = sample[e['dtype'].__name__]
+    assert qc.verify_header(dict(base), ['full']) == []
+
+    def outcome(h, key):
+        try:
+            w = qc.verify_header(h, ['full'])
+        except KeyError:
+            return 'KeyError', []
+        except ValueError:
+            return 'ValueError', []
+        return 'ok', [m for m in w if ('keyword ' + key + ' ') in m or ('keyword ' + key + ':') in m]
+    for key, e in known.items():
+        h = dict(base); del h[key]
+        res, w = outcome(h, key)
+        assert (res if res != 'ok' else ('warning' if w else 'silent')) == e['missing'], key
+        h = dict(base); h[key] = 'None'
+        assert outcome(h, key)[0] == e['none'], key
+        good = []
+        for tname, val in sample.items():
+            h = dict(base); h[key] = val
+            res, w = outcome(h, key)
+            if not any('dtype of keyword' in m for m in w):
+                good.append(tname)
+        assert good == e['dtype_ok'], key
+    # the families the reference spells out for channels 1 and 16 only carry the same rule for every channel
+    for fam in ('GAIN', 'BIASM', 'RDN', 'VFITOK'):
+        for c in range(2, 16):
+            assert qc.REDUCTION_CONTRACT['%s%d' % (fam, c)] == qc.REDUCTION_CONTRACT['%s1' % fam]
