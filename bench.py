@@ -152,7 +152,7 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras
     return raw.contiguous(), flat, bpm
 
 
-def synth_reference(torch, dev, scene0, seed, depth=4.0, sky_ref=120.0):
+def synth_reference(torch, dev, scene0, seed, depth=4.0, sky_ref=0.0):
     """the co-added reference image of the field: the same scene without
     cosmic rays / trails / transients at [depth] x the exposure (noise / sqrt(depth) in the
     new frame's units), another sky level; mask all zero"""
@@ -354,7 +354,10 @@ def main():
     S = 25
     psf_n = torch.from_numpy(moffat_stamp(S, 4.0)).to(dev)
     psf_r = torch.from_numpy(moffat_stamp(S, 4.0)).to(dev)
-    sub_kw = dict(ref=ref, ref_mask=ref_mask, psf_new=psf_n, psf_ref=psf_r, fratio=1.0, dx=0.03, dy=0.03, ref_is_bkgsub=False,
+    # the reference is a co-add: background-subtracted, with its `_bkg_std_mini` image (buildref products)
+    ref_std_mini = np.full((2 * ysz // box, 8 * xsz // box), 8.0, np.float32)
+    sub_kw = dict(ref=ref, ref_mask=ref_mask, psf_new=psf_n, psf_ref=psf_r, fratio=1.0, dx=0.03, dy=0.03, ref_is_bkgsub=True,
+                  ref_bkg_std_mini=ref_std_mini,
                   cat_extract=True, trans_extract=True, subimage_size=size, subimage_border=border, bkg_boxsize=box)
     base_kw = dict(mflat=flat, bpm=bpm)
     kws = {
@@ -445,15 +448,21 @@ def main():
         L = size + 2 * border
         nsub = (2 * ysz // size) * (8 * xsz // size)
         # algorithmic bytes per launch
+        HP = ((L // 2 + 1 + 5) // 6) * 6                     # padded half-spectrum width of bbx_zogy2.hip (NL = 6)
+        spec = nsub * HP * L * 8                              # one half spectrum of all sub-images, bytes
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
             'k_lac_cand': (1, 4 * N),
-            # ZOGY: I/O-only model -- 4 input images read with the tile overlap (L/size)^2, 4 output images written
-            'zogy_subimages': (6, int(4 * 4 * nsub * L * L + 4 * 4 * N)),
+            # k_final_rows (bbx_zogy2.hip): reads the four column-transformed half spectra (D, V_S, S_n, S_r),
+            # writes D, Scorr, Fpsf, Fpsferr
+            'k_final_rows': (7, 4 * spec + 4 * 4 * N),
+            # the other kernels of bbx_zogy_frame together (PSF side, row and column passes); bytes: DESIGN.md section 4
+            'zogy_frame_other': (6, int(37 * spec)),
         }
+        zogy_io_model = int(4 * 4 * nsub * L * L + 4 * 4 * N)     # 4 inputs read with the tile overlap, 4 outputs written
         iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items() if iso_calls[sl]}
         live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items() if calls[sl]}
-        dom = max(live, key=lambda k: live[k][0])          # each runs once per frame
+        dom = max((k for k in live if k != 'zogy_frame_other'), key=lambda k: live[k][0])          # the slowest single kernel; each runs once per frame
 
         def gbs(t):
             return t[1] / (t[0] * 1e-3) / 1e9
@@ -466,6 +475,13 @@ def main():
                           '(other lanes\' kernels run concurrently)' % lanes)
         roof['isolated'] = {k: dict(avg_launch_ms=iso[k][0], launches=int(iso[k][2]), achieved=gbs(iso[k]),
                                     frac=gbs(iso[k]) / HBM_PEAK_GBS, note='serial frames, kernel alone on the GPU') for k in iso}
+        if 'k_final_rows' in iso and 'zogy_frame_other' in iso:
+            zms = iso['k_final_rows'][0] + iso['zogy_frame_other'][0]
+            roof['zogy_stage'] = dict(ms_alone=zms, io_model_bytes=zogy_io_model, achieved=zogy_io_model / (zms * 1e-3) / 1e9,
+                                      frac=zogy_io_model / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      moved_bytes_by_design=int(41 * spec + 16 * N),
+                                      note='SURVEY 8d I/O-only model (3.79 GB) over the whole bbx_zogy_frame call; the design moves '
+                                           '~41 half-spectrum passes (DESIGN.md section 4)')
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))['kernels']
             if not args.small and args.raw == 'u16' and dom in pmc:

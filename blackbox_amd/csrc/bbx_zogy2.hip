@@ -753,6 +753,8 @@ static int run(bbx_ctx* ctx, state* st, int ny, int nx, int size, int border, co
     // row blocks that hold output rows: border .. border + size - 1
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
     const dim3 gfin(yb1 - yb0 + 1, nsub);
+    bbx_prof_stop(ctx, s);
+    bbx_prof_start(ctx, BBX_PROF_ZOGY_FINAL, s);
     hipLaunchKernelGGL(k_final_rows<P>, gfin, dim3(((P::NL * P::NT + 64 + 63) / 64) * 64), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial, inv_n2, tw, oa, yb0);
     bbx_prof_stop(ctx, s);
     BBX_LAUNCH_CHECK();

@@ -121,7 +121,8 @@ int  bbx_copy_async(void *dst, const void *src, size_t nbytes, int kind, void *s
 #define BBX_PROF_XTALK 3       /* k_xtalk                                     */
 #define BBX_PROF_VOS_STD 4     /* read-noise passes      (1 group / frame)   */
 #define BBX_PROF_MASK_FINISH 5 /* mask_init tail + fill  (1 group / frame)   */
-#define BBX_PROF_ZOGY 6        /* bbx_zogy_subimages     (1 group / frame)   */
+#define BBX_PROF_ZOGY 6        /* bbx_zogy_subimages, or the kernels of bbx_zogy_frame before its last one (1 group / frame) */
+#define BBX_PROF_ZOGY_FINAL 7  /* k_final_rows of bbx_zogy_frame (1 launch / frame) */
 #define BBX_PROF_NSLOTS 8
 int  bbx_profile_enable(bbx_ctx *ctx, int on);
 /* synchronises on the recorded events; ms_total/calls have nslots entries; resets */

@@ -15,8 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
     # the ABI / host tests load the in-tree libraries: build them once if a fresh checkout has
     # none yet (hipcc cross-compiles gfx950 without a GPU); a GPU box gets them with the snapshot
+    # ... and rebuild when a source is newer than the library (make decides; needs hipcc)
     lib = os.path.join(ROOT, 'blackbox_amd', 'libbbx_hip.so')
-    if not os.path.isfile(lib) and os.path.isfile(os.path.join(ROOT, 'Makefile')):
+    import glob
+    import shutil
+    srcs = glob.glob(os.path.join(ROOT, 'blackbox_amd', 'csrc', '*')) + [os.path.join(ROOT, 'include', 'bbx.h')]
+    srcs = [f for f in srcs if f.endswith(('.hip', '.h'))]
+    stale = os.path.isfile(lib) and any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs)
+    hipcc = shutil.which('hipcc') or (os.path.isfile('/opt/rocm/bin/hipcc') and '/opt/rocm/bin/hipcc')
+    if (not os.path.isfile(lib) or (stale and hipcc)) and os.path.isfile(os.path.join(ROOT, 'Makefile')):
         import subprocess
         subprocess.run(['make', '-C', ROOT, '-j8', 'all'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
 
