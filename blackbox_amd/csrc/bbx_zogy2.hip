@@ -804,6 +804,9 @@ extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border
         if (e != hipSuccess) return bbx_hip_fail(ctx, e, "twiddle table", __LINE__);
         st->L = L;
     }
+    if (ctx->zogy_core == 1 && bbx_zogy3_supported(L))
+        return bbx_zogy3_run(ctx, st->d_tw, L, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, h_scal, d_D, d_S,
+                             d_Scorr, d_Fpsf, d_Fpsferr, s);
 #define Z2_RUN(N1, N2) return z2::run<z2::Plan<N1, N2>>(ctx, st, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, \
                                                         h_scal, d_D, d_S, d_Scorr, d_Fpsf, d_Fpsferr, s)
     switch (L) {

@@ -1,0 +1,702 @@
+// bbx_zogy3.hip -- ZOGY on whole frames, second FFT core: radix passes in LDS by many threads.
+// Same kernel sequence, data layouts (T / U tiles, C coefficient arrays, halo rows) and algebra as
+// bbx_zogy2.hip -- see the header of that file -- with another 1-D transform inside the kernels:
+//
+//   bbx_zogy2: a line of L = N1 N2 values is transformed in two steps of register DFTs of 35 and
+//              40 points, one thread per sub-transform: ~210 VGPRs, 8 waves per CU at most;
+//   here     : L = R0 R1 [R2 [R3]] (1400 = 5 * 7 * 5 * 8); a step is L / R butterflies of radix R
+//              per line (decimation in frequency, in place: a butterfly reads and writes the same
+//              R positions), any thread takes any butterfly: ~64 VGPRs, 16 waves per CU, all data
+//              movement is loops over the workgroup.  The spectrum is left in the digit-reversed
+//              order of the in-place algorithm (pos(k) below); the inverse runs the steps backwards.
+//
+// Which core bbx_zogy_frame uses: BBX_OPT_ZOGY_CORE (bbx_set_option).
+#include "bbx_common.h"
+#ifndef Z3_NO_CONTRACT
+#pragma clang fp contract(fast)      // the transforms are compared within a tolerance, not bit by bit: let mul + add fuse
+#endif
+#include "bbx_fft_gen.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace z3 {
+
+struct zscal { float sn, sr, fn, fr, dx, dy; };
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; return s; }
+
+#ifndef Z3_THREADS
+#define Z3_THREADS 512         // two workgroups per CU (LDS: 77 KB of lines each)
+#endif
+#ifndef Z3_FIN_THREADS
+#define Z3_FIN_THREADS 1024    // k_final_rows: one workgroup per CU (LDS: 7 lines + the V_S block)
+#endif
+#ifndef Z3_NL
+#define Z3_NL 6
+#endif
+#ifndef Z3_MINW
+#define Z3_MINW 4              // waves per SIMD the register allocation must allow (two workgroups of 512)
+#endif
+#ifndef Z3_FIN_MINW
+#define Z3_FIN_MINW 4
+#endif
+#ifndef Z3_PLAN1400
+#define Z3_PLAN1400 5, 7, 5, 8
+#endif
+#ifndef Z3_TWL
+#define Z3_TWL 0               // twiddle table in LDS (1) or read from global memory (0)
+#endif
+
+template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
+    static constexpr int R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+    static constexpr int L = R0_ * R1_ * R2_ * R3_, H = L / 2 + 1;
+    static constexpr int NL = L >= 512 ? Z3_NL : 16;                // lines per workgroup
+    static constexpr int THREADS = L >= 512 ? Z3_THREADS : 256, FIN_THREADS = L >= 512 ? Z3_FIN_THREADS : 256;
+    static constexpr int G = (H + NL - 1) / NL, HP = G * NL;        // column groups, padded half-spectrum width
+    static constexpr int LP = L + L / 8 + 1;                        // padded line: one pad per 8 entries
+    static constexpr int LS = line_stride(LP);
+    static constexpr int LB = (L + NL - 1) / NL;                    // row blocks of NL rows
+    static constexpr size_t UNIT = (size_t)LB * NL * HP;            // elements of one T / U / C array per sub-image
+    static constexpr int TWL = Z3_TWL;
+    static constexpr int MINW = L >= 512 ? Z3_MINW : 1, FIN_MINW = L >= 512 ? Z3_FIN_MINW : 1;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+template <int N> __device__ __forceinline__ void idft(float2 (&x)[N]) {      // inverse = forward on swapped pairs
+#pragma unroll
+    for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
+    bbx_dft<N>::run(x);
+#pragma unroll
+    for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
+}
+
+__device__ __forceinline__ int npos(int n) { return n + (n >> 3); }                       // LDS position of entry n of a line
+// position of spectral index k after the forward transform (digit reversal of the in-place passes)
+template <class P> __device__ __forceinline__ int ppos(int k) {
+    int p = (k % P::R0) * (P::L / P::R0); k /= P::R0;
+    p += (k % P::R1) * (P::L / (P::R0 * P::R1)); k /= P::R1;
+    if (P::R2 > 1) { p += (k % P::R2) * (P::L / (P::R0 * P::R1 * P::R2)); k /= P::R2; }
+    if (P::R3 > 1) p += k;
+    return npos(p);
+}
+
+// one radix-R pass over blocks of B entries of NLINES lines (B / R = M butterflies per block).  The
+// butterfly's R positions are base + r M: with the padding they stay an affine function of r when M
+// is a multiple of 8, or when M = 1 and the block starts at a multiple of 8 (constant offsets).
+template <class P, int R, int B, bool INV, int NLINES>
+__device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ tw) {
+    constexpr int M = B / R, PER = P::L / R, NTASK = NLINES * PER, TWS = P::L / B;
+    constexpr bool AFF8 = M % 8 == 0, AFF1 = M == 1 && (8 % R == 0 || R % 8 == 0);
+    for (int task = threadIdx.x; task < NTASK; task += blockDim.x) {
+        const int l = task / PER, j = task - l * PER;
+        const int b = j / M, m = j - b * M;
+        const int base = b * B + m;
+        float2* line = s + l * P::LS + ((AFF8 || AFF1) ? npos(base) : 0);
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) u[r] = line[AFF8 ? r * (M + M / 8) : AFF1 ? r + r / 8 : npos(base + r * M)];
+        if (!INV) {
+            bbx_dft<R>::run(u);
+            if constexpr (M > 1) {
+#pragma unroll
+                for (int k = 1; k < R; k++) u[k] = cmul(u[k], tw[m * k * TWS]);
+            }
+        } else {
+            if constexpr (M > 1) {
+#pragma unroll
+                for (int k = 1; k < R; k++) u[k] = cmulc(u[k], tw[m * k * TWS]);
+            }
+            idft<R>(u);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) line[AFF8 ? r * (M + M / 8) : AFF1 ? r + r / 8 : npos(base + r * M)] = u[r];
+    }
+}
+// forward: natural order -> spectrum at ppos; inverse: back (unnormalised).  Barriers after every pass.
+template <class P, int NLINES = P::NL> __device__ __forceinline__ void fft_fwd(float2* s, const float2* tw) {
+#ifdef Z3_SKIP_FFT
+    __syncthreads(); return;
+#endif
+    fft_step<P, P::R0, P::L, false, NLINES>(s, tw); __syncthreads();
+    fft_step<P, P::R1, P::L / P::R0, false, NLINES>(s, tw); __syncthreads();
+    if constexpr (P::R2 > 1) { fft_step<P, P::R2, P::L / (P::R0 * P::R1), false, NLINES>(s, tw); __syncthreads(); }
+    if constexpr (P::R3 > 1) { fft_step<P, P::R3, P::L / (P::R0 * P::R1 * P::R2), false, NLINES>(s, tw); __syncthreads(); }
+}
+template <class P, int NLINES = P::NL> __device__ __forceinline__ void fft_inv(float2* s, const float2* tw) {
+#ifdef Z3_SKIP_FFT
+    __syncthreads(); return;
+#endif
+    if constexpr (P::R3 > 1) { fft_step<P, P::R3, P::L / (P::R0 * P::R1 * P::R2), true, NLINES>(s, tw); __syncthreads(); }
+    if constexpr (P::R2 > 1) { fft_step<P, P::R2, P::L / (P::R0 * P::R1), true, NLINES>(s, tw); __syncthreads(); }
+    fft_step<P, P::R1, P::L / P::R0, true, NLINES>(s, tw); __syncthreads();
+    fft_step<P, P::R0, P::L, true, NLINES>(s, tw); __syncthreads();
+}
+
+// the twiddle table: LDS copy (after the line buffers) or the global one
+template <class P> __device__ __forceinline__ const float2* tw_setup(float2* after_lines, const float2* __restrict__ tw) {
+    if (!P::TWL) return tw;
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) after_lines[e] = tw[e];
+    return after_lines;                                             // visible after the caller's next barrier
+}
+
+// Workgroup -> (x, y) of an nx * ny task grid, launched as a 1-D grid of a multiple of 8 workgroups.
+// Workgroups are dealt round-robin over the 8 XCDs (observed, for speed only): the tasks are numbered so
+// that the ones an XCD runs at the same time are neighbours -- they read adjacent 288-byte pieces
+// of the same 128-byte lines, which then come from that XCD's L2 instead of HBM a second time.
+#ifndef Z3_NO_XCD
+__device__ __forceinline__ int xcd_task() { return (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8); }
+#else
+__device__ __forceinline__ int xcd_task() { return (int)blockIdx.x; }
+#endif
+#define WG_TASK(nx_, ny_, x_, y_)                       \
+    const int task_ = xcd_task();                       \
+    if (task_ >= (nx_) * (ny_)) return;                 \
+    const int x_ = task_ % (nx_), y_ = task_ / (nx_);
+static inline dim3 grid8(int nx, int ny) { return dim3((unsigned)(((size_t)nx * ny + 7) / 8 * 8)); }
+
+// ---- data movement (loops over the workgroup) ---------------------------------------------------
+// LDS (natural order, after an inverse column pass) -> U tiles U[sub][g][y][l]; halo rows on request
+template <class P> __device__ __forceinline__ void store_u(const float2* s, float2* __restrict__ U, int sub, int g, float2* __restrict__ halo = nullptr) {
+    float2* base = U + (size_t)sub * P::UNIT + (size_t)g * P::L * P::NL;
+    for (int e = threadIdx.x; e < P::L * P::NL; e += blockDim.x) {
+        const int y = e / P::NL, l = e - y * P::NL;
+        const float2 v = s[l * P::LS + npos(y)];
+        base[e] = v;
+        if (halo && (y % P::NL == P::NL - 1 || y == P::L - 1)) halo[((size_t)sub * P::LB + y / P::NL) * P::HP + g * P::NL + l] = v;
+    }
+}
+// T tiles T[sub][yb][kx][yi] of column group g -> LDS lines, natural order
+template <class P> __device__ __forceinline__ void load_t_lines(const float2* T, int sub, int g, float2* s) {
+    static_assert(P::NL % 2 == 0 && P::L % 2 == 0, "even tile side and line length");
+    const float2* src = T + (size_t)sub * P::UNIT + (size_t)g * P::NL * P::NL;
+    constexpr int TV = P::NL * P::NL / 2, NV = P::LB * TV;          // float4 per tile, per workgroup
+    for (int e0 = threadIdx.x; e0 < NV; e0 += 4 * (int)blockDim.x) {
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = e0 + i * (int)blockDim.x;
+            if (e < NV) { const int yb = e / TV, j = e - yb * TV; v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = e0 + i * (int)blockDim.x;
+            if (e < NV) {
+                const int yb = e / TV, j = e - yb * TV, l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
+                if (y < P::L) {
+                    float2* line = s + l * P::LS;
+                    line[npos(y)] = make_float2(v[i].x, v[i].y); line[npos(y + 1)] = make_float2(v[i].z, v[i].w);
+                }
+            }
+        }
+    }
+}
+// entry e (= l * L + p) of the workgroup's scratch in its own, already consumed T tiles
+template <class P> __device__ __forceinline__ float2* park_ptr(float2* T, int sub, int g, int e) {
+    constexpr int TS = P::NL * P::NL;
+    return T + (size_t)sub * P::UNIT + (size_t)(e / TS) * P::HP * P::NL + (size_t)g * TS + e % TS;
+}
+template <class P> __device__ __forceinline__ void pack_store(float2* line, int kx, float2 a, float2 b) {
+    if (kx >= P::H) return;
+    line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
+    if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
+}
+// Hermitian packing of two U half spectra (row block yb) into full complex lines in spectrum order: Z = a + i b
+template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb, float2* s) {
+    constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
+    const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::NL * P::NL;
+    for (int e0 = threadIdx.x; e0 < NV; e0 += 2 * (int)blockDim.x) {
+        float4 va[2], vb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = e0 + i * (int)blockDim.x;
+            if (e < NV) {
+                const int g = e / TV, j = e - g * TV;
+                const size_t o = base + (size_t)g * P::L * P::NL + 2 * j;
+                va[i] = *reinterpret_cast<const float4*>(Ua + o); vb[i] = *reinterpret_cast<const float4*>(Ub + o);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = e0 + i * (int)blockDim.x;
+            if (e < NV) {
+                const int g = e / TV, j = e - g * TV, row = (2 * j) / P::NL, l = (2 * j) % P::NL;      // tile entry [row][l], l even
+                if (yb * P::NL + row < P::L) {
+                    float2* line = s + row * P::LS;
+                    pack_store<P>(line, g * P::NL + l, make_float2(va[i].x, va[i].y), make_float2(vb[i].x, vb[i].y));
+                    pack_store<P>(line, g * P::NL + l + 1, make_float2(va[i].z, va[i].w), make_float2(vb[i].z, vb[i].w));
+                }
+            }
+        }
+    }
+}
+template <class P> __device__ __forceinline__ void load_halo_pair(const float2* __restrict__ Ha, const float2* __restrict__ Hb, int sub, int yb, float2* line) {
+    const size_t base = ((size_t)sub * P::LB + yb) * P::HP;
+    for (int kx = threadIdx.x; kx < P::H; kx += blockDim.x) pack_store<P>(line, kx, Ha[base + kx], Hb[base + kx]);
+}
+// Hermitian split of a packed transform Z (LDS, spectrum order) -> two half spectra, T tiles of row block yb
+template <class P> __device__ __forceinline__ void store_t_split(const float2* s, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub, int yb) {
+    const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::HP * P::NL;         // the block's entries (kx, row) are contiguous
+    for (int e = threadIdx.x; e < P::NL * P::H; e += blockDim.x) {
+        const int kx = e / P::NL, row = e - kx * P::NL;
+        const float2* line = s + row * P::LS;
+        const float2 zk = line[ppos<P>(kx)], zm = line[ppos<P>(kx ? P::L - kx : 0)];
+        Ta[base + e] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        Tb[base + e] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+    }
+}
+// spectrum entry e = l * L + p of the C layout <-> LDS
+// the same loop with a per-thread register array alongside: iteration k of thread t is entry e = t + k THREADS,
+// every time, so a value parked in reg[k] meets the same entry again
+// (the thread index goes through an empty asm so that the 17 entry addresses are recomputed in every
+// loop instead of being kept in registers across the transforms in between)
+__device__ __forceinline__ int opaque_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#define R_LOOP(k, e, l, p)                                                                     \
+    for (int t_ = opaque_tid(), once_ = 1; once_; once_ = 0)                                     \
+    _Pragma("unroll") for (int k = 0, e, l, p; k < NE; k++)                                      \
+        if (e = t_ + k * P::THREADS, l = e / P::L, p = e - l * P::L, e < P::NL * P::L)
+#define C_LOOP(e, l, p) for (int e = threadIdx.x, l, p; l = e / P::L, p = e - l * P::L, e < P::NL * P::L; e += blockDim.x)
+
+// ---- PSF side ---------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
+                                                         const zscal* __restrict__ sc, const float2* __restrict__ twg,
+                                                         float2* __restrict__ cA, float2* __restrict__ cB, float2* __restrict__ cKn,
+                                                         float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
+                                                         double* __restrict__ fs_partial, int nsub) {
+    extern __shared__ float2 s[];
+    __shared__ double red[3][P::THREADS / 64];
+    WG_TASK(P::G, nsub, g, sub);
+    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const int h = S / 2;
+    const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
+    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    float2 park[NE];                                               // Pn^, then kn^
+    for (int pass = 0; pass < 2; pass++) {
+        const float* st = (pass ? psf_r : psf_n) + (size_t)sub * S * S;
+        for (int e = threadIdx.x; e < P::NL * P::LS; e += blockDim.x) s[e] = make_float2(0.f, 0.f);
+        __syncthreads();
+        // row DFT of the S non-zero rows, summed directly: line[y] = sum_x p[y][x] W^(kx x)
+        for (int e = threadIdx.x; e < P::NL * S; e += blockDim.x) {
+            const int ll = e % P::NL, j = e / P::NL;
+            const int kk = g * P::NL + ll;
+            if (kk >= P::H) continue;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int i = 0; i < S; i++) {
+                const int xw = ((i - h) % P::L + P::L) % P::L;
+                const float2 w = twg[(int)(((long long)kk * xw) % P::L)];
+                const float p = st[j * S + i];
+                acc.x += p * w.x; acc.y += p * w.y;
+            }
+            const int y = ((j - h) % P::L + P::L) % P::L;
+            s[ll * P::LS + npos(y)] = acc;
+        }
+        __syncthreads();
+        fft_fwd<P>(s, tw);
+        if (pass == 0) {
+            R_LOOP(k, e, l, p) park[k] = s[l * P::LS + npos(p)];      // Pn^ waits in registers while Pr^ is transformed
+            __syncthreads();
+        }
+    }
+    const zscal z = sc[sub];
+    const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
+    double fs = 0.0, sk2n = 0.0, sk2r = 0.0;                      // F_S and the Parseval sums of kn^2, kr^2
+    R_LOOP(k, e, l, p) {
+        const int kx = g * P::NL + l;
+        float2 a = make_float2(0.f, 0.f), b = a, kn = a, kr = a;
+        if (kx < P::H) {
+            const double wgt = (kx == 0 || (P::L % 2 == 0 && kx == P::L / 2)) ? 1.0 : 2.0;
+            const float2 pn = park[k], pr = s[l * P::LS + npos(p)];
+            const float pn2 = pn.x * pn.x + pn.y * pn.y, pr2 = pr.x * pr.x + pr.y * pr.y;
+            const float den = (sn2 * fr2) * pr2 + (sr2 * fn2) * pn2;
+            const float isd = 1.0f / sqrtf(den);
+            a = cscale(pr, z.fr * isd);                                   // D^ = A N^ - B R^
+            b = cscale(pn, z.fn * isd);
+            kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 / den);
+            kn = cscale(make_float2(pn.x, -pn.y), z.fn * fr2 * pr2 / den);
+            fs += wgt * (double)(fn2 * pn2 * fr2 * pr2 / den);
+            sk2n += wgt * (double)(kn.x * kn.x + kn.y * kn.y);
+            sk2r += wgt * (double)(kr.x * kr.x + kr.y * kr.y);
+        }
+        cA[cbase + e] = a; cB[cbase + e] = b; cKn[cbase + e] = kn; cKr[cbase + e] = kr;
+        s[l * P::LS + npos(p)] = kr;
+        park[k] = kn;
+    }
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, Ukr, sub, g);
+    __syncthreads();
+    R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = park[k];
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, Ukn, sub, g);
+    fs = wave_sum_f64(fs); sk2n = wave_sum_f64(sk2n); sk2r = wave_sum_f64(sk2r);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = fs; red[1][threadIdx.x >> 6] = sk2n; red[2][threadIdx.x >> 6] = sk2r; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double tot = 0.0;
+        for (int i = 0; i < (int)blockDim.x / 64; i++) tot += red[threadIdx.x][i];
+        fs_partial[((size_t)threadIdx.x * nsub + sub) * P::G + g] = tot;      // [3][nsub][G]
+    }
+}
+
+// inverse row pass of kr^, kn^ -> kr, kn -> squares -> forward row pass, T tiles
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
+                                                         const float2* __restrict__ twg, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2,
+                                                         int nsub) {
+    extern __shared__ float2 s[];
+    WG_TASK(P::LB, nsub, yb, sub);
+    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    load_u_pair<P>(Ukr, Ukn, sub, yb, s);
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    C_LOOP(e, l, p) {
+        float2* q = s + l * P::LS + npos(p);
+        const float a = q->x * inv_n2, b = q->y * inv_n2;
+        *q = make_float2(a * a, b * b);
+    }
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    store_t_split<P>(s, Tkr2, Tkn2, sub, yb);
+}
+
+// forward column pass of one T array -> C layout
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ twg, float2* __restrict__ Cout, int nsub) {
+    extern __shared__ float2 s[];
+    WG_TASK(P::G, nsub, g, sub);
+    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    load_t_lines<P>(T, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
+    C_LOOP(e, l, p) Cout[cbase + e] = s[l * P::LS + npos(p)];
+}
+
+// see bbx_zogy2.hip: V(S)^ is scaled by a power of two before it shares a transform with D
+template <class P> __device__ __forceinline__ float vs_scale(const double* __restrict__ fs_partial, int nsub, int sub, const zscal& z) {
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < P::G; g++) {
+        a += fs_partial[((size_t)1 * nsub + sub) * P::G + g];
+        b += fs_partial[((size_t)2 * nsub + sub) * P::G + g];
+    }
+    const double n2 = (double)P::L * (double)P::L;
+    const float level = (float)(((double)z.sn * z.sn * a + (double)z.sr * z.sr * b) / n2);            // Parseval: sum_x k^2 = sum_k |k^|^2 / L^2
+    if (!(level > 0.f) || !isfinite(level)) return 1.f;
+    return exp2f(-rintf(log2f(level)));
+}
+
+// ---- image side -------------------------------------------------------------------------------
+struct frame_args {
+    const float* a; const float* b;          // the two frames of a pair (new, ref)
+    const float* sa; const float* sb;        // sigma images (variance pair) or NULL
+    int ny, nx, size, border, nsx, vec4;
+};
+
+// cut + forward row pass of a pair of real frames: (N, R) or, with sigma images, (Vn, Vr)
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_rows(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta, float2* __restrict__ Tb, int nsub) {
+    extern __shared__ float2 s[];
+    WG_TASK(P::LB, nsub, yb, sub);
+    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const int y0 = yb * P::NL;
+    const int sy = sub / f.nsx, sx = sub - sy * f.nsx;
+    const int Y0 = sy * f.size - f.border, X0 = sx * f.size - f.border;
+    if (f.vec4) {
+        // groups of four pixels never straddle the frame edge (size, border, nx multiples of 4)
+        constexpr int NV = P::NL * P::L / 4;
+        for (int e0 = threadIdx.x; e0 < NV; e0 += 2 * (int)blockDim.x) {
+            float4 va[2], vb[2];
+            bool in[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int e = e0 + i * (int)blockDim.x;
+                va[i] = vb[i] = make_float4(0.f, 0.f, 0.f, 0.f); in[i] = false;
+                if (e < NV) {
+                    const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                    const int Y = Y0 + y0 + ll, X = X0 + x;
+                    if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
+                        const size_t o = (size_t)Y * f.nx + X;
+                        in[i] = true;
+                        va[i] = *reinterpret_cast<const float4*>(f.a + o); vb[i] = *reinterpret_cast<const float4*>(f.b + o);
+                        if (f.sa) {
+                            const float4 p = *reinterpret_cast<const float4*>(f.sa + o), q4 = *reinterpret_cast<const float4*>(f.sb + o);
+                            va[i] = make_float4(fmaxf(va[i].x, 0.f) + p.x * p.x, fmaxf(va[i].y, 0.f) + p.y * p.y, fmaxf(va[i].z, 0.f) + p.z * p.z,
+                                                fmaxf(va[i].w, 0.f) + p.w * p.w);
+                            vb[i] = make_float4(fmaxf(vb[i].x, 0.f) + q4.x * q4.x, fmaxf(vb[i].y, 0.f) + q4.y * q4.y,
+                                                fmaxf(vb[i].z, 0.f) + q4.z * q4.z, fmaxf(vb[i].w, 0.f) + q4.w * q4.w);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int e = e0 + i * (int)blockDim.x;
+                if (e < NV) {
+                    const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                    float2* line = s + ll * P::LS;
+                    line[npos(x)] = make_float2(va[i].x, vb[i].x); line[npos(x + 1)] = make_float2(va[i].y, vb[i].y);
+                    line[npos(x + 2)] = make_float2(va[i].z, vb[i].z); line[npos(x + 3)] = make_float2(va[i].w, vb[i].w);
+                }
+            }
+        }
+    } else
+    for (int e = threadIdx.x; e < P::NL * P::L; e += blockDim.x) {
+        const int ll = e / P::L, x = e - ll * P::L;
+        const int Y = Y0 + y0 + ll, X = X0 + x;
+        float2 v = make_float2(0.f, 0.f);
+        if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
+            const size_t o = (size_t)Y * f.nx + X;
+            v.x = f.a[o]; v.y = f.b[o];
+            if (f.sa) { const float p = f.sa[o], q = f.sb[o]; v.x = fmaxf(v.x, 0.f) + p * p; v.y = fmaxf(v.y, 0.f) + q * q; }
+        }
+        s[ll * P::LS + npos(x)] = v;
+    }
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    store_t_split<P>(s, Ta, Tb, sub, yb);
+}
+
+// column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U tiles)
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* __restrict__ TN, const float2* __restrict__ TR, const float2* __restrict__ cA,
+                                                         const float2* __restrict__ cB, const float2* __restrict__ cKn,
+                                                         const float2* __restrict__ cKr, const float2* __restrict__ twg,
+                                                         float2* __restrict__ UD, float2* __restrict__ USn, float2* __restrict__ USr,
+                                                         float2* __restrict__ HSn, float2* __restrict__ HSr, int nsub) {
+    extern __shared__ float2 s[];
+    WG_TASK(P::G, nsub, g, sub);
+    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
+    load_t_lines<P>(TN, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    float2 park[NE];                                               // the partial D^ = A N^ waits in registers
+    R_LOOP(k, e, l, p) {
+        float2* q = s + l * P::LS + npos(p);
+        const float2 x = *q;
+        park[k] = cmul(cA[cbase + e], x);
+        *q = cmul(cKn[cbase + e], x);
+    }
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, USn, sub, g, HSn);
+    __syncthreads();
+    load_t_lines<P>(TR, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    R_LOOP(k, e, l, p) {
+        float2* q = s + l * P::LS + npos(p);
+        const float2 x = *q;
+        const float2 br = cmul(cB[cbase + e], x);
+        park[k] = make_float2(park[k].x - br.x, park[k].y - br.y);
+        *q = cmul(cKr[cbase + e], x);
+    }
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, USr, sub, g, HSr);
+    __syncthreads();
+    R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = park[k];
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, UD, sub, g);
+}
+
+// column pass of the variance pair: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^ and back (U tiles)
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ cK2n,
+                                                         const float2* __restrict__ cK2r, const float2* __restrict__ twg,
+                                                         float2* __restrict__ UVS, const zscal* __restrict__ sc,
+                                                         const double* __restrict__ fs_partial, int nsub) {
+    extern __shared__ float2 s[];
+    __shared__ float s_beta;
+    WG_TASK(P::G, nsub, g, sub);
+    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, nsub, sub, sc[sub]);
+    const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
+    load_t_lines<P>(TVn, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    float2 park[NE];
+    R_LOOP(k, e, l, p) park[k] = cmul(cK2n[cbase + e], s[l * P::LS + npos(p)]);
+    __syncthreads();
+    load_t_lines<P>(TVr, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    const float beta = s_beta;
+    R_LOOP(k, e, l, p) {
+        float2* q = s + l * P::LS + npos(p);
+        const float2 v = cmul(cK2r[cbase + e], *q);
+        *q = make_float2((park[k].x + v.x) * beta, (park[k].y + v.y) * beta);
+    }
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, UVS, sub, g);
+}
+
+struct out_args {
+    float* D; float* S; float* Scorr; float* Fpsf; float* Fpsferr;      // full frames [ny][nx]; S may be NULL
+    int ny, nx, size, border, nsx, vec4;
+};
+
+// inverse row pass of (D, V_S) and (Sn, Sr) + the final algebra, written into the full frames.  A
+// workgroup takes one block of NL rows; the row above the block comes from the halo arrays as one more line.
+template <class P>
+__global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(const float2* __restrict__ UD, const float2* __restrict__ UVS,
+                                                           const float2* __restrict__ USn, const float2* __restrict__ USr,
+                                                           const float2* __restrict__ HSn, const float2* __restrict__ HSr,
+                                                           const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
+                                                           float inv_n2, const float2* __restrict__ twg, out_args o, int yb0, int nyb,
+                                                           int nsub) {
+    extern __shared__ float2 s[];
+    float2* hline = s + P::NL * P::LS;                              // the halo line
+    __shared__ float s_fs, s_ibeta;
+    WG_TASK(nyb, nsub, ybi, sub);
+    const float2* tw = tw_setup<P>(s + (P::NL + 1) * P::LS, twg);
+    const int yb = yb0 + ybi, y0 = yb * P::NL;
+    const zscal z = sc[sub];
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int g = 0; g < P::G; g++) tot += fs_partial[(size_t)sub * P::G + g];
+        s_fs = (float)(tot / ((double)P::L * (double)P::L));
+        s_ibeta = 1.0f / vs_scale<P>(fs_partial, nsub, sub, z);
+    }
+    const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
+    const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
+    const int sy = sub / o.nsx, sx = sub - sy * o.nsx;
+    // (D, V_S): D goes out at once, V_S waits in registers (the same thread takes the same pixels below)
+    constexpr int NE = (P::NL * P::L + P::FIN_THREADS - 1) / P::FIN_THREADS;
+    float vsr[NE];
+    load_u_pair<P>(UD, UVS, sub, yb, s);
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    const float ibeta = s_ibeta, fs = s_fs;
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        const int e = threadIdx.x + k * P::FIN_THREADS;
+        vsr[k] = 0.f;
+        if (e < P::NL * o.size) {
+            const int l = e / o.size, xi = e - l * o.size, y = y0 + l;
+            const float2 v = s[l * P::LS + npos(o.border + xi)];
+            vsr[k] = v.y * inv_n2 * ibeta;
+            if (y >= o.border && y < o.border + o.size) {
+                const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
+                if (Y < o.ny && Xf < o.nx) o.D[(size_t)Y * o.nx + Xf] = v.x * inv_n2 / fD;
+            }
+        }
+    }
+    __syncthreads();
+    // (Sn, Sr): the block's rows + the row above it (row L - 1 above row 0: np.roll)
+    load_u_pair<P>(USn, USr, sub, yb, s);
+    load_halo_pair<P>(HSn, HSr, sub, yb ? yb - 1 : P::LB - 1, hline);
+    __syncthreads();
+    fft_inv<P, P::NL + 1>(s, tw);
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        const int e = threadIdx.x + k * P::FIN_THREADS;
+        if (e >= P::NL * o.size) continue;
+        const int l = e / o.size, xi = e - l * o.size, y = y0 + l, xx = o.border + xi;
+        if (y < o.border || y >= o.border + o.size) continue;
+        const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
+        if (Y >= o.ny || Xf >= o.nx) continue;
+        const float2* line = s + l * P::LS;
+        const float2* upline = l ? line - P::LS : hline;
+        const float2 c = cscale(line[npos(xx)], inv_n2);                                  // (Sn, Sr) here
+        const float2 up = cscale(upline[npos(xx)], inv_n2), lf = cscale(line[npos(xx == 0 ? P::L - 1 : xx - 1)], inv_n2);
+        const float sval = c.x - c.y;                                                      // S = Sn - Sr
+        const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
+        const float vast = z.dx * z.dx * (dSndx * dSndx + dSrdx * dSrdx) + z.dy * z.dy * (dSndy * dSndy + dSrdy * dSrdy);
+        const float vs = vsr[k];
+        const size_t q = (size_t)Y * o.nx + Xf;
+        if (o.S) o.S[q] = sval;
+        o.Scorr[q] = sval / sqrtf(vs + vast);
+        o.Fpsf[q] = sval / fs;
+        o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) / fs;
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+template <class P>
+static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+               const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
+               float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
+    const int nsy = ny / size, nsx = nx / size, nsub = nsy * nsx;
+    int rc;
+    const size_t unit = (size_t)nsub * P::UNIT, hunit = (size_t)nsub * P::LB * P::HP;
+    // 4 T + 4 U + 6 C arrays + 2 halo arrays + scalars + partial sums
+    const size_t bytes = (14 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 3 * (size_t)nsub * P::G * sizeof(double) + 4096;
+    char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
+    float2* arr[14]; for (int i = 0; i < 14; i++) arr[i] = (float2*)ws + (size_t)i * unit;
+    float2 *HSn = (float2*)ws + 14 * unit, *HSr = HSn + hunit;
+    char* p = ws + (14 * unit + 2 * hunit) * sizeof(float2);
+    zscal* d_sc = (zscal*)p; p += (size_t)nsub * sizeof(zscal);
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    double* fs_partial = (double*)p;
+    float2 *T0 = arr[0], *T1 = arr[1], *T2 = arr[2], *T3 = arr[3], *U0 = arr[4], *U1 = arr[5], *U2 = arr[6], *U3 = arr[7];
+    float2 *cA = arr[8], *cB = arr[9], *cKn = arr[10], *cKr = arr[11], *cK2n = arr[12], *cK2r = arr[13];
+    BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
+    const size_t lds_tw = P::TWL ? (size_t)P::L * sizeof(float2) : 0;
+    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + lds_tw,
+                 lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2) + lds_tw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        BBX_HIP(hipFuncSetAttribute((const void*)k_psf_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_psf_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_cols_fwd<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_var_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_final_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
+        attr_set = true;
+    }
+    const float inv_n2 = 1.0f / ((float)P::L * (float)P::L);
+    const dim3 gcol = grid8(P::G, nsub), grow = grid8(P::LB, nsub), blk(P::THREADS);
+    const float2* tw = d_tw;
+    bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
+    hipLaunchKernelGGL(k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub);
+    hipLaunchKernelGGL(k_psf_rows<P>, grow, blk, lds, s, U1, U0, inv_n2, tw, T0, T1, nsub);
+    hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T0, tw, cK2r, nsub);
+    hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T1, tw, cK2n, nsub);
+    frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
+    fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T0, T1, nsub);
+    fa.sa = d_sig_new; fa.sb = d_sig_ref;
+    hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3, nsub);
+    hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
+    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
+    out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
+    oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
+    const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
+    const dim3 gfin = grid8(yb1 - yb0 + 1, nsub);
+    bbx_prof_stop(ctx, s);
+    bbx_prof_start(ctx, BBX_PROF_ZOGY_FINAL, s);
+    hipLaunchKernelGGL(k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial, inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub);
+    bbx_prof_stop(ctx, s);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+}  // namespace z3
+
+int bbx_zogy3_supported(int L) { return (L == 1400 || L == 140 || L == 128 || L == 100 || L == 64) ? 1 : 0; }
+
+int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, int L, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+                  const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
+                  float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
+#define Z3_RUN(...) return z3::run<z3::Plan<__VA_ARGS__>>(ctx, d_tw, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, \
+                                                          h_scal, d_D, d_S, d_Scorr, d_Fpsf, d_Fpsferr, s)
+    switch (L) {
+        case 1400: Z3_RUN(Z3_PLAN1400);
+        case 140: Z3_RUN(5, 7, 4);
+        case 128: Z3_RUN(8, 16);
+        case 100: Z3_RUN(5, 5, 4);
+        case 64: Z3_RUN(8, 8);
+    }
+    return BBX_ERR_ARG;
+}

@@ -87,6 +87,9 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * it, below the allocated one -- lets a test drive the list-overflow path (BBX_ERR_OVERFLOW ->
  * COSMIC-P = False) with an ordinary frame. */
 #define BBX_OPT_DEBUG_LISTCAP 2
+/* BBX_OPT_ZOGY_CORE: which 1-D transform bbx_zogy_frame's kernels use: 0 = two steps of register
+ * DFTs (bbx_zogy2.hip), 1 = radix passes in LDS (bbx_zogy3.hip).  Same results to rounding. */
+#define BBX_OPT_ZOGY_CORE 3
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
 
 /* Per-step attribution of device-side errors.  Kernels report list overflow / non-convergence by
