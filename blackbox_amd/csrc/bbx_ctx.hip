@@ -99,7 +99,7 @@ int bbx_ctx_create(int device, bbx_ctx** out) {
     if (!out) return BBX_ERR_ARG;
     *out = nullptr;
     bbx_ctx* ctx = (bbx_ctx*)calloc(1, sizeof(bbx_ctx));
-    if (ctx) { const char* e = getenv("BBX_ZOGY_CORE"); if (e) ctx->zogy_core = atoi(e) ? 1 : 0; }
+    if (ctx) { const char* e = getenv("BBX_ZOGY_CORE"); ctx->zogy_core = e ? (atoi(e) ? 1 : 0) : 1; }
     if (!ctx) return BBX_ERR_NOMEM;
     ctx->device = device;
     hipError_t e = hipSetDevice(device);

@@ -27,19 +27,22 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; return s; }
 
 #ifndef Z3_THREADS
-#define Z3_THREADS 512         // two workgroups per CU (LDS: 77 KB of lines each)
+#define Z3_THREADS 512         // two workgroups per CU
 #endif
 #ifndef Z3_FIN_THREADS
-#define Z3_FIN_THREADS 1024    // k_final_rows: one workgroup per CU (LDS: 7 lines + the V_S block)
+#define Z3_FIN_THREADS 768     // k_final_rows: 5 lines = 64 KB, two workgroups per CU
 #endif
 #ifndef Z3_NL
-#define Z3_NL 6
+#define Z3_NL 4                // 4 x 4 tiles of float2 = one 128-byte line; LDS: 4 lines = 51 KB per workgroup
 #endif
 #ifndef Z3_MINW
 #define Z3_MINW 4              // waves per SIMD the register allocation must allow (two workgroups of 512)
 #endif
+#ifndef Z3_MINW_LIGHT
+#define Z3_MINW_LIGHT Z3_MINW  // the same for the kernels without parked registers (k_psf_rows, k_cols_fwd, k_img_rows)
+#endif
 #ifndef Z3_FIN_MINW
-#define Z3_FIN_MINW 4
+#define Z3_FIN_MINW 6
 #endif
 #ifndef Z3_PLAN1400
 #define Z3_PLAN1400 5, 7, 5, 8
@@ -59,6 +62,7 @@ template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
     static constexpr int LB = (L + NL - 1) / NL;                    // row blocks of NL rows
     static constexpr size_t UNIT = (size_t)LB * NL * HP;            // elements of one T / U / C array per sub-image
     static constexpr int TWL = Z3_TWL;
+    static constexpr int MINW_LIGHT = L >= 512 ? Z3_MINW_LIGHT : 1;
     static constexpr int MINW = L >= 512 ? Z3_MINW : 1, FIN_MINW = L >= 512 ? Z3_FIN_MINW : 1;
 };
 
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_cols(const float* _
 
 // inverse row pass of kr^, kn^ -> kr, kn -> squares -> forward row pass, T tiles
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
+__global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
                                                          const float2* __restrict__ twg, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2,
                                                          int nsub) {
     extern __shared__ float2 s[];
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_rows(const float2* 
 
 // forward column pass of one T array -> C layout
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ twg, float2* __restrict__ Cout, int nsub) {
+__global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ twg, float2* __restrict__ Cout, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::G, nsub, g, sub);
     const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
@@ -399,7 +403,7 @@ struct frame_args {
 
 // cut + forward row pass of a pair of real frames: (N, R) or, with sigma images, (Vn, Vr)
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_rows(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta, float2* __restrict__ Tb, int nsub) {
+__global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_img_rows(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta, float2* __restrict__ Tb, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::LB, nsub, yb, sub);
     const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);

@@ -116,11 +116,15 @@ def test_background_mesh_fullsize(scene):
     np.testing.assert_allclose(bstd.cpu().numpy(), bstd_o, rtol=2e-6)
 
 
-def test_zogy_fullsize(scene):
+@pytest.mark.parametrize('core', [1, 0], ids=['core-ldspasses', 'core-regdft'])
+def test_zogy_fullsize(scene, core):
     """optimal_subtraction on the full frame (64 sub-images of 1400^2) against the oracle's
     run_zogy on whole sub-images (a corner, an interior one, the last one); every injected
-    transient is recovered with its flux"""
+    transient is recovered with its flux.  Both 1-D transform cores of bbx_zogy_frame
+    (BBX_OPT_ZOGY_CORE = 3: 1 = radix passes 5*7*5*8 in LDS, the default; 0 = register DFTs 35*40)."""
+    from blackbox_amd._lib import lib
     ctx = scene['ctx']
+    assert lib.bbx_set_option(ctx.h, 3, core) == 0
     pn, pr = bench.moffat_stamp(25, 4.0), bench.moffat_stamp(25, 3.6)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)       # noqa: E731
     dx, dy = 0.03, 0.02
@@ -183,6 +187,7 @@ def test_zogy_fullsize(scene):
             sky = ok & (big < 2e3)
             assert sky.sum() > 0.3 * sky.size and (err[sky] <= 6e-3 * noise).all(), (key, (sy, sx), float((err[sky] / noise).max()))
     print('ZOGY full size, max |HIP - oracle| (/ local noise, / tolerance):', worst)
+    assert lib.bbx_set_option(ctx.h, 3, 1) == 0
     # Scorr of the unmasked frame ~ N(0, 1) (QC ranges set_qc.py:382-383)
     assert abs(hdr['Z-SCMED'][0]) < 0.3 and abs(hdr['Z-SCSTD'][0] - 1) < 0.15
     # injected transients: found within a pixel, flux within 3 sigma + 5 %
