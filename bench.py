@@ -61,8 +61,7 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras
     gain = torch.tensor(settings.gain['ML1'], dtype=torch.float32, device=dev)
     yy = torch.arange(ny, device=dev, dtype=torch.float32)[:, None]
     xx = torch.arange(nx, device=dev, dtype=torch.float32)[None, :]
-    scene = 250.0 + 12.0 * (xx / nx - 0.5) + 8.0 * (yy / ny - 0.5)
-    scene = scene.expand(ny, nx).contiguous()
+    scene = sky_model(torch, dev, ny, nx)
     # stars: Moffat beta=2.5, FWHM 3-5 px, power-law fluxes, ~20 saturating
     nstar = max(20, int(2.0e4 * (ny * nx) / 111513600.0))
     rs = np.random.RandomState(seed)
@@ -152,14 +151,21 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras
     return raw.contiguous(), flat, bpm
 
 
+def sky_model(torch, dev, ny, nx):
+    """the smooth sky of the synthetic scene [e-]"""
+    yy = torch.arange(ny, device=dev, dtype=torch.float32)[:, None]
+    xx = torch.arange(nx, device=dev, dtype=torch.float32)[None, :]
+    return (250.0 + 12.0 * (xx / nx - 0.5) + 8.0 * (yy / ny - 0.5)).expand(ny, nx).contiguous()
+
+
 def synth_reference(torch, dev, scene0, seed, depth=4.0, sky_ref=0.0):
     """the co-added reference image of the field: the same scene without
     cosmic rays / trails / transients at [depth] x the exposure (noise / sqrt(depth) in the
-    new frame's units), another sky level; mask all zero"""
+    new frame's units); background-subtracted like a buildref product (sky_ref = 0) or with
+    a flat sky level of its own; mask all zero"""
     g = torch.Generator(device=dev)
     g.manual_seed(seed + 4242)
-    sky = 250.0                                                   # mean sky of synth_frame_device's scene
-    ref = scene0 - sky + sky_ref
+    ref = scene0 - sky_model(torch, dev, *scene0.shape) + sky_ref
     ref = ref + torch.sqrt((scene0 / depth).clamp(min=0)) * torch.randn(scene0.shape, device=dev, generator=g)
     return ref.contiguous(), torch.zeros(scene0.shape, dtype=torch.uint8, device=dev)
 
@@ -448,16 +454,17 @@ def main():
         L = size + 2 * border
         nsub = (2 * ysz // size) * (8 * xsz // size)
         # algorithmic bytes per launch
-        HP = ((L // 2 + 1 + 5) // 6) * 6                     # padded half-spectrum width of bbx_zogy2.hip (NL = 6)
+        HP = ((L // 2 + 1 + 3) // 4) * 4                     # padded half-spectrum width of bbx_zogy3.hip (NL = 4)
         spec = nsub * HP * L * 8                              # one half spectrum of all sub-images, bytes
+        cut = 4 * nsub * L * L                                # one frame read as overlapping sub-images, bytes
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
             'k_lac_cand': (1, 4 * N),
-            # k_final_rows (bbx_zogy2.hip): reads the four column-transformed half spectra (D, V_S, S_n, S_r),
-            # writes D, Scorr, Fpsf, Fpsferr
+            # k_final_rows: reads the four column-transformed half spectra (D, V_S, S_n, S_r), writes D, Scorr, Fpsf, Fpsferr
             'k_final_rows': (7, 4 * spec + 4 * 4 * N),
-            # the other kernels of bbx_zogy_frame together (PSF side, row and column passes); bytes: DESIGN.md section 4
-            'zogy_frame_other': (6, int(37 * spec)),
+            # the other kernels of bbx_zogy_frame together: k_psf_cols 6 spec, k_psf_rows 4,
+            # k_cols_fwd 2 x 2, k_img_rows 2 x 2 + the six frame cuts, k_img_cols 9, k_var_cols 5
+            'zogy_frame_other': (6, int(32 * spec + 6 * cut)),
         }
         zogy_io_model = int(4 * 4 * nsub * L * L + 4 * 4 * N)     # 4 inputs read with the tile overlap, 4 outputs written
         iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items() if iso_calls[sl]}
@@ -479,9 +486,9 @@ def main():
             zms = iso['k_final_rows'][0] + iso['zogy_frame_other'][0]
             roof['zogy_stage'] = dict(ms_alone=zms, io_model_bytes=zogy_io_model, achieved=zogy_io_model / (zms * 1e-3) / 1e9,
                                       frac=zogy_io_model / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      moved_bytes_by_design=int(41 * spec + 16 * N),
+                                      moved_bytes_by_design=int(36 * spec + 6 * cut + 16 * N),
                                       note='SURVEY 8d I/O-only model (3.79 GB) over the whole bbx_zogy_frame call; the design moves '
-                                           '~41 half-spectrum passes (DESIGN.md section 4)')
+                                           '36 half-spectrum passes + 6 frame cuts + 4 outputs (DESIGN.md section 4)')
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))['kernels']
             if not args.small and args.raw == 'u16' and dom in pmc:
@@ -491,7 +498,8 @@ def main():
             pass
         shape = '%dx%d raw (%s)' % (raw.shape[0], raw.shape[1], args.raw)
         names = {'zogy': 'configs[4] per frame on one GPU: one %s -> reduce (gain+overscan+flat+mask+LA-Cosmic(niter=3)+xtalk+'
-                         'sat trail+counts+edge fill) + optimal_subtraction vs a co-added reference (bkg mesh x2, variance, %d '
+                         'sat trail+counts+edge fill) + optimal_subtraction vs a co-added, background-subtracted reference with its '
+                         'bkg_std_mini (buildref products): bkg mesh of the new frame, variance images, %d '
                          'sub-images of %d^2 ZOGY, D/Scorr/Fpsf/Fpsferr, transients, PSF-photometry catalogue), ML1'
                          % (shape, nsub, L),
                  'full': 'configs[2]: one %s -> full calibration + LA-Cosmic + xtalk + sat trail + counts + edge fill + '
@@ -522,6 +530,15 @@ def main():
             l2, d2 = (6, 18)
             r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 18, d2, l2, pool, barrier)
             others[w2] = dict(frames_per_s=60 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 60, frames_in_flight=d2, lanes=l2)
+        if wl == 'zogy':
+            # the same workload against a reference that still carries a sky of its own: its background mesh and
+            # sigma image are then made per frame as well (bkg mesh x2)
+            ref2 = ref + 120.0
+            kw2 = dict(kws['zogy'], subtract=dict(sub_kw, ref=ref2, ref_is_bkgsub=False, ref_bkg_std_mini=None))
+            r2 = run_pipeline(torch, ctx, tel, geom, raws, kw2, 30, 10, depth, lanes, pool, barrier)
+            others['zogy_ref_with_sky'] = dict(frames_per_s=30 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 30, frames_in_flight=depth,
+                                               lanes=lanes, note='reference not background-subtracted: bkg mesh x2 per frame')
+            del ref2
         out['other_workloads'] = others
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
     pool.close()

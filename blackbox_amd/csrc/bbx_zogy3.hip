@@ -35,6 +35,12 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; r
 #ifndef Z3_NL
 #define Z3_NL 4                // 4 x 4 tiles of float2 = one 128-byte line; LDS: 4 lines = 51 KB per workgroup
 #endif
+#ifndef Z3_LOADS_T
+#define Z3_LOADS_T 4
+#endif
+#ifndef Z3_LOADS_U
+#define Z3_LOADS_U 2
+#endif
 #ifndef Z3_MINW
 #define Z3_MINW 4              // waves per SIMD the register allocation must allow (two workgroups of 512)
 #endif
@@ -178,15 +184,16 @@ template <class P> __device__ __forceinline__ void load_t_lines(const float2* T,
     static_assert(P::NL % 2 == 0 && P::L % 2 == 0, "even tile side and line length");
     const float2* src = T + (size_t)sub * P::UNIT + (size_t)g * P::NL * P::NL;
     constexpr int TV = P::NL * P::NL / 2, NV = P::LB * TV;          // float4 per tile, per workgroup
-    for (int e0 = threadIdx.x; e0 < NV; e0 += 4 * (int)blockDim.x) {
-        float4 v[4];
+    constexpr int TD = Z3_LOADS_T;                                  // 16-byte loads in flight per thread
+    for (int e0 = threadIdx.x; e0 < NV; e0 += TD * (int)blockDim.x) {
+        float4 v[TD];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < TD; i++) {
             const int e = e0 + i * (int)blockDim.x;
             if (e < NV) { const int yb = e / TV, j = e - yb * TV; v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < TD; i++) {
             const int e = e0 + i * (int)blockDim.x;
             if (e < NV) {
                 const int yb = e / TV, j = e - yb * TV, l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
@@ -212,10 +219,11 @@ template <class P> __device__ __forceinline__ void pack_store(float2* line, int 
 template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb, float2* s) {
     constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
     const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::NL * P::NL;
-    for (int e0 = threadIdx.x; e0 < NV; e0 += 2 * (int)blockDim.x) {
-        float4 va[2], vb[2];
+    constexpr int UD = Z3_LOADS_U;                                  // pairs of 16-byte loads in flight per thread
+    for (int e0 = threadIdx.x; e0 < NV; e0 += UD * (int)blockDim.x) {
+        float4 va[UD], vb[UD];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < UD; i++) {
             const int e = e0 + i * (int)blockDim.x;
             if (e < NV) {
                 const int g = e / TV, j = e - g * TV;
@@ -224,7 +232,7 @@ template <class P> __device__ __forceinline__ void load_u_pair(const float2* __r
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < UD; i++) {
             const int e = e0 + i * (int)blockDim.x;
             if (e < NV) {
                 const int g = e / TV, j = e - g * TV, row = (2 * j) / P::NL, l = (2 * j) % P::NL;      // tile entry [row][l], l even

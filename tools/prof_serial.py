@@ -24,7 +24,8 @@ def main():
     psf = torch.from_numpy(bench.moffat_stamp(25, 4.0)).to(dev)
     for i in range(n + 1):
         data, mask, h, hm = R.reduce_object(ctx, raw, {}, 'ML1', mflat=flat, bpm=bpm, xtalk_coeffs=coeffs, exptime=60.0)
-        res = G.optimal_subtraction(ctx, data, ref, mask, ref_mask, psf, psf, fratio=1.0, dx=0.03, dy=0.03, cat_extract=True)
+        res = G.optimal_subtraction(ctx, data, ref, mask, ref_mask, psf, psf, fratio=1.0, dx=0.03, dy=0.03, cat_extract=True,
+                                    ref_is_bkgsub=True, ref_bkg_std_mini=np.full((176, 176), 8.0, np.float32))
         ctx.sync()
         del res
     print('done', n + 1, 'frames')
