@@ -24,7 +24,10 @@ namespace z3 {
 struct zscal { float sn, sr, fn, fr, dx, dy; };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; return s; }
+#ifndef Z3_LSMOD
+#define Z3_LSMOD 8
+#endif
+constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD) s++; return s; }
 
 #ifndef Z3_THREADS
 #define Z3_THREADS 512         // two workgroups per CU
@@ -54,7 +57,8 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != 8) s++; r
 #define Z3_PLAN1400 5, 7, 5, 8
 #endif
 #ifndef Z3_TWL
-#define Z3_TWL 0               // twiddle table in LDS (1) or read from global memory (0)
+#define Z3_TWL 1               // twiddle table in LDS (1) or read from global memory (0: three 8-byte reads per point
+                               // and transform through the vector memory path, +9 % on the whole call)
 #endif
 
 template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
@@ -109,16 +113,28 @@ __device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ t
         float2 u[R];
 #pragma unroll
         for (int r = 0; r < R; r++) u[r] = line[AFF8 ? r * (M + M / 8) : AFF1 ? r + r / 8 : npos(base + r * M)];
+        // twiddles W^(m k TWS), k = 1 .. R-1: one table read, the powers by multiplication (Z3_TWPOW), or R-1 reads
+        float2 w[R];
+        if constexpr (M > 1) {
+#ifdef Z3_TWPOW
+            w[1] = tw[m * TWS];
+#pragma unroll
+            for (int k = 2; k < R; k++) w[k] = (k % 2 == 0) ? cmul(w[k / 2], w[k / 2]) : cmul(w[k - 1], w[1]);
+#else
+#pragma unroll
+            for (int k = 1; k < R; k++) w[k] = tw[m * k * TWS];
+#endif
+        }
         if (!INV) {
             bbx_dft<R>::run(u);
             if constexpr (M > 1) {
 #pragma unroll
-                for (int k = 1; k < R; k++) u[k] = cmul(u[k], tw[m * k * TWS]);
+                for (int k = 1; k < R; k++) u[k] = cmul(u[k], w[k]);
             }
         } else {
             if constexpr (M > 1) {
 #pragma unroll
-                for (int k = 1; k < R; k++) u[k] = cmulc(u[k], tw[m * k * TWS]);
+                for (int k = 1; k < R; k++) u[k] = cmulc(u[k], w[k]);
             }
             idft<R>(u);
         }
@@ -146,12 +162,23 @@ template <class P, int NLINES = P::NL> __device__ __forceinline__ void fft_inv(f
     fft_step<P, P::R0, P::L, true, NLINES>(s, tw); __syncthreads();
 }
 
-// the twiddle table: LDS copy (after the line buffers) or the global one
-template <class P> __device__ __forceinline__ const float2* tw_setup(float2* after_lines, const float2* __restrict__ tw) {
-    if (!P::TWL) return tw;
-    for (int e = threadIdx.x; e < P::L; e += blockDim.x) after_lines[e] = tw[e];
-    return after_lines;                                             // visible after the caller's next barrier
+// per-workgroup tables behind the line buffers: the twiddles (LDS copy, or the global table) and the
+// position of every spectral index (ppos costs ~25 VALU instructions; the packing / splitting loops need two per entry)
+struct aux_t { const float2* tw; const unsigned short* pp; };
+template <class P> __device__ __forceinline__ aux_t aux_setup(float2* after_lines, const float2* __restrict__ twg) {
+    aux_t a;
+    a.tw = twg;
+    if (P::TWL) {
+        for (int e = threadIdx.x; e < P::L; e += blockDim.x) after_lines[e] = twg[e];
+        a.tw = after_lines;
+        after_lines += P::L;
+    }
+    unsigned short* pp = reinterpret_cast<unsigned short*>(after_lines);
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) pp[e] = (unsigned short)ppos<P>(e);
+    a.pp = pp;
+    return a;                                                       // visible after the caller's next barrier
 }
+template <class P> constexpr size_t aux_bytes() { return (P::TWL ? (size_t)P::L * sizeof(float2) : 0) + (((size_t)P::L * 2 + 15) & ~(size_t)15); }
 
 // Workgroup -> (x, y) of an nx * ny task grid, launched as a 1-D grid of a multiple of 8 workgroups.
 // Workgroups are dealt round-robin over the 8 XCDs (observed, for speed only): the tasks are numbered so
@@ -210,13 +237,14 @@ template <class P> __device__ __forceinline__ float2* park_ptr(float2* T, int su
     constexpr int TS = P::NL * P::NL;
     return T + (size_t)sub * P::UNIT + (size_t)(e / TS) * P::HP * P::NL + (size_t)g * TS + e % TS;
 }
-template <class P> __device__ __forceinline__ void pack_store(float2* line, int kx, float2 a, float2 b) {
+template <class P> __device__ __forceinline__ void pack_store(float2* line, const unsigned short* pp, int kx, float2 a, float2 b) {
     if (kx >= P::H) return;
-    line[ppos<P>(kx)] = make_float2(a.x - b.y, a.y + b.x);
-    if (kx >= 1 && P::L - kx >= P::H) line[ppos<P>(P::L - kx)] = make_float2(a.x + b.y, b.x - a.y);
+    line[pp[kx]] = make_float2(a.x - b.y, a.y + b.x);
+    if (kx >= 1 && P::L - kx >= P::H) line[pp[P::L - kx]] = make_float2(a.x + b.y, b.x - a.y);
 }
 // Hermitian packing of two U half spectra (row block yb) into full complex lines in spectrum order: Z = a + i b
-template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb, float2* s) {
+template <class P> __device__ __forceinline__ void load_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb, float2* s,
+                                                                const unsigned short* pp) {
     constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
     const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::NL * P::NL;
     constexpr int UD = Z3_LOADS_U;                                  // pairs of 16-byte loads in flight per thread
@@ -238,24 +266,82 @@ template <class P> __device__ __forceinline__ void load_u_pair(const float2* __r
                 const int g = e / TV, j = e - g * TV, row = (2 * j) / P::NL, l = (2 * j) % P::NL;      // tile entry [row][l], l even
                 if (yb * P::NL + row < P::L) {
                     float2* line = s + row * P::LS;
-                    pack_store<P>(line, g * P::NL + l, make_float2(va[i].x, va[i].y), make_float2(vb[i].x, vb[i].y));
-                    pack_store<P>(line, g * P::NL + l + 1, make_float2(va[i].z, va[i].w), make_float2(vb[i].z, vb[i].w));
+                    pack_store<P>(line, pp, g * P::NL + l, make_float2(va[i].x, va[i].y), make_float2(vb[i].x, vb[i].y));
+                    pack_store<P>(line, pp, g * P::NL + l + 1, make_float2(va[i].z, va[i].w), make_float2(vb[i].z, vb[i].w));
                 }
             }
         }
     }
 }
-template <class P> __device__ __forceinline__ void load_halo_pair(const float2* __restrict__ Ha, const float2* __restrict__ Hb, int sub, int yb, float2* line) {
+template <class P> __device__ __forceinline__ void load_halo_pair(const float2* __restrict__ Ha, const float2* __restrict__ Hb, int sub, int yb, float2* line,
+                                                                   const unsigned short* pp) {
     const size_t base = ((size_t)sub * P::LB + yb) * P::HP;
-    for (int kx = threadIdx.x; kx < P::H; kx += blockDim.x) pack_store<P>(line, kx, Ha[base + kx], Hb[base + kx]);
+    for (int kx = threadIdx.x; kx < P::H; kx += blockDim.x) pack_store<P>(line, pp, kx, Ha[base + kx], Hb[base + kx]);
+}
+// The same loads split in two: all of a workgroup's 16-byte loads into registers first (issued before a
+// transform of other data, so that their latency hides behind it), the LDS stores later.
+template <class P, int T> struct t_regs { static constexpr int N = (P::LB * P::NL * P::NL / 2 + T - 1) / T; float4 v[N]; };
+template <class P, int T> __device__ __forceinline__ void fetch_t_lines(const float2* __restrict__ Tin, int sub, int g, t_regs<P, T>& r) {
+    const float2* src = Tin + (size_t)sub * P::UNIT + (size_t)g * P::NL * P::NL;
+    constexpr int TV = P::NL * P::NL / 2, NV = P::LB * TV;
+#pragma unroll
+    for (int i = 0; i < t_regs<P, T>::N; i++) {
+        const int e = (int)threadIdx.x + i * T;
+        if (e < NV) { const int yb = e / TV, j = e - yb * TV; r.v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
+    }
+}
+template <class P, int T> __device__ __forceinline__ void pack_t_lines(const t_regs<P, T>& r, float2* s) {
+    constexpr int TV = P::NL * P::NL / 2, NV = P::LB * TV;
+#pragma unroll
+    for (int i = 0; i < t_regs<P, T>::N; i++) {
+        const int e = (int)threadIdx.x + i * T;
+        if (e < NV) {
+            const int yb = e / TV, j = e - yb * TV, l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
+            if (y < P::L) {
+                float2* line = s + l * P::LS;
+                line[npos(y)] = make_float2(r.v[i].x, r.v[i].y); line[npos(y + 1)] = make_float2(r.v[i].z, r.v[i].w);
+            }
+        }
+    }
+}
+template <class P, int T> struct u_regs { static constexpr int N = (P::G * P::NL * P::NL / 2 + T - 1) / T; float4 a[N], b[N]; };
+template <class P, int T> __device__ __forceinline__ void fetch_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb,
+                                                                        u_regs<P, T>& r) {
+    constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
+    const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::NL * P::NL;
+#pragma unroll
+    for (int i = 0; i < u_regs<P, T>::N; i++) {
+        const int e = (int)threadIdx.x + i * T;
+        if (e < NV) {
+            const int g = e / TV, j = e - g * TV;
+            const size_t o = base + (size_t)g * P::L * P::NL + 2 * j;
+            r.a[i] = *reinterpret_cast<const float4*>(Ua + o); r.b[i] = *reinterpret_cast<const float4*>(Ub + o);
+        }
+    }
+}
+template <class P, int T> __device__ __forceinline__ void pack_u_pair(const u_regs<P, T>& r, int yb, float2* s, const unsigned short* pp) {
+    constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
+#pragma unroll
+    for (int i = 0; i < u_regs<P, T>::N; i++) {
+        const int e = (int)threadIdx.x + i * T;
+        if (e < NV) {
+            const int g = e / TV, j = e - g * TV, row = (2 * j) / P::NL, l = (2 * j) % P::NL;
+            if (yb * P::NL + row < P::L) {
+                float2* line = s + row * P::LS;
+                pack_store<P>(line, pp, g * P::NL + l, make_float2(r.a[i].x, r.a[i].y), make_float2(r.b[i].x, r.b[i].y));
+                pack_store<P>(line, pp, g * P::NL + l + 1, make_float2(r.a[i].z, r.a[i].w), make_float2(r.b[i].z, r.b[i].w));
+            }
+        }
+    }
 }
 // Hermitian split of a packed transform Z (LDS, spectrum order) -> two half spectra, T tiles of row block yb
-template <class P> __device__ __forceinline__ void store_t_split(const float2* s, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub, int yb) {
+template <class P> __device__ __forceinline__ void store_t_split(const float2* s, const unsigned short* pp, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub,
+                                                                  int yb) {
     const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::HP * P::NL;         // the block's entries (kx, row) are contiguous
     for (int e = threadIdx.x; e < P::NL * P::H; e += blockDim.x) {
         const int kx = e / P::NL, row = e - kx * P::NL;
         const float2* line = s + row * P::LS;
-        const float2 zk = line[ppos<P>(kx)], zm = line[ppos<P>(kx ? P::L - kx : 0)];
+        const float2 zk = line[pp[kx]], zm = line[pp[kx ? P::L - kx : 0]];
         Ta[base + e] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         Tb[base + e] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
     }
@@ -282,7 +368,8 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_cols(const float* _
     extern __shared__ float2 s[];
     __shared__ double red[3][P::THREADS / 64];
     WG_TASK(P::G, nsub, g, sub);
-    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
     const int h = S / 2;
     const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
     constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
@@ -362,8 +449,10 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_psf_rows(const fl
                                                          int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::LB, nsub, yb, sub);
-    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
-    load_u_pair<P>(Ukr, Ukn, sub, yb, s);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
+    __syncthreads();                                                // the position table is used right away
+    load_u_pair<P>(Ukr, Ukn, sub, yb, s, aux.pp);
     __syncthreads();
     fft_inv<P>(s, tw);
     C_LOOP(e, l, p) {
@@ -373,7 +462,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_psf_rows(const fl
     }
     __syncthreads();
     fft_fwd<P>(s, tw);
-    store_t_split<P>(s, Tkr2, Tkn2, sub, yb);
+    store_t_split<P>(s, aux.pp, Tkr2, Tkn2, sub, yb);
 }
 
 // forward column pass of one T array -> C layout
@@ -381,7 +470,8 @@ template <class P>
 __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_cols_fwd(const float2* __restrict__ T, const float2* __restrict__ twg, float2* __restrict__ Cout, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::G, nsub, g, sub);
-    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
     load_t_lines<P>(T, sub, g, s);
     __syncthreads();
     fft_fwd<P>(s, tw);
@@ -414,7 +504,8 @@ template <class P>
 __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_img_rows(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta, float2* __restrict__ Tb, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::LB, nsub, yb, sub);
-    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
     const int y0 = yb * P::NL;
     const int sy = sub / f.nsx, sx = sub - sy * f.nsx;
     const int Y0 = sy * f.size - f.border, X0 = sx * f.size - f.border;
@@ -470,7 +561,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_img_rows(frame_ar
     }
     __syncthreads();
     fft_fwd<P>(s, tw);
-    store_t_split<P>(s, Ta, Tb, sub, yb);
+    store_t_split<P>(s, aux.pp, Ta, Tb, sub, yb);
 }
 
 // column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U tiles)
@@ -482,9 +573,14 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
                                                          float2* __restrict__ HSn, float2* __restrict__ HSr, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::G, nsub, g, sub);
-    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
     const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
     load_t_lines<P>(TN, sub, g, s);
+#ifndef Z3_NO_PREFETCH
+    t_regs<P, P::THREADS> rr;                                      // T_R on its way while T_N is transformed
+    fetch_t_lines<P, P::THREADS>(TR, sub, g, rr);
+#endif
     __syncthreads();
     fft_fwd<P>(s, tw);
     constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
@@ -499,7 +595,11 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     fft_inv<P>(s, tw);
     store_u<P>(s, USn, sub, g, HSn);
     __syncthreads();
+#ifndef Z3_NO_PREFETCH
+    pack_t_lines<P, P::THREADS>(rr, s);
+#else
     load_t_lines<P>(TR, sub, g, s);
+#endif
     __syncthreads();
     fft_fwd<P>(s, tw);
     R_LOOP(k, e, l, p) {
@@ -528,7 +628,8 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* 
     extern __shared__ float2 s[];
     __shared__ float s_beta;
     WG_TASK(P::G, nsub, g, sub);
-    const float2* tw = tw_setup<P>(s + P::NL * P::LS, twg);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
     if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, nsub, sub, sc[sub]);
     const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
     load_t_lines<P>(TVn, sub, g, s);
@@ -570,7 +671,9 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
     float2* hline = s + P::NL * P::LS;                              // the halo line
     __shared__ float s_fs, s_ibeta;
     WG_TASK(nyb, nsub, ybi, sub);
-    const float2* tw = tw_setup<P>(s + (P::NL + 1) * P::LS, twg);
+    const aux_t aux = aux_setup<P>(s + (P::NL + 1) * P::LS, twg);
+    const float2* tw = aux.tw;
+    __syncthreads();                                                // the position table is used right away
     const int yb = yb0 + ybi, y0 = yb * P::NL;
     const zscal z = sc[sub];
     if (threadIdx.x == 0) {
@@ -583,53 +686,83 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
     const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
     const int sy = sub / o.nsx, sx = sub - sy * o.nsx;
     // (D, V_S): D goes out at once, V_S waits in registers (the same thread takes the same pixels below)
-    constexpr int NE = (P::NL * P::L + P::FIN_THREADS - 1) / P::FIN_THREADS;
-    float vsr[NE];
-    load_u_pair<P>(UD, UVS, sub, yb, s);
+    constexpr int KX = (P::L + P::FIN_THREADS - 1) / P::FIN_THREADS;   // pixels of a row per thread: x = border + t + k T
+    float vsr[P::NL][KX];
+#ifndef Z3_NO_PREFETCH
+    // all of this workgroup's global loads go out now; the second pair waits in registers behind the first transform
+    u_regs<P, P::FIN_THREADS> ra, rb;
+    fetch_u_pair<P, P::FIN_THREADS>(UD, UVS, sub, yb, ra);
+    fetch_u_pair<P, P::FIN_THREADS>(USn, USr, sub, yb, rb);
+    static_assert(P::H <= 2 * P::FIN_THREADS, "halo line: two entries per thread");
+    float2 ha[2], hb[2];
+    {
+        const size_t hbase = ((size_t)sub * P::LB + (yb ? yb - 1 : P::LB - 1)) * P::HP;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int kx = (int)threadIdx.x + i * P::FIN_THREADS;
+            if (kx < P::H) { ha[i] = HSn[hbase + kx]; hb[i] = HSr[hbase + kx]; }
+        }
+    }
+    pack_u_pair<P, P::FIN_THREADS>(ra, yb, s, aux.pp);
+#else
+    load_u_pair<P>(UD, UVS, sub, yb, s, aux.pp);
+#endif
     __syncthreads();
     fft_inv<P>(s, tw);
-    const float ibeta = s_ibeta, fs = s_fs;
+    const float ibeta = s_ibeta, ifs = 1.0f / s_fs, ifD = inv_n2 / fD, vscale = inv_n2 * ibeta;
 #pragma unroll
-    for (int k = 0; k < NE; k++) {
-        const int e = threadIdx.x + k * P::FIN_THREADS;
-        vsr[k] = 0.f;
-        if (e < P::NL * o.size) {
-            const int l = e / o.size, xi = e - l * o.size, y = y0 + l;
-            const float2 v = s[l * P::LS + npos(o.border + xi)];
-            vsr[k] = v.y * inv_n2 * ibeta;
-            if (y >= o.border && y < o.border + o.size) {
-                const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
-                if (Y < o.ny && Xf < o.nx) o.D[(size_t)Y * o.nx + Xf] = v.x * inv_n2 / fD;
+    for (int l = 0; l < P::NL; l++) {
+        const int y = y0 + l, Y = sy * o.size + (y - o.border);
+        const bool rowok = y >= o.border && y < o.border + o.size && Y < o.ny;
+#pragma unroll
+        for (int k = 0; k < KX; k++) {
+            const int xi = (int)threadIdx.x + k * P::FIN_THREADS, Xf = sx * o.size + xi;
+            vsr[l][k] = 0.f;
+            if (xi < o.size) {
+                const float2 v = s[l * P::LS + npos(o.border + xi)];
+                vsr[l][k] = v.y * vscale;
+                if (rowok && Xf < o.nx) o.D[(size_t)Y * o.nx + Xf] = v.x * ifD;
             }
         }
     }
     __syncthreads();
     // (Sn, Sr): the block's rows + the row above it (row L - 1 above row 0: np.roll)
-    load_u_pair<P>(USn, USr, sub, yb, s);
-    load_halo_pair<P>(HSn, HSr, sub, yb ? yb - 1 : P::LB - 1, hline);
+#ifndef Z3_NO_PREFETCH
+    pack_u_pair<P, P::FIN_THREADS>(rb, yb, s, aux.pp);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int kx = (int)threadIdx.x + i * P::FIN_THREADS;
+        if (kx < P::H) pack_store<P>(hline, aux.pp, kx, ha[i], hb[i]);
+    }
+#else
+    load_u_pair<P>(USn, USr, sub, yb, s, aux.pp);
+    load_halo_pair<P>(HSn, HSr, sub, yb ? yb - 1 : P::LB - 1, hline, aux.pp);
+#endif
     __syncthreads();
     fft_inv<P, P::NL + 1>(s, tw);
+    const float dx2 = z.dx * z.dx, dy2 = z.dy * z.dy;
 #pragma unroll
-    for (int k = 0; k < NE; k++) {
-        const int e = threadIdx.x + k * P::FIN_THREADS;
-        if (e >= P::NL * o.size) continue;
-        const int l = e / o.size, xi = e - l * o.size, y = y0 + l, xx = o.border + xi;
-        if (y < o.border || y >= o.border + o.size) continue;
-        const int Y = sy * o.size + (y - o.border), Xf = sx * o.size + xi;
-        if (Y >= o.ny || Xf >= o.nx) continue;
+    for (int l = 0; l < P::NL; l++) {
+        const int y = y0 + l, Y = sy * o.size + (y - o.border);
+        if (!(y >= o.border && y < o.border + o.size && Y < o.ny)) continue;
         const float2* line = s + l * P::LS;
         const float2* upline = l ? line - P::LS : hline;
-        const float2 c = cscale(line[npos(xx)], inv_n2);                                  // (Sn, Sr) here
-        const float2 up = cscale(upline[npos(xx)], inv_n2), lf = cscale(line[npos(xx == 0 ? P::L - 1 : xx - 1)], inv_n2);
-        const float sval = c.x - c.y;                                                      // S = Sn - Sr
-        const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
-        const float vast = z.dx * z.dx * (dSndx * dSndx + dSrdx * dSrdx) + z.dy * z.dy * (dSndy * dSndy + dSrdy * dSrdy);
-        const float vs = vsr[k];
-        const size_t q = (size_t)Y * o.nx + Xf;
-        if (o.S) o.S[q] = sval;
-        o.Scorr[q] = sval / sqrtf(vs + vast);
-        o.Fpsf[q] = sval / fs;
-        o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) / fs;
+#pragma unroll
+        for (int k = 0; k < KX; k++) {
+            const int xi = (int)threadIdx.x + k * P::FIN_THREADS, Xf = sx * o.size + xi, xx = o.border + xi;
+            if (xi >= o.size || Xf >= o.nx) continue;
+            const float2 c = cscale(line[npos(xx)], inv_n2);                              // (Sn, Sr) here
+            const float2 up = cscale(upline[npos(xx)], inv_n2), lf = cscale(line[npos(xx == 0 ? P::L - 1 : xx - 1)], inv_n2);
+            const float sval = c.x - c.y;                                                  // S = Sn - Sr
+            const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
+            const float vast = dx2 * (dSndx * dSndx + dSrdx * dSrdx) + dy2 * (dSndy * dSndy + dSrdy * dSrdy);
+            const float vs = vsr[l][k];
+            const size_t q = (size_t)Y * o.nx + Xf;
+            if (o.S) o.S[q] = sval;
+            o.Scorr[q] = sval / sqrtf(vs + vast);
+            o.Fpsf[q] = sval * ifs;
+            o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) * ifs;
+        }
     }
 }
 
@@ -653,9 +786,8 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     float2 *T0 = arr[0], *T1 = arr[1], *T2 = arr[2], *T3 = arr[3], *U0 = arr[4], *U1 = arr[5], *U2 = arr[6], *U3 = arr[7];
     float2 *cA = arr[8], *cB = arr[9], *cKn = arr[10], *cKr = arr[11], *cK2n = arr[12], *cK2r = arr[13];
     BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
-    const size_t lds_tw = P::TWL ? (size_t)P::L * sizeof(float2) : 0;
-    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + lds_tw,
-                 lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2) + lds_tw;
+    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + aux_bytes<P>(),
+                 lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2) + aux_bytes<P>();
     static bool attr_set = false;
     if (!attr_set) {
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -52,16 +52,13 @@ def _axis_map(nin, nout, offset):
     return (fl + offset).astype(np.int32), _bspline_weights(cc - fl)
 
 
-def zoom_plan(mini, box, channels=None):
-    """host part of mini2back: B-spline coefficients of the (edge-padded) mini image and the
-    per-row / per-column tap tables for scipy.ndimage.zoom(mini, box, order=3, mode='nearest');
-    channels=(cy, cx) boxes -> every channel block gets its own padded coefficient patch
-    (interp_Xchan=False)."""
-    mini = np.asarray(mini, np.float64)
-    nby, nbx = mini.shape
-    cy, cx = (nby, nbx) if channels is None else channels
+import functools
+
+
+@functools.lru_cache(maxsize=16)
+def _tap_tables(nby, nbx, box, cy, cx):
+    """per-row / per-column tap tables of the zoom (shape-only: cached)"""
     py, px = cy + 2 * NPAD, cx + 2 * NPAD
-    coef = np.empty(((nby // cy) * py, (nbx // cx) * px))
     fy = np.empty(nby * box, np.int32); wy = np.empty((nby * box, 4))
     fx = np.empty(nbx * box, np.int32); wx = np.empty((nbx * box, 4))
     for iy in range(nby // cy):
@@ -70,12 +67,44 @@ def zoom_plan(mini, box, channels=None):
     for ix in range(nbx // cx):
         f, w = _axis_map(cx, cx * box, ix * px)
         fx[ix * cx * box:(ix + 1) * cx * box], wx[ix * cx * box:(ix + 1) * cx * box] = f, w
+    for a in (fy, wy, fx, wx):
+        a.setflags(write=False)
+    return fy, wy, fx, wx
+
+
+def zoom_coefficients(mini, channels=None):
+    """B-spline coefficients of the (edge-padded) mini image; channels=(cy, cx) boxes -> every
+    channel block gets its own padded coefficient patch (interp_Xchan=False)"""
+    mini = np.asarray(mini, np.float64)
+    nby, nbx = mini.shape
+    cy, cx = (nby, nbx) if channels is None else channels
+    py, px = cy + 2 * NPAD, cx + 2 * NPAD
+    coef = np.empty(((nby // cy) * py, (nbx // cx) * px))
     for iy in range(nby // cy):
         for ix in range(nbx // cx):
             blk = np.pad(mini[iy * cy:(iy + 1) * cy, ix * cx:(ix + 1) * cx], NPAD, mode='edge')
             coef[iy * py:(iy + 1) * py, ix * px:(ix + 1) * px] = ndimage.spline_filter(blk, order=3, mode='nearest',
                                                                                       output=np.float64)
-    return coef, fy, wy, fx, wx
+    return coef
+
+
+def zoom_plan(mini, box, channels=None):
+    """host part of mini2back: B-spline coefficients of the (edge-padded) mini image and the
+    per-row / per-column tap tables for scipy.ndimage.zoom(mini, box, order=3, mode='nearest');
+    channels=(cy, cx) boxes -> every channel block gets its own padded coefficient patch
+    (interp_Xchan=False)."""
+    nby, nbx = np.shape(mini)
+    cy, cx = (nby, nbx) if channels is None else channels
+    return (zoom_coefficients(mini, channels),) + _tap_tables(nby, nbx, box, cy, cx)
+
+
+def _device_taps(ctx, nby, nbx, box, cy, cx):
+    """the tap tables on the context's device (kept with the context)"""
+    cache = ctx.__dict__.setdefault('_zoom_taps', {})
+    key = (nby, nbx, box, cy, cx)
+    if key not in cache:
+        cache[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device) for a in _tap_tables(*key))
+    return cache[key]
 
 
 def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_from=None, want_bkg=True):
@@ -89,11 +118,12 @@ def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_fr
             raise ValueError('interp_Xchan=False needs a whole number of boxes per channel: mini image {}x{} over {}x{} channels'
                              .format(mini_h.shape[0], mini_h.shape[1], settings.ny, settings.nx))
         channels = (mini_h.shape[0] // settings.ny, mini_h.shape[1] // settings.nx)
-    coef, fy, wy, fx, wx = zoom_plan(mini_h, box, channels)
+    nby, nbx = mini_h.shape
+    cy, cx = (nby, nbx) if channels is None else channels
+    coef = zoom_coefficients(mini_h, channels)
+    d_fy, d_wy, d_fx, d_wx = _device_taps(ctx, nby, nbx, box, cy, cx)
     dev = ctx.device
     d_coef = torch.from_numpy(coef).to(dev)
-    d_fy, d_wy = torch.from_numpy(fy).to(dev), torch.from_numpy(wy).to(dev)
-    d_fx, d_wx = torch.from_numpy(fx).to(dev), torch.from_numpy(wx).to(dev)
     ny, nx = shape
     bkg = torch.empty((ny, nx), dtype=torch.float32, device=dev) if want_bkg else None
     check(lib.bbx_spline_zoom(ctx.h, ny, nx, _p(d_coef), coef.shape[0], coef.shape[1], _p(d_fy), _p(d_wy), _p(d_fx),
@@ -204,6 +234,12 @@ def psf_model_stamps(ctx, basis, x, y, polzero, polscal, poldeg, normalize=True)
 
 def find_transients(ctx, Scorr, nsigma=None, max_out=100000):
     """connected regions of |Scorr| >= T-NSIGMA -> sorted list of (y, x, Scorr peak)"""
+    ys, xs, val = find_peaks_arrays(ctx, Scorr, nsigma, max_out)
+    return list(zip(ys.tolist(), xs.tolist(), val.tolist()))
+
+
+def find_peaks_arrays(ctx, Scorr, nsigma=None, max_out=100000):
+    """the same as arrays (y int32, x int32, peak float32), sorted by (y, x): no per-source Python work"""
     nsigma = settings.transient_nsigma if nsigma is None else nsigma
     ny, nx = Scorr.shape
     dev = ctx.device
@@ -216,7 +252,7 @@ def find_transients(ctx, Scorr, nsigma=None, max_out=100000):
     n = min(int(cnt.item()), max_out)
     yx, val = yx[:n].cpu().numpy(), val[:n].cpu().numpy()
     order = np.lexsort((yx[:, 1], yx[:, 0])) if n else np.zeros(0, int)
-    return [(int(yx[i, 0]), int(yx[i, 1]), float(val[i])) for i in order]
+    return yx[order, 0], yx[order, 1], val[order]
 
 
 def embed_psfs(ctx, stamps, L):
@@ -351,21 +387,23 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     res['catalog'] = None
     if cat_extract and sub_pn is not None:
         thr = float(cat_nsigma) * hdr['S-BKGSTD'][0]
-        peaks = [p for p in find_transients(ctx, work, thr, max_out=max_sources) if p[2] > 0]
-        ok = new_mask[torch.as_tensor([p[0] for p in peaks], device=ctx.device, dtype=torch.long),
-                      torch.as_tensor([p[1] for p in peaks], device=ctx.device, dtype=torch.long)].cpu().numpy() == 0 \
-            if peaks else np.zeros(0, bool)
-        peaks = [p for p, k in zip(peaks, ok) if k]
-        ys, xs = [p[0] for p in peaks], [p[1] for p in peaks]
-        if peaks:
+        ys, xs, pk = find_peaks_arrays(ctx, work, thr, max_out=max_sources)
+        keep = pk > 0
+        ys, xs, pk = ys[keep], xs[keep], pk[keep]
+        if ys.size:
+            d_ys, d_xs = torch.from_numpy(ys.astype(np.int64)).to(ctx.device), torch.from_numpy(xs.astype(np.int64)).to(ctx.device)
+            ok = new_mask[d_ys, d_xs].cpu().numpy() == 0
+            ys, xs, pk = ys[ok], xs[ok], pk[ok]
+        peaks = ys
+        if ys.size:
             stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
             Vn = variance(ctx, work, bstd)
             f, e = psf_optflux(ctx, work, Vn, stamps, ys, xs)
             f, e = f.cpu().numpy(), e.cpu().numpy()
         else:
             f = e = np.zeros(0, np.float32)
-        res['catalog'] = dict(Y_POS=np.asarray(ys, np.float32) + 1, X_POS=np.asarray(xs, np.float32) + 1,
-                              E_FLUX_PEAK=np.asarray([p[2] for p in peaks], np.float32), E_FLUX_OPT=f, E_FLUXERR_OPT=e,
+        res['catalog'] = dict(Y_POS=ys.astype(np.float32) + 1, X_POS=xs.astype(np.float32) + 1,
+                              E_FLUX_PEAK=pk.astype(np.float32), E_FLUX_OPT=f, E_FLUXERR_OPT=e,
                               SNR_OPT=np.where(e > 0, f / np.where(e > 0, e, 1), 0).astype(np.float32))
         hdr['NOBJECTS'] = (len(peaks), 'number of objects detected')
     if not have_ref:
@@ -404,14 +442,16 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     # ---- sub-images
     bs = size // box if size % box == 0 else None
     scal = np.zeros((nsub, 6), np.float32)
-    for k in range(nsub):
-        sy, sx = divmod(k, nsx)
+
+    def tile_medians(a):
+        """median of the mini image over the boxes of each sub-image (or over all of it)"""
+        if bs and a.shape == (nsy * bs, nsx * bs):
+            return np.median(a.reshape(nsy, bs, nsx, bs).transpose(0, 2, 1, 3).reshape(nsub, bs * bs), axis=1)
         if bs:
-            tn = sdn[sy * bs:(sy + 1) * bs, sx * bs:(sx + 1) * bs]
-            tr = sdr[sy * bs:(sy + 1) * bs, sx * bs:(sx + 1) * bs]
-        else:
-            tn, tr = sdn, sdr
-        scal[k] = [np.median(tn), np.median(tr), 1.0, 1.0 / fratio if fratio else 1.0, dx, dy]
+            return np.asarray([np.median(a[(k // nsx) * bs:(k // nsx + 1) * bs, (k % nsx) * bs:(k % nsx + 1) * bs]) for k in range(nsub)])
+        return np.full(nsub, np.median(a))
+    scal[:, 0], scal[:, 1] = tile_medians(sdn), tile_medians(sdr)
+    scal[:, 2], scal[:, 3], scal[:, 4], scal[:, 5] = 1.0, (1.0 / fratio if fratio else 1.0), dx, dy
     sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
     if frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]:
         # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
@@ -431,17 +471,18 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     # ---- transient candidates: regions of |Scorr| >= T-NSIGMA, flux = Fpsf at the peak
     nsig = settings.transient_nsigma if nsigma is None else nsigma
     try:
-        trans = find_transients(ctx, res['Scorr'], nsig)
-        ntrans = len(trans)
+        tys, txs, tsc = find_peaks_arrays(ctx, res['Scorr'], nsig)
+        ntrans = int(tys.size)
     except _lib_BBXError:
         # more significant pixels than the candidate list holds (a failed subtraction: wrong
         # reference, gross misalignment): the images stand, the candidate table stays empty
-        trans, ntrans = [], 'None'
-    if trans:
-        ys = torch.as_tensor([t[0] for t in trans], device=ctx.device)
-        xs = torch.as_tensor([t[1] for t in trans], device=ctx.device)
-        f, e = res['Fpsf'][ys, xs].cpu().numpy(), res['Fpsferr'][ys, xs].cpu().numpy()
-        res['transients'] = [dict(y=t[0], x=t[1], scorr=t[2], fpsf=float(f[i]), fpsferr=float(e[i])) for i, t in enumerate(trans)]
+        tys = txs = np.zeros(0, np.int32); tsc = np.zeros(0, np.float32)
+        ntrans = 'None'
+    if tys.size:
+        d_ys, d_xs = torch.from_numpy(tys.astype(np.int64)).to(ctx.device), torch.from_numpy(txs.astype(np.int64)).to(ctx.device)
+        fe = torch.stack([res['Fpsf'][d_ys, d_xs], res['Fpsferr'][d_ys, d_xs]]).cpu().numpy()
+        res['transients'] = [dict(y=y, x=x, scorr=sc, fpsf=f, fpsferr=e)
+                             for y, x, sc, f, e in zip(tys.tolist(), txs.tolist(), tsc.tolist(), fe[0].tolist(), fe[1].tolist())]
     else:
         res['transients'] = []
     hdr['Z-P'] = (True, 'successfully processed by ZOGY?')
