@@ -339,8 +339,8 @@ def main():
         ysz, xsz, os_y, os_x = 5280, 1320, 20, 180
         size, border, box = 1320, 40, 60
     wl = args.workload
-    lanes = args.lanes or {'zogy': 5, 'full': 6, 'calib': 6}[wl]
-    depth = args.depth or {'zogy': 14, 'full': 18, 'calib': 18}[wl]
+    lanes = args.lanes or {'zogy': 6, 'full': 6, 'calib': 6}[wl]
+    depth = args.depth or {'zogy': 16, 'full': 18, 'calib': 18}[wl]
     seed = 1000 * 4 + rank
     raw, flat, bpm, ex = synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, args.raw, extras=True, ntrans=50)
     ref, ref_mask = synth_reference(torch, dev, ex.pop('scene0'), seed)
