@@ -328,3 +328,49 @@ def test_lacosmic_background_level(ctx, constant_sky, feed):
     assert list(st[:len(ncr_o)]) == ncr_o
     assert st[15] == 1                                              # "the level was needed"
 
+
+
+@pytest.mark.gpu
+def test_saturated_frame_one_percent(ctx):
+    """a frame with > 1 % saturated pixels (blobs of 3..9 px across, so that saturated-connected
+    pixels, hole filling and the object count all have work): the saturated-pixel queue takes one
+    reservation per wave in k_calibrate; mask, counts and pixels equal the oracle's mask_init bit
+    for bit (the queue's capacity is N/8 + 4096 entries: no overflow at this density)"""
+    tel, ys, xs, os_y, os_x = 'ML1', 330, 330, 20, 45
+    case = synth.make_case(ys, xs, 77, tel=tel, os_y=os_y, os_x=os_x, n_stars=40, n_sat=3, n_cr=0)
+    raw = case['raw'].copy()
+    rs = np.random.RandomState(3)
+    dy, dx = ys + os_y, xs + os_x
+    nblob = 0
+    for _ in range(900):
+        cy_, cx_ = rs.randint(0, 2), rs.randint(0, 8)
+        r = rs.randint(1, 5)
+        j = rs.randint(r, ys - r) + cy_ * dy + (os_y if cy_ else 0)
+        i = rs.randint(r, xs - r) + cx_ * dx
+        yy, xx = np.ogrid[-r:r + 1, -r:r + 1]
+        blob = (yy * yy + xx * xx) <= r * r
+        if rs.rand() < 0.3 and r >= 3:
+            blob = blob & ~((yy * yy + xx * xx) <= 1)             # a hole: fill_sat_holes closes it
+        raw[j - r:j + r + 1, i - r:i + r + 1][blob] = 65535
+        nblob += 1
+    rawf = raw.astype(np.float32)
+    dev = ctx.device
+    geom = R.geometry(raw.shape, ys, xs)
+    header, hm = {}, {}
+    R.gain_corr(header, tel)
+    d_raw = torch.from_numpy(rawf).to(dev)
+    sol = R.os_solve(ctx, d_raw, header, tel, geom)
+    bpm, flat = torch.from_numpy(case['bpm']).to(dev), torch.from_numpy(case['flat']).to(dev)
+    data, mask = R.calibrate(ctx, d_raw, sol, header, hm, tel, geom, mflat=flat, bpm=bpm)
+    d_nobj = R.mask_init_finish(ctx, mask, header, hm, geom)
+    ctx.sync()
+    # oracle on the same raw
+    o = rawf.copy()
+    O.gain_corr(o, settings.gain[tel], ys, xs)
+    o_os, oh, _ = O.os_corr(o, ys, xs, tel=tel, gain=settings.gain[tel], satlevel=settings.satlevel[tel])
+    o_mask, ohm = O.mask_init(o_os, oh, case['bpm'], settings.gain[tel], settings.satlevel[tel], ys, xs)
+    got = mask.cpu().numpy()
+    assert ((o_mask & 4) != 0).mean() > 0.01                       # > 1 % saturated
+    assert ((o_mask & 8) != 0).sum() > 0                           # and connected pixels around them
+    assert np.array_equal(got, o_mask)
+    assert int(d_nobj.item()) == int(oh['NOBJ-SAT'])

@@ -24,12 +24,14 @@ def pool():
     p.close()
 
 
-@pytest.mark.parametrize('tel,ys,xs,os_y,os_x', [('ML1', 96, 330, 20, 45), ('BG3', 2640, 330, 20, 45)])
-def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
+@pytest.mark.parametrize('tel,ys,xs,os_y,os_x,lanes,nframes', [('ML1', 96, 330, 20, 45, 2, 4), ('BG3', 2640, 330, 20, 45, 2, 4),
+                                                               ('ML1', 96, 330, 20, 45, 6, 12)])
+def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x, lanes, nframes):
+    """(the six-lane case: twelve frames of which every other one needs LA-Cosmic's background level)"""
     ctx = R.Context(0)
     dev = ctx.device
     cases = [synth.make_case(ys, xs, 100 + k, tel=tel, os_y=os_y, os_x=os_x, n_stars=60, n_sat=4, n_cr=60)
-             for k in range(4)]
+             for k in range(nframes)]
     # frames 1 and 3 hold a hot pixel inside a fully masked 5x5 block: the cleaned value is LA-Cosmic's
     # background level -- selected over the frame on demand in the serial runs and in the pipeline's
     # first such frame, prepared in advance (BBX_OPT_LAC_LEVEL_FEED) in the pipeline's later ones
@@ -39,7 +41,7 @@ def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
         bpm_np[j - 2:j + 3, i - 2:i + 3] |= 1
         bpm_np[j, i] = 0
     dy, dx = ys + os_y, xs + os_x
-    for k in (1, 3):
+    for k in range(1, nframes, 2):
         for (j, i) in hot:
             iy, ix = j // ys, i // xs
             rj = iy * dy + (j - iy * ys) + (0 if iy == 0 else os_y)
@@ -57,7 +59,7 @@ def test_pipeline_equals_serial(pool, tel, ys, xs, os_y, os_x):
         serial.append((d.cpu().numpy(), m.cpu().numpy(), h))
 
     pipe = FramePipeline(ctx, tel, geom, mflat=flat, bpm=bpm, xtalk_coeffs=coeffs, exptime=60.0, pool=pool,
-                         depth=3, do_finish=True, keep_outputs=True)
+                         depth=3 if lanes == 2 else 9, do_finish=True, keep_outputs=True, lanes=lanes)
     got = {}
 
     def done(idx, f):
