@@ -478,7 +478,8 @@ def main():
                     others={k: dict(avg_launch_ms=live[k][0], achieved=gbs(live[k]), frac=gbs(live[k]) / HBM_PEAK_GBS)
                             for k in live if k != dom})
         roof['frac'] = roof['achieved'] / roof['peak']
-        roof['timing'] = ('HIP events around each launch (group) on the launch stream, timed region, lane 0 of %d '
+        roof['timing'] = ('HIP events stamped by the launch itself (hipExtLaunchKernelGGL start / stop events: the kernel\'s execution; '
+                          'kernel groups: events recorded around the group) on the launch stream, timed region, lane 0 of %d '
                           '(other lanes\' kernels run concurrently)' % lanes)
         roof['isolated'] = {k: dict(avg_launch_ms=iso[k][0], launches=int(iso[k][2]), achieved=gbs(iso[k]),
                                     frac=gbs(iso[k]) / HBM_PEAK_GBS, note='serial frames, kernel alone on the GPU') for k in iso}

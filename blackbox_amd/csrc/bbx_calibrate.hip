@@ -227,17 +227,17 @@ extern "C" int bbx_calibrate(bbx_ctx* ctx, const bbx_geom* g, const void* d_raw,
                (((uintptr_t)d_data) % 16 == 0) && (((uintptr_t)d_mask) % 4 == 0) &&
                (!d_flat || ((uintptr_t)d_flat) % 16 == 0) && (!d_bias || ((uintptr_t)d_bias) % 16 == 0) &&
                (!d_bpm || ((uintptr_t)d_bpm) % 4 == 0);
-    bbx_prof_start(ctx, BBX_PROF_CALIBRATE, s);
     if (vec) {
         dim3 grid((a.d.nx / 4 + 255) / 256, a.d.ny / CAL_ROWS);
         if (a.nonlin) {
-            if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_U16, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_F32, true>), grid, dim3(256), 0, s, a);
+            if (raw_type == BBX_RAW_U16) BBX_LAUNCH_TIMED(ctx, BBX_PROF_CALIBRATE, (k_calibrate_v4<BBX_RAW_U16, true>), grid, dim3(256), 0, s, a);
+            else BBX_LAUNCH_TIMED(ctx, BBX_PROF_CALIBRATE, (k_calibrate_v4<BBX_RAW_F32, true>), grid, dim3(256), 0, s, a);
         } else {
-            if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_U16, false>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_calibrate_v4<BBX_RAW_F32, false>), grid, dim3(256), 0, s, a);
+            if (raw_type == BBX_RAW_U16) BBX_LAUNCH_TIMED(ctx, BBX_PROF_CALIBRATE, (k_calibrate_v4<BBX_RAW_U16, false>), grid, dim3(256), 0, s, a);
+            else BBX_LAUNCH_TIMED(ctx, BBX_PROF_CALIBRATE, (k_calibrate_v4<BBX_RAW_F32, false>), grid, dim3(256), 0, s, a);
         }
     } else {
+        bbx_prof_start(ctx, BBX_PROF_CALIBRATE, s);
         unsigned grid = (unsigned)((npix + 255) / 256);
         if (grid > 256u * 16u) grid = 256u * 16u;
         if (raw_type == BBX_RAW_U16) hipLaunchKernelGGL(k_calibrate_s<BBX_RAW_U16>, dim3(grid), dim3(256), 0, s, a);

@@ -1,6 +1,7 @@
 // bbx_common.h -- internal helpers shared by the HIP translation units (gfx950).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -73,6 +74,15 @@ struct bbx_ctx {
 #define BBX_PROF_MAX 8192
 void bbx_prof_start(bbx_ctx* ctx, int slot, hipStream_t s);
 void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s);
+// single kernels: an event pair that the launch itself stamps (hipExtLaunchKernelGGL) -- begin and end of the kernel's
+// execution, without the time the launch waits behind other streams' kernels; (nullptr, nullptr) when profiling is off
+void bbx_prof_events(bbx_ctx* ctx, int slot, hipEvent_t* e0, hipEvent_t* e1);
+#define BBX_LAUNCH_TIMED(ctx, slot, kern, grid, blk, lds, s, ...)                                   \
+    do {                                                                                              \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                      \
+        bbx_prof_events(ctx, slot, &e0_, &e1_);                                                       \
+        hipExtLaunchKernelGGL(kern, grid, blk, lds, s, e0_, e1_, 0, __VA_ARGS__);                     \
+    } while (0)
 
 enum {
     // one 64-byte line per counter: same-line atomics serialise (~11 ns each on MI355X)

@@ -39,6 +39,15 @@ void bbx_prof_start(bbx_ctx* ctx, int slot, hipStream_t s) {
     (void)hipEventRecord(ctx->prof_ev[2 * n], s);
     ctx->prof_open = 1; ctx->prof_open_idx = n;
 }
+void bbx_prof_events(bbx_ctx* ctx, int slot, hipEvent_t* e0, hipEvent_t* e1) {
+    *e0 = *e1 = nullptr;
+    ctx->prof_open = 0;
+    if (!ctx->prof_on || ctx->prof_n >= BBX_PROF_MAX) return;
+    const int n = ctx->prof_n;
+    ctx->prof_slot[n] = slot;
+    *e0 = ctx->prof_ev[2 * n]; *e1 = ctx->prof_ev[2 * n + 1];
+    ctx->prof_n = n + 1;
+}
 void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s) {
     if (!ctx->prof_open) return;
     ctx->prof_open = 0;
@@ -71,8 +80,9 @@ int bbx_profile_read(bbx_ctx* ctx, double* ms_total, int32_t* calls, int nslots)
     for (int i = 0; i < nslots; i++) { ms_total[i] = 0.0; calls[i] = 0; }
     for (int k = 0; k < ctx->prof_n; k++) {
         float ms = 0.f;
-        BBX_HIP(hipEventSynchronize(ctx->prof_ev[2 * k + 1]));
-        BBX_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]));
+        // a pair whose launch never happened (profiling switched while a lane was between reserve and launch) is skipped
+        if (hipEventSynchronize(ctx->prof_ev[2 * k + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
         const int sl = ctx->prof_slot[k];
         if (sl >= 0 && sl < nslots) { ms_total[sl] += ms; calls[sl]++; }
     }

@@ -1072,9 +1072,10 @@ extern "C" int bbx_lacosmic(bbx_ctx* ctx, int ny, int nx, float* d_data, uint8_t
     for (int it = 0; it < niter; it++) {
         if (it == 0) {
             // the one dense pass: candidates of the first iteration (+ the background-level feed)
-            bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
-            if (vec && feed) hipLaunchKernelGGL(k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
-            else if (vec) hipLaunchKernelGGL(k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            if (vec && feed) BBX_LAUNCH_TIMED(ctx, BBX_PROF_LAC_DENSE, k_lac_cand_v4<true>, gvec, dim3(64), CAND_WQ * 4 + FEED_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            else if (vec) BBX_LAUNCH_TIMED(ctx, BBX_PROF_LAC_DENSE, k_lac_cand_v4<false>, gvec, dim3(64), CAND_WQ * 4, s, d_data, d_mask, p, tile_cnt, tile_seg, ovf, cnt, (uint32_t)capovf, ctx->d_err, bs);
+            else bbx_prof_start(ctx, BBX_PROF_LAC_DENSE, s);
+            if (vec) {}
             else if (feed) hipLaunchKernelGGL(k_lac_cand_s<true>, dim3(gdense), dim3(256), sizeof(bsel_lds), s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)capk, ctx->d_err, bs);
             else hipLaunchKernelGGL(k_lac_cand_s<false>, dim3(gdense), dim3(256), 0, s, d_data, d_mask, p, cand_raw, cnt, (uint32_t)capk, ctx->d_err, bs);
             bbx_prof_stop(ctx, s);

@@ -819,9 +819,8 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
     const dim3 gfin = grid8(yb1 - yb0 + 1, nsub);
     bbx_prof_stop(ctx, s);
-    bbx_prof_start(ctx, BBX_PROF_ZOGY_FINAL, s);
-    hipLaunchKernelGGL(k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial, inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub);
-    bbx_prof_stop(ctx, s);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_ZOGY_FINAL, k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial,
+                     inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

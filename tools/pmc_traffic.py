@@ -27,16 +27,22 @@ def load(d, counter):
 def main():
     fe, wr = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
     out = {'_note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 3 '
-                    '--warmup 1 --no-cpu --depth 1` on MI355X; counter unit KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 '
+                    '--warmup 1 --no-cpu --no-extras --lanes 1 --depth 2` on MI355X; counter unit KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 '
                     '(gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section; '
                     '8-B and 4-B/lane loads are uncalibrated)',
            'kernels': {}}
     for k, (n, v) in fe.items():
-        if not (k.startswith('k_') or 'rocclr' in k):
+        if not (k.startswith('k_') or k.startswith('z3::') or k.startswith('z2::') or 'rocclr' in k):
             continue
         w = wr.get(k, [n, 0.0])
         fk, wk = v / n, w[1] / max(1, w[0])
-        out['kernels'][k] = dict(launches=n, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, traffic_bytes_per_launch=(2 * fk + wk) * 1024)
+        rec = dict(launches=n, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, traffic_bytes_per_launch=(2 * fk + wk) * 1024)
+        out['kernels'][k] = rec
+        # the names bench.py uses: kernels of bbx_zogy_frame without namespace / plan, the calibration kernels without variant
+        short = re.sub(r'<.*', '', k).split('::')[-1]
+        short = {'k_calibrate_v4': 'k_calibrate', 'k_lac_cand_v4': 'k_lac_cand'}.get(short, short)
+        if short != k and short not in out['kernels']:
+            out['kernels'][short] = dict(rec, alias_of=k)
     json.dump(out, sys.stdout, indent=1)
 
 
