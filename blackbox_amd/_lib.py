@@ -79,7 +79,8 @@ SIGNATURES = {
     'bbx_mask_counts': (_i, [_vp, C.c_int64, _vp, _vp, _vp]),
     'bbx_edge_fill': (_i, [_vp, _pg, _vp, _vp, _vp, _vp]),
     'bbx_median_stack': (_i, [_vp, C.c_int64, _i, C.POINTER(_vp), _pf, _vp, _i, _vp, _vp]),
-    'bbx_sat_trails': (_i, [_vp, _i, _i, _vp, _vp, _pd, _i, _vp, _vp, _vp]),
+    'bbx_canny_edge_map': (_i, [_vp, _i, _i, _vp, _pd, _i, C.c_double, C.c_double, _i, _vp, _vp, _vp]),
+    'bbx_sat_trails': (_i, [_vp, _i, _i, _vp, _vp, _pd, _i, _pd, _i, _vp, _vp, _vp]),
     'bbx_bkg_boxstats': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'bbx_mini_fill_filter': (_i, [_vp, _i, _i, _vp, _vp]),
     'bbx_spline_zoom': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,338 @@
+// bbx_canny.hip -- the edge detector in front of the satellite-trail Hough transform (row a12).
+// acstools.satdet.detsat (what sat_detect calls, blackbox.py:4183-4186: sigma=3, h_thresh=0.2, low_thresh
+// default 0.1) prepares its edge map with numpy.percentile(4.5, 93) + skimage.exposure.rescale_intensity +
+// skimage.feature.canny + skimage.morphology.remove_small_objects(60).  This file does exactly those
+// steps on the 2x2-binned frame, with the libraries' arithmetic order (oracle/sattrail.py `edges`,
+// pinned against scikit-image 0.18.3 by tests/golden/sat_front.npz):
+//
+//   percentiles    exact order statistics by a 3-pass radix select of four ranks (12 + 10 + 10 key bits),
+//                  numpy's linear rule: a + float32(b - a) * g, or b - float32(b - a) * (1 - g) for g >= 0.5
+//   rescale        float32: (clip(x, p1, p2) - p1) / float32(p2 - p1)
+//   smoothing      scipy.ndimage.gaussian_filter(sigma, mode='constant'): axis 0 then axis 1, double
+//                  accumulation centre first, then the pairs from the outside in, float32 after each axis;
+//                  divided by the same filter of an all-ones image (float64) + eps
+//   gradients      ndimage.sobel on the float64 image, reflecting borders; magnitude sqrt(i^2 + j^2)
+//   suppression    four direction sectors, linear interpolation between the two neighbours next to the
+//                  gradient direction; where sectors overlap the later one decides (gradients, magnitudes and
+//                  suppression of a 64 x 16 tile in LDS: the magnitude image never goes to HBM)
+//   hysteresis     8-connected components of the low mask that hold a pixel of the high mask, and of those
+//                  the ones with at least 60 pixels (remove_small_objects) -- bbx_mask.hip's sparse union-find
+//
+// Traffic on a 5280^2 binned frame (112 MB as float32): ~1.3 GB in 8 passes; everything after the suppression
+// works on a sparse pixel list.
+#include "bbx_common.h"
+
+#define CANNY_MAXR 32
+
+struct canny_par {
+    unsigned prefix[4];                    // radix select: key bits fixed so far, per rank
+    unsigned long long rank[4];            // rank inside the current bin
+    double p1, p2, low, high;
+    float p1f, p2f, den;
+    int degenerate;
+    double w[CANNY_MAXR + 1];              // Gaussian weights, centre first
+    int radius;
+};
+
+__device__ __forceinline__ unsigned fkey(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ void k_canny_init(canny_par* p, size_t n, double q1, double q2, const double* __restrict__ w, int radius, unsigned* hist) {
+    const int t = threadIdx.x;
+    for (int i = t; i < 4 * 4096; i += blockDim.x) hist[i] = 0;
+    if (t <= radius) p->w[t] = w[t];
+    if (t == 0) {
+        // numpy: virtual index (n - 1) q, neighbours floor / floor + 1
+        const double v1 = (double)(n - 1) * q1, v2 = (double)(n - 1) * q2;
+        const unsigned long long l1 = (unsigned long long)floor(v1), l2 = (unsigned long long)floor(v2);
+        p->rank[0] = l1; p->rank[1] = l1 + 1 < n ? l1 + 1 : n - 1;
+        p->rank[2] = l2; p->rank[3] = l2 + 1 < n ? l2 + 1 : n - 1;
+        for (int q = 0; q < 4; q++) p->prefix[q] = 0;
+        p->radius = radius; p->degenerate = 0;
+    }
+}
+
+// one digit of the select: pass 0 counts the top 12 key bits of every pixel (one histogram for all ranks),
+// passes 1 and 2 the next 10 bits of the pixels that match a rank's prefix (one histogram per rank)
+template <int PASS>
+__global__ __launch_bounds__(256) void k_canny_hist(const float* __restrict__ b, size_t n, const canny_par* __restrict__ p,
+                                                    unsigned* __restrict__ hist) {
+    __shared__ unsigned h[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    unsigned pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pre[q] = p->prefix[q];
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    const float4* b4 = (const float4*)b;
+    auto count = [&](float f) {
+        const unsigned k = fkey(f);
+        if (PASS == 0) atomicAdd(&h[k >> 20], 1u);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (PASS == 1 && (k >> 20) == pre[q]) atomicAdd(&h[q * 1024 + ((k >> 10) & 1023u)], 1u);
+                if (PASS == 2 && (k >> 10) == pre[q]) atomicAdd(&h[q * 1024 + (k & 1023u)], 1u);
+            }
+        }
+    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 f = b4[i];
+        count(f.x); count(f.y); count(f.z); count(f.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) count(b[n4 * 4 + threadIdx.x]);      // the last n mod 4 pixels
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// locate the bin of every rank, extend its prefix; after the last pass: the four order statistics -> parameters
+template <int PASS>
+__global__ __launch_bounds__(256) void k_canny_scan(canny_par* p, unsigned* hist) {
+    __shared__ unsigned sh[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) sh[i] = hist[i];
+    __syncthreads();
+    // wave q serves rank q: every lane sums a chunk of the histogram, the wave locates the chunk, lane 0 the bin
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned* h = PASS == 0 ? sh : sh + q * 1024;
+    constexpr int NB = PASS == 0 ? 4096 : 1024, CH = NB / 64;
+    unsigned long long mine = 0;
+    for (int i = 0; i < CH; i++) mine += h[lane * CH + i];
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const unsigned long long r = p->rank[q];
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(incl > r);       // first chunk whose running total exceeds the rank
+    const int chunk = m ? __ffsll((long long)m) - 1 : 63;
+    const unsigned long long before = __shfl(incl - mine, chunk, 64);
+    if (lane == 0) {
+        unsigned long long cum = before;
+        int bin = chunk * CH + CH - 1;
+        for (int i = 0; i < CH; i++) { const unsigned v = h[chunk * CH + i]; if (cum + v > r) { bin = chunk * CH + i; break; } cum += v; }
+        p->rank[q] = r - cum;
+        p->prefix[q] = PASS == 0 ? (unsigned)bin : ((p->prefix[q] << 10) | (unsigned)bin);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) hist[i] = 0;
+}
+
+__global__ void k_canny_params(canny_par* p, size_t n, double q1, double q2, double low_frac, double high_frac) {
+    if (threadIdx.x != 0) return;
+    float os[4];
+    for (int q = 0; q < 4; q++) os[q] = fkey_inv(p->prefix[q]);
+    double pc[2];
+    for (int j = 0; j < 2; j++) {
+        const double v = (double)(n - 1) * (j ? q2 : q1), g = v - floor(v);
+        const float a = os[2 * j], b = os[2 * j + 1];
+        const double diff = (double)(b - a);                       // the difference is taken in float32
+        pc[j] = g < 0.5 ? (double)a + diff * g : (double)b - diff * (1.0 - g);
+    }
+    if (pc[0] < 0.0) pc[0] = 0.0;                                  // acstools: "if p1 < 0: p1 = 0.0"
+    p->p1 = pc[0]; p->p2 = pc[1];
+    p->p1f = (float)pc[0]; p->p2f = (float)pc[1]; p->den = (float)(pc[1] - pc[0]);
+    p->degenerate = !(pc[1] > pc[0]);
+    const float immax = (p->p2f - p->p1f) / p->den;                // the rescaled value of every pixel >= p2
+    p->low = (double)immax * low_frac; p->high = (double)immax * high_frac;
+}
+
+__global__ __launch_bounds__(256) void k_canny_rescale(const float* __restrict__ b, size_t n, const canny_par* __restrict__ p,
+                                                       float* __restrict__ img) {
+    const float p1 = p->p1f, p2 = p->p2f, den = p->den;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = b[i];
+        const float c = fminf(fmaxf(x, p1), p2);                  // np.clip
+        img[i] = (c - p1) / den;
+    }
+}
+
+// Gaussian along y: a thread produces RY consecutive rows of one column from a register window (x across lanes)
+#define GV_RY 16
+template <int R>
+__global__ __launch_bounds__(256) void k_canny_gauss_v(const float* __restrict__ img, int ny, int nx, const canny_par* __restrict__ p,
+                                                       float* __restrict__ tmp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * GV_RY;
+    if (x >= nx) return;
+    double w[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; j++) w[j] = p->w[j];
+    double in[GV_RY + 2 * R];
+#pragma unroll
+    for (int k = 0; k < GV_RY + 2 * R; k++) {
+        const int y = y0 - R + k;
+        in[k] = (y >= 0 && y < ny) ? (double)img[(size_t)y * nx + x] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < GV_RY; r++) {
+        if (y0 + r >= ny) break;
+        double t = in[r + R] * w[0];
+#pragma unroll
+        for (int j = R; j >= 1; j--) t += (in[r + R - j] + in[r + R + j]) * w[j];
+        tmp[(size_t)(y0 + r) * nx + x] = (float)t;
+    }
+}
+
+// Gaussian along x + normalisation by the filtered all-ones image -> smoothed image, float64.  A workgroup takes 256
+// pixels of one row: the row piece with its halo goes through LDS; the all-ones image depends on the row (v0) and,
+// away from the left / right border, not on the column, so its interior value is computed once per thread from v0.
+template <int R>
+__global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__ tmp, int ny, int nx, const canny_par* __restrict__ p,
+                                                       double* __restrict__ sm) {
+    __shared__ float row[256 + 2 * R];
+    const int x0 = blockIdx.x * 256, x = x0 + threadIdx.x, y = blockIdx.y;
+    const float* src = tmp + (size_t)y * nx;
+    for (int i = threadIdx.x; i < 256 + 2 * R; i += 256) { const int xx = x0 - R + i; row[i] = (xx >= 0 && xx < nx) ? src[xx] : 0.f; }
+    double w[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; j++) w[j] = p->w[j];
+    __syncthreads();
+    if (x >= nx) return;
+    double t = (double)row[threadIdx.x + R] * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; j--) t += ((double)row[threadIdx.x + R - j] + (double)row[threadIdx.x + R + j]) * w[j];
+    const float s32 = (float)t;
+    // the all-ones image through the same two passes (float64 throughout)
+    double v0 = 1.0 * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; j--) v0 += ((y - j >= 0 ? 1.0 : 0.0) + (y + j < ny ? 1.0 : 0.0)) * w[j];
+    double bl = v0 * w[0];
+    if (x >= R && x + R < nx) {
+#pragma unroll
+        for (int j = R; j >= 1; j--) bl += (v0 + v0) * w[j];
+    } else {
+#pragma unroll
+        for (int j = R; j >= 1; j--) bl += ((x - j >= 0 ? v0 : 0.0) + (x + j < nx ? v0 : 0.0)) * w[j];
+    }
+    sm[(size_t)y * nx + x] = (double)s32 / (bl + 2.220446049250313e-16);
+}
+
+// Gradients, magnitude, non-maximum suppression and both thresholds on a 64 x 16 tile: the smoothed image with a
+// 2-pixel halo and the magnitudes with a 1-pixel halo live in LDS; the low-mask pixels of the tile go to the list in
+// one reservation, each with a flag "also in the high mask".
+//   ndimage.sobel(axis): derivative along the axis ([-1, 0, 1]), [1, 2, 1] across it, reflecting borders (index -1 -> 0:
+//   the clamped loads below); magnitude sqrt(i^2 + j^2)
+#define CT_X 64
+#define CT_Y 16
+__global__ __launch_bounds__(256) void k_canny_tile(const double* __restrict__ sm, int ny, int nx, const canny_par* __restrict__ p,
+                                                    uint32_t* list, uint8_t* hflag, int32_t* cnt, uint32_t cap, int32_t* err) {
+    __shared__ double s_sm[CT_Y + 4][CT_X + 4];
+    __shared__ double s_mag[CT_Y + 2][CT_X + 2];
+    __shared__ uint32_t q[CT_X * CT_Y];
+    __shared__ unsigned qn, gbase;
+    const int tid = threadIdx.x, x0 = blockIdx.x * CT_X, y0 = blockIdx.y * CT_Y;
+    if (tid == 0) qn = 0;
+    for (int i = tid; i < (CT_Y + 4) * (CT_X + 4); i += 256) {
+        const int r = i / (CT_X + 4), c = i - r * (CT_X + 4);
+        const int yy = min(max(y0 - 2 + r, 0), ny - 1), xx = min(max(x0 - 2 + c, 0), nx - 1);
+        s_sm[r][c] = sm[(size_t)yy * nx + xx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (CT_Y + 2) * (CT_X + 2); i += 256) {
+        const int r = i / (CT_X + 2), c = i - r * (CT_X + 2);           // image position (y0 - 1 + r, x0 - 1 + c)
+        const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
+        const double js = d1 * 2.0 + (d0 + d2);
+        const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
+        const double is = e1 * 2.0 + (e0 + e2);
+        s_mag[r][c] = sqrt(is * is + js * js);
+    }
+    __syncthreads();
+    const double low = p->low, high = p->high;
+    const bool live = !p->degenerate;
+    for (int i = tid; i < CT_X * CT_Y; i += 256) {
+        const int ty = i / CT_X, tx = i - ty * CT_X, y = y0 + ty, x = x0 + tx;
+        if (!live || y < 1 || y > ny - 2 || x < 1 || x > nx - 2) continue;      // binary_erosion of the all-ones mask
+        const int r = ty + 1, c = tx + 1;                                      // in s_mag; s_sm centre is [r + 1][c + 1]
+        const double m = s_mag[r][c];
+        if (!(m > 0.0 && m >= low)) continue;
+        const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
+        const double js = d1 * 2.0 + (d0 + d2);
+        const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
+        const double is = e1 * 2.0 + (e0 + e2);
+        const double ai = fabs(is), aj = fabs(js);
+        const bool same = (is >= 0 && js >= 0) || (is <= 0 && js <= 0), opp = (is <= 0 && js >= 0) || (is >= 0 && js <= 0);
+        const double* mu = s_mag[r - 1]; const double* mc = s_mag[r]; const double* md = s_mag[r + 1];
+        bool loc = false;
+        // c2 w + c1 (1 - w) <= m on both sides of the gradient direction; later sectors overwrite earlier ones
+        if (same && ai >= aj) { const double w = aj / ai; loc = (md[c + 1] * w + md[c] * (1 - w) <= m) && (mu[c - 1] * w + mu[c] * (1 - w) <= m); }
+        if (same && ai <= aj) { const double w = ai / aj; loc = (md[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (mu[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
+        if (opp && ai <= aj) { const double w = ai / aj; loc = (mu[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (md[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
+        if (opp && ai >= aj) { const double w = aj / ai; loc = (mu[c + 1] * w + mu[c] * (1 - w) <= m) && (md[c - 1] * w + md[c] * (1 - w) <= m); }
+        if (loc) { const unsigned k = atomicAdd(&qn, 1u); q[k] = (uint32_t)((size_t)y * nx + x) | (m >= high ? 0x80000000u : 0u); }
+    }
+    __syncthreads();
+    const unsigned n = qn;
+    if (!n) return;
+    if (tid == 0) gbase = atomicAdd((unsigned*)cnt, n);
+    __syncthreads();
+    for (unsigned t = tid; t < n; t += 256) {
+        if (gbase + t < cap) { list[gbase + t] = q[t] & 0x7fffffffu; hflag[gbase + t] = (uint8_t)(q[t] >> 31); }
+        else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+    }
+}
+
+int bbx_cc_filter_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt, size_t cap, int ny, int nx, const uint8_t* d_flag,
+                       int min_size, uint32_t* d_out, int32_t* d_out_cnt, uint32_t out_cap, hipStream_t s);
+
+// binned frame -> list of edge pixels (after hysteresis and remove_small_objects) in d_out / *d_out_cnt
+int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const double* h_gauss, int radius, double low_frac, double high_frac,
+                    int min_size, uint32_t* d_out, int32_t* d_out_cnt, uint32_t out_cap, hipStream_t s) {
+    if (radius < 1 || radius > CANNY_MAXR || ny < 3 || nx < 3) return BBX_ERR_ARG;
+    const size_t n = (size_t)ny * nx;
+    int rc;
+    const size_t cap = n / 8 + 4096;                               // low-mask pixels
+    const size_t o_par = 0, o_hist = 4096, o_w = o_hist + 4 * 4096 * 4, o_img = o_w + 1024;
+    const size_t o_tmp = o_img + ((n * 4 + 255) & ~(size_t)255), o_sm = o_tmp + ((n * 4 + 255) & ~(size_t)255);
+    const size_t o_list = o_sm + ((n * 8 + 255) & ~(size_t)255), o_flag = o_list + ((cap * 4 + 255) & ~(size_t)255);
+    const size_t total = o_flag + cap + 256;
+    char* ws = (char*)bbx_ws(ctx, WS_CANNY, total, &rc); if (rc) return rc;
+    canny_par* par = (canny_par*)(ws + o_par); unsigned* hist = (unsigned*)(ws + o_hist); double* d_w = (double*)(ws + o_w);
+    float* img = (float*)(ws + o_img); float* tmp = (float*)(ws + o_tmp); double* sm = (double*)(ws + o_sm);
+    uint32_t* list = (uint32_t*)(ws + o_list); uint8_t* hflag = (uint8_t*)(ws + o_flag);
+    int32_t* cnt = &ctx->d_counters[CNT_TMP];
+    const double q1 = 4.5 / 100.0, q2 = 93.0 / 100.0;             // np.percentile(image, (4.5, 93.0))
+    BBX_HIP(hipMemcpyAsync(d_w, h_gauss, (size_t)(radius + 1) * 8, hipMemcpyHostToDevice, s));
+    BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_canny_init, dim3(1), dim3(256), 0, s, par, n, q1, q2, d_w, radius, hist);
+    hipLaunchKernelGGL(k_canny_hist<0>, dim3(1024), dim3(256), 0, s, d_bin, n, par, hist);
+    hipLaunchKernelGGL(k_canny_scan<0>, dim3(1), dim3(256), 0, s, par, hist);
+    hipLaunchKernelGGL(k_canny_hist<1>, dim3(1024), dim3(256), 0, s, d_bin, n, par, hist);
+    hipLaunchKernelGGL(k_canny_scan<1>, dim3(1), dim3(256), 0, s, par, hist);
+    hipLaunchKernelGGL(k_canny_hist<2>, dim3(1024), dim3(256), 0, s, d_bin, n, par, hist);
+    hipLaunchKernelGGL(k_canny_scan<2>, dim3(1), dim3(256), 0, s, par, hist);
+    hipLaunchKernelGGL(k_canny_params, dim3(1), dim3(64), 0, s, par, n, q1, q2, low_frac, high_frac);
+    hipLaunchKernelGGL(k_canny_rescale, dim3(2048), dim3(256), 0, s, d_bin, n, par, img);
+    const dim3 gx((nx + 255) / 256, ny), gv((nx + 255) / 256, (ny + GV_RY - 1) / GV_RY);
+    if (radius == 12) {
+        hipLaunchKernelGGL(k_canny_gauss_v<12>, gv, dim3(256), 0, s, img, ny, nx, par, tmp);
+        hipLaunchKernelGGL(k_canny_gauss_h<12>, gx, dim3(256), 0, s, tmp, ny, nx, par, sm);
+    } else {
+        return BBX_ERR_ARG;                                        // sigma = 3 (radius 12) is what sat_detect asks for
+    }
+    hipLaunchKernelGGL(k_canny_tile, dim3((nx + CT_X - 1) / CT_X, (ny + CT_Y - 1) / CT_Y), dim3(256), 0, s, sm, ny, nx, par, list, hflag, cnt,
+                       (uint32_t)cap, ctx->d_err);
+    BBX_LAUNCH_CHECK();
+    return bbx_cc_filter_list(ctx, list, cnt, cap, ny, nx, hflag, min_size, d_out, d_out_cnt, out_cap, s);
+}
+
+// the edge map itself (tests; the trail detector consumes the list): d_map[ny * nx] = 1 at edge pixels, 0 elsewhere
+__global__ __launch_bounds__(256) void k_canny_scatter(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, uint32_t cap,
+                                                       uint8_t* __restrict__ map) {
+    const uint32_t n = min((uint32_t)*cnt, cap);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) map[list[e]] = 1;
+}
+
+extern "C" int bbx_canny_edge_map(bbx_ctx* ctx, int ny, int nx, const float* d_img, const double* h_gauss, int gauss_radius,
+                                  double low_frac, double high_frac, int min_size, uint8_t* d_map, int32_t* d_count, void* stream) {
+    if (!ctx || !d_img || !h_gauss || !d_map || !d_count || ((uintptr_t)d_img) % 16) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const size_t n = (size_t)ny * nx, cap = n / 8 + 4096;
+    uint32_t* out = (uint32_t*)bbx_ws(ctx, WS_CRLIST, cap * sizeof(uint32_t), &rc); if (rc) return rc;
+    BBX_HIP(hipMemsetAsync(d_map, 0, n, s));
+    rc = bbx_canny_edges(ctx, d_img, ny, nx, h_gauss, gauss_radius, low_frac, high_frac, min_size, out, d_count, (uint32_t)cap, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_canny_scatter, dim3(256), dim3(256), 0, s, out, d_count, (uint32_t)cap, d_map);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}

@@ -666,6 +666,55 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
     return BBX_OK;
 }
 
+// ---- hysteresis + small-object filter on a pixel list (Canny edges of the satellite-trail detector) ----
+// components (8-connected) of the listed pixels; a component stays when one of its pixels carries a flag (the
+// high mask) and it has at least min_size pixels; the pixels of the components that stay go to d_out
+__global__ __launch_bounds__(256) void k_ccf_acc(const int32_t* __restrict__ cnt, int cap, uint32_t* parent, const uint8_t* __restrict__ flag,
+                                                 uint32_t* size, uint32_t* has) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t root = cc_find(parent, (uint32_t)i);
+        atomicAdd(&size[root], 1u);
+        if (flag[i]) has[root] = 1u;
+    }
+}
+__global__ __launch_bounds__(256) void k_ccf_emit(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, int cap, uint32_t* parent,
+                                                  const uint32_t* __restrict__ size, const uint32_t* __restrict__ has, uint32_t min_size,
+                                                  uint32_t* out, int32_t* out_cnt, uint32_t out_cap, int32_t* err) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    const int lane = threadIdx.x & 63;
+    const int nround = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+    for (int r = 0; r < nround; r++) {
+        const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        bool keep = false;
+        if (i < n) { const uint32_t root = cc_find(parent, (uint32_t)i); keep = has[root] && size[root] >= min_size; }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (!m) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd((unsigned*)out_cnt, (unsigned)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (keep) {
+            const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (pos < out_cap) out[pos] = list[i]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+        }
+    }
+}
+
+int bbx_cc_filter_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt, size_t cap, int ny, int nx, const uint8_t* d_flag,
+                       int min_size, uint32_t* d_out, int32_t* d_out_cnt, uint32_t out_cap, hipStream_t s) {
+    int rc = bbx_cc_count_list(ctx, d_list, d_cnt, cap, ny, nx, &ctx->d_counters[CNT_CC_ROOTS], s); if (rc) return rc;
+    uint32_t* parent = (uint32_t*)ctx->d_ws[WS_PARENT];
+    uint32_t* size = (uint32_t*)bbx_ws(ctx, WS_STAGE2, 2 * cap * sizeof(uint32_t), &rc); if (rc) return rc;
+    uint32_t* has = size + cap;
+    BBX_HIP(hipMemsetAsync(size, 0, 2 * cap * sizeof(uint32_t), s));
+    BBX_HIP(hipMemsetAsync(d_out_cnt, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_ccf_acc, dim3(1024), dim3(256), 0, s, d_cnt, (int)cap, parent, d_flag, size, has);
+    hipLaunchKernelGGL(k_ccf_emit, dim3(1024), dim3(256), 0, s, d_list, d_cnt, (int)cap, parent, size, has, (uint32_t)min_size, d_out, d_out_cnt,
+                       out_cap, ctx->d_err);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
 // ---- peaks of connected regions of |img| >= thr (transient candidates on S_corr) ---------
 // Hits go through a per-workgroup LDS queue (wave ballots + an LDS counter) that is flushed with
 // one global reservation per ~1024 entries: a returning atomic per hit on one global counter

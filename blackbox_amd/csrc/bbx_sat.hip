@@ -1,12 +1,16 @@
 // bbx_sat.hip -- satellite-trail masking (reference sat_detect, blackbox.py:4163-4254).
-// [EXT / unpinnable: acstools' probabilistic Hough is random, ASTA is a CNN without weights;
-//  the deterministic classical detector implemented here is specified in oracle/sattrail.py]
+// The reference calls acstools.satdet (or ASTA, a CNN without weights here); acstools is absent from this
+// image.  The detector follows acstools' published chain where it is deterministic and is specified in
+// oracle/sattrail.py:
 //
-//   2x2 sum binning -> clipped level/sigma -> edge pixels (3..50 sigma) -> full Hough
-//   accumulator (720 angles x 1-px rho bins, one integer atomic per vote) -> best cell ->
-//   chord test -> perpendicular profile (float64 atomics into 81 bins) -> strip -> bit 16.
-// Traffic: one read of the frame (4N) for binning, then everything works on the 4x smaller
-// binned frame and on a sparse edge list.
+//   2x2 sum binning -> [bbx_canny.hip: percentile rescale, Canny(sigma 3, 0.1 / 0.2 of the maximum),
+//   remove_small_objects(60): pinned against scikit-image] -> full Hough accumulator over acstools' theta grid
+//   (2 .. 177.5 deg, skimage.transform.hough_line's cells; stands in for the *random* probabilistic transform)
+//   -> best cell with >= 210 votes whose supporting edge pixels span the frame to within buf = 40 px of both
+//   borders -> perpendicular profile (clipped level / sigma of the binned frame, float64 atomics into 81 bins)
+//   -> strip -> bit 16.
+// Traffic: one read of the frame (4N) for binning, then everything works on the 4x smaller binned frame and on
+// sparse pixel lists.
 #include "bbx_common.h"
 
 #define SAT_PROF_HALF 40
@@ -19,6 +23,10 @@ struct sat_state {
     int accept, found, k, lo_off, hi_off; // line accepted / strip found, theta index, strip offsets
     int votes;
     double rho, c, s, chord;
+    unsigned long long tmin, tmax;        // ordered keys of the smallest / largest position of a supporting edge pixel along the line
+    double t0, t1;                        // where the line enters / leaves the frame
+    unsigned long long fit_n; long long fit_t, fit_d, fit_tt, fit_td;   // integer sums (1/16 px) of the refinement
+    double icpt, slope;                   // refined line: distance d - (icpt + slope t)
     double prof_sum[SAT_NPROF];
     unsigned long long prof_n[SAT_NPROF];
 };
@@ -36,7 +44,8 @@ __global__ void k_sat_init(sat_state* st) {
     if (threadIdx.x == 0) {
         st->lo = -__builtin_huge_val(); st->hi = __builtin_huge_val(); st->mean = 0; st->std = 0; st->best = 0;
         st->accept = 0; st->found = 0; st->k = 0; st->lo_off = 0; st->hi_off = 0; st->votes = 0;
-        st->rho = 0; st->c = 0; st->s = 0; st->chord = 0;
+        st->rho = 0; st->c = 0; st->s = 0; st->chord = 0; st->tmin = ~0ull; st->tmax = 0ull; st->t0 = 0; st->t1 = 0;
+        st->fit_n = 0; st->fit_t = st->fit_d = st->fit_tt = st->fit_td = 0; st->icpt = 0; st->slope = 0;
     }
     if (threadIdx.x < SAT_NPROF) { st->prof_sum[threadIdx.x] = 0.0; st->prof_n[threadIdx.x] = 0; }
 }
@@ -103,39 +112,6 @@ __global__ __launch_bounds__(256) void k_clip_update(sat_state* st, const double
     if (hi < st->hi) st->hi = hi;
 }
 
-// edge pixels -> compact list.  Hits are staged in LDS and flushed with one global atomic
-// per block and flush (a single global counter hammered per wave serialises badly).
-#define EDGE_STAGE 2048
-__global__ __launch_bounds__(256) void k_edge_compact(const float* __restrict__ b, size_t n, const sat_state* __restrict__ st,
-                                                      uint32_t* list, int32_t* cnt, uint32_t cap, int32_t* err) {
-    __shared__ uint32_t stage[EDGE_STAGE];
-    __shared__ unsigned scnt, sbase;
-    const double t0 = st->mean + 3.0 * st->std, t1 = st->mean + 50.0 * st->std;
-    if (threadIdx.x == 0) scnt = 0;
-    __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t nend = ((n + stride - 1) / stride) * stride;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nend; i += stride) {
-        bool hit = false;
-        if (i < n) { const double x = (double)b[i]; hit = (x > t0 && x < t1); }
-        if (hit) { const unsigned k = atomicAdd(&scnt, 1u); stage[k] = (uint32_t)i; }      // <= 256 per round, room checked below
-        __syncthreads();
-        const unsigned c = scnt;
-        const bool last = (i + stride >= nend);
-        if (c + 256 > EDGE_STAGE || last) {
-            if (threadIdx.x == 0) sbase = c ? atomicAdd((unsigned*)cnt, c) : 0u;
-            __syncthreads();
-            for (unsigned k = threadIdx.x; k < c; k += blockDim.x) {
-                const unsigned pos = sbase + k;
-                if (pos < cap) list[pos] = stage[k]; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) scnt = 0;
-        }
-        __syncthreads();
-    }
-}
-
 // Hough votes: one block per angle keeps the rho histogram of that angle in LDS and reports
 // only its best cell -- no global accumulator.  Order of the edge list does not matter.
 __global__ __launch_bounds__(1024) void k_hough_lds(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, uint32_t cap,
@@ -150,7 +126,8 @@ __global__ __launch_bounds__(1024) void k_hough_lds(const uint32_t* __restrict__
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         const uint32_t p = list[e];
         const double y = (double)(p / nxb), x = (double)(p % nxb);
-        atomicAdd(&hist[(int)floor(x * c + y * s + 0.5) + off], 1u);
+        const double r = c * x + s * y;
+        atomicAdd(&hist[(int)(r > 0.0 ? r + 0.5 : r - 0.5) + off], 1u);       // skimage.transform.hough_line: round half away from zero
     }
     __syncthreads();
     unsigned long long best = 0;
@@ -174,7 +151,15 @@ __device__ double chord_length(double c, double s, double rho, int ny, int nx) {
     return m < 2 ? 0.0 : best;
 }
 
-__global__ void k_trail_decide(sat_state* st, const double* __restrict__ cs, int nrho, int nyb, int nxb) {
+__device__ __forceinline__ unsigned long long dkey(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+__global__ void k_trail_decide(sat_state* st, const double* __restrict__ cs, int nrho, int nyb, int nxb, int min_votes) {
     if (threadIdx.x != 0) return;
     const unsigned long long b = st->best;
     if (!b) return;
@@ -183,7 +168,84 @@ __global__ void k_trail_decide(sat_state* st, const double* __restrict__ cs, int
     const int k = (int)(flat / nrho), r = (int)(flat % nrho);
     st->k = k; st->votes = (int)votes; st->rho = (double)(r - nrho / 2); st->c = cs[2 * k]; st->s = cs[2 * k + 1];
     st->chord = chord_length(st->c, st->s, st->rho, nyb, nxb);
-    st->accept = (votes >= 200u && (double)votes >= 0.2 * st->chord) ? 1 : 0;
+    st->accept = (votes >= (unsigned)min_votes) ? 1 : 0;          // provisional: the support test follows
+    // where the line x c + y s = rho crosses the frame rectangle, as positions t = y c - x s along it
+    const double c = st->c, s = st->s, rho = st->rho;
+    double t0 = __builtin_huge_val(), t1 = -__builtin_huge_val(); int m = 0;
+    const double xs[2] = {0.0, nxb - 1.0}, ys[2] = {0.0, nyb - 1.0};
+    for (int i = 0; i < 2; i++) if (fabs(s) > 1e-12) { const double y = (rho - xs[i] * c) / s; if (y >= -1e-9 && y <= nyb - 1 + 1e-9) { const double t = y * c - xs[i] * s; t0 = fmin(t0, t); t1 = fmax(t1, t); m++; } }
+    for (int i = 0; i < 2; i++) if (fabs(c) > 1e-12) { const double x = (rho - ys[i] * s) / c; if (x >= -1e-9 && x <= nxb - 1 + 1e-9) { const double t = ys[i] * c - x * s; t0 = fmin(t0, t); t1 = fmax(t1, t); m++; } }
+    st->t0 = t0; st->t1 = t1;
+    if (m < 2) st->accept = 0;
+}
+
+// The best cell fixes the line to half a grid step (0.25 deg): refine it on the edge pixels inside a cone of that
+// opening -- least squares d = a + b t on 1/16-px fixed-point coordinates with integer sums (order-independent)
+#define SAT_TAN_HALF_STEP 0.004363350820701567
+// round 0: the cone around the cell's line; later rounds (tol > 0): the pixels within tol of the line fitted so far
+__global__ __launch_bounds__(256) void k_trail_cone(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, uint32_t cap, int nxb,
+                                                    sat_state* st, double tol) {
+    if (!st->accept) return;
+    const uint32_t n = min((uint32_t)*cnt, cap);
+    const double c = st->c, s = st->s, rho = st->rho, tm = 0.5 * (st->t0 + st->t1), icpt = st->icpt, slope = st->slope;
+    long long a_n = 0, a_t = 0, a_d = 0, a_tt = 0, a_td = 0;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint32_t p = list[e];
+        const double y = (double)(p / nxb), x = (double)(p % nxb);
+        const double d = c * x + s * y - rho, t = y * c - x * s;
+        if (tol > 0.0 ? fabs(d - (icpt + slope * t)) <= tol : fabs(d) <= 1.5 + SAT_TAN_HALF_STEP * fabs(t - tm)) {
+            const long long tq = (long long)floor(t * 16.0 + 0.5), dq = (long long)floor(d * 16.0 + 0.5);
+            a_n++; a_t += tq; a_d += dq; a_tt += tq * tq; a_td += tq * dq;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a_n += __shfl_xor(a_n, o, 64); a_t += __shfl_xor(a_t, o, 64); a_d += __shfl_xor(a_d, o, 64);
+        a_tt += __shfl_xor(a_tt, o, 64); a_td += __shfl_xor(a_td, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && a_n) {
+        atomicAdd(&st->fit_n, (unsigned long long)a_n);
+        atomicAdd((unsigned long long*)&st->fit_t, (unsigned long long)a_t); atomicAdd((unsigned long long*)&st->fit_d, (unsigned long long)a_d);
+        atomicAdd((unsigned long long*)&st->fit_tt, (unsigned long long)a_tt); atomicAdd((unsigned long long*)&st->fit_td, (unsigned long long)a_td);
+    }
+}
+
+__global__ void k_trail_refine(sat_state* st) {
+    if (threadIdx.x != 0 || !st->accept) return;
+    if (st->fit_n < 2) { st->accept = 0; return; }
+    const double n = (double)st->fit_n;
+    const double mt = (double)st->fit_t / n, md = (double)st->fit_d / n;
+    const double var = (double)st->fit_tt / n - mt * mt, cov = (double)st->fit_td / n - mt * md;
+    const double slope = var > 0.0 ? cov / var : 0.0;
+    st->slope = slope;
+    st->icpt = (md - slope * mt) / 16.0;
+    st->fit_n = 0; st->fit_t = st->fit_d = st->fit_tt = st->fit_td = 0;      // for the next round
+}
+
+// extent along the line of the edge pixels within 1.5 px of the refined line
+__global__ __launch_bounds__(256) void k_trail_support(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, uint32_t cap, int nxb,
+                                                       sat_state* st) {
+    if (!st->accept) return;
+    const uint32_t n = min((uint32_t)*cnt, cap);
+    const double c = st->c, s = st->s, rho = st->rho, icpt = st->icpt, slope = st->slope;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint32_t p = list[e];
+        const double y = (double)(p / nxb), x = (double)(p % nxb);
+        const double d = c * x + s * y - rho, t = y * c - x * s;
+        if (fabs(d - (icpt + slope * t)) <= 1.5) { const unsigned long long k = dkey(t); lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64);
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && hi) { atomicMin(&st->tmin, lo); atomicMax(&st->tmax, hi); }
+}
+
+__global__ void k_trail_accept(sat_state* st, double buf) {
+    if (threadIdx.x != 0 || !st->accept) return;
+    if (!st->tmax) { st->accept = 0; return; }
+    const double tmin = dkey_inv(st->tmin), tmax = dkey_inv(st->tmax);
+    st->accept = (tmin - st->t0 <= buf && st->t1 - tmax <= buf) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_trail_profile(const float* __restrict__ b, int nyb, int nxb, sat_state* st) {
@@ -192,11 +254,12 @@ __global__ __launch_bounds__(256) void k_trail_profile(const float* __restrict__
     __shared__ unsigned long long lcnt[SAT_NPROF];
     for (int i = threadIdx.x; i < SAT_NPROF; i += blockDim.x) { lsum[i] = 0.0; lcnt[i] = 0; }
     __syncthreads();
-    const double c = st->c, s = st->s, rho = st->rho, t1 = st->mean + 50.0 * st->std;
+    const double c = st->c, s = st->s, rho = st->rho, t1 = st->mean + 50.0 * st->std, icpt = st->icpt, slope = st->slope;
     const size_t n = (size_t)nyb * nxb;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / nxb), x = (int)(i - (size_t)y * nxb);
-        const long long d = (long long)floor((double)x * c + (double)y * s - rho + 0.5);
+        const double dd = (double)x * c + (double)y * s - rho, tt = (double)y * c - (double)x * s;
+        const long long d = (long long)floor(dd - (icpt + slope * tt) + 0.5);
         if (d < -SAT_PROF_HALF || d > SAT_PROF_HALF) continue;
         const float f = b[i];
         if (!isfinite(f) || !((double)f < t1)) continue;
@@ -231,12 +294,14 @@ __global__ void k_trail_strip(sat_state* st) {
 
 __global__ __launch_bounds__(256) void k_trail_mask(uint8_t* mask, int ny, int nx, const sat_state* __restrict__ st) {
     if (!st->found) return;
-    const double c = st->c, s = st->s, rho = st->rho;
+    const double c = st->c, s = st->s, rho = st->rho, icpt = st->icpt, slope = st->slope;
     const int lo = st->lo_off, hi = st->hi_off;
     const size_t n = (size_t)ny * nx;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int Y = (int)(i / nx), X = (int)(i - (size_t)Y * nx);
-        const long long d = (long long)floor((double)(X >> 1) * c + (double)(Y >> 1) * s - rho + 0.5);
+        const double xb = (double)(X >> 1), yb = (double)(Y >> 1);
+        const double dd = xb * c + yb * s - rho, tt = yb * c - xb * s;
+        const long long d = (long long)floor(dd - (icpt + slope * tt) + 0.5);
         if (d >= lo && d <= hi) mask[i] |= BBX_MASK_SATELLITE;
     }
 }
@@ -250,42 +315,52 @@ __global__ void k_sat_info(const sat_state* __restrict__ st, float* info) {
 
 extern "C" int bbx_count_objects(bbx_ctx* ctx, int ny, int nx, const uint8_t* d_mask, int bit, int32_t* d_count, void* stream);
 
+int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const double* h_gauss, int radius, double low_frac, double high_frac,
+                    int min_size, uint32_t* d_out, int32_t* d_out_cnt, uint32_t out_cap, hipStream_t s);
+
 extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data, uint8_t* d_mask, const double* h_cos_sin,
-                              int ntheta, int32_t* d_nsats, float* d_info, void* stream) {
-    if (!ctx || !d_data || !d_mask || !h_cos_sin || !d_nsats || !d_info || ny < 4 || nx < 4 || (ny & 1) || (nx & 1) ||
+                              int ntheta, const double* h_gauss, int gauss_radius, int32_t* d_nsats, float* d_info, void* stream) {
+    if (!ctx || !d_data || !d_mask || !h_cos_sin || !h_gauss || !d_nsats || !d_info || ny < 8 || nx < 8 || (ny & 1) || (nx & 1) ||
         ntheta < 4 || ntheta > 4096 || ((uintptr_t)d_data) % 8)
         return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int nyb = ny / 2, nxb = nx / 2;
     const size_t nb = (size_t)nyb * nxb;
-    const int nrho = 2 * (int)ceil(hypot((double)nyb, (double)nxb)) + 1;
+    // skimage.transform.hough_line: offset = ceil(hypot(ny, nx)), 2 offset cells of one pixel
+    const int nrho = 2 * (int)ceil(sqrt((double)nyb * nyb + (double)nxb * nxb));
     int rc;
     const size_t cap = nb / 8 + 4096;
-    // workspace: binned frame | accumulator | edge list | cos/sin | partials | state
-    const size_t o_bin = 0, o_acc = o_bin + ((nb * 4 + 255) & ~(size_t)255), o_list = o_acc + (((size_t)ntheta * nrho * 4 + 255) & ~(size_t)255);
+    // workspace: binned frame | edge list | cos/sin | partials | state
+    const size_t o_bin = 0, o_list = o_bin + ((nb * 4 + 255) & ~(size_t)255);
     const size_t o_cs = o_list + ((cap * 4 + 255) & ~(size_t)255), o_part = o_cs + (((size_t)ntheta * 16 + 255) & ~(size_t)255);
     const size_t o_st = o_part + SAT_BLOCKS * 3 * 8, total = o_st + sizeof(sat_state) + 256;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, total, &rc); if (rc) return rc;
-    float* bin = (float*)(ws + o_bin); unsigned* acc = (unsigned*)(ws + o_acc); uint32_t* list = (uint32_t*)(ws + o_list);
+    float* bin = (float*)(ws + o_bin); uint32_t* list = (uint32_t*)(ws + o_list);
     double* cs = (double*)(ws + o_cs); double* partial = (double*)(ws + o_part); sat_state* st = (sat_state*)(ws + o_st);
-    int32_t* cnt = &ctx->d_counters[CNT_TMP];
+    int32_t* cnt = &ctx->d_counters[CNT_CAND];
     BBX_HIP(hipMemcpyAsync(cs, h_cos_sin, (size_t)ntheta * 16, hipMemcpyHostToDevice, s));
-    BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_sat_init, dim3(1), dim3(128), 0, s, st);
     hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin);
     for (int pass = 0; pass < 4; pass++) {
         hipLaunchKernelGGL(k_clip_pass, dim3(SAT_BLOCKS), dim3(256), 0, s, bin, nb, st, partial);
         hipLaunchKernelGGL(k_clip_update, dim3(1), dim3(256), 0, s, st, partial, SAT_BLOCKS);
     }
-    hipLaunchKernelGGL(k_edge_compact, dim3(2048), dim3(256), 0, s, bin, nb, st, list, cnt, (uint32_t)cap, ctx->d_err);
+    // acstools' front end: sigma = 3 (sat_detect), low_thresh = 0.1 (default), h_thresh = 0.2 (sat_detect), small_edge = 60
+    rc = bbx_canny_edges(ctx, bin, nyb, nxb, h_gauss, gauss_radius, 0.1, 0.2, 60, list, cnt, (uint32_t)cap, s); if (rc) return rc;
     if ((size_t)nrho * 4 <= 150 * 1024) {
         // rho histogram of one angle fits in LDS (frames up to ~26k binned pixels across)
         hipLaunchKernelGGL(k_hough_lds, dim3(ntheta), dim3(1024), (size_t)nrho * 4, s, list, cnt, (uint32_t)cap, nxb, cs, nrho, st);
     } else {
         return BBX_ERR_ARG;                                  // frame too large for the LDS histogram
     }
-    (void)acc;
-    hipLaunchKernelGGL(k_trail_decide, dim3(1), dim3(64), 0, s, st, cs, nrho, nyb, nxb);
+    hipLaunchKernelGGL(k_trail_decide, dim3(1), dim3(64), 0, s, st, cs, nrho, nyb, nxb, 210);    // the probabilistic transform's threshold
+    const double refine_tol[4] = {0.0, 3.0, 2.0, 1.5};                                          // oracle/sattrail.py REFINE_TOL
+    for (int it = 0; it < 4; it++) {
+        hipLaunchKernelGGL(k_trail_cone, dim3(256), dim3(256), 0, s, list, cnt, (uint32_t)cap, nxb, st, refine_tol[it]);
+        hipLaunchKernelGGL(k_trail_refine, dim3(1), dim3(64), 0, s, st);
+    }
+    hipLaunchKernelGGL(k_trail_support, dim3(256), dim3(256), 0, s, list, cnt, (uint32_t)cap, nxb, st);
+    hipLaunchKernelGGL(k_trail_accept, dim3(1), dim3(64), 0, s, st, 40.0);                       // buf = 40 (sat_detect)
     hipLaunchKernelGGL(k_trail_profile, dim3(2048), dim3(256), 0, s, bin, nyb, nxb, st);
     hipLaunchKernelGGL(k_trail_strip, dim3(1), dim3(64), 0, s, st);
     hipLaunchKernelGGL(k_trail_mask, dim3(2048), dim3(256), 0, s, d_mask, ny, nx, st);

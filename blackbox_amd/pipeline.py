@@ -530,7 +530,8 @@ class FramePipeline:
             try:
                 d_nsats = sl['d_nsats']
                 check(lib.bbx_sat_trails(ctx.h, data.shape[0], data.shape[1], R._ptr(data), R._ptr(mask), R.sat_cos_sin(),
-                                         R.NTHETA_SAT, R._ptr(d_nsats), R._ptr(sl['d_info']), sp), 'bbx_sat_trails', ctx.h)
+                                         R.NTHETA_SAT, *R.sat_gauss_weights(), R._ptr(d_nsats), R._ptr(sl['d_info']), sp),
+                      'bbx_sat_trails', ctx.h)
                 h['SAT-P'] = (True, 'processed for satellite trails?')
             except _lib.BBXError:
                 d_nsats = None

@@ -388,8 +388,9 @@ def nonlin_corr(ctx, data, geom, tel, splines=None):
     return data
 
 
-NTHETA_SAT = 720
-
+SAT_THETA_DEG = np.arange(2, 178, 0.5, dtype=float)      # acstools.satdet: np.radians(np.arange(2, 178, 0.5))
+NTHETA_SAT = SAT_THETA_DEG.size
+SAT_SIGMA = 3.0                                           # sat_detect: detsat(..., sigma=3, ...)
 
 _SAT_CS = None
 
@@ -398,11 +399,27 @@ def sat_cos_sin():
     """cos / sin table of the Hough angles (float64), shared by the device code and the oracle"""
     global _SAT_CS
     if _SAT_CS is None:
-        th = np.arange(NTHETA_SAT) * (np.pi / NTHETA_SAT)
+        th = np.radians(SAT_THETA_DEG)
         cs = np.empty(2 * NTHETA_SAT)
         cs[0::2], cs[1::2] = np.cos(th), np.sin(th)
         _SAT_CS = (cs, cs.ctypes.data_as(C.POINTER(C.c_double)))
     return _SAT_CS[1]
+
+
+_SAT_GW = None
+
+
+def sat_gauss_weights():
+    """scipy.ndimage's Gaussian kernel for Canny's sigma, centre first: radius int(4 sigma + 0.5),
+    exp(-0.5 / sigma^2 x^2) normalised by its sum over -radius .. radius (float64) -> (pointer, radius)"""
+    global _SAT_GW
+    if _SAT_GW is None:
+        r = int(4.0 * SAT_SIGMA + 0.5)
+        x = np.arange(-r, r + 1)
+        w = np.exp(-0.5 / (SAT_SIGMA * SAT_SIGMA) * x ** 2)
+        w = np.ascontiguousarray((w / w.sum())[r:])
+        _SAT_GW = (w, w.ctypes.data_as(C.POINTER(C.c_double)), r)
+    return _SAT_GW[1], _SAT_GW[2]
 
 
 def sat_detect(ctx, data, header, data_mask, header_mask):
@@ -413,8 +430,9 @@ def sat_detect(ctx, data, header, data_mask, header_mask):
     _expect(data_mask, torch.uint8, (ny, nx), 'data_mask')
     d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
     d_info = torch.zeros(8, dtype=torch.float32, device=ctx.device)
+    gw, gr = sat_gauss_weights()
     check(lib.bbx_sat_trails(ctx.h, ny, nx, _ptr(data), _ptr(data_mask), sat_cos_sin(),
-                             NTHETA_SAT, _ptr(d_n), _ptr(d_info), ctx.stream()), 'bbx_sat_trails', ctx.h)
+                             NTHETA_SAT, gw, gr, _ptr(d_n), _ptr(d_info), ctx.stream()), 'bbx_sat_trails', ctx.h)
     return d_n, d_info
 
 

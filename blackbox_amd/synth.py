@@ -327,3 +327,27 @@ def clip_points(seed=21):
     _, first = np.unique(key, return_index=True)
     first.sort()
     return x[first], y[first], n[first], (ny, nx)
+
+
+# ---- a12: binned frames for the satellite-trail front end (skimage fixtures, oracle, HIP) ---------
+SAT_SCENES = {'trail': dict(seed=1, ny=256, nx=320, trail=(0.5, 200.0, 150.0, 1.5)),
+              'faint': dict(seed=2, ny=300, nx=280, trail=(2.3, -60.0, 60.0, 2.0)),
+              'none': dict(seed=3, ny=200, nx=360, trail=None)}
+
+
+def sat_scene(name):
+    """a 2x2-binned frame (float32, e-): sky + noise, 25 Gaussian stars of 10^3..10^5.5 e-, optionally a
+    trail (theta [rad], rho [px], amplitude [e-], sigma [px]) x cos(theta) + y sin(theta) = rho"""
+    p = SAT_SCENES[name]
+    rs = np.random.RandomState(p['seed'])
+    ny, nx = p['ny'], p['nx']
+    b = (1000 + 30 * rs.standard_normal((ny, nx))).astype(np.float32)
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    for _ in range(25):
+        cy, cx, fl = rs.uniform(0, ny), rs.uniform(0, nx), 10 ** rs.uniform(3, 5.5)
+        b += (fl / (2 * np.pi * 4) * np.exp(-0.5 * ((yy - cy) ** 2 + (xx - cx) ** 2) / 4)).astype(np.float32)
+    if p['trail'] is not None:
+        th, rho, amp, sig = p['trail']
+        d = xx * np.cos(th) + yy * np.sin(th) - rho
+        b += (amp * np.exp(-0.5 * (d / sig) ** 2)).astype(np.float32)
+    return b

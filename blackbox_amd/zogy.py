@@ -103,7 +103,7 @@ def _device_taps(ctx, nby, nbx, box, cy, cx):
     cache = ctx.__dict__.setdefault('_zoom_taps', {})
     key = (nby, nbx, box, cy, cx)
     if key not in cache:
-        cache[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device) for a in _tap_tables(*key))
+        cache[key] = tuple(torch.from_numpy(np.array(a)).to(ctx.device) for a in _tap_tables(*key))      # (writable copies)
     return cache[key]
 
 

@@ -366,16 +366,30 @@ int bbx_median_stack(bbx_ctx *ctx, int64_t npix, int nframes, const float *const
                      float *d_out, void *stream);
 
 /* ---- a12: satellite trails (sat_detect, blackbox.py:4163-4254) ------------------------------
- * [EXT / unpinnable: acstools' probabilistic Hough is random, ASTA is a CNN; the deterministic
- * detector is specified in oracle/sattrail.py]  2x2 sum binning, clipped level/sigma, edge
- * pixels, full Hough accumulator over ntheta angles (h_cos_sin[2*k], [2*k+1] = cos, sin of
- * theta_k, float64, supplied by the host so that both sides use the same table), strongest line
- * with >= 200 votes and >= 0.2 x chord, perpendicular profile, strip -> bit 16 in d_mask.
+ * The reference calls acstools.satdet.detsat(buf=40, sigma=3, h_thresh=0.2) + make_mask(sigma=5)
+ * [EXT: acstools is not in the image; its probabilistic Hough transform draws random pixels, ASTA
+ * is a CNN without weights].  Specified in oracle/sattrail.py: 2x2 sum binning; acstools' front end
+ * (percentile (4.5, 93) rescale, skimage Canny sigma 3 with thresholds 0.1 / 0.2 of the maximum,
+ * remove_small_objects(60): pinned against scikit-image); full Hough accumulator over ntheta angles
+ * with skimage.transform.hough_line's cells (h_cos_sin[2*k], [2*k+1] = cos, sin of theta_k, float64,
+ * supplied by the host so that both sides use the same table; acstools' grid is 2 .. 177.5 deg in
+ * half-degree steps); strongest line with >= 210 votes whose supporting edge pixels reach within
+ * 40 px of both frame borders; perpendicular profile, strip -> bit 16 in d_mask.
+ *  h_gauss [gauss_radius + 1] : scipy.ndimage's Gaussian weights for sigma = 3, centre first
+ *                               (radius int(4 sigma + 0.5) = 12), float64, from the host like the angles.
  *  d_nsats [1] i32 : 8-connected objects of bit 16 (NSATS).
  *  d_info [8] f32  : level, sigma, votes, theta index, rho, strip lo, strip hi, found.     */
 int bbx_sat_trails(bbx_ctx *ctx, int ny, int nx, const float *d_data, uint8_t *d_mask,
-                   const double *h_cos_sin, int ntheta, int32_t *d_nsats, float *d_info,
-                   void *stream);
+                   const double *h_cos_sin, int ntheta, const double *h_gauss, int gauss_radius,
+                   int32_t *d_nsats, float *d_info, void *stream);
+
+/* bbx_canny_edge_map: the front end of bbx_sat_trails on its own (parity tests against scikit-image):
+ * np.percentile(img, (4.5, 93)) + skimage.exposure.rescale_intensity + skimage.feature.canny(sigma from
+ * h_gauss, low / high = low_frac / high_frac x the rescaled maximum) + remove_small_objects(min_size,
+ * connectivity 8) of a float32 image -> d_map [ny*nx] u8 (1 = edge), *d_count = number of edge pixels. */
+int bbx_canny_edge_map(bbx_ctx *ctx, int ny, int nx, const float *d_img, const double *h_gauss,
+                       int gauss_radius, double low_frac, double high_frac, int min_size,
+                       uint8_t *d_map, int32_t *d_count, void *stream);
 
 /* ---- a15: background mesh (zogy.get_back / mini2back; buildref.py:2398-2405, 2480-2495) ----
  * [EXT algorithm: conventions in oracle/zogy_core.py]
