@@ -189,6 +189,42 @@ int64_t bbx_polyfit_prep(const double *restrict V, const uint8_t *restrict mask,
 typedef int (*bbx_lstsq_fn)(const double *lhs, int64_t m, int order, const double *rhs, double rcond, double *coef,
                             int *rank);
 
+/* The same solve without the trip through the interpreter: LAPACK's dgelsd of the BLAS that numpy itself is
+ * linked with (ILP64 build: scipy_dgelsd_64_), called the way numpy's umath_linalg does -- column-major copy of the
+ * left-hand side, ldb = max(m, n), workspace sizes from a query call -- so that the same routine sees the same
+ * numbers with the same block sizes.  The host installs the entry point (bbx_host_set_dgelsd); without it the
+ * callback is used. */
+typedef void (*bbx_dgelsd_fn)(int64_t *m, int64_t *n, int64_t *nrhs, double *a, int64_t *lda, double *b, int64_t *ldb,
+                              double *s, double *rcond, int64_t *rank, double *work, int64_t *lwork, int64_t *iwork,
+                              int64_t *info);
+static bbx_dgelsd_fn g_dgelsd = 0;
+void bbx_host_set_dgelsd(void *fn) { g_dgelsd = (bbx_dgelsd_fn)fn; }
+int bbx_host_has_dgelsd(void) { return g_dgelsd != 0; }
+
+int bbx_lstsq_direct(const double *lhs, int64_t m, int order, const double *rhs, double rcond, double *coef, int *rank) {
+    if (!g_dgelsd || m < 1 || order < 1) return 1;
+    int64_t mm = m, n = order, nrhs = 1, lda = m, ldb = m > n ? m : n, rk = 0, info = 0, lwork = -1, iwq = 0;
+    double wq = 0.0, sdummy[16], rc = rcond;
+    double *a = (double *)malloc(((size_t)m * order + (size_t)ldb) * sizeof(double));
+    if (!a) return 1;
+    double *b = a + (size_t)m * order;
+    for (int j = 0; j < order; j++)
+        for (int64_t i = 0; i < m; i++) a[(size_t)j * m + i] = lhs[(size_t)i * order + j];
+    for (int64_t i = 0; i < ldb; i++) b[i] = i < m ? rhs[i] : 0.0;
+    g_dgelsd(&mm, &n, &nrhs, a, &lda, b, &ldb, sdummy, &rc, &rk, &wq, &lwork, &iwq, &info);
+    if (info != 0) { free(a); return 1; }
+    lwork = (int64_t)wq;
+    const int64_t liwork = iwq > 1 ? iwq : 1;
+    double *work = (double *)malloc((size_t)(lwork > 1 ? lwork : 1) * sizeof(double) + (size_t)liwork * sizeof(int64_t));
+    if (!work) { free(a); return 1; }
+    int64_t *iwork = (int64_t *)(work + (lwork > 1 ? lwork : 1));
+    g_dgelsd(&mm, &n, &nrhs, a, &lda, b, &ldb, sdummy, &rc, &rk, work, &lwork, iwork, &info);
+    const int ok = info == 0;
+    if (ok) { for (int j = 0; j < order; j++) coef[j] = b[j]; *rank = (int)rk; }
+    free(work); free(a);
+    return ok ? 0 : 1;
+}
+
 /* numpy's pairwise summation of a contiguous float64 vector (np.add.reduce: blocks of 128 with
  * eight accumulators, halves split at a multiple of 8) */
 static double pairwise_sum(const double *a, int64_t n) {
@@ -239,7 +275,7 @@ static int polyfit_masked(const double *V, const uint8_t *mask, int64_t n, int o
     int64_t k = 0;
     for (int64_t i = 0; i < n; i++) if (mask[i]) rhs[k++] = yfull[i] + 0.0;
     const double rcond = (double)m * 2.220446049250313e-16;
-    if (lstsq(lhs, m, order, rhs, rcond, coef, rank) != 0) return 2;
+    if ((lstsq ? lstsq(lhs, m, order, rhs, rcond, coef, rank) : bbx_lstsq_direct(lhs, m, order, rhs, rcond, coef, rank)) != 0) return 2;
     for (int j = 0; j < order; j++) coef[j] = coef[j] / scale[j];
     return 0;
 }

@@ -36,11 +36,40 @@ try:
     _HOST.bbx_channel_solve_ml1.argtypes = ([_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_int, _C.c_int,
                                              _C.c_int, _C.c_int, _C.c_double, _C.c_void_p, _C.c_void_p, _C.c_void_p]
                                             + [_C.c_void_p] * 5)
+    _HOST.bbx_lstsq_direct.restype = _C.c_int
+    _HOST.bbx_lstsq_direct.argtypes = [_C.c_void_p, _C.c_int64, _C.c_int, _C.c_void_p, _C.c_double, _C.c_void_p, _C.c_void_p]
+    _HOST.bbx_host_set_dgelsd.argtypes = [_C.c_void_p]
     _HOST.bbx_polyfit_prep.restype = _C.c_int64
     _HOST.bbx_polyfit_prep.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_int, _C.c_void_p, _C.c_void_p]
 except OSError:
     _HOST = None
 
+
+def _install_numpy_lapack():
+    """hand the C driver the dgelsd of the BLAS numpy itself is linked with (the ILP64 OpenBLAS that the
+    numpy wheels bundle: `scipy_dgelsd_64_`), so that np.linalg.lstsq's arithmetic is reached without
+    the interpreter; any other numpy build keeps the callback (same results, slower)"""
+    if _HOST is None:
+        return False
+    try:
+        import glob
+        import numpy.linalg._umath_linalg                       # noqa: F401  (makes sure the library is mapped)
+        libs = glob.glob(_os.path.join(_os.path.dirname(_os.path.dirname(np.__file__)), 'numpy.libs', 'libscipy_openblas64_*.so'))
+        if len(libs) != 1:
+            return False
+        blas = _C.CDLL(libs[0])                                  # already mapped by numpy: the same instance
+        fn = _C.cast(blas.scipy_dgelsd_64_, _C.c_void_p).value
+        if not fn:
+            return False
+        _HOST.bbx_host_set_dgelsd(fn)
+        return True
+    except (OSError, AttributeError, ImportError):
+        return False
+
+
+DIRECT_LAPACK = _install_numpy_lapack()
+
+USE_DIRECT_LAPACK = True   # the C driver calls numpy's own dgelsd itself instead of np.linalg.lstsq through a callback
 USE_C_DRIVER = True   # channel_solve through libbbx_host.so (bit-identical; tests switch it off to compare)
 IDX_SWITCH = 150      # blackbox.py:6683
 OVERLAP = 30          # blackbox.py:6684
@@ -425,7 +454,8 @@ def _channel_solve_c(c, mean_vos_col, hos, ysz, xsz, poldeg, data_limit):
     level, dlevel = _C.c_double(), _C.c_double()
     rc = _HOST.bbx_channel_solve_ml1(c, col.ctypes.data, dy, h.ctypes.data, hos_rows, dx, ysz, xsz, poldeg, float(data_limit),
                                      _vander_full(0, dy, poldeg + 1).ctypes.data, _vander_full(1, xsz, 8).ctypes.data,
-                                     _LSTSQ_CB, fit.ctypes.data, coeffs.ctypes.data, _C.addressof(level),
+                                     None if (DIRECT_LAPACK and USE_DIRECT_LAPACK) else _LSTSQ_CB, fit.ctypes.data, coeffs.ctypes.data,
+                                     _C.addressof(level),
                                      _C.addressof(dlevel), oscan.ctypes.data)
     if rc < 0:
         raise MemoryError('bbx_channel_solve_ml1')

@@ -175,3 +175,41 @@ def test_c_driver_equals_numpy_path():
     both(a)
     a = _channel_case(5, 0); a[1][:] = 1000.0
     both(a)
+
+
+@pytest.mark.skipif(overscan._HOST is None or not overscan.DIRECT_LAPACK, reason='numpy\'s bundled LAPACK not found')
+def test_direct_lapack_equals_numpy_lstsq():
+    """bbx_lstsq_direct (dgelsd of numpy's own BLAS, called like numpy's umath_linalg) == np.linalg.lstsq bit
+    for bit: tall and small systems, the scaled Vandermonde matrices of the overscan fits, a rank-deficient
+    one; and the C driver gives the same channel solution with the direct call as with the callback"""
+    import ctypes as C
+    rs = np.random.RandomState(0)
+    cases = []
+    for (m, n) in ((5300, 4), (1320, 8), (180, 8), (40, 4), (9, 8), (8, 8)):
+        x = np.linspace(-1, 1, m)
+        A = np.vander(x, n) / np.sqrt((np.vander(x, n) ** 2).sum(0))
+        cases.append((np.ascontiguousarray(A), rs.normal(1000, 5, m)))
+    A = rs.normal(0, 1, (50, 6)); A[:, 5] = A[:, 4]                 # rank 5
+    cases.append((A, rs.normal(0, 1, 50)))
+    for A, b in cases:
+        m, n = A.shape
+        rcond = m * np.finfo(float).eps
+        want, _, rank, _ = np.linalg.lstsq(A, b, rcond)
+        coef = np.empty(n); rk = C.c_int()
+        assert overscan._HOST.bbx_lstsq_direct(A.ctypes.data, m, n, b.ctypes.data, rcond, coef.ctypes.data, C.addressof(rk)) == 0
+        assert rk.value == rank
+        assert np.array_equal(coef, want), (m, n, np.abs(coef - want).max())
+    for seed in range(6):
+        a = _channel_case(seed, (3 * seed) % 16, dy=5300, dx=1500, ysz=5280, xsz=1320)
+        overscan.USE_DIRECT_LAPACK = True
+        try:
+            r1 = overscan._channel_solve_c(a[0], a[1], a[2], a[3], a[4], a[5], a[7])
+        finally:
+            overscan.USE_DIRECT_LAPACK = False
+        try:
+            r2 = overscan._channel_solve_c(a[0], a[1], a[2], a[3], a[4], a[5], a[7])
+        finally:
+            overscan.USE_DIRECT_LAPACK = True
+        assert r1 is not None and r2 is not None
+        for k in r2:
+            assert np.array_equal(np.asarray(r1[k]), np.asarray(r2[k]), equal_nan=True), k
