@@ -273,6 +273,11 @@ class FramePipeline:
         self.do_cosmics, self.do_finish, self.accum = do_cosmics, do_finish, accum
         self.detect_sats = detect_sats and bool(get_par(settings.detect_sats, tel))
         self.subtract = dict(subtract) if subtract else None
+        # one lane at a time inside bbx_zogy_frame (BBX_ZOGY_GATE=0 switches the gate off)
+        self.zogy_gate = None
+        if self.subtract and os.environ.get('BBX_ZOGY_GATE', '1') != '0':
+            from . import zogy as G
+            self.zogy_gate = G.StreamGate()
         self.keep_sub = ('D', 'Scorr', 'Fpsf', 'Fpsferr')        # device products kept on the frame when keep_outputs
         self.log = log
         self.keep_outputs = keep_outputs
@@ -545,7 +550,7 @@ class FramePipeline:
         if self.subtract is not None:
             from . import zogy as G
             try:
-                sub = G.optimal_subtraction(ctx, data, new_mask=mask, **self.subtract)
+                sub = G.optimal_subtraction(ctx, data, new_mask=mask, zogy_gate=self.zogy_gate, **self.subtract)
                 if not self.keep_outputs:
                     for k in list(sub):
                         if torch.is_tensor(sub[k]):

@@ -336,10 +336,43 @@ def frame_clipped_stats(ctx, img, mask=None, step=8):
     return float(st[1]), float(st[3])
 
 
+class StreamGate:
+    """Lets one stream at a time run a section on the GPU: a section starts when the previous one (of any
+    stream) has finished.  bbx_zogy_frame's kernels each fill the whole GPU; two lanes running them side
+    by side only slice each other's time."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.last = None
+
+    def __enter__(self):
+        self.lock.acquire()
+        if self.last is not None:
+            torch.cuda.current_stream().wait_event(self.last)
+        return self
+
+    def __exit__(self, *exc):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.last = ev
+        self.lock.release()
+        return False
+
+
+class _NoGate:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fratio=1.0, dx=0.0, dy=0.0,
                         subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None,
                         ref_is_bkgsub=False, ref_bkg_std_mini=None, ref_grid=None, ref_grid_step=32,
-                        cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000):
+                        cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000,
+                        zogy_gate=None):
     """The numerical core of zogy.optimal_subtraction(new_fits, ref_fits, ...) (call sites
     blackbox.py:2350-2354 new-only, 2460-2465 new + ref) on device tensors: background mesh +
     subtraction, variance images, [remapping of the reference to the new frame's grid],
@@ -455,7 +488,8 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
     if frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]:
         # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
-        D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border)
+        with (zogy_gate or _NoGate()):
+            D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border)
         res['D'], res['Scorr'], res['Fpsf'], res['Fpsferr'] = D, Scorr, Fpsf, Fpsferr
     else:
         Vn = Vn if Vn is not None else variance(ctx, work, bstd)
