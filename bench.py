@@ -463,8 +463,8 @@ def main():
             # k_final_rows: reads the four column-transformed half spectra (D, V_S, S_n, S_r), writes D, Scorr, Fpsf, Fpsferr
             'k_final_rows': (7, 4 * spec + 4 * 4 * N),
             # the other kernels of bbx_zogy_frame together: k_psf_cols 6 spec, k_psf_rows 4,
-            # k_cols_fwd 2 x 2, k_img_rows 2 x 2 + the six frame cuts, k_img_cols 9, k_var_cols 5
-            'zogy_frame_other': (6, int(32 * spec + 6 * cut)),
+            # k_img_rows 2 x 2 + the six frame cuts, k_img_cols 9, k_var_cols 5
+            'zogy_frame_other': (6, int(28 * spec + 6 * cut)),
         }
         zogy_io_model = int(4 * 4 * nsub * L * L + 4 * 4 * N)     # 4 inputs read with the tile overlap, 4 outputs written
         iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items() if iso_calls[sl]}
@@ -487,9 +487,9 @@ def main():
             zms = iso['k_final_rows'][0] + iso['zogy_frame_other'][0]
             roof['zogy_stage'] = dict(ms_alone=zms, io_model_bytes=zogy_io_model, achieved=zogy_io_model / (zms * 1e-3) / 1e9,
                                       frac=zogy_io_model / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      moved_bytes_by_design=int(36 * spec + 6 * cut + 16 * N),
+                                      moved_bytes_by_design=int(32 * spec + 6 * cut + 16 * N),
                                       note='SURVEY 8d I/O-only model (3.79 GB) over the whole bbx_zogy_frame call; the design moves '
-                                           '36 half-spectrum passes + 6 frame cuts + 4 outputs (DESIGN.md section 4)')
+                                           '32 half-spectrum passes + 6 frame cuts + 4 outputs (DESIGN.md section 4)')
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))['kernels']
             if not args.small and args.raw == 'u16' and dom in pmc:

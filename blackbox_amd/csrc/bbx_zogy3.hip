@@ -619,10 +619,12 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     store_u<P>(s, UD, sub, g);
 }
 
-// column pass of the variance pair: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^ and back (U tiles)
+// column pass of the variance pair: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^ and back (U tiles).  The spectra (kn^2)^, (kr^2)^
+// get their column pass here as well (their row pass is k_psf_rows): a workgroup needs exactly its own column group
+// of them, so they go from the T tiles through the transform into registers and never to HBM as coefficient arrays.
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ cK2n,
-                                                         const float2* __restrict__ cK2r, const float2* __restrict__ twg,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ Tk2n,
+                                                         const float2* __restrict__ Tk2r, const float2* __restrict__ twg,
                                                          float2* __restrict__ UVS, const zscal* __restrict__ sc,
                                                          const double* __restrict__ fs_partial, int nsub) {
     extern __shared__ float2 s[];
@@ -631,13 +633,22 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* 
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, nsub, sub, sc[sub]);
-    const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
+    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    float2 park[NE], coef[NE];
+    load_t_lines<P>(Tk2n, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kn^2)^
+    __syncthreads();
     load_t_lines<P>(TVn, sub, g, s);
     __syncthreads();
     fft_fwd<P>(s, tw);
-    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
-    float2 park[NE];
-    R_LOOP(k, e, l, p) park[k] = cmul(cK2n[cbase + e], s[l * P::LS + npos(p)]);
+    R_LOOP(k, e, l, p) park[k] = cmul(coef[k], s[l * P::LS + npos(p)]);
+    __syncthreads();
+    load_t_lines<P>(Tk2r, sub, g, s);
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kr^2)^
     __syncthreads();
     load_t_lines<P>(TVr, sub, g, s);
     __syncthreads();
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* 
     const float beta = s_beta;
     R_LOOP(k, e, l, p) {
         float2* q = s + l * P::LS + npos(p);
-        const float2 v = cmul(cK2r[cbase + e], *q);
+        const float2 v = cmul(coef[k], *q);
         *q = make_float2((park[k].x + v.x) * beta, (park[k].y + v.y) * beta);
     }
     __syncthreads();
@@ -804,16 +815,15 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     const float2* tw = d_tw;
     bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
     hipLaunchKernelGGL(k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub);
-    hipLaunchKernelGGL(k_psf_rows<P>, grow, blk, lds, s, U1, U0, inv_n2, tw, T0, T1, nsub);
-    hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T0, tw, cK2r, nsub);
-    hipLaunchKernelGGL(k_cols_fwd<P>, gcol, blk, lds, s, T1, tw, cK2n, nsub);
+    float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
+    hipLaunchKernelGGL(k_psf_rows<P>, grow, blk, lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T0, T1, nsub);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3, nsub);
     hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
-    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, cK2n, cK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
+    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
