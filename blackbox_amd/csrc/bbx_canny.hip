@@ -137,17 +137,7 @@ __global__ void k_canny_params(canny_par* p, size_t n, double q1, double q2, dou
     p->low = (double)immax * low_frac; p->high = (double)immax * high_frac;
 }
 
-__global__ __launch_bounds__(256) void k_canny_rescale(const float* __restrict__ b, size_t n, const canny_par* __restrict__ p,
-                                                       float* __restrict__ img) {
-    const float p1 = p->p1f, p2 = p->p2f, den = p->den;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = b[i];
-        const float c = fminf(fmaxf(x, p1), p2);                  // np.clip
-        img[i] = (c - p1) / den;
-    }
-}
-
-// Gaussian along y: a thread produces RY consecutive rows of one column from a register window (x across lanes)
+// rescale + Gaussian along y: a thread produces RY consecutive rows of one column from a register window (x across lanes)
 #define GV_RY 16
 template <int R>
 __global__ __launch_bounds__(256) void k_canny_gauss_v(const float* __restrict__ img, int ny, int nx, const canny_par* __restrict__ p,
@@ -157,11 +147,13 @@ __global__ __launch_bounds__(256) void k_canny_gauss_v(const float* __restrict__
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; j++) w[j] = p->w[j];
+    const float p1 = p->p1f, p2 = p->p2f, den = p->den;
     double in[GV_RY + 2 * R];
 #pragma unroll
     for (int k = 0; k < GV_RY + 2 * R; k++) {
         const int y = y0 - R + k;
-        in[k] = (y >= 0 && y < ny) ? (double)img[(size_t)y * nx + x] : 0.0;
+        // the rescaled pixel (float32: np.clip, subtract, divide), zero outside the frame
+        in[k] = (y >= 0 && y < ny) ? (double)((fminf(fmaxf(img[(size_t)y * nx + x], p1), p2) - p1) / den) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < GV_RY; r++) {
@@ -214,60 +206,71 @@ __global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__
 //   the clamped loads below); magnitude sqrt(i^2 + j^2)
 #define CT_X 64
 #define CT_Y 16
+#define CT_NT 8                                            // tiles (stacked in y) per workgroup: one list reservation for all of them
+#define CT_Q 2048                                          // (every workgroup's returning atomic on the one list counter costs ~11 ns)
 __global__ __launch_bounds__(256) void k_canny_tile(const double* __restrict__ sm, int ny, int nx, const canny_par* __restrict__ p,
                                                     uint32_t* list, uint8_t* hflag, int32_t* cnt, uint32_t cap, int32_t* err) {
     __shared__ double s_sm[CT_Y + 4][CT_X + 4];
     __shared__ double s_mag[CT_Y + 2][CT_X + 2];
-    __shared__ uint32_t q[CT_X * CT_Y];
+    __shared__ uint32_t q[CT_Q];
     __shared__ unsigned qn, gbase;
-    const int tid = threadIdx.x, x0 = blockIdx.x * CT_X, y0 = blockIdx.y * CT_Y;
+    const int tid = threadIdx.x, x0 = blockIdx.x * CT_X;
     if (tid == 0) qn = 0;
-    for (int i = tid; i < (CT_Y + 4) * (CT_X + 4); i += 256) {
-        const int r = i / (CT_X + 4), c = i - r * (CT_X + 4);
-        const int yy = min(max(y0 - 2 + r, 0), ny - 1), xx = min(max(x0 - 2 + c, 0), nx - 1);
-        s_sm[r][c] = sm[(size_t)yy * nx + xx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (CT_Y + 2) * (CT_X + 2); i += 256) {
-        const int r = i / (CT_X + 2), c = i - r * (CT_X + 2);           // image position (y0 - 1 + r, x0 - 1 + c)
-        const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
-        const double js = d1 * 2.0 + (d0 + d2);
-        const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
-        const double is = e1 * 2.0 + (e0 + e2);
-        s_mag[r][c] = sqrt(is * is + js * js);
-    }
-    __syncthreads();
     const double low = p->low, high = p->high;
     const bool live = !p->degenerate;
-    for (int i = tid; i < CT_X * CT_Y; i += 256) {
-        const int ty = i / CT_X, tx = i - ty * CT_X, y = y0 + ty, x = x0 + tx;
-        if (!live || y < 1 || y > ny - 2 || x < 1 || x > nx - 2) continue;      // binary_erosion of the all-ones mask
-        const int r = ty + 1, c = tx + 1;                                      // in s_mag; s_sm centre is [r + 1][c + 1]
-        const double m = s_mag[r][c];
-        if (!(m > 0.0 && m >= low)) continue;
-        const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
-        const double js = d1 * 2.0 + (d0 + d2);
-        const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
-        const double is = e1 * 2.0 + (e0 + e2);
-        const double ai = fabs(is), aj = fabs(js);
-        const bool same = (is >= 0 && js >= 0) || (is <= 0 && js <= 0), opp = (is <= 0 && js >= 0) || (is >= 0 && js <= 0);
-        const double* mu = s_mag[r - 1]; const double* mc = s_mag[r]; const double* md = s_mag[r + 1];
-        bool loc = false;
-        // c2 w + c1 (1 - w) <= m on both sides of the gradient direction; later sectors overwrite earlier ones
-        if (same && ai >= aj) { const double w = aj / ai; loc = (md[c + 1] * w + md[c] * (1 - w) <= m) && (mu[c - 1] * w + mu[c] * (1 - w) <= m); }
-        if (same && ai <= aj) { const double w = ai / aj; loc = (md[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (mu[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
-        if (opp && ai <= aj) { const double w = ai / aj; loc = (mu[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (md[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
-        if (opp && ai >= aj) { const double w = aj / ai; loc = (mu[c + 1] * w + mu[c] * (1 - w) <= m) && (md[c - 1] * w + md[c] * (1 - w) <= m); }
-        if (loc) { const unsigned k = atomicAdd(&qn, 1u); q[k] = (uint32_t)((size_t)y * nx + x) | (m >= high ? 0x80000000u : 0u); }
-    }
-    __syncthreads();
-    const unsigned n = qn;
-    if (!n) return;
-    if (tid == 0) gbase = atomicAdd((unsigned*)cnt, n);
-    __syncthreads();
-    for (unsigned t = tid; t < n; t += 256) {
-        if (gbase + t < cap) { list[gbase + t] = q[t] & 0x7fffffffu; hflag[gbase + t] = (uint8_t)(q[t] >> 31); }
-        else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+    for (int it = 0; it <= CT_NT; it++) {
+        const int y0 = (blockIdx.y * CT_NT + it) * CT_Y;
+        const bool more = it < CT_NT && y0 < ny;
+        __syncthreads();
+        // flush when the next tile might not fit, and at the end
+        const unsigned n = qn;
+        if (n && (!more || n + CT_X * CT_Y > CT_Q)) {
+            if (tid == 0) gbase = atomicAdd((unsigned*)cnt, n);
+            __syncthreads();
+            for (unsigned t = tid; t < n; t += 256) {
+                if (gbase + t < cap) { list[gbase + t] = q[t] & 0x7fffffffu; hflag[gbase + t] = (uint8_t)(q[t] >> 31); }
+                else atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+            }
+            __syncthreads();
+            if (tid == 0) qn = 0;
+        }
+        if (!more) break;
+        for (int i = tid; i < (CT_Y + 4) * (CT_X + 4); i += 256) {
+            const int r = i / (CT_X + 4), c = i - r * (CT_X + 4);
+            const int yy = min(max(y0 - 2 + r, 0), ny - 1), xx = min(max(x0 - 2 + c, 0), nx - 1);
+            s_sm[r][c] = sm[(size_t)yy * nx + xx];
+        }
+        __syncthreads();
+        for (int i = tid; i < (CT_Y + 2) * (CT_X + 2); i += 256) {
+            const int r = i / (CT_X + 2), c = i - r * (CT_X + 2);           // image position (y0 - 1 + r, x0 - 1 + c)
+            const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
+            const double js = d1 * 2.0 + (d0 + d2);
+            const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
+            const double is = e1 * 2.0 + (e0 + e2);
+            s_mag[r][c] = sqrt(is * is + js * js);
+        }
+        __syncthreads();
+        for (int i = tid; i < CT_X * CT_Y; i += 256) {
+            const int ty = i / CT_X, tx = i - ty * CT_X, y = y0 + ty, x = x0 + tx;
+            if (!live || y < 1 || y > ny - 2 || x < 1 || x > nx - 2) continue;      // binary_erosion of the all-ones mask
+            const int r = ty + 1, c = tx + 1;                                      // in s_mag; s_sm centre is [r + 1][c + 1]
+            const double m = s_mag[r][c];
+            if (!(m > 0.0 && m >= low)) continue;
+            const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
+            const double js = d1 * 2.0 + (d0 + d2);
+            const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
+            const double is = e1 * 2.0 + (e0 + e2);
+            const double ai = fabs(is), aj = fabs(js);
+            const bool same = (is >= 0 && js >= 0) || (is <= 0 && js <= 0), opp = (is <= 0 && js >= 0) || (is >= 0 && js <= 0);
+            const double* mu = s_mag[r - 1]; const double* mc = s_mag[r]; const double* md = s_mag[r + 1];
+            bool loc = false;
+            // c2 w + c1 (1 - w) <= m on both sides of the gradient direction; later sectors overwrite earlier ones
+            if (same && ai >= aj) { const double w = aj / ai; loc = (md[c + 1] * w + md[c] * (1 - w) <= m) && (mu[c - 1] * w + mu[c] * (1 - w) <= m); }
+            if (same && ai <= aj) { const double w = ai / aj; loc = (md[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (mu[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
+            if (opp && ai <= aj) { const double w = ai / aj; loc = (mu[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (md[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
+            if (opp && ai >= aj) { const double w = aj / ai; loc = (mu[c + 1] * w + mu[c] * (1 - w) <= m) && (md[c - 1] * w + md[c] * (1 - w) <= m); }
+            if (loc) { const unsigned k = atomicAdd(&qn, 1u); q[k] = (uint32_t)((size_t)y * nx + x) | (m >= high ? 0x80000000u : 0u); }
+        }
     }
 }
 
@@ -281,13 +284,13 @@ int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const doub
     const size_t n = (size_t)ny * nx;
     int rc;
     const size_t cap = n / 8 + 4096;                               // low-mask pixels
-    const size_t o_par = 0, o_hist = 4096, o_w = o_hist + 4 * 4096 * 4, o_img = o_w + 1024;
-    const size_t o_tmp = o_img + ((n * 4 + 255) & ~(size_t)255), o_sm = o_tmp + ((n * 4 + 255) & ~(size_t)255);
+    const size_t o_par = 0, o_hist = 4096, o_w = o_hist + 4 * 4096 * 4, o_tmp = o_w + 1024;
+    const size_t o_sm = o_tmp + ((n * 4 + 255) & ~(size_t)255);
     const size_t o_list = o_sm + ((n * 8 + 255) & ~(size_t)255), o_flag = o_list + ((cap * 4 + 255) & ~(size_t)255);
     const size_t total = o_flag + cap + 256;
     char* ws = (char*)bbx_ws(ctx, WS_CANNY, total, &rc); if (rc) return rc;
     canny_par* par = (canny_par*)(ws + o_par); unsigned* hist = (unsigned*)(ws + o_hist); double* d_w = (double*)(ws + o_w);
-    float* img = (float*)(ws + o_img); float* tmp = (float*)(ws + o_tmp); double* sm = (double*)(ws + o_sm);
+    float* tmp = (float*)(ws + o_tmp); double* sm = (double*)(ws + o_sm);
     uint32_t* list = (uint32_t*)(ws + o_list); uint8_t* hflag = (uint8_t*)(ws + o_flag);
     int32_t* cnt = &ctx->d_counters[CNT_TMP];
     const double q1 = 4.5 / 100.0, q2 = 93.0 / 100.0;             // np.percentile(image, (4.5, 93.0))
@@ -301,15 +304,14 @@ int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const doub
     hipLaunchKernelGGL(k_canny_hist<2>, dim3(1024), dim3(256), 0, s, d_bin, n, par, hist);
     hipLaunchKernelGGL(k_canny_scan<2>, dim3(1), dim3(256), 0, s, par, hist);
     hipLaunchKernelGGL(k_canny_params, dim3(1), dim3(64), 0, s, par, n, q1, q2, low_frac, high_frac);
-    hipLaunchKernelGGL(k_canny_rescale, dim3(2048), dim3(256), 0, s, d_bin, n, par, img);
     const dim3 gx((nx + 255) / 256, ny), gv((nx + 255) / 256, (ny + GV_RY - 1) / GV_RY);
     if (radius == 12) {
-        hipLaunchKernelGGL(k_canny_gauss_v<12>, gv, dim3(256), 0, s, img, ny, nx, par, tmp);
+        hipLaunchKernelGGL(k_canny_gauss_v<12>, gv, dim3(256), 0, s, d_bin, ny, nx, par, tmp);
         hipLaunchKernelGGL(k_canny_gauss_h<12>, gx, dim3(256), 0, s, tmp, ny, nx, par, sm);
     } else {
         return BBX_ERR_ARG;                                        // sigma = 3 (radius 12) is what sat_detect asks for
     }
-    hipLaunchKernelGGL(k_canny_tile, dim3((nx + CT_X - 1) / CT_X, (ny + CT_Y - 1) / CT_Y), dim3(256), 0, s, sm, ny, nx, par, list, hflag, cnt,
+    hipLaunchKernelGGL(k_canny_tile, dim3((nx + CT_X - 1) / CT_X, (ny + CT_Y * CT_NT - 1) / (CT_Y * CT_NT)), dim3(256), 0, s, sm, ny, nx, par, list, hflag, cnt,
                        (uint32_t)cap, ctx->d_err);
     BBX_LAUNCH_CHECK();
     return bbx_cc_filter_list(ctx, list, cnt, cap, ny, nx, hflag, min_size, d_out, d_out_cnt, out_cap, s);
