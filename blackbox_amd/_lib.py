@@ -84,6 +84,7 @@ SIGNATURES = {
     'bbx_bkg_boxstats': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'bbx_mini_fill_filter': (_i, [_vp, _i, _i, _vp, _vp]),
     'bbx_spline_zoom': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_spline_zoom_sub': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_variance': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp]),
     'bbx_embed_psf': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_cut_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     'bbx_zogy_frame_supported': (_i, [_i]),
     'bbx_zogy_frame': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_psf_optflux_sigma': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_find_peaks': (_i, [_vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_count_objects': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
 }

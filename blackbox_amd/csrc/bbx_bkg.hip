@@ -238,7 +238,8 @@ __global__ __launch_bounds__(1024) void k_mini_fill_filter(float* mini, float* t
 __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const double* __restrict__ coef, int cnx,
                                                      const int32_t* __restrict__ fy, const double* __restrict__ wy,
                                                      const int32_t* __restrict__ fx, const double* __restrict__ wx,
-                                                     float* data, float* bkg) {
+                                                     float* data, float* bkg, const float* __restrict__ src) {
+    // (src: where the pixels to subtract from are read -- data itself, or another frame that stays as it is)
     // the 4 coefficient rows of an output row are first folded with the row weights into a
     // short LDS vector (a 256-pixel span touches only a handful of coefficient columns); each
     // pixel then needs 4 taps instead of 16 strided float64 loads
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const doubl
             const float v = (float)t;
             const size_t o = (size_t)Y * nx + X;
             if (bkg) bkg[o] = v;
-            if (data) data[o] = data[o] - v;
+            if (data) data[o] = (src ? src[o] : data[o]) - v;
         }
         return;
     }
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const doubl
             const float v = (float)t;
             const size_t o = (size_t)Y * nx + X;
             if (bkg) bkg[o] = v;
-            if (data) data[o] = data[o] - v;
+            if (data) data[o] = (src ? src[o] : data[o]) - v;
         }
     }
 }
@@ -339,7 +340,18 @@ int bbx_spline_zoom(bbx_ctx* ctx, int ny, int nx, const double* d_coef, int cny,
     if (!ctx || !d_coef || !d_fy || !d_wy || !d_fx || !d_wx || (!d_data && !d_bkg) || ny < 1 || nx < 1 || cny < 4 || cnx < 4)
         return BBX_ERR_ARG;
     hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
-                       d_fy, d_wy, d_fx, d_wx, d_data, d_bkg);
+                       d_fy, d_wy, d_fx, d_wx, d_data, d_bkg, (const float*)nullptr);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_spline_zoom_sub(bbx_ctx* ctx, int ny, int nx, const double* d_coef, int cny, int cnx, const int32_t* d_fy,
+                        const double* d_wy, const int32_t* d_fx, const double* d_wx, const float* d_in, float* d_out,
+                        void* stream) {
+    if (!ctx || !d_coef || !d_fy || !d_wy || !d_fx || !d_wx || !d_in || !d_out || ny < 1 || nx < 1 || cny < 4 || cnx < 4)
+        return BBX_ERR_ARG;
+    hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
+                       d_fy, d_wy, d_fx, d_wx, d_out, (float*)nullptr, d_in);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

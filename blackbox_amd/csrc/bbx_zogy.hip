@@ -230,6 +230,9 @@ __global__ __launch_bounds__(256) void k_stitch(const float* __restrict__ subs, 
 }
 
 // ---- PSF photometry: one wave per source ---------------------------------------------------
+// (SIGMA: V holds the sigma image of the background-subtracted frame D; the variance max(D, 0) + sigma^2 is formed here,
+// in float32 like k_variance does, instead of being written out for the whole frame first)
+template <bool SIGMA>
 __global__ __launch_bounds__(256) void k_psf_optflux(int ny, int nx, const float* __restrict__ D, const float* __restrict__ V,
                                                      const float* __restrict__ psfs, int S, int nsrc,
                                                      const int32_t* __restrict__ ys, const int32_t* __restrict__ xs,
@@ -243,7 +246,9 @@ __global__ __launch_bounds__(256) void k_psf_optflux(int ny, int nx, const float
             const int j = t / S, i = t - j * S;
             const int y = ys[k] + j - h, x = xs[k] + i - h;
             if (y < 0 || y >= ny || x < 0 || x >= nx) continue;
-            const double v = (double)V[(size_t)y * nx + x];
+            float vf = V[(size_t)y * nx + x];
+            if (SIGMA) vf = fmaxf(D[(size_t)y * nx + x], 0.f) + vf * vf;
+            const double v = (double)vf;
             if (!(v > 0.0)) continue;
             const double p = (double)psfs[((size_t)k * S + j) * S + i];
             num += p * (double)D[(size_t)y * nx + x] / v;
@@ -359,7 +364,17 @@ int bbx_psf_optflux(bbx_ctx* ctx, int ny, int nx, const float* d_D, const float*
     if (!ctx || !d_D || !d_V || !d_psfs || !d_ys || !d_xs || !d_flux || !d_err || S < 1 || nsrc < 0) return BBX_ERR_ARG;
     if (nsrc == 0) return BBX_OK;
     unsigned grid = (unsigned)((nsrc + 3) / 4); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_psf_optflux, dim3(grid), dim3(256), 0, (hipStream_t)stream, ny, nx, d_D, d_V, d_psfs, S, nsrc, d_ys, d_xs, d_flux, d_err);
+    hipLaunchKernelGGL(k_psf_optflux<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ny, nx, d_D, d_V, d_psfs, S, nsrc, d_ys, d_xs, d_flux, d_err);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_psf_optflux_sigma(bbx_ctx* ctx, int ny, int nx, const float* d_D, const float* d_sigma, const float* d_psfs, int S, int nsrc,
+                          const int32_t* d_ys, const int32_t* d_xs, float* d_flux, float* d_err, void* stream) {
+    if (!ctx || !d_D || !d_sigma || !d_psfs || !d_ys || !d_xs || !d_flux || !d_err || S < 1 || nsrc < 0) return BBX_ERR_ARG;
+    if (nsrc == 0) return BBX_OK;
+    unsigned grid = (unsigned)((nsrc + 3) / 4); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_psf_optflux<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ny, nx, d_D, d_sigma, d_psfs, S, nsrc, d_ys, d_xs, d_flux, d_err);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -274,6 +274,7 @@ class FramePipeline:
         self.detect_sats = detect_sats and bool(get_par(settings.detect_sats, tel))
         self.subtract = dict(subtract) if subtract else None
         # one lane at a time inside bbx_zogy_frame (BBX_ZOGY_GATE=0 switches the gate off)
+        self.ref_bkg_std = None
         self.zogy_gate = None
         if self.subtract and os.environ.get('BBX_ZOGY_GATE', '1') != '0':
             from . import zogy as G
@@ -550,7 +551,14 @@ class FramePipeline:
         if self.subtract is not None:
             from . import zogy as G
             try:
-                sub = G.optimal_subtraction(ctx, data, new_mask=mask, zogy_gate=self.zogy_gate, **self.subtract)
+                sub = G.optimal_subtraction(ctx, data, new_mask=mask, zogy_gate=self.zogy_gate, ref_bkg_std=self.ref_bkg_std,
+                                            **self.subtract)
+                if (self.ref_bkg_std is None and self.subtract.get('ref_is_bkgsub') and self.subtract.get('ref_bkg_std_mini') is not None
+                        and self.subtract.get('ref_grid') is None and 'bkg_std_ref' in sub):
+                    # the reference's sigma image is the same for every frame of the run: made once, on whichever lane
+                    # comes first (its stream has finished with it before any other lane can pick it up: see below)
+                    torch.cuda.current_stream().synchronize()
+                    self.ref_bkg_std = sub['bkg_std_ref']
                 if not self.keep_outputs:
                     for k in list(sub):
                         if torch.is_tensor(sub[k]):

@@ -107,9 +107,10 @@ def _device_taps(ctx, nby, nbx, box, cy, cx):
     return cache[key]
 
 
-def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_from=None, want_bkg=True):
+def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_from=None, want_bkg=True, subtract_into=None):
     """zogy.mini2back(data_mini, data_shape, order_interp=3, bkg_boxsize, interp_Xchan): full-
-    frame background from the mini image; with subtract_from the same pass does `data -= bkg`."""
+    frame background from the mini image; with subtract_from the same pass does `data -= bkg`
+    (in place, or into the tensor subtract_into with subtract_from left as it is)."""
     box = bkg_boxsize or settings.bkg_boxsize
     mini_h = mini.cpu().numpy() if torch.is_tensor(mini) else np.asarray(mini)
     channels = None
@@ -125,6 +126,10 @@ def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_fr
     dev = ctx.device
     d_coef = torch.from_numpy(coef).to(dev)
     ny, nx = shape
+    if subtract_into is not None:
+        check(lib.bbx_spline_zoom_sub(ctx.h, ny, nx, _p(d_coef), coef.shape[0], coef.shape[1], _p(d_fy), _p(d_wy), _p(d_fx),
+                                      _p(d_wx), _p(subtract_from), _p(subtract_into), ctx.stream()), 'bbx_spline_zoom_sub', ctx.h)
+        return None
     bkg = torch.empty((ny, nx), dtype=torch.float32, device=dev) if want_bkg else None
     check(lib.bbx_spline_zoom(ctx.h, ny, nx, _p(d_coef), coef.shape[0], coef.shape[1], _p(d_fy), _p(d_wy), _p(d_fx),
                               _p(d_wx), _p(subtract_from), _p(bkg), ctx.stream()), 'bbx_spline_zoom', ctx.h)
@@ -187,8 +192,10 @@ def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, bo
     return outs
 
 
-def psf_optflux(ctx, D, V, psfs, ys, xs):
-    """zogy.get_psfoptflux at integer positions -> (flux, fluxerr) float32 device tensors"""
+def psf_optflux(ctx, D, V, psfs, ys, xs, v_is_sigma=False):
+    """zogy.get_psfoptflux at integer positions -> (flux, fluxerr) float32 device tensors; with v_is_sigma
+    V is the sigma image of the background-subtracted frame D and the variance max(D, 0) + sigma^2 is
+    formed at the stamp pixels only"""
     nsrc, S, _ = psfs.shape
     dev = ctx.device
     d_ys = torch.as_tensor(np.asarray(ys, np.int32)).to(dev)
@@ -196,8 +203,8 @@ def psf_optflux(ctx, D, V, psfs, ys, xs):
     flux = torch.empty(nsrc, dtype=torch.float32, device=dev)
     err = torch.empty(nsrc, dtype=torch.float32, device=dev)
     ny, nx = D.shape
-    check(lib.bbx_psf_optflux(ctx.h, ny, nx, _p(D), _p(V), _p(psfs), S, nsrc, _p(d_ys), _p(d_xs), _p(flux), _p(err),
-                              ctx.stream()), 'bbx_psf_optflux', ctx.h)
+    fn = lib.bbx_psf_optflux_sigma if v_is_sigma else lib.bbx_psf_optflux
+    check(fn(ctx.h, ny, nx, _p(D), _p(V), _p(psfs), S, nsrc, _p(d_ys), _p(d_xs), _p(flux), _p(err), ctx.stream()), 'bbx_psf_optflux', ctx.h)
     return flux, err
 
 
@@ -372,7 +379,7 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
                         subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None,
                         ref_is_bkgsub=False, ref_bkg_std_mini=None, ref_grid=None, ref_grid_step=32,
                         cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000,
-                        zogy_gate=None):
+                        zogy_gate=None, ref_bkg_std=None):
     """The numerical core of zogy.optimal_subtraction(new_fits, ref_fits, ...) (call sites
     blackbox.py:2350-2354 new-only, 2460-2465 new + ref) on device tensors: background mesh +
     subtraction, variance images, [remapping of the reference to the new frame's grid],
@@ -382,7 +389,9 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
       ref, ref_mask : reference frame or None (new-only mode, trans_extract False or no ref:
                       the 2350-2354 branch): then only the background products and the catalogue
       ref_is_bkgsub : the reference is a background-subtracted co-add (buildref product);
-                      ref_bkg_std_mini: its `_bkg_std_mini` image (else measured here)
+                      ref_bkg_std_mini: its `_bkg_std_mini` image (else measured here);
+                      ref_bkg_std: the full-frame sigma image made from it, when the caller keeps it
+                      for many frames of the same field (res['bkg_std_ref'] of an earlier call)
       ref_grid      : projection lattice (coadd.projection_grid) when the reference lives on
                       another pixel grid: it is remapped with the LANCZOS3 kernel (zogy runs SWarp)
       psf_new/ref   : PSF stamps [nsub, S, S] / [S, S] (unit sum) or a PSFEx model dict
@@ -401,8 +410,8 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
 
     # ---- new frame: mesh, subtraction, sigma image, variance
     mini, mini_std = get_back(ctx, new, new_mask, bkg_boxsize=box)
-    work = new.clone()
-    mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=work, want_bkg=False)
+    work = torch.empty_like(new)
+    mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=new, subtract_into=work)
     bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
     Vn = None                                                        # variance image: only where a consumer needs it
     sdn = mini_std.cpu().numpy()
@@ -430,8 +439,7 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         peaks = ys
         if ys.size:
             stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
-            Vn = variance(ctx, work, bstd)
-            f, e = psf_optflux(ctx, work, Vn, stamps, ys, xs)
+            f, e = psf_optflux(ctx, work, bstd, stamps, ys, xs, v_is_sigma=True)
             f, e = f.cpu().numpy(), e.cpu().numpy()
         else:
             f = e = np.zeros(0, np.float32)
@@ -455,8 +463,8 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
             sdr = np.asarray(ref_bkg_std_mini, np.float32)
     else:
         rmini, rstd_mini = get_back(ctx, ref, ref_mask, bkg_boxsize=box)
-        rwork = ref.clone()
-        mini2back(ctx, rmini, (rny, rnx), bkg_boxsize=box, interp_Xchan=True, subtract_from=rwork, want_bkg=False)
+        rwork = torch.empty_like(ref)
+        mini2back(ctx, rmini, (rny, rnx), bkg_boxsize=box, interp_Xchan=True, subtract_from=ref, subtract_into=rwork)
         sdr = rstd_mini.cpu().numpy() if ref_bkg_std_mini is None else np.asarray(ref_bkg_std_mini, np.float32)
         res['bkg_mini_ref'] = rmini.cpu().numpy()
     res['bkg_std_mini_ref'] = sdr
@@ -468,7 +476,8 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     elif (rny, rnx) != (ny, nx):
         raise ValueError('reference frame of another shape needs ref_grid')
     # co-added reference: no channel structure in its noise -> interpolation across the frame
-    rbstd = mini2back(ctx, sdr, (ny, nx), bkg_boxsize=box, interp_Xchan=True)
+    rbstd = ref_bkg_std if (ref_bkg_std is not None and ref_grid is None and tuple(ref_bkg_std.shape) == (ny, nx)) \
+        else mini2back(ctx, sdr, (ny, nx), bkg_boxsize=box, interp_Xchan=True)
     res['ref_bkgsub'], res['bkg_std_ref'] = rwork, rbstd
     hdr_t['S-BKGSTDR'] = (float(np.median(sdr)), '[e-] sigma (STD) background reference image')
 

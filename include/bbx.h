@@ -410,6 +410,10 @@ int bbx_mini_fill_filter(bbx_ctx *ctx, int nby, int nbx, float *d_mini, void *st
 int bbx_spline_zoom(bbx_ctx *ctx, int ny, int nx, const double *d_coef, int cny, int cnx,
                     const int32_t *d_fy, const double *d_wy, const int32_t *d_fx,
                     const double *d_wx, float *d_data, float *d_bkg, void *stream);
+/* the same with separate input and output: d_out = d_in - background (d_in stays as it is) */
+int bbx_spline_zoom_sub(bbx_ctx *ctx, int ny, int nx, const double *d_coef, int cny, int cnx,
+                        const int32_t *d_fy, const double *d_wy, const int32_t *d_fx,
+                        const double *d_wx, const float *d_in, float *d_out, void *stream);
 
 /* ---- a16: ZOGY sub-image subtraction (zogy.optimal_subtraction -> run_ZOGY; call sites
  * blackbox.py:2350-2354, 2460-2465) with rocFFT.  [EXT algorithm: Zackay, Ofek & Gal-Yam
@@ -471,6 +475,11 @@ int bbx_psf_model(bbx_ctx *ctx, int nsrc, int ncoef, int npix, const float *d_te
 int bbx_psf_optflux(bbx_ctx *ctx, int ny, int nx, const float *d_D, const float *d_V,
                     const float *d_psfs, int S, int nsrc, const int32_t *d_ys,
                     const int32_t *d_xs, float *d_flux, float *d_err, void *stream);
+/* the same on a background-subtracted frame d_D with its sigma image: V = max(D, 0) + sigma^2 is formed
+ * per stamp pixel (float32, as bbx_variance would) instead of being written out for the whole frame */
+int bbx_psf_optflux_sigma(bbx_ctx *ctx, int ny, int nx, const float *d_D, const float *d_sigma,
+                          const float *d_psfs, int S, int nsrc, const int32_t *d_ys,
+                          const int32_t *d_xs, float *d_flux, float *d_err, void *stream);
 
 /* ---- a17: transient candidates: 8-connected regions of |img| >= thr (|S_corr| >= T-NSIGMA,
  * set_qc.py:387); per region the pixel of largest |value| (first in C order on ties).
