@@ -728,17 +728,25 @@ __global__ __launch_bounds__(256) void k_compact_abs(const float* __restrict__ i
     __syncthreads();
     const size_t step = (size_t)gridDim.x * 1024;
     const size_t nround = (npix + step - 1) / step * step;
+    const bool vec = (((uintptr_t)img) & 15) == 0;
     for (size_t b = (size_t)blockIdx.x * 1024; b < nround; b += step) {
+        // 1024 pixels per workgroup and round: one 16-byte load per thread where the frame allows it
+        float v[4];
+        const size_t i0 = b + (size_t)tid * 4;
+        if (vec && i0 + 3 < npix) { const float4 f = *(const float4*)(img + i0); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = i0 + r < npix ? img[i0 + r] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const size_t i = b + (size_t)r * 256 + tid;
-            const bool hit = i < npix && fabsf(img[i]) >= thr;   // NaN compares false
+            const bool hit = i0 + r < npix && fabsf(v[r]) >= thr;   // NaN compares false
             const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
             if (m) {
                 unsigned wb = 0;
                 if (lane == 0) wb = atomicAdd(&qn, (unsigned)__popcll(m));
                 wb = __shfl(wb, 0, 64);
-                if (hit) q[wb + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint32_t)i;
+                if (hit) q[wb + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint32_t)(i0 + r);
             }
         }
         __syncthreads();
