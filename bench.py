@@ -592,6 +592,32 @@ def io_inclusive(torch, ctx, raw, N, ms_compute, wl):
                                  note='products quantised (q=16) + Rice-compressed on the device, only the streams cross PCIe')
     except Exception as e:                                         # the figure is informative only
         out['with_fpack'] = dict(error=str(e))
+    # files included (SURVEY 8d iii): one frame's products written by the product's own FITS writers to a scratch
+    # directory -- uncompressed float32 (D2H + fitsio.write_image) and as .fits.fz (fpack.fpack_image: compressed on the
+    # device, the host writes the streams) -- one writer thread, as the per-file CLI does it
+    try:
+        import tempfile
+        from blackbox_amd import fitsio
+        side = int(np.sqrt(N))
+        img2 = (250 + 20 * torch.randn(side, side, device=dev)).contiguous()
+        with tempfile.TemporaryDirectory(prefix='bbx_bench_') as td:
+            t0 = time.perf_counter()
+            fitsio.write_image(os.path.join(td, 'a.fits'), img2.cpu().numpy())
+            ms_plain = 1e3 * (time.perf_counter() - t0)
+            P.fpack_image(ctx, os.path.join(td, 'warm.fits.fz'), img2)
+            t0 = time.perf_counter()
+            P.fpack_image(ctx, os.path.join(td, 'b.fits.fz'), img2)
+            ms_fz = 1e3 * (time.perf_counter() - t0)
+            sz_plain, sz_fz = os.path.getsize(os.path.join(td, 'a.fits')), os.path.getsize(os.path.join(td, 'b.fits.fz'))
+        out['fits_inclusive'] = dict(ms_per_float_image_uncompressed=ms_plain, ms_per_float_image_fz=ms_fz, MB_uncompressed=sz_plain / 1e6,
+                                     MB_fz=sz_fz / 1e6, float_images_per_frame=nprod,
+                                     frames_per_s_one_writer_uncompressed=1e3 / (nprod * ms_plain),
+                                     frames_per_s_one_writer_fz=1e3 / (nprod * ms_fz),
+                                     note='one host thread writing the float products of a frame one after the other to local scratch '
+                                          '(the mask and the tables are small beside them); writers of several frames run in parallel '
+                                          'in a deployment (one per lane)')
+    except Exception as e:
+        out['fits_inclusive'] = dict(error=str(e))
     return out
 
 
