@@ -344,7 +344,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_rows(const float2* 
     extern __shared__ float2 s[];
     float2* twl = s + P::NL * P::LS;                                   // the twiddle table, in LDS for the gathers of the two steps
     for (int e = threadIdx.x; e < P::L; e += blockDim.x) twl[e] = tw[e];
-    const int y0 = blockIdx.x * P::NL, sub = blockIdx.y;
+    const int sub = blockIdx.y;
     const int l = threadIdx.x % P::NL, t = threadIdx.x / P::NL;
     load_u_pair<P>(Ukr, Ukn, sub, blockIdx.x, s);
     __syncthreads();

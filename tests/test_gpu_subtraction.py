@@ -132,3 +132,37 @@ def test_optimal_subtraction_chain(ctx):
     oracle_pos = {(a, b) for a, b, _ in Z.find_transients(Z.stitch_subimages(np.stack(outs['Scorr']), ny, nx, size, border), 6.0)}
     assert set(found) == oracle_pos
     assert res['header']['Z-SIZE'] == size and res['header']['T-NTRANS'] == len(found)
+
+
+def test_empty_lists_and_new_only_mode(ctx):
+    """edge cases of the operator: a frame pair without a single significant pixel (empty transient table and
+    catalogue, T-NTRANS 0, NOBJECTS 0), identical new and reference (D == 0 exactly where the noise models
+    agree), and the new-only branch (blackbox.py:2350-2354: no reference -> background products + catalogue,
+    Z-P False)"""
+    rs = np.random.RandomState(3)
+    size, border, box = 48, 8, 24
+    ny, nx = 2 * size, 8 * size
+    psf = dev(ctx, moffat_stamp(11, 3.2))
+    new = (100 + rs.normal(0, 5, (ny, nx))).astype(F)
+    ref = (rs.normal(0, 2, (ny, nx))).astype(F)
+    zero = torch.zeros((ny, nx), dtype=torch.uint8, device=ctx.device)
+    kw = dict(fratio=1.0, dx=0.0, dy=0.0, subimage_size=size, subimage_border=border, bkg_boxsize=box, ref_is_bkgsub=True,
+              ref_bkg_std_mini=np.full((ny // box, nx // box), 2.0, F), cat_extract=True, cat_nsigma=8.0)
+    res = G.optimal_subtraction(ctx, dev(ctx, new), dev(ctx, ref), zero, zero, psf, psf, **kw)
+    ctx.sync()
+    assert res['transients'] == [] and res['header_trans']['T-NTRANS'][0] == 0
+    assert res['catalog']['X_POS'].size == 0 and res['header_new']['NOBJECTS'][0] == 0
+    assert res['header_new']['Z-P'][0] is True
+    for k in ('D', 'Scorr', 'Fpsf', 'Fpsferr'):
+        assert torch.isfinite(res[k]).all(), k
+    # identical inputs with identical noise models: D vanishes
+    same = (rs.normal(0, 5, (ny, nx))).astype(F)
+    kw2 = dict(kw, ref_bkg_std_mini=None, ref_is_bkgsub=False)
+    r2 = G.optimal_subtraction(ctx, dev(ctx, same), dev(ctx, same), zero, zero, psf, psf, **kw2)
+    ctx.sync()
+    assert float(r2['D'].abs().max()) <= 1e-4 * float(np.abs(same).max())
+    assert r2['transients'] == []
+    # new-only
+    r3 = G.optimal_subtraction(ctx, dev(ctx, new), None, zero, None, psf, None, **kw)
+    assert r3['header_new']['Z-P'][0] is False and 'D' not in r3 and r3['bkg_mini_new'].shape == (ny // box, nx // box)
+    assert abs(float(np.median(r3['bkg_mini_new'])) - 100) < 1.0
