@@ -50,6 +50,9 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #ifndef Z3_MINW_LIGHT
 #define Z3_MINW_LIGHT Z3_MINW  // the same for the kernels without parked registers (k_psf_rows, k_cols_fwd, k_img_rows)
 #endif
+#ifndef Z3_MINW_PSF
+#define Z3_MINW_PSF Z3_MINW
+#endif
 #ifndef Z3_FIN_MINW
 #define Z3_FIN_MINW 6
 #endif
@@ -73,6 +76,7 @@ template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
     static constexpr size_t UNIT = (size_t)LB * NL * HP;            // elements of one T / U / C array per sub-image
     static constexpr int TWL = Z3_TWL;
     static constexpr int MINW_LIGHT = L >= 512 ? Z3_MINW_LIGHT : 1;
+    static constexpr int MINW_PSF = L >= 512 ? Z3_MINW_PSF : 1;
     static constexpr int MINW = L >= 512 ? Z3_MINW : 1, FIN_MINW = L >= 512 ? Z3_FIN_MINW : 1;
 };
 
@@ -360,7 +364,7 @@ __device__ __forceinline__ int opaque_tid() { int t = (int)threadIdx.x; asm vola
 
 // ---- PSF side ---------------------------------------------------------------------------------
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
+__global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
                                                          const zscal* __restrict__ sc, const float2* __restrict__ twg,
                                                          float2* __restrict__ cA, float2* __restrict__ cB, float2* __restrict__ cKn,
                                                          float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
