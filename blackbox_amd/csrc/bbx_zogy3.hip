@@ -388,11 +388,13 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             const int kk = g * P::NL + ll;
             if (kk >= P::H) continue;
             float2 acc = make_float2(0.f, 0.f);
+            // the stamp's columns sit at x = -h .. S-1-h (mod L): the twiddle index kx x advances by kx per column
+            int idx = (kk * ((P::L - h % P::L) % P::L)) % P::L;         // kx (L - h) < H L: 32-bit
             for (int i = 0; i < S; i++) {
-                const int xw = ((i - h) % P::L + P::L) % P::L;
-                const float2 w = twg[(int)(((long long)kk * xw) % P::L)];
+                const float2 w = twg[idx];
                 const float p = st[j * S + i];
                 acc.x += p * w.x; acc.y += p * w.y;
+                idx += kk; if (idx >= P::L) idx -= P::L;
             }
             const int y = ((j - h) % P::L + P::L) % P::L;
             s[ll * P::LS + npos(y)] = acc;
