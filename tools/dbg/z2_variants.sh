@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: time bbx_zogy_frame for builds of $SRC.hip (bbx_zogy2 or bbx_zogy3) with different -D flags (scratch copies of
+# (needs the object files of the other sources on the box: take the `*.o` line out of .gpurunignore for such a run)
 # the library under /tmp; the product .so is not touched).  PROF=1: per-kernel rocprofv3 stats instead.
 SRC=${SRC:-bbx_zogy3}
 FL="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function"
