@@ -44,6 +44,9 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #ifndef Z3_LOADS_U
 #define Z3_LOADS_U 2
 #endif
+#ifndef Z3_IMG_LOADS
+#define Z3_IMG_LOADS 3
+#endif
 #ifndef Z3_MINW
 #define Z3_MINW 4              // waves per SIMD the register allocation must allow (two workgroups of 512)
 #endif
@@ -518,11 +521,12 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_img_rows(frame_ar
     if (f.vec4) {
         // groups of four pixels never straddle the frame edge (size, border, nx multiples of 4)
         constexpr int NV = P::NL * P::L / 4;
-        for (int e0 = threadIdx.x; e0 < NV; e0 += 2 * (int)blockDim.x) {
-            float4 va[2], vb[2];
-            bool in[2];
+        constexpr int IL = Z3_IMG_LOADS;                        // groups of four pixels per thread and round: all of a workgroup's loads in one round trip
+        for (int e0 = threadIdx.x; e0 < NV; e0 += IL * (int)blockDim.x) {
+            float4 va[IL], vb[IL];
+            bool in[IL];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < IL; i++) {
                 const int e = e0 + i * (int)blockDim.x;
                 va[i] = vb[i] = make_float4(0.f, 0.f, 0.f, 0.f); in[i] = false;
                 if (e < NV) {
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_img_rows(frame_ar
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < IL; i++) {
                 const int e = e0 + i * (int)blockDim.x;
                 if (e < NV) {
                     const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
