@@ -30,7 +30,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD) s++; return s; }
 
 #ifndef Z3_THREADS
-#define Z3_THREADS 512         // two workgroups per CU
+#define Z3_THREADS 768         // two workgroups per CU: 24 waves, <= 85 VGPRs (8 parked float2 per thread in the column kernels)
 #endif
 #ifndef Z3_FIN_THREADS
 #define Z3_FIN_THREADS 768     // k_final_rows: 5 lines = 64 KB, two workgroups per CU
@@ -47,8 +47,11 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #ifndef Z3_IMG_LOADS
 #define Z3_IMG_LOADS 3
 #endif
+#ifndef Z3_LIGHT_THREADS
+#define Z3_LIGHT_THREADS Z3_THREADS   // k_psf_rows, k_img_rows (nothing parked in registers)
+#endif
 #ifndef Z3_MINW
-#define Z3_MINW 4              // waves per SIMD the register allocation must allow (two workgroups of 512)
+#define Z3_MINW 6              // waves per SIMD the register allocation must allow (two workgroups of 768 threads)
 #endif
 #ifndef Z3_MINW_LIGHT
 #define Z3_MINW_LIGHT Z3_MINW  // the same for the kernels without parked registers (k_psf_rows, k_cols_fwd, k_img_rows)
@@ -72,6 +75,7 @@ template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
     static constexpr int L = R0_ * R1_ * R2_ * R3_, H = L / 2 + 1;
     static constexpr int NL = L >= 512 ? Z3_NL : 16;                // lines per workgroup
     static constexpr int THREADS = L >= 512 ? Z3_THREADS : 256, FIN_THREADS = L >= 512 ? Z3_FIN_THREADS : 256;
+    static constexpr int LIGHT_THREADS = L >= 512 ? Z3_LIGHT_THREADS : 256;
     static constexpr int G = (H + NL - 1) / NL, HP = G * NL;        // column groups, padded half-spectrum width
     static constexpr int LP = L + L / 8 + 1;                        // padded line: one pad per 8 entries
     static constexpr int LS = line_stride(LP);
@@ -206,11 +210,14 @@ static inline dim3 grid8(int nx, int ny) { return dim3((unsigned)(((size_t)nx * 
 // LDS (natural order, after an inverse column pass) -> U tiles U[sub][g][y][l]; halo rows on request
 template <class P> __device__ __forceinline__ void store_u(const float2* s, float2* __restrict__ U, int sub, int g, float2* __restrict__ halo = nullptr) {
     float2* base = U + (size_t)sub * P::UNIT + (size_t)g * P::L * P::NL;
-    for (int e = threadIdx.x; e < P::L * P::NL; e += blockDim.x) {
-        const int y = e / P::NL, l = e - y * P::NL;
-        const float2 v = s[l * P::LS + npos(y)];
-        base[e] = v;
-        if (halo && (y % P::NL == P::NL - 1 || y == P::L - 1)) halo[((size_t)sub * P::LB + y / P::NL) * P::HP + g * P::NL + l] = v;
+    // two neighbouring lines per item: one 16-byte store
+    constexpr int HL = P::NL / 2;
+    for (int e = threadIdx.x; e < P::L * HL; e += blockDim.x) {
+        const int y = e / HL, l = 2 * (e - y * HL), py = npos(y);
+        const float2 v0 = s[l * P::LS + py], v1 = s[(l + 1) * P::LS + py];
+        *reinterpret_cast<float4*>(base + (size_t)y * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        if (halo && (y % P::NL == P::NL - 1 || y == P::L - 1))
+            *reinterpret_cast<float4*>(halo + ((size_t)sub * P::LB + y / P::NL) * P::HP + g * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
     }
 }
 // T tiles T[sub][yb][kx][yi] of column group g -> LDS lines, natural order
@@ -345,12 +352,17 @@ template <class P, int T> __device__ __forceinline__ void pack_u_pair(const u_re
 template <class P> __device__ __forceinline__ void store_t_split(const float2* s, const unsigned short* pp, float2* __restrict__ Ta, float2* __restrict__ Tb, int sub,
                                                                   int yb) {
     const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::HP * P::NL;         // the block's entries (kx, row) are contiguous
-    for (int e = threadIdx.x; e < P::NL * P::H; e += blockDim.x) {
-        const int kx = e / P::NL, row = e - kx * P::NL;
-        const float2* line = s + row * P::LS;
-        const float2 zk = line[pp[kx]], zm = line[pp[kx ? P::L - kx : 0]];
-        Ta[base + e] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        Tb[base + e] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+    // a thread takes a column kx for all rows of the block: one pair of positions, NL / 2 16-byte stores per output array
+    for (int kx = threadIdx.x; kx < P::H; kx += blockDim.x) {
+        const int pk = pp[kx], pm = pp[kx ? P::L - kx : 0];
+        float4* ta = reinterpret_cast<float4*>(Ta + base + (size_t)kx * P::NL);
+        float4* tb = reinterpret_cast<float4*>(Tb + base + (size_t)kx * P::NL);
+#pragma unroll
+        for (int r = 0; r < P::NL; r += 2) {
+            const float2 zk0 = s[r * P::LS + pk], zm0 = s[r * P::LS + pm], zk1 = s[(r + 1) * P::LS + pk], zm1 = s[(r + 1) * P::LS + pm];
+            ta[r / 2] = make_float4(0.5f * (zk0.x + zm0.x), 0.5f * (zk0.y - zm0.y), 0.5f * (zk1.x + zm1.x), 0.5f * (zk1.y - zm1.y));
+            tb[r / 2] = make_float4(0.5f * (zk0.y + zm0.y), 0.5f * (zm0.x - zk0.x), 0.5f * (zk1.y + zm1.y), 0.5f * (zm1.x - zk1.x));
+        }
     }
 }
 // spectrum entry e = l * L + p of the C layout <-> LDS
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
 
 // inverse row pass of kr^, kn^ -> kr, kn -> squares -> forward row pass, T tiles
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
+__global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
                                                          const float2* __restrict__ twg, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2,
                                                          int nsub) {
     extern __shared__ float2 s[];
@@ -510,7 +522,7 @@ struct frame_args {
 
 // cut + forward row pass of a pair of real frames: (N, R) or, with sigma images, (Vn, Vr)
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_img_rows(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta, float2* __restrict__ Tb, int nsub) {
+__global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta, float2* __restrict__ Tb, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK(P::LB, nsub, yb, sub);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
@@ -826,12 +838,12 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
     hipLaunchKernelGGL(k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub);
     float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
-    hipLaunchKernelGGL(k_psf_rows<P>, grow, blk, lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub);
+    hipLaunchKernelGGL(k_psf_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T0, T1, nsub);
+    hipLaunchKernelGGL(k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
-    hipLaunchKernelGGL(k_img_rows<P>, grow, blk, lds, s, fa, tw, T2, T3, nsub);
+    hipLaunchKernelGGL(k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
     hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
     hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;

@@ -15,7 +15,22 @@ for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/z2v/$name/blackbox_amd/libbbx_hip.so $objs /tmp/z2v/$name/z2.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib || exit 1
   cp bench.py /tmp/z2v/$name/; cp tools/dbg/z2_time.py /tmp/z2v/$name/tools/dbg/; cp tools/prof_summary.py /tmp/z2v/$name/tools/
   echo "== $name ($defs)"
-  if [ -n "$PROF" ]; then
+  if [ -n "$PMC" ]; then
+    # effective clock per kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration
+    (cd /tmp/z2v/$name && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/z2v/$name/prof -o r -- python3 tools/dbg/z2_time.py > /tmp/z2v/$name/prof.log 2>&1
+     timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/z2v/$name/pmc -o r -- python3 tools/dbg/z2_time.py > /tmp/z2v/$name/pmc.log 2>&1
+     python3 - <<PY
+import csv, glob, re
+st = {re.sub(r'\(.*', '', r['Name']): float(r['AverageNs']) for r in csv.DictReader(open(glob.glob('/tmp/z2v/$name/prof/*kernel_stats.csv')[0]))}
+acc = {}
+for r in csv.DictReader(open(glob.glob('/tmp/z2v/$name/pmc/*counter_collection.csv')[0])):
+    if r['Counter_Name'] != 'GRBM_GUI_ACTIVE': continue
+    k = re.sub(r'\(.*', '', r['Kernel_Name']); a = acc.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r['Counter_Value'])
+for k, (n, v) in acc.items():
+    if 'z3::' in k and k in st: print('%-40s avg %.0f us  clock %.2f GHz' % (k[:40], st[k] / 1e3, v / n / 8 / st[k]))
+PY
+    )
+  elif [ -n "$PROF" ]; then
     (cd /tmp/z2v/$name && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/z2v/$name/prof -o r -- python3 tools/dbg/z2_time.py > /tmp/z2v/$name/prof.log 2>&1; python3 tools/prof_summary.py /tmp/z2v/$name/prof 7 50 | grep "z[23]::\|total" | cut -c1-40,70-130)
   else
     (cd /tmp/z2v/$name && timeout -k 10 120 python3 tools/dbg/z2_time.py 2>&1 | grep -v "^W2026\|amdgpu.ids" | tail -2)
