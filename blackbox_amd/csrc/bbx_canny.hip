@@ -168,35 +168,53 @@ __global__ __launch_bounds__(256) void k_canny_gauss_v(const float* __restrict__
 // Gaussian along x + normalisation by the filtered all-ones image -> smoothed image, float64.  A workgroup takes 256
 // pixels of one row: the row piece with its halo goes through LDS; the all-ones image depends on the row (v0) and,
 // away from the left / right border, not on the column, so its interior value is computed once per thread from v0.
+#ifndef GH_ROWS
+#define GH_ROWS 8                                          // rows per workgroup: one barrier, one set of weights for all of them
+#endif
 template <int R>
 __global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__ tmp, int ny, int nx, const canny_par* __restrict__ p,
                                                        double* __restrict__ sm) {
-    __shared__ float row[256 + 2 * R];
-    const int x0 = blockIdx.x * 256, x = x0 + threadIdx.x, y = blockIdx.y;
-    const float* src = tmp + (size_t)y * nx;
-    for (int i = threadIdx.x; i < 256 + 2 * R; i += 256) { const int xx = x0 - R + i; row[i] = (xx >= 0 && xx < nx) ? src[xx] : 0.f; }
+    __shared__ double row[GH_ROWS][256 + 2 * R];            // the row pieces, converted once
+    __shared__ double s_v0[GH_ROWS], s_bl[GH_ROWS];         // the all-ones image: after the first pass (per row), after both (away from the borders)
+    const int x0 = blockIdx.x * 256, x = x0 + threadIdx.x, yb = blockIdx.y * GH_ROWS;
+    for (int i = threadIdx.x; i < GH_ROWS * (256 + 2 * R); i += 256) {
+        const int r = i / (256 + 2 * R), c = i - r * (256 + 2 * R), xx = x0 - R + c, yy = yb + r;
+        row[r][c] = (yy < ny && xx >= 0 && xx < nx) ? (double)tmp[(size_t)yy * nx + xx] : 0.0;
+    }
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; j++) w[j] = p->w[j];
-    __syncthreads();
-    if (x >= nx) return;
-    double t = (double)row[threadIdx.x + R] * w[0];
+    if (threadIdx.x < GH_ROWS) {
+        // the all-ones image through the same two passes (float64 throughout): column-independent after the first pass,
+        // and after the second one too wherever the window does not touch the left / right border
+        const int y = yb + threadIdx.x;
+        double v0 = 1.0 * w[0];
 #pragma unroll
-    for (int j = R; j >= 1; j--) t += ((double)row[threadIdx.x + R - j] + (double)row[threadIdx.x + R + j]) * w[j];
-    const float s32 = (float)t;
-    // the all-ones image through the same two passes (float64 throughout)
-    double v0 = 1.0 * w[0];
-#pragma unroll
-    for (int j = R; j >= 1; j--) v0 += ((y - j >= 0 ? 1.0 : 0.0) + (y + j < ny ? 1.0 : 0.0)) * w[j];
-    double bl = v0 * w[0];
-    if (x >= R && x + R < nx) {
+        for (int j = R; j >= 1; j--) v0 += ((y - j >= 0 ? 1.0 : 0.0) + (y + j < ny ? 1.0 : 0.0)) * w[j];
+        double bl = v0 * w[0];
 #pragma unroll
         for (int j = R; j >= 1; j--) bl += (v0 + v0) * w[j];
-    } else {
-#pragma unroll
-        for (int j = R; j >= 1; j--) bl += ((x - j >= 0 ? v0 : 0.0) + (x + j < nx ? v0 : 0.0)) * w[j];
+        s_v0[threadIdx.x] = v0; s_bl[threadIdx.x] = bl;
     }
-    sm[(size_t)y * nx + x] = (double)s32 / (bl + 2.220446049250313e-16);
+    __syncthreads();
+    if (x >= nx) return;
+    const bool inner = x >= R && x + R < nx;
+    for (int r = 0; r < GH_ROWS; r++) {
+        const int y = yb + r;
+        if (y >= ny) break;
+        double t = row[r][threadIdx.x + R] * w[0];
+#pragma unroll
+        for (int j = R; j >= 1; j--) t += (row[r][threadIdx.x + R - j] + row[r][threadIdx.x + R + j]) * w[j];
+        const float s32 = (float)t;
+        double bl = s_bl[r];
+        if (!inner) {
+            const double v0 = s_v0[r];
+            bl = v0 * w[0];
+#pragma unroll
+            for (int j = R; j >= 1; j--) bl += ((x - j >= 0 ? v0 : 0.0) + (x + j < nx ? v0 : 0.0)) * w[j];
+        }
+        sm[(size_t)y * nx + x] = (double)s32 / (bl + 2.220446049250313e-16);
+    }
 }
 
 // Gradients, magnitude, non-maximum suppression and both thresholds on a 64 x 16 tile: the smoothed image with a
@@ -206,7 +224,10 @@ __global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__
 //   the clamped loads below); magnitude sqrt(i^2 + j^2)
 #define CT_X 64
 #define CT_Y 16
-#define CT_NT 8                                            // tiles (stacked in y) per workgroup: one list reservation for all of them
+#ifndef CT_NT
+#define CT_NT 8
+#endif
+//                                                        tiles (stacked in y) per workgroup: one list reservation for all of them
 #define CT_Q 2048                                          // (every workgroup's returning atomic on the one list counter costs ~11 ns)
 __global__ __launch_bounds__(256) void k_canny_tile(const double* __restrict__ sm, int ny, int nx, const canny_par* __restrict__ p,
                                                     uint32_t* list, uint8_t* hflag, int32_t* cnt, uint32_t cap, int32_t* err) {
@@ -304,7 +325,7 @@ int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const doub
     hipLaunchKernelGGL(k_canny_hist<2>, dim3(1024), dim3(256), 0, s, d_bin, n, par, hist);
     hipLaunchKernelGGL(k_canny_scan<2>, dim3(1), dim3(256), 0, s, par, hist);
     hipLaunchKernelGGL(k_canny_params, dim3(1), dim3(64), 0, s, par, n, q1, q2, low_frac, high_frac);
-    const dim3 gx((nx + 255) / 256, ny), gv((nx + 255) / 256, (ny + GV_RY - 1) / GV_RY);
+    const dim3 gx((nx + 255) / 256, (ny + GH_ROWS - 1) / GH_ROWS), gv((nx + 255) / 256, (ny + GV_RY - 1) / GV_RY);
     if (radius == 12) {
         hipLaunchKernelGGL(k_canny_gauss_v<12>, gv, dim3(256), 0, s, d_bin, ny, nx, par, tmp);
         hipLaunchKernelGGL(k_canny_gauss_h<12>, gx, dim3(256), 0, s, tmp, ny, nx, par, sm);
