@@ -50,6 +50,10 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #ifndef Z3_LIGHT_THREADS
 #define Z3_LIGHT_THREADS Z3_THREADS   // k_psf_rows, k_img_rows (nothing parked in registers)
 #endif
+#ifndef Z3_VAR_THREADS
+#define Z3_VAR_THREADS 512     // k_var_cols keeps two spectra in registers
+#define Z3_VAR_MINW 4
+#endif
 #ifndef Z3_MINW
 #define Z3_MINW 6              // waves per SIMD the register allocation must allow (two workgroups of 768 threads)
 #endif
@@ -76,6 +80,7 @@ template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
     static constexpr int NL = L >= 512 ? Z3_NL : 16;                // lines per workgroup
     static constexpr int THREADS = L >= 512 ? Z3_THREADS : 256, FIN_THREADS = L >= 512 ? Z3_FIN_THREADS : 256;
     static constexpr int LIGHT_THREADS = L >= 512 ? Z3_LIGHT_THREADS : 256;
+    static constexpr int VAR_THREADS = L >= 512 ? Z3_VAR_THREADS : 256, VAR_MINW = L >= 512 ? Z3_VAR_MINW : 1;
     static constexpr int G = (H + NL - 1) / NL, HP = G * NL;        // column groups, padded half-spectrum width
     static constexpr int LP = L + L / 8 + 1;                        // padded line: one pad per 8 entries
     static constexpr int LS = line_stride(LP);
@@ -374,7 +379,7 @@ __device__ __forceinline__ int opaque_tid() { int t = (int)threadIdx.x; asm vola
 #define R_LOOP(k, e, l, p)                                                                     \
     for (int t_ = opaque_tid(), once_ = 1; once_; once_ = 0)                                     \
     _Pragma("unroll") for (int k = 0, e, l, p; k < NE; k++)                                      \
-        if (e = t_ + k * P::THREADS, l = e / P::L, p = e - l * P::L, e < P::NL * P::L)
+        if (e = t_ + k * RT, l = e / P::L, p = e - l * P::L, e < P::NL * P::L)        /* RT: the kernel's thread count */
 #define C_LOOP(e, l, p) for (int e = threadIdx.x, l, p; l = e / P::L, p = e - l * P::L, e < P::NL * P::L; e += blockDim.x)
 
 // ---- PSF side ---------------------------------------------------------------------------------
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
     const float2* tw = aux.tw;
     const int h = S / 2;
     const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
-    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    constexpr int RT = P::THREADS, NE = (P::NL * P::L + RT - 1) / RT;
     float2 park[NE];                                               // Pn^, then kn^
     for (int pass = 0; pass < 2; pass++) {
         const float* st = (pass ? psf_r : psf_n) + (size_t)sub * S * S;
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
 #endif
     __syncthreads();
     fft_fwd<P>(s, tw);
-    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    constexpr int RT = P::THREADS, NE = (P::NL * P::L + RT - 1) / RT;
     float2 park[NE];                                               // the partial D^ = A N^ waits in registers
     R_LOOP(k, e, l, p) {
         float2* q = s + l * P::LS + npos(p);
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
 // get their column pass here as well (their row pass is k_psf_rows): a workgroup needs exactly its own column group
 // of them, so they go from the T tiles through the transform into registers and never to HBM as coefficient arrays.
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ Tk2n,
+__global__ __launch_bounds__(P::VAR_THREADS, P::VAR_MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ Tk2n,
                                                          const float2* __restrict__ Tk2r, const float2* __restrict__ twg,
                                                          float2* __restrict__ UVS, const zscal* __restrict__ sc,
                                                          const double* __restrict__ fs_partial, int nsub) {
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_var_cols(const float2* 
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, nsub, sub, sc[sub]);
-    constexpr int NE = (P::NL * P::L + P::THREADS - 1) / P::THREADS;
+    constexpr int RT = P::VAR_THREADS, NE = (P::NL * P::L + RT - 1) / RT;        // two parked arrays: 512 threads, <= 128 VGPRs, no spills
     float2 park[NE], coef[NE];
     load_t_lines<P>(Tk2n, sub, g, s);
     __syncthreads();
@@ -845,7 +850,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     hipLaunchKernelGGL(k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
     hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
-    hipLaunchKernelGGL(k_var_cols<P>, gcol, blk, lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
+    hipLaunchKernelGGL(k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
