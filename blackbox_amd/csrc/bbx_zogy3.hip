@@ -840,22 +840,20 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     const float inv_n2 = 1.0f / ((float)P::L * (float)P::L);
     const dim3 gcol = grid8(P::G, nsub), grow = grid8(P::LB, nsub), blk(P::THREADS);
     const float2* tw = d_tw;
-    bbx_prof_start(ctx, BBX_PROF_ZOGY, s);
-    hipLaunchKernelGGL(k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub);
     float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
-    hipLaunchKernelGGL(k_psf_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_ROWS, k_psf_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
-    hipLaunchKernelGGL(k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
-    hipLaunchKernelGGL(k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
-    hipLaunchKernelGGL(k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
     const dim3 gfin = grid8(yb1 - yb0 + 1, nsub);
-    bbx_prof_stop(ctx, s);
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_ZOGY_FINAL, k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial,
                      inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub);
     BBX_LAUNCH_CHECK();

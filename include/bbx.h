@@ -124,9 +124,14 @@ int  bbx_copy_async(void *dst, const void *src, size_t nbytes, int kind, void *s
 #define BBX_PROF_XTALK 3       /* k_xtalk                                     */
 #define BBX_PROF_VOS_STD 4     /* read-noise passes      (1 group / frame)   */
 #define BBX_PROF_MASK_FINISH 5 /* mask_init tail + fill  (1 group / frame)   */
-#define BBX_PROF_ZOGY 6        /* bbx_zogy_subimages, or the kernels of bbx_zogy_frame before its last one (1 group / frame) */
+#define BBX_PROF_ZOGY 6        /* bbx_zogy_subimages, or (register-DFT core) the kernels of bbx_zogy_frame before its last one */
 #define BBX_PROF_ZOGY_FINAL 7  /* k_final_rows of bbx_zogy_frame (1 launch / frame) */
-#define BBX_PROF_NSLOTS 8
+#define BBX_PROF_Z_PSF_COLS 8  /* the other kernels of bbx_zogy_frame (LDS-pass core), one slot each: k_psf_cols, */
+#define BBX_PROF_Z_PSF_ROWS 9  /*   k_psf_rows, */
+#define BBX_PROF_Z_IMG_ROWS 10 /*   k_img_rows (2 launches / frame), */
+#define BBX_PROF_Z_IMG_COLS 11 /*   k_img_cols, */
+#define BBX_PROF_Z_VAR_COLS 12 /*   k_var_cols */
+#define BBX_PROF_NSLOTS 13
 int  bbx_profile_enable(bbx_ctx *ctx, int on);
 /* synchronises on the recorded events; ms_total/calls have nslots entries; resets */
 int  bbx_profile_read(bbx_ctx *ctx, double *ms_total, int32_t *calls, int nslots);
