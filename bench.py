@@ -19,10 +19,12 @@ rates are also measured briefly and attached to the headline line (other_workloa
   N > 1: one rank per GPU (torch.distributed.run; `--gpus N` alone spawns it); every rank
   reduces its own frames (independent, no data-path collective) -> weak scaling.
 
-Timing: W + K frames go through the frames-in-flight pipeline in one run.  The clock starts
-when the W-th frame completes (pipeline full, no drain in between) and stops after the last
-frame completed and the device is idle: exactly K frames, steady state plus the drain.
-`fill_inclusive` is the rate of all W + K frames including the pipeline fill.
+Timing: depth + W + K + depth frames go through the frames-in-flight pipeline in one run
+(depth = frames in flight).  The clock runs from the completion of the last warm-up frame to the
+completion of the K-th frame after it: exactly K completions with the pipeline full at both
+ends (neither its fill nor its drain inside the region; barrier + device synchronisation
+around the run).  `idle_to_idle` is the rate of all those frames from an idle device to an idle
+device, `long_run` the same steady-state measurement over 240 frames.
 
 Prints ONE JSON line (rank 0) with the roofline of the dominant kernel and a CPU baseline.
 """
@@ -249,38 +251,73 @@ def cpu_baseline(workload):
                                           '(no LA-Cosmic, no ZOGY: packages absent)')
 
 
-def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None):
-    """W + K frames through a FramePipeline; -> dict(dt timed region, dt_all, stats of the pipeline)"""
+def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None, sink=None):
+    """Steady-state rate of a FramePipeline: depth + W + K + depth frames go through it in one run, fed
+    continuously.  The first [depth] frames fill the pipeline, then W warm-up frames; the clock runs from the
+    completion of the last warm-up frame to the completion of the K-th frame after it -- exactly K completions with
+    the pipeline full at both ends ([depth] cool-down frames are still in flight behind the last timed one, so the
+    timed region holds neither the fill nor the drain; a region that ends with the drain reads too fast, because
+    the frames in flight at its start were partly done already).  barrier + device synchronisation before the run
+    and after it.  sink: optional callable(frame) run at each completion (the output stage).
+    -> dict(dt, dt_all (idle to idle, all frames), ...)"""
     from blackbox_amd import _lib
     from blackbox_amd.pipeline import FramePipeline
     pipe = FramePipeline(ctx, tel, geom, pool=pool, depth=depth, lanes=lanes, **kw)
     # untimed: first-use allocations, rocFFT plans, workspace growth of every lane
     pipe.run([(raws[i % len(raws)], {}) for i in range(max(lanes, 2))])
     pipe.t_stats = [0.0, 0.0, 0.0, 0]
-    mark = {}
-    n_all = warmup + steps
+    mark = {'n': 0}
+    first = depth + warmup                      # completions before the clock starts
+    n_all = first + steps + depth
 
     def on_done(idx, f):
-        mark.setdefault('n', 0)
         mark['n'] += 1
-        if mark['n'] == warmup:
+        if sink is not None:
+            sink(f)
+        if mark['n'] == first:
             mark['t0'] = time.perf_counter()
             if prof_ctx is not None:
                 _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
+        elif mark['n'] == first + steps:
+            mark['t1'] = time.perf_counter()
+            if prof_ctx is not None:
+                _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 0), 'bbx_profile_enable')
         mark['last'] = f
     barrier()
     t_all0 = time.perf_counter()
-    if warmup == 0:
-        mark['t0'] = t_all0
-        if prof_ctx is not None:
-            _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
     pipe.run([(raws[i % len(raws)], {}) for i in range(n_all)], on_done=on_done)
     torch.cuda.synchronize()
     barrier()
-    t1 = time.perf_counter()
-    out = dict(dt=t1 - mark['t0'], dt_all=t1 - t_all0, t_stats=list(pipe.t_stats), last=mark.get('last'), nworkers=pipe.pool.n)
+    t_end = time.perf_counter()
+    out = dict(dt=mark['t1'] - mark['t0'], dt_all=t_end - t_all0, n_all=n_all, t_stats=list(pipe.t_stats), last=mark.get('last'),
+               nworkers=pipe.pool.n)
     pipe.close()
     return out
+
+
+def load_pmc(args):
+    """HBM traffic per launch from the tracked PMC summary (profiles/*_pmc_traffic.json: two --pmc passes of this
+    command, FETCH_SIZE / WRITE_SIZE with the gfx950 corrections) -- only while the kernels it was taken from are
+    the ones in the tree: the summary records the SHA-256 of the HIP sources it profiled"""
+    import glob
+    import hashlib
+    if args.small or args.raw != 'u16' or args.workload != 'zogy':
+        return None, 'no PMC summary for this configuration'
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None, 'no PMC summary'
+    path = files[-1]
+    try:
+        j = json.load(open(path))
+        want = j.get('source_sha256', {})
+        if not want:
+            return None, '%s carries no source stamp: not used' % os.path.relpath(path, ROOT)
+        for rel, sha in want.items():
+            if hashlib.sha256(open(os.path.join(ROOT, rel), 'rb').read()).hexdigest() != sha:
+                return None, '%s is stale (%s changed since the PMC run): traffic not reported' % (os.path.relpath(path, ROOT), rel)
+        return j['kernels'], '%s (commit %s)' % (os.path.relpath(path, ROOT), j.get('commit', '?'))
+    except Exception as e:
+        return None, 'PMC summary unreadable: %s' % e
 
 
 def spawn_ranks(n, argv):
@@ -473,40 +510,64 @@ def main():
         zogy_io_model = int(4 * 4 * nsub * L * L + 4 * 4 * N)     # 4 inputs read with the tile overlap, 4 outputs written
         iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items() if iso_calls[sl]}
         live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items() if calls[sl]}
-        # the dominant kernel: the one that costs most on its own (its duration inside the pipeline also carries whatever
-        # the other lanes run beside it, which changes from run to run); its figures below are those of the timed region
-        dom = max((k for k in live if k in iso), key=lambda k: iso[k][0]) if any(k in iso for k in live) else max(live, key=lambda k: live[k][0])
 
         def gbs(t):
             return t[1] / (t[0] * 1e-3) / 1e9
-        roof = dict(bound='hbm', kernel=dom, achieved=gbs(live[dom]), peak=HBM_PEAK_GBS, unit='GB/s',
-                    avg_launch_ms=live[dom][0], launches=int(live[dom][2]), bytes_per_launch=live[dom][1], traffic=None,
-                    others={k: dict(avg_launch_ms=live[k][0], achieved=gbs(live[k]), frac=gbs(live[k]) / HBM_PEAK_GBS)
-                            for k in live if k != dom})
-        roof['frac'] = roof['achieved'] / roof['peak']
-        roof['timing'] = ('HIP events stamped by the launch itself (hipExtLaunchKernelGGL start / stop events: the kernel\'s execution; '
-                          'kernel groups: events recorded around the group) on the launch stream, timed region, lane 0 of %d '
-                          '(other lanes\' kernels run concurrently)' % lanes)
-        roof['isolated'] = {k: dict(avg_launch_ms=iso[k][0], launches=int(iso[k][2]), achieved=gbs(iso[k]),
-                                    frac=gbs(iso[k]) / HBM_PEAK_GBS, note='serial frames, kernel alone on the GPU') for k in iso}
-        if all(k in iso for k in zogy_kernels):
-            per_frame = {k: (2 if k == 'k_img_rows' else 1) for k in zogy_kernels}
-            zms = sum(iso[k][0] * per_frame[k] for k in zogy_kernels)
-            zms_live = sum(live[k][0] * per_frame[k] for k in zogy_kernels) if all(k in live for k in zogy_kernels) else None
-            roof['zogy_stage'] = dict(ms_alone=zms, ms_in_pipeline=zms_live, io_model_bytes=zogy_io_model,
-                                      achieved=zogy_io_model / (zms * 1e-3) / 1e9,
-                                      frac=zogy_io_model / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      moved_bytes_by_design=int(32 * spec + 6 * cut + 16 * N),
-                                      achieved_moved=int(32 * spec + 6 * cut + 16 * N) / (zms * 1e-3) / 1e9,
-                                      note='sum of the seven launches of bbx_zogy_frame; SURVEY 8d I/O-only model (3.79 GB) and the bytes the '
-                                           'design moves: 32 half-spectrum passes + 6 frame cuts + 4 outputs (DESIGN.md section 4b)')
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))['kernels']
-            if not args.small and args.raw == 'u16' and dom in pmc:
+
+        def kdict(t):
+            return dict(avg_launch_ms=t[0], launches=int(t[2]), moved_bytes_per_launch=int(t[1]), achieved_moved=gbs(t),
+                        frac_moved=gbs(t) / HBM_PEAK_GBS)
+        pmc, pmc_note = load_pmc(args)
+        per_frame = {k: (2 if k == 'k_img_rows' else 1) for k in zogy_kernels}
+        # SURVEY 8d frame figure (config 5, u16 raw): calibration 12N(u16)/14N(f32) + LA-Cosmic 22N + xtalk 9N + masks 6N +
+        # sat 8N + mesh 9N + ZOGY 34N + photometry (n_src x S^2 x 3 images x 4 B)
+        Nraw = raw.numel()
+        frame_bytes = int((b_raw * Nraw + 10 * N) + 22 * N)                                       # configs[1]
+        if wl != 'calib':
+            frame_bytes += int(9 * N + 6 * N + 8 * N + 9 * N)                                     # configs[2]
+        if wl == 'zogy':
+            frame_bytes += int(zogy_io_model + 12000 * S * S * 12)                                # configs[4]
+        if wl == 'zogy' and all(k in live for k in zogy_kernels) and all(k in iso for k in zogy_kernels):
+            # the dominant launch group of the headline workload: bbx_zogy_frame = 7 launches per frame (one library call).
+            # achieved = SURVEY 8d algorithmic bytes of the stage (inputs once with the tile overlap + outputs once)
+            # / the summed duration of its launches in the timed region (HIP events stamped by the launches themselves,
+            # lane 0's stream)
+            zms = sum(live[k][0] * per_frame[k] for k in zogy_kernels)
+            zms_iso = sum(iso[k][0] * per_frame[k] for k in zogy_kernels)
+            moved = int(sum(live[k][1] * per_frame[k] for k in zogy_kernels))
+            roof = dict(bound='hbm', kernel='bbx_zogy_frame (launch group: k_psf_cols, k_psf_rows, 2 x k_img_rows, k_img_cols, '
+                                            'k_var_cols, k_final_rows)',
+                        achieved=zogy_io_model / (zms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                        avg_launch_ms=zms, launches=int(min(live[k][2] // per_frame[k] for k in zogy_kernels)),
+                        bytes_per_launch=zogy_io_model, traffic=None,
+                        bytes_model='SURVEY 8d: 4 inputs (new, ref, 2 sigma images) read once with the tile overlap (L/size)^2 + '
+                                    '4 outputs (D, Scorr, Fpsf, Fpsferr) written once = 34N',
+                        alone=dict(avg_launch_ms=zms_iso, achieved=zogy_io_model / (zms_iso * 1e-3) / 1e9,
+                                   frac=zogy_io_model / (zms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   note='serial frames before the timed region: the group alone on the GPU'),
+                        moved_bytes_by_design=moved, achieved_moved=moved / (zms * 1e-3) / 1e9,
+                        frac_moved=moved / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        kernels={k: dict(kdict(live[k]), alone_ms=iso[k][0], per_frame=per_frame[k]) for k in zogy_kernels},
+                        others={k: kdict(live[k]) for k in live if k not in zogy_kernels})
+            if pmc is not None and all(k in pmc for k in zogy_kernels):
+                roof['traffic'] = int(sum(pmc[k]['traffic_bytes_per_launch'] * per_frame[k] for k in zogy_kernels))
+                roof['traffic_per_kernel'] = {k: pmc[k]['traffic_bytes_per_launch'] for k in zogy_kernels}
+        else:
+            dom = 'k_calibrate' if 'k_calibrate' in live else max(live, key=lambda k: live[k][0])
+            roof = dict(bound='hbm', kernel=dom, achieved=gbs(live[dom]), peak=HBM_PEAK_GBS, unit='GB/s',
+                        avg_launch_ms=live[dom][0], launches=int(live[dom][2]), bytes_per_launch=live[dom][1], traffic=None,
+                        others={k: kdict(live[k]) for k in live if k != dom})
+            if dom in iso:
+                roof['alone'] = dict(avg_launch_ms=iso[dom][0], achieved=gbs(iso[dom]), frac=gbs(iso[dom]) / HBM_PEAK_GBS)
+            if pmc is not None and dom in pmc:
                 roof['traffic'] = pmc[dom]['traffic_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r02_pmc_traffic.json'
-        except Exception:
-            pass
+        roof['frac'] = roof['achieved'] / roof['peak']
+        roof['traffic_source'] = pmc_note
+        roof['timing'] = ('HIP events stamped by the launch itself (hipExtLaunchKernelGGL start / stop events: the kernel\'s execution) '
+                          'on the launch stream, over the timed region, lane 0 of %d (other lanes\' kernels run concurrently)' % lanes)
+        roof['frame'] = dict(bytes=frame_bytes, achieved=frame_bytes / (dt / args.steps) / 1e9,
+                             frac=frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                             note='SURVEY 8d algorithmic bytes of a whole frame of this workload (config 5: 11.45 GB with a u16 raw) / ms_per_step')
         shape = '%dx%d raw (%s)' % (raw.shape[0], raw.shape[1], args.raw)
         names = {'zogy': 'configs[4] per frame on one GPU: one %s -> reduce (gain+overscan+flat+mask+LA-Cosmic(niter=3)+xtalk+'
                          'sat trail+counts+edge fill) + optimal_subtraction vs a co-added, background-subtracted reference with its '
@@ -524,10 +585,12 @@ def main():
                    config=dict(workload=names[wl],
                                frames_per_gpu=args.steps, frames_in_flight=depth, stageC_lanes=lanes, host_fit_workers=r['nworkers'],
                                distinct_raw_buffers=nbuf, parallelism='frame-per-gpu x%d (no collective)' % world),
-                   timing='clock from the completion of warm-up frame %d (pipeline full) to device idle after the last of the %d '
-                          'timed frames' % (args.warmup, args.steps),
-                   fill_inclusive=dict(frames=args.warmup + args.steps, frames_per_s=(args.warmup + args.steps) * world / dt_all,
-                                       note='all frames incl. the pipeline fill from an idle device'),
+                   timing='steady state: %d frames fill the pipeline, %d warm-up frames, then the clock runs from the completion of '
+                          'the last warm-up frame to the completion of the %d-th frame after it, with %d more frames in flight '
+                          'behind it (no fill, no drain inside the region); barrier + device synchronisation around the run'
+                          % (depth, args.warmup, args.steps, depth),
+                   idle_to_idle=dict(frames=r['n_all'], frames_per_s=r['n_all'] * world / dt_all,
+                                     note='all frames of the run from an idle device to an idle device (pipeline fill and drain included)'),
                    pipeline_wall_ms_per_frame=dict(zip(['stageA_stats', 'stageB_host_fits', 'stageC_device'],
                                                        [1e3 * t / max(1, r['t_stats'][3]) for t in r['t_stats'][:3]])),
                    single_frame_latency_ms=latency_ms, stage_ms_serial=stage_ms, lacosmic_stats=stats, subtraction=sub_info,
@@ -539,18 +602,21 @@ def main():
             if w2 == wl:
                 continue
             l2, d2 = (6, 18)
-            r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 18, d2, l2, pool, barrier)
+            r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 4, d2, l2, pool, barrier)
             others[w2] = dict(frames_per_s=60 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 60, frames_in_flight=d2, lanes=l2)
         if wl == 'zogy':
             # the same workload against a reference that still carries a sky of its own: its background mesh and
             # sigma image are then made per frame as well (bkg mesh x2)
             ref2 = ref + 120.0
             kw2 = dict(kws['zogy'], subtract=dict(sub_kw, ref=ref2, ref_is_bkgsub=False, ref_bkg_std_mini=None))
-            r2 = run_pipeline(torch, ctx, tel, geom, raws, kw2, 30, 10, depth, lanes, pool, barrier)
+            r2 = run_pipeline(torch, ctx, tel, geom, raws, kw2, 30, 4, depth, lanes, pool, barrier)
             others['zogy_ref_with_sky'] = dict(frames_per_s=30 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 30, frames_in_flight=depth,
                                                lanes=lanes, note='reference not background-subtracted: bkg mesh x2 per frame')
             del ref2
         out['other_workloads'] = others
+        # the same steady-state measurement over a long run (the headline's K frames are few)
+        r3 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 240, 4, depth, lanes, pool, barrier)
+        out['long_run'] = dict(frames=240, frames_per_s=240 / r3['dt'], ms_per_frame=1e3 * r3['dt'] / 240)
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
     pool.close()
     if rank == 0:

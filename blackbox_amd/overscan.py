@@ -400,6 +400,23 @@ def hos_fit(n, mean_hos, std_hos, mask_sat_row=None, bg2_chan9=False,
 # per-channel work units (what the host worker pool executes; pure numpy/scipy,
 # picklable arguments, no GPU)
 # --------------------------------------------------------------------------------
+class OverscanFailure(Exception):
+    """os_corr raised while it was working on channel [chan] (0-based).  Inside the reference's
+    os_corr every warning is an error (blackbox.py:6432), and it rewrites the frame channel by
+    channel IN PLACE; when it raises, blackbox_reduce crops the data sections out of that
+    half-processed array (1541-1585).  So the pixels depend on how far it got: channels before
+    [chan] carry both overscan corrections, channel [chan] its vertical-overscan fit [fit]
+    (the vertical step itself never raises: 6503-6556 fall back to the nanmedian), the others
+    nothing.  args = (chan, fit, coeffs, ok, message): picklable, crosses the worker pool."""
+
+    def __init__(self, chan, fit, coeffs, ok, message):
+        Exception.__init__(self, chan, fit, coeffs, ok, message)
+        self.chan, self.fit, self.coeffs, self.ok, self.message = chan, fit, coeffs, ok, message
+
+    def __str__(self):
+        return 'channel {}: {}'.format(self.chan + 1, self.message)
+
+
 def channel_phase1(c, mean_vos_col, hos, ysz, xsz, poldeg=3, accum='f32seq'):
     """vertical-overscan fit and horizontal-overscan level of channel [c].
     [hos]: gain-corrected overscan rows (hos_rows, dx) float32 as copied from the device.
@@ -410,7 +427,13 @@ def channel_phase1(c, mean_vos_col, hos, ysz, xsz, poldeg=3, accum='f32seq'):
     # overscan rows after the vertical fit: float32 - float64 -> float32 (blackbox.py:6553)
     rl0 = (dy - hos_rows) if c < 8 else 0
     strip = (hos.astype(np.float64) - fit[rl0:rl0 + hos_rows, None]).astype(np.float32)
-    dlevel, _, _ = clipped_stats_flat(strip[:, xsz - 300:xsz], accum=accum)
+    window = strip[:, xsz - 300:xsz]                      # blackbox.py:6565-6566 (python slice on the dx-wide strip)
+    dlevel = clipped_stats_flat(window, accum=accum)[0] if window.size else np.nan
+    if not np.isfinite(dlevel):
+        # the reference subtracts the NaN level from the strip, which overlaps the vertical-overscan
+        # section; the clipped statistics of that section (6572) then warn = raise
+        raise OverscanFailure(c, fit, coeffs, ok, 'level of the horizontal overscan is not finite (window of {} columns)'
+                              .format(window.shape[1]))
     strip -= np.float32(dlevel)
     return dict(fit=fit, coeffs=coeffs, ok=ok, level=level, dlevel=float(dlevel), strip=strip)
 
@@ -473,7 +496,10 @@ def channel_solve(args):
         if r is not None:
             return r
     r = channel_phase1(c, mean_vos_col, hos, ysz, xsz, poldeg, accum)
-    r['oscan'] = channel_phase2(c, r.pop('strip'), xsz, tel, data_limit, None, accum)
+    try:
+        r['oscan'] = channel_phase2(c, r.pop('strip'), xsz, tel, data_limit, None, accum)
+    except Exception as e:
+        raise OverscanFailure(c, r['fit'], r['coeffs'], r['ok'], 'horizontal overscan: {}: {}'.format(type(e).__name__, e))
     return r
 
 

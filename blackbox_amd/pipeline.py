@@ -175,17 +175,32 @@ def _shm_solve(args):
     """worker: both phases of channel [c] of the frame staged in [slot] (ML1 path)"""
     layout, slot, c, ysz, xsz, poldeg, tel, data_limit, accum = args
     a = _arena(layout)
-    r = overscan.channel_solve((c, a.view(slot, 'mean')[c], a.view(slot, 'hos')[c], ysz, xsz, poldeg, tel,
-                                data_limit, accum))
+    try:
+        r = overscan.channel_solve((c, a.view(slot, 'mean')[c], a.view(slot, 'hos')[c], ysz, xsz, poldeg, tel,
+                                    data_limit, accum))
+    except overscan.OverscanFailure as e:
+        return _failed(a, slot, c, e)
     a.view(slot, 'vfit')[c] = r.pop('fit')
     a.view(slot, 'oscan')[c] = r.pop('oscan')
     return r
 
 
+def _failed(a, slot, c, e):
+    """a channel on which os_corr would have raised: its vertical fit is kept (the reference had subtracted it
+    already), the horizontal vector is zero; the driver sorts out which channels count (_partial_overscan)"""
+    a.view(slot, 'vfit')[c] = e.fit
+    a.view(slot, 'oscan')[c] = 0.0
+    return dict(failed=str(e), coeffs=e.coeffs, ok=e.ok, level=0.0, dlevel=0.0)
+
+
 def _shm_phase1(args):
     layout, slot, c, ysz, xsz, poldeg, accum = args
     a = _arena(layout)
-    r = overscan.channel_phase1(c, a.view(slot, 'mean')[c], a.view(slot, 'hos')[c], ysz, xsz, poldeg, accum)
+    try:
+        r = overscan.channel_phase1(c, a.view(slot, 'mean')[c], a.view(slot, 'hos')[c], ysz, xsz, poldeg, accum)
+    except overscan.OverscanFailure as e:
+        a.view(slot, 'strip')[c] = 0.0
+        return _failed(a, slot, c, e)
     a.view(slot, 'vfit')[c] = r.pop('fit')
     a.view(slot, 'strip')[c] = r.pop('strip')
     return r
@@ -194,14 +209,18 @@ def _shm_phase1(args):
 def _shm_phase2(args):
     layout, slot, c, xsz, tel, data_limit, msr, accum = args
     a = _arena(layout)
-    a.view(slot, 'oscan')[c] = overscan.channel_phase2(c, a.view(slot, 'strip')[c], xsz, tel, data_limit, msr, accum)
+    try:
+        a.view(slot, 'oscan')[c] = overscan.channel_phase2(c, a.view(slot, 'strip')[c], xsz, tel, data_limit, msr, accum)
+    except Exception as e:
+        a.view(slot, 'oscan')[c] = 0.0
+        return dict(failed='channel {}: horizontal overscan: {}: {}'.format(c + 1, type(e).__name__, e))
     return c
 
 
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
                  'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane', 'err',
-                 'sub', 'failed', 'os_ok')
+                 'sub', 'failed', 'os_ok', 'os_fail')
 
 
 class _LaneCtx:
@@ -463,6 +482,24 @@ class FramePipeline:
         f.res2 = self.pool.submit(_shm_phase2, tasks)
         f.state = 'B2'
 
+    def _partial_overscan(self, f, results):
+        """channels on which os_corr would have raised (overscan.OverscanFailure): the reference stops at the first
+        of them and crops its half-processed array -- keep the vectors of the channels before it and the vertical
+        fit of that one, zero the rest (the arena holds the vectors the device stage uploads)"""
+        f.os_fail = None
+        if results is None:
+            return None
+        bad = [c for c, r in enumerate(results) if r.get('failed')]
+        if bad:
+            k = bad[0]
+            f.os_fail = (k, results[k]['failed'])
+            self.arena.view(f.slot, 'vfit')[k + 1:] = 0.0
+            self.arena.view(f.slot, 'oscan')[k:] = 0.0
+            if self.log is not None:
+                self.log.error('frame %d: os_corr failed (%s); adopting an overscan of zero for all channels', f.idx,
+                               results[k]['failed'])
+        return results
+
     # ---- stage C ------------------------------------------------------------------
     def _device_stage(self, f, results):
         ctx = self.lane_ctx[f.lane]
@@ -486,6 +523,21 @@ class FramePipeline:
             zs = R.zero_overscan_solution(ctx, h, geom)
             sol.vfit, sol.oscan, sol.d_vfit, sol.d_oscan = zs.vfit, zs.oscan, zs.d_vfit, zs.d_oscan
             h['N-INFNAN'] = (int(f.h_ninf.item()), 'number of pixels with infinite/nan values')
+            d_std.fill_(10.0)
+            f.os_ok = False
+        elif getattr(f, 'os_fail', None) is not None:
+            # os_corr raised part-way: the crop of the reference's half-processed array (_partial_overscan)
+            k = f.os_fail[0]
+            for c, r in enumerate(results[:k + 1]):
+                if r.get('coeffs') is not None:
+                    for (key, comment), v in zip(self._k_bias[c], r['coeffs']):
+                        h[key] = (float(v) if np.isfinite(v) else 'None', comment)
+                    h[self._k_vfitok[c][0]] = (bool(r['ok']), self._k_vfitok[c][1])
+            R.zero_overscan_solution(None, h, geom, header_only=True)
+            h['N-INFNAN'] = (int(f.h_ninf.item()), 'number of pixels with infinite/nan values')
+            sol.vfit, sol.oscan = self.arena.view(f.slot, 'vfit'), self.arena.view(f.slot, 'oscan')
+            sol.d_vfit, sol.d_oscan = sl['d_vfit'], sl['d_oscan']
+            check(lib.bbx_copy_async(*sl['cp_vo'], sp), 'bbx_copy_async')
             d_std.fill_(10.0)
             f.os_ok = False
         else:
@@ -670,8 +722,9 @@ class FramePipeline:
                         if self.log is not None:
                             self.log.error('frame %d: overscan fits failed (%s); adopting an overscan of zero', f.idx, e)
                         results = None
+                    results = self._partial_overscan(f, results)
                     f.state = 'Q'                                  # queued at its lane
-                    second = self.two_phase and results is not None
+                    second = self.two_phase and results is not None and f.os_fail is None
                     self.lane_thread[f.lane].q.put((self._satcol if second else self._device_stage, f, results))
                     progressed = True
                 elif f.state == 'S' and lib.bbx_event_query(f.evS) == 1:
@@ -679,7 +732,11 @@ class FramePipeline:
                     progressed = True
                 elif f.state == 'B2' and f.res2.ready():
                     try:
-                        f.res2.get()
+                        r2 = f.res2.get()
+                        bad = [c for c, r in enumerate(r2) if isinstance(r, dict)]
+                        if bad:
+                            f.p1[bad[0]] = dict(f.p1[bad[0]], failed=r2[bad[0]]['failed'])
+                            f.p1 = self._partial_overscan(f, f.p1)
                     except Exception as e:
                         if self.log is not None:
                             self.log.error('frame %d: overscan fits failed (%s); adopting an overscan of zero', f.idx, e)

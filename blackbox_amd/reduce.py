@@ -175,35 +175,58 @@ def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
               'bbx_satcol_counts', ctx.h)
         cnt = d_cnt.cpu().numpy()
         mask_sat_rows = (cnt[0] >= 3) | (cnt[1] >= 10)
-    oscan = np.empty((16, xsz))
+    oscan = np.zeros((16, xsz))
     aux = dict(dlevel=[], mean_hos=[], n_hos=[])
     strips = []
+    failure = None
     for c in range(16):
         # horizontal overscan rows after the vertical fit: float32 - float64 -> float32
         rl0 = (dy - hos_rows) if c < 8 else 0
         strip = (hos[c].astype(np.float64) - vfit[c][rl0:rl0 + hos_rows, None]).astype(np.float32)
-        dlevel, _, _ = overscan.clipped_stats_flat(strip[:, xsz - 300:xsz], accum=accum)
+        window = strip[:, xsz - 300:xsz]                   # blackbox.py:6565-6566: python slice on the dx-wide strip
+        dlevel = overscan.clipped_stats_flat(window, accum=accum)[0] if window.size else np.nan
+        if not np.isfinite(dlevel):
+            failure = overscan.OverscanFailure(c, vfit[c], None, None, 'level of the horizontal overscan is not finite '
+                                               '(window of {} columns)'.format(window.shape[1]))
+            break
         strip -= np.float32(dlevel)
         strips.append(strip)
         aux['dlevel'].append(float(dlevel))
     # read noise per channel on the GPU (float64 accumulators); runs while the host fits
     d_std = torch.empty(16, dtype=torch.float64, device=dev)
-    check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit),
-                          _lib.f32x16(np.float32(aux['dlevel'])), _ptr(d_std), ctx.stream()),
-          'bbx_vos_std', ctx.h)
-    for c in range(16):
-        data_hos = strips[c][:, :xsz]
-        if tel == 'ML1':
-            mask_hos = overscan.hos_mask_ml1(data_hos, data_limit)
-            msr = None
-        else:
-            msr = mask_sat_rows[c]
-            mask_hos = np.zeros(data_hos.shape, dtype=bool) | msr[None, :]
-        n, mean_hos, std_hos = overscan.hos_column_stats(data_hos, mask_hos, accum=accum)
-        oscan[c] = overscan.hos_fit(n, mean_hos, std_hos, msr, bg2_chan9=(tel == 'BG2' and c == 8),
-                                    accum=accum)
+    if failure is None:
+        check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit),
+                              _lib.f32x16(np.float32(aux['dlevel'])), _ptr(d_std), ctx.stream()),
+              'bbx_vos_std', ctx.h)
+    for c in range(16 if failure is None else failure.chan):
+        try:
+            data_hos = strips[c][:, :xsz]
+            if tel == 'ML1':
+                mask_hos = overscan.hos_mask_ml1(data_hos, data_limit)
+                msr = None
+            else:
+                msr = mask_sat_rows[c]
+                mask_hos = np.zeros(data_hos.shape, dtype=bool) | msr[None, :]
+            n, mean_hos, std_hos = overscan.hos_column_stats(data_hos, mask_hos, accum=accum)
+            oscan[c] = overscan.hos_fit(n, mean_hos, std_hos, msr, bg2_chan9=(tel == 'BG2' and c == 8),
+                                        accum=accum)
+        except Exception as e:
+            failure = overscan.OverscanFailure(c, vfit[c], None, None, 'horizontal overscan: {}: {}'.format(type(e).__name__, e))
+            oscan[c] = 0.0
+            break
         aux['mean_hos'].append(mean_hos)
         aux['n_hos'].append(n)
+    if failure is not None:
+        # how far the reference's in-place os_corr had got when it raised (overscan.OverscanFailure):
+        # channels before the failing one fully corrected, that one by its vertical fit, the rest untouched
+        k = failure.chan
+        vfit[k + 1:] = 0.0
+        oscan[k:] = 0.0
+        for c in range(k + 1, 16):
+            for key in ['VFITOK{}'.format(c + 1)] + ['BIAS{}A{}'.format(c + 1, j) for j in range(settings.voscan_poldeg + 1)]:
+                header.pop(key, None)
+        failure.partial = (vfit, oscan)
+        raise failure
     std_vos = d_std.cpu().numpy()
     for c in range(16):
         header['BIASM{}'.format(c + 1)] = (float(mean_vos[c]), '[e-] channel {} mean vertical overscan'.format(c + 1))
@@ -491,10 +514,12 @@ def step_mark(ctx, d_steps, step):
     check(lib.bbx_step_mark(ctx.h, C.c_void_p(d_steps.data_ptr() + 4 * k), ctx.stream()), 'bbx_step_mark', ctx.h)
 
 
-def zero_overscan_solution(ctx, header, geom):
+def zero_overscan_solution(ctx, header, geom, partial=None, header_only=False):
     """the reference's fallback when os_corr raises (blackbox.py:1546-1585): adopt an overscan of
     zero for all channels -- the data sections are only cropped -- with BIASM{c} = 0, RDN{c} = 10,
-    BIASMEAN = 0, RDNOISE = 10"""
+    BIASMEAN = 0, RDNOISE = 10.  partial = (vfit, oscan): what the reference's in-place os_corr had
+    subtracted from the channels it got through before it raised (overscan.OverscanFailure) -- the
+    crop is taken from that half-processed array, so those channels keep their correction"""
     dy = geom.ny_raw // 2
     for c in range(16):
         header['BIASM{}'.format(c + 1)] = (0.0, '[e-] channel {} mean vertical overscan'.format(c + 1))
@@ -502,10 +527,17 @@ def zero_overscan_solution(ctx, header, geom):
         header['RDN{}'.format(c + 1)] = (10.0, '[e-] channel {} sigma (STD) vertical overscan'.format(c + 1))
     header['BIASMEAN'] = (0.0, '[e-] average all channel means vert. overscan')
     header['RDNOISE'] = (10.0, '[e-] average all channel sigmas vert. overscan')
+    if header_only:
+        return None
     sol = OverscanSolution()
-    sol.vfit, sol.oscan = np.zeros((16, dy)), np.zeros((16, geom.xsize_chan))
-    sol.d_vfit = torch.zeros(16 * dy, dtype=torch.float64, device=ctx.device)
-    sol.d_oscan = torch.zeros(16 * geom.xsize_chan, dtype=torch.float64, device=ctx.device)
+    if partial is not None:
+        sol.vfit, sol.oscan = (np.ascontiguousarray(a, np.float64) for a in partial)
+        sol.d_vfit = torch.from_numpy(sol.vfit.reshape(-1)).to(ctx.device)
+        sol.d_oscan = torch.from_numpy(sol.oscan.reshape(-1)).to(ctx.device)
+    else:
+        sol.vfit, sol.oscan = np.zeros((16, dy)), np.zeros((16, geom.xsize_chan))
+        sol.d_vfit = torch.zeros(16 * dy, dtype=torch.float64, device=ctx.device)
+        sol.d_oscan = torch.zeros(16 * geom.xsize_chan, dtype=torch.float64, device=ctx.device)
     sol.aux = None
     return sol
 
@@ -561,10 +593,10 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
     try:
         sol = os_solve(ctx, raw, header, tel, geom, accum=accum)
         os_ok = True
-    except Exception:
+    except Exception as e:
         # os_corr failed: adopt an overscan of zero for all channels (blackbox.py:1537-1585)
         logexc('os_corr; adopting an overscan of zero for all channels')
-        sol = zero_overscan_solution(ctx, header, geom)
+        sol = zero_overscan_solution(ctx, header, geom, partial=getattr(e, 'partial', None))
         os_ok = False
     header['OS-P'] = (os_ok, 'corrected for overscan?')
     # non-linearity correction (off upstream: set_bb.correct_nonlin False): done inside the fused

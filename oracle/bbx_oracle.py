@@ -365,18 +365,25 @@ def vos_fit(mean_vos_col, nrows, i_chan, poldeg=3):
     return fit, p[::-1], polyfit_ok, level
 
 
+class OsCorrError(Exception):
+    """what makes the reference's os_corr raise: inside it every warning is an error
+    (blackbox.py:6432)"""
+
+
 def os_corr(data, ysize_chan, xsize_chan, tel='ML1', gain=None, satlevel=None,
-            data_limit=2000, accum='f64', ypix_lim=None):
+            data_limit=2000, accum='f64', ypix_lim=None, header=None):
     """blackbox.py:6407-6879.  [data] float32 raw-shaped array after gain_corr,
     modified in place like the reference does; returns (data_out float32
-    without overscans, header dict, aux dict with the 1-D vectors)."""
+    without overscans, header dict, aux dict with the 1-D vectors).  [header]: a dict
+    to fill (it keeps the keys of the channels done when the function raises, as
+    the reference's header does)."""
     chan_sec, data_sec, os_sec_hori, os_sec_vert, data_sec_red = \
         define_sections(data.shape, ysize_chan, xsize_chan)
     ncols, nrows = xsize_chan, ysize_chan
     data_out = np.zeros((nrows * NY, ncols * NX), dtype='float32')
     mean_vos = np.zeros(16)
     std_vos = np.zeros(16)
-    header = {}
+    header = {} if header is None else header
     aux = dict(vfit=[], oscan=[], dlevel=[], mean_hos=[], std_hos=[], n_hos=[],
                mean_vos_col=[])
     nrows_chan = data[chan_sec[0]].shape[0]
@@ -403,6 +410,12 @@ def os_corr(data, ysize_chan, xsize_chan, tel='ML1', gain=None, satlevel=None,
         dlevel, _, _ = sigma_clipped_stats_flat(hos[:, ncols - 300:ncols],
                                                 accum=accum)
         hos -= np.float32(dlevel)
+        if not np.isfinite(dlevel):
+            # an empty window (channels narrower than 300 columns: the slice is taken on
+            # the strip incl. the overscan columns) gives a NaN level; the NaN strip
+            # overlaps the vertical-overscan section, whose clipped statistics (6572)
+            # then warn "Input data contains invalid values" = raise
+            raise OsCorrError('channel {}: level of the horizontal overscan is not finite'.format(c + 1))
         _, std_vos[c], _ = sigma_clipped_stats_flat(data[os_sec_vert[c]],
                                                     mask_value=0, accum=accum)
         # ---- horizontal overscan ----------------------------------------------
@@ -441,6 +454,31 @@ def os_corr(data, ysize_chan, xsize_chan, tel='ML1', gain=None, satlevel=None,
     header['BIASMEAN'] = float(np.nanmean(mean_vos))
     header['RDNOISE'] = float(np.nanmean(std_vos))
     return data_out, header, aux
+
+
+def os_corr_or_zero(data, ysize_chan, xsize_chan, **kw):
+    """os_corr inside blackbox_reduce's try / except (blackbox.py:1531-1591): when it raises,
+    "adopt an overscan of zero for all channels" = crop the data sections out of the array
+    os_corr was modifying in place (channels done before the failure keep their
+    correction, the failing one its vertical-overscan subtraction), BIASM{c} = 0,
+    RDN{c} = 10, BIASMEAN = 0, RDNOISE = 10, OS-P False.  -> (data_out, header)"""
+    header = {}
+    try:
+        data_out, header, _ = os_corr(data, ysize_chan, xsize_chan, header=header, **kw)
+        header['OS-P'] = True
+    except Exception:
+        _, data_sec, _, _, data_sec_red = define_sections(data.shape, ysize_chan, xsize_chan)
+        data_out = np.zeros((ysize_chan * NY, xsize_chan * NX), dtype='float32')
+        for c in range(16):
+            data_out[data_sec_red[c]] = data[data_sec[c]]
+        for c in range(16):
+            header['BIASM{}'.format(c + 1)] = 0.0
+        for c in range(16):
+            header['RDN{}'.format(c + 1)] = 10.0
+        header['BIASMEAN'] = 0.0
+        header['RDNOISE'] = 10.0
+        header['OS-P'] = False
+    return data_out, header
 
 
 # --------------------------------------------------------------------------------

@@ -193,6 +193,49 @@ def psf_optflux(D, V, psfs, ys, xs):
     return flux, err
 
 
+def psf_optflux_vec(D, V, psfs, ys, xs):
+    """psf_optflux for many sources: the same sums (float64, pixels outside the frame or with V <= 0
+    skipped) formed with array operations per source; psfs [nsrc, S, S] or one stamp [S, S] for all"""
+    D = np.asarray(D); V = np.asarray(V)
+    one = np.ndim(psfs) == 2
+    S = psfs.shape[-1]
+    h = S // 2
+    ny, nx = D.shape
+    nsrc = len(ys)
+    flux = np.zeros(nsrc, F); err = np.zeros(nsrc, F)
+    for k in range(nsrc):
+        y0, x0 = int(ys[k]) - h, int(xs[k]) - h
+        ja, jb, ia, ib = max(0, -y0), min(S, ny - y0), max(0, -x0), min(S, nx - x0)
+        if ja >= jb or ia >= ib:
+            continue
+        p = (psfs if one else psfs[k])[ja:jb, ia:ib].astype(np.float64)
+        d = D[y0 + ja:y0 + jb, x0 + ia:x0 + ib].astype(np.float64)
+        v = V[y0 + ja:y0 + jb, x0 + ia:x0 + ib].astype(np.float64)
+        ok = v > 0
+        num = (p[ok] * d[ok] / v[ok]).sum()
+        den = (p[ok] * p[ok] / v[ok]).sum()
+        if den > 0:
+            flux[k], err[k] = F(num / den), F(1.0 / np.sqrt(den))
+    return flux, err
+
+
+def find_transients_fast(Scorr, nsigma=6.0, regions=False):
+    """find_transients for big frames: the same regions and peaks through ndimage.find_objects (the C order of a
+    region's pixels inside its bounding box is their C order in the frame: same pixel on ties).
+    regions=True -> (label image, [(y, x, peak, (y0, y1, x0, x1)) per label 1..n]): the bounding boxes as well"""
+    a = np.abs(Scorr)
+    lab, n = ndimage.label(a >= nsigma, structure=np.ones((3, 3), bool))
+    out = []
+    for k, sl in enumerate(ndimage.find_objects(lab), start=1):
+        sub = np.where(lab[sl] == k, a[sl], -1.0)
+        j, i = np.unravel_index(np.argmax(sub), sub.shape)
+        y, x = sl[0].start + int(j), sl[1].start + int(i)
+        out.append((y, x, float(Scorr[y, x]), (sl[0].start, sl[0].stop, sl[1].start, sl[1].stop)))
+    if regions:
+        return lab, out
+    return sorted(t[:3] for t in out)
+
+
 def find_transients(Scorr, nsigma=6.0):
     """connected regions (8-conn) of |Scorr| >= nsigma -> list of (y, x, peak) of the pixel
     with the largest |Scorr| per region (first in C order on ties), sorted by (y, x)"""

@@ -116,21 +116,31 @@ def test_background_mesh_fullsize(scene):
     np.testing.assert_allclose(bstd.cpu().numpy(), bstd_o, rtol=2e-6)
 
 
-@pytest.mark.parametrize('core', [1, 0], ids=['core-ldspasses', 'core-regdft'])
-def test_zogy_fullsize(scene, core):
+@pytest.mark.parametrize('core,branch', [(1, 'ref-with-mesh'), (1, 'ref-bkgsub'), (0, 'ref-with-mesh')],
+                         ids=['core-ldspasses', 'core-ldspasses-refbkgsub', 'core-regdft'])
+def test_zogy_fullsize(scene, core, branch):
     """optimal_subtraction on the full frame (64 sub-images of 1400^2) against the oracle's
     run_zogy on whole sub-images (a corner, an interior one, the last one); every injected
-    transient is recovered with its flux.  Both 1-D transform cores of bbx_zogy_frame
-    (BBX_OPT_ZOGY_CORE = 3: 1 = radix passes 5*7*5*8 in LDS, the default; 0 = register DFTs 35*40)."""
+    transient is recovered with its flux; the transient list of those sub-images and the PSF
+    photometry of the catalogue against the oracle.  Both 1-D transform cores of bbx_zogy_frame
+    (BBX_OPT_ZOGY_CORE = 3: 1 = radix passes 5*7*5*8 in LDS, the default; 0 = register DFTs 35*40) and both
+    ways a reference comes: with its own sky (mesh + sigma image made here) or as buildref delivers
+    it -- background-subtracted with its `_bkg_std_mini` image ('ref-bkgsub': the configuration bench.py times)."""
     from blackbox_amd._lib import lib
     ctx = scene['ctx']
     assert lib.bbx_set_option(ctx.h, 3, core) == 0
     pn, pr = bench.moffat_stamp(25, 4.0), bench.moffat_stamp(25, 3.6)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)       # noqa: E731
     dx, dy = 0.03, 0.02
+    kw = dict(ref_is_bkgsub=False)
+    if branch == 'ref-bkgsub':
+        kw = dict(ref_is_bkgsub=True, ref_bkg_std_mini=np.full((NY // BOX, NX // BOX), 8.0, F))
     res = G.optimal_subtraction(ctx, scene['data'], scene['ref'], scene['mask'], scene['ref_mask'], d(pn), d(pr),
-                                fratio=1.0, dx=dx, dy=dy, ref_is_bkgsub=False, cat_extract=True)
+                                fratio=1.0, dx=dx, dy=dy, cat_extract=True, **kw)
     ctx.sync()
+    if branch == 'ref-bkgsub':
+        assert res['ref_bkgsub'] is scene['ref'] and 'bkg_mini_ref' not in res          # no mesh of the reference
+        assert float(res['bkg_std_ref'].min()) == float(res['bkg_std_ref'].max()) == 8.0
     hdr = res['header_trans']
     assert res['header_new']['Z-P'][0] is True and hdr['Z-SIZE'][0] == SIZE and hdr['Z-BSIZE'][0] == BORDER
     nsx = NX // SIZE
@@ -153,6 +163,7 @@ def test_zogy_fullsize(scene, core):
         return out
     Pn, Pr = embed(pn), embed(pr)
     worst = {}
+    trans_h = res['transients']
     for (sy, sx) in ((0, 0), (3, 4), (7, 7)):
         k = sy * nsx + sx
         sn, sr = res['scal'][k, 0], res['scal'][k, 1]
@@ -168,6 +179,7 @@ def test_zogy_fullsize(scene, core):
         a = np.abs(cut(Nw, sy, sx)) + np.abs(cut(Rw, sy, sx))
         big = np.maximum(a.max(axis=1)[:, None], a.max(axis=0)[None, :])[inner]
         fe = Fe[inner]
+        tols = {}
         for key, want in (('D', D), ('Scorr', Sc), ('Fpsf', Fp), ('Fpsferr', Fe)):
             got = res[key][tile].cpu().numpy()
             want = want[inner]
@@ -180,12 +192,46 @@ def test_zogy_fullsize(scene, core):
             # Fpsf: x 6; Scorr = S / sigma_S with sigma_S / F_S = Fpsferr)
             unit = {'D': 1.0, 'Fpsf': 6.0, 'Fpsferr': 6.0, 'Scorr': 6.0 / np.maximum(fe, 1e-3)}[key]
             tol = 5e-3 * noise + 4e-6 * big * unit
+            tols[key] = tol
             err = np.abs(got - want)
             worst[(key, k)] = (float((err[ok] / noise).max()), float((err[ok] / tol[ok]).max()))
             assert (err[ok] <= tol[ok]).all(), (key, (sy, sx), worst[(key, k)], noise)
             # on lines without a bright star (nothing above 2000 e-) the local-noise term alone holds
             sky = ok & (big < 2e3)
             assert sky.sum() > 0.3 * sky.size and (err[sky] <= 6e-3 * noise).all(), (key, (sy, sx), float((err[sky] / noise).max()))
+        # ---- the transient list of this sub-image (get_trans: 8-connected regions of |Scorr| >= 6, peak pixel, Fpsf
+        # and Fpsferr there) against the oracle's finder on the oracle's own Scorr.  Compared: the regions that lie
+        # inside the tile, a pixel off its seams (beyond a seam the stitched frame holds the neighbouring sub-image's
+        # evaluation, which agrees with this one's border only roughly -- that is what the borders are for); a peak of
+        # the product inside the tile must be such a region's, or belong to an oracle region that leaves the tile.
+        # Peaks within 0.05 of the threshold may exist on one side only (the two images differ by the tolerance above).
+        y0, x0 = sy * SIZE - BORDER, sx * SIZE - BORDER
+        sc_o = np.where(np.isfinite(Sc), Sc, 0).astype(F)
+        lab_o, regs = Z.find_transients_fast(sc_o, 6.0, regions=True)
+        inside = lambda b: b[0] > BORDER and b[1] < BORDER + SIZE and b[2] > BORDER and b[3] < BORDER + SIZE      # noqa: E731
+        want_t = {(y + y0, x + x0): v for (y, x, v, box) in regs if inside(box)}
+        open_lab = {k + 1 for k, r in enumerate(regs) if not inside(r[3])}
+        got_t = {(t['y'], t['x']): t for t in trans_h
+                 if sy * SIZE + 1 <= t['y'] < (sy + 1) * SIZE - 1 and sx * SIZE + 1 <= t['x'] < (sx + 1) * SIZE - 1
+                 and int(lab_o[t['y'] - y0, t['x'] - x0]) not in open_lab}
+        sure_w = {p for p, v in want_t.items() if abs(v) >= 6.05}
+        sure_g = {p for p, t in got_t.items() if abs(t['scorr']) >= 6.05}
+        miss_w = sorted(p for p in sure_w if not near(p, got_t))
+        miss_g = sorted(p for p in sure_g if not near(p, want_t))
+        assert not miss_w and not miss_g, ((sy, sx), miss_w, miss_g)
+        assert len(sure_w) >= 3
+        nsame = 0
+        for p in sure_w:
+            q = p if p in got_t else near(p, got_t)[0]
+            nsame += q == p
+            t = got_t[q]
+            yy, xx = q[0] - y0, q[1] - x0
+            # the values the operator reports = the images at the peak: the images' own per-pixel tolerance
+            ti = (yy - BORDER, xx - BORDER)
+            assert t['scorr'] == pytest.approx(float(Sc[yy, xx]), abs=float(tols['Scorr'][ti])), (q, t)
+            assert t['fpsferr'] == pytest.approx(float(Fe[yy, xx]), abs=float(tols['Fpsferr'][ti])), (q, t)
+            assert t['fpsf'] == pytest.approx(float(Fp[yy, xx]), abs=float(tols['Fpsf'][ti])), (q, t)
+        assert nsame >= 0.9 * len(sure_w)
     print('ZOGY full size, max |HIP - oracle| (/ local noise, / tolerance):', worst)
     assert lib.bbx_set_option(ctx.h, 3, 1) == 0
     # Scorr of the unmasked frame ~ N(0, 1) (QC ranges set_qc.py:382-383)
@@ -205,7 +251,23 @@ def test_zogy_fullsize(scene, core):
         assert abs(near[0]['fpsf'] - fl) <= 3.5 * near[0]['fpsferr'] + 0.06 * fl, (ty, tx, fl, near[0])
         nfound += 1
     assert nfound >= 20
-    # catalogue: sources with PSF-weighted optimal fluxes
+    # ---- catalogue (a17): the source list = peaks of the 8-connected regions of the background-subtracted frame
+    # above 5 x S-BKGSTD on unmasked pixels, PSF-weighted optimal flux of each with the variance max(D, 0) + sigma^2
+    # (bbx_psf_optflux_sigma) -- positions identical to the oracle's finder on the same frame, fluxes of 1500
+    # sources spread over the list against the oracle's psf_optflux
     cat = res['catalog']
     assert cat is not None and len(cat['X_POS']) > 5000
     assert np.isfinite(cat['E_FLUX_OPT']).all() and (cat['E_FLUXERR_OPT'] > 0).all()
+    work_h, sig_h = Nw.cpu().numpy(), res['bkg_std'].cpu().numpy()
+    thr = 5.0 * res['header_new']['S-BKGSTD'][0]
+    peaks_o = [(y, x, v) for (y, x, v) in Z.find_transients_fast(work_h, thr) if v > 0 and mask_h[y, x] == 0]
+    ys_c, xs_c = cat['Y_POS'].astype(np.int64) - 1, cat['X_POS'].astype(np.int64) - 1
+    assert [(y, x) for y, x, _ in peaks_o] == list(zip(ys_c.tolist(), xs_c.tolist()))
+    assert np.array_equal(cat['E_FLUX_PEAK'], np.asarray([v for *_, v in peaks_o], F))
+    pick = np.unique(np.concatenate([np.arange(0, ys_c.size, max(1, ys_c.size // 1500)), np.argsort(cat['E_FLUX_PEAK'])[-50:],
+                                     np.argsort(ys_c)[:20], np.argsort(xs_c)[-20:]]))
+    assert pick.size >= 1000
+    V_h = (np.maximum(work_h, F(0)) + sig_h * sig_h).astype(F)
+    f_o, e_o = Z.psf_optflux_vec(work_h, V_h, pn, ys_c[pick], xs_c[pick])
+    np.testing.assert_allclose(cat['E_FLUX_OPT'][pick], f_o, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(cat['E_FLUXERR_OPT'][pick], e_o, rtol=1e-5)

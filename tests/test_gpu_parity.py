@@ -374,3 +374,52 @@ def test_saturated_frame_one_percent(ctx):
     assert ((o_mask & 8) != 0).sum() > 0                           # and connected pixels around them
     assert np.array_equal(got, o_mask)
     assert int(d_nobj.item()) == int(oh['NOBJ-SAT'])
+
+
+def test_config0_2048_bias_flat(ctx, monkeypatch):
+    """BASELINE configs[0] through the product: a 2048 x 2048 float32 frame (2 x 8 channels of 1024 x 256 + overscans),
+    bias + flat only, bit-exact against what the REFERENCE's own gain_corr / os_corr-in-try-except / -= mbias /
+    /= mflat make of it (tests/golden/cfg0_2048.npz, oracle/gen_golden_cfg0.py).  The reference's os_corr raises on
+    channels narrower than 300 columns; blackbox_reduce then adopts an overscan of zero and crops the array os_corr
+    had half processed in place (channel 1 carries its vertical-overscan fit).  reduce_object and the frame pipeline
+    follow: OS-P False, BIASMEAN 0, RDNOISE 10, identical pixels."""
+    g = np.load(os.path.join(GOLD, 'cfg0_2048.npz'))
+    meta = json.loads(str(g['meta']))
+    ys, xs, tel, ss = meta['ysize_chan'], meta['xsize_chan'], meta['tel'], meta['subsample']
+    case = synth.make_case(ys, xs, meta['seed'], tel=tel, os_y=meta['os_y'], os_x=meta['os_x'], with_bias=True, **meta['kw'])
+    raw = case['raw'].astype(np.float32)
+    assert hashlib.sha256(raw.tobytes()).hexdigest() == meta['sha_raw_f32']
+    ghdr = json.loads(str(g['header']))
+    monkeypatch.setattr(settings, 'subtract_mbias', {'ML1': True, 'BG': True})     # "bias + flat": the generator subtracts it
+    dev = ctx.device
+    d_raw, d_flat, d_bias = (torch.from_numpy(a).to(dev) for a in (raw, case['flat'], case['bias']))
+    data, mask, header, hm = R.reduce_object(ctx, d_raw, {}, tel, mflat=d_flat, mbias=d_bias, ysize_chan=ys, xsize_chan=xs,
+                                             do_cosmics=False, detect_sats=False)
+    assert tuple(data.shape) == (2048, 2048)
+    assert hv(header, 'OS-P') is False and ghdr['OS-P'] is False
+    assert hv(header, 'MBIAS-P') is True and hv(header, 'MFLAT-P') is True
+    for k in ['BIASMEAN', 'RDNOISE'] + ['BIASM%d' % (c + 1) for c in range(16)] + ['RDN%d' % (c + 1) for c in range(16)]:
+        assert hv(header, k) == ghdr[k], k
+    for k in ghdr:                                    # the vertical fit of channel 1 was made before os_corr raised
+        if k.startswith('BIAS1A'):
+            assert hv(header, k) == pytest.approx(ghdr[k], rel=1e-6, abs=1e-12), k
+    assert 'BIAS2A0' not in header and 'BIAS2A0' not in ghdr
+    got = data.cpu().numpy()
+    assert np.array_equal(got[::ss], g['data_final'])
+    assert hashlib.sha256(got.tobytes()).hexdigest() == meta['sha_data_final']
+    # the same frame through the pipeline (fits in the worker pool, device stage on a lane)
+    from blackbox_amd.pipeline import FramePipeline, HostPool
+    pool = HostPool(2)
+    try:
+        geom = R.geometry(raw.shape, ys, xs)
+        pipe = FramePipeline(ctx, tel, geom, mflat=d_flat, mbias=d_bias, pool=pool, depth=2, lanes=2, do_cosmics=False,
+                             keep_outputs=True)
+        done = {}
+        pipe.run([(d_raw, {}), (d_raw, {})], on_done=lambda i, f: done.__setitem__(i, f))
+        for i in (0, 1):
+            f = done[i]
+            assert hv(f.header, 'OS-P') is False and hv(f.header, 'RDNOISE') == 10.0 and hv(f.header, 'BIASMEAN') == 0.0
+            assert hashlib.sha256(f.data.cpu().numpy().tobytes()).hexdigest() == meta['sha_data_final']
+        pipe.close()
+    finally:
+        pool.close()

@@ -222,6 +222,37 @@ def test_cut_stitch_and_photometry(ctx):
     np.testing.assert_allclose(eg.cpu().numpy(), eo, rtol=1e-5)
 
 
+def test_psf_optflux_sigma_vs_oracle(ctx):
+    """the entry the operator's catalogue photometry runs (bbx_psf_optflux_sigma, zogy.get_psfoptflux with the
+    variance formed on the fly): D = background-subtracted frame, sigma image -> V = max(D, 0) + sigma^2 in float32
+    at the stamp pixels only; against the oracle's psf_optflux on that variance image.  Sources at the frame
+    edges and corners, negative pixels, a patch of zero variance (D <= 0 and sigma = 0), one stamp per source."""
+    rs = np.random.RandomState(7)
+    ny, nx, S, nsrc = 120, 176, 11, 300
+    D = rs.normal(0, 12, (ny, nx)).astype(F)
+    for _ in range(30):
+        y, x = rs.randint(3, ny - 3), rs.randint(3, nx - 3)
+        D[y - 2:y + 3, x - 2:x + 3] += rs.uniform(50, 5000)
+    sig = np.abs(rs.normal(12, 1.5, (ny, nx))).astype(F)
+    sig[40:46, 60:66] = 0
+    D[40:46, 60:66] = -np.abs(D[40:46, 60:66])                 # V = 0 there: skipped by both sides
+    V = (np.maximum(D, F(0)) + sig * sig).astype(F)
+    ys = rs.randint(0, ny, nsrc); xs = rs.randint(0, nx, nsrc)
+    ys[:6] = [0, ny - 1, 0, ny - 1, 43, 2]; xs[:6] = [0, nx - 1, nx - 1, 0, 63, nx - 2]
+    psfs = np.abs(rs.normal(0, 1, (nsrc, S, S))).astype(F)
+    psfs /= psfs.sum(axis=(1, 2), keepdims=True)
+    fo, eo = Z.psf_optflux(D, V, psfs, ys, xs)
+    fg, eg = G.psf_optflux(ctx, dev(ctx, D), dev(ctx, sig), dev(ctx, psfs), ys, xs, v_is_sigma=True)
+    ctx.sync()
+    # float64 sums in wave order, rounded to float32 (same bar as bbx_psf_optflux)
+    np.testing.assert_allclose(fg.cpu().numpy(), fo, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(eg.cpu().numpy(), eo, rtol=1e-5)
+    # and the explicit-variance entry on the same variance image gives the same numbers
+    f2, e2 = G.psf_optflux(ctx, dev(ctx, D), dev(ctx, V), dev(ctx, psfs), ys, xs)
+    ctx.sync()
+    assert torch.equal(f2, fg) and torch.equal(e2, eg)
+
+
 def test_psf_model_mfma(ctx):
     """a17 PSFEx model evaluation: basis cube x polynomial terms on the f32 MFMA against the
     float32 fma-chain oracle (exact but for rare double roundings) and a float64 contraction"""

@@ -213,3 +213,22 @@ def test_direct_lapack_equals_numpy_lstsq():
         assert r1 is not None and r2 is not None
         for k in r2:
             assert np.array_equal(np.asarray(r1[k]), np.asarray(r2[k]), equal_nan=True), k
+
+
+def test_narrow_channel_raises_like_the_reference():
+    """channels narrower than 300 columns: the reference's level window [ncols-300:ncols] of the (ncols + overscan)-wide
+    strip is empty, its os_corr raises (blackbox.py:6565-6573 with warnings as errors); the worker-side solve raises
+    OverscanFailure carrying the vertical fit the reference had already subtracted; the exception survives pickling
+    (it crosses the worker pool)"""
+    import pickle
+    rs = np.random.RandomState(5)
+    ysz, xsz, dy, dx = 64, 256, 84, 301
+    col = 6000 + rs.normal(0, 1, dy)
+    hos = (6000 + rs.normal(0, 8, (10, dx))).astype(np.float32)
+    with pytest.raises(overscan.OverscanFailure) as ei:
+        overscan.channel_solve((3, col, hos, ysz, xsz, 3, 'ML1', 2000, 'f32seq'))
+    e = pickle.loads(pickle.dumps(ei.value))
+    assert e.chan == 3 and e.fit.shape == (dy,) and np.all(np.abs(e.fit - 6000) < 5) and 'channel 4' in str(e)
+    # 330 columns: the window is [30:330], fine
+    r = overscan.channel_solve((3, col, (6000 + rs.normal(0, 8, (10, 375))).astype(np.float32), ysz, 330, 3, 'ML1', 2000, 'f32seq'))
+    assert np.isfinite(r['oscan']).all() and r['oscan'].shape == (330,)

@@ -136,3 +136,37 @@ def test_sigma_clipped_stats_vs_astropy_golden():
         assert mean == pytest.approx(want[0], rel=2e-6)
         assert med == pytest.approx(want[1], rel=1e-7)
         assert std == pytest.approx(want[2], rel=5e-6)
+
+
+def load_cfg0():
+    g = np.load(os.path.join(GOLD, 'cfg0_2048.npz'))
+    meta = json.loads(str(g['meta']))
+    case = synth.make_case(meta['ysize_chan'], meta['xsize_chan'], meta['seed'], tel=meta['tel'], os_y=meta['os_y'],
+                           os_x=meta['os_x'], with_bias=True, **meta['kw'])
+    raw = case['raw'].astype(np.float32)
+    assert hashlib.sha256(raw.tobytes()).hexdigest() == meta['sha_raw_f32']
+    assert hashlib.sha256(case['flat'].tobytes()).hexdigest() == meta['sha_flat']
+    assert hashlib.sha256(case['bias'].tobytes()).hexdigest() == meta['sha_bias']
+    return g, meta, case, raw
+
+
+def test_oracle_config0_2048_bias_flat():
+    """BASELINE configs[0]: a 2048 x 2048 float32 frame (2 x 8 channels of 1024 x 256 + overscans), bias + flat only,
+    as the reference's own gain_corr / os_corr-in-try-except / -= mbias / /= mflat reduce it
+    (oracle/gen_golden_cfg0.py): os_corr raises for channels narrower than 300 columns, blackbox_reduce adopts an
+    overscan of zero and crops the half-processed array"""
+    g, meta, case, raw = load_cfg0()
+    ys, xs, tel = meta['ysize_chan'], meta['xsize_chan'], meta['tel']
+    data = raw.copy()
+    O.gain_corr(data, settings.gain[tel], ys, xs)
+    data, header = O.os_corr_or_zero(data, ys, xs, tel=tel, accum='bn32')
+    assert data.shape == (2048, 2048)
+    ghdr = json.loads(str(g['header']))
+    assert header['OS-P'] is False and ghdr['OS-P'] is False
+    for k in ['BIASMEAN', 'RDNOISE'] + ['BIASM%d' % (c + 1) for c in range(16)] + ['RDN%d' % (c + 1) for c in range(16)]:
+        assert header[k] == ghdr[k], k
+    assert hashlib.sha256(data.tobytes()).hexdigest() == meta['sha_data_os']
+    data -= case['bias']
+    data /= case['flat']
+    assert np.array_equal(data[::meta['subsample']], g['data_final'])
+    assert hashlib.sha256(data.tobytes()).hexdigest() == meta['sha_data_final']
