@@ -281,7 +281,7 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
         elif mark['n'] == first + steps:
             mark['t1'] = time.perf_counter()
             if prof_ctx is not None:
-                _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 0), 'bbx_profile_enable')
+                _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 2), 'bbx_profile_enable')      # pause, keep the records
         mark['last'] = f
     barrier()
     t_all0 = time.perf_counter()

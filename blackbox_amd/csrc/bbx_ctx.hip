@@ -70,6 +70,7 @@ int bbx_profile_enable(bbx_ctx* ctx, int on) {
     }
     ctx->prof_on = 0;
     ctx->prof_gen++;
+    if (on == 2) return BBX_OK;          // pause: stop recording, keep what was recorded for bbx_profile_read
     ctx->prof_n = 0;
     ctx->prof_on = on ? 1 : 0;
     return BBX_OK;

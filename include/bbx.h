@@ -132,7 +132,7 @@ int  bbx_copy_async(void *dst, const void *src, size_t nbytes, int kind, void *s
 #define BBX_PROF_Z_IMG_COLS 11 /*   k_img_cols, */
 #define BBX_PROF_Z_VAR_COLS 12 /*   k_var_cols */
 #define BBX_PROF_NSLOTS 13
-int  bbx_profile_enable(bbx_ctx *ctx, int on);
+int  bbx_profile_enable(bbx_ctx *ctx, int on);   /* 1: clear + record; 0: clear + stop; 2: stop, keep the records */
 /* synchronises on the recorded events; ms_total/calls have nslots entries; resets */
 int  bbx_profile_read(bbx_ctx *ctx, double *ms_total, int32_t *calls, int nslots);
 
