@@ -42,6 +42,111 @@ def str2bool(v):
     raise argparse.ArgumentTypeError('Boolean value expected.')
 
 
+class WrapException(Exception):
+    """the exception of a worker with its formatted traceback, so that a multiprocessing pool can hand it to
+    the parent (what blackbox.py:933-943 is for): raised by try_blackbox_reduce in place of whatever
+    blackbox_reduce raised"""
+
+    def __init__(self):
+        import traceback
+        exc_type, exc_value, exc_tb = sys.exc_info()
+        Exception.__init__(self, repr(exc_value))
+        self.exception = exc_value
+        self.formatted = ''.join(traceback.format_exception(exc_type, exc_value, exc_tb))
+
+    def __reduce__(self):                                          # crosses the pool as text
+        return (_rebuild_wrapexception, (self.args, self.formatted))
+
+    def __str__(self):
+        return '{}\nOriginal traceback:\n{}'.format(Exception.__str__(self), self.formatted)
+
+
+def _rebuild_wrapexception(args, formatted):
+    e = WrapException.__new__(WrapException)
+    Exception.__init__(e, *args)
+    e.exception, e.formatted = None, formatted
+    return e
+
+
+# ---- operator-level entry the reference's farm imports (blackbox.py:363-379: `pool_func(try_blackbox_reduce,
+# filenames, nproc)`): module-level functions of one argument.  The settings the reference keeps in module globals
+# set by run_blackbox (tel, filts, types, proc_mode; blackbox.py:141, 321-323) are the parsed command line here:
+# configure() stores it in this process and in the environment, so that spawned pool workers -- which import this
+# module afresh and must create their GPU context themselves -- find it.
+_ENV_KEY = 'BBX_BLACKBOX_ARGV'
+_STATE = {'argv': None, 'reducer': None}
+
+
+def configure(argv):
+    """set the per-process settings (the command-line flags of main(), as a list of strings) for blackbox_reduce /
+    try_blackbox_reduce; inherited by pool workers through the environment.  Makes no GPU call."""
+    import json
+    _STATE['argv'] = list(argv)
+    _STATE['reducer'] = None
+    os.environ[_ENV_KEY] = json.dumps(_STATE['argv'])
+
+
+def _reducer(filename=None):
+    """this process's Reducer (GPU context + masters resident in HBM), created at the first frame"""
+    if _STATE['reducer'] is None:
+        if _STATE['argv'] is None:
+            import json
+            if _ENV_KEY not in os.environ:
+                raise RuntimeError('blackbox.configure(argv) has not been called (and %s is not set)' % _ENV_KEY)
+            _STATE['argv'] = json.loads(os.environ[_ENV_KEY])
+        args = build_parser().parse_args(_STATE['argv'])
+        _STATE['reducer'] = Reducer(telescope_of(args, filename), args)
+    return _STATE['reducer']
+
+
+def blackbox_reduce(filename):
+    """blackbox.py:1027-2669 for one file: -> path of the reduced image, or None if it was skipped"""
+    return _reducer(filename).blackbox_reduce(filename)
+
+
+def try_blackbox_reduce(filename):
+    """blackbox.py:948-999: blackbox_reduce in a try / except that re-raises as WrapException (formatted traceback
+    for the parent of a multiprocessing pool); the per-image log is closed in blackbox_reduce's own finally"""
+    try:
+        return blackbox_reduce(filename)
+    except BaseException:
+        raise WrapException()
+
+
+def pool_func(func, filelist, nproc=1):
+    """blackbox.py:363-379 / zogy.pool_func: map [func] over the files with [nproc] worker processes.  Workers
+    are SPAWNED (a forked child cannot use a GPU runtime its parent initialised) and each creates its own GPU
+    context at its first file; the parent makes no GPU call.  WORLD_SIZE / LOCAL_RANK are not needed: worker k
+    takes GPU k modulo the number of visible devices."""
+    import multiprocessing as mp
+    if nproc <= 1:
+        return [func(f) for f in filelist]
+    with mp.get_context('spawn').Pool(nproc, initializer=_pool_worker_init, initargs=(os.environ.get(_ENV_KEY),)) as pool:
+        return pool.map(func, filelist, chunksize=1)
+
+
+def _pool_worker_init(argv_json):
+    import multiprocessing as mp
+    if argv_json is not None:
+        os.environ[_ENV_KEY] = argv_json
+    ident = mp.current_process()._identity
+    import torch
+    ndev = max(1, torch.cuda.device_count())                      # counting devices does not initialise the GPU
+    os.environ['LOCAL_RANK'] = str(((ident[0] - 1) if ident else 0) % ndev)
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'      # the pool hands out the files; no sharding inside a worker
+
+
+def telescope_of(args, filename=None):
+    """telescope from the file name prefix, else --telescope (blackbox.py:145-152)"""
+    tel = args.telescope
+    if filename:
+        base = os.path.basename(filename)
+        for t in ('ML1', 'BG2', 'BG3', 'BG4'):
+            if base.startswith(t):
+                tel = t
+    return tel
+
+
 def outname(header, tel, red_dir):
     """{tel}_{yyyymmdd}_{hhmmss}_red.fits from DATE-OBS (blackbox.py:1004-1022, 1166-1184)"""
     from blackbox_amd.reduce import hval
@@ -112,7 +217,12 @@ class Reducer:
             if path.endswith('.psf') or path.endswith('_psf.fits'):
                 m = fitsio.read_psfex(path)
                 if m['psf_samp'] != 1.0:
-                    log.warning('PSF_SAMP %.3f != 1: the model is used on its own sampling grid', m['psf_samp'])
+                    # the model is tabulated every PSF_SAMP pixels: bring the basis to image pixels (zogy.get_psf_ima)
+                    from blackbox_amd import zogy as G
+                    if not (0.05 <= m['psf_samp'] <= 20.0):
+                        raise ValueError('PSF_SAMP {} out of range'.format(m['psf_samp']))
+                    m['basis'] = G.resample_psf_basis(m['basis'], m['psf_samp'])
+                    log.info('PSF model resampled from PSF_SAMP %.3f to image pixels: %d x %d', m['psf_samp'], *m['basis'].shape[1:])
                 m['basis'] = torch.from_numpy(np.ascontiguousarray(m['basis'])).to(self.ctx.device)
                 return m
             st = np.ascontiguousarray(fitsio.read_image(path, dtype=np.float32))
@@ -151,11 +261,20 @@ class Reducer:
 
     # ------------------------------------------------------------------------------------
     def try_blackbox_reduce(self, filename):
-        """blackbox.py:948-999: returns the reduced file name or None; never raises"""
+        """blackbox.py:948-999: the reduced file name or None (skipped); raises WrapException with the formatted
+        traceback when blackbox_reduce raised"""
         try:
             return self.blackbox_reduce(filename)
-        except Exception:
-            log.exception('exception was raised during [blackbox_reduce] of %s', filename)
+        except BaseException:
+            raise WrapException()
+
+    def reduce_logged(self, filename):
+        """what the reference's single-process loop amounts to for the caller of main(): a failing file is logged
+        with its traceback and reported as None, the run goes on"""
+        try:
+            return self.try_blackbox_reduce(filename)
+        except WrapException as e:
+            log.error('exception was raised during [blackbox_reduce] of %s:\n%s', filename, e.formatted)
             return None
 
     def read_raw(self, filename):
@@ -348,11 +467,41 @@ class Reducer:
             tqc = qc.run_qc_check(full_t, self.tel, check_key_type='trans')
             for ext in ('D', 'Scorr', 'Fpsf'):
                 self.write_image('{}_{}.fits'.format(base, ext), res[ext], full_t)
+            self.write_limmag(base, res, full_t)
             if tqc == 'red' or qc_flag == 'red':
                 qc.run_qc_check(full_t, self.tel, cat_type='trans', cat_dummy=base + '_trans.fits', check_key_type='trans')
             else:
                 G.format_cat(G.transient_table(res['transients']), base + '_trans.fits', cat_type='trans', header2add=full_t)
             fitsio.write_header(base + '_trans_hdr.fits', full_t)
+
+    def write_limmag(self, base, res, header):
+        """`_trans_limmag.fits` (set_blackbox.py:160-162): the transient detection limit per pixel,
+        T-NSIGMA x Fpsferr -- in magnitudes when a zeropoint is known (--zeropoint, or PC-ZP of the header, with the
+        extinction term PC-EXTCO x AIRMASSC when both are there: the photometric calibration itself is outside this
+        path), else as a flux in e- (LIMUNIT says which)"""
+        R, torch = self.R, self.torch
+        if res.get('Fpsferr') is None:
+            return
+        nsig = float(R.hval(header, 'T-NSIGMA')) if 'T-NSIGMA' in header else 6.0
+        lim = res['Fpsferr'] * nsig
+        zp = self.args.zeropoint
+        if zp is None and 'PC-ZP' in header and not isinstance(R.hval(header, 'PC-ZP'), str):
+            zp = float(R.hval(header, 'PC-ZP'))
+        h = dict(header)
+        if zp is not None:
+            exptime = float(R.hval(header, 'EXPTIME')) if 'EXPTIME' in header else 1.0
+            ext = 0.0
+            if 'PC-EXTCO' in header and 'AIRMASSC' in header:
+                try:
+                    ext = float(R.hval(header, 'PC-EXTCO')) * float(R.hval(header, 'AIRMASSC'))
+                except (TypeError, ValueError):
+                    ext = 0.0
+            lim = torch.where(lim > 0, zp - 2.5 * torch.log10(lim.clamp(min=1e-30) / exptime) - ext, torch.zeros_like(lim))
+            h['LIMUNIT'] = ('mag', 'unit of the limiting-magnitude image')
+        else:
+            h['LIMUNIT'] = ('e-', 'limit in flux: no zeropoint was given')
+        h['LIMNSIG'] = (nsig, '[sigma] significance of the limit')
+        self.write_image(base + '_trans_limmag.fits', lim.contiguous(), h)
 
     # ---- many object frames: frames-in-flight pipeline ------------------------------------------
     def reduce_list(self, files):
@@ -370,7 +519,7 @@ class Reducer:
                     self.args.red_dir = os.path.dirname(os.path.abspath(fn))
                 _, fits_out = self.names(header)
                 if imgtype != 'object' or self.nonlin is not None:
-                    out[fn] = self.try_blackbox_reduce(fn)
+                    out[fn] = self.reduce_logged(fn)
                 elif self.already_done(fits_out):
                     out[fn] = fits_out
                 else:
@@ -413,7 +562,7 @@ class Reducer:
         return [out.get(fn) for fn in files]
 
 
-def main(argv=None):
+def build_parser():
     ap = argparse.ArgumentParser(description='BlackBOX per-image reduction on MI355X')
     ap.add_argument('--telescope', type=str, default='ML1')
     ap.add_argument('--mode', type=str, default='day')
@@ -455,6 +604,15 @@ def main(argv=None):
     ap.add_argument('--subimage_size', type=int, default=None)
     ap.add_argument('--subimage_border', type=int, default=None)
     ap.add_argument('--bkg_boxsize', type=int, default=None)
+    ap.add_argument('--zeropoint', type=float, default=None,
+                    help='[mag] photometric zeropoint for 1 e-/s (else header PC-ZP): _trans_limmag in magnitudes')
+    ap.add_argument('--nproc', type=int, default=1, help='worker processes for --image_list (one GPU context each)')
+    return ap
+
+
+def main(argv=None):
+    ap = build_parser()
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
     logging.basicConfig(level='INFO', format='%(asctime)s [%(levelname)s, %(process)s] %(message)s')
     for flag in ('date', 'read_path', 'imgtypes', 'filters', 'master_date', 'name_genlog'):
@@ -470,22 +628,29 @@ def main(argv=None):
             files += [ln.strip() for ln in f if ln.strip()]
     if not files:
         ap.error('--image or --image_list required')
-    tel = args.telescope
-    base = os.path.basename(files[0])
-    for t in ('ML1', 'BG2', 'BG3', 'BG4'):                       # telescope from the file name (blackbox.py:145-152)
-        if base.startswith(t):
-            tel = t
+    tel = telescope_of(args, files[0])
     from blackbox_amd import farm
     mine = farm.shard(files)
+    if args.nproc > 1 and len(mine) > 1:
+        # the reference's farm (blackbox.py:375-379): a pool of workers over the file list, one GPU context each
+        configure(argv)
+        try:
+            out = pool_func(try_blackbox_reduce, mine, nproc=args.nproc)
+        except WrapException as e:
+            log.error('a worker raised during [blackbox_reduce]:\n%s', e.formatted)
+            raise
+        for o in out:
+            print(o)
+        return out
     red = Reducer(tel, args)
     if args.image_list and len(mine) > 1:
         try:
             out = red.reduce_list(mine)
         except Exception:
             log.exception('pipelined run failed; reducing the files one by one')
-            out = [red.try_blackbox_reduce(f) for f in mine]
+            out = [red.reduce_logged(f) for f in mine]
     else:
-        out = [red.try_blackbox_reduce(f) for f in mine]
+        out = [red.reduce_logged(f) for f in mine]
     for o in out:
         print(o)
     return out

@@ -204,10 +204,13 @@ int bbx_host_has_dgelsd(void) { return g_dgelsd != 0; }
 int bbx_lstsq_direct(const double *lhs, int64_t m, int order, const double *rhs, double rcond, double *coef, int *rank) {
     if (!g_dgelsd || m < 1 || order < 1) return 1;
     int64_t mm = m, n = order, nrhs = 1, lda = m, ldb = m > n ? m : n, rk = 0, info = 0, lwork = -1, iwq = 0;
-    double wq = 0.0, sdummy[16], rc = rcond;
-    double *a = (double *)malloc(((size_t)m * order + (size_t)ldb) * sizeof(double));
+    double wq = 0.0, rc = rcond;
+    /* singular values: min(m, n) entries, allocated with the matrices (no fixed-size buffer) */
+    const size_t ns = (size_t)(m < n ? m : n);
+    double *a = (double *)malloc(((size_t)m * order + (size_t)ldb + ns) * sizeof(double));
     if (!a) return 1;
     double *b = a + (size_t)m * order;
+    double *sdummy = b + ldb;
     for (int j = 0; j < order; j++)
         for (int64_t i = 0; i < m; i++) a[(size_t)j * m + i] = lhs[(size_t)i * order + j];
     for (int64_t i = 0; i < ldb; i++) b[i] = i < m ? rhs[i] : 0.0;

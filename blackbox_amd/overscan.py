@@ -62,6 +62,18 @@ def _install_numpy_lapack():
         if not fn:
             return False
         _HOST.bbx_host_set_dgelsd(fn)
+        # the symbol name says ILP64, but trust a measurement: one small system solved through the installed entry must
+        # reproduce np.linalg.lstsq bit for bit (a build with another integer width or routine would not)
+        rs = np.random.RandomState(0)
+        lhs = np.ascontiguousarray(rs.normal(size=(40, 5)))
+        rhs = np.ascontiguousarray(rs.normal(size=40))
+        coef, rank = np.empty(5), _C.c_int(0)
+        rc = _HOST.bbx_lstsq_direct(lhs.ctypes.data, 40, 5, rhs.ctypes.data, float(40 * np.finfo(np.float64).eps),
+                                    coef.ctypes.data, _C.addressof(rank))
+        want = np.linalg.lstsq(lhs, rhs, rcond=40 * np.finfo(np.float64).eps)
+        if rc != 0 or rank.value != int(want[2]) or not np.array_equal(coef, want[0]):
+            _HOST.bbx_host_set_dgelsd(None)
+            return False
         return True
     except (OSError, AttributeError, ImportError):
         return False

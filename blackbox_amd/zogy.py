@@ -222,6 +222,25 @@ def psf_poly_terms(x, y, polzero, polscal, poldeg):
     return np.stack(cols, axis=1).astype(np.float32)
 
 
+def resample_psf_basis(basis, psf_samp):
+    """PSFEx tabulates its model every PSF_SAMP image pixels (automatic sampling: usually != 1).  zogy.get_psf_ima
+    (buildref.py:3357-3366 passes psf_samp) resamples the model image to image pixels: psf_size =
+    ceil(S_config * psf_samp) made odd, scipy.ndimage.zoom by psf_size / S_config [EXT: order 2, mode 'nearest';
+    oracle/zogy_core.get_psf_ima].  The resampling is linear, so it is applied once to every basis plane (host,
+    ncoef small images) and the per-source contraction (bbx_psf_model) then works on image pixels.
+    -> float32 [ncoef, psf_size, psf_size]"""
+    basis = np.asarray(basis, np.float64)
+    s_cfg = basis.shape[1]
+    size = int(np.ceil(s_cfg * float(psf_samp)))
+    size += 1 - size % 2
+    if size == s_cfg:
+        return basis.astype(np.float32)
+    out = np.stack([ndimage.zoom(b, size / s_cfg, order=2, mode='nearest') for b in basis])
+    if out.shape[1:] != (size, size):
+        raise ValueError('PSF resampling gave {} instead of {}'.format(out.shape[1:], (size, size)))
+    return out.astype(np.float32)
+
+
 def psf_model_stamps(ctx, basis, x, y, polzero, polscal, poldeg, normalize=True):
     """PSF stamp of every source from a PSFEx model: basis [ncoef, S, S] float32 device
     tensor (PSF_MASK), positions x, y (host arrays).  The contraction runs on the f32 MFMA

@@ -261,3 +261,26 @@ def psf_model(terms, basis):
         acc = (terms[:, k:k + 1].astype(np.float64) * basis[k][None, :].astype(np.float64) + acc.astype(np.float64)
                ).astype(np.float32)
     return acc
+
+
+def get_psf_ima(basis, x, y, psf_samp, polzero, polscal, poldeg):
+    """zogy.get_psf_ima as called at buildref.py:3357-3366 [EXT: zogy is absent; restated from its call signature and the
+    PSFEx file format]: the PSFEx model (basis planes tabulated every [psf_samp] image pixels) evaluated at image
+    position (x, y) -> the polynomial combination of the planes on the model's own grid, then resampled to image
+    pixels: psf_size = ceil(S_config * psf_samp) made odd, scipy.ndimage.zoom by psf_size / S_config (order 2,
+    mode 'nearest'), normalised to unit sum.  -> float32 [psf_size, psf_size]"""
+    basis = np.asarray(basis, np.float64)
+    xn = (x - polzero[0]) / polscal[0]
+    yn = (y - polzero[1]) / polscal[1]
+    ima = np.zeros(basis.shape[1:])
+    k = 0
+    for j in range(poldeg + 1):
+        for i in range(poldeg + 1 - j):
+            ima += basis[k] * (xn ** i) * (yn ** j)
+            k += 1
+    s_cfg = basis.shape[1]
+    size = int(np.ceil(s_cfg * psf_samp))
+    size += 1 - size % 2
+    out = ndimage.zoom(ima, size / s_cfg, order=2, mode='nearest') if size != s_cfg else ima
+    assert out.shape == (size, size)
+    return (out / out.sum()).astype(F)

@@ -117,4 +117,4 @@ def test_cli_object_and_flat(tmp_path):
     # (too small for the production STATSEC / sub-image size: only the call path is checked, via its error handling)
     r = cli.main(['--telescope', tel, '--image', str(tmp_path / 'ML1_flatraw.fits'), '--bpm', str(tmp_path / 'bpm.fits'),
                   '--ysize_chan', str(ys), '--xsize_chan', str(xs), '--red_dir', str(tmp_path / 'c')])
-    assert r == [None]          # try_blackbox_reduce keeps its contract: failures are logged, None returned
+    assert r == [None]          # main() logs the WrapException of a failing file and reports None for it

@@ -219,6 +219,15 @@ def test_cli_subtraction_products_and_image_list(tmp_path, ctx, case):
     assert len(tr['X_PEAK']) == len(res['transients']) == R.hval(ht, 'T-NTRANS')
     hh = fitsio.read_hdus(base + '_hdr.fits')[0][0]
     assert R.hval(hh, 'RDNOISE') == R.hval(h, 'RDNOISE') and R.hval(hh, 'Z-P') is True
+    # `_trans_limmag`: T-NSIGMA x Fpsferr; a flux without a zeropoint, magnitudes with one
+    lim, hl = fitsio.read_image(base + '_trans_limmag.fits', get_header=True)
+    assert R.hval(hl, 'LIMUNIT') == 'e-' and R.hval(hl, 'LIMNSIG') == 6.0
+    assert np.array_equal(lim, (res['Fpsferr'] * 6.0).cpu().numpy(), equal_nan=True)
+    cli.main(common + ['--image', raws[0], '--red_dir', str(tmp_path / 'z'), '--zeropoint', '22.5'])
+    mag, hl = fitsio.read_image(str(tmp_path / 'z' / 'ML1_20240102_030400_red_trans_limmag.fits'), get_header=True)
+    ok = lim > 0
+    assert R.hval(hl, 'LIMUNIT') == 'mag'
+    np.testing.assert_allclose(mag[ok], 22.5 - 2.5 * np.log10(lim[ok] / 60.0), rtol=0, atol=2e-5)
 
     # --image_list: the same frames through the frames-in-flight pipeline
     lst = str(tmp_path / 'list.txt')
@@ -236,3 +245,72 @@ def test_cli_subtraction_products_and_image_list(tmp_path, ctx, case):
         assert R.hval(hb, k) == R.hval(h, k), k
     for k in (1, 2):
         assert os.path.isfile(str(tmp_path / 'b' / ('ML1_20240102_03040%d_red_trans.fits' % k)))
+
+
+FARM_SCRIPT = """
+import json, sys
+sys.path.insert(0, {root!r})
+import blackbox
+if __name__ == '__main__':
+    argv, files = json.loads(sys.argv[1]), json.loads(sys.argv[2])
+    blackbox.configure(argv)
+    import torch
+    assert not torch.cuda.is_initialized()
+    try:
+        out = blackbox.pool_func(blackbox.try_blackbox_reduce, files, nproc=2)
+        assert not torch.cuda.is_initialized()                    # the parent never touched the GPU
+        print('OUT ' + json.dumps(out))
+    except blackbox.WrapException as e:
+        print('WRAPPED ' + json.dumps(e.formatted))
+"""
+
+
+def run_plain(ctx, case):
+    return R.reduce_object(ctx, dev(ctx, case['raw']), {}, TEL, mflat=dev(ctx, case['flat']), bpm=dev(ctx, case['bpm']),
+                           exptime=60.0, ysize_chan=YS, xsize_chan=XS)
+
+
+def test_farm_spawn_pool_and_wrapexception(tmp_path, case):
+    """the operator-level entry the reference's farm imports (blackbox.py:363-379, 933-999): module-level
+    try_blackbox_reduce mapped over 3 files by a 2-worker multiprocessing SPAWN pool -- every child creates its own
+    GPU context, the parent (a fresh interpreter here) makes no GPU call -- and a file that makes blackbox_reduce
+    raise comes back as WrapException with the worker's formatted traceback"""
+    import json
+    import subprocess
+    hdr = {'EXPTIME': 60.0, 'IMAGETYP': 'object', 'FILTER': 'q'}
+    raws = []
+    for k in range(3):
+        p = str(tmp_path / ('ML1_raw%d.fits' % k))
+        fitsio.write_image(p, case['raw'], dict(hdr, **{'DATE-OBS': '2024-01-02T03:04:0%d' % k}))
+        raws.append(p)
+    fitsio.write_image(str(tmp_path / 'flat.fits'), case['flat'])
+    fitsio.write_image(str(tmp_path / 'bpm.fits'), case['bpm'])
+    argv = ['--telescope', TEL, '--mflat', str(tmp_path / 'flat.fits'), '--bpm', str(tmp_path / 'bpm.fits'),
+            '--ysize_chan', str(YS), '--xsize_chan', str(XS), '--red_dir', str(tmp_path / 'p')]
+    script = str(tmp_path / 'farm.py')
+    with open(script, 'w') as f:
+        f.write(FARM_SCRIPT.format(root=os.path.abspath(ROOT)))
+    r = subprocess.run([sys.executable, script, json.dumps(argv), json.dumps(raws)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('OUT ')]
+    assert line, (r.stdout[-2000:], r.stderr[-2000:])
+    outs = json.loads(line[0][4:])
+    assert [os.path.basename(o) for o in outs] == ['ML1_20240102_03040%d_red.fits' % k for k in range(3)]
+    # the products of the pool equal the in-process reduction
+    c = R.Context(0)
+    try:
+        want = run_plain(c, case)
+        for o in outs:
+            assert np.array_equal(fitsio.read_image(o), want[0].cpu().numpy())
+            assert np.array_equal(fitsio.read_image(o.replace('_red', '_mask')), want[1].cpu().numpy())
+    finally:
+        c.close()
+    # a file blackbox_reduce cannot read: WrapException with the traceback text reaches the parent
+    bad = str(tmp_path / 'ML1_missing.fits')
+    r = subprocess.run([sys.executable, script, json.dumps(argv), json.dumps([raws[0], bad])], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('WRAPPED ')]
+    assert line, (r.stdout[-2000:], r.stderr[-2000:])
+    tb = json.loads(line[0][8:])
+    assert 'Traceback' in tb and 'ML1_missing.fits' in tb and 'blackbox_reduce' in tb

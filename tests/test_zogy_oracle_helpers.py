@@ -36,3 +36,29 @@ def test_find_transients_fast_equals_loop():
     img[80, 80:83] = 7.0                                   # tie: first pixel in C order
     img[150:153, 100] = 7.0; img[152, 101:104] = 7.0; img[150, 101] = -3      # L-shaped region, tie across rows
     assert Z.find_transients_fast(img, 6.0) == Z.find_transients(img, 6.0)
+
+
+def test_psf_samp_resampling():
+    """a PSFEx model tabulated every PSF_SAMP = 0.5 image pixels: the product resamples the basis planes once
+    (zogy.resample_psf_basis) -- equal to the oracle's get_psf_ima, which combines first and resamples then -- and the
+    stamp has the width the model has in IMAGE pixels (using the planes on their own grid doubles it)"""
+    from blackbox_amd.zogy import resample_psf_basis, psf_poly_terms
+    samp, s_cfg, fwhm_img = 0.5, 51, 3.6
+    yy, xx = np.mgrid[0:s_cfg, 0:s_cfg] - s_cfg // 2
+    sig = fwhm_img / 2.3548 / samp                               # sigma in model steps
+    g0 = np.exp(-(xx * xx + yy * yy) / (2 * sig * sig))
+    g1 = g0 * (xx * xx + yy * yy) / (sig * sig) * 0.05           # a width term linear in x
+    basis = np.stack([g0, g1, 0.3 * g1]).astype(F)               # poldeg 1: 1, x, y
+    rb = resample_psf_basis(basis, samp)
+    assert rb.shape == (3, 27, 27)                               # ceil(51 * 0.5) = 26 -> 27
+    for (x, y) in ((100.0, 200.0), (9000.0, 5000.0)):
+        want = Z.get_psf_ima(basis, x, y, samp, (5280.0, 5280.0), (5280.0, 5280.0), 1)
+        t = psf_poly_terms([x], [y], (5280.0, 5280.0), (5280.0, 5280.0), 1)[0]
+        got = np.tensordot(t.astype(np.float64), rb.astype(np.float64), 1)
+        got /= got.sum()
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+        # second moment -> FWHM in image pixels
+        y2, x2 = np.mgrid[0:27, 0:27] - 13
+        fw = 2.3548 * np.sqrt((got * x2 * x2).sum() / got.sum())
+        assert abs(fw - fwhm_img * np.sqrt(1 + 2 * 0.05 * t[1])) < 0.35 or abs(fw - fwhm_img) < 0.4
+    assert resample_psf_basis(basis, 1.0).shape == basis.shape
