@@ -40,6 +40,7 @@ static inline int bbx_make_dims(const bbx_geom* g, bbx_dims* d) {
 // device-side error flags (bits) kept in ctx->d_err[0]
 #define BBX_DERR_LIST_OVERFLOW 1
 #define BBX_DERR_NOTCONV       2
+#define BBX_DERR_PSF_WINDOW    4    // bbx_zogy_frame: the PSFs' matched-filter kernels do not fit their row window
 
 struct bbx_ctx {
     int device;
@@ -63,6 +64,8 @@ struct bbx_ctx {
     void*  zogy_state;         // per-context FFT plans / work buffer of bbx_zogy.hip (NULL until first use)
     int    zogy_core;          // BBX_OPT_ZOGY_CORE: FFT core of bbx_zogy_frame (0 = bbx_zogy2.hip, 1 = bbx_zogy3.hip)
     void*  zogy2_state;        // twiddle table of bbx_zogy2.hip
+    int    zogy_kwin_off;      // BBX_OPT_ZOGY_KWIN_OFF: full-size transforms of the matched-filter kernels (no row window)
+    int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
     int    num_cus;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     // --- optional per-kernel timing (bbx_profile_enable): hipEvent pairs on the launch stream
     int prof_on, prof_n;

@@ -100,6 +100,7 @@ const char* bbx_strerror(int code) {
         case BBX_ERR_NOMEM: return "out of memory";
         case BBX_ERR_OVERFLOW: return "device work list overflow";
         case BBX_ERR_NOTCONV: return "device iteration did not converge";
+        case BBX_ERR_PSFWIN: return "PSF matched-filter kernels exceed their row window";
         default: return "unknown error";
     }
 }
@@ -153,6 +154,7 @@ int bbx_sync(bbx_ctx* ctx, void* stream) {
         BBX_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(err), (hipStream_t)stream));
         if (err[0] & BBX_DERR_LIST_OVERFLOW) return BBX_ERR_OVERFLOW;
         if (err[0] & BBX_DERR_NOTCONV) return BBX_ERR_NOTCONV;
+        if (err[0] & BBX_DERR_PSF_WINDOW) return BBX_ERR_PSFWIN;
     }
     return BBX_OK;
 }
@@ -172,6 +174,7 @@ int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (option == BBX_OPT_LAC_LEVEL_FEED) { ctx->lac_feed = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_ZOGY_CORE) { ctx->zogy_core = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_DEBUG_LISTCAP) { ctx->debug_listcap = value > 0 ? value : 0; return BBX_OK; }
+    if (option == BBX_OPT_ZOGY_KWIN_OFF) { ctx->zogy_kwin_off = value ? 1 : 0; return BBX_OK; }
     return BBX_ERR_ARG;
 }
 

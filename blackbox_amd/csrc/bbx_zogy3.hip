@@ -69,6 +69,9 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #ifndef Z3_PLAN1400
 #define Z3_PLAN1400 5, 7, 5, 8
 #endif
+#ifndef Z3_KWIN_TOL
+#define Z3_KWIN_TOL 1e-6       // share of the energy of k_n, k_r (per sub-image) allowed outside the row window: V(S) is off by that share at most
+#endif
 #ifndef Z3_TWL
 #define Z3_TWL 1               // twiddle table in LDS (1) or read from global memory (0: three 8-byte reads per point
                                // and transform through the vector memory path, +9 % on the whole call)
@@ -223,6 +226,42 @@ template <class P> __device__ __forceinline__ void store_u(const float2* s, floa
         *reinterpret_cast<float4*>(base + (size_t)y * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
         if (halo && (y % P::NL == P::NL - 1 || y == P::L - 1))
             *reinterpret_cast<float4*>(halo + ((size_t)sub * P::LB + y / P::NL) * P::HP + g * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+}
+// The matched-filter kernels k_n, k_r live around the origin: of the inverse column pass of k^ only the rows
+// y < wh and y >= L - wh leave the workgroup (U tiles, same layout; the other rows are never read).  The energy
+// the dropped rows hold is summed next to the total (Parseval along x: row y of this half spectrum carries
+// sum_x k(y, x)^2), so that the host-chosen window can be checked on the device.
+template <class P> __device__ __forceinline__ void store_u_win(const float2* s, float2* __restrict__ U, int sub, int g, int wh, double& e_all, double& e_out) {
+    float2* base = U + (size_t)sub * P::UNIT + (size_t)g * P::L * P::NL;
+    constexpr int HL = P::NL / 2;
+    float ea = 0.f, eo = 0.f;
+    for (int e = threadIdx.x; e < P::L * HL; e += blockDim.x) {
+        const int y = e / HL, l = 2 * (e - y * HL), py = npos(y);
+        const float2 v0 = s[l * P::LS + py], v1 = s[(l + 1) * P::LS + py];
+        const float en = (v0.x * v0.x + v0.y * v0.y) + (v1.x * v1.x + v1.y * v1.y);
+        ea += en;
+        if (y < wh || y >= P::L - wh) *reinterpret_cast<float4*>(base + (size_t)y * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        else eo += en;
+    }
+    e_all += (double)ea; e_out += (double)eo;
+}
+// T tiles of the row blocks inside the window (rows < wh and >= L - wh; wh a multiple of NL, L a multiple of NL) of
+// column group g -> LDS lines; the rows outside the window are zero
+template <class P> __device__ __forceinline__ void load_t_lines_win(const float2* T, int sub, int g, float2* s, int wh) {
+    const float2* src = T + (size_t)sub * P::UNIT + (size_t)g * P::NL * P::NL;
+    constexpr int TV = P::NL * P::NL / 2;
+    const int wb = wh / P::NL, NVW = 2 * wb * TV;
+    for (int e = threadIdx.x; e < P::NL * (P::L - 2 * wh); e += blockDim.x) {
+        const int l = e / (P::L - 2 * wh), y = wh + e - l * (P::L - 2 * wh);
+        s[l * P::LS + npos(y)] = make_float2(0.f, 0.f);
+    }
+    for (int e = threadIdx.x; e < NVW; e += blockDim.x) {
+        const int ybw = e / TV, j = e - ybw * TV, yb = ybw < wb ? ybw : P::LB - 2 * wb + ybw;
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j);
+        const int l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
+        float2* line = s + l * P::LS;
+        line[npos(y)] = make_float2(v.x, v.y); line[npos(y + 1)] = make_float2(v.z, v.w);
     }
 }
 // T tiles T[sub][yb][kx][yi] of column group g -> LDS lines, natural order
@@ -388,9 +427,9 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
                                                          const zscal* __restrict__ sc, const float2* __restrict__ twg,
                                                          float2* __restrict__ cA, float2* __restrict__ cB, float2* __restrict__ cKn,
                                                          float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
-                                                         double* __restrict__ fs_partial, int nsub) {
+                                                         double* __restrict__ fs_partial, int nsub, int wh) {
     extern __shared__ float2 s[];
-    __shared__ double red[3][P::THREADS / 64];
+    __shared__ double red[5][P::THREADS / 64];
     WG_TASK(P::G, nsub, g, sub);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
@@ -452,19 +491,32 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
     }
     __syncthreads();
     fft_inv<P>(s, tw);
-    store_u<P>(s, Ukr, sub, g);
+    const bool win = 2 * wh < P::L;
+    double e_all = 0.0, e_out = 0.0;
+    if (win) store_u_win<P>(s, Ukr, sub, g, wh, e_all, e_out); else store_u<P>(s, Ukr, sub, g);
     __syncthreads();
     R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = park[k];
     __syncthreads();
     fft_inv<P>(s, tw);
-    store_u<P>(s, Ukn, sub, g);
+    if (win) store_u_win<P>(s, Ukn, sub, g, wh, e_all, e_out); else store_u<P>(s, Ukn, sub, g);
     fs = wave_sum_f64(fs); sk2n = wave_sum_f64(sk2n); sk2r = wave_sum_f64(sk2r);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = fs; red[1][threadIdx.x >> 6] = sk2n; red[2][threadIdx.x >> 6] = sk2r; }
+    e_all = wave_sum_f64(e_all); e_out = wave_sum_f64(e_out);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = fs; red[1][threadIdx.x >> 6] = sk2n; red[2][threadIdx.x >> 6] = sk2r;
+        red[3][threadIdx.x >> 6] = e_all; red[4][threadIdx.x >> 6] = e_out;
+    }
     __syncthreads();
     if (threadIdx.x < 3) {
         double tot = 0.0;
         for (int i = 0; i < (int)blockDim.x / 64; i++) tot += red[threadIdx.x][i];
         fs_partial[((size_t)threadIdx.x * nsub + sub) * P::G + g] = tot;      // [3][nsub][G]
+    }
+    if (win && (threadIdx.x == 3 || threadIdx.x == 4)) {
+        // energy of k_n, k_r in this column group: all rows / the rows dropped by the window (summed over the groups
+        // and checked by k_var_cols)
+        double tot = 0.0;
+        for (int i = 0; i < (int)blockDim.x / 64; i++) tot += red[threadIdx.x][i];
+        fs_partial[((size_t)threadIdx.x * nsub + sub) * P::G + g] = tot;      // [5][nsub][G]
     }
 }
 
@@ -472,9 +524,11 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
 template <class P>
 __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
                                                          const float2* __restrict__ twg, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2,
-                                                         int nsub) {
+                                                         int nsub, int nyb, int wb) {
     extern __shared__ float2 s[];
-    WG_TASK(P::LB, nsub, yb, sub);
+    WG_TASK(nyb, nsub, ybw, sub);
+    // with a row window only the blocks that hold rows < wh or >= L - wh exist: nyb = 2 wb of them
+    const int yb = (nyb == P::LB || ybw < wb) ? ybw : P::LB - 2 * wb + ybw;
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     __syncthreads();                                                // the position table is used right away
@@ -653,16 +707,26 @@ template <class P>
 __global__ __launch_bounds__(P::VAR_THREADS, P::VAR_MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ Tk2n,
                                                          const float2* __restrict__ Tk2r, const float2* __restrict__ twg,
                                                          float2* __restrict__ UVS, const zscal* __restrict__ sc,
-                                                         const double* __restrict__ fs_partial, int nsub) {
+                                                         const double* __restrict__ fs_partial, int nsub, int wh, int32_t* __restrict__ d_err) {
     extern __shared__ float2 s[];
     __shared__ float s_beta;
     WG_TASK(P::G, nsub, g, sub);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, nsub, sub, sc[sub]);
+    if (2 * wh < P::L && g == 0 && threadIdx.x == 64) {
+        // the rows the window dropped from k_n, k_r must hold nothing a float32 transform could tell from zero
+        double ta = 0.0, to = 0.0;
+        for (int gg = 0; gg < P::G; gg++) {
+            ta += fs_partial[((size_t)3 * nsub + sub) * P::G + gg];
+            to += fs_partial[((size_t)4 * nsub + sub) * P::G + gg];
+        }
+        if (!(to <= Z3_KWIN_TOL * ta)) atomicOr(d_err, BBX_DERR_PSF_WINDOW);
+    }
     constexpr int RT = P::VAR_THREADS, NE = (P::NL * P::L + RT - 1) / RT;        // two parked arrays: 512 threads, <= 128 VGPRs, no spills
     float2 park[NE], coef[NE];
-    load_t_lines<P>(Tk2n, sub, g, s);
+    const bool win = 2 * wh < P::L;
+    if (win) load_t_lines_win<P>(Tk2n, sub, g, s, wh); else load_t_lines<P>(Tk2n, sub, g, s);
     __syncthreads();
     fft_fwd<P>(s, tw);
     R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kn^2)^
@@ -672,7 +736,7 @@ __global__ __launch_bounds__(P::VAR_THREADS, P::VAR_MINW) void k_var_cols(const 
     fft_fwd<P>(s, tw);
     R_LOOP(k, e, l, p) park[k] = cmul(coef[k], s[l * P::LS + npos(p)]);
     __syncthreads();
-    load_t_lines<P>(Tk2r, sub, g, s);
+    if (win) load_t_lines_win<P>(Tk2r, sub, g, s, wh); else load_t_lines<P>(Tk2r, sub, g, s);
     __syncthreads();
     fft_fwd<P>(s, tw);
     R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kr^2)^
@@ -813,7 +877,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     int rc;
     const size_t unit = (size_t)nsub * P::UNIT, hunit = (size_t)nsub * P::LB * P::HP;
     // 4 T + 4 U + 6 C arrays + 2 halo arrays + scalars + partial sums
-    const size_t bytes = (14 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 3 * (size_t)nsub * P::G * sizeof(double) + 4096;
+    const size_t bytes = (14 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 5 * (size_t)nsub * P::G * sizeof(double) + 4096;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
     float2* arr[14]; for (int i = 0; i < 14; i++) arr[i] = (float2*)ws + (size_t)i * unit;
     float2 *HSn = (float2*)ws + 14 * unit, *HSr = HSn + hunit;
@@ -826,8 +890,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
     const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + aux_bytes<P>(),
                  lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2) + aux_bytes<P>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (ctx->zogy3_attr_L != P::L) {                       // per context (= per device and issuing thread)
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_cols_fwd<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -835,21 +898,34 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
         BBX_HIP(hipFuncSetAttribute((const void*)k_img_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_var_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_final_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
-        attr_set = true;
+        ctx->zogy3_attr_L = P::L;
     }
     const float inv_n2 = 1.0f / ((float)P::L * (float)P::L);
     const dim3 gcol = grid8(P::G, nsub), grow = grid8(P::LB, nsub), blk(P::THREADS);
     const float2* tw = d_tw;
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub);
+    // Row window of the matched-filter kernels k_n, k_r (real space): they are as compact as the PSFs they are made
+    // of, so only 2 wh of their L rows go through the inverse row pass, the squares and the forward row pass; the rest
+    // is below float32 rounding (checked on the device, Z3_KWIN_TOL).  wh: a multiple of NL; W = 2 wh >= 4 S + 32.
+    int wh = P::L;                                          // 2 wh >= L: no window
+    if (!ctx->zogy_kwin_off && P::L % P::NL == 0) {
+        int w = ((4 * S + 32) / 2 + P::NL - 1) / P::NL * P::NL;
+        if (w < 32) w = (32 + P::NL - 1) / P::NL * P::NL;
+        if (2 * w < P::L) wh = w;
+    }
+    const bool win = 2 * wh < P::L;
+    const int wb = win ? wh / P::NL : 0, nyb_psf = win ? 2 * wb : P::LB;
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub,
+                     wh);
     float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_ROWS, k_psf_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_ROWS, k_psf_rows<P>, grid8(nyb_psf, nsub), dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub,
+                     nyb_psf, wb);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub);            // V_S
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub, wh, ctx->d_err);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;

@@ -41,6 +41,7 @@ extern "C" {
 #define BBX_ERR_NOMEM    -3
 #define BBX_ERR_OVERFLOW -4   /* a device work list overflowed its capacity */
 #define BBX_ERR_NOTCONV  -5   /* an iterative device loop hit its bound */
+#define BBX_ERR_PSFWIN   -6   /* bbx_zogy_frame: the PSFs' matched-filter kernels exceed their row window (BBX_OPT_ZOGY_KWIN_OFF) */
 
 #define BBX_NCHAN 16
 
@@ -90,6 +91,12 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
 /* BBX_OPT_ZOGY_CORE: which 1-D transform bbx_zogy_frame's kernels use: 0 = two steps of register
  * DFTs (bbx_zogy2.hip), 1 = radix passes in LDS (bbx_zogy3.hip).  Same results to rounding. */
 #define BBX_OPT_ZOGY_CORE 3
+/* BBX_OPT_ZOGY_KWIN_OFF (default 0): bbx_zogy_frame takes the matched-filter kernels k_n, k_r (real space) through
+ * their inverse row pass, the squares and the forward row pass on a window of 2 wh >= 4 S + 32 rows around the origin
+ * only -- they are as compact as the S x S PSF stamps they are made of; the share of their energy outside the
+ * window is summed on the device and must stay below 1e-6 (stamp-truncation ringing sits at 1e-9), else the call's step is flagged (device error bit 4).
+ * 1: all L rows (the textbook evaluation; same results to float32 rounding). */
+#define BBX_OPT_ZOGY_KWIN_OFF 4
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
 
 /* Per-step attribution of device-side errors.  Kernels report list overflow / non-convergence by
@@ -97,7 +104,7 @@ int  bbx_set_option(bbx_ctx *ctx, int option, int value);
  * them when a stage function returns.  bbx_step_mark enqueues, on [stream], a move of the flags
  * accumulated so far into *d_slot (device int32, caller-owned; e.g. one slot per stage inside the
  * frame's packed result record) and clears them.  A host that marks after every stage reads, with
- * the frame's scalars, which stage failed (bit 1 = BBX_ERR_OVERFLOW, bit 2 = BBX_ERR_NOTCONV) and
+ * the frame's scalars, which stage failed (bit 1 = BBX_ERR_OVERFLOW, bit 2 = BBX_ERR_NOTCONV, bit 4 = BBX_ERR_PSFWIN) and
  * applies the reference's convention: `<STEP>-P = False` and carry on (blackbox.py:1866-1878). */
 int  bbx_step_mark(bbx_ctx *ctx, int32_t *d_slot, void *stream);
 
