@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbbx_hip.so')
+# BBX_LIB_PATH: a scratch build of the library (kernel-variant experiments, tools/exp/zvar.sh); the product is the in-tree one
+LIB_PATH = os.environ.get('BBX_LIB_PATH') or os.path.join(_HERE, 'libbbx_hip.so')
 
 BBX_RAW_U16, BBX_RAW_F32 = 0, 1
 
@@ -63,6 +64,7 @@ SIGNATURES = {
     'bbx_fpack_tile_stride': (C.c_size_t, [_i, _i]),
     'bbx_fpack_tiles': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_fpack_gather': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_fpack_body': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _i, _vp]),
     'bbx_funpack_tiles': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     'bbx_coadd_prep': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'bbx_resample_lanczos3': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),

@@ -347,6 +347,103 @@ extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const 
 }
 
 // ---------------------------------------------------------------------------------
+// The body of the COMPRESSED_IMAGE binary table as it goes into the file, made on the device in one
+// enqueue (no host round trip between the steps): [ny descriptor rows, big-endian][heap of tile streams].
+//   descriptor row (FITS 4.0 section 10): int32 length, int32 heap offset of COMPRESSED_DATA
+//   [, int32 length, int32 offset of GZIP_COMPRESSED_DATA (0, 0 here), float64 ZSCALE, float64 ZZERO]
+// Rows the quantiser refuses (flag != 0: zero noise / range, NaN) get length 0; their indices are listed in
+// info[] and the host stores them losslessly (gzip column) behind the heap, as CFITSIO does.
+// info (int64): [0] heap bytes, [1] rows listed, [2] 1 = the heap does not fit cap_heap (nothing gathered),
+//               [3] longest tile stream, [4 ...] listed rows (any order)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void put_be32(uint8_t* p, unsigned v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+__device__ __forceinline__ void put_be64(uint8_t* p, unsigned long long v) { put_be32(p, (unsigned)(v >> 32)); put_be32(p + 4, (unsigned)v); }
+
+#define FP_SCAN_THREADS 1024
+__global__ __launch_bounds__(FP_SCAN_THREADS) void k_fp_scan_table(const fp_tile* __restrict__ tiles, int ny, int quant, uint8_t* __restrict__ table,
+                                                                   long long* __restrict__ offsets, long long* __restrict__ info,
+                                                                   long long cap_heap, int max_list) {
+    __shared__ unsigned long long wsum[FP_SCAN_THREADS / 64];
+    __shared__ unsigned wmax[FP_SCAN_THREADS / 64];
+    __shared__ int nlist;
+    const int tid = threadIdx.x, lane = tid & 63, per = (ny + FP_SCAN_THREADS - 1) / FP_SCAN_THREADS;
+    const int r0 = min(tid * per, ny), r1 = min(r0 + per, ny);
+    if (tid == 0) nlist = 0;
+    unsigned long long mine = 0; unsigned mx = 0;
+    for (int r = r0; r < r1; r++) { const unsigned n = tiles[r].nbytes; mine += n; mx = max(mx, n); }
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+    if (lane == 63) wsum[tid >> 6] = incl;
+    if (lane == 0) wmax[tid >> 6] = mx;
+    __syncthreads();
+    unsigned long long base = 0, total = 0; unsigned allmax = 0;
+    for (int w = 0; w < FP_SCAN_THREADS / 64; w++) { if (w < (tid >> 6)) base += wsum[w]; total += wsum[w]; allmax = max(allmax, wmax[w]); }
+    unsigned long long off = base + incl - mine;
+    const int rowlen = quant ? 32 : 8;
+    for (int r = r0; r < r1; r++) {
+        const fp_tile t = tiles[r];
+        offsets[r] = (long long)off;
+        uint8_t* d = table + (size_t)r * rowlen;
+        put_be32(d, t.nbytes); put_be32(d + 4, (unsigned)off);
+        if (quant) {
+            put_be32(d + 8, 0u); put_be32(d + 12, 0u);
+            const bool listed = t.flag != 0;
+            put_be64(d + 16, listed ? 0ull : (unsigned long long)__double_as_longlong(t.zscale));
+            put_be64(d + 24, listed ? 0ull : (unsigned long long)__double_as_longlong(t.zzero));
+            if (listed) { const int k = atomicAdd(&nlist, 1); if (k < max_list) info[4 + k] = r; }
+        }
+        off += t.nbytes;
+    }
+    __syncthreads();
+    if (tid == 0) { info[0] = (long long)total; info[1] = nlist; info[2] = ((long long)total > cap_heap || nlist > max_list) ? 1 : 0; info[3] = allmax; }
+}
+
+// tile streams -> contiguous heap; the destination is unaligned: aligned 4-byte stores assembled from two source words
+__global__ __launch_bounds__(256) void k_fp_gather4(const uint8_t* __restrict__ scratch, size_t tile_stride, const fp_tile* __restrict__ tiles,
+                                                    const long long* __restrict__ offsets, const long long* __restrict__ info,
+                                                    uint8_t* __restrict__ heap) {
+    if (info[2]) return;
+    const int row = blockIdx.x;
+    const unsigned n = tiles[row].nbytes;
+    if (!n) return;
+    const uint8_t* s = scratch + (size_t)row * tile_stride;              // 64-byte aligned
+    uint8_t* d = heap + offsets[row];
+    const unsigned head = min(n, (unsigned)((4 - ((uintptr_t)d & 3)) & 3));
+    if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+    const unsigned nw = (n - head) / 4, sh = 8 * (head & 3);
+    const unsigned* sw = reinterpret_cast<const unsigned*>(s);
+    unsigned* dw = reinterpret_cast<unsigned*>(d + head);
+    for (unsigned k = threadIdx.x; k < nw; k += 256) {
+        // destination word k holds source bytes head + 4k .. head + 4k + 3 (little endian words)
+        const unsigned lo = sw[k], hi = sw[k + 1];                        // (the row's slot is padded: k + 1 is readable)
+        dw[k] = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+    }
+    const unsigned done = head + 4 * nw;
+    if (threadIdx.x < n - done) d[done + threadIdx.x] = s[done + threadIdx.x];
+}
+
+extern "C" int bbx_fpack_body(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed, const float* d_rnd,
+                              uint8_t* d_scratch, void* d_tiles, long long* d_offsets, uint8_t* d_body, long long cap_body, long long* d_info,
+                              int max_list, void* stream) {
+    if (!d_offsets || !d_body || !d_info || max_list < 0) return BBX_ERR_ARG;
+    const int rc = bbx_fpack_tiles(ctx, ny, nx, d_img, bitpix, qlevel, dither_seed, d_rnd, d_scratch, d_tiles, stream);
+    if (rc) return rc;
+    const int quant = bitpix == -32, rowlen = quant ? 32 : 8, bytepix = quant ? 4 : bitpix / 8;
+    const long long table = (long long)ny * rowlen;
+    if (cap_body < table) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_fp_scan_table, dim3(1), dim3(FP_SCAN_THREADS), 0, s, (const fp_tile*)d_tiles, ny, quant, d_body, d_offsets, d_info,
+                       cap_body - table, max_list);
+    hipLaunchKernelGGL(k_fp_gather4, dim3(ny), dim3(256), 0, s, d_scratch, fp_tile_stride(nx, bytepix), (const fp_tile*)d_tiles, d_offsets, d_info,
+                       d_body + table);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // funpack: Rice decode of row tiles (+ un-quantisation of float images).  The codes of a
 // tile are sequential (unary prefixes), so one thread walks one tile; the ~10^4 tiles of a
 // frame run side by side.  Decoded values are staged per 32-pixel block in registers and

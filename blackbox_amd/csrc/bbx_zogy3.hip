@@ -51,8 +51,8 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #define Z3_LIGHT_THREADS Z3_THREADS   // k_psf_rows, k_img_rows (nothing parked in registers)
 #endif
 #ifndef Z3_VAR_THREADS
-#define Z3_VAR_THREADS 512     // k_var_cols keeps two spectra in registers
-#define Z3_VAR_MINW 4
+#define Z3_VAR_THREADS 512     // k_var_cols keeps two spectra in registers (768 threads with one of them parked in the
+#define Z3_VAR_MINW 4          // consumed T tiles instead: no faster -- the kernel is bound by its five transforms)
 #endif
 #ifndef Z3_MINW
 #define Z3_MINW 6              // waves per SIMD the register allocation must allow (two workgroups of 768 threads)
@@ -449,9 +449,25 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             float2 acc = make_float2(0.f, 0.f);
             // the stamp's columns sit at x = -h .. S-1-h (mod L): the twiddle index kx x advances by kx per column
             int idx = (kk * ((P::L - h % P::L) % P::L)) % P::L;         // kx (L - h) < H L: 32-bit
-            for (int i = 0; i < S; i++) {
-                const float2 w = twg[idx];
-                const float p = st[j * S + i];
+            // four terms per round: their loads (stamp row from global memory, twiddles from the workgroup's table) go out
+            // together instead of one round trip per term
+            const float* row = st + j * S;
+            int i = 0;
+            for (; i + 4 <= S; i += 4) {
+                int i1 = idx + kk; if (i1 >= P::L) i1 -= P::L;
+                int i2 = i1 + kk; if (i2 >= P::L) i2 -= P::L;
+                int i3 = i2 + kk; if (i3 >= P::L) i3 -= P::L;
+                const float p0 = row[i], p1 = row[i + 1], p2 = row[i + 2], p3 = row[i + 3];
+                const float2 w0 = tw[idx], w1 = tw[i1], w2 = tw[i2], w3 = tw[i3];
+                acc.x += p0 * w0.x; acc.y += p0 * w0.y;
+                acc.x += p1 * w1.x; acc.y += p1 * w1.y;
+                acc.x += p2 * w2.x; acc.y += p2 * w2.y;
+                acc.x += p3 * w3.x; acc.y += p3 * w3.y;
+                idx = i3 + kk; if (idx >= P::L) idx -= P::L;
+            }
+            for (; i < S; i++) {
+                const float2 w = tw[idx];
+                const float p = row[i];
                 acc.x += p * w.x; acc.y += p * w.y;
                 idx += kk; if (idx >= P::L) idx -= P::L;
             }
@@ -888,8 +904,11 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     float2 *T0 = arr[0], *T1 = arr[1], *T2 = arr[2], *T3 = arr[3], *U0 = arr[4], *U1 = arr[5], *U2 = arr[6], *U3 = arr[7];
     float2 *cA = arr[8], *cB = arr[9], *cKn = arr[10], *cKr = arr[11], *cK2n = arr[12], *cK2r = arr[13];
     BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
-    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + aux_bytes<P>(),
-                 lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2) + aux_bytes<P>();
+#ifndef Z3_LDS_PAD
+#define Z3_LDS_PAD 0           // experiments: extra dynamic LDS per workgroup (forces one workgroup per CU)
+#endif
+    const size_t lds = (size_t)P::NL * P::LS * sizeof(float2) + aux_bytes<P>() + Z3_LDS_PAD,
+                 lds_fin = (size_t)(P::NL + 1) * P::LS * sizeof(float2) + aux_bytes<P>() + Z3_LDS_PAD;
     if (ctx->zogy3_attr_L != P::L) {                       // per context (= per device and issuing thread)
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

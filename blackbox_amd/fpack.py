@@ -101,26 +101,20 @@ def compress_tiles(ctx, img, qlevel=16, dither_seed=1, _view=False):
                 flag=t['flag'], gz_nbytes=gz_nbytes, gz_offsets=gz_offsets)
 
 
-def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=None, header=None, qlevel=16,
-                dither_seed=1, gz_nbytes=None, gz_offsets=None, bzero=None):
-    """write primary HDU + COMPRESSED_IMAGE binary table (FITS 4.0 section 10) around tile
-    streams that are already compressed"""
+def fz_header_bytes(shape, bitpix, pcount, maxlen, maxgz=0, header=None, dither_seed=1, bzero=None):
+    """primary HDU + header of the COMPRESSED_IMAGE binary table (FITS 4.0 section 10), padded to blocks"""
     ny, nx = shape
     quant = bitpix == -32
     rowlen = 8 + (24 if quant else 0)
-    maxlen = int(np.max(nbytes)) if len(nbytes) else 0
-    if gz_nbytes is None:
-        gz_nbytes, gz_offsets = np.zeros(ny, np.int64), np.zeros(ny, np.int64)
-    maxgz = int(np.max(gz_nbytes)) if len(gz_nbytes) else 0
     cards = [fitsio._card('XTENSION', 'BINTABLE', 'binary table extension'), fitsio._card('BITPIX', 8, 'array data type'),
              fitsio._card('NAXIS', 2, 'number of array dimensions'), fitsio._card('NAXIS1', rowlen, 'width of table in bytes'),
-             fitsio._card('NAXIS2', ny, 'number of rows in table'), fitsio._card('PCOUNT', int(len(heap)), 'size of the heap'),
+             fitsio._card('NAXIS2', ny, 'number of rows in table'), fitsio._card('PCOUNT', int(pcount), 'size of the heap'),
              fitsio._card('GCOUNT', 1, 'number of groups'), fitsio._card('TFIELDS', 4 if quant else 1, 'number of fields in each row'),
              fitsio._card('TTYPE1', 'COMPRESSED_DATA', 'label for field 1'),
-             fitsio._card('TFORM1', '1PB({})'.format(maxlen), 'data format of field: variable length array')]
+             fitsio._card('TFORM1', '1PB({})'.format(int(maxlen)), 'data format of field: variable length array')]
     if quant:
         cards += [fitsio._card('TTYPE2', 'GZIP_COMPRESSED_DATA', 'label for field 2'),
-                  fitsio._card('TFORM2', '1PB({})'.format(maxgz), 'data format of field: variable length array'),
+                  fitsio._card('TFORM2', '1PB({})'.format(int(maxgz)), 'data format of field: variable length array'),
                   fitsio._card('TTYPE3', 'ZSCALE', 'label for field 3'), fitsio._card('TFORM3', '1D', 'data format of field: 8-byte DOUBLE'),
                   fitsio._card('TTYPE4', 'ZZERO', 'label for field 4'), fitsio._card('TFORM4', '1D', 'data format of field: 8-byte DOUBLE')]
     cards += [fitsio._card('ZIMAGE', True, 'extension contains compressed image'),
@@ -152,6 +146,20 @@ def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=N
                     fitsio._card('NAXIS', 0, 'number of array dimensions'), fitsio._card('EXTEND', True),
                     'END'.ljust(80)]).encode('ascii')
     prim += b' ' * ((-len(prim)) % fitsio.BLOCK)
+    return prim + ext
+
+
+def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=None, header=None, qlevel=16,
+                dither_seed=1, gz_nbytes=None, gz_offsets=None, bzero=None):
+    """write primary HDU + COMPRESSED_IMAGE binary table (FITS 4.0 section 10) around tile
+    streams that are already compressed"""
+    ny, nx = shape
+    quant = bitpix == -32
+    maxlen = int(np.max(nbytes)) if len(nbytes) else 0
+    if gz_nbytes is None:
+        gz_nbytes, gz_offsets = np.zeros(ny, np.int64), np.zeros(ny, np.int64)
+    maxgz = int(np.max(gz_nbytes)) if len(gz_nbytes) else 0
+    head = fz_header_bytes(shape, bitpix, len(heap), maxlen, maxgz, header, dither_seed, bzero)
     if quant:
         rows = np.zeros(ny, dtype=[('len', '>i4'), ('off', '>i4'), ('glen', '>i4'), ('goff', '>i4'), ('zscale', '>f8'),
                                    ('zzero', '>f8')])
@@ -162,17 +170,95 @@ def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=N
     rows['len'], rows['off'] = nbytes, offsets
     body = rows.tobytes() + bytes(heap)
     with open(path, 'wb') as f:
-        f.write(prim)
-        f.write(ext)
+        f.write(head)
         f.write(body)
         f.write(b'\0' * ((-len(body)) % fitsio.BLOCK))
     return path
 
 
+_BODY = {}
+
+
+def _body_buffers(dev, ny, nx, need=None):
+    """device buffers of the one-enqueue path (bbx_fpack_body), kept per device and shape"""
+    key = (str(dev), ny, nx)
+    b = _BODY.get(key)
+    cap = ny * 32 + (int(0.6 * ny * nx * 4) if need is None else int(need)) + 4096
+    if b is None or b['cap'] < cap:
+        b = _BODY[key] = dict(cap=cap, scratch=torch.empty(ny * lib.bbx_fpack_tile_stride(nx, 4), dtype=torch.uint8, device=dev),
+                              tiles=torch.empty(ny * 24, dtype=torch.uint8, device=dev), off=torch.empty(ny, dtype=torch.int64, device=dev),
+                              body=torch.empty(cap, dtype=torch.uint8, device=dev),
+                              info=torch.empty(4 + 4096, dtype=torch.int64, device=dev))
+    return b
+
+
 def fpack_image(ctx, path, img, header=None, quant=None, dither_seed=1):
     """the reference's fpack(filename) for a device image: float32 -> quantised with level
     [quant] (default by product name: 2 for Scorr / limmag, 4 for Fpsf, else 16); integer ->
-    lossless.  -> path of the .fz file"""
+    lossless.  -> path of the .fz file.  One enqueue on the device (tile streams, offsets, descriptor table:
+    bbx_fpack_body), one copy of exactly the bytes of the file body, the rows the quantiser refused gzip-compressed
+    on the host as CFITSIO stores them."""
+    if quant is None:
+        quant = 2 if ('Scorr' in path or 'limmag' in path) else (4 if 'Fpsf' in path else 16)
+    out = path if path.endswith('.fz') else path + '.fz'
+    if img.dim() != 2 or not img.is_contiguous():
+        raise ValueError('contiguous 2-D image expected')
+    bzero = None
+    if img.dtype == torch.uint16:                       # FITS stores uint16 as int16 with BZERO = 32768
+        img = (img.to(torch.int32) - 32768).to(torch.int16)
+        bzero = 32768
+    bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32}[img.dtype]
+    ny, nx = img.shape
+    dev = img.device
+    rowlen = 32 if bitpix == -32 else 8
+    need = None
+    for _ in range(2):
+        b = _body_buffers(dev, ny, nx, need)
+        rnd = _rnd(dev) if bitpix == -32 else None
+        check(lib.bbx_fpack_body(ctx.h, ny, nx, C.c_void_p(img.data_ptr()), bitpix, float(quant), int(dither_seed),
+                                 C.c_void_p(rnd.data_ptr()) if rnd is not None else None, C.c_void_p(b['scratch'].data_ptr()),
+                                 C.c_void_p(b['tiles'].data_ptr()), C.c_void_p(b['off'].data_ptr()), C.c_void_p(b['body'].data_ptr()),
+                                 b['cap'], C.c_void_p(b['info'].data_ptr()), 4096, ctx.stream()), 'bbx_fpack_body', ctx.h)
+        info = b['info'].cpu().numpy()
+        total, nlist, overflow, maxlen = int(info[0]), int(info[1]), int(info[2]), int(info[3])
+        if not overflow:
+            break
+        if nlist > 4096:
+            raise ValueError('{} rows of the image cannot be quantised'.format(nlist))
+        need = total                                    # an image that hardly compresses: once more with room for it
+    nbody = ny * rowlen + total
+    hp = _pinned(nbody)
+    hp.copy_(b['body'][:nbody], non_blocking=True)
+    parts, maxgz = [], 0
+    listed = np.sort(info[4:4 + nlist]) if nlist else None
+    rows = img[torch.from_numpy(listed).to(dev)].cpu().numpy().astype('>f4') if nlist else None
+    torch.cuda.current_stream(dev).synchronize()
+    body = hp.numpy()
+    if nlist:
+        import gzip
+        table = body[:ny * rowlen].view([('len', '>i4'), ('off', '>i4'), ('glen', '>i4'), ('goff', '>i4'), ('zscale', '>f8'), ('zzero', '>f8')])
+        pos = total
+        for k, r in enumerate(listed):
+            g = gzip.compress(rows[k].tobytes(), 6, mtime=0)
+            table['glen'][r], table['goff'][r] = len(g), pos
+            pos += len(g)
+            maxgz = max(maxgz, len(g))
+            parts.append(g)
+    pcount = total + sum(len(g) for g in parts)
+    head = fz_header_bytes((ny, nx), bitpix, pcount, maxlen, maxgz, header, dither_seed, bzero)
+    nb = nbody + pcount - total
+    with open(out, 'wb') as f:
+        f.write(head)
+        f.write(memoryview(body))
+        for g in parts:
+            f.write(g)
+        f.write(b'\0' * ((-nb) % fitsio.BLOCK))
+    return out
+
+
+def fpack_image_serial(ctx, path, img, header=None, quant=None, dither_seed=1):
+    """the same file through the step-by-step path (compress_tiles + assemble_fz): kept as the cross-check of the
+    one-enqueue path (tests/test_fpack.py: byte-identical files)"""
     if quant is None:
         quant = 2 if ('Scorr' in path or 'limmag' in path) else (4 if 'Fpsf' in path else 16)
     out = path if path.endswith('.fz') else path + '.fz'

@@ -1,0 +1,234 @@
+"""Output stage: the products of a frame leave the GPU as tile-compressed FITS (`.fits.fz`) without
+stalling the lane that made them.
+
+The reference writes its products with astropy and fpacks the files it keeps afterwards
+(blackbox.py:1981-1990 write, 812-857 fpack, 3933-4035 copy_files2keep).  Here the compression runs on
+the device, queued on the lane's stream right behind the kernels that produced the image
+(bbx_fpack_body: tile streams, offsets and the big-endian descriptor table in one enqueue); a pool of host
+writer threads takes over from there:
+
+    lane thread    : bbx_fpack_body -> async copy of the 4-number summary -> event          (no host wait)
+    writer thread  : wait for the event -> device-to-host copy of exactly table + heap bytes into its pinned
+                     buffer (own copy stream) -> device slot free again -> rows the quantiser refused: fetched and
+                     gzip-compressed (CFITSIO's GZIP_COMPRESSED_DATA column) -> header cards -> file
+
+Everything a writer thread waits on releases the GIL (event / stream synchronisation, zlib, file writes).
+The files are byte-identical to what fpack.fpack_image writes.
+"""
+import ctypes as C
+import gzip
+import os
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from . import fitsio, fpack
+from ._lib import lib, check
+
+MAX_LIST = 4096                      # rows per image the quantiser may refuse before the image falls back to the serial path
+
+
+def default_quant(path):
+    """quantisation level by product name, as the reference fpacks them (blackbox.py:826-845)"""
+    return 2 if ('Scorr' in path or 'limmag' in path) else (4 if 'Fpsf' in path else 16)
+
+
+class _Slot:
+    __slots__ = ('d_body', 'd_info', 'h_info', 'ev', 'cap')
+
+
+class _Job:
+    __slots__ = ('lane', 'slot', 'img', 'path', 'quant', 'seed', 'bitpix', 'shape', 'header', 'header_ready', 'group', 'bzero')
+
+
+class FrameGroup:
+    """the files of one frame: done() fires when the last of them is on disk"""
+
+    def __init__(self, token, on_done):
+        self.token, self.on_done = token, on_done
+        self.left, self.lock, self.paths, self.error = 0, threading.Lock(), [], None
+        self.header_ready = threading.Event()
+        self.headers = {}
+
+    def file_done(self, path, err=None):
+        with self.lock:
+            self.left -= 1
+            self.paths.append(path)
+            if err is not None and self.error is None:
+                self.error = err
+            last = self.left == 0
+        if last and self.on_done is not None:
+            self.on_done(self)
+
+
+class FzLane:
+    """device buffers of one lane (a library context + its stream): one scratch for the tile streams at their stride
+    (reused image after image: stream order), [nslots] output slots that hold table + heap until a writer has copied them"""
+
+    def __init__(self, ctx, ny, nx, nslots=8, heap_frac=0.6):
+        self.ctx, self.ny, self.nx = ctx, ny, nx
+        dev = ctx.device
+        self.d_scratch = torch.empty(ny * lib.bbx_fpack_tile_stride(nx, 4), dtype=torch.uint8, device=dev)
+        self.d_tiles = torch.empty(ny * 24, dtype=torch.uint8, device=dev)
+        self.d_off = torch.empty(ny, dtype=torch.int64, device=dev)
+        self.free = queue.Queue()
+        self.slots = []
+        cap = ny * 32 + int(heap_frac * ny * nx * 4) + 4096
+        for _ in range(nslots):
+            s = _Slot()
+            s.cap = cap
+            s.d_body = torch.empty(cap, dtype=torch.uint8, device=dev)
+            s.d_info = torch.empty(4 + MAX_LIST, dtype=torch.int64, device=dev)
+            s.h_info = torch.empty(4 + MAX_LIST, dtype=torch.int64, pin_memory=True)
+            s.ev = torch.cuda.Event()
+            self.slots.append(s)
+            self.free.put(s)
+
+    def enqueue(self, img, quant, seed):
+        """queue the compression of [img] (contiguous 2-D float32 / uint8 / int16 / int32 device tensor of this lane's
+        shape) on the current stream -> slot (blocks only when all slots are still waiting for their writer)"""
+        if tuple(img.shape) != (self.ny, self.nx) or not img.is_contiguous():
+            raise ValueError('image of shape {} expected'.format((self.ny, self.nx)))
+        bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32}[img.dtype]
+        s = self.free.get()
+        rnd = fpack._rnd(img.device) if bitpix == -32 else None
+        st = torch.cuda.current_stream(img.device)
+        check(lib.bbx_fpack_body(self.ctx.h, self.ny, self.nx, C.c_void_p(img.data_ptr()), bitpix, float(quant), int(seed),
+                                 C.c_void_p(rnd.data_ptr()) if rnd is not None else None, C.c_void_p(self.d_scratch.data_ptr()),
+                                 C.c_void_p(self.d_tiles.data_ptr()), C.c_void_p(self.d_off.data_ptr()),
+                                 C.c_void_p(s.d_body.data_ptr()), s.cap, C.c_void_p(s.d_info.data_ptr()), MAX_LIST,
+                                 C.c_void_p(st.cuda_stream)), 'bbx_fpack_body', self.ctx.h)
+        s.h_info.copy_(s.d_info, non_blocking=True)
+        s.ev.record(st)
+        return s, bitpix
+
+
+class OutputStage:
+    """writer pool + per-lane device buffers.  submit() is called by a lane thread (inside its torch.cuda.stream) right
+    after the image has been queued; headers may come later (FrameGroup.header_ready)."""
+
+    def __init__(self, device, ny, nx, nwriters=8, nslots=8, heap_frac=0.6, dither_seed=1):
+        self.device, self.ny, self.nx = device, ny, nx
+        self.nslots, self.heap_frac, self.seed = nslots, heap_frac, dither_seed
+        self.lanes = {}
+        self.q = queue.Queue()
+        self.threads = [threading.Thread(target=self._writer, args=(k,), daemon=True) for k in range(nwriters)]
+        self.bytes_written, self.files_written = 0, 0
+        self.stat_lock = threading.Lock()
+        for t in self.threads:
+            t.start()
+
+    def lane(self, ctx):
+        """the device buffers of the lane behind [ctx] (made at its first image, under its stream)"""
+        key = id(ctx)
+        if key not in self.lanes:
+            self.lanes[key] = FzLane(ctx, self.ny, self.nx, self.nslots, self.heap_frac)
+        return self.lanes[key]
+
+    def new_group(self, token=None, on_done=None):
+        return FrameGroup(token, on_done)
+
+    def submit(self, ctx, group, img, path, quant=None, bzero=None):
+        """queue [img] -> [path].fz.  The caller keeps [img] unchanged until the group reports the file done."""
+        lane = self.lane(ctx)
+        out = path if path.endswith('.fz') else path + '.fz'
+        q = default_quant(path) if quant is None else quant
+        if img.dtype == torch.uint16:                       # FITS stores uint16 as int16 with BZERO = 32768
+            img = (img.to(torch.int32) - 32768).to(torch.int16)
+            bzero = 32768
+        slot, bitpix = lane.enqueue(img, q, self.seed)
+        j = _Job()
+        j.lane, j.slot, j.img, j.path, j.quant, j.seed, j.bitpix, j.shape, j.group, j.bzero = lane, slot, img, out, q, self.seed, bitpix, \
+            (self.ny, self.nx), group, bzero
+        with group.lock:
+            group.left += 1
+        self.q.put(j)
+        return out
+
+    def close(self):
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join(60.0)
+        self.lanes.clear()
+
+    # ---- writer thread ----------------------------------------------------------------------------
+    def _writer(self, k):
+        torch.cuda.set_device(self.device)
+        copy_stream = torch.cuda.Stream(device=self.device)
+        pinned = [None]
+
+        def buf(n):
+            if pinned[0] is None or pinned[0].numel() < n:
+                pinned[0] = torch.empty(int(n * 1.2) + 65536, dtype=torch.uint8, pin_memory=True)
+            return pinned[0][:n]
+        while True:
+            j = self.q.get()
+            if j is None:
+                return
+            try:
+                self._write(j, copy_stream, buf)
+                j.group.file_done(j.path)
+            except BaseException as e:                                     # reported with the frame
+                j.group.file_done(j.path, e)
+
+    def _write(self, j, copy_stream, buf):
+        ny, nx = j.shape
+        quant = j.bitpix == -32
+        rowlen = 32 if quant else 8
+        s = j.slot
+        s.ev.synchronize()
+        info = s.h_info.numpy()
+        total, nlist, overflow, maxlen = int(info[0]), int(info[1]), int(info[2]), int(info[3])
+        if overflow:
+            # heap larger than the slot (an image that hardly compresses) or too many refused rows: the serial path
+            j.lane.free.put(s)
+            with torch.cuda.stream(copy_stream):
+                fpack.fpack_image(j.lane.ctx, j.path, j.img, self._header(j), j.quant, j.seed)
+            return
+        nbody = ny * rowlen + total
+        hb = buf(nbody)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(s.ev)
+            hb.copy_(s.d_body[:nbody], non_blocking=True)
+            listed = np.sort(info[4:4 + nlist].copy()) if nlist else None
+            rows = None
+            if nlist:
+                rows = j.img[torch.from_numpy(listed).to(j.img.device)].to('cpu', non_blocking=False).numpy()
+        copy_stream.synchronize()
+        j.lane.free.put(s)                                                 # the device slot can take the next image
+        body = hb.numpy()
+        parts, maxgz = [], 0
+        if nlist:
+            table = body[:ny * rowlen].view([('len', '>i4'), ('off', '>i4'), ('glen', '>i4'), ('goff', '>i4'), ('zscale', '>f8'), ('zzero', '>f8')])
+            pos = total
+            be = rows.astype('>f4')
+            for k, r in enumerate(listed):
+                g = gzip.compress(be[k].tobytes(), 6, mtime=0)
+                table['glen'][r], table['goff'][r] = len(g), pos
+                pos += len(g)
+                maxgz = max(maxgz, len(g))
+                parts.append(g)
+        pcount = total + sum(len(g) for g in parts)
+        head = fpack.fz_header_bytes(j.shape, j.bitpix, pcount, maxlen, maxgz, self._header(j), j.seed, j.bzero)
+        nb = nbody + (pcount - total)
+        with open(j.path, 'wb') as f:
+            f.write(head)
+            f.write(memoryview(body))
+            for g in parts:
+                f.write(g)
+            f.write(b'\0' * ((-nb) % fitsio.BLOCK))
+        with self.stat_lock:
+            self.bytes_written += len(head) + nb
+            self.files_written += 1
+
+    @staticmethod
+    def _header(j):
+        g = j.group
+        g.header_ready.wait()
+        h = g.headers.get(j.path)
+        if h is None:
+            h = g.headers.get(None)
+        return h

@@ -302,6 +302,18 @@ int bbx_fpack_tiles(bbx_ctx *ctx, int ny, int nx, const void *d_img, int bitpix,
 int bbx_fpack_gather(bbx_ctx *ctx, int ny, int nx, int bitpix, const uint8_t *d_scratch,
                      const void *d_tiles, const long long *d_offsets, uint8_t *d_heap,
                      void *stream);
+/* The same compression in ONE enqueue, down to the bytes of the file: tile streams, their offsets (prefix sum on the
+ * device) and the descriptor table of the COMPRESSED_IMAGE extension (big-endian) -- d_body = [ny rows of
+ * {int32 len, int32 off [, int32 gzlen = 0, int32 gzoff = 0, float64 ZSCALE, float64 ZZERO]}][heap].  No host round
+ * trip between the steps, so a lane can queue it behind the kernels that make the image (reference: fpack of the
+ * products that are kept, blackbox.py:812-857, 3933-4035).  d_scratch: ny * bbx_fpack_tile_stride bytes; d_tiles:
+ * ny * 24 bytes; d_offsets: ny int64; d_info: (4 + max_list) int64 = [heap bytes, rows listed, 1 = heap larger than
+ * cap_body - table (nothing gathered), longest stream, rows the quantiser refused (length 0 in the table: the
+ * host stores them gzip-compressed behind the heap, as CFITSIO does)]. */
+int bbx_fpack_body(bbx_ctx *ctx, int ny, int nx, const void *d_img, int bitpix, float qlevel, int dither_seed,
+                   const float *d_rnd, uint8_t *d_scratch, void *d_tiles, long long *d_offsets, uint8_t *d_body,
+                   long long cap_body, long long *d_info, int max_list, void *stream);
+
 
 /* ---- a1 / f2: funpack -- reading tile-compressed images (raw frames arrive as .fits.fz;
  * read_hdulist, blackbox.py:1451) -------------------------------------------------------

@@ -174,3 +174,68 @@ def test_gpu_funpack(tmp_path):
         q = FP.rice_decode(c['heap'][c['offsets'][r]:c['offsets'][r] + c['nbytes'][r]].tobytes(), 10560, 4)
         assert np.array_equal(back[r], FP.unquantize_row(q, r + 9999, c['zscale'][r], c['zzero'][r]))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_one_enqueue_path_and_output_stage(tmp_path):
+    """bbx_fpack_body (tile streams + offsets + big-endian descriptor table in one enqueue) writes the very files of
+    the step-by-step path -- float images at the three quantisation levels with rows the quantiser refuses (constant,
+    NaN), the uint8 mask, a uint16 raw frame, an image that hardly compresses (retry with a larger slot) -- and so
+    does the asynchronous output stage (outstage.OutputStage: compression queued on a lane's stream, writer threads,
+    headers handed over after the images were queued)."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import threading
+    from blackbox_amd import reduce as R
+    from blackbox_amd import fpack as P
+    from blackbox_amd import outstage
+    ctx = R.Context(0)
+    rs = np.random.RandomState(11)
+    ny, nx = 96, 2640
+    img = (250 + rs.normal(0, 11, (ny, nx))).astype(np.float32)
+    img[0:6] = 251.5; img[90:] = -3.0; img[40, 17] = np.nan; img[41, :] = np.inf
+    img[50, 100:140] += 6e4
+    msk = np.zeros((ny, nx), np.uint8); msk[rs.rand(ny, nx) < 0.01] = 2; msk[:6] = 32; msk[30:34, 500:900] = 4
+    raw = rs.randint(900, 1400, (ny, nx)).astype(np.uint16)
+    noise = rs.normal(0, 1e6, (ny, nx)).astype(np.float32)            # Rice cannot do anything with this at q = 16 ... fits anyway
+    hdr = {'OBJECT': 'field', 'RDNOISE': 9.5, 'Z-P': True}
+    cases = [('a_red.fits', img, None), ('a_Scorr.fits', img, None), ('a_Fpsf.fits', img, None), ('a_mask.fits', msk, None),
+             ('a_raw.fits', raw, None), ('a_noise_red.fits', noise, None)]
+    for name, a, q in cases:
+        t = torch.from_numpy(a).to(ctx.device)
+        p1 = P.fpack_image(ctx, str(tmp_path / ('one_' + name)), t, hdr, q, dither_seed=5)
+        p2 = P.fpack_image_serial(ctx, str(tmp_path / ('ser_' + name)), t, hdr, q, dither_seed=5)
+        assert open(p1, 'rb').read() == open(p2, 'rb').read(), name
+    # the asynchronous stage: two "frames" of three files each, headers set after the submission
+    stage = outstage.OutputStage(ctx.device, ny, nx, nwriters=3, nslots=3, dither_seed=5)
+    done = []
+    ev = threading.Event()
+
+    def on_done(g):
+        done.append((g.token, sorted(g.paths), g.error))
+        if len(done) == 2:
+            ev.set()
+    keep = []
+    lane_stream = torch.cuda.Stream(device=ctx.device)
+    groups = []
+    with torch.cuda.stream(lane_stream):
+        for k in range(2):
+            g = stage.new_group(k, on_done)
+            for name, a in (('red', img), ('mask', msk), ('Scorr', img)):
+                t = torch.from_numpy(a).to(ctx.device)
+                keep.append(t)
+                stage.submit(ctx, g, t, str(tmp_path / ('async%d_a_%s.fits' % (k, name))))
+            groups.append(g)
+    for g in groups:
+        g.headers[None] = hdr
+        g.header_ready.set()
+    assert ev.wait(60.0)
+    stage.close()
+    assert [d[0] for d in sorted(done)] == [0, 1] and all(d[2] is None for d in done), done
+    for k in range(2):
+        for name in ('red', 'mask', 'Scorr'):
+            got = open(str(tmp_path / ('async%d_a_%s.fits.fz' % (k, name))), 'rb').read()
+            assert got == open(str(tmp_path / ('one_a_%s.fits.fz' % name)), 'rb').read(), (k, name)
+    assert stage.files_written == 6
+    ctx.close()
