@@ -251,47 +251,109 @@ def cpu_baseline(workload):
                                           '(no LA-Cosmic, no ZOGY: packages absent)')
 
 
-def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None, sink=None):
+def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None, outdir=None, nwriters=8):
     """Steady-state rate of a FramePipeline: depth + W + K + depth frames go through it in one run, fed
     continuously.  The first [depth] frames fill the pipeline, then W warm-up frames; the clock runs from the
     completion of the last warm-up frame to the completion of the K-th frame after it -- exactly K completions with
     the pipeline full at both ends ([depth] cool-down frames are still in flight behind the last timed one, so the
     timed region holds neither the fill nor the drain; a region that ends with the drain reads too fast, because
     the frames in flight at its start were partly done already).  barrier + device synchronisation before the run
-    and after it.  sink: optional callable(frame) run at each completion (the output stage).
+    and after it.
+    outdir: run the output stage as well (outstage.OutputStage: every image product of a frame tile-compressed on its
+    lane and written as .fits.fz by writer threads, the small products by the frame's callback); a frame then counts
+    as complete when its last file is on disk (files are removed again at once: the directory may be a RAM disk).
     -> dict(dt, dt_all (idle to idle, all frames), ...)"""
     from blackbox_amd import _lib
     from blackbox_amd.pipeline import FramePipeline
-    pipe = FramePipeline(ctx, tel, geom, pool=pool, depth=depth, lanes=lanes, **kw)
-    # untimed: first-use allocations, rocFFT plans, workspace growth of every lane
-    pipe.run([(raws[i % len(raws)], {}) for i in range(max(lanes, 2))])
-    pipe.t_stats = [0.0, 0.0, 0.0, 0]
-    mark = {'n': 0}
+    mark = {'n': 0, 'bytes': 0, 'files': 0, 'err': None}
     first = depth + warmup                      # completions before the clock starts
     n_all = first + steps + depth
+    import threading
+    lock, all_done = threading.Lock(), threading.Event()
+
+    def count(f):
+        with lock:
+            mark['n'] += 1
+            n = mark['n']
+            if n == first:
+                mark['t0'] = time.perf_counter()
+                if prof_ctx is not None:
+                    _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
+            elif n == first + steps:
+                mark['t1'] = time.perf_counter()
+                if prof_ctx is not None:
+                    _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 2), 'bbx_profile_enable')      # pause, keep the records
+            mark['last'] = f
+            if n == n_all:
+                all_done.set()
+    stage = None
+    extra = {}
+    if outdir is not None:
+        from blackbox_amd import fitsio, outstage, zogy as G
+        ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
+        stage = outstage.OutputStage(ctx.device, ny, nx, nwriters=nwriters)
+
+        def on_written(f, group):
+            """a writer thread, after the last image of the frame: the small products (mini images, tables, header files),
+            then the frame counts; its files are removed again"""
+            try:
+                if group.error is not None:
+                    raise group.error
+                base = f.out_base
+                small = []
+                if f.sub is not None:
+                    hb = {'BKG-SIZE': f.sub['header_new']['BKG-SIZE']}
+                    for name in ('bkg_mini_new', 'bkg_std_mini_new'):
+                        p = base + '_' + name.replace('_new', '') + '.fits'
+                        fitsio.write_image(p, f.sub[name], hb); small.append(p)
+                    if f.sub.get('catalog') is not None:
+                        small.append(G.format_cat(f.sub['catalog'], base + '_cat.fits', cat_type='new', header2add=f.header))
+                    if f.sub.get('transients') is not None and 'D' in f.out_names:
+                        small.append(G.format_cat(G.transient_table(f.sub['transients']), base + '_trans.fits', cat_type='trans',
+                                                  header2add=f.header))
+                fitsio.write_header(base + '_hdr.fits', f.header); small.append(base + '_hdr.fits')
+                nb = 0
+                for p in list(group.paths) + [q for q in small if q]:
+                    nb += os.path.getsize(p)
+                    os.unlink(p)
+                with lock:
+                    mark['bytes'] += nb
+                    mark['files'] += len(group.paths) + len(small)
+            except BaseException as e:
+                mark['err'] = e
+            count(f)
+        extra = dict(outstage=stage, out_base=lambda idx, h: os.path.join(outdir, 'ML1_f%06d_red' % idx), on_written=on_written)
+    pipe = FramePipeline(ctx, tel, geom, pool=pool, depth=depth, lanes=lanes, **dict(kw, **extra))
+    # untimed: first-use allocations, rocFFT plans, workspace growth of every lane
+    save = (mark['n'], first)
+    first = 10 ** 9                             # (the warm-up frames of the pipeline do not count)
+    pipe.run([(raws[i % len(raws)], {}) for i in range(max(lanes, 2))])
+    if stage is not None:
+        t_end = time.time() + 120
+        while mark['n'] < max(lanes, 2) and time.time() < t_end:
+            time.sleep(0.01)
+    mark['n'], first = 0, save[1]
+    mark['bytes'], mark['files'] = 0, 0
+    pipe.t_stats = [0.0, 0.0, 0.0, 0]
 
     def on_done(idx, f):
-        mark['n'] += 1
-        if sink is not None:
-            sink(f)
-        if mark['n'] == first:
-            mark['t0'] = time.perf_counter()
-            if prof_ctx is not None:
-                _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
-        elif mark['n'] == first + steps:
-            mark['t1'] = time.perf_counter()
-            if prof_ctx is not None:
-                _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 2), 'bbx_profile_enable')      # pause, keep the records
-        mark['last'] = f
+        if stage is None:
+            count(f)
     barrier()
     t_all0 = time.perf_counter()
     pipe.run([(raws[i % len(raws)], {}) for i in range(n_all)], on_done=on_done)
     torch.cuda.synchronize()
+    if stage is not None and not all_done.wait(300.0):
+        raise RuntimeError('output stage: %d of %d frames written (%r)' % (mark['n'], n_all, mark['err']))
     barrier()
     t_end = time.perf_counter()
+    if mark['err'] is not None:
+        raise mark['err']
     out = dict(dt=mark['t1'] - mark['t0'], dt_all=t_end - t_all0, n_all=n_all, t_stats=list(pipe.t_stats), last=mark.get('last'),
-               nworkers=pipe.pool.n)
+               nworkers=pipe.pool.n, bytes_written=mark['bytes'], files_written=mark['files'])
     pipe.close()
+    if stage is not None:
+        stage.close()
     return out
 
 
@@ -344,6 +406,8 @@ def main():
     ap.add_argument('--depth', type=int, default=None, help='frames in flight')
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
     ap.add_argument('--lanes', type=int, default=None, help='stage-C lanes (context + stream + issuing thread) per GPU')
+    ap.add_argument('--writers', type=int, default=8, help='writer threads of the output stage (io_inclusive.measured)')
+    ap.add_argument('--io-only', action='store_true', help='only the measured I/O-inclusive run (debug)')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -618,6 +682,28 @@ def main():
         r3 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 240, 4, depth, lanes, pool, barrier)
         out['long_run'] = dict(frames=240, frames_per_s=240 / r3['dt'], ms_per_frame=1e3 * r3['dt'] / 240)
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
+        # ---- measured: the same pipeline with the output stage in the loop (SURVEY 8d timing item iii) ------------
+        meas = {}
+        import shutil
+        import tempfile
+        for label, root in (('ramdisk', '/dev/shm'), ('scratch', tempfile.gettempdir())):
+            if not os.path.isdir(root) or not os.access(root, os.W_OK):
+                continue
+            td = tempfile.mkdtemp(prefix='bbx_bench_out_', dir=root)
+            try:
+                r4 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 40, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers)
+                meas[label] = dict(frames_per_s=40 / r4['dt'], ms_per_frame=1e3 * r4['dt'] / 40, dir=root,
+                                   MB_per_frame=r4['bytes_written'] / max(1, r4['n_all']) / 1e6,
+                                   files_per_frame=r4['files_written'] / max(1, r4['n_all']), writer_threads=args.writers)
+            except Exception as e:
+                meas[label] = dict(error=repr(e))
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
+        meas['note'] = ('the timed pipeline with every product of a frame on disk before the frame counts: _red, _mask, _D, _Scorr, '
+                        '_Fpsf, _trans_limmag tile-compressed on the lane that made them (bbx_fpack_body, q = 16 / lossless / 16 / 2 / '
+                        '4 / 2) and written as .fits.fz by writer threads; _bkg_mini, _bkg_std_mini, _cat, _trans, _hdr by the '
+                        'frame\'s callback; inputs resident in HBM; steady state over 40 frames; files removed as soon as written')
+        out['io_inclusive']['measured'] = meas
     pool.close()
     if rank == 0:
         if not args.no_cpu:
@@ -635,6 +721,7 @@ def io_inclusive(torch, ctx, raw, N, ms_compute, wl):
     dev = ctx.device
     nprod = 5 if wl == 'zogy' else 1                            # float32 images leaving: red (+ D, Scorr, Fpsf, Fpsferr)
     h_raw = torch.empty(raw.shape, dtype=raw.dtype, pin_memory=True)
+    d_raw = torch.empty_like(raw)                                 # (the upload target: the benchmark's raw frames stay as they are)
     h_img = torch.empty(N, dtype=torch.float32, pin_memory=True)
     h_msk = torch.empty(N, dtype=torch.uint8, pin_memory=True)
     d_img = torch.randn(N, device=dev)
@@ -645,7 +732,7 @@ def io_inclusive(torch, ctx, raw, N, ms_compute, wl):
     reps = 3
     for _ in range(reps):
         with torch.cuda.stream(s1):
-            raw.copy_(h_raw, non_blocking=True)
+            d_raw.copy_(h_raw, non_blocking=True)
         with torch.cuda.stream(s2):
             for _ in range(nprod):
                 h_img.copy_(d_img, non_blocking=True)

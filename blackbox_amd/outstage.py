@@ -48,14 +48,24 @@ class FrameGroup:
 
     def __init__(self, token, on_done):
         self.token, self.on_done = token, on_done
-        self.left, self.lock, self.paths, self.error = 0, threading.Lock(), [], None
+        # left counts the files still to be written + 1 while the frame may still submit more (seal() takes that one)
+        self.left, self.lock, self.paths, self.error = 1, threading.Lock(), [], None
         self.header_ready = threading.Event()
-        self.headers = {}
+        self.headers = {}                      # path -> header dict; None -> the header of every other file
+
+    def set_headers(self, headers):
+        self.headers.update(headers)
+        self.header_ready.set()
+
+    def seal(self):
+        """no more files will be submitted for this frame"""
+        self.file_done(None)
 
     def file_done(self, path, err=None):
         with self.lock:
             self.left -= 1
-            self.paths.append(path)
+            if path is not None:
+                self.paths.append(path)
             if err is not None and self.error is None:
                 self.error = err
             last = self.left == 0
@@ -67,7 +77,7 @@ class FzLane:
     """device buffers of one lane (a library context + its stream): one scratch for the tile streams at their stride
     (reused image after image: stream order), [nslots] output slots that hold table + heap until a writer has copied them"""
 
-    def __init__(self, ctx, ny, nx, nslots=8, heap_frac=0.6):
+    def __init__(self, ctx, ny, nx, nslots=12, heap_frac=0.6):
         self.ctx, self.ny, self.nx = ctx, ny, nx
         dev = ctx.device
         self.d_scratch = torch.empty(ny * lib.bbx_fpack_tile_stride(nx, 4), dtype=torch.uint8, device=dev)
@@ -109,7 +119,9 @@ class OutputStage:
     """writer pool + per-lane device buffers.  submit() is called by a lane thread (inside its torch.cuda.stream) right
     after the image has been queued; headers may come later (FrameGroup.header_ready)."""
 
-    def __init__(self, device, ny, nx, nwriters=8, nslots=8, heap_frac=0.6, dither_seed=1):
+    def __init__(self, device, ny, nx, nwriters=8, nslots=12, heap_frac=0.6, dither_seed=1):
+        # nslots: at least the images of two frames per lane, so that a lane can always finish queueing its frame (a writer
+        # that has copied a slot out may then wait for that frame's header, which only comes once the lane is through)
         self.device, self.ny, self.nx = device, ny, nx
         self.nslots, self.heap_frac, self.seed = nslots, heap_frac, dither_seed
         self.lanes = {}

@@ -220,7 +220,7 @@ def _shm_phase2(args):
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
                  'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane', 'err',
-                 'sub', 'failed', 'os_ok', 'os_fail')
+                 'sub', 'failed', 'os_ok', 'os_fail', 'out_group', 'out_base', 'out_names')
 
 
 class _LaneCtx:
@@ -271,12 +271,17 @@ def _new_event():
 class FramePipeline:
     def __init__(self, ctx, tel, geom, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None, exptime=60.0,
                  pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=2,
-                 detect_sats=False, subtract=None, log=None):
+                 detect_sats=False, subtract=None, log=None, outstage=None, out_base=None, on_written=None):
         """do_finish: crosstalk, mask counts, edge fill (the tail of blackbox_reduce);
         detect_sats: satellite trails before them (blackbox.py:1919-1952);
         subtract: dict of keyword arguments for zogy.optimal_subtraction (ref=, ref_mask=, psf_new=,
         psf_ref=, ...) -- the frame then continues into the background mesh / ZOGY / photometry
-        stage on the same lane (blackbox.py:2350-2354, 2460-2465), results in frame.sub"""
+        stage on the same lane (blackbox.py:2350-2354, 2460-2465), results in frame.sub;
+        outstage: an outstage.OutputStage -- the frame's image products (_red, _mask, and with a subtraction _D, _Scorr,
+        _Fpsf, _trans_limmag) are tile-compressed on the lane right behind the kernels that made them and written as
+        `.fits.fz` by the stage's writer threads (blackbox.py:1981-1990, 812-857); out_base(idx, header) -> path of the
+        frame's _red product without '.fits'; on_written(frame, group) is called by a writer thread when the last file
+        of the frame is on disk"""
         self.ctx, self.tel, self.geom = ctx, tel, geom
         # stage-C lanes: (context, stream); lane 0 is the caller's context
         self.own_ctx = [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
@@ -300,6 +305,9 @@ class FramePipeline:
             self.zogy_gate = G.StreamGate()
         self.keep_sub = ('D', 'Scorr', 'Fpsf', 'Fpsferr')        # device products kept on the frame when keep_outputs
         self.log = log
+        self.outstage, self.out_base, self.on_written = outstage, out_base, on_written
+        if outstage is not None and out_base is None:
+            raise ValueError('outstage needs out_base')
         self.keep_outputs = keep_outputs
         self.sA = torch.cuda.Stream(device=ctx.device)
         # stage A has a library context of its own: it is driven from the orchestrating thread
@@ -312,7 +320,7 @@ class FramePipeline:
         # outputs: one (data, mask) pair per lane unless the caller keeps them (frames of a lane
         # are ordered on its stream, so the pair is free again when the next one starts)
         ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
-        self.lane_out = None if keep_outputs else [
+        self.lane_out = None if (keep_outputs or outstage is not None) else [
             (torch.empty((ny, nx), dtype=torch.float32, device=ctx.device),
              torch.empty((ny, nx), dtype=torch.uint8, device=ctx.device)) for _ in self.lane_ctx]
         self.gain = get_par(settings.gain, tel)
@@ -611,16 +619,19 @@ class FramePipeline:
                     # comes first (its stream has finished with it before any other lane can pick it up: see below)
                     torch.cuda.current_stream().synchronize()
                     self.ref_bkg_std = sub['bkg_std_ref']
-                if not self.keep_outputs:
-                    for k in list(sub):
-                        if torch.is_tensor(sub[k]):
-                            del sub[k]                                # device products stay only on request
                 f.sub = sub
             except (_lib.BBXError, ValueError) as e:
                 f.failed.append('zogy')
                 if self.log is not None:
                     self.log.error('frame %d: [optimal_subtraction] failed: %s', f.idx, e)
             R.step_mark(ctx, d_steps, 'zogy')
+        f.out_group = None
+        if self.outstage is not None:
+            self._submit_outputs(f, ctx, data, mask)
+        if not self.keep_outputs and f.sub is not None:
+            for k in list(f.sub):
+                if torch.is_tensor(f.sub[k]):
+                    del f.sub[k]                                      # device products stay only on request
         # scalar results: one small pinned D2H of the packed record
         f.h_out = (sl['h_std'], sl['h_nobj'] if d_nobj is not None else None, sl['h_stats'] if d_stats is not None else None,
                    sl['h_cnt6'], sl['h_nsats'] if d_nsats is not None else None, sl['h_steps'])
@@ -630,6 +641,30 @@ class FramePipeline:
         f.d_keep = (sol, d_std, d_nobj, d_stats, d_cnt)
         f.data, f.mask = (data, mask) if self.keep_outputs else (None, None)
         f.state = 'C'
+
+    def _submit_outputs(self, f, ctx, data, mask):
+        """queue the frame's image products on this lane for the output stage (no host wait)"""
+        st = self.outstage
+        base = self.out_base(f.idx, f.header)
+        g = st.new_group(f, self._group_done)
+        f.out_group, f.out_base = g, base
+        names = {}
+        names['red'] = st.submit(ctx, g, data, base + '.fits')
+        names['mask'] = st.submit(ctx, g, mask, base.replace('_red', '_mask') + '.fits') if base.endswith('_red') else \
+            st.submit(ctx, g, mask, base + '_mask.fits')
+        sub = f.sub
+        if sub is not None and sub.get('D') is not None:
+            for ext in ('D', 'Scorr', 'Fpsf'):
+                names[ext] = st.submit(ctx, g, sub[ext], '{}_{}.fits'.format(base, ext))
+            nsig = float(sub['header_trans']['T-NSIGMA'][0])
+            lim = sub['Fpsferr'] * nsig                                # `_trans_limmag` as a flux limit (no zeropoint on this path)
+            names['limmag'] = st.submit(ctx, g, lim, base + '_trans_limmag.fits')
+        f.out_names = names
+        g.seal()
+
+    def _group_done(self, g):
+        if self.on_written is not None:
+            self.on_written(g.token, g)
 
     def _finalize(self, f):
         h, hm = f.header, f.hm
@@ -662,6 +697,17 @@ class FramePipeline:
                 h['NSATS'] = hm['NSATS'] = ('None', 'number of satellite trails identified')
         # device-side error flags per step (bbx_step_mark) -> <STEP>-P False for this frame only
         f.failed += R.apply_step_errors(h, hm, f.h_out[5].numpy(), self.log)
+        if getattr(f, 'out_group', None) is not None:
+            # the headers the writers were waiting for: reduction keywords for _red, mask keywords for _mask, reduction +
+            # transient keywords for the subtraction images
+            hdrs = {None: h, f.out_names['mask']: hm}
+            if f.sub is not None and 'header_new' in f.sub:
+                h.update(f.sub['header_new'])
+                ht = dict(h); ht.update(f.sub.get('header_trans', {}))
+                for k in ('D', 'Scorr', 'Fpsf', 'limmag'):
+                    if k in f.out_names:
+                        hdrs[f.out_names[k]] = ht
+            f.out_group.set_headers(hdrs)
         f.d_keep = None
         f.state = 'done'
 

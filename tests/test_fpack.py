@@ -226,10 +226,10 @@ def test_gpu_one_enqueue_path_and_output_stage(tmp_path):
                 t = torch.from_numpy(a).to(ctx.device)
                 keep.append(t)
                 stage.submit(ctx, g, t, str(tmp_path / ('async%d_a_%s.fits' % (k, name))))
+            g.seal()
             groups.append(g)
     for g in groups:
-        g.headers[None] = hdr
-        g.header_ready.set()
+        g.set_headers({None: hdr})
     assert ev.wait(60.0)
     stage.close()
     assert [d[0] for d in sorted(done)] == [0, 1] and all(d[2] is None for d in done), done
