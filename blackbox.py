@@ -424,6 +424,12 @@ class Reducer:
         return written
 
     def write_image(self, path, img, header):
+        staged = getattr(self, '_staged', None)
+        if staged is not None and (path + '.fz') in staged['names']:
+            # the output stage is writing this image already (compressed on its lane): it only waits for the header
+            staged['headers'][path + '.fz'] = dict(header)
+            staged['wanted'].add(path + '.fz')
+            return path + '.fz'
         if self.args.fpack:
             # products leave the GPU tile-compressed (reference: fpack of the files kept,
             # copy_files2keep 4033-4035): only the compressed bytes cross PCIe
@@ -485,7 +491,10 @@ class Reducer:
         nsig = float(R.hval(header, 'T-NSIGMA')) if 'T-NSIGMA' in header else 6.0
         lim = res['Fpsferr'] * nsig
         zp = self.args.zeropoint
-        if zp is None and 'PC-ZP' in header and not isinstance(R.hval(header, 'PC-ZP'), str):
+        staged = getattr(self, '_staged', None)
+        if staged is not None and (base + '_trans_limmag.fits.fz') in staged['names']:
+            zp = None                                   # the output stage has queued the flux limit already: describe that file
+        elif zp is None and 'PC-ZP' in header and not isinstance(R.hval(header, 'PC-ZP'), str):
             zp = float(R.hval(header, 'PC-ZP'))
         h = dict(header)
         if zp is not None:
@@ -506,14 +515,17 @@ class Reducer:
     # ---- many object frames: frames-in-flight pipeline ------------------------------------------
     def reduce_list(self, files):
         """object frames of one geometry through FramePipeline (several frames in flight on this
-        GPU); anything else goes through blackbox_reduce one by one.  -> list of output names"""
+        GPU); anything else goes through blackbox_reduce one by one.  Raw frames are read and uploaded as
+        the pipeline takes them (at most its depth in HBM at a time).  With --fpack True the image products are
+        compressed on the lane that made them and written by the output stage's threads
+        (blackbox_amd/outstage.py).  -> list of output names"""
         R, torch = self.R, self.torch
         from blackbox_amd.pipeline import FramePipeline
         out = {}
         todo = []
         for fn in files:
             try:
-                d_raw, header = self.read_raw(fn)
+                header = self.read_header(fn)
                 imgtype = str(R.hval(header, 'IMAGETYP')).lower() if 'IMAGETYP' in header else 'object'
                 if not self.args.red_dir:
                     self.args.red_dir = os.path.dirname(os.path.abspath(fn))
@@ -523,43 +535,128 @@ class Reducer:
                 elif self.already_done(fits_out):
                     out[fn] = fits_out
                 else:
-                    todo.append((fn, d_raw, header, fits_out))
+                    todo.append((fn, fits_out))
             except Exception:
                 log.exception('exception was raised while reading %s', fn)
                 out[fn] = None
-        if todo:
-            shapes = {tuple(t[1].shape) for t in todo}
-            if len(shapes) > 1:
-                raise ValueError('frames of different shapes in one --image_list: {}'.format(sorted(shapes)))
-            geom = R.geometry(todo[0][1].shape, self.args.ysize_chan, self.args.xsize_chan)
-            exptime = R.hval(todo[0][2], 'EXPTIME') if 'EXPTIME' in todo[0][2] else 1.0
-            sub = None
-            if self.sub is not None:
-                sub = dict(self.sub)
-            pipe = FramePipeline(self.ctx, self.tel, geom, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
-                                 xtalk_coeffs=self.xtalk, exptime=exptime, depth=max(2, min(8, len(todo))), lanes=2,
-                                 do_finish=True, detect_sats=True, keep_outputs=True, subtract=sub, log=log)
-            os.makedirs(self.args.red_dir, exist_ok=True)
-            t0 = time.time()
+        if not todo:
+            return [out.get(fn) for fn in files]
+        first_raw, first_hdr = self.read_raw(todo[0][0])
+        geom = R.geometry(first_raw.shape, self.args.ysize_chan, self.args.xsize_chan)
+        exptime = R.hval(first_hdr, 'EXPTIME') if 'EXPTIME' in first_hdr else 1.0
+        sub = dict(self.sub) if self.sub is not None else None
+        os.makedirs(self.args.red_dir, exist_ok=True)
+        t0 = time.time()
+        live = {}                                                  # idx -> (fn, header, fits_out)
+        stage, written = None, {}
+        import threading
+        all_written = threading.Event()
+        kw = {}
+        if self.args.fpack:
+            from blackbox_amd import outstage
+            ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
+            stage = outstage.OutputStage(self.ctx.device, ny, nx, nwriters=4)
 
-            def on_done(idx, f):
-                fn, _, header, fits_out = todo[idx]
+            def header_hook(f, hdrs):
+                """the frame's scalars are in: complete the headers (bookkeeping, QC flags, subtraction keywords) through
+                the very code of the serial path; its image writes only hand their headers to the stage"""
+                fn, header, fits_out = live[f.idx]
+                self._staged = dict(names=set(f.out_names.values()), headers={}, wanted=set())
                 try:
-                    # the pipeline works with one exposure time; NCOSMICS follows the frame's own
-                    et = R.hval(header, 'EXPTIME') if 'EXPTIME' in header else 1.0
-                    if et != exptime and not isinstance(R.hval(header, 'NCOSMICS'), str):
-                        header['NCOSMICS'] = (R.hval(header, 'NCOSMICS') * float(exptime) / float(et), header['NCOSMICS'][1])
-                    if 'zogy' in f.failed:
-                        header['Z-P'] = (False, 'successfully processed by ZOGY?')
-                    out[fn] = self.finish_object(fn, f.data, f.mask, header, f.hm, fits_out, t0, sub_result=f.sub)
-                except Exception:
-                    log.exception('exception was raised during [blackbox_reduce] of %s', fn)
-                    out[fn] = None
+                    self._finish_from_pipeline(f, fn, header, fits_out, t0)
+                    f.staged_wanted = set(self._staged['wanted'])
+                    res = dict(hdrs)
+                    res.update(self._staged['headers'])
+                    return res
+                finally:
+                    self._staged = None
+
+            def on_written(f, group):
+                # products the frame's QC decided against (red flag: no subtraction products) were queued before the flag
+                # was known: take them away again
+                for p in group.paths:
+                    if p not in getattr(f, 'staged_wanted', set(group.paths)):
+                        try:
+                            os.unlink(p)
+                        except OSError:
+                            pass
+                written[f.idx] = group.error
+                if len(written) == len(todo):
+                    all_written.set()
+            kw = dict(outstage=stage, out_base=lambda idx, h: todo[idx][1].replace('.fits', ''), on_written=on_written,
+                      header_hook=header_hook, stage_limmag=self.args.zeropoint is None)
+        self._pipe_exptime = exptime
+        pipe = FramePipeline(self.ctx, self.tel, geom, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
+                             xtalk_coeffs=self.xtalk, exptime=exptime, depth=max(2, min(8, len(todo))), lanes=2,
+                             do_finish=True, detect_sats=True, keep_outputs=True, subtract=sub, log=log, **kw)
+
+        def frames():
+            """read + upload a frame when the pipeline asks for the next one"""
+            for idx, (fn, fits_out) in enumerate(todo):
+                d_raw, header = (first_raw, first_hdr) if idx == 0 else self.read_raw(fn)
+                if tuple(d_raw.shape) != (geom.ny_raw, geom.nx_raw):
+                    raise ValueError('frames of different shapes in one --image_list: {} vs {}'.format(
+                        tuple(d_raw.shape), (geom.ny_raw, geom.nx_raw)))
+                live[idx] = (fn, header, fits_out)
+                yield d_raw, header
+
+        def on_done(idx, f):
+            fn, header, fits_out = live[idx]
             try:
-                pipe.run([(t[1], t[2]) for t in todo], on_done=on_done)
-            finally:
-                pipe.close()
+                if stage is None:
+                    self._finish_from_pipeline(f, fn, header, fits_out, t0)
+                out[fn] = getattr(f, 'written_name', None)
+            except Exception:
+                log.exception('exception was raised during [blackbox_reduce] of %s', fn)
+                out[fn] = None
+            if stage is None:
+                live.pop(idx, None)
+        try:
+            pipe.run(frames(), on_done=on_done)
+            if stage is not None and not all_written.wait(600.0):
+                log.error('output stage: %d of %d frames written', len(written), len(todo))
+            for idx, err in written.items():
+                if err is not None:
+                    log.error('writing the products of %s failed: %r', todo[idx][0], err)
+                    out[todo[idx][0]] = None
+        finally:
+            pipe.close()
+            if stage is not None:
+                stage.close()
         return [out.get(fn) for fn in files]
+
+    def _finish_from_pipeline(self, f, fn, header, fits_out, t0):
+        """header completion + products of a frame that came out of the pipeline"""
+        R = self.R
+        # the pipeline works with one exposure time; NCOSMICS follows the frame's own
+        et = R.hval(header, 'EXPTIME') if 'EXPTIME' in header else 1.0
+        if et != f_exptime(self, f) and not isinstance(R.hval(header, 'NCOSMICS'), str):
+            header['NCOSMICS'] = (R.hval(header, 'NCOSMICS') * float(f_exptime(self, f)) / float(et), header['NCOSMICS'][1])
+        if 'zogy' in f.failed:
+            header['Z-P'] = (False, 'successfully processed by ZOGY?')
+        fh = self.open_image_log(fits_out)                    # the per-image log (blackbox.py:1311-1318) of a pipelined frame:
+        try:                                                  # what its completion has to say (QC flags, failed steps)
+            for step in f.failed:
+                log.error('step [%s] failed for %s', step, fn)
+            f.written_name = self.finish_object(fn, f.data, f.mask, header, f.hm, fits_out, t0, sub_result=f.sub)
+        finally:
+            self.close_image_log(fh)
+
+    def read_header(self, filename):
+        """the header of a raw frame without its pixels"""
+        if filename.endswith('.fz'):
+            h = self.fitsio.read_hdus(filename, headers_only=True)[1][0]
+        else:
+            h = self.fitsio.read_hdus(filename, headers_only=True)[0][0]
+        header = dict(h)
+        for k in ('BZERO', 'BSCALE', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'SIMPLE', 'EXTEND'):
+            header.pop(k, None)
+        return header
+
+
+def f_exptime(reducer, f):
+    """the exposure time the pipeline of this run works with"""
+    return getattr(reducer, '_pipe_exptime', 1.0)
 
 
 def build_parser():

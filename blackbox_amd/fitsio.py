@@ -82,9 +82,10 @@ def _hv(h, k, default=None):
     return v[0] if isinstance(v, tuple) else v
 
 
-def read_hdus(path):
+def read_hdus(path, headers_only=False):
     """-> list of (header dict, data ndarray or None).  Binary tables come back as their raw
-    row bytes (uint8 [NAXIS2, NAXIS1]) with the heap under header key '__heap__'."""
+    row bytes (uint8 [NAXIS2, NAXIS1]) with the heap under header key '__heap__'.
+    headers_only: the data units are skipped (data None)."""
     out = []
     with open(path, 'rb') as f:
         while True:
@@ -100,6 +101,11 @@ def read_hdus(path):
             if naxis > 0:
                 shape = tuple(int(_hv(h, 'NAXIS%d' % k)) for k in range(naxis, 0, -1))
                 npix = int(np.prod(shape))
+                if headers_only:
+                    nbytes = npix * abs(bitpix) // 8 + int(_hv(h, 'PCOUNT', 0) or 0)
+                    f.seek(nbytes + (-nbytes) % BLOCK, 1)
+                    out.append((h, None))
+                    continue
                 raw = np.fromfile(f, dtype=_BITPIX[bitpix], count=npix)
                 if raw.size != npix:
                     raise EOFError('truncated FITS data in {}'.format(path))

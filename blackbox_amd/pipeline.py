@@ -220,7 +220,7 @@ def _shm_phase2(args):
 class _Frame:
     __slots__ = ('idx', 'raw', 'header', 'hm', 'state', 'evA', 'h_mean', 'h_hos', 'h_ninf', 'res', 'res2',
                  'evC', 'data', 'mask', 'h_out', 'd_keep', 'p1', 'h_cnt', 'evS', 't0', 'tA', 'tB', 'tC', 'slot', 'lane', 'err',
-                 'sub', 'failed', 'os_ok', 'os_fail', 'out_group', 'out_base', 'out_names')
+                 'sub', 'failed', 'os_ok', 'os_fail', 'out_group', 'out_base', 'out_names', 'written_name', 'staged_wanted')
 
 
 class _LaneCtx:
@@ -271,7 +271,8 @@ def _new_event():
 class FramePipeline:
     def __init__(self, ctx, tel, geom, mflat=None, mbias=None, bpm=None, xtalk_coeffs=None, exptime=60.0,
                  pool=None, depth=4, do_cosmics=True, do_finish=False, accum='f32seq', keep_outputs=False, lanes=2,
-                 detect_sats=False, subtract=None, log=None, outstage=None, out_base=None, on_written=None):
+                 detect_sats=False, subtract=None, log=None, outstage=None, out_base=None, on_written=None, header_hook=None,
+                 stage_limmag=True):
         """do_finish: crosstalk, mask counts, edge fill (the tail of blackbox_reduce);
         detect_sats: satellite trails before them (blackbox.py:1919-1952);
         subtract: dict of keyword arguments for zogy.optimal_subtraction (ref=, ref_mask=, psf_new=,
@@ -281,7 +282,8 @@ class FramePipeline:
         _Fpsf, _trans_limmag) are tile-compressed on the lane right behind the kernels that made them and written as
         `.fits.fz` by the stage's writer threads (blackbox.py:1981-1990, 812-857); out_base(idx, header) -> path of the
         frame's _red product without '.fits'; on_written(frame, group) is called by a writer thread when the last file
-        of the frame is on disk"""
+        of the frame is on disk; header_hook(frame, headers) -> headers lets the caller complete the headers of the
+        frame's files ({path: header, None: default}) when the frame's scalars are in, before the writers use them"""
         self.ctx, self.tel, self.geom = ctx, tel, geom
         # stage-C lanes: (context, stream); lane 0 is the caller's context
         self.own_ctx = [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
@@ -305,7 +307,8 @@ class FramePipeline:
             self.zogy_gate = G.StreamGate()
         self.keep_sub = ('D', 'Scorr', 'Fpsf', 'Fpsferr')        # device products kept on the frame when keep_outputs
         self.log = log
-        self.outstage, self.out_base, self.on_written = outstage, out_base, on_written
+        self.outstage, self.out_base, self.on_written, self.header_hook = outstage, out_base, on_written, header_hook
+        self.stage_limmag = stage_limmag           # False: the caller makes `_trans_limmag` itself (in magnitudes, with a zeropoint)
         if outstage is not None and out_base is None:
             raise ValueError('outstage needs out_base')
         self.keep_outputs = keep_outputs
@@ -656,9 +659,10 @@ class FramePipeline:
         if sub is not None and sub.get('D') is not None:
             for ext in ('D', 'Scorr', 'Fpsf'):
                 names[ext] = st.submit(ctx, g, sub[ext], '{}_{}.fits'.format(base, ext))
-            nsig = float(sub['header_trans']['T-NSIGMA'][0])
-            lim = sub['Fpsferr'] * nsig                                # `_trans_limmag` as a flux limit (no zeropoint on this path)
-            names['limmag'] = st.submit(ctx, g, lim, base + '_trans_limmag.fits')
+            if self.stage_limmag:
+                nsig = float(sub['header_trans']['T-NSIGMA'][0])
+                lim = sub['Fpsferr'] * nsig                            # `_trans_limmag` as a flux limit (no zeropoint on this path)
+                names['limmag'] = st.submit(ctx, g, lim, base + '_trans_limmag.fits')
         f.out_names = names
         g.seal()
 
@@ -678,7 +682,7 @@ class FramePipeline:
             h['NOBJ-SAT'] = hm['NOBJ-SAT'] = (nobj, 'number of saturated objects')
         if f.h_out[2] is not None:
             st = f.h_out[2].numpy()
-            h['NCOSMICS'] = hm['NCOSMICS'] = (st[6] / float(self.exptime), '[/s] number of cosmic rays identified')
+            h['NCOSMICS'] = hm['NCOSMICS'] = (float(st[6]) / float(self.exptime), '[/s] number of cosmic rays identified')
             h['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
             if st[15]:
                 self.level_feed_left = 64             # a frame needed the level: feed it for the next frames
@@ -707,6 +711,12 @@ class FramePipeline:
                 for k in ('D', 'Scorr', 'Fpsf', 'limmag'):
                     if k in f.out_names:
                         hdrs[f.out_names[k]] = ht
+            if self.header_hook is not None:
+                try:
+                    hdrs = self.header_hook(f, hdrs)
+                except BaseException as e:                          # the files still get the default headers
+                    if self.log is not None:
+                        self.log.exception('frame %d: header hook failed: %s', f.idx, e)
             f.out_group.set_headers(hdrs)
         f.d_keep = None
         f.state = 'done'

@@ -686,7 +686,7 @@ def reduce_object(ctx, raw, header, tel, mflat=None, mbias=None, bpm=None, xtalk
     if d_stats is not None:
         st = d_stats.cpu().numpy()
         t = float(exptime) if exptime else 1.0
-        header['NCOSMICS'] = header_mask['NCOSMICS'] = (st[6] / t, '[/s] number of cosmic rays identified')
+        header['NCOSMICS'] = header_mask['NCOSMICS'] = (float(st[6]) / t, '[/s] number of cosmic rays identified')
         header['NCRPIX'] = (int(st[7]), 'number of cosmic-ray pixels')
     apply_step_errors(header, header_mask, d_steps.cpu().numpy(), log)
     return data, mask, header, header_mask

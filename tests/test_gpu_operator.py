@@ -314,3 +314,51 @@ def test_farm_spawn_pool_and_wrapexception(tmp_path, case):
     assert line, (r.stdout[-2000:], r.stderr[-2000:])
     tb = json.loads(line[0][8:])
     assert 'Traceback' in tb and 'ML1_missing.fits' in tb and 'blackbox_reduce' in tb
+
+
+def test_cli_image_list_through_output_stage(tmp_path, ctx, case):
+    """--image_list --fpack True: the image products are compressed on the lane that made them and written by the output
+    stage's threads (blackbox_amd/outstage.py), headers completed by the serial path's own code once the frame's scalars
+    are in.  Same files as the one-by-one --image --fpack True run: identical compressed tables + heaps, identical
+    header keywords (but for the time stamps), the small products next to them."""
+    cli = load_cli()
+    hdr = {'EXPTIME': 60.0, 'IMAGETYP': 'object', 'FILTER': 'q'}
+    raws = []
+    for k in range(3):
+        p = str(tmp_path / ('ML1_raw%d.fits' % k))
+        fitsio.write_image(p, case['raw'], dict(hdr, **{'DATE-OBS': '2024-01-02T03:04:0%d' % k}))
+        raws.append(p)
+    fitsio.write_image(str(tmp_path / 'flat.fits'), case['flat'])
+    fitsio.write_image(str(tmp_path / 'bpm.fits'), case['bpm'])
+    synth.write_xtalk(str(tmp_path / 'xtalk.dat'), case['xtalk'])
+    d0, m0, h0, _ = run(ctx, case)
+    rs = np.random.RandomState(3)
+    fitsio.write_image(str(tmp_path / 'ref.fits'), (d0.cpu().numpy() - 100.0 + rs.normal(0, 4, d0.shape)).astype(np.float32))
+    fitsio.write_image(str(tmp_path / 'psf.fits'), moffat(15, 3.5))
+    common = ['--telescope', TEL, '--mflat', str(tmp_path / 'flat.fits'), '--bpm', str(tmp_path / 'bpm.fits'),
+              '--crosstalk', str(tmp_path / 'xtalk.dat'), '--ysize_chan', str(YS), '--xsize_chan', str(XS),
+              '--cat_extract', 'True', '--trans_extract', 'True', '--ref', str(tmp_path / 'ref.fits'),
+              '--psf_new', str(tmp_path / 'psf.fits'), '--psf_ref', str(tmp_path / 'psf.fits'),
+              '--subimage_size', '120', '--subimage_border', '10', '--bkg_boxsize', '30', '--fpack', 'True']
+    one = cli.main(common + ['--image', raws[0], '--red_dir', str(tmp_path / 'one')])
+    lst = str(tmp_path / 'list.txt')
+    with open(lst, 'w') as f:
+        f.write('\n'.join(raws) + '\n')
+    outs = cli.main(common + ['--image_list', lst, '--red_dir', str(tmp_path / 'lst')])
+    assert len(outs) == 3 and all(o and o.endswith('_red.fits.fz') and os.path.isfile(o) for o in outs), outs
+    assert os.path.basename(outs[0]) == os.path.basename(one[0])
+    b1, b2 = one[0].replace('.fits.fz', ''), outs[0].replace('.fits.fz', '')
+    for ext in ('.fits.fz', '_D.fits.fz', '_Scorr.fits.fz', '_Fpsf.fits.fz', '_trans_limmag.fits.fz'):
+        (_, _), (ha, ta) = fitsio.read_hdus(b1 + ext)
+        (_, _), (hb, tb) = fitsio.read_hdus(b2 + ext)
+        assert np.array_equal(ta, tb) and np.array_equal(ha['__heap__'], hb['__heap__']), ext
+        ka = {k: R.hval(ha, k) for k in ha if k not in ('__heap__', 'BB-START')}
+        kb = {k: R.hval(hb, k) for k in hb if k not in ('__heap__', 'BB-START')}
+        assert ka == kb, (ext, {k: (ka.get(k), kb.get(k)) for k in set(ka) | set(kb) if ka.get(k) != kb.get(k)})
+        assert R.hval(hb, 'ZCMPTYPE') == 'RICE_1'
+    ma, mb = fitsio.read_hdus(b1.replace('_red', '_mask') + '.fits.fz')[1], fitsio.read_hdus(b2.replace('_red', '_mask') + '.fits.fz')[1]
+    assert np.array_equal(ma[1], mb[1]) and np.array_equal(ma[0]['__heap__'], mb[0]['__heap__'])
+    for ext in ('_hdr.fits', '_cat.fits', '_trans.fits', '_trans_hdr.fits', '_bkg_mini.fits', '.log'):
+        assert os.path.isfile(b2 + ext), ext
+    for k in (1, 2):
+        assert os.path.isfile(str(tmp_path / 'lst' / ('ML1_20240102_03040%d_red_Scorr.fits.fz' % k)))
