@@ -351,3 +351,33 @@ def sat_scene(name):
         d = xx * np.cos(th) + yy * np.sin(th) - rho
         b += (amp * np.exp(-0.5 * (d / sig) ** 2)).astype(np.float32)
     return b
+
+
+# ---- full-resolution scenes for the satellite-trail mask (oracle/gen_golden_sat.py -> tests/golden/sat_mask.npz) ----------
+# (xa, ya, xb, yb, amplitude [e-], FWHM [px]) of a straight trail through (xa, ya), (xb, yb); frames of ny x nx pixels
+SAT_MASK_SCENES = {'shallow': dict(seed=1, ny=600, nx=900, trail=(0, 120, 900, 470, 120.0, 6.0)),
+                   'steep': dict(seed=2, ny=600, nx=900, trail=(200, 0, 520, 600, 80.0, 6.0)),
+                   'level': dict(seed=4, ny=600, nx=900, trail=(0, 300, 900, 305, 200.0, 8.0)),
+                   'falling': dict(seed=5, ny=700, nx=1100, trail=(0, 610, 1100, 40, 150.0, 5.0)),
+                   'upright': dict(seed=6, ny=1000, nx=560, trail=(300, 0, 250, 1000, 160.0, 7.0))}
+
+
+def sat_full_scene(seed, ny=600, nx=900, trail=None, nstars=150):
+    """a reduced frame (float32, e-): sky 250 + noise 18, [nstars] Gaussian stars (sigma 1.7 px, 10^3..10^5.5 e-), a trail
+    -> (frame, truth mask of the trail within its FWHM)"""
+    rs = np.random.RandomState(seed)
+    img = 250 + rs.normal(0, 18, (ny, nx))
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    for _ in range(nstars):
+        y0, x0, f = rs.uniform(0, ny), rs.uniform(0, nx), 10 ** rs.uniform(3, 5.5)
+        r2 = (yy - y0) ** 2 + (xx - x0) ** 2
+        sel = r2 < 15 ** 2
+        img[sel] += (f / (2 * np.pi * 1.7 ** 2)) * np.exp(-r2[sel] / (2 * 1.7 ** 2))
+    truth = np.zeros((ny, nx), bool)
+    if trail is not None:
+        (xa, ya, xb, yb, amp, width) = trail
+        norm = np.hypot(xb - xa, yb - ya)
+        d = ((xx - xa) * (yb - ya) - (yy - ya) * (xb - xa)) / norm
+        img += amp * np.exp(-0.5 * (d / (width / 2.355)) ** 2)
+        truth = np.abs(d) <= width / 2
+    return img.astype(np.float32), truth
