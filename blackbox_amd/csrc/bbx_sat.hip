@@ -20,7 +20,6 @@
 #define SAT_BLOCKS 1024
 
 struct sat_state {
-    double lo, hi, mean, std;             // clipped statistics of the binned frame
     unsigned long long best;              // (votes << 32) | (0xffffffff - flat index)
     int accept, found, k, lo_off, hi_off; // line accepted / strip found, theta index, strip offsets
     int votes;
@@ -46,86 +45,40 @@ struct sat_state {
 #define SAT_SUBW 200
 struct sat_rect { int r0, r1, c0, c1; };
 
-__global__ __launch_bounds__(256) void k_bin2(const float* __restrict__ d, int nyb, int nxb, float* __restrict__ b) {
+__device__ __forceinline__ unsigned fkey(float f) { const unsigned u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k); }
+
+// 2 x 2 sums (blackbox.py:4171-4172) and, in the same pass, the largest and smallest binned value (make_mask divides by the
+// maximum; the interpolation is clipped to the image's range)
+__global__ __launch_bounds__(256) void k_bin2(const float* __restrict__ d, int nyb, int nxb, float* __restrict__ b, sat_state* st) {
     const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
-    if (X >= nxb) return;
-    const size_t nx = (size_t)nxb * 2;
-    const float2 r0 = *(const float2*)(d + (size_t)(2 * Y) * nx + 2 * X);
-    const float2 r1 = *(const float2*)(d + (size_t)(2 * Y + 1) * nx + 2 * X);
-    b[(size_t)Y * nxb + X] = (r0.x + r0.y) + (r1.x + r1.y);
+    unsigned hi = 0u, lo = ~0u;
+    if (X < nxb) {
+        const size_t nx = (size_t)nxb * 2;
+        const float2 r0 = *(const float2*)(d + (size_t)(2 * Y) * nx + 2 * X);
+        const float2 r1 = *(const float2*)(d + (size_t)(2 * Y + 1) * nx + 2 * X);
+        const float f = (r0.x + r0.y) + (r1.x + r1.y);
+        b[(size_t)Y * nxb + X] = f;
+        if (isfinite(f)) { hi = lo = fkey(f); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned a = __shfl_xor(hi, o, 64), c = __shfl_xor(lo, o, 64); hi = a > hi ? a : hi; lo = c < lo ? c : lo; }
+    // (same-address atomics retire one at a time, ~11 ns each: a wave only goes there when it would change the extreme --
+    // after the first waves that is a handful of times per frame)
+    if ((threadIdx.x & 63) == 0 && hi) {
+        if (hi > __atomic_load_n(&st->bmax_key, __ATOMIC_RELAXED)) atomicMax(&st->bmax_key, hi);
+        if (lo < __atomic_load_n(&st->bmin_key, __ATOMIC_RELAXED)) atomicMin(&st->bmin_key, lo);
+    }
 }
 
 __global__ void k_sat_init(sat_state* st) {
     if (threadIdx.x == 0) {
-        st->lo = -__builtin_huge_val(); st->hi = __builtin_huge_val(); st->mean = 0; st->std = 0; st->best = 0;
+        st->best = 0;
         st->accept = 0; st->found = 0; st->k = 0; st->lo_off = 0; st->hi_off = 0; st->votes = 0;
         st->rho = 0; st->c = 0; st->s = 0; st->chord = 0; st->tmin = ~0ull; st->tmax = 0ull; st->t0 = 0; st->t1 = 0;
         st->fit_n = 0; st->fit_t = st->fit_d = st->fit_tt = st->fit_td = 0; st->icpt = 0; st->slope = 0;
         st->bmax_key = 0u; st->bmin_key = ~0u; st->seg_ok = 0; st->nwin = 0; st->row_min = 0x7fffffff; st->row_max = -1;
         st->band_r0 = 0; st->band_rows = 0; st->rot_rows = st->rot_cols = 0;
     }
-}
-
-__device__ __forceinline__ void clip_acc(float f, double lo, double hi, double& s1, double& s2, int& cnt) {
-    const double x = (double)f;
-    if (isfinite(f) && x >= lo && x <= hi) { s1 += x; s2 += x * x; cnt++; }
-}
-
-// sums of the binned pixels inside the current clip range: 16-byte loads, four in flight per
-// thread; one partial triple per workgroup (fixed launch shape -> the same sums in every run)
-__global__ __launch_bounds__(256) void k_clip_pass(const float* __restrict__ b, size_t n, const sat_state* __restrict__ st,
-                                                   double* __restrict__ partial) {
-    const double lo = st->lo, hi = st->hi;
-    double s1 = 0.0, s2 = 0.0; int cnt = 0;
-    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
-    const float4* b4 = (const float4*)b;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        float4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) q[u] = b4[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            clip_acc(q[u].x, lo, hi, s1, s2, cnt); clip_acc(q[u].y, lo, hi, s1, s2, cnt);
-            clip_acc(q[u].z, lo, hi, s1, s2, cnt); clip_acc(q[u].w, lo, hi, s1, s2, cnt);
-        }
-    }
-    for (; i < n4; i += stride) {
-        const float4 q = b4[i];
-        clip_acc(q.x, lo, hi, s1, s2, cnt); clip_acc(q.y, lo, hi, s1, s2, cnt);
-        clip_acc(q.z, lo, hi, s1, s2, cnt); clip_acc(q.w, lo, hi, s1, s2, cnt);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) clip_acc(b[(n4 << 2) + threadIdx.x], lo, hi, s1, s2, cnt);
-    __shared__ double sh1[4], sh2[4]; __shared__ int shn[4];
-    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2); cnt = wave_sum_i32(cnt);
-    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = s1; sh2[threadIdx.x >> 6] = s2; shn[threadIdx.x >> 6] = cnt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* p = partial + (size_t)blockIdx.x * 3;
-        p[0] = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]); p[1] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
-        p[2] = (double)(shn[0] + shn[1] + shn[2] + shn[3]);
-    }
-}
-
-// one workgroup of 256 folds the partial triples (thread t takes blocks t, t+256, ...; then a
-// fixed tree) and narrows the clip range
-__global__ __launch_bounds__(256) void k_clip_update(sat_state* st, const double* __restrict__ partial, int nblocks) {
-    __shared__ double sh[3][4];
-    double a = 0, q = 0, m = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) { a += partial[3 * b]; q += partial[3 * b + 1]; m += partial[3 * b + 2]; }
-    a = wave_sum_f64(a); q = wave_sum_f64(q); m = wave_sum_f64(m);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = q; sh[2][threadIdx.x >> 6] = m; }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]); q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-    m = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
-    const double mean = a / m;
-    double var = q / m - mean * mean; if (var < 0) var = 0;
-    const double sd = sqrt(var);
-    st->mean = mean; st->std = sd;
-    const double lo = mean - 3.0 * sd, hi = mean + 3.0 * sd;
-    if (lo > st->lo) st->lo = lo;
-    if (hi < st->hi) st->hi = hi;
 }
 
 // Hough votes: one block per angle keeps the rho histogram of that angle in LDS and reports
@@ -265,19 +218,6 @@ __global__ void k_trail_accept(sat_state* st, double buf) {
 }
 
 // ---- make_mask ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned fkey(float f) { const unsigned u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
-__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k); }
-
-__global__ __launch_bounds__(256) void k_bin_minmax(const float* __restrict__ b, size_t n, sat_state* st) {
-    unsigned hi = 0u, lo = ~0u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float f = b[i];
-        if (isfinite(f)) { const unsigned k = fkey(f); hi = k > hi ? k : hi; lo = k < lo ? k : lo; }
-    }
-    for (int o = 32; o > 0; o >>= 1) { const unsigned a = __shfl_xor(hi, o, 64), c = __shfl_xor(lo, o, 64); hi = a > hi ? a : hi; lo = c < lo ? c : lo; }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&st->bmax_key, hi); atomicMin(&st->bmin_key, lo); }
-}
-
 // rotate_matrix of oracle/sattrail.py: one IEEE operation per written operation, in that order
 __device__ void sat_rotate_matrix(int rows, int cols, double dirx, double diry, double* m, int* out_rows, int* out_cols) {
     const double h = sqrt(dirx * dirx + diry * diry);
@@ -598,7 +538,7 @@ __global__ __launch_bounds__(256) void k_sat_paint(uint8_t* mask, int nyb, int n
 
 __global__ void k_sat_info(const sat_state* __restrict__ st, float* info) {
     if (threadIdx.x == 0) {
-        info[0] = (float)st->mean; info[1] = (float)st->std; info[2] = (float)st->votes; info[3] = (float)st->k;
+        info[0] = fkey_inv(st->bmax_key); info[1] = fkey_inv(st->bmin_key); info[2] = (float)st->votes; info[3] = (float)st->k;
         info[4] = (float)st->rho; info[5] = (float)st->nwin; info[6] = (float)st->seg_ok; info[7] = (float)st->found;
     }
 }
@@ -630,16 +570,12 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     const size_t total = o_band + (size_t)2 * SAT_BANDH * band_cols * sizeof(double) + 256;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, total, &rc); if (rc) return rc;
     float* bin = (float*)(ws + o_bin); uint32_t* list = (uint32_t*)(ws + o_list);
-    double* cs = (double*)(ws + o_cs); double* partial = (double*)(ws + o_part); sat_state* st = (sat_state*)(ws + o_st);
+    double* cs = (double*)(ws + o_cs); sat_state* st = (sat_state*)(ws + o_st);
     sat_rect* rects = (sat_rect*)(ws + o_rect); double* band = (double*)(ws + o_band);
     int32_t* cnt = &ctx->d_counters[CNT_CAND];
     BBX_HIP(hipMemcpyAsync(cs, h_cos_sin, (size_t)ntheta * 16, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sat_init, dim3(1), dim3(128), 0, s, st);
-    hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin);
-    for (int pass = 0; pass < 4; pass++) {
-        hipLaunchKernelGGL(k_clip_pass, dim3(SAT_BLOCKS), dim3(256), 0, s, bin, nb, st, partial);
-        hipLaunchKernelGGL(k_clip_update, dim3(1), dim3(256), 0, s, st, partial, SAT_BLOCKS);
-    }
+    hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin, st);
     // acstools' front end: sigma = 3 (sat_detect), low_thresh = 0.1 (default), h_thresh = 0.2 (sat_detect), small_edge = 60
     rc = bbx_canny_edges(ctx, bin, nyb, nxb, h_gauss, gauss_radius, 0.1, 0.2, 60, list, cnt, (uint32_t)cap, s); if (rc) return rc;
     if ((size_t)nrho * 4 <= 150 * 1024) {
@@ -657,7 +593,6 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     hipLaunchKernelGGL(k_trail_support, dim3(256), dim3(256), 0, s, list, cnt, (uint32_t)cap, nxb, st);
     hipLaunchKernelGGL(k_trail_accept, dim3(1), dim3(64), 0, s, st, 40.0);                       // buf = 40 (sat_detect)
     // make_mask (oracle/sattrail.py): segment + geometry, the band of the rotated frame, the walk, the strips painted back
-    hipLaunchKernelGGL(k_bin_minmax, dim3(1024), dim3(256), 0, s, bin, nb, st);
     const size_t seg_lds = (size_t)SAT_SEG_CAP * 12;
     if (ctx->sat_attr_set != 1) {
         BBX_HIP(hipFuncSetAttribute((const void*)k_trail_segment, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));

@@ -137,6 +137,7 @@ def clipped_stats_flat(values, sigma=3.0, maxiters=5, accum='f32seq'):
 
 
 _VANDER = {}
+_VANDER_LOCK = __import__('threading').Lock()
 
 
 def _vander_full(start, n, order):
@@ -146,9 +147,12 @@ def _vander_full(start, n, order):
     key = (start, n, order)
     v = _VANDER.get(key)
     if v is None:
-        if len(_VANDER) > 64:
-            _VANDER.clear()
-        v = _VANDER[key] = np.vander(np.arange(start, start + n) + 0.0, order)
+        # (callers hand the array's address to C and rely on the cache to keep it alive: one array per key, ever --
+        # several threads may ask for a new key at once)
+        with _VANDER_LOCK:
+            v = _VANDER.get(key)
+            if v is None:
+                v = _VANDER[key] = np.vander(np.arange(start, start + n) + 0.0, order)
     return v
 
 
@@ -497,6 +501,11 @@ def _channel_solve_c(c, mean_vos_col, hos, ysz, xsz, poldeg, data_limit):
     if rc != 0:
         return None
     return dict(fit=fit, coeffs=coeffs, ok=True, level=level.value, dlevel=dlevel.value, oscan=oscan)
+
+
+def fast_path_available(accum, hos_dtype):
+    """the per-channel C driver (bbx_channel_solve_ml1) applies: a channel is one call that runs without the interpreter lock"""
+    return _HOST is not None and USE_C_DRIVER and accum == 'f32seq' and hos_dtype == np.float32
 
 
 def channel_solve(args):

@@ -130,6 +130,92 @@ def gain_corr(header, tel):
     return gain
 
 
+_FIT_THREADS = []
+
+
+def _fit_threads():
+    """a few host threads for the per-channel overscan fits of the serial path (created at first use)"""
+    if not _FIT_THREADS:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        _FIT_THREADS.append(ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4)))))
+    return _FIT_THREADS[0]
+
+
+def _vos_header(header, c, coeffs, ok):
+    for k, v in enumerate(coeffs):
+        header['BIAS{}A{}'.format(c + 1, k)] = (float(v) if np.isfinite(v) else 'None',
+                                               '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
+    header['VFITOK{}'.format(c + 1)] = (bool(ok), 'channel {} vert. overscan polyfit finite?'.format(c + 1))
+
+
+def _os_solve_stepwise(ctx, raw, header, tel, geom, data_limit, accum, mean_vos_col, hos, vfit, mean_vos, oscan, aux, d_std, g32, rt):
+    """the channels one after the other, with the device step BlackGEM needs in between (saturated-column counts after
+    the vertical fits) -> (failure or None, d_vfit)"""
+    dev = ctx.device
+    ny_raw, nx_raw = raw.shape
+    ysz, xsz = geom.ysize_chan, geom.xsize_chan
+    dy, dx = ny_raw // 2, nx_raw // 8
+    hos_rows = dy - ysz - 10
+    gain = get_par(settings.gain, tel)
+    for c in range(16):
+        fit, coeffs, ok, level = overscan.vos_polyfit(mean_vos_col[c], ysz, c, settings.voscan_poldeg)
+        _vos_header(header, c, coeffs, ok)
+        vfit[c] = fit
+        mean_vos[c] = level
+    d_vfit = torch.from_numpy(vfit.reshape(-1)).to(dev)
+    mask_sat_rows = None
+    if tel != 'ML1':
+        lim = settings.os_ypix_lim[tel]
+        satl = np.array(get_par(settings.satlevel, tel)) * np.array(gain)
+        thr = _lib.f32x16(np.float32(0.9 * satl))
+        d_cnt = torch.empty((2, 16, xsz), dtype=torch.int32, device=dev)
+        check(lib.bbx_satcol_counts(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit), thr,
+                                    int(lim[0]), int(lim[1]), _ptr(d_cnt), ctx.stream()),
+              'bbx_satcol_counts', ctx.h)
+        cnt = d_cnt.cpu().numpy()
+        mask_sat_rows = (cnt[0] >= 3) | (cnt[1] >= 10)
+    strips = []
+    failure = None
+    for c in range(16):
+        # horizontal overscan rows after the vertical fit: float32 - float64 -> float32
+        rl0 = (dy - hos_rows) if c < 8 else 0
+        strip = (hos[c].astype(np.float64) - vfit[c][rl0:rl0 + hos_rows, None]).astype(np.float32)
+        window = strip[:, xsz - 300:xsz]                   # blackbox.py:6565-6566: python slice on the dx-wide strip
+        dlevel = overscan.clipped_stats_flat(window, accum=accum)[0] if window.size else np.nan
+        if not np.isfinite(dlevel):
+            failure = overscan.OverscanFailure(c, vfit[c], None, None, 'level of the horizontal overscan is not finite '
+                                               '(window of {} columns)'.format(window.shape[1]))
+            break
+        strip -= np.float32(dlevel)
+        strips.append(strip)
+        aux['dlevel'].append(float(dlevel))
+    # read noise per channel on the GPU (float64 accumulators); runs while the host fits
+    if failure is None:
+        check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit),
+                              _lib.f32x16(np.float32(aux['dlevel'])), _ptr(d_std), ctx.stream()),
+              'bbx_vos_std', ctx.h)
+    for c in range(16 if failure is None else failure.chan):
+        try:
+            data_hos = strips[c][:, :xsz]
+            if tel == 'ML1':
+                mask_hos = overscan.hos_mask_ml1(data_hos, data_limit)
+                msr = None
+            else:
+                msr = mask_sat_rows[c]
+                mask_hos = np.zeros(data_hos.shape, dtype=bool) | msr[None, :]
+            n, mean_hos, std_hos = overscan.hos_column_stats(data_hos, mask_hos, accum=accum)
+            oscan[c] = overscan.hos_fit(n, mean_hos, std_hos, msr, bg2_chan9=(tel == 'BG2' and c == 8),
+                                        accum=accum)
+        except Exception as e:
+            failure = overscan.OverscanFailure(c, vfit[c], None, None, 'horizontal overscan: {}: {}'.format(type(e).__name__, e))
+            oscan[c] = 0.0
+            break
+        aux['mean_hos'].append(mean_hos)
+        aux['n_hos'].append(n)
+    return failure, d_vfit
+
+
 def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
     """os_corr (blackbox.py:6407-6879) up to the point where the overscan vectors
     are known: strip statistics on the GPU, fits on the host.  Updates [header]
@@ -154,68 +240,39 @@ def os_solve(ctx, raw, header, tel, geom, data_limit=2000, accum='f32seq'):
     header['N-INFNAN'] = (int(d_ninf.item()), 'number of pixels with infinite/nan values')
     vfit = np.empty((16, dy))
     mean_vos = np.zeros(16)
-    for c in range(16):
-        fit, coeffs, ok, level = overscan.vos_polyfit(mean_vos_col[c], ysz, c, settings.voscan_poldeg)
-        for k, v in enumerate(coeffs):
-            header['BIAS{}A{}'.format(c + 1, k)] = (
-                float(v) if np.isfinite(v) else 'None',
-                '[e-] channel {} vert. overscan A{} polyfit coeff'.format(c + 1, k))
-        header['VFITOK{}'.format(c + 1)] = (bool(ok), 'channel {} vert. overscan polyfit finite?'.format(c + 1))
-        vfit[c] = fit
-        mean_vos[c] = level
-    d_vfit = torch.from_numpy(vfit.reshape(-1)).to(dev)
-    mask_sat_rows = None
-    if tel != 'ML1':
-        lim = settings.os_ypix_lim[tel]
-        satl = np.array(get_par(settings.satlevel, tel)) * np.array(gain)
-        thr = _lib.f32x16(np.float32(0.9 * satl))
-        d_cnt = torch.empty((2, 16, xsz), dtype=torch.int32, device=dev)
-        check(lib.bbx_satcol_counts(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit), thr,
-                                    int(lim[0]), int(lim[1]), _ptr(d_cnt), ctx.stream()),
-              'bbx_satcol_counts', ctx.h)
-        cnt = d_cnt.cpu().numpy()
-        mask_sat_rows = (cnt[0] >= 3) | (cnt[1] >= 10)
     oscan = np.zeros((16, xsz))
     aux = dict(dlevel=[], mean_hos=[], n_hos=[])
-    strips = []
-    failure = None
-    for c in range(16):
-        # horizontal overscan rows after the vertical fit: float32 - float64 -> float32
-        rl0 = (dy - hos_rows) if c < 8 else 0
-        strip = (hos[c].astype(np.float64) - vfit[c][rl0:rl0 + hos_rows, None]).astype(np.float32)
-        window = strip[:, xsz - 300:xsz]                   # blackbox.py:6565-6566: python slice on the dx-wide strip
-        dlevel = overscan.clipped_stats_flat(window, accum=accum)[0] if window.size else np.nan
-        if not np.isfinite(dlevel):
-            failure = overscan.OverscanFailure(c, vfit[c], None, None, 'level of the horizontal overscan is not finite '
-                                               '(window of {} columns)'.format(window.shape[1]))
-            break
-        strip -= np.float32(dlevel)
-        strips.append(strip)
-        aux['dlevel'].append(float(dlevel))
-    # read noise per channel on the GPU (float64 accumulators); runs while the host fits
     d_std = torch.empty(16, dtype=torch.float64, device=dev)
-    if failure is None:
-        check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit),
-                              _lib.f32x16(np.float32(aux['dlevel'])), _ptr(d_std), ctx.stream()),
-              'bbx_vos_std', ctx.h)
-    for c in range(16 if failure is None else failure.chan):
-        try:
-            data_hos = strips[c][:, :xsz]
-            if tel == 'ML1':
-                mask_hos = overscan.hos_mask_ml1(data_hos, data_limit)
-                msr = None
-            else:
-                msr = mask_sat_rows[c]
-                mask_hos = np.zeros(data_hos.shape, dtype=bool) | msr[None, :]
-            n, mean_hos, std_hos = overscan.hos_column_stats(data_hos, mask_hos, accum=accum)
-            oscan[c] = overscan.hos_fit(n, mean_hos, std_hos, msr, bg2_chan9=(tel == 'BG2' and c == 8),
-                                        accum=accum)
-        except Exception as e:
-            failure = overscan.OverscanFailure(c, vfit[c], None, None, 'horizontal overscan: {}: {}'.format(type(e).__name__, e))
-            oscan[c] = 0.0
-            break
-        aux['mean_hos'].append(mean_hos)
-        aux['n_hos'].append(n)
+    failure = None
+    if tel == 'ML1' and overscan.fast_path_available(accum, hos.dtype):
+        # MeerLICHT: a channel's fits need nothing from the device in between -- the 16 channels are solved side by
+        # side (the C driver and LAPACK run without the interpreter lock); same arithmetic as the loop below
+        res = [None] * 16
+
+        def solve(c):
+            try:
+                res[c] = overscan.channel_solve((c, mean_vos_col[c], hos[c], ysz, xsz, settings.voscan_poldeg, tel, data_limit, accum))
+            except overscan.OverscanFailure as e:
+                res[c] = e
+        list(_fit_threads().map(solve, range(16)))
+        for c in range(16):
+            r = res[c]
+            if isinstance(r, overscan.OverscanFailure):
+                vfit[c] = r.fit
+                if r.coeffs is not None:
+                    _vos_header(header, c, r.coeffs, r.ok)
+                failure = r
+                break
+            _vos_header(header, c, r['coeffs'], r['ok'])
+            vfit[c], mean_vos[c], oscan[c] = r['fit'], r['level'], r['oscan']
+            aux['dlevel'].append(float(r['dlevel']))
+        d_vfit = torch.from_numpy(vfit.reshape(-1)).to(dev)
+        if failure is None:
+            check(lib.bbx_vos_std(ctx.h, C.byref(geom), _ptr(raw), rt, g32, _ptr(d_vfit),
+                                  _lib.f32x16(np.float32(aux['dlevel'])), _ptr(d_std), ctx.stream()), 'bbx_vos_std', ctx.h)
+    else:
+        failure, d_vfit = _os_solve_stepwise(ctx, raw, header, tel, geom, data_limit, accum, mean_vos_col, hos, vfit, mean_vos, oscan, aux,
+                                             d_std, g32, rt)
     if failure is not None:
         # how far the reference's in-place os_corr had got when it raised (overscan.OverscanFailure):
         # channels before the failing one fully corrected, that one by its vertical fit, the rest untouched

@@ -46,8 +46,7 @@ What is kept from sat_detect itself: 2x2 SUM binning (4171-4172), one trail at m
 
 Steps:
  1. binned = 2x2 sums (float32, (a00+a01)+(a10+a11)).
- 2. level, sigma = 3-sigma clipped mean / std of the binned frame (4 passes), float64 -- used by the
-    profile only.
+ 2. (the largest / smallest binned value: make_mask's normalisation and clip range; reported as info.)
  3. edge map = edges(binned) (front end above).
  4. Hough accumulator: theta_k = radians(2 + k/2), k = 0..351, cell = round_half_away(x cos + y sin)
     + offset, offset = ceil(hypot(ny, nx)) (float64), one vote per edge pixel and theta.
@@ -77,18 +76,6 @@ F = np.float32
 def bin2(data):
     d = data.astype(F)
     return ((d[0::2, 0::2] + d[0::2, 1::2]) + (d[1::2, 0::2] + d[1::2, 1::2])).astype(F)
-
-
-def clipped_level(b):
-    v = b[np.isfinite(b)].astype(np.float64)
-    lo, hi = -np.inf, np.inf
-    mean = std = 0.0
-    for _ in range(4):
-        w = v[(v >= lo) & (v <= hi)]
-        mean = w.sum() / w.size
-        std = np.sqrt(max((w * w).sum() / w.size - mean * mean, 0.0))
-        lo, hi = max(lo, mean - 3 * std), min(hi, mean + 3 * std)
-    return mean, std
 
 
 def order_percentile(sorted_vals, q):
@@ -532,8 +519,6 @@ def detect(data, return_debug=False):
     """-> (mask_sat uint8 full resolution, nsats, info dict)"""
     b = bin2(data)
     ny, nx = b.shape
-    level, sigma = clipped_level(b)
-    bd = b.astype(np.float64)
     edge = edges(b)
     ys, xs = np.nonzero(edge)
     acc, off = hough(edge)
@@ -544,7 +529,8 @@ def detect(data, return_debug=False):
     k, r = divmod(flat, nrho)
     votes = int(acc[r, k])
     theta, rho = th[k], float(r - off)
-    info = dict(level=level, sigma=sigma, nedge=int(edge.sum()), votes=votes, theta=theta, rho=rho, k=k)
+    info = dict(bmax=float(b[np.isfinite(b)].max()), bmin=float(b[np.isfinite(b)].min()), nedge=int(edge.sum()), votes=votes, theta=theta,
+                rho=rho, k=k)
     mask_full = np.zeros(data.shape, np.uint8)
     info['chord'] = chord_length(theta, rho, ny, nx)
     span = chord_span(ct[k], st[k], rho, ny, nx)

@@ -55,7 +55,7 @@ def test_sat_trails_vs_oracle(ctx, seed, trail):
     d_n, d_info = R.sat_detect(ctx, torch.from_numpy(img).to(ctx.device), {}, d_mask, {})
     ctx.sync()
     info = d_info.cpu().numpy()
-    assert info[0] == pytest.approx(info_o['level'], rel=1e-6) and info[1] == pytest.approx(info_o['sigma'], rel=1e-6)
+    assert info[0] == np.float32(info_o['bmax']) and info[1] == np.float32(info_o['bmin'])
     assert int(info[2]) == info_o['votes']
     assert np.array_equal(d_mask.cpu().numpy(), m_o)                 # uint8 mask bit-exact
     assert int(d_n.item()) == nsats_o
