@@ -62,8 +62,7 @@ struct bbx_ctx {
     int    lac_feed;           // BBX_OPT_LAC_LEVEL_FEED (bbx_set_option)
     int    debug_listcap;      // BBX_OPT_DEBUG_LISTCAP: capacity the LA-Cosmic kernels see (0 = the allocated one)
     void*  zogy_state;         // per-context FFT plans / work buffer of bbx_zogy.hip (NULL until first use)
-    int    zogy_core;          // BBX_OPT_ZOGY_CORE: FFT core of bbx_zogy_frame (0 = bbx_zogy2.hip, 1 = bbx_zogy3.hip)
-    void*  zogy2_state;        // twiddle table of bbx_zogy2.hip
+    void*  zogy2_state;        // twiddle table of bbx_zogy_frame (bbx_zogy3.hip)
     int    zogy_kwin_off;      // BBX_OPT_ZOGY_KWIN_OFF: full-size transforms of the matched-filter kernels (no row window)
     int    sat_attr_set;       // dynamic-LDS attribute of k_trail_segment set through this context
     int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
@@ -118,7 +117,7 @@ void bbx_zogy2_release(bbx_ctx* ctx);
 int bbx_zogy3_supported(int L);
 int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, int L, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
                   const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
-                  float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s);     // bbx_zogy2.hip
+                  float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s);     // bbx_zogy3.hip
 void bbx_zogy_release(bbx_ctx* ctx);      // bbx_zogy.hip: frees ctx->zogy_state (called by bbx_ctx_destroy)
 void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc);
 

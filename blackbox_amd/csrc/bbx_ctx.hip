@@ -111,7 +111,6 @@ int bbx_ctx_create(int device, bbx_ctx** out) {
     if (!out) return BBX_ERR_ARG;
     *out = nullptr;
     bbx_ctx* ctx = (bbx_ctx*)calloc(1, sizeof(bbx_ctx));
-    if (ctx) { const char* e = getenv("BBX_ZOGY_CORE"); ctx->zogy_core = e ? (atoi(e) ? 1 : 0) : 1; }
     if (!ctx) return BBX_ERR_NOMEM;
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
@@ -172,7 +171,7 @@ int bbx_step_mark(bbx_ctx* ctx, int32_t* d_slot, void* stream) {
 int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (!ctx) return BBX_ERR_ARG;
     if (option == BBX_OPT_LAC_LEVEL_FEED) { ctx->lac_feed = value ? 1 : 0; return BBX_OK; }
-    if (option == BBX_OPT_ZOGY_CORE) { ctx->zogy_core = value ? 1 : 0; return BBX_OK; }
+    if (option == BBX_OPT_ZOGY_CORE) return BBX_OK;               // (one transform core since round 3: accepted, no effect)
     if (option == BBX_OPT_DEBUG_LISTCAP) { ctx->debug_listcap = value > 0 ? value : 0; return BBX_OK; }
     if (option == BBX_OPT_ZOGY_KWIN_OFF) { ctx->zogy_kwin_off = value ? 1 : 0; return BBX_OK; }
     return BBX_ERR_ARG;

@@ -1,16 +1,14 @@
-// bbx_zogy3.hip -- ZOGY on whole frames, second FFT core: radix passes in LDS by many threads.
-// Same kernel sequence, data layouts (T / U tiles, C coefficient arrays, halo rows) and algebra as
-// bbx_zogy2.hip -- see the header of that file -- with another 1-D transform inside the kernels:
+// bbx_zogy3.hip -- ZOGY on whole frames (bbx_zogy_frame): a 2-D FFT pipeline written for this shape.
+// Kernel sequence, data layouts (T / U tiles, C coefficient arrays, halo rows) and algebra: DESIGN.md section 4b.
+// (The first core of round 2, bbx_zogy2.hip -- lines of 1400 = 35 * 40 points in two steps of register DFTs, one thread per
+// sub-transform, ~210 VGPRs, 8 waves per CU, 11.3 ms per frame -- was removed in round 3.)
 //
-//   bbx_zogy2: a line of L = N1 N2 values is transformed in two steps of register DFTs of 35 and
-//              40 points, one thread per sub-transform: ~210 VGPRs, 8 waves per CU at most;
-//   here     : L = R0 R1 [R2 [R3]] (1400 = 5 * 7 * 5 * 8); a step is L / R butterflies of radix R
+//   1-D transform: L = R0 R1 [R2 [R3]] (1400 = 5 * 7 * 5 * 8); a step is L / R butterflies of radix R
 //              per line (decimation in frequency, in place: a butterfly reads and writes the same
 //              R positions), any thread takes any butterfly: ~64 VGPRs, 16 waves per CU, all data
 //              movement is loops over the workgroup.  The spectrum is left in the digit-reversed
 //              order of the in-place algorithm (pos(k) below); the inverse runs the steps backwards.
 //
-// Which core bbx_zogy_frame uses: BBX_OPT_ZOGY_CORE (bbx_set_option).
 #include "bbx_common.h"
 #ifndef Z3_NO_CONTRACT
 #pragma clang fp contract(fast)      // the transforms are compared within a tolerance, not bit by bit: let mul + add fuse
@@ -575,7 +573,8 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_cols_fwd(const fl
     C_LOOP(e, l, p) Cout[cbase + e] = s[l * P::LS + npos(p)];
 }
 
-// see bbx_zogy2.hip: V(S)^ is scaled by a power of two before it shares a transform with D
+// V(S)^ is scaled by a power of two before it shares a transform with D (float32 rounding leaks ~1e-7 of the larger part of a
+// complex transform into the smaller; the scale, chosen per sub-image from Parseval sums of k^2, is exact to undo)
 template <class P> __device__ __forceinline__ float vs_scale(const double* __restrict__ fs_partial, int nsub, int sub, const zscal& z) {
     double a = 0.0, b = 0.0;
     for (int g = 0; g < P::G; g++) {
@@ -972,4 +971,51 @@ int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, int L, int ny, int nx, int s
         case 64: Z3_RUN(8, 8);
     }
     return BBX_ERR_ARG;
+}
+
+// ---- entry points (include/bbx.h) ------------------------------------------------------------------------------------
+struct zogy_tw_state { float2* d_tw; int L; };
+
+void bbx_zogy2_release(bbx_ctx* ctx) {          // (name kept: bbx_ctx_destroy calls it) frees the context's twiddle table
+    if (!ctx || !ctx->zogy2_state) return;
+    zogy_tw_state* st = (zogy_tw_state*)ctx->zogy2_state;
+    if (st->d_tw) (void)hipFree(st->d_tw);
+    free(st);
+    ctx->zogy2_state = nullptr;
+}
+
+extern "C" int bbx_zogy_frame_supported(int L) { return bbx_zogy3_supported(L); }
+
+extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+                              const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S,
+                              const float* h_scal, float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr,
+                              void* stream) {
+    if (!ctx || !d_new || !d_ref || !d_sig_new || !d_sig_ref || !d_psf_n || !d_psf_r || !h_scal || !d_D || !d_Scorr || !d_Fpsf || !d_Fpsferr)
+        return BBX_ERR_ARG;
+    if (size < 1 || border < 0 || ny < size || nx < size || ny % size || nx % size || S < 1) return BBX_ERR_ARG;
+    const int L = size + 2 * border;
+    if (!bbx_zogy_frame_supported(L) || S > L || (ny / size) * (nx / size) > 4096) return BBX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->zogy2_state) {
+        ctx->zogy2_state = calloc(1, sizeof(zogy_tw_state));
+        if (!ctx->zogy2_state) return BBX_ERR_NOMEM;
+    }
+    zogy_tw_state* st = (zogy_tw_state*)ctx->zogy2_state;
+    if (st->L != L) {
+        // twiddle table W^m = exp(-2 pi i m / L), float64 on the host, rounded once
+        if (st->d_tw) { BBX_HIP(hipDeviceSynchronize()); BBX_HIP(hipFree(st->d_tw)); st->d_tw = nullptr; }
+        float2* h = (float2*)malloc((size_t)L * sizeof(float2));
+        if (!h) return BBX_ERR_NOMEM;
+        for (int m = 0; m < L; m++) {
+            const double a = -2.0 * M_PI * (double)m / (double)L;
+            h[m] = make_float2((float)cos(a), (float)sin(a));
+        }
+        hipError_t e = hipMalloc((void**)&st->d_tw, (size_t)L * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(st->d_tw, h, (size_t)L * sizeof(float2), hipMemcpyHostToDevice);
+        free(h);
+        if (e != hipSuccess) return bbx_hip_fail(ctx, e, "twiddle table", __LINE__);
+        st->L = L;
+    }
+    return bbx_zogy3_run(ctx, st->d_tw, L, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, h_scal, d_D, d_S,
+                         d_Scorr, d_Fpsf, d_Fpsferr, s);
 }

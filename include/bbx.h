@@ -88,8 +88,8 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * it, below the allocated one -- lets a test drive the list-overflow path (BBX_ERR_OVERFLOW ->
  * COSMIC-P = False) with an ordinary frame. */
 #define BBX_OPT_DEBUG_LISTCAP 2
-/* BBX_OPT_ZOGY_CORE: which 1-D transform bbx_zogy_frame's kernels use: 0 = two steps of register
- * DFTs (bbx_zogy2.hip), 1 = radix passes in LDS (bbx_zogy3.hip).  Same results to rounding. */
+/* BBX_OPT_ZOGY_CORE: selected between two 1-D transform cores in round 2; the register-DFT core (bbx_zogy2.hip) is
+ * gone, the option is accepted and has no effect. */
 #define BBX_OPT_ZOGY_CORE 3
 /* BBX_OPT_ZOGY_KWIN_OFF (default 0): bbx_zogy_frame takes the matched-filter kernels k_n, k_r (real space) through
  * their inverse row pass, the squares and the forward row pass on a window of 2 wh >= 4 S + 32 rows around the origin

@@ -116,19 +116,14 @@ def test_background_mesh_fullsize(scene):
     np.testing.assert_allclose(bstd.cpu().numpy(), bstd_o, rtol=2e-6)
 
 
-@pytest.mark.parametrize('core,branch', [(1, 'ref-with-mesh'), (1, 'ref-bkgsub'), (0, 'ref-with-mesh')],
-                         ids=['core-ldspasses', 'core-ldspasses-refbkgsub', 'core-regdft'])
-def test_zogy_fullsize(scene, core, branch):
+@pytest.mark.parametrize('branch', ['ref-with-mesh', 'ref-bkgsub'])
+def test_zogy_fullsize(scene, branch):
     """optimal_subtraction on the full frame (64 sub-images of 1400^2) against the oracle's
     run_zogy on whole sub-images (a corner, an interior one, the last one); every injected
     transient is recovered with its flux; the transient list of those sub-images and the PSF
-    photometry of the catalogue against the oracle.  Both 1-D transform cores of bbx_zogy_frame
-    (BBX_OPT_ZOGY_CORE = 3: 1 = radix passes 5*7*5*8 in LDS, the default; 0 = register DFTs 35*40) and both
-    ways a reference comes: with its own sky (mesh + sigma image made here) or as buildref delivers
+    photometry of the catalogue against the oracle.  Both ways a reference comes: with its own sky (mesh + sigma image made here) or as buildref delivers
     it -- background-subtracted with its `_bkg_std_mini` image ('ref-bkgsub': the configuration bench.py times)."""
-    from blackbox_amd._lib import lib
     ctx = scene['ctx']
-    assert lib.bbx_set_option(ctx.h, 3, core) == 0
     pn, pr = bench.moffat_stamp(25, 4.0), bench.moffat_stamp(25, 3.6)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)       # noqa: E731
     dx, dy = 0.03, 0.02
@@ -238,7 +233,6 @@ def test_zogy_fullsize(scene, core, branch):
             assert t['fpsf'] == pytest.approx(float(Fp[yy, xx]), abs=float(tols['Fpsf'][ti])), (q, t)
         assert nsame >= 0.9 * len(sure_w)
     print('ZOGY full size, max |HIP - oracle| (/ local noise, / tolerance):', worst)
-    assert lib.bbx_set_option(ctx.h, 3, 1) == 0
     # Scorr of the unmasked frame ~ N(0, 1) (QC ranges set_qc.py:382-383)
     assert abs(hdr['Z-SCMED'][0]) < 0.3 and abs(hdr['Z-SCSTD'][0] - 1) < 0.15
     # injected transients: found within a pixel, flux within 3 sigma + 5 %

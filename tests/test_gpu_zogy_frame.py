@@ -1,8 +1,7 @@
-"""GPU: bbx_zogy_frame -- the hand-written 2-D FFT path of the ZOGY stage, with both of its 1-D
-transform cores (BBX_OPT_ZOGY_CORE: bbx_zogy2.hip / bbx_zogy3.hip) -- against
+"""GPU: bbx_zogy_frame -- the hand-written 2-D FFT path of the ZOGY stage (bbx_zogy3.hip) -- against
 the oracle's run_zogy on every sub-image (cut with zero padding, per-sub-image PSFs and
 scalars, stitched), for each sub-image side the path is built for (64 = 8*8, 128 = 8*16,
-140 = 10*14 = 5*7*4; 1400 = 35*40 = 5*7*5*8 is covered at full size in test_gpu_fullsize_zogy.py), with and
+100 = 5*5*4, 140 = 5*7*4; 1400 = 5*7*5*8 is covered at full size in test_gpu_fullsize_zogy.py), with and
 without a border (the finite differences then wrap around like np.roll), and against the
 rocFFT path (bbx_zogy_subimages) on the same inputs."""
 import ctypes as C
@@ -84,19 +83,9 @@ def oracle(new, ref, sig_n, sig_r, pn, pr, scal, size, border):
     return [Z.stitch_subimages(np.stack(o), ny, nx, size, border) for o in outs]
 
 
-BBX_OPT_ZOGY_CORE = 3
-
-
-@pytest.fixture(params=[0, 1], ids=['core-regdft', 'core-ldspasses'])
-def core(ctx, request):
-    assert lib.bbx_set_option(ctx.h, BBX_OPT_ZOGY_CORE, request.param) == 0
-    yield request.param
-    assert lib.bbx_set_option(ctx.h, BBX_OPT_ZOGY_CORE, 1) == 0
-
-
-@pytest.mark.parametrize('size,border,nsy,nsx,S', [(48, 8, 2, 3, 11), (64, 0, 2, 2, 9), (100, 14, 2, 3, 15), (120, 10, 2, 4, 15),
+@pytest.mark.parametrize('size,border,nsy,nsx,S', [(48, 8, 2, 3, 11), (64, 0, 2, 2, 9), (100, 14, 2, 3, 15), (120, 10, 2, 4, 15), (100, 0, 2, 2, 9),
                                                   (128, 0, 1, 2, 13)])
-def test_frame_path_vs_oracle(ctx, core, size, border, nsy, nsx, S):
+def test_frame_path_vs_oracle(ctx, size, border, nsy, nsx, S):
     L = size + 2 * border
     assert lib.bbx_zogy_frame_supported(L)
     new, ref, sig_n, sig_r, pn, pr, scal = make(size, border, nsy, nsx, S, seed=L + border)
@@ -113,7 +102,7 @@ def test_frame_path_vs_oracle(ctx, core, size, border, nsy, nsx, S):
         assert np.abs(g[ok] - w[ok]).max() <= 2e-5 * scale, (name, np.abs(g[ok] - w[ok]).max(), scale)
 
 
-def test_frame_path_vs_rocfft_path(ctx, core):
+def test_frame_path_vs_rocfft_path(ctx):
     """the two device implementations on the same inputs (L = 140: radices 2, 5, 7 like 1400)"""
     size, border, nsy, nsx, S = 120, 10, 2, 4, 15
     L = size + 2 * border

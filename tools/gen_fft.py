@@ -20,7 +20,7 @@ import subprocess
 import sys
 import tempfile
 
-SIZES = [2, 3, 4, 5, 7, 8, 10, 14, 15, 16, 25, 35, 40]
+SIZES = [2, 3, 4, 5, 7, 8, 16]                 # the radices of bbx_zogy3.hip's plans (1400 = 5 7 5 8, 140 = 5 7 4, 128 = 8 16, ...)
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'blackbox_amd', 'csrc', 'bbx_fft_gen.h')
 
 
