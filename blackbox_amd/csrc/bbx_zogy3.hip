@@ -115,7 +115,9 @@ template <class P> __device__ __forceinline__ int ppos(int k) {
     return npos(p);
 }
 
-// one radix-R pass over blocks of B entries of NLINES lines (B / R = M butterflies per block).  The
+// one radix-R pass over blocks of B entries of NLINES lines (B / R = M butterflies per block).  (A thread taking the same
+// butterfly of two neighbouring lines -- positions and twiddles worked out once for both -- needs ~50 more registers than
+// the 85 that two workgroups of 768 threads leave: it spills and is 15 % slower.)  The
 // butterfly's R positions are base + r M: with the padding they stay an affine function of r when M
 // is a multiple of 8, or when M = 1 and the block starts at a multiple of 8 (constant offsets).
 template <class P, int R, int B, bool INV, int NLINES>
