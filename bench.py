@@ -335,6 +335,8 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
     mark['n'], first = 0, save[1]
     mark['bytes'], mark['files'] = 0, 0
     pipe.t_stats = [0.0, 0.0, 0.0, 0]
+    pipe.lane_cpu = [0.0, 0.0, 0]
+    t_cpu_main = time.thread_time()
 
     def on_done(idx, f):
         if stage is None:
@@ -350,7 +352,10 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
     if mark['err'] is not None:
         raise mark['err']
     out = dict(dt=mark['t1'] - mark['t0'], dt_all=t_end - t_all0, n_all=n_all, t_stats=list(pipe.t_stats), last=mark.get('last'),
-               nworkers=pipe.pool.n, bytes_written=mark['bytes'], files_written=mark['files'])
+               nworkers=pipe.pool.n, bytes_written=mark['bytes'], files_written=mark['files'],
+               host_ms_per_frame=dict(lane_threads_cpu=1e3 * pipe.lane_cpu[0] / max(1, pipe.lane_cpu[2]),
+                                      lane_threads_wall=1e3 * pipe.lane_cpu[1] / max(1, pipe.lane_cpu[2]),
+                                      orchestrator_cpu=1e3 * (time.thread_time() - t_cpu_main) / n_all))
     pipe.close()
     if stage is not None:
         stage.close()
@@ -657,6 +662,7 @@ def main():
                                      note='all frames of the run from an idle device to an idle device (pipeline fill and drain included)'),
                    pipeline_wall_ms_per_frame=dict(zip(['stageA_stats', 'stageB_host_fits', 'stageC_device'],
                                                        [1e3 * t / max(1, r['t_stats'][3]) for t in r['t_stats'][:3]])),
+                   host_ms_per_frame=r['host_ms_per_frame'],
                    single_frame_latency_ms=latency_ms, stage_ms_serial=stage_ms, lacosmic_stats=stats, subtraction=sub_info,
                    roofline=roof)
     # ---- the other workloads, briefly, and the I/O-inclusive figures (not part of `value`) ---------

@@ -48,25 +48,36 @@ struct sat_rect { int r0, r1, c0, c1; };
 __device__ __forceinline__ unsigned fkey(float f) { const unsigned u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k); }
 
-// 2 x 2 sums (blackbox.py:4171-4172) and, in the same pass, the largest and smallest binned value (make_mask divides by the
-// maximum; the interpolation is clipped to the image's range)
-__global__ __launch_bounds__(256) void k_bin2(const float* __restrict__ d, int nyb, int nxb, float* __restrict__ b, sat_state* st) {
+// 2 x 2 sums (blackbox.py:4171-4172)
+__global__ __launch_bounds__(256) void k_bin2(const float* __restrict__ d, int nyb, int nxb, float* __restrict__ b) {
     const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    if (X >= nxb) return;
+    const size_t nx = (size_t)nxb * 2;
+    const float2 r0 = *(const float2*)(d + (size_t)(2 * Y) * nx + 2 * X);
+    const float2 r1 = *(const float2*)(d + (size_t)(2 * Y + 1) * nx + 2 * X);
+    b[(size_t)Y * nxb + X] = (r0.x + r0.y) + (r1.x + r1.y);
+}
+
+// the largest and the smallest binned value (make_mask divides by the maximum; the interpolation is clipped to the image's
+// range): 16-byte loads, one pair of atomics per workgroup (same-address atomics retire one at a time, ~11 ns each)
+__global__ __launch_bounds__(256) void k_bin_minmax(const float* __restrict__ b, size_t n, sat_state* st) {
     unsigned hi = 0u, lo = ~0u;
-    if (X < nxb) {
-        const size_t nx = (size_t)nxb * 2;
-        const float2 r0 = *(const float2*)(d + (size_t)(2 * Y) * nx + 2 * X);
-        const float2 r1 = *(const float2*)(d + (size_t)(2 * Y + 1) * nx + 2 * X);
-        const float f = (r0.x + r0.y) + (r1.x + r1.y);
-        b[(size_t)Y * nxb + X] = f;
-        if (isfinite(f)) { hi = lo = fkey(f); }
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    const float4* b4 = (const float4*)b;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 q = b4[i];
+        const float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (isfinite(f[u])) { const unsigned k = fkey(f[u]); hi = k > hi ? k : hi; lo = k < lo ? k : lo; }
     }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float f = b[(n4 << 2) + threadIdx.x]; if (isfinite(f)) { const unsigned k = fkey(f); hi = k > hi ? k : hi; lo = k < lo ? k : lo; } }
     for (int o = 32; o > 0; o >>= 1) { const unsigned a = __shfl_xor(hi, o, 64), c = __shfl_xor(lo, o, 64); hi = a > hi ? a : hi; lo = c < lo ? c : lo; }
-    // (same-address atomics retire one at a time, ~11 ns each: a wave only goes there when it would change the extreme --
-    // after the first waves that is a handful of times per frame)
-    if ((threadIdx.x & 63) == 0 && hi) {
-        if (hi > __atomic_load_n(&st->bmax_key, __ATOMIC_RELAXED)) atomicMax(&st->bmax_key, hi);
-        if (lo < __atomic_load_n(&st->bmin_key, __ATOMIC_RELAXED)) atomicMin(&st->bmin_key, lo);
+    __shared__ unsigned shi[4], slo[4];
+    if ((threadIdx.x & 63) == 0) { shi[threadIdx.x >> 6] = hi; slo[threadIdx.x >> 6] = lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { hi = shi[w] > hi ? shi[w] : hi; lo = slo[w] < lo ? slo[w] : lo; }
+        if (hi) { atomicMax(&st->bmax_key, hi); atomicMin(&st->bmin_key, lo); }
     }
 }
 
@@ -575,7 +586,8 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     int32_t* cnt = &ctx->d_counters[CNT_CAND];
     BBX_HIP(hipMemcpyAsync(cs, h_cos_sin, (size_t)ntheta * 16, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sat_init, dim3(1), dim3(128), 0, s, st);
-    hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin, st);
+    hipLaunchKernelGGL(k_bin2, dim3((nxb + 255) / 256, nyb), dim3(256), 0, s, d_data, nyb, nxb, bin);
+    hipLaunchKernelGGL(k_bin_minmax, dim3(1024), dim3(256), 0, s, bin, nb, st);
     // acstools' front end: sigma = 3 (sat_detect), low_thresh = 0.1 (default), h_thresh = 0.2 (sat_detect), small_edge = 60
     rc = bbx_canny_edges(ctx, bin, nyb, nxb, h_gauss, gauss_radius, 0.1, 0.2, 60, list, cnt, (uint32_t)cap, s); if (rc) return rc;
     if ((size_t)nrho * 4 <= 150 * 1024) {

@@ -334,6 +334,7 @@ class FramePipeline:
         self.hos_rows = self.dy - self.ysz - 10
         self.two_phase = tel != 'ML1'
         self.t_stats = [0.0, 0.0, 0.0, 0]      # wall: start->stats on host, fits, device stage; frames
+        self.lane_cpu = [0.0, 0.0, 0]          # lane threads: CPU seconds, wall seconds inside the device stage, frames
         # staging buffers, one set per frame in flight (pinned host + device), allocated once:
         # pin_memory()/hipHostMalloc costs ~10 ms per call and must stay out of the frame loop
         dev = ctx.device
@@ -516,8 +517,13 @@ class FramePipeline:
         ctx = self.lane_ctx[f.lane]
         # every torch allocation / operation of the stage belongs to the lane's stream (the caching
         # allocator hands a freed block only to work queued behind it on the same stream)
+        t_cpu, t_wall = time.thread_time(), time.perf_counter()
         with torch.cuda.stream(ctx.torch_stream):
             self._device_stage_on_lane(f, results, ctx)
+        # host cost of the stage: CPU seconds of this lane thread (what it holds the interpreter for, roughly) and its wall time
+        self.lane_cpu[0] += time.thread_time() - t_cpu
+        self.lane_cpu[1] += time.perf_counter() - t_wall
+        self.lane_cpu[2] += 1
 
     def _device_stage_on_lane(self, f, results, ctx):
         geom, tel = self.geom, self.tel
