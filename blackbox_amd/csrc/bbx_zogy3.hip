@@ -941,6 +941,8 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
                      nyb_psf, wb);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
+    // (one launch for both pairs -- the frames read once, the variance pair waiting in registers behind the first transform -- spills
+    // 108 registers and takes twice the time of the two launches: a transform leaves no registers to park anything)
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
     fa.sa = d_sig_new; fa.sb = d_sig_ref;
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);

@@ -1,6 +1,9 @@
 """Merge two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic.
 
-    python3 tools/pmc_traffic.py <dir FETCH_SIZE pass> <dir WRITE_SIZE pass> > traffic.json
+    python3 tools/pmc_traffic.py <dir FETCH_SIZE pass> <dir WRITE_SIZE pass> [commit] > traffic.json
+
+The summary records the SHA-256 of the HIP sources the profiled kernels come from: bench.py reports `traffic` only while
+those files are unchanged.
 
 Counter unit: KB.  bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports
 half of a wide coalesced read (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
@@ -24,9 +27,17 @@ def load(d, counter):
     return acc
 
 
+STAMPED = ['blackbox_amd/csrc/bbx_zogy3.hip', 'blackbox_amd/csrc/bbx_calibrate.hip', 'blackbox_amd/csrc/bbx_lacosmic.hip']
+
+
 def main():
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
     fe, wr = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-    out = {'_note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 3 '
+    out = {'commit': sys.argv[3] if len(sys.argv) > 3 else 'unknown',
+           'source_sha256': {f: hashlib.sha256(open(os.path.join(root, f), 'rb').read()).hexdigest() for f in STAMPED},
+           '_note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 3 '
                     '--warmup 1 --no-cpu --no-extras --lanes 1 --depth 2` on MI355X; counter unit KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 '
                     '(gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section; '
                     '8-B and 4-B/lane loads are uncalibrated)',
