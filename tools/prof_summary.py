@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(f)))
 tot = 0
 rows.sort(key=lambda r: -float(r['TotalDurationNs']))
 SETUP = ('distribution_', 'indexFunc', 'index_add', 'randn', 'normal_', 'philox', 'cumsum', 'sort', 'scatter', 'index_put', 'arange', 'gather', 'index_elementwise')
-setup = [r for r in rows if any(k in r['Name'] for k in SETUP)]
+setup = [r for r in rows if not r['Name'].startswith('k_') and 'z3::' not in r['Name'] and any(k in r['Name'] for k in SETUP)]
 rows = [r for r in rows if r not in setup]
 for r in rows:
     n = r['Name']
