@@ -445,8 +445,8 @@ def main():
         ysz, xsz, os_y, os_x = 5280, 1320, 20, 180
         size, border, box = 1320, 40, 60
     wl = args.workload
-    lanes = args.lanes or {'zogy': 6, 'full': 6, 'calib': 6}[wl]
-    depth = args.depth or {'zogy': 16, 'full': 18, 'calib': 18}[wl]
+    lanes = args.lanes or {'zogy': 6, 'full': 6, 'calib': 8}[wl]          # (calib: 4 / 6 / 8 / 10 lanes -> 1180 / 1230 / 1370 / 1210 frames/s)
+    depth = args.depth or {'zogy': 16, 'full': 18, 'calib': 24}[wl]
     seed = 1000 * 4 + rank
     raw, flat, bpm, ex = synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, args.raw, extras=True, ntrans=50)
     ref, ref_mask = synth_reference(torch, dev, ex.pop('scene0'), seed)
@@ -671,7 +671,7 @@ def main():
         for w2 in ('calib', 'full'):
             if w2 == wl:
                 continue
-            l2, d2 = (6, 18)
+            l2, d2 = (8, 24) if w2 == 'calib' else (6, 18)
             r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 4, d2, l2, pool, barrier)
             others[w2] = dict(frames_per_s=60 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 60, frames_in_flight=d2, lanes=l2)
         if wl == 'zogy':
