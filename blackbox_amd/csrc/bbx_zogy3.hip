@@ -22,8 +22,11 @@ namespace z3 {
 struct zscal { float sn, sr, fn, fr, dx, dy; };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+#ifndef Z3_SPREAD
+#define Z3_SPREAD 1
+#endif
 #ifndef Z3_LSMOD
-#define Z3_LSMOD 8
+#define Z3_LSMOD (Z3_SPREAD ? 16 : 8)
 #endif
 constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD) s++; return s; }
 
@@ -93,17 +96,12 @@ template <int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Plan {
     static constexpr int MINW = L >= 512 ? Z3_MINW : 1, FIN_MINW = L >= 512 ? Z3_FIN_MINW : 1;
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+typedef bbx_v2f __attribute__((may_alias)) v2f_a;     // a float2 of the line buffers read / written as one (re, im) pair
+__device__ __forceinline__ bbx_v2f to_v(float2 a) { return bbx_v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 from_v(bbx_v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return from_v(bbx_cmul(to_v(a), to_v(b))); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return from_v(bbx_cmulc(to_v(a), to_v(b))); }   // a * conj(b)
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
-
-template <int N> __device__ __forceinline__ void idft(float2 (&x)[N]) {      // inverse = forward on swapped pairs
-#pragma unroll
-    for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
-    bbx_dft<N>::run(x);
-#pragma unroll
-    for (int i = 0; i < N; i++) { const float t = x[i].x; x[i].x = x[i].y; x[i].y = t; }
-}
 
 __device__ __forceinline__ int npos(int n) { return n + (n >> 3); }                       // LDS position of entry n of a line
 // position of spectral index k after the forward transform (digit reversal of the in-place passes)
@@ -124,38 +122,50 @@ template <class P, int R, int B, bool INV, int NLINES>
 __device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ tw) {
     constexpr int M = B / R, PER = P::L / R, NTASK = NLINES * PER, TWS = P::L / B;
     constexpr bool AFF8 = M % 8 == 0, AFF1 = M == 1 && (8 % R == 0 || R % 8 == 0);
+    // Lanes -> butterflies.  SPREAD (M a multiple of 8, groups of 4 lines): 8 consecutive lanes take 8 consecutive
+    // butterflies of one line, the next 8 lanes the same butterflies of the next line.  With the line stride = 8 entries
+    // mod 32 the 32 lanes one ds_read_b64 group serves then touch 32 different 8-byte banks (a run of 32 consecutive
+    // entries of ONE line covers 35 padded positions: a two-way conflict on every read), and their twiddle reads are the
+    // same 8 addresses for the 4 lines.
+    constexpr bool SPREAD = Z3_SPREAD && AFF8 && PER % 8 == 0 && NLINES >= 4;
+    constexpr int NSPREAD = SPREAD ? (NLINES / 4) * 4 * PER : 0;
     for (int task = threadIdx.x; task < NTASK; task += blockDim.x) {
-        const int l = task / PER, j = task - l * PER;
+        int l, j;
+        if (SPREAD && task < NSPREAD) {
+            const int lg = NLINES >= 8 ? task / (4 * PER) : 0, t = task - lg * (4 * PER);
+            l = lg * 4 + ((t >> 3) & 3); j = ((t >> 5) << 3) | (t & 7);
+        } else { l = task / PER; j = task - l * PER; }
         const int b = j / M, m = j - b * M;
         const int base = b * B + m;
-        float2* line = s + l * P::LS + ((AFF8 || AFF1) ? npos(base) : 0);
-        float2 u[R];
+        v2f_a* line = reinterpret_cast<v2f_a*>(s + l * P::LS + ((AFF8 || AFF1) ? npos(base) : 0));
+        const v2f_a* twv = reinterpret_cast<const v2f_a*>(tw);
+        bbx_v2f u[R];
 #pragma unroll
         for (int r = 0; r < R; r++) u[r] = line[AFF8 ? r * (M + M / 8) : AFF1 ? r + r / 8 : npos(base + r * M)];
         // twiddles W^(m k TWS), k = 1 .. R-1: one table read, the powers by multiplication (Z3_TWPOW), or R-1 reads
-        float2 w[R];
+        bbx_v2f w[R];
         if constexpr (M > 1) {
 #ifdef Z3_TWPOW
-            w[1] = tw[m * TWS];
+            w[1] = twv[m * TWS];
 #pragma unroll
-            for (int k = 2; k < R; k++) w[k] = (k % 2 == 0) ? cmul(w[k / 2], w[k / 2]) : cmul(w[k - 1], w[1]);
+            for (int k = 2; k < R; k++) w[k] = (k % 2 == 0) ? bbx_cmul(w[k / 2], w[k / 2]) : bbx_cmul(w[k - 1], w[1]);
 #else
 #pragma unroll
-            for (int k = 1; k < R; k++) w[k] = tw[m * k * TWS];
+            for (int k = 1; k < R; k++) w[k] = twv[m * k * TWS];
 #endif
         }
         if (!INV) {
-            bbx_dft<R>::run(u);
+            bbx_dft<R>::fwd(u);
             if constexpr (M > 1) {
 #pragma unroll
-                for (int k = 1; k < R; k++) u[k] = cmul(u[k], w[k]);
+                for (int k = 1; k < R; k++) u[k] = bbx_cmul(u[k], w[k]);
             }
         } else {
             if constexpr (M > 1) {
 #pragma unroll
-                for (int k = 1; k < R; k++) u[k] = cmulc(u[k], w[k]);
+                for (int k = 1; k < R; k++) u[k] = bbx_cmulc(u[k], w[k]);
             }
-            idft<R>(u);
+            bbx_dft<R>::inv(u);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) line[AFF8 ? r * (M + M / 8) : AFF1 ? r + r / 8 : npos(base + r * M)] = u[r];
@@ -415,11 +425,18 @@ template <class P> __device__ __forceinline__ void store_t_split(const float2* s
 // (the thread index goes through an empty asm so that the 17 entry addresses are recomputed in every
 // loop instead of being kept in registers across the transforms in between)
 __device__ __forceinline__ int opaque_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+// entry e -> (line l, position p).  With 4 lines of a multiple of 8 entries: 8 consecutive entries of one line, then the
+// same 8 of the next line (as the butterflies of fft_step: the 32 lanes of a read group touch 32 different banks).  The
+// C arrays are stored in this order of e, by the same loops.
+template <class P> __device__ __forceinline__ void e2lp(int e, int& l, int& p) {
+    if constexpr (Z3_SPREAD && P::NL == 4 && P::L % 8 == 0) { l = (e >> 3) & 3; p = ((e >> 5) << 3) | (e & 7); }
+    else { l = e / P::L; p = e - l * P::L; }
+}
 #define R_LOOP(k, e, l, p)                                                                     \
     for (int t_ = opaque_tid(), once_ = 1; once_; once_ = 0)                                     \
     _Pragma("unroll") for (int k = 0, e, l, p; k < NE; k++)                                      \
-        if (e = t_ + k * RT, l = e / P::L, p = e - l * P::L, e < P::NL * P::L)        /* RT: the kernel's thread count */
-#define C_LOOP(e, l, p) for (int e = threadIdx.x, l, p; l = e / P::L, p = e - l * P::L, e < P::NL * P::L; e += blockDim.x)
+        if (e = t_ + k * RT, e2lp<P>(e, l, p), e < P::NL * P::L)                      /* RT: the kernel's thread count */
+#define C_LOOP(e, l, p) for (int e = threadIdx.x, l, p; e2lp<P>(e, l, p), e < P::NL * P::L; e += blockDim.x)
 
 // ---- PSF side ---------------------------------------------------------------------------------
 template <class P>
