@@ -564,6 +564,7 @@ def main():
         HP = ((L // 2 + 1 + 3) // 4) * 4                     # padded half-spectrum width of bbx_zogy3.hip (NL = 4)
         spec = nsub * HP * L * 8                              # one half spectrum of all sub-images, bytes
         cut = 4 * nsub * L * L                                # one frame read as overlapping sub-images, bytes
+        rows_once = not (calls[10] and calls[11]) or calls[10] < 2 * calls[11]
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
             'k_lac_cand': (1, 4 * N),
@@ -571,7 +572,9 @@ def main():
             'k_final_rows': (7, 4 * spec + 4 * 4 * N),          # reads D^, V_S^, S_n^, S_r^ (column-transformed), writes D, Scorr, Fpsf, Fpsferr
             'k_psf_cols': (8, 6 * spec),                        # writes A, B, k_n^, k_r^ and the two column-inverted k^
             'k_psf_rows': (9, 4 * spec),
-            'k_img_rows': (10, int(2 * spec + 3 * cut)),        # two launches: 2 + 4 frame cuts read, 2 half spectra written each (average)
+            # one launch for both pairs (4 frame cuts read, 4 half spectra written); frames whose rows are not 16-byte aligned
+            # take two launches (2 + 4 cuts read, 2 spectra written each: the average below)
+            'k_img_rows': (10, int(4 * spec + 4 * cut) if rows_once else int(2 * spec + 3 * cut)),
             'k_img_cols': (11, 9 * spec),
             'k_var_cols': (12, 5 * spec),
         }
@@ -587,7 +590,7 @@ def main():
             return dict(avg_launch_ms=t[0], launches=int(t[2]), moved_bytes_per_launch=int(t[1]), achieved_moved=gbs(t),
                         frac_moved=gbs(t) / HBM_PEAK_GBS)
         pmc, pmc_note = load_pmc(args)
-        per_frame = {k: (2 if k == 'k_img_rows' else 1) for k in zogy_kernels}
+        per_frame = {k: (2 if k == 'k_img_rows' and not rows_once else 1) for k in zogy_kernels}
         # SURVEY 8d frame figure (config 5, u16 raw): calibration 12N(u16)/14N(f32) + LA-Cosmic 22N + xtalk 9N + masks 6N +
         # sat 8N + mesh 9N + ZOGY 34N + photometry (n_src x S^2 x 3 images x 4 B)
         Nraw = raw.numel()
@@ -604,7 +607,7 @@ def main():
             zms = sum(live[k][0] * per_frame[k] for k in zogy_kernels)
             zms_iso = sum(iso[k][0] * per_frame[k] for k in zogy_kernels)
             moved = int(sum(live[k][1] * per_frame[k] for k in zogy_kernels))
-            roof = dict(bound='hbm', kernel='bbx_zogy_frame (launch group: k_psf_cols, k_psf_rows, 2 x k_img_rows, k_img_cols, '
+            roof = dict(bound='hbm', kernel='bbx_zogy_frame (launch group: k_psf_cols, k_psf_rows, k_img_rows, k_img_cols, '
                                             'k_var_cols, k_final_rows)',
                         achieved=zogy_io_model / (zms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                         avg_launch_ms=zms, launches=int(min(live[k][2] // per_frame[k] for k in zogy_kernels)),

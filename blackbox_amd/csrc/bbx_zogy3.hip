@@ -52,8 +52,8 @@ constexpr int line_stride(int lp) { int s = lp; while ((2 * s) % 64 != Z3_LSMOD)
 #define Z3_LIGHT_THREADS Z3_THREADS   // k_psf_rows, k_img_rows (nothing parked in registers)
 #endif
 #ifndef Z3_VAR_THREADS
-#define Z3_VAR_THREADS 512     // k_var_cols keeps two spectra in registers (768 threads with one of them parked in the
-#define Z3_VAR_MINW 4          // consumed T tiles instead: no faster -- the kernel is bound by its five transforms)
+#define Z3_VAR_THREADS 768     // k_var_cols keeps two spectra in registers: 2 x 8 float2 per thread, 85 VGPRs without spills
+#define Z3_VAR_MINW 6          // since the transforms work on (re, im) pairs (512 threads / 128 VGPRs before)
 #endif
 #ifndef Z3_MINW
 #define Z3_MINW 6              // waves per SIMD the register allocation must allow (two workgroups of 768 threads)
@@ -679,6 +679,71 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows(fr
     store_t_split<P>(s, aux.pp, Ta, Tb, sub, yb);
 }
 
+// The same for both pairs in one launch (frames whose groups of four pixels are aligned): the four frames are read once;
+// the variance pair (max(N, 0) + sigma_N^2, max(R, 0) + sigma_R^2) waits in registers behind the first transform.
+template <class P>
+__global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_both(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta,
+                                                                                float2* __restrict__ Tb, float2* __restrict__ Tva, float2* __restrict__ Tvb, int nsub) {
+    extern __shared__ float2 s[];
+    WG_TASK(P::LB, nsub, yb, sub);
+    const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
+    const float2* tw = aux.tw;
+    const int y0 = yb * P::NL;
+    const int sy = sub / f.nsx, sx = sub - sy * f.nsx;
+    const int Y0 = sy * f.size - f.border, X0 = sx * f.size - f.border;
+    constexpr int NV = P::NL * P::L / 4, NP = (NV + P::LIGHT_THREADS - 1) / P::LIGHT_THREADS;
+    float4 pa[NP], pb[NP];
+    {
+        float4 va[NP], vb[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int e = (int)threadIdx.x + i * P::LIGHT_THREADS;
+            va[i] = vb[i] = pa[i] = pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < NV) {
+                const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                const int Y = Y0 + y0 + ll, X = X0 + x;
+                if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
+                    const size_t o = (size_t)Y * f.nx + X;
+                    va[i] = *reinterpret_cast<const float4*>(f.a + o); vb[i] = *reinterpret_cast<const float4*>(f.b + o);
+                    pa[i] = *reinterpret_cast<const float4*>(f.sa + o); pb[i] = *reinterpret_cast<const float4*>(f.sb + o);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int e = (int)threadIdx.x + i * P::LIGHT_THREADS;
+            if (e < NV) {
+                const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                float2* line = s + ll * P::LS;
+                line[npos(x)] = make_float2(va[i].x, vb[i].x); line[npos(x + 1)] = make_float2(va[i].y, vb[i].y);
+                line[npos(x + 2)] = make_float2(va[i].z, vb[i].z); line[npos(x + 3)] = make_float2(va[i].w, vb[i].w);
+                const float4 p = pa[i], q4 = pb[i];
+                pa[i] = make_float4(fmaxf(va[i].x, 0.f) + p.x * p.x, fmaxf(va[i].y, 0.f) + p.y * p.y, fmaxf(va[i].z, 0.f) + p.z * p.z,
+                                    fmaxf(va[i].w, 0.f) + p.w * p.w);
+                pb[i] = make_float4(fmaxf(vb[i].x, 0.f) + q4.x * q4.x, fmaxf(vb[i].y, 0.f) + q4.y * q4.y, fmaxf(vb[i].z, 0.f) + q4.z * q4.z,
+                                    fmaxf(vb[i].w, 0.f) + q4.w * q4.w);
+            }
+        }
+    }
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    store_t_split<P>(s, aux.pp, Ta, Tb, sub, yb);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int e = (int)threadIdx.x + i * P::LIGHT_THREADS;
+        if (e < NV) {
+            const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+            float2* line = s + ll * P::LS;
+            line[npos(x)] = make_float2(pa[i].x, pb[i].x); line[npos(x + 1)] = make_float2(pa[i].y, pb[i].y);
+            line[npos(x + 2)] = make_float2(pa[i].z, pb[i].z); line[npos(x + 3)] = make_float2(pa[i].w, pb[i].w);
+        }
+    }
+    __syncthreads();
+    fft_fwd<P>(s, tw);
+    store_t_split<P>(s, aux.pp, Tva, Tvb, sub, yb);
+}
+
 // column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U tiles)
 template <class P>
 __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* __restrict__ TN, const float2* __restrict__ TR, const float2* __restrict__ cA,
@@ -932,6 +997,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_cols_fwd<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows_both<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_img_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_var_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_final_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
@@ -958,11 +1024,17 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
                      nyb_psf, wb);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
-    // (one launch for both pairs -- the frames read once, the variance pair waiting in registers behind the first transform -- spills
-    // 108 registers and takes twice the time of the two launches: a transform leaves no registers to park anything)
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
-    fa.sa = d_sig_new; fa.sb = d_sig_ref;
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
+#ifndef Z3_ROWS_SPLIT
+    if (fa.vec4) {
+        fa.sa = d_sig_new; fa.sb = d_sig_ref;
+        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows_both<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, T2, T3, nsub);
+    } else
+#endif
+    {
+        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, nsub);
+        fa.sa = d_sig_new; fa.sb = d_sig_ref;
+        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
+    }
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub, wh, ctx->d_err);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
