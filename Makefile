@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := blackbox_amd/csrc
 SRCS  := $(CSRC)/bbx_ctx.hip $(CSRC)/bbx_overscan.hip $(CSRC)/bbx_calibrate.hip \
          $(CSRC)/bbx_mask.hip $(CSRC)/bbx_select.hip $(CSRC)/bbx_lacosmic.hip $(CSRC)/bbx_xtalk.hip \
-         $(CSRC)/bbx_stack.hip $(CSRC)/bbx_bkg.hip $(CSRC)/bbx_zogy.hip $(CSRC)/bbx_zogy3.hip $(CSRC)/bbx_sat.hip $(CSRC)/bbx_canny.hip $(CSRC)/bbx_psf.hip $(CSRC)/bbx_fpack.hip $(CSRC)/bbx_coadd.hip
+         $(CSRC)/bbx_stack.hip $(CSRC)/bbx_bkg.hip $(CSRC)/bbx_zogy.hip $(CSRC)/bbx_zogy3.hip $(CSRC)/bbx_sat.hip $(CSRC)/bbx_canny.hip $(CSRC)/bbx_psf.hip $(CSRC)/bbx_fpack.hip $(CSRC)/bbx_coadd.hip $(CSRC)/bbx_clipstats.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := blackbox_amd/libbbx_hip.so
 HOSTLIB := blackbox_amd/libbbx_host.so

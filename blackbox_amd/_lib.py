@@ -61,6 +61,7 @@ SIGNATURES = {
     'bbx_calibrate': (_i, [_vp, _pg, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp]),
     'bbx_rect_stats': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'bbx_rect_clipped_stats': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, C.c_double, _i, _i, _vp, _vp]),
+    'bbx_frame_clipped_stats': (_i, [_vp, _i, _i, _vp, _vp, _i, C.c_double, _i, _i, _vp, _vp]),
     'bbx_fpack_tile_stride': (C.c_size_t, [_i, _i]),
     'bbx_fpack_tiles': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_fpack_gather': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

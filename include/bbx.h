@@ -218,6 +218,17 @@ int bbx_rect_clipped_stats(bbx_ctx *ctx, int ny, int nx, int stride, const float
                            const uint8_t *d_mask, int ysz, int xsz, double sigma, int maxiters,
                            int skip_zero, double *d_out, void *stream);
 
+/* ---- a16 (Z-SCMED, Z-SCSTD, Z-FPEMED, Z-FPESTD): sigma-clipped statistics of a whole frame -------------------
+ * replaces the sigma_clipped_stats calls zogy's optimal_subtraction makes on the Scorr and Fpsferr frames for its
+ * header (3 sigma, 5 rounds, centre = median, spread = std, mask_value 0).  zogy feeds a random subset of the
+ * pixels; here the sample is the lattice of every [step]-th pixel of both axes of the contiguous [ny][nx] frame.
+ * Pixels with mask bits other than the cosmic-ray flag, non-finite values (astropy masks them) and (skip_zero)
+ * zeros do not take part.  d_out[8] = { n, median, mean, sigma, 0, 0, 0, 0 } of the survivors of [maxiters] rounds:
+ * the first four numbers of bbx_rect_clipped_stats on the lattice as one segment (exact medians; the float64 sums are
+ * taken in another order), from one sort instead of a bracketed select per round.                              */
+int bbx_frame_clipped_stats(bbx_ctx *ctx, int ny, int nx, const float *d_img, const uint8_t *d_mask, int step,
+                            double sigma, int maxiters, int skip_zero, double *d_out, void *stream);
+
 /* ---- a8 (GAINCF): channel scaling of the master flat copy ---------------------------
  * replaces `master_median_corr[data_sec_red[c]] /= med` and `*= ratio` (blackbox.py:5104,
  * 5139-5140): float32 IEEE division / multiplication of a rectangle in place.            */

@@ -119,3 +119,41 @@ def test_gpu_master_level_stats():
         assert R.hval(h, 'MBIASM%d' % (c + 1)) == pytest.approx(mean, rel=1e-9, abs=1e-9)
         assert R.hval(h, 'MBRDN%d' % (c + 1)) == pytest.approx(std, rel=1e-9)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,step', [((1003, 1500), 8), ((64, 48), 1), ((700, 900), 3)])
+def test_frame_clipped_stats_vs_oracle_and_select_path(shape, step):
+    """bbx_frame_clipped_stats (one sort, clipping rounds as index arithmetic) against astropy's algorithm restated
+    (oracle.sigma_clipped_stats_median, pinned by tests/golden/sigclip.npz) and against the bracketed-select path
+    (bbx_rect_clipped_stats) on the same lattice: n and median exact, mean / std to float64 summation order."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R, zogy as G, flatstats
+    ctx = R.Context(0)
+    rs = np.random.RandomState(shape[0] + step)
+    img = rs.normal(3.0, 2.0, shape).astype(np.float32)
+    img[rs.randint(0, shape[0], 2000), rs.randint(0, shape[1], 2000)] += rs.uniform(20, 500, 2000).astype(np.float32)   # outliers: clipped
+    img[rs.randint(0, shape[0], 500), rs.randint(0, shape[1], 500)] = 0                # the masked value
+    img[::step, ::step][1, 2] = np.nan
+    mask = np.zeros(shape, np.uint8)
+    mask[rs.randint(0, shape[0], 3000), rs.randint(0, shape[1], 3000)] = rs.choice([1, 2, 4, 16, 32], 3000).astype(np.uint8)
+    d_img, d_mask = torch.from_numpy(img).to(ctx.device), torch.from_numpy(mask).to(ctx.device)
+    for m, dm in ((None, None), (mask, d_mask)):
+        st = G.frame_clipped_stats_enqueue(ctx, d_img, dm, step).cpu().numpy()
+        sub = img[::step, ::step].copy()
+        if m is not None:
+            sub[(m[::step, ::step] & ~np.uint8(2)) != 0] = np.nan                      # bits other than the cosmic-ray flag (2) drop the pixel
+        mean, med, std, n = O.sigma_clipped_stats_median(sub)
+        assert st[0] == n and np.float32(st[1]) == med
+        assert st[2] == pytest.approx(mean, rel=1e-12, abs=1e-12) and st[3] == pytest.approx(std, rel=1e-12)
+        dsub = d_img[::step, ::step].contiguous()
+        msub = dm[::step, ::step].contiguous() if dm is not None else None
+        ref = flatstats.rect_clipped_stats(ctx, dsub, msub, 0, 0, dsub.shape[0], dsub.shape[1], dsub.shape[0], dsub.shape[1], skip_zero=True)[0]
+        assert st[0] == ref[0] and st[1] == ref[1]
+        assert st[2] == pytest.approx(ref[2], rel=1e-12, abs=1e-12) and st[3] == pytest.approx(ref[3], rel=1e-12)
+    # nothing valid: n = 0, NaN median
+    st = G.frame_clipped_stats_enqueue(ctx, torch.zeros(16, 16, device=ctx.device), None, 1).cpu().numpy()
+    assert st[0] == 0 and np.isnan(st[1])
+    ctx.close()
