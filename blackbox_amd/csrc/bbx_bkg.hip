@@ -311,6 +311,77 @@ __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const doubl
     }
 }
 
+// ---- B-spline prefilter of the mini image: scipy.ndimage.spline_filter(np.pad(block, npad, 'edge'), order = 3, mode = 'nearest') ----
+// What scipy's C does per line (ni_splines.c: apply_filter, _init_causal_reflect, _init_anticausal_reflect), operation by
+// operation in float64 and without fused multiply-adds, so that the coefficients are the same bits: gain, the in-place
+// causal start (its last term reads the c[0] it is accumulating into), the two recursions.  The pole is sqrt(3) - 2
+// correctly rounded, as gcc folds `sqrt(3.0) - 2.0` when it compiles scipy (the run-time double expression is 2 ulp off);
+// pow(z, len) comes from the host's libm, like scipy's.
+#define SPF_LINES 32
+#define SPF_MAXLEN 512
+__device__ __forceinline__ void spf_line(double* c, int n, int stride, double zn) {
+    const double z = -0.2679491924311227064725536584941276330571947461896;
+    const double gain = 1.0 * ((1.0 - 1.0 / z) * (1.0 - z));
+    for (int i = 0; i < n; i++) c[i * stride] *= gain;
+    if (n < 2) return;
+    const double c0 = c[0];
+    double acc = c[(n - 1) * stride] * zn + c0, zi = z;
+    c[0] = acc;
+    for (int i = 1; i < n; i++) {
+        acc += zi * (c[(n - 1 - i) * stride] * zn + c[i * stride]);
+        zi *= z;
+        c[0] = acc;
+    }
+    c[0] = acc * (z / (1.0 - zn * zn)) + c0;
+    for (int i = 1; i < n; i++) c[i * stride] += z * c[(i - 1) * stride];
+    c[(n - 1) * stride] *= z / (z - 1.0);
+    for (int i = n - 2; i >= 0; i--) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+}
+// axis 0: strips of SPF_LINES columns of one padded block, read from the mini image with the edge padding
+__global__ __launch_bounds__(256) void k_spf_axis0(const float* __restrict__ mini, int nbx, int cy, int cx, int npad, int nblkx, double zn,
+                                                    double* __restrict__ coef, int cnx) {
+    extern __shared__ double sp[];                    // [py][SPF_LINES + 1]
+    const int py = cy + 2 * npad, px = cx + 2 * npad;
+    const int nstrip = (px + SPF_LINES - 1) / SPF_LINES;
+    const int blk = blockIdx.x / nstrip, j0 = (blockIdx.x - blk * nstrip) * SPF_LINES;
+    const int by = blk / nblkx, bx = blk - by * nblkx;
+    const int W = SPF_LINES + 1;
+    for (int e = threadIdx.x; e < py * SPF_LINES; e += blockDim.x) {
+        const int i = e / SPF_LINES, jj = e - i * SPF_LINES, j = j0 + jj;
+        if (j < px) {
+            const int my = by * cy + min(max(i - npad, 0), cy - 1), mx = bx * cx + min(max(j - npad, 0), cx - 1);
+            sp[i * W + jj] = (double)mini[(size_t)my * nbx + mx];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SPF_LINES && j0 + (int)threadIdx.x < px) spf_line(sp + threadIdx.x, py, W, zn);
+    __syncthreads();
+    for (int e = threadIdx.x; e < py * SPF_LINES; e += blockDim.x) {
+        const int i = e / SPF_LINES, jj = e - i * SPF_LINES, j = j0 + jj;
+        if (j < px) coef[(size_t)(by * py + i) * cnx + bx * px + j] = sp[i * W + jj];
+    }
+}
+// axis 1: strips of SPF_LINES rows, in place
+__global__ __launch_bounds__(256) void k_spf_axis1(int cy, int cx, int npad, int nblkx, double zn, double* __restrict__ coef, int cnx) {
+    extern __shared__ double sp[];                    // [SPF_LINES][px + 1]
+    const int py = cy + 2 * npad, px = cx + 2 * npad;
+    const int nstrip = (py + SPF_LINES - 1) / SPF_LINES;
+    const int blk = blockIdx.x / nstrip, i0 = (blockIdx.x - blk * nstrip) * SPF_LINES;
+    const int by = blk / nblkx, bx = blk - by * nblkx;
+    const int W = px + 1;
+    for (int e = threadIdx.x; e < SPF_LINES * px; e += blockDim.x) {
+        const int ii = e / px, j = e - ii * px;
+        if (i0 + ii < py) sp[ii * W + j] = coef[(size_t)(by * py + i0 + ii) * cnx + bx * px + j];
+    }
+    __syncthreads();
+    if (threadIdx.x < SPF_LINES && i0 + (int)threadIdx.x < py) spf_line(sp + threadIdx.x * W, px, 1, zn);
+    __syncthreads();
+    for (int e = threadIdx.x; e < SPF_LINES * px; e += blockDim.x) {
+        const int ii = e / px, j = e - ii * px;
+        if (i0 + ii < py) coef[(size_t)(by * py + i0 + ii) * cnx + bx * px + j] = sp[ii * W + j];
+    }
+}
+
 extern "C" {
 
 int bbx_bkg_boxstats(bbx_ctx* ctx, int ny, int nx, int box, const float* d_data, const uint8_t* d_mask,
@@ -352,6 +423,26 @@ int bbx_spline_zoom_sub(bbx_ctx* ctx, int ny, int nx, const double* d_coef, int 
         return BBX_ERR_ARG;
     hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
                        d_fy, d_wy, d_fx, d_wx, d_out, (float*)nullptr, d_in);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_spline_prefilter(bbx_ctx* ctx, int nby, int nbx, int cy, int cx, int npad, double zn_y, double zn_x, const float* d_mini,
+                         double* d_coef, void* stream) {
+    if (!ctx || !d_mini || !d_coef || nby < 1 || nbx < 1 || cy < 1 || cx < 1 || npad < 0 || nby % cy || nbx % cx) return BBX_ERR_ARG;
+    const int py = cy + 2 * npad, px = cx + 2 * npad;
+    if (py > SPF_MAXLEN || px > SPF_MAXLEN) return BBX_ERR_ARG;
+    const int nblky = nby / cy, nblkx = nbx / cx, cnx = nblkx * px;
+    const size_t l0 = (size_t)py * (SPF_LINES + 1) * sizeof(double), l1 = (size_t)SPF_LINES * (px + 1) * sizeof(double);
+    if (ctx->spf_attr_bytes < (int)(l0 > l1 ? l0 : l1)) {
+        BBX_HIP(hipFuncSetAttribute((const void*)k_spf_axis0, hipFuncAttributeMaxDynamicSharedMemorySize, SPF_MAXLEN * (SPF_LINES + 1) * 8));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_spf_axis1, hipFuncAttributeMaxDynamicSharedMemorySize, SPF_LINES * (SPF_MAXLEN + 1) * 8));
+        ctx->spf_attr_bytes = SPF_MAXLEN * (SPF_LINES + 1) * 8;
+    }
+    hipLaunchKernelGGL(k_spf_axis0, dim3(nblky * nblkx * ((px + SPF_LINES - 1) / SPF_LINES)), dim3(256), l0, (hipStream_t)stream, d_mini, nbx, cy, cx,
+                       npad, nblkx, zn_y, d_coef, cnx);
+    hipLaunchKernelGGL(k_spf_axis1, dim3(nblky * nblkx * ((py + SPF_LINES - 1) / SPF_LINES)), dim3(256), l1, (hipStream_t)stream, cy, cx, npad, nblkx,
+                       zn_x, d_coef, cnx);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

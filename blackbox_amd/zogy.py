@@ -107,31 +107,54 @@ def _device_taps(ctx, nby, nbx, box, cy, cx):
     return cache[key]
 
 
+SPLINE_POLE = -0.2679491924311227          # sqrt(3) - 2 correctly rounded: the constant gcc folds into scipy's ni_splines.c
+
+
+def device_zoom_coefficients(ctx, mini, channels=None):
+    """zoom_coefficients on the device (bbx_spline_prefilter: scipy's prefilter operation by operation, same bits):
+    mini = float32 device tensor [nby, nbx] -> float64 device tensor of the padded coefficient patches"""
+    import math
+    nby, nbx = mini.shape
+    cy, cx = (nby, nbx) if channels is None else channels
+    py, px = cy + 2 * NPAD, cx + 2 * NPAD
+    coef = torch.empty(((nby // cy) * py, (nbx // cx) * px), dtype=torch.float64, device=mini.device)
+    check(lib.bbx_spline_prefilter(ctx.h, nby, nbx, cy, cx, NPAD, math.pow(SPLINE_POLE, py), math.pow(SPLINE_POLE, px), _p(mini), _p(coef),
+                                   ctx.stream()), 'bbx_spline_prefilter', ctx.h)
+    return coef
+
+
 def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_from=None, want_bkg=True, subtract_into=None):
     """zogy.mini2back(data_mini, data_shape, order_interp=3, bkg_boxsize, interp_Xchan): full-
     frame background from the mini image; with subtract_from the same pass does `data -= bkg`
-    (in place, or into the tensor subtract_into with subtract_from left as it is)."""
+    (in place, or into the tensor subtract_into with subtract_from left as it is).  A float32 mini image (device tensor
+    or numpy) never leaves the device: the B-spline prefilter runs there too (no host round trip in the frame's path);
+    a float64 numpy mini image takes scipy's prefilter on the host."""
     box = bkg_boxsize or settings.bkg_boxsize
-    mini_h = mini.cpu().numpy() if torch.is_tensor(mini) else np.asarray(mini)
+    dev = ctx.device
+    nby, nbx = mini.shape
     channels = None
     if not interp_Xchan:
-        if mini_h.shape[0] % settings.ny or mini_h.shape[1] % settings.nx:
+        if nby % settings.ny or nbx % settings.nx:
             raise ValueError('interp_Xchan=False needs a whole number of boxes per channel: mini image {}x{} over {}x{} channels'
-                             .format(mini_h.shape[0], mini_h.shape[1], settings.ny, settings.nx))
-        channels = (mini_h.shape[0] // settings.ny, mini_h.shape[1] // settings.nx)
-    nby, nbx = mini_h.shape
+                             .format(nby, nbx, settings.ny, settings.nx))
+        channels = (nby // settings.ny, nbx // settings.nx)
     cy, cx = (nby, nbx) if channels is None else channels
-    coef = zoom_coefficients(mini_h, channels)
+    if not torch.is_tensor(mini) and np.asarray(mini).dtype != np.float32:
+        d_coef = torch.from_numpy(zoom_coefficients(np.asarray(mini), channels)).to(dev)
+    else:
+        d_mini = mini if torch.is_tensor(mini) else torch.from_numpy(np.ascontiguousarray(mini)).to(dev)
+        if d_mini.dtype != torch.float32 or not d_mini.is_contiguous():
+            d_mini = d_mini.to(torch.float32).contiguous()
+        d_coef = device_zoom_coefficients(ctx, d_mini, channels)
+    cshape = tuple(d_coef.shape)
     d_fy, d_wy, d_fx, d_wx = _device_taps(ctx, nby, nbx, box, cy, cx)
-    dev = ctx.device
-    d_coef = torch.from_numpy(coef).to(dev)
     ny, nx = shape
     if subtract_into is not None:
-        check(lib.bbx_spline_zoom_sub(ctx.h, ny, nx, _p(d_coef), coef.shape[0], coef.shape[1], _p(d_fy), _p(d_wy), _p(d_fx),
+        check(lib.bbx_spline_zoom_sub(ctx.h, ny, nx, _p(d_coef), cshape[0], cshape[1], _p(d_fy), _p(d_wy), _p(d_fx),
                                       _p(d_wx), _p(subtract_from), _p(subtract_into), ctx.stream()), 'bbx_spline_zoom_sub', ctx.h)
         return None
     bkg = torch.empty((ny, nx), dtype=torch.float32, device=dev) if want_bkg else None
-    check(lib.bbx_spline_zoom(ctx.h, ny, nx, _p(d_coef), coef.shape[0], coef.shape[1], _p(d_fy), _p(d_wy), _p(d_fx),
+    check(lib.bbx_spline_zoom(ctx.h, ny, nx, _p(d_coef), cshape[0], cshape[1], _p(d_fy), _p(d_wy), _p(d_fx),
                               _p(d_wx), _p(subtract_from), _p(bkg), ctx.stream()), 'bbx_spline_zoom', ctx.h)
     return bkg
 

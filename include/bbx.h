@@ -437,11 +437,19 @@ int bbx_canny_edge_map(bbx_ctx *ctx, int ny, int nx, const float *d_img, const d
  * bbx_spline_zoom: evaluates scipy.ndimage.zoom(order=3, mode='nearest') from prefiltered
  *   B-spline coefficients d_coef[cny][cnx] (float64) with per-output-row / -column tap
  *   bases d_fy/d_fx (floor index into coef) and weights d_wy/d_wx ([n][4] float64);
- *   writes the background to d_bkg (if non-NULL) and subtracts it from d_data (if non-NULL). */
+ *   writes the background to d_bkg (if non-NULL) and subtracts it from d_data (if non-NULL).
+ * bbx_spline_prefilter: the coefficients themselves, on the device: the mini image d_mini[nby][nbx] (float32) cut into
+ *   blocks of cy x cx boxes (cy = nby, cx = nbx: one block; the channel blocks for interp_Xchan = False), every block
+ *   padded by [npad] edge samples (scipy.ndimage.zoom pads 'nearest' inputs by 12) and run through
+ *   scipy.ndimage.spline_filter(order = 3, mode = 'nearest') -> d_coef[(nby/cy)(cy+2 npad)][(nbx/cx)(cx+2 npad)] float64,
+ *   bit for bit scipy's values (gcc builds).  zn_y = pow(z, cy + 2 npad), zn_x = pow(z, cx + 2 npad) with
+ *   z = sqrt(3) - 2 correctly rounded (-0.2679491924311227), computed by the caller's libm.               */
 int bbx_bkg_boxstats(bbx_ctx *ctx, int ny, int nx, int box, const float *d_data,
                      const uint8_t *d_mask, const uint8_t *d_objmask, float limfrac,
                      float *d_mini_med, float *d_mini_std, void *stream);
 int bbx_mini_fill_filter(bbx_ctx *ctx, int nby, int nbx, float *d_mini, void *stream);
+int bbx_spline_prefilter(bbx_ctx *ctx, int nby, int nbx, int cy, int cx, int npad, double zn_y, double zn_x,
+                         const float *d_mini, double *d_coef, void *stream);
 int bbx_spline_zoom(bbx_ctx *ctx, int ny, int nx, const double *d_coef, int cny, int cnx,
                     const int32_t *d_fy, const double *d_wy, const int32_t *d_fx,
                     const double *d_wx, float *d_data, float *d_bkg, void *stream);
