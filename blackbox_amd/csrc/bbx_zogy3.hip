@@ -509,12 +509,14 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             const float2 pn = park[k], pr = s[l * P::LS + npos(p)];
             const float pn2 = pn.x * pn.x + pn.y * pn.y, pr2 = pr.x * pr.x + pr.y * pr.y;
             const float den = (sn2 * fr2) * pr2 + (sr2 * fn2) * pn2;
-            const float isd = 1.0f / sqrtf(den);
+            // one division per entry: 1 / den as the square of 1 / sqrt(den) (a float32 division is ~10 instructions,
+            // four of them were a fifth of this kernel's arithmetic)
+            const float isd = 1.0f / sqrtf(den), rden = isd * isd;
             a = cscale(pr, z.fr * isd);                                   // D^ = A N^ - B R^
             b = cscale(pn, z.fn * isd);
-            kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 / den);
-            kn = cscale(make_float2(pn.x, -pn.y), z.fn * fr2 * pr2 / den);
-            fs += wgt * (double)(fn2 * pn2 * fr2 * pr2 / den);
+            kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 * rden);
+            kn = cscale(make_float2(pn.x, -pn.y), z.fn * fr2 * pr2 * rden);
+            fs += wgt * (double)(fn2 * pn2 * fr2 * pr2 * rden);
             sk2n += wgt * (double)(kn.x * kn.x + kn.y * kn.y);
             sk2r += wgt * (double)(kr.x * kr.x + kr.y * kr.y);
         }
@@ -960,9 +962,17 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
             const float vs = vsr[l][k];
             const size_t q = (size_t)Y * o.nx + Xf;
             if (o.S) o.S[q] = sval;
+#ifndef Z3_EXACT_SQRT
+            // v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded division and square roots (~30 instructions per
+            // pixel: 8 % of this kernel); the transforms in front are good to ~1e-6 of the image scale
+            o.Scorr[q] = sval * __builtin_amdgcn_rsqf(vs + vast);
+            o.Fpsf[q] = sval * ifs;
+            o.Fpsferr[q] = __builtin_amdgcn_sqrtf(fmaxf(vs, 0.f)) * ifs;
+#else
             o.Scorr[q] = sval / sqrtf(vs + vast);
             o.Fpsf[q] = sval * ifs;
             o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) * ifs;
+#endif
         }
     }
 }
