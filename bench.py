@@ -565,18 +565,19 @@ def main():
         spec = nsub * HP * L * 8                              # one half spectrum of all sub-images, bytes
         cut = 4 * nsub * L * L                                # one frame read as overlapping sub-images, bytes
         rows_once = not (calls[10] and calls[11]) or calls[10] < 2 * calls[11]
+        wfrac = min(1.0, (4 * S + 32) / float(L))             # row window of the matched-filter kernels
         kern = {
             'k_calibrate': (0, b_raw * N + 4 * N + N + 4 * N + N),
             'k_lac_cand': (1, 4 * N),
             # the kernels of bbx_zogy_frame, half-spectrum arrays of [spec] bytes:
             'k_final_rows': (7, 4 * spec + 4 * 4 * N),          # reads D^, V_S^, S_n^, S_r^ (column-transformed), writes D, Scorr, Fpsf, Fpsferr
-            'k_psf_cols': (8, 6 * spec),                        # writes A, B, k_n^, k_r^ and the two column-inverted k^
-            'k_psf_rows': (9, 4 * spec),
+            'k_psf_cols': (8, int((2.5 + 2 * wfrac) * spec)),   # writes A, B, sqrt(den) (float) and the window rows of the two column-inverted k^
+            'k_psf_rows': (9, int(4 * wfrac * spec)),           # the window rows of k_r, k_n in, their squares' row pass out
             # one launch for both pairs (4 frame cuts read, 4 half spectra written); frames whose rows are not 16-byte aligned
             # take two launches (2 + 4 cuts read, 2 spectra written each: the average below)
             'k_img_rows': (10, int(4 * spec + 4 * cut) if rows_once else int(2 * spec + 3 * cut)),
-            'k_img_cols': (11, 9 * spec),
-            'k_var_cols': (12, 5 * spec),
+            'k_img_cols': (11, int(7.5 * spec)),                # N^, R^, A, B, sqrt(den) in; D^, S_n^, S_r^ out
+            'k_var_cols': (12, int((3 + 2 * wfrac) * spec)),    # V_n^, V_r^ and the window rows of (k^2)^ in, V_S^ out
         }
         zogy_kernels = ('k_psf_cols', 'k_psf_rows', 'k_img_rows', 'k_img_cols', 'k_var_cols', 'k_final_rows')
         zogy_io_model = int(4 * 4 * nsub * L * L + 4 * 4 * N)     # 4 inputs read with the tile overlap, 4 outputs written

@@ -442,8 +442,8 @@ template <class P> __device__ __forceinline__ void e2lp(int e, int& l, int& p) {
 template <class P>
 __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
                                                          const zscal* __restrict__ sc, const float2* __restrict__ twg,
-                                                         float2* __restrict__ cA, float2* __restrict__ cB, float2* __restrict__ cKn,
-                                                         float2* __restrict__ cKr, float2* __restrict__ Ukn, float2* __restrict__ Ukr,
+                                                         float2* __restrict__ cA, float2* __restrict__ cB, float* __restrict__ cSd,
+                                                         float2* __restrict__ Ukn, float2* __restrict__ Ukr,
                                                          double* __restrict__ fs_partial, int nsub, int wh) {
     extern __shared__ float2 s[];
     __shared__ double red[5][P::THREADS / 64];
@@ -504,6 +504,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
     R_LOOP(k, e, l, p) {
         const int kx = g * P::NL + l;
         float2 a = make_float2(0.f, 0.f), b = a, kn = a, kr = a;
+        float sdv = 0.f;
         if (kx < P::H) {
             const double wgt = (kx == 0 || (P::L % 2 == 0 && kx == P::L / 2)) ? 1.0 : 2.0;
             const float2 pn = park[k], pr = s[l * P::LS + npos(p)];
@@ -511,7 +512,8 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             const float den = (sn2 * fr2) * pr2 + (sr2 * fn2) * pn2;
             // one division per entry: 1 / den as the square of 1 / sqrt(den) (a float32 division is ~10 instructions,
             // four of them were a fifth of this kernel's arithmetic)
-            const float isd = 1.0f / sqrtf(den), rden = isd * isd;
+            const float sd = sqrtf(den), isd = 1.0f / sd, rden = isd * isd;
+            sdv = sd;
             a = cscale(pr, z.fr * isd);                                   // D^ = A N^ - B R^
             b = cscale(pn, z.fn * isd);
             kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 * rden);
@@ -520,7 +522,9 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             sk2n += wgt * (double)(kn.x * kn.x + kn.y * kn.y);
             sk2r += wgt * (double)(kr.x * kr.x + kr.y * kr.y);
         }
-        cA[cbase + e] = a; cB[cbase + e] = b; cKn[cbase + e] = kn; cKr[cbase + e] = kr;
+        // k_n^ = conj(B) |A|^2 sqrt(den), k_r^ = conj(A) |B|^2 sqrt(den): k_img_cols gets A, B and sqrt(den) (20 bytes
+        // per entry, read once) instead of four complex arrays (32 bytes, read in two loops)
+        cA[cbase + e] = a; cB[cbase + e] = b; cSd[cbase + e] = sdv;
         s[l * P::LS + npos(p)] = kr;
         park[k] = kn;
     }
@@ -749,8 +753,7 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
 // column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U tiles)
 template <class P>
 __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* __restrict__ TN, const float2* __restrict__ TR, const float2* __restrict__ cA,
-                                                         const float2* __restrict__ cB, const float2* __restrict__ cKn,
-                                                         const float2* __restrict__ cKr, const float2* __restrict__ twg,
+                                                         const float2* __restrict__ cB, const float* __restrict__ cSd, const float2* __restrict__ twg,
                                                          float2* __restrict__ UD, float2* __restrict__ USn, float2* __restrict__ USr,
                                                          float2* __restrict__ HSn, float2* __restrict__ HSr, int nsub) {
     extern __shared__ float2 s[];
@@ -766,36 +769,34 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     __syncthreads();
     fft_fwd<P>(s, tw);
     constexpr int RT = P::THREADS, NE = (P::NL * P::L + RT - 1) / RT;
-    float2 park[NE];                                               // the partial D^ = A N^ waits in registers
-    R_LOOP(k, e, l, p) {
-        float2* q = s + l * P::LS + npos(p);
-        const float2 x = *q;
-        park[k] = cmul(cA[cbase + e], x);
-        *q = cmul(cKn[cbase + e], x);
-    }
-    __syncthreads();
-    fft_inv<P>(s, tw);
-    store_u<P>(s, USn, sub, g, HSn);
+    // N^ waits in registers for R^; then one loop makes D^, S_n^ (both parked) and S_r^ (into the lines) from A, B, sqrt(den)
+    float2 park[NE], parkd[NE];
+    R_LOOP(k, e, l, p) park[k] = s[l * P::LS + npos(p)];
     __syncthreads();
 #ifndef Z3_NO_PREFETCH
     pack_t_lines<P, P::THREADS>(rr, s);
-#else
-    load_t_lines<P>(TR, sub, g, s);
-#endif
     __syncthreads();
     fft_fwd<P>(s, tw);
     R_LOOP(k, e, l, p) {
         float2* q = s + l * P::LS + npos(p);
-        const float2 x = *q;
-        const float2 br = cmul(cB[cbase + e], x);
-        park[k] = make_float2(park[k].x - br.x, park[k].y - br.y);
-        *q = cmul(cKr[cbase + e], x);
+        const float2 r = *q, n = park[k], A = cA[cbase + e], B = cB[cbase + e];
+        const float sd = cSd[cbase + e];
+        const float qn = (A.x * A.x + A.y * A.y) * sd, qr = (B.x * B.x + B.y * B.y) * sd;
+        const float2 an = cmul(A, n), br = cmul(B, r);
+        parkd[k] = make_float2(an.x - br.x, an.y - br.y);
+        park[k] = cscale(cmulc(n, B), qn);                          // conj(B) n
+        *q = cscale(cmulc(r, A), qr);
     }
     __syncthreads();
     fft_inv<P>(s, tw);
     store_u<P>(s, USr, sub, g, HSr);
     __syncthreads();
     R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = park[k];
+    __syncthreads();
+    fft_inv<P>(s, tw);
+    store_u<P>(s, USn, sub, g, HSn);
+    __syncthreads();
+    R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = parkd[k];
     __syncthreads();
     fft_inv<P>(s, tw);
     store_u<P>(s, UD, sub, g);
@@ -985,17 +986,18 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     const int nsy = ny / size, nsx = nx / size, nsub = nsy * nsx;
     int rc;
     const size_t unit = (size_t)nsub * P::UNIT, hunit = (size_t)nsub * P::LB * P::HP;
-    // 4 T + 4 U + 6 C arrays + 2 halo arrays + scalars + partial sums
-    const size_t bytes = (14 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 5 * (size_t)nsub * P::G * sizeof(double) + 4096;
+    // 4 T + 4 U + 4 C arrays + sqrt(den) (float: half an array, rounded up to one) + 2 halo arrays + scalars + partial sums
+    const size_t bytes = (13 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 5 * (size_t)nsub * P::G * sizeof(double) + 4096;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
-    float2* arr[14]; for (int i = 0; i < 14; i++) arr[i] = (float2*)ws + (size_t)i * unit;
-    float2 *HSn = (float2*)ws + 14 * unit, *HSr = HSn + hunit;
-    char* p = ws + (14 * unit + 2 * hunit) * sizeof(float2);
+    float2* arr[13]; for (int i = 0; i < 13; i++) arr[i] = (float2*)ws + (size_t)i * unit;
+    float2 *HSn = (float2*)ws + 13 * unit, *HSr = HSn + hunit;
+    char* p = ws + (13 * unit + 2 * hunit) * sizeof(float2);
     zscal* d_sc = (zscal*)p; p += (size_t)nsub * sizeof(zscal);
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     double* fs_partial = (double*)p;
     float2 *T0 = arr[0], *T1 = arr[1], *T2 = arr[2], *T3 = arr[3], *U0 = arr[4], *U1 = arr[5], *U2 = arr[6], *U3 = arr[7];
-    float2 *cA = arr[8], *cB = arr[9], *cKn = arr[10], *cKr = arr[11], *cK2n = arr[12], *cK2r = arr[13];
+    float2 *cA = arr[8], *cB = arr[9], *cK2n = arr[11], *cK2r = arr[12];
+    float* cSd = (float*)arr[10];
     BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
 #ifndef Z3_LDS_PAD
 #define Z3_LDS_PAD 0           // experiments: extra dynamic LDS per workgroup (forces one workgroup per CU)
@@ -1027,7 +1029,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     }
     const bool win = 2 * wh < P::L;
     const int wb = win ? wh / P::NL : 0, nyb_psf = win ? 2 * wb : P::LB;
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cKn, cKr, U0, U1, fs_partial, nsub,
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cSd, U0, U1, fs_partial, nsub,
                      wh);
     float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_ROWS, k_psf_rows<P>, grid8(nyb_psf, nsub), dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub,
@@ -1045,7 +1047,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
         fa.sa = d_sig_new; fa.sb = d_sig_ref;
         BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
     }
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cKn, cKr, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cSd, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub, wh, ctx->d_err);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;

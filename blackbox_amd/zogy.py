@@ -200,7 +200,12 @@ def frame_path_supported(L):
     return bool(lib.bbx_zogy_frame_supported(int(L))) and not os.environ.get('BBX_ZOGY_ROCFFT')
 
 
-def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, border, want_S=False):
+def zogy_frame_outputs(new, want_S=False):
+    """the frames bbx_zogy_frame fills: D, S (or None), Scorr, Fpsf, Fpsferr"""
+    return [torch.empty_like(new) if (k != 1 or want_S) else None for k in range(5)]
+
+
+def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, border, want_S=False, outs=None):
     """ZOGY of whole frames (bbx_zogy_frame): background-subtracted frames + sigma images + PSF
     stamps [nsub, S, S] -> D, S (or None), Scorr, Fpsf, Fpsferr full frames"""
     ny, nx = new.shape
@@ -208,7 +213,7 @@ def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, bo
     scal = np.ascontiguousarray(scal, dtype=np.float32)
     assert scal.shape == (nsub, 6) and psf_n.shape[0] == nsub and psf_r.shape[0] == nsub
     S = int(psf_n.shape[1])
-    outs = [torch.empty_like(new) if (k != 1 or want_S) else None for k in range(5)]
+    outs = outs or zogy_frame_outputs(new, want_S)
     check(lib.bbx_zogy_frame(ctx.h, ny, nx, int(size), int(border), _p(new), _p(ref), _p(sig_new), _p(sig_ref),
                              _p(psf_n.contiguous()), _p(psf_r.contiguous()), S, scal.ctypes.data_as(C.POINTER(C.c_float)),
                              *[_p(o) for o in outs], ctx.stream()), 'bbx_zogy_frame', ctx.h)
@@ -397,23 +402,38 @@ def frame_clipped_stats(ctx, img, mask=None, step=8):
 class StreamGate:
     """Lets one stream at a time run a section on the GPU: a section starts when the previous one (of any
     stream) has finished.  bbx_zogy_frame's kernels each fill the whole GPU; two lanes running them side
-    by side only slice each other's time."""
+    by side only slice each other's time.  With priority=True the sections run on ONE high-priority stream of the
+    gate's own (in order: that is the gate), between a wait for the caller's stream and a wait of the caller's stream:
+    the short kernels of the other lanes then take the CUs a section leaves free instead of an equal share of all of
+    them.  Tensors a section is to fill must be allocated before it (they belong to the caller's stream)."""
 
-    def __init__(self):
+    def __init__(self, device=None, priority=False):
         import threading
         self.lock = threading.Lock()
         self.last = None
+        self.hp = torch.cuda.Stream(device=device, priority=-1) if priority else None
+        self._cm = self._cur = None
 
     def __enter__(self):
         self.lock.acquire()
-        if self.last is not None:
-            torch.cuda.current_stream().wait_event(self.last)
+        cur = torch.cuda.current_stream()
+        if self.hp is not None:
+            self.hp.wait_stream(cur)
+            self._cur, self._cm = cur, torch.cuda.stream(self.hp)
+            self._cm.__enter__()
+        elif self.last is not None:
+            cur.wait_event(self.last)
         return self
 
     def __exit__(self, *exc):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.last = ev
+        if self.hp is not None:
+            self._cm.__exit__(*exc)
+            self._cur.wait_stream(self.hp)
+            self._cm = self._cur = None
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.last = ev
         self.lock.release()
         return False
 
@@ -548,8 +568,10 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
     if frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]:
         # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
+        outs = zogy_frame_outputs(work)                           # allocated on the caller's stream, filled inside the gate
+        sub_pn, sub_pr = sub_pn.contiguous(), sub_pr.contiguous()
         with (zogy_gate or _NoGate()):
-            D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border)
+            D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border, outs=outs)
         res['D'], res['Scorr'], res['Fpsf'], res['Fpsferr'] = D, Scorr, Fpsf, Fpsferr
     else:
         Vn = Vn if Vn is not None else variance(ctx, work, bstd)
