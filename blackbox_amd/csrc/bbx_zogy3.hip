@@ -775,6 +775,9 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     __syncthreads();
 #ifndef Z3_NO_PREFETCH
     pack_t_lines<P, P::THREADS>(rr, s);
+#else
+    load_t_lines<P>(TR, sub, g, s);
+#endif
     __syncthreads();
     fft_fwd<P>(s, tw);
     R_LOOP(k, e, l, p) {
