@@ -51,7 +51,8 @@ def main():
         out['kernels'][k] = rec
         # the names bench.py uses: kernels of bbx_zogy_frame without namespace / plan, the calibration kernels without variant
         short = re.sub(r'<.*', '', k).split('::')[-1]
-        short = {'k_calibrate_v4': 'k_calibrate', 'k_lac_cand_v4': 'k_lac_cand'}.get(short, short)
+        short = {'k_calibrate_v4': 'k_calibrate', 'k_lac_cand_v4': 'k_lac_cand', 'k_img_rows_both': 'k_img_rows',
+                 'k_spline_zoom4': 'k_spline_zoom'}.get(short, short)
         if short != k and short not in out['kernels']:
             out['kernels'][short] = dict(rec, alias_of=k)
     json.dump(out, sys.stdout, indent=1)
