@@ -65,6 +65,7 @@ struct bbx_ctx {
     void*  zogy2_state;        // twiddle table of bbx_zogy_frame (bbx_zogy3.hip)
     int    zogy_kwin_off;      // BBX_OPT_ZOGY_KWIN_OFF: full-size transforms of the matched-filter kernels (no row window)
     int    sat_attr_set;       // dynamic-LDS attribute of k_trail_segment set through this context
+    int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context
     int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
     int    num_cus;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)

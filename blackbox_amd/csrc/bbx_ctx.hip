@@ -174,6 +174,7 @@ int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (option == BBX_OPT_ZOGY_CORE) return BBX_OK;               // (one transform core since round 3: accepted, no effect)
     if (option == BBX_OPT_DEBUG_LISTCAP) { ctx->debug_listcap = value > 0 ? value : 0; return BBX_OK; }
     if (option == BBX_OPT_ZOGY_KWIN_OFF) { ctx->zogy_kwin_off = value ? 1 : 0; return BBX_OK; }
+    if (option == BBX_OPT_FPACK_ONE_WG) { ctx->fpack_one_wg = value ? 1 : 0; return BBX_OK; }
     return BBX_ERR_ARG;
 }
 

@@ -82,15 +82,24 @@ __device__ __forceinline__ unsigned rice_diff(const int* vals, int i) {
 
 // FLOAT_IN: src = float32 rows, quantised first; else src = integer rows of BYTEPIX bytes.
 // dynamic LDS: int vals[nxpad] | unsigned words[maxwords] | unsigned blkbits[nblk+1] | uint8 fsv[nblk] (+ float mode scratch)
-template <int BYTEPIX, bool FLOAT_IN>
-__global__ __launch_bounds__(FP_THREADS) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
+// MODE 0: the bit stream buffer holds the worst case (every pixel at full width): ~100 KB of LDS for a 10560-pixel float row,
+//         one workgroup per CU.
+// MODE 1: a buffer of [capwords] words (the host gives half the worst case: 16 bits per pixel of a float row; real frames
+//         take 7-8) -- ~66 KB, TWO workgroups per CU, whose barrier-separated phases then overlap; a row whose stream does
+//         not fit is marked FP_FLAG_RETRY.
+// MODE 2: only the rows marked FP_FLAG_RETRY, with the worst-case buffer (same bytes as MODE 0 would have made).
+#define FP_FLAG_RETRY 3u
+template <int BYTEPIX, bool FLOAT_IN, int MODE>
+__global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
                                                  float qlevel, int dither_seed, const float* __restrict__ rnd,
-                                                 uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles) {
+                                                 uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles,
+                                                 int capwords) {
     typedef rice_par<BYTEPIX> RP;
     extern __shared__ __align__(16) unsigned char lds[];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (MODE == 2 && tiles[row].flag != FP_FLAG_RETRY) return;
     const int nblk = (nx + 31) / 32;
-    const int maxwords = (8 * BYTEPIX + nblk * RP::fsbits + nx * RP::bbits + 31) / 32 + 2;
+    const int maxwords = MODE == 1 ? capwords : (8 * BYTEPIX + nblk * RP::fsbits + nx * RP::bbits + 31) / 32 + 2;
     int* vals = reinterpret_cast<int*>(lds);
     unsigned* words = reinterpret_cast<unsigned*>(vals + ((nx + 3) & ~3));
     unsigned* blkbits = words + maxwords;
@@ -249,6 +258,10 @@ __global__ __launch_bounds__(FP_THREADS) void k_fp_tile(const void* __restrict__
         if (tid == FP_THREADS - 1) blkbits[nblk] = excl + mine;   // total bits (threads beyond nblk hold zeros)
     }
     __syncthreads();
+    if (MODE == 1 && blkbits[nblk] + 64u > 32u * (unsigned)maxwords) {     // the stream does not fit the short buffer
+        if (tid == 0) { out->flag = FP_FLAG_RETRY; out->nbytes = 0; }
+        return;
+    }
     // ---- pass 2: write the codes
     if (tid == 0) {
         unsigned first = (unsigned)vals[0];
@@ -317,15 +330,27 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
     const int nblk = (nx + 31) / 32;
     const int fsbits = bytepix == 1 ? 3 : (bytepix == 2 ? 4 : 5);
     const size_t maxwords = (8 * (size_t)bytepix + (size_t)nblk * fsbits + (size_t)nx * 8 * bytepix + 31) / 32 + 2;
-    const size_t ldsbytes = (size_t)((nx + 3) & ~3) * 4 + maxwords * 4 + ((size_t)nblk + 1) * 4 + (size_t)nblk + 16;
+    const size_t fixed = (size_t)((nx + 3) & ~3) * 4 + ((size_t)nblk + 1) * 4 + (size_t)nblk + 16;
+    const size_t ldsbytes = fixed + maxwords * 4;
     if (ldsbytes > 150 * 1024) return BBX_ERR_ARG;
+    // first try with half the worst-case stream buffer (two workgroups per CU), then the rows that did not fit
+    const size_t capwords = maxwords / 2 + 16, ldshalf = fixed + capwords * 4;
+    const bool two = ldshalf + 4096 <= 80 * 1024 && !ctx->fpack_one_wg;
     fp_tile* tiles = (fp_tile*)d_tiles;
 #define FP_LAUNCH(BP, FL)                                                                                              \
     do {                                                                                                               \
-        BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                    (int)ldsbytes));                                                                   \
-        hipLaunchKernelGGL((k_fp_tile<BP, FL>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel,    \
-                           dither_seed, d_rnd, d_scratch, stride, tiles);                                              \
+        if (two) {                                                                                                     \
+            BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldshalf)); \
+            BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
+            hipLaunchKernelGGL((k_fp_tile<BP, FL, 1>), dim3(ny), dim3(FP_THREADS), ldshalf, s, d_img, ny, nx, (size_t)nx, qlevel, \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords);                           \
+            hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, 0);                                       \
+        } else {                                                                                                       \
+            BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
+            hipLaunchKernelGGL((k_fp_tile<BP, FL, 0>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, 0);                                       \
+        }                                                                                                              \
     } while (0)
     if (bitpix == -32) FP_LAUNCH(4, true);
     else if (bitpix == 8) FP_LAUNCH(1, false);

@@ -97,6 +97,10 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * window is summed on the device and must stay below 1e-6 (stamp-truncation ringing sits at 1e-9), else the call's step is flagged (device error bit 4).
  * 1: all L rows (the textbook evaluation; same results to float32 rounding). */
 #define BBX_OPT_ZOGY_KWIN_OFF 4
+/* BBX_OPT_FPACK_ONE_WG (default 0): bbx_fpack_tiles / bbx_fpack_body compress a row with a bit-stream buffer of half the
+ * worst case first (two workgroups per CU) and redo the rows that do not fit with the full buffer; 1: full buffer for
+ * every row (one workgroup per CU).  Same bytes either way. */
+#define BBX_OPT_FPACK_ONE_WG 5
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
 
 /* Per-step attribution of device-side errors.  Kernels report list overflow / non-convergence by

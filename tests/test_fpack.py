@@ -239,3 +239,45 @@ def test_gpu_one_enqueue_path_and_output_stage(tmp_path):
             assert got == open(str(tmp_path / ('one_a_%s.fits.fz' % name)), 'rb').read(), (k, name)
     assert stage.files_written == 6
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_short_stream_buffer_and_retry_equal_full_buffer():
+    """k_fp_tile with the half-size bit-stream buffer (two workgroups per CU) + the retry of the rows that do not fit
+    (BBX_OPT_FPACK_ONE_WG = 0, the default) against the worst-case buffer for every row (= 1): the same bytes, for float
+    rows that compress, float rows that need more than 16 bits per pixel, integer rows of both kinds; and against the
+    oracle's encoder"""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R, _lib
+    from blackbox_amd import fpack as P
+    ctx = R.Context(0)
+    rs = np.random.RandomState(12)
+    nx = 10560
+    img = (300 + rs.normal(0, 9, (24, nx))).astype(np.float32)
+    # rows whose pixel-to-pixel differences are huge against the noise estimate (a median): > 16 bits per pixel
+    jump = rs.rand(24, nx) < 0.2
+    img[8:16][jump[8:16]] += (rs.uniform(-1, 1, int(jump[8:16].sum())) * 3e6).astype(np.float32)
+    raw = rs.randint(0, 65535, (10, 12000)).astype(np.uint16)
+    raw[5:] = (1500 + rs.normal(0, 9, (5, 12000))).astype(np.uint16)
+    msk = (rs.rand(8, nx) < 0.03).astype(np.uint8) * 32
+    got = {}
+    for one in (0, 1):
+        _lib.check(_lib.lib.bbx_set_option(ctx.h, 5, one), 'bbx_set_option')
+        got[one] = [P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), 16, 5),
+                    P.compress_tiles(ctx, torch.from_numpy((raw.astype(np.int32) - 32768).astype(np.int16)).to(ctx.device)),
+                    P.compress_tiles(ctx, torch.from_numpy(msk).to(ctx.device))]
+    _lib.check(_lib.lib.bbx_set_option(ctx.h, 5, 0), 'bbx_set_option')
+    for a, b in zip(got[0], got[1]):
+        for k in ('nbytes', 'offsets', 'flag'):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a['heap'], b['heap'])
+        if 'zscale' in a and a['zscale'] is not None:
+            assert np.array_equal(a['zscale'], b['zscale']) and np.array_equal(a['zzero'], b['zzero'])
+    t = got[0][0]
+    assert (t['nbytes'][8:16] > nx * 2).all() and (t['nbytes'][:8] < nx * 1.5).all()       # the retried rows are the long ones
+    for r, (b, zs, zz) in enumerate(FP.compress_float_image(img, 16, 5)):
+        assert t['zscale'][r] == zs and t['zzero'][r] == zz, r
+        assert t['heap'][t['offsets'][r]:t['offsets'][r] + t['nbytes'][r]].tobytes() == b, r
+    ctx.close()
