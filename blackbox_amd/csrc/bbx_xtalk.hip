@@ -5,10 +5,10 @@
 // the channel grid: it reads the 16 source values that couple to each other -- the
 // 8 lower-row channels at row y and the 8 upper-row channels at the mirrored row
 // ysize-1-y -- keeps them in float64 registers, and then takes the 16 victims in turn:
-// the victim's 16 coefficients arrive by scalar loads, its own value is read again
-// (L2) and the corrected value written back in place.  From HBM every pixel is read
-// once and written once: 4N + N (mask) + 4N bytes (16 float64 FMAs per output pixel
-// are far below the vector rate, so no MFMA reshaping).
+// the victim's 16 coefficients arrive by scalar loads, its own value comes from the registers
+// and the corrected value written back in place.  Every pixel is read once and written
+// once: 4N + N (mask) + 4N bytes (16 float64 FMAs per output pixel are far below the
+// vector rate, so no MFMA reshaping).
 #include "bbx_common.h"
 #include <stdlib.h>
 
@@ -32,8 +32,11 @@ template <int VEC> __device__ __forceinline__ void xtalk_fetch(const float* data
 // The loop over the victims is a real loop: the 16 coefficients of a victim are fetched by scalar
 // loads from the kernel-argument segment when its turn comes.  (Unrolled, the 256 coefficients
 // are loop invariants that the compiler keeps in 512 SGPRs it does not have: it spilled them to
-// VGPR lanes and the kernel spent its time in v_readlane, 0.72 ms per frame.)  The victim's own
-// value and mask byte are read again (L2 hits) rather than kept in registers for the same reason.
+// VGPR lanes and the kernel spent its time in v_readlane, 0.72 ms per frame.)
+// Round 3: the 16 values stay in registers as the float32 they were read as, with two bit sets (usable as a source /
+// edge pixel as a victim); the float64 source terms are converted when a victim needs them.  Until then the kernel kept
+// 16 float64 sources and read every victim's value and mask byte a second time -- from L2 in theory, but the PMC
+// traffic was 1.54 GB for 1.0 GB of algorithmic bytes.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __restrict__ mask, bbx_dims d, f64x256 cf) {
     const int ngx = d.xsz / VEC;
@@ -41,41 +44,40 @@ __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __res
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(t / ngx), x = (int)(t - (size_t)y * ngx) * VEC;
         const size_t off_lo = (size_t)y * d.nx + x, off_hi = (size_t)(d.ysz + (d.ysz - 1 - y)) * d.nx + x;
-        double src[16][VEC];
+        float val[16][VEC];
+        unsigned use[VEC], edge[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; q++) use[q] = edge[q] = 0u;
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const size_t off = ((c >> 3) ? off_hi : off_lo) + (size_t)(c & 7) * d.xsz;
-            float v[VEC]; uint8_t m[VEC];
-            xtalk_fetch<VEC>(data, mask, off, v, m);
+            uint8_t m[VEC];
+            xtalk_fetch<VEC>(data, mask, off, val[c], m);
 #pragma unroll
             for (int q = 0; q < VEC; q++) {
-                // mask_source: positive, not bad, not cosmic (7178-7180)
-                const bool use = (v[q] > 0.f) && !(m[q] & BBX_MASK_BAD) && !(m[q] & BBX_MASK_COSMIC);
-                src[c][q] = use ? (double)v[q] : 0.0;
+                // mask_source: positive, not bad, not cosmic (7178-7180); mask_victim: not edge (7184)
+                if ((val[c][q] > 0.f) && !(m[q] & BBX_MASK_BAD) && !(m[q] & BBX_MASK_COSMIC)) use[q] |= 1u << c;
+                if (m[q] & BBX_MASK_EDGE) edge[q] |= 1u << c;
             }
         }
-        // the victim's value and mask byte are fetched one turn ahead
-        float nval[VEC]; uint8_t nm[VEC];
-        xtalk_fetch<VEC>(data, mask, off_lo, nval, nm);
 #pragma unroll 1
         for (int v = 0; v < 16; v++) {
             const size_t off = ((v >> 3) ? off_hi : off_lo) + (size_t)(v & 7) * d.xsz;
-            float val[VEC]; uint8_t m[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC; q++) { val[q] = nval[q]; m[q] = nm[q]; }
-            if (v < 15) xtalk_fetch<VEC>(data, mask, (((v + 1) >> 3) ? off_hi : off_lo) + (size_t)((v + 1) & 7) * d.xsz, nval, nm);
             const double* cv = &cf.v[v * 16];
             float o[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; q++) {
                 double q_lo = 0.0, q_hi = 0.0;                 // the two K=8 quadrant products
 #pragma unroll
-                for (int s = 0; s < 8; s++) q_lo = fma(src[s][q], cv[s], q_lo);
+                for (int s = 0; s < 8; s++) q_lo = fma(((use[q] >> s) & 1u) ? (double)val[s][q] : 0.0, cv[s], q_lo);
 #pragma unroll
-                for (int s = 8; s < 16; s++) q_hi = fma(src[s][q], cv[s], q_hi);
+                for (int s = 8; s < 16; s++) q_hi = fma(((use[q] >> s) & 1u) ? (double)val[s][q] : 0.0, cv[s], q_hi);
                 const double corr = (0.0 + q_lo) + q_hi;
-                // mask_victim: not edge (7184)
-                o[q] = (float)((double)val[q] - (!(m[q] & BBX_MASK_EDGE) ? corr : corr * 0.0));
+                // the victim's own value: register v of the 16 (a run-time index: picked by a chain of selects)
+                float own = val[0][q];
+#pragma unroll
+                for (int c = 1; c < 16; c++) own = (v == c) ? val[c][q] : own;
+                o[q] = (float)((double)own - (!((edge[q] >> v) & 1u) ? corr : corr * 0.0));
             }
             if (VEC == 4) *(float4*)(data + off) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
             else if (VEC == 2) *(float2*)(data + off) = make_float2(o[0], o[VEC - 1]);
