@@ -118,8 +118,8 @@ template <class P> __device__ __forceinline__ int ppos(int k) {
 // the 85 that two workgroups of 768 threads leave: it spills and is 15 % slower.)  The
 // butterfly's R positions are base + r M: with the padding they stay an affine function of r when M
 // is a multiple of 8, or when M = 1 and the block starts at a multiple of 8 (constant offsets).
-template <class P, int R, int B, bool INV, int NLINES>
-__device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ tw) {
+template <class P, int R, int B, bool INV, int NLINES, int ZP = 0>
+__device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ tw, int zw = 0) {
     constexpr int M = B / R, PER = P::L / R, NTASK = NLINES * PER, TWS = P::L / B;
     constexpr bool AFF8 = M % 8 == 0, AFF1 = M == 1 && (8 % R == 0 || R % 8 == 0);
     // Lanes -> butterflies.  SPREAD (M a multiple of 8, groups of 4 lines): 8 consecutive lanes take 8 consecutive
@@ -136,6 +136,10 @@ __device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ t
             l = lg * 4 + ((t >> 3) & 3); j = ((t >> 5) << 3) | (t & 7);
         } else { l = task / PER; j = task - l * PER; }
         const int b = j / M, m = j - b * M;
+        // lines that are zero outside their first and last [zw] entries (PSF stamps, windowed kernels): a butterfly of the
+        // first pass (ZP 1) or the second (ZP 2) whose inputs all lie in the zero stretch leaves its zeros as they are
+        if (ZP == 1 && zw > 0 && m >= zw && m < M - zw) continue;
+        if (ZP == 2 && zw > 0 && m >= zw && m + (R - 1) * M < B - zw) continue;
         const int base = b * B + m;
         v2f_a* line = reinterpret_cast<v2f_a*>(s + l * P::LS + ((AFF8 || AFF1) ? npos(base) : 0));
         const v2f_a* twv = reinterpret_cast<const v2f_a*>(tw);
@@ -172,12 +176,16 @@ __device__ __forceinline__ void fft_step(float2* s, const float2* __restrict__ t
     }
 }
 // forward: natural order -> spectrum at ppos; inverse: back (unnormalised).  Barriers after every pass.
-template <class P, int NLINES = P::NL> __device__ __forceinline__ void fft_fwd(float2* s, const float2* tw) {
+// (zw > 0: the lines are exactly zero outside their first and last zw entries)
+template <class P, int NLINES = P::NL> __device__ __forceinline__ void fft_fwd(float2* s, const float2* tw, int zw = 0) {
 #ifdef Z3_SKIP_FFT
     __syncthreads(); return;
 #endif
-    fft_step<P, P::R0, P::L, false, NLINES>(s, tw); __syncthreads();
-    fft_step<P, P::R1, P::L / P::R0, false, NLINES>(s, tw); __syncthreads();
+#ifdef Z3_NO_ZSKIP
+    zw = 0;
+#endif
+    fft_step<P, P::R0, P::L, false, NLINES, 1>(s, tw, zw); __syncthreads();
+    fft_step<P, P::R1, P::L / P::R0, false, NLINES, 2>(s, tw, zw); __syncthreads();
     if constexpr (P::R2 > 1) { fft_step<P, P::R2, P::L / (P::R0 * P::R1), false, NLINES>(s, tw); __syncthreads(); }
     if constexpr (P::R3 > 1) { fft_step<P, P::R3, P::L / (P::R0 * P::R1 * P::R2), false, NLINES>(s, tw); __syncthreads(); }
 }
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             s[ll * P::LS + npos(y)] = acc;
         }
         __syncthreads();
-        fft_fwd<P>(s, tw);
+        fft_fwd<P>(s, tw, S - h);                                      // the stamp's rows: [0, S - h) and [L - h, L)
         if (pass == 0) {
             R_LOOP(k, e, l, p) park[k] = s[l * P::LS + npos(p)];      // Pn^ waits in registers while Pr^ is transformed
             __syncthreads();
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(P::VAR_THREADS, P::VAR_MINW) void k_var_cols(const 
     const bool win = 2 * wh < P::L;
     if (win) load_t_lines_win<P>(Tk2n, sub, g, s, wh); else load_t_lines<P>(Tk2n, sub, g, s);
     __syncthreads();
-    fft_fwd<P>(s, tw);
+    fft_fwd<P>(s, tw, win ? wh : 0);
     R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kn^2)^
     __syncthreads();
     load_t_lines<P>(TVn, sub, g, s);
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(P::VAR_THREADS, P::VAR_MINW) void k_var_cols(const 
     __syncthreads();
     if (win) load_t_lines_win<P>(Tk2r, sub, g, s, wh); else load_t_lines<P>(Tk2r, sub, g, s);
     __syncthreads();
-    fft_fwd<P>(s, tw);
+    fft_fwd<P>(s, tw, win ? wh : 0);
     R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kr^2)^
     __syncthreads();
     load_t_lines<P>(TVr, sub, g, s);
