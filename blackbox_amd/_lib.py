@@ -30,6 +30,13 @@ class Geom(C.Structure):
 if not os.path.isfile(LIB_PATH):
     raise ImportError('{} not found: build it with `make` (hipcc, gfx950); the '
                       'reduction has no CPU fallback'.format(LIB_PATH))
+# PyTorch (device memory, streams) ships its own copy of the HIP runtime.  It has to be the first one in the process: loaded
+# after this library -- which names libamdhip64 of /opt/rocm -- it ends up sharing a runtime of another release and no
+# device is found ("no ROCm-capable device is detected" from bbx_ctx_create).  So: torch first, whenever it is there.
+try:
+    import torch  # noqa: F401
+except ImportError:      # the C ABI can be used without it (include/bbx.h); the host layer of this package cannot
+    pass
 lib = C.CDLL(LIB_PATH)
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
