@@ -670,6 +670,14 @@ def main():
                    single_frame_latency_ms=latency_ms, stage_ms_serial=stage_ms, lacosmic_stats=stats, subtraction=sub_info,
                    roofline=roof)
     # ---- the other workloads, briefly, and the I/O-inclusive figures (not part of `value`) ---------
+    t_sec = [time.perf_counter()]
+
+    def section(name):
+        """progress on stderr: the extras below take most of the run's wall time"""
+        now = time.perf_counter()
+        sys.stderr.write('[bench] %s: %.1f s\n' % (name, now - t_sec[0]))
+        sys.stderr.flush()
+        t_sec[0] = now
     if world == 1 and not args.no_extras:
         others = {}
         for w2 in ('calib', 'full'):
@@ -678,6 +686,7 @@ def main():
             l2, d2 = (8, 24) if w2 == 'calib' else (6, 18)
             r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 4, d2, l2, pool, barrier)
             others[w2] = dict(frames_per_s=60 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 60, frames_in_flight=d2, lanes=l2)
+            section('workload ' + w2)
         if wl == 'zogy':
             # the same workload against a reference that still carries a sky of its own: its background mesh and
             # sigma image are then made per frame as well (bkg mesh x2)
@@ -687,11 +696,14 @@ def main():
             others['zogy_ref_with_sky'] = dict(frames_per_s=30 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 30, frames_in_flight=depth,
                                                lanes=lanes, note='reference not background-subtracted: bkg mesh x2 per frame')
             del ref2
+            section('zogy_ref_with_sky')
         out['other_workloads'] = others
         # the same steady-state measurement over a long run (the headline's K frames are few)
         r3 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 240, 4, depth, lanes, pool, barrier)
         out['long_run'] = dict(frames=240, frames_per_s=240 / r3['dt'], ms_per_frame=1e3 * r3['dt'] / 240)
+        section('long_run')
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
+        section('io_inclusive (pcie, serial writers)')
         # ---- measured: the same pipeline with the output stage in the loop (SURVEY 8d timing item iii) ------------
         meas = {}
         import shutil
@@ -709,6 +721,7 @@ def main():
                 meas[label] = dict(error=repr(e))
             finally:
                 shutil.rmtree(td, ignore_errors=True)
+            section('io_inclusive.measured ' + label)
         meas['note'] = ('the timed pipeline with every product of a frame on disk before the frame counts: _red, _mask, _D, _Scorr, '
                         '_Fpsf, _trans_limmag tile-compressed on the lane that made them (bbx_fpack_body, q = 16 / lossless / 16 / 2 / '
                         '4 / 2) and written as .fits.fz by writer threads; _bkg_mini, _bkg_std_mini, _cat, _trans, _hdr by the '
@@ -718,6 +731,7 @@ def main():
     if rank == 0:
         if not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(wl)
+            section('cpu_baseline')
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
