@@ -42,6 +42,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
+NSL = 13                                                         # BBX_PROF_NSLOTS (launch slots of bbx_profile_read)
+
+
 def moffat_stamp(S, fwhm, beta=2.5):
     """unit-sum Moffat PSF stamp [S, S] (float32), centre at S // 2"""
     a = fwhm / (2 * np.sqrt(2 ** (1 / beta) - 1))
@@ -277,12 +280,12 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
             n = mark['n']
             if n == first:
                 mark['t0'] = time.perf_counter()
-                if prof_ctx is not None:
-                    _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 1), 'bbx_profile_enable')
+                for h in mark.get('prof_h', ()):
+                    _lib.check(_lib.lib.bbx_profile_enable(h, 1), 'bbx_profile_enable')
             elif n == first + steps:
                 mark['t1'] = time.perf_counter()
-                if prof_ctx is not None:
-                    _lib.check(_lib.lib.bbx_profile_enable(prof_ctx.h, 2), 'bbx_profile_enable')      # pause, keep the records
+                for h in mark.get('prof_h', ()):
+                    _lib.check(_lib.lib.bbx_profile_enable(h, 2), 'bbx_profile_enable')      # pause, keep the records
             mark['last'] = f
             if n == n_all:
                 all_done.set()
@@ -324,6 +327,8 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
             count(f)
         extra = dict(outstage=stage, out_base=lambda idx, h: os.path.join(outdir, 'ML1_f%06d_red' % idx), on_written=on_written)
     pipe = FramePipeline(ctx, tel, geom, pool=pool, depth=depth, lanes=lanes, **dict(kw, **extra))
+    if prof_ctx is not None:
+        mark['prof_h'] = [lc.h for lc in pipe.lane_ctx]        # the launches of every lane are timed (prof_ctx = lane 0's context)
     # untimed: first-use allocations, rocFFT plans, workspace growth of every lane
     save = (mark['n'], first)
     first = 10 ** 9                             # (the warm-up frames of the pipeline do not count)
@@ -356,6 +361,17 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
                host_ms_per_frame=dict(lane_threads_cpu=1e3 * pipe.lane_cpu[0] / max(1, pipe.lane_cpu[2]),
                                       lane_threads_wall=1e3 * pipe.lane_cpu[1] / max(1, pipe.lane_cpu[2]),
                                       orchestrator_cpu=1e3 * (time.thread_time() - t_cpu_main) / n_all))
+    if prof_ctx is not None:
+        # per-launch-slot totals over the timed region, all lanes
+        import ctypes as C
+        ms_sum, n_sum = [0.0] * NSL, [0] * NSL
+        for h in mark['prof_h']:
+            ms, nc = (C.c_double * NSL)(), (C.c_int32 * NSL)()
+            _lib.check(_lib.lib.bbx_profile_read(h, ms, nc, NSL), 'bbx_profile_read', h)
+            _lib.check(_lib.lib.bbx_profile_enable(h, 0), 'bbx_profile_enable')
+            for k in range(NSL):
+                ms_sum[k] += ms[k]; n_sum[k] += nc[k]
+        out['prof'] = (ms_sum, n_sum)
     pipe.close()
     if stage is not None:
         stage.close()
@@ -522,7 +538,6 @@ def main():
     nser = 3
     for _ in range(nser):
         frame_serial(wl == 'zogy')
-    NSL = 13                                                     # BBX_PROF_NSLOTS
     iso_ms = (C.c_double * NSL)()
     iso_calls = (C.c_int32 * NSL)()
     _lib.check(_lib.lib.bbx_profile_read(ctx.h, iso_ms, iso_calls, NSL), 'bbx_profile_read', ctx.h)
@@ -545,11 +560,7 @@ def main():
     # ---- timed region ----------------------------------------------------------------------------
     r = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], args.steps, args.warmup, depth, lanes, pool, barrier, prof_ctx=ctx)
     dt, dt_all = r['dt'], r['dt_all']
-    nsl = NSL
-    ms_tot = (C.c_double * nsl)()
-    calls = (C.c_int32 * nsl)()
-    _lib.check(_lib.lib.bbx_profile_read(ctx.h, ms_tot, calls, nsl), 'bbx_profile_read', ctx.h)
-    _lib.check(_lib.lib.bbx_profile_enable(ctx.h, 0), 'bbx_profile_enable')
+    ms_tot, calls = r['prof']
     if world > 1:
         t = torch.tensor([dt, dt_all], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -637,7 +648,7 @@ def main():
         roof['frac'] = roof['achieved'] / roof['peak']
         roof['traffic_source'] = pmc_note
         roof['timing'] = ('HIP events stamped by the launch itself (hipExtLaunchKernelGGL start / stop events: the kernel\'s execution) '
-                          'on the launch stream, over the timed region, lane 0 of %d (other lanes\' kernels run concurrently)' % lanes)
+                          'on the launch streams, over the timed region, all %d lanes (kernels of different lanes run concurrently)' % lanes)
         roof['frame'] = dict(bytes=frame_bytes, achieved=frame_bytes / (dt / args.steps) / 1e9,
                              frac=frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                              note='SURVEY 8d algorithmic bytes of a whole frame of this workload (config 5: 11.45 GB with a u16 raw) / ms_per_step')
