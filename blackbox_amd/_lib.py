@@ -102,6 +102,7 @@ SIGNATURES = {
     'bbx_stitch_subimages': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bbx_zogy_subimages': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_zogy_frame_supported': (_i, [_i]),
+    'bbx_zogy_candidates': (_i, [_vp, _f]),
     'bbx_zogy_frame': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux_sigma': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -65,6 +65,9 @@ struct bbx_ctx {
     void*  zogy2_state;        // twiddle table of bbx_zogy_frame (bbx_zogy3.hip)
     int    zogy_kwin_off;      // BBX_OPT_ZOGY_KWIN_OFF: full-size transforms of the matched-filter kernels (no row window)
     int    sat_attr_set;       // dynamic-LDS attribute of k_trail_segment set through this context
+    float  zcand_thr;          // bbx_zogy_candidates: > 0: bbx_zogy_frame lists the pixels with |Scorr| >= thr (WS_ZCAND, CNT_ZCAND)
+    const float* zcand_img;    // the Scorr frame the list in WS_ZCAND belongs to (NULL: none); consumed by bbx_find_peaks
+    float  zcand_thr_used; size_t zcand_npix;
     int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context
     int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
@@ -104,13 +107,14 @@ enum {
     CNT_CANDOVF = 160,    // LA-Cosmic candidates that did not fit their tile segment
     CNT_CANDRAW = 176,    // LA-Cosmic candidates before the s > sigclip pre-filter
     CNT_TICKET = 192,     // workgroups of the current kernel that have finished (last one does the epilogue)
+    CNT_ZCAND = 208,      // bbx_zogy_frame: pixels with |Scorr| >= the candidate threshold (bbx_zogy_candidates)
     CNT_MAX = 256
 };
 
 // workspace slots
 enum {
     WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
-    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND,
     WS_MAX
 };
 

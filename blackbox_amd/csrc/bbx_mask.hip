@@ -803,9 +803,17 @@ extern "C" int bbx_find_peaks(bbx_ctx* ctx, int ny, int nx, const float* d_img, 
     uint32_t* list = (uint32_t*)bbx_ws(ctx, WS_CCLIST, cap * sizeof(uint32_t), &rc); if (rc) return rc;
     unsigned long long* best = (unsigned long long*)bbx_ws(ctx, WS_STAGE2, cap * sizeof(unsigned long long), &rc); if (rc) return rc;
     int32_t* cnt = &ctx->d_counters[CNT_CC_N];
-    BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
     BBX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_compact_abs, dim3(2048), dim3(256), 0, s, d_img, npix, thr, list, cnt, (uint32_t)cap, ctx->d_err);
+    if (ctx->zcand_img == d_img && ctx->zcand_thr_used == thr && ctx->zcand_npix == npix && ctx->d_ws[WS_ZCAND]) {
+        // the frame is the Scorr image of the last bbx_zogy_frame call, which listed these pixels as it wrote them
+        // (bbx_zogy_candidates): no pass over the frame
+        list = (uint32_t*)ctx->d_ws[WS_ZCAND];
+        cnt = &ctx->d_counters[CNT_ZCAND];
+        ctx->zcand_img = nullptr;
+    } else {
+        BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_compact_abs, dim3(2048), dim3(256), 0, s, d_img, npix, thr, list, cnt, (uint32_t)cap, ctx->d_err);
+    }
     // union-find over the list (the object count itself is not needed: reuse its scratch)
     rc = bbx_cc_count_list(ctx, list, cnt, cap, ny, nx, &ctx->d_counters[CNT_CC_ROOTS], s); if (rc) return rc;
     uint32_t* parent = (uint32_t*)ctx->d_ws[WS_PARENT];

@@ -881,7 +881,8 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
                                                            const float2* __restrict__ HSn, const float2* __restrict__ HSr,
                                                            const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
                                                            float inv_n2, const float2* __restrict__ twg, out_args o, int yb0, int nyb,
-                                                           int nsub) {
+                                                           int nsub, float cand_thr, uint32_t* __restrict__ cand_list,
+                                                           int32_t* __restrict__ cand_cnt, uint32_t cand_cap, int32_t* __restrict__ d_err) {
     extern __shared__ float2 s[];
     float2* hline = s + P::NL * P::LS;                              // the halo line
     __shared__ float s_fs, s_ibeta;
@@ -977,14 +978,32 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
 #ifndef Z3_EXACT_SQRT
             // v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded division and square roots (~30 instructions per
             // pixel: 8 % of this kernel); the transforms in front are good to ~1e-6 of the image scale
-            o.Scorr[q] = sval * __builtin_amdgcn_rsqf(vs + vast);
+            const float scv = sval * __builtin_amdgcn_rsqf(vs + vast);
+            o.Scorr[q] = scv;
             o.Fpsf[q] = sval * ifs;
             o.Fpsferr[q] = __builtin_amdgcn_sqrtf(fmaxf(vs, 0.f)) * ifs;
 #else
-            o.Scorr[q] = sval / sqrtf(vs + vast);
+            const float scv = sval / sqrtf(vs + vast);
+            o.Scorr[q] = scv;
             o.Fpsf[q] = sval * ifs;
             o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) * ifs;
 #endif
+            // transient candidates (bbx_zogy_candidates): the pixels bbx_find_peaks would collect in a pass of its own over
+            // the Scorr frame.  They are rare (a few thousand per frame): one reservation per wave that holds any.
+            if (cand_thr > 0.f) {
+                const bool hit = fabsf(scv) >= cand_thr;             // NaN compares false
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                if (hm) {
+                    const int leader = (int)__builtin_ctzll(hm);
+                    unsigned base = 0;
+                    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd((unsigned*)cand_cnt, (unsigned)__popcll(hm));
+                    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                    if (hit) {
+                        const unsigned k = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                        if (k < cand_cap) cand_list[k] = (uint32_t)q; else atomicOr(d_err, BBX_DERR_LIST_OVERFLOW);
+                    }
+                }
+            }
         }
     }
 }
@@ -1064,8 +1083,19 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
     const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
     const dim3 gfin = grid8(yb1 - yb0 + 1, nsub);
+    // transient candidates on request (bbx_zogy_candidates): listed by the kernel that writes Scorr
+    float cand_thr = 0.f; uint32_t* cand_list = nullptr; uint32_t cand_cap = 0;
+    int32_t* cand_cnt = &ctx->d_counters[CNT_ZCAND];
+    ctx->zcand_img = nullptr;
+    if (ctx->zcand_thr > 0.f && (size_t)ny * nx < 0xffffffffull) {
+        cand_cap = (uint32_t)((size_t)ny * nx / 16 + 1024);
+        cand_list = (uint32_t*)bbx_ws(ctx, WS_ZCAND, (size_t)cand_cap * sizeof(uint32_t), &rc); if (rc) return rc;
+        BBX_HIP(hipMemsetAsync(cand_cnt, 0, sizeof(int32_t), s));
+        cand_thr = ctx->zcand_thr;
+    }
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_ZOGY_FINAL, k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial,
-                     inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub);
+                     inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub, cand_thr, cand_list, cand_cnt, cand_cap, ctx->d_err);
+    if (cand_thr > 0.f) { ctx->zcand_img = d_Scorr; ctx->zcand_thr_used = cand_thr; ctx->zcand_npix = (size_t)ny * nx; }
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
@@ -1101,6 +1131,13 @@ void bbx_zogy2_release(bbx_ctx* ctx) {          // (name kept: bbx_ctx_destroy c
 }
 
 extern "C" int bbx_zogy_frame_supported(int L) { return bbx_zogy3_supported(L); }
+
+extern "C" int bbx_zogy_candidates(bbx_ctx* ctx, float thr) {
+    if (!ctx || !(thr >= 0.f)) return BBX_ERR_ARG;
+    ctx->zcand_thr = thr;
+    ctx->zcand_img = nullptr;
+    return BBX_OK;
+}
 
 extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
                               const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S,

@@ -570,6 +570,9 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
         # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
         outs = zogy_frame_outputs(work)                           # allocated on the caller's stream, filled inside the gate
         sub_pn, sub_pr = sub_pn.contiguous(), sub_pr.contiguous()
+        # the kernel that writes Scorr lists the pixels above the transient threshold for the peak search below
+        nsig_cand = float(settings.transient_nsigma if nsigma is None else nsigma)
+        check(lib.bbx_zogy_candidates(ctx.h, nsig_cand), 'bbx_zogy_candidates', ctx.h)
         with (zogy_gate or _NoGate()):
             D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border, outs=outs)
         res['D'], res['Scorr'], res['Fpsf'], res['Fpsferr'] = D, Scorr, Fpsf, Fpsferr

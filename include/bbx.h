@@ -501,6 +501,11 @@ int bbx_zogy_subimages(bbx_ctx *ctx, int L, int nsub, float *d_new, float *d_ref
  * S = S_n - S_r is formed in real space (identical in exact arithmetic to the inverse transform
  * of S^ that bbx_zogy_subimages takes). */
 int bbx_zogy_frame_supported(int L);
+/* bbx_zogy_candidates(ctx, thr): thr > 0: the following bbx_zogy_frame calls of this context also list the pixels with
+ * |Scorr| >= thr as they write them ([EXT] zogy's get_trans thresholds |Scorr| at transient_nsigma of its settings file,
+ * 6 in the deployment: Settings/set_qc.py:387); bbx_find_peaks on that very Scorr frame with the same threshold then starts from the list
+ * instead of a pass of its own over the frame (same regions, same peaks).  0 switches the listing off. */
+int bbx_zogy_candidates(bbx_ctx *ctx, float thr);
 int bbx_zogy_frame(bbx_ctx *ctx, int ny, int nx, int size, int border, const float *d_new,
                    const float *d_ref, const float *d_sig_new, const float *d_sig_ref,
                    const float *d_psf_n, const float *d_psf_r, int S, const float *h_scal,
