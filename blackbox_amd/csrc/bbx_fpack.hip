@@ -89,6 +89,7 @@ __device__ __forceinline__ unsigned rice_diff(const int* vals, int i) {
 //         not fit is marked FP_FLAG_RETRY.
 // MODE 2: only the rows marked FP_FLAG_RETRY, with the worst-case buffer (same bytes as MODE 0 would have made).
 #define FP_FLAG_RETRY 3u
+#define FP_NCOLL 128               // keys collected in the last select pass before it falls back to a histogram
 template <int BYTEPIX, bool FLOAT_IN, int MODE>
 __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
                                                  float qlevel, int dither_seed, const float* __restrict__ rnd,
@@ -104,7 +105,9 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
     unsigned* words = reinterpret_cast<unsigned*>(vals + ((nx + 3) & ~3));
     unsigned* blkbits = words + maxwords;
     uint8_t* fsv = reinterpret_cast<uint8_t*>(blkbits + nblk + 1);
-    __shared__ unsigned hist[3][256];
+    __shared__ unsigned hist[3][1024];                              // 2048 bins each: two 16-bit counters per word
+    __shared__ unsigned coll[3][FP_NCOLL], ncoll[3];
+    __shared__ int s_many;
     __shared__ unsigned sel_prefix[3], sel_rank[3];
     __shared__ float red_min[FP_THREADS / 64], red_max[FP_THREADS / 64];
     __shared__ double s_delta, s_zero;
@@ -122,43 +125,102 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
             if (!isfinite(v)) bad = 1;
             mn = fminf(mn, v); mx = fmaxf(mx, v);
         }
-        if (tid == 0) s_flag = 0;
+        if (tid == 0) { s_flag = 0; s_many = 0; }
         __syncthreads();
         if (bad) s_flag = 2;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
         if (lane == 0) { red_min[tid >> 6] = mn; red_max[tid >> 6] = mx; }
-        // lower medians of the 2nd / 3rd / 5th order differences: 4-pass radix select
+        // lower medians of the 2nd / 3rd / 5th order differences, exact: radix select in two histogram passes of 11 bits
+        // (2048 bins as pairs of 16-bit counters in one word: a row has fewer than 65536 pixels) and a third pass that just
+        // collects the handful of keys that share the 22 leading bits (a histogram pass over the last 10 bits only if they are
+        // many: rows with long runs of equal differences).  An LDS atomic costs its ~64 cycles per wave instruction whatever
+        // the addresses, and the histogram atomics were 1.0 of this kernel's 1.7 ms with four 8-bit passes.
         const int nd = nx - 8;
-        if (tid < 3) { sel_prefix[tid] = 0; sel_rank[tid] = nd > 0 ? (unsigned)((nd - 1) / 2) : 0u; }
+        if (tid < 3) { sel_prefix[tid] = 0; sel_rank[tid] = nd > 0 ? (unsigned)((nd - 1) / 2) : 0u; ncoll[tid] = 0; }
         __syncthreads();
         if (nd > 0) {
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                for (int i = tid; i < 3 * 256; i += FP_THREADS) (&hist[0][0])[i] = 0;
-                __syncthreads();
-                const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1], p2 = sel_prefix[2];
-                for (int i = tid; i < nd; i += FP_THREADS) {
-                    const float v1 = fv[i], v3 = fv[i + 2], v5 = fv[i + 4], v7 = fv[i + 6], v9 = fv[i + 8];
-                    const unsigned k2 = __float_as_uint(fabsf(v5 - v7));
-                    const unsigned k3 = __float_as_uint(fabsf((2.f * v5) - v3 - v7));
-                    const unsigned k5 = __float_as_uint(fabsf((6.f * v5) - (4.f * v3) - (4.f * v7) + v1 + v9));
-                    if (shift == 24 || (k2 >> (shift + 8)) == (p0 >> (shift + 8))) atomicAdd(&hist[0][(k2 >> shift) & 255u], 1u);
-                    if (shift == 24 || (k3 >> (shift + 8)) == (p1 >> (shift + 8))) atomicAdd(&hist[1][(k3 >> shift) & 255u], 1u);
-                    if (shift == 24 || (k5 >> (shift + 8)) == (p2 >> (shift + 8))) atomicAdd(&hist[2][(k5 >> shift) & 255u], 1u);
+#pragma unroll 1
+            for (int pass = 0; pass < 3; pass++) {
+                const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+                const unsigned dmask = pass == 2 ? 1023u : 2047u;
+                const bool collect = pass == 2 && !s_many;            // workgroup-uniform
+                if (!collect) {
+                    for (int i = tid; i < 3 * 1024; i += FP_THREADS) (&hist[0][0])[i] = 0;
+                    __syncthreads();
                 }
+                const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1], p2 = sel_prefix[2];
+                const int up = pass == 0 ? 31 : (pass == 1 ? 21 : 10);   // keys take part when they agree above this bit position
+#define FP_KEYS(i)                                                                                                      \
+                    const float v1 = fv[i], v3 = fv[i + 2], v5 = fv[i + 4], v7 = fv[i + 6], v9 = fv[i + 8];               \
+                    const unsigned k2 = __float_as_uint(fabsf(v5 - v7));                                                    \
+                    const unsigned k3 = __float_as_uint(fabsf((2.f * v5) - v3 - v7));                                        \
+                    const unsigned k5 = __float_as_uint(fabsf((6.f * v5) - (4.f * v3) - (4.f * v7) + v1 + v9));
+                if (collect) {
+                    for (int i = tid; i < nd; i += FP_THREADS) {
+                        FP_KEYS(i)
+                        if ((k2 >> 10) == (p0 >> 10)) { const unsigned j = atomicAdd(&ncoll[0], 1u); if (j < FP_NCOLL) coll[0][j] = k2; }
+                        if ((k3 >> 10) == (p1 >> 10)) { const unsigned j = atomicAdd(&ncoll[1], 1u); if (j < FP_NCOLL) coll[1][j] = k3; }
+                        if ((k5 >> 10) == (p2 >> 10)) { const unsigned j = atomicAdd(&ncoll[2], 1u); if (j < FP_NCOLL) coll[2][j] = k5; }
+                    }
+                } else if (pass == 0) {
+                    for (int i = tid; i < nd; i += FP_THREADS) {
+                        FP_KEYS(i)
+                        { const unsigned d = k2 >> 21; atomicAdd(&hist[0][d >> 1], 1u << ((d & 1u) * 16)); }
+                        { const unsigned d = k3 >> 21; atomicAdd(&hist[1][d >> 1], 1u << ((d & 1u) * 16)); }
+                        { const unsigned d = k5 >> 21; atomicAdd(&hist[2][d >> 1], 1u << ((d & 1u) * 16)); }
+                    }
+                } else {
+                    for (int i = tid; i < nd; i += FP_THREADS) {
+                        FP_KEYS(i)
+                        if ((k2 >> up) == (p0 >> up)) { const unsigned d = (k2 >> shift) & dmask; atomicAdd(&hist[0][d >> 1], 1u << ((d & 1u) * 16)); }
+                        if ((k3 >> up) == (p1 >> up)) { const unsigned d = (k3 >> shift) & dmask; atomicAdd(&hist[1][d >> 1], 1u << ((d & 1u) * 16)); }
+                        if ((k5 >> up) == (p2 >> up)) { const unsigned d = (k5 >> shift) & dmask; atomicAdd(&hist[2][d >> 1], 1u << ((d & 1u) * 16)); }
+                    }
+                }
+#undef FP_KEYS
                 __syncthreads();
-                if (tid < 192) {                                   // one wave per histogram, 4 bins per lane
+                if (collect) {
+                    if (ncoll[0] > FP_NCOLL || ncoll[1] > FP_NCOLL || ncoll[2] > FP_NCOLL) {
+                        // too many keys with these 22 leading bits: the histogram pass after all (workgroup-uniform)
+                        __syncthreads();
+                        if (tid == 0) s_many = 1;
+                        __syncthreads();
+                        pass = 1;                                     // (the loop's increment makes it pass 2 again)
+                        continue;
+                    }
+                    if (tid < 3) {                                    // a thread per key type: the rank-th smallest of <= FP_NCOLL keys
+                        const int n = (int)ncoll[tid];
+                        const unsigned r = sel_rank[tid];
+                        unsigned best = 0;
+#pragma unroll 1
+                        for (int a = 0; a < n; a++) {
+                            const unsigned ka = coll[tid][a];
+                            unsigned below = 0, equal = 0;
+#pragma unroll 1
+                            for (int c = 0; c < n; c++) { below += coll[tid][c] < ka; equal += coll[tid][c] == ka; }
+                            if (r >= below && r < below + equal) { best = ka; break; }
+                        }
+                        sel_prefix[tid] = best;
+                    }
+                } else if (tid < 192) {                               // one wave per histogram, 32 bins (16 words) per lane
                     const int k = tid >> 6;
-                    const unsigned c0 = hist[k][4 * lane], c1 = hist[k][4 * lane + 1], c2 = hist[k][4 * lane + 2],
-                                   c3 = hist[k][4 * lane + 3];
-                    const unsigned mine = c0 + c1 + c2 + c3;
+                    unsigned mine = 0;
+#pragma unroll 4
+                    for (int w = 0; w < 16; w++) { const unsigned c = hist[k][16 * lane + w]; mine += (c & 0xffffu) + (c >> 16); }
                     unsigned incl = mine;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
                     const unsigned excl = incl - mine, r = sel_rank[k];
                     if (r >= excl && r < incl) {                   // the one lane whose bins hold the rank
-                        unsigned rr = r - excl, b = 4 * lane;
-                        if (rr >= c0) { rr -= c0; b++; if (rr >= c1) { rr -= c1; b++; if (rr >= c2) { rr -= c2; b++; } } }
+                        unsigned rr = r - excl, b = 32 * lane;
+#pragma unroll 1
+                        for (int w = 0; w < 32; w++) {
+                            const unsigned c = hist[k][(32 * lane + w) >> 1];
+                            const unsigned cnt = (w & 1) ? (c >> 16) : (c & 0xffffu);
+                            if (rr < cnt) { b = 32 * lane + w; break; }
+                            rr -= cnt;
+                        }
                         sel_rank[k] = rr;
                         sel_prefix[k] |= b << shift;
                     }
@@ -335,7 +397,7 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
     if (ldsbytes > 150 * 1024) return BBX_ERR_ARG;
     // first try with half the worst-case stream buffer (two workgroups per CU), then the rows that did not fit
     const size_t capwords = maxwords / 2 + 16, ldshalf = fixed + capwords * 4;
-    const bool two = ldshalf + 4096 <= 80 * 1024 && !ctx->fpack_one_wg;
+    const bool two = ldshalf + 15 * 1024 <= 80 * 1024 && !ctx->fpack_one_wg;       // (+ the kernel's static LDS: histograms 12 KB, lists, sums)
     fp_tile* tiles = (fp_tile*)d_tiles;
 #define FP_LAUNCH(BP, FL)                                                                                              \
     do {                                                                                                               \
