@@ -612,7 +612,7 @@ def main():
         if wl == 'zogy':
             frame_bytes += int(zogy_io_model + 12000 * S * S * 12)                                # configs[4]
         if wl == 'zogy' and all(k in live for k in zogy_kernels) and all(k in iso for k in zogy_kernels):
-            # the dominant launch group of the headline workload: bbx_zogy_frame = 7 launches per frame (one library call).
+            # the dominant launch group of the headline workload: bbx_zogy_frame = 6 launches per frame (one library call).
             # achieved = SURVEY 8d algorithmic bytes of the stage (inputs once with the tile overlap + outputs once)
             # / the summed duration of its launches in the timed region (HIP events stamped by the launches themselves,
             # lane 0's stream)

@@ -10,7 +10,7 @@
 //   k_mini_fill_filter  NaN boxes <- nan-median of 3x3 neighbours (repeated), then a 3x3
 //                    median filter with replicated edges, on the 176x176 mini image.
 //   k_spline_zoom    scipy.ndimage.zoom(order=3, mode='nearest') evaluation: the cubic
-//                    B-spline coefficients (tiny, prefiltered on the host) are combined with
+//                    B-spline coefficients (tiny; k_spf_axis0/1 below: scipy's prefilter, same bits) are combined with
 //                    per-row / per-column tap weights in float64; optionally fused with the
 //                    subtraction from the frame (read 4N + write 4N).
 #include "bbx_common.h"

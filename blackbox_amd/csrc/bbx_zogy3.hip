@@ -5,9 +5,11 @@
 //
 //   1-D transform: L = R0 R1 [R2 [R3]] (1400 = 5 * 7 * 5 * 8); a step is L / R butterflies of radix R
 //              per line (decimation in frequency, in place: a butterfly reads and writes the same
-//              R positions), any thread takes any butterfly: ~64 VGPRs, 16 waves per CU, all data
+//              R positions), any thread takes any butterfly: 45-77 VGPRs, 24 waves per CU, all data
 //              movement is loops over the workgroup.  The spectrum is left in the digit-reversed
 //              order of the in-place algorithm (pos(k) below); the inverse runs the steps backwards.
+//              The butterflies (bbx_fft_gen.h, tools/gen_fft.py) work on (re, im) pairs: packed fp32
+//              instructions, the half-crossing operations spelled out with op_sel / neg modifiers.
 //
 #include "bbx_common.h"
 #ifndef Z3_NO_CONTRACT
