@@ -672,10 +672,24 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
 __global__ __launch_bounds__(256) void k_ccf_acc(const int32_t* __restrict__ cnt, int cap, uint32_t* parent, const uint8_t* __restrict__ flag,
                                                  uint32_t* size, uint32_t* has) {
     const int n = (*cnt > cap) ? cap : *cnt;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t root = cc_find(parent, (uint32_t)i);
-        atomicAdd(&size[root], 1u);
-        if (flag[i]) has[root] = 1u;
+    const int lane = threadIdx.x & 63;
+    const int nround = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+    for (int r = 0; r < nround; r++) {
+        const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        bool on = i < n;
+        uint32_t root = 0;
+        if (on) { root = cc_find(parent, (uint32_t)i); if (flag[i]) has[root] = 1u; }
+        // neighbours in the list mostly belong to the same component: one add per root and wave (an add per pixel on the
+        // few roots of long edges queues up at ~11 ns each: 117 us for the edges of a frame)
+        unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+        while (m) {
+            const int leader = (int)__builtin_ctzll(m);
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)root, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(on && root == r0);
+            if (lane == leader) atomicAdd(&size[r0], (unsigned)__popcll(same));
+            on = on && root != r0;
+            m &= ~same;
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_ccf_emit(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, int cap, uint32_t* parent,
