@@ -234,7 +234,10 @@ __global__ __launch_bounds__(1024) void k_mini_fill_filter(float* mini, float* t
 // One workgroup = 256 columns x ZOOM_ROWS rows: the column taps (index + 4 float64 weights per
 // pixel, 36 bytes) are read once per thread and reused down the rows -- with a workgroup per row
 // they came through the L2 again for every row, 4.5x the bytes of the image itself.
-#define ZOOM_ROWS 16
+#ifndef ZOOM_ROWS
+#define ZOOM_ROWS 32                // (16: 0.157 / 0.340 ms write-only / with the subtraction; 32: 0.144 / 0.316; 64: 0.148 / 0.299)
+#endif
+static_assert(ZOOM_ROWS * 32 <= 1024, "k_spline_zoom folds ZOOM_ROWS x 32 coefficients into rowc[2][512]");
 __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const double* __restrict__ coef, int cnx,
                                                      const int32_t* __restrict__ fy, const double* __restrict__ wy,
                                                      const int32_t* __restrict__ fx, const double* __restrict__ wx,
