@@ -235,6 +235,15 @@ def test_zogy_fullsize(scene, branch):
     print('ZOGY full size, max |HIP - oracle| (/ local noise, / tolerance):', worst)
     # Scorr of the unmasked frame ~ N(0, 1) (QC ranges set_qc.py:382-383)
     assert abs(hdr['Z-SCMED'][0]) < 0.3 and abs(hdr['Z-SCSTD'][0] - 1) < 0.15
+    # the header statistics themselves: astropy's sigma_clipped_stats (oracle restatement, pinned by tests/golden/sigclip.npz)
+    # of the lattice of every 8th pixel of the HIP frames, pixels with mask bits other than the cosmic-ray flag left out
+    import bbx_oracle as O
+    sel = (scene['mask'].cpu().numpy()[::8, ::8] & ~np.uint8(2)) == 0
+    for key_m, key_s, name in (('Z-SCMED', 'Z-SCSTD', 'Scorr'), ('Z-FPEMED', 'Z-FPESTD', 'Fpsferr')):
+        lat = res[name][::8, ::8].cpu().numpy()
+        _, med, std, n = O.sigma_clipped_stats_median(np.where(sel, lat, np.nan))
+        assert hdr[key_m][0] == float(med), name                                  # exact order statistic
+        assert hdr[key_s][0] == pytest.approx(float(std), rel=1e-10), name
     # injected transients: found within a pixel, flux within 3 sigma + 5 %
     found = {(t['y'], t['x']): t for t in res['transients']}
     mask_h = scene['mask'].cpu().numpy()
