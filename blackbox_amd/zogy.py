@@ -292,8 +292,8 @@ def find_transients(ctx, Scorr, nsigma=None, max_out=100000):
     return list(zip(ys.tolist(), xs.tolist(), val.tolist()))
 
 
-def find_peaks_arrays(ctx, Scorr, nsigma=None, max_out=100000):
-    """the same as arrays (y int32, x int32, peak float32), sorted by (y, x): no per-source Python work"""
+def find_peaks_enqueue(ctx, Scorr, nsigma=None, max_out=100000):
+    """queue bbx_find_peaks -> the device tensors find_peaks_collect reads (host work in between overlaps the search)"""
     nsigma = settings.transient_nsigma if nsigma is None else nsigma
     ny, nx = Scorr.shape
     dev = ctx.device
@@ -302,11 +302,22 @@ def find_peaks_arrays(ctx, Scorr, nsigma=None, max_out=100000):
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib.bbx_find_peaks(ctx.h, ny, nx, _p(Scorr), float(nsigma), max_out, _p(yx), _p(val), _p(cnt), ctx.stream()),
           'bbx_find_peaks', ctx.h)
+    return yx, val, cnt, max_out
+
+
+def find_peaks_collect(ctx, pending):
+    """-> arrays (y int32, x int32, peak float32), sorted by (y, x)"""
+    yx, val, cnt, max_out = pending
     ctx.sync()
     n = min(int(cnt.item()), max_out)
     yx, val = yx[:n].cpu().numpy(), val[:n].cpu().numpy()
     order = np.lexsort((yx[:, 1], yx[:, 0])) if n else np.zeros(0, int)
     return yx[order, 0], yx[order, 1], val[order]
+
+
+def find_peaks_arrays(ctx, Scorr, nsigma=None, max_out=100000):
+    """the same as arrays (y int32, x int32, peak float32), sorted by (y, x): no per-source Python work"""
+    return find_peaks_collect(ctx, find_peaks_enqueue(ctx, Scorr, nsigma, max_out))
 
 
 def embed_psfs(ctx, stamps, L):
@@ -489,9 +500,23 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     res['bkg_mini_new'], res['bkg_std_mini_new'] = mini.cpu().numpy(), sdn
     hdr['BKG-SIZE'] = (box, '[pix] background boxsize used')
     hdr['BKG-SUB'] = (False, 'sky background was subtracted?')          # the _red product keeps its sky
-    hdr['S-BKG'] = (float(np.median(res['bkg_mini_new'])), '[e-] median background full-frame image')
     hdr['S-BKGSTD'] = (float(np.median(sdn)), '[e-] sigma (STD) background full-frame image')
     res['data_bkgsub'], res['bkg_std'] = work, bstd
+    bs = size // box if size % box == 0 else None
+
+    def tile_medians(a):
+        """median of the mini image over the boxes of each sub-image (or over all of it)"""
+        if bs and a.shape == (nsy * bs, nsx * bs):
+            return np.median(a.reshape(nsy, bs, nsx, bs).transpose(0, 2, 1, 3).reshape(nsub, bs * bs), axis=1)
+        if bs:
+            return np.asarray([np.median(a[(k // nsx) * bs:(k // nsx + 1) * bs, (k % nsx) * bs:(k % nsx + 1) * bs]) for k in range(nsub)])
+        return np.full(nsub, np.median(a))
+    scal_n = None
+
+    def host_side_meanwhile():
+        """host work that needs nothing from the device: done while a search runs there"""
+        hdr['S-BKG'] = (float(np.median(res['bkg_mini_new'])), '[e-] median background full-frame image')
+        return tile_medians(sdn) if have_ref else None
 
     sub_pn = subimage_psfs(ctx, psf_new, nsy, nsx, size) if psf_new is not None else None
 
@@ -500,7 +525,9 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     res['catalog'] = None
     if cat_extract and sub_pn is not None:
         thr = float(cat_nsigma) * hdr['S-BKGSTD'][0]
-        ys, xs, pk = find_peaks_arrays(ctx, work, thr, max_out=max_sources)
+        pending = find_peaks_enqueue(ctx, work, thr, max_out=max_sources)
+        scal_n = host_side_meanwhile()
+        ys, xs, pk = find_peaks_collect(ctx, pending)
         keep = pk > 0
         ys, xs, pk = ys[keep], xs[keep], pk[keep]
         if ys.size:
@@ -518,6 +545,8 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
                               E_FLUX_PEAK=pk.astype(np.float32), E_FLUX_OPT=f, E_FLUXERR_OPT=e,
                               SNR_OPT=np.where(e > 0, f / np.where(e > 0, e, 1), 0).astype(np.float32))
         hdr['NOBJECTS'] = (len(peaks), 'number of objects detected')
+    if 'S-BKG' not in hdr:
+        scal_n = host_side_meanwhile()
     if not have_ref:
         hdr['Z-P'] = (False, 'successfully processed by ZOGY?')
         res['header'], res['header_new'], res['header_trans'], res['transients'] = _HeaderView(hdr, hdr_t), hdr, hdr_t, []
@@ -553,17 +582,8 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     hdr_t['S-BKGSTDR'] = (float(np.median(sdr)), '[e-] sigma (STD) background reference image')
 
     # ---- sub-images
-    bs = size // box if size % box == 0 else None
     scal = np.zeros((nsub, 6), np.float32)
-
-    def tile_medians(a):
-        """median of the mini image over the boxes of each sub-image (or over all of it)"""
-        if bs and a.shape == (nsy * bs, nsx * bs):
-            return np.median(a.reshape(nsy, bs, nsx, bs).transpose(0, 2, 1, 3).reshape(nsub, bs * bs), axis=1)
-        if bs:
-            return np.asarray([np.median(a[(k // nsx) * bs:(k // nsx + 1) * bs, (k % nsx) * bs:(k % nsx + 1) * bs]) for k in range(nsub)])
-        return np.full(nsub, np.median(a))
-    scal[:, 0], scal[:, 1] = tile_medians(sdn), tile_medians(sdr)
+    scal[:, 0], scal[:, 1] = scal_n, tile_medians(sdr)
     scal[:, 2], scal[:, 3], scal[:, 4], scal[:, 5] = 1.0, (1.0 / fratio if fratio else 1.0), dx, dy
     sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
     if frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]:
