@@ -94,6 +94,8 @@ SIGNATURES = {
     'bbx_bkg_boxstats': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'bbx_mini_fill_filter': (_i, [_vp, _i, _i, _vp, _vp]),
     'bbx_spline_prefilter': (_i, [_vp, _i, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _vp, _vp]),
+    'bbx_mini_median': (_i, [_vp, _i, _vp, _vp, _vp]),
+    'bbx_zoom_candidates': (_i, [_vp, _vp, C.c_double]),
     'bbx_spline_zoom': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_spline_zoom_sub': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bbx_variance': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp]),

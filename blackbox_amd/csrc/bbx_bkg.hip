@@ -231,12 +231,115 @@ __global__ __launch_bounds__(1024) void k_mini_fill_filter(float* mini, float* t
     (void)err;
 }
 
+// np.median of a float32 array (one workgroup): exact radix select of the middle element(s) on order-preserving keys,
+// an even count gives the float32 mean of the two (numpy: np.mean of the pair in float32); NaN when the array holds one.
+// The same for n <= 32768 (a 176 x 176 mini image): the keys stay in registers, 32 per thread, and the middle element is
+// found bit by bit -- ans = the largest value with count(keys < ans) <= rank -- with compare-and-count passes over the
+// registers (the histogram version below spends its time in LDS atomics: 169 us against 15).
+__device__ __forceinline__ unsigned mm_count_below(const unsigned (&k)[32], int nk, unsigned cand, int* sh) {
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < 32; r++) if (r < nk) c += k[r] < cand ? 1 : 0;
+    c = wave_sum_i32(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += sh[w];
+    return (unsigned)t;
+}
+__global__ __launch_bounds__(1024) void k_mini_median_regs(const float* __restrict__ a, int n, float* __restrict__ out) {
+    __shared__ int sh[16];
+    __shared__ unsigned s_nan;
+    const int tid = threadIdx.x;
+    unsigned k[32];
+    const int nk = (n - tid + 1023) / 1024;                      // elements tid, tid + 1024, ... of this thread
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        k[r] = 0xffffffffu;
+        if (r < nk) { const float v = a[tid + 1024 * r]; nan |= !(v == v); const unsigned u = __float_as_uint(v); k[r] = (u >> 31) ? ~u : (u | 0x80000000u); }
+    }
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    if (nan) s_nan = 1;
+    __syncthreads();
+    if (s_nan) { if (tid == 0) out[0] = __uint_as_float(0x7fc00000u); return; }
+    // lower middle element: rank (n - 1) / 2
+    const unsigned rank = (unsigned)((n - 1) / 2);
+    unsigned ans = 0;
+    for (int b = 31; b >= 0; b--) {
+        const unsigned cand = ans | (1u << b);
+        if (mm_count_below(k, nk, cand, sh) <= rank) ans = cand;
+    }
+    unsigned ans2 = ans;
+    if (!(n & 1)) {
+        // upper middle element (rank n / 2): the same value when enough keys equal it, else the smallest key above it
+        const unsigned le = ans == 0xffffffffu ? (unsigned)n : mm_count_below(k, nk, ans + 1u, sh);
+        if (le <= (unsigned)(n / 2)) {
+            unsigned m = 0xffffffffu;
+#pragma unroll
+            for (int r = 0; r < 32; r++) if (r < nk && k[r] > ans) m = min(m, k[r]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o, 64));
+            __syncthreads();
+            if ((tid & 63) == 0) sh[tid >> 6] = (int)m;
+            __syncthreads();
+            for (int w = 0; w < 16; w++) m = min(m, (unsigned)sh[w]);
+            ans2 = m;
+        }
+    }
+    if (tid == 0) {
+        const float v1 = __uint_as_float((ans >> 31) ? (ans & 0x7fffffffu) : ~ans), v2 = __uint_as_float((ans2 >> 31) ? (ans2 & 0x7fffffffu) : ~ans2);
+        out[0] = (n & 1) ? v1 : (v1 + v2) * 0.5f;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_mini_median(const float* __restrict__ a, int n, float* __restrict__ out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_rank, s_nan;
+    __shared__ float s_val[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) if (!(a[i] == a[i])) s_nan = 1;
+    __syncthreads();
+    if (s_nan || n < 1) { if (tid == 0) out[0] = __uint_as_float(0x7fc00000u); return; }
+    for (int which = 0; which < 2; which++) {
+        const unsigned rank = which == 0 ? (unsigned)((n - 1) / 2) : (unsigned)(n / 2);
+        if (tid == 0) { s_prefix = 0; s_rank = rank; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            const unsigned pre = s_prefix;
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned u = __float_as_uint(a[i]);
+                const unsigned k = (u >> 31) ? ~u : (u | 0x80000000u);
+                if (shift == 24 || (k >> (shift + 8)) == (pre >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned r = s_rank, b = 0;
+                while (r >= hist[b]) { r -= hist[b]; b++; }
+                s_rank = r; s_prefix = pre | (b << shift);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { const unsigned k = s_prefix; s_val[which] = __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k); }
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = (n & 1) ? s_val[0] : (s_val[0] + s_val[1]) * 0.5f;
+}
+
 // One workgroup = 256 columns x ZOOM_ROWS rows: the column taps (index + 4 float64 weights per
 // pixel, 36 bytes) are read once per thread and reused down the rows -- with a workgroup per row
 // they came through the L2 again for every row, 4.5x the bytes of the image itself.
 #ifndef ZOOM_ROWS
 #define ZOOM_ROWS 32                // (16: 0.157 / 0.340 ms write-only / with the subtraction; 32: 0.144 / 0.316; 64: 0.148 / 0.299)
 #endif
+#define ZOOM_CQ 2048                // LDS queue of candidate pixels per workgroup (k_spline_zoom4)
 static_assert(ZOOM_ROWS * 32 <= 1024, "k_spline_zoom folds ZOOM_ROWS x 32 coefficients into rowc[2][512]");
 __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const double* __restrict__ coef, int cnx,
                                                      const int32_t* __restrict__ fy, const double* __restrict__ wy,
@@ -320,7 +423,17 @@ __global__ __launch_bounds__(256) void k_spline_zoom(int ny, int nx, const doubl
 __global__ __launch_bounds__(256) void k_spline_zoom4(int ny, int nx, const double* __restrict__ coef, int cnx,
                                                       const int32_t* __restrict__ fy, const double* __restrict__ wy,
                                                       const int32_t* __restrict__ fx, const double* __restrict__ wx,
-                                                      float* data, float* bkg, const float* __restrict__ src) {
+                                                      float* data, float* bkg, const float* __restrict__ src,
+                                                      const float* __restrict__ cand_med, double cand_nsig, uint32_t* __restrict__ cand_list,
+                                                      int32_t* __restrict__ cand_cnt, uint32_t cand_cap, int32_t* __restrict__ d_err) {
+    // cand_list: the pixels of the subtracted frame with |value| >= (float)(cand_med[0] * cand_nsig) are listed as they
+    // are written (the catalogue search's pass over the frame, bbx_zoom_candidates).  They come in clusters (stars): a
+    // workgroup queues them in LDS, one reservation per wave and row, and appends the queue with one global
+    // reservation at its end; a wave that finds the queue full appends its own directly.
+    __shared__ uint32_t cq[ZOOM_CQ];
+    __shared__ unsigned cqn, cqbad;
+    const float cthr = cand_list ? (float)((double)cand_med[0] * cand_nsig) : 0.f;
+    if (cand_list) { if (threadIdx.x == 0) { cqn = 0; cqbad = 0xffffffffu; } }
     __shared__ double rc[ZOOM_ROWS * 64];      // (64 columns: a span of 1024 pixels that crosses a channel border takes in its two padded patch edges)
     const int X0 = blockIdx.x * 1024, X = X0 + 4 * (int)threadIdx.x;
     const int j0 = fx[X0] - 1, j1 = fx[min(X0 + 1023, nx - 1)] + 2;
@@ -344,8 +457,7 @@ __global__ __launch_bounds__(256) void k_spline_zoom4(int ny, int nx, const doub
             }
         }
         __syncthreads();
-        if (!live) return;
-        for (int Y = Y0; Y < Y1; Y++) {
+        for (int Y = Y0; Y < Y1 && live; Y++) {
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -360,7 +472,52 @@ __global__ __launch_bounds__(256) void k_spline_zoom4(int ny, int nx, const doub
             if (bkg) __builtin_nontemporal_store(zv4{v[0], v[1], v[2], v[3]}, reinterpret_cast<zv4*>(bkg + o));
             if (data) {
                 const float4 d = *reinterpret_cast<const float4*>((src ? src : data) + o);
-                *reinterpret_cast<float4*>(data + o) = make_float4(d.x - v[0], d.y - v[1], d.z - v[2], d.w - v[3]);
+                const float r0 = d.x - v[0], r1 = d.y - v[1], r2 = d.z - v[2], r3 = d.w - v[3];
+                *reinterpret_cast<float4*>(data + o) = make_float4(r0, r1, r2, r3);
+                if (cand_list) {
+                    const float rr[4] = {r0, r1, r2, r3};
+                    bool hit[4]; unsigned long long hm[4]; unsigned tot = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { hit[c] = fabsf(rr[c]) >= cthr; hm[c] = __builtin_amdgcn_ballot_w64(hit[c]); tot += (unsigned)__popcll(hm[c]); }
+                    if (tot) {                                       // wave-uniform
+                        const int lane = threadIdx.x & 63;
+                        const unsigned long long any = hm[0] | hm[1] | hm[2] | hm[3];
+                        const int leader = (int)__builtin_ctzll(any);
+                        unsigned base = 0;
+                        if (lane == leader) base = atomicAdd(&cqn, tot);
+                        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                        const bool fits = base + tot <= ZOOM_CQ;
+                        unsigned gbase = 0;
+                        if (!fits) {
+                            if (lane == leader) { atomicMin(&cqbad, base); gbase = atomicAdd((unsigned*)cand_cnt, tot); }
+                            gbase = (unsigned)__builtin_amdgcn_readlane((int)gbase, leader);
+                        }
+                        unsigned off = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            if (hit[c]) {
+                                const unsigned k = off + __builtin_amdgcn_mbcnt_hi((unsigned)(hm[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm[c], 0u));
+                                const uint32_t px = (uint32_t)(o + c);
+                                if (fits) cq[base + k] = px;
+                                else if (gbase + k < cand_cap) cand_list[gbase + k] = px;
+                                else atomicOr(d_err, BBX_DERR_LIST_OVERFLOW);
+                            }
+                            off += (unsigned)__popcll(hm[c]);
+                        }
+                    }
+                }
+            }
+        }
+        if (cand_list) {
+            __syncthreads();
+            const unsigned nq = min(min(cqn, cqbad), (unsigned)ZOOM_CQ);
+            __shared__ unsigned cg;
+            if (nq) {
+                if (threadIdx.x == 0) cg = atomicAdd((unsigned*)cand_cnt, nq);
+                __syncthreads();
+                for (unsigned t = threadIdx.x; t < nq; t += blockDim.x) {
+                    if (cg + t < cand_cap) cand_list[cg + t] = cq[t]; else atomicOr(d_err, BBX_DERR_LIST_OVERFLOW);
+                }
             }
         }
         return;
@@ -382,7 +539,14 @@ __global__ __launch_bounds__(256) void k_spline_zoom4(int ny, int nx, const doub
             const float v = (float)t;
             const size_t o = (size_t)Y * nx + X + c;
             if (bkg) bkg[o] = v;
-            if (data) data[o] = (src ? src[o] : data[o]) - v;
+            if (data) {
+                const float r = (src ? src[o] : data[o]) - v;
+                data[o] = r;
+                if (cand_list && fabsf(r) >= cthr) {                 // (rare geometry: a reservation per pixel)
+                    const unsigned k = atomicAdd((unsigned*)cand_cnt, 1u);
+                    if (k < cand_cap) cand_list[k] = (uint32_t)o; else atomicOr(d_err, BBX_DERR_LIST_OVERFLOW);
+                }
+            }
         }
     }
 }
@@ -508,7 +672,8 @@ int bbx_spline_zoom(bbx_ctx* ctx, int ny, int nx, const double* d_coef, int cny,
         return BBX_ERR_ARG;
     if (nx % 4 == 0 && (((uintptr_t)d_data | (uintptr_t)d_bkg) & 15) == 0)
         hipLaunchKernelGGL(k_spline_zoom4, dim3((nx + 1023) / 1024, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef,
-                           cnx, d_fy, d_wy, d_fx, d_wx, d_data, d_bkg, (const float*)nullptr);
+                           cnx, d_fy, d_wy, d_fx, d_wx, d_data, d_bkg, (const float*)nullptr, (const float*)nullptr, 0.0, (uint32_t*)nullptr,
+                           (int32_t*)nullptr, 0u, ctx->d_err);
     else
         hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
                            d_fy, d_wy, d_fx, d_wx, d_data, d_bkg, (const float*)nullptr);
@@ -521,10 +686,21 @@ int bbx_spline_zoom_sub(bbx_ctx* ctx, int ny, int nx, const double* d_coef, int 
                         void* stream) {
     if (!ctx || !d_coef || !d_fy || !d_wy || !d_fx || !d_wx || !d_in || !d_out || ny < 1 || nx < 1 || cny < 4 || cnx < 4)
         return BBX_ERR_ARG;
-    if (nx % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0)
+    // catalogue candidates on request (bbx_zoom_candidates, one-shot): listed by the kernel that writes the subtracted frame
+    const float* cmed = ctx->bcand_med; const double cnsig = ctx->bcand_nsig;
+    ctx->bcand_med = nullptr; ctx->bcand_img = nullptr;
+    if (nx % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0) {
+        uint32_t* clist = nullptr; uint32_t ccap = 0; int32_t* ccnt = &ctx->d_counters[CNT_BCAND];
+        if (cmed && (size_t)ny * nx < 0xffffffffull) {
+            int rc;
+            ccap = (uint32_t)((size_t)ny * nx / 16 + 1024);
+            clist = (uint32_t*)bbx_ws(ctx, WS_BCAND, (size_t)ccap * sizeof(uint32_t), &rc); if (rc) return rc;
+            BBX_HIP(hipMemsetAsync(ccnt, 0, sizeof(int32_t), (hipStream_t)stream));
+        }
         hipLaunchKernelGGL(k_spline_zoom4, dim3((nx + 1023) / 1024, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef,
-                           cnx, d_fy, d_wy, d_fx, d_wx, d_out, (float*)nullptr, d_in);
-    else
+                           cnx, d_fy, d_wy, d_fx, d_wx, d_out, (float*)nullptr, d_in, cmed, cnsig, clist, ccnt, ccap, ctx->d_err);
+        if (clist) { ctx->bcand_img = d_out; ctx->bcand_img_med = cmed; ctx->bcand_img_nsig = cnsig; ctx->bcand_npix = (size_t)ny * nx; }
+    } else
         hipLaunchKernelGGL(k_spline_zoom, dim3((nx + 255) / 256, (ny + ZOOM_ROWS - 1) / ZOOM_ROWS), dim3(256), 0, (hipStream_t)stream, ny, nx, d_coef, cnx,
                            d_fy, d_wy, d_fx, d_wx, d_out, (float*)nullptr, d_in);
     BBX_LAUNCH_CHECK();
@@ -548,6 +724,20 @@ int bbx_spline_prefilter(bbx_ctx* ctx, int nby, int nbx, int cy, int cx, int npa
     hipLaunchKernelGGL(k_spf_axis1, dim3(nblky * nblkx * ((py + SPF_LINES - 1) / SPF_LINES)), dim3(256), l1, (hipStream_t)stream, cy, cx, npad, nblkx,
                        zn_x, d_coef, cnx);
     BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_mini_median(bbx_ctx* ctx, int n, const float* d_a, float* d_med, void* stream) {
+    if (!ctx || !d_a || !d_med || n < 1 || n > (1 << 24)) return BBX_ERR_ARG;
+    if (n <= 32768) hipLaunchKernelGGL(k_mini_median_regs, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_a, n, d_med);
+    else hipLaunchKernelGGL(k_mini_median, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_a, n, d_med);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_zoom_candidates(bbx_ctx* ctx, const float* d_med, double nsigma) {
+    if (!ctx || (d_med && !(nsigma > 0.0))) return BBX_ERR_ARG;
+    ctx->bcand_med = d_med; ctx->bcand_nsig = nsigma; ctx->bcand_img = nullptr;
     return BBX_OK;
 }
 

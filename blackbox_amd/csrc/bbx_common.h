@@ -68,6 +68,10 @@ struct bbx_ctx {
     float  zcand_thr;          // bbx_zogy_candidates: > 0: bbx_zogy_frame lists the pixels with |Scorr| >= thr (WS_ZCAND, CNT_ZCAND)
     const float* zcand_img;    // the Scorr frame the list in WS_ZCAND belongs to (NULL: none); consumed by bbx_find_peaks
     float  zcand_thr_used; size_t zcand_npix;
+    const float* bcand_med;    // bbx_zoom_candidates: device scalar m; the next bbx_spline_zoom_sub lists |out| >= (float)(m * bcand_nsig) (WS_BCAND, CNT_BCAND)
+    double bcand_nsig;
+    const float* bcand_img;    // the frame the list in WS_BCAND belongs to (consumed by bbx_find_peaks), its median scalar and factor
+    const float* bcand_img_med; double bcand_img_nsig; size_t bcand_npix;
     int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context
     int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
@@ -108,13 +112,14 @@ enum {
     CNT_CANDRAW = 176,    // LA-Cosmic candidates before the s > sigclip pre-filter
     CNT_TICKET = 192,     // workgroups of the current kernel that have finished (last one does the epilogue)
     CNT_ZCAND = 208,      // bbx_zogy_frame: pixels with |Scorr| >= the candidate threshold (bbx_zogy_candidates)
+    CNT_BCAND = 224,      // bbx_spline_zoom_sub: pixels above the catalogue threshold (bbx_zoom_candidates)
     CNT_MAX = 256
 };
 
 // workspace slots
 enum {
     WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
-    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND, WS_BCAND,
     WS_MAX
 };
 

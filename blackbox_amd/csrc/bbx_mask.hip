@@ -806,6 +806,11 @@ __global__ __launch_bounds__(256) void k_cc_peak_emit(const int32_t* __restrict_
     }
 }
 
+// the threshold a candidate list was made with against the one the caller passes
+__global__ void k_thr_check(const float* __restrict__ med, double nsig, float thr, int32_t* err) {
+    if (threadIdx.x == 0 && !((float)((double)med[0] * nsig) == thr)) atomicOr(err, BBX_DERR_LIST_OVERFLOW);
+}
+
 extern "C" int bbx_find_peaks(bbx_ctx* ctx, int ny, int nx, const float* d_img, float thr, int max_out, int32_t* d_yx,
                               float* d_val, int32_t* d_count, void* stream) {
     if (!ctx || !d_img || !d_yx || !d_val || !d_count || ny < 1 || nx < 1 || max_out < 1) return BBX_ERR_ARG;
@@ -824,6 +829,14 @@ extern "C" int bbx_find_peaks(bbx_ctx* ctx, int ny, int nx, const float* d_img, 
         list = (uint32_t*)ctx->d_ws[WS_ZCAND];
         cnt = &ctx->d_counters[CNT_ZCAND];
         ctx->zcand_img = nullptr;
+    } else if (ctx->bcand_img == d_img && ctx->bcand_npix == npix && ctx->d_ws[WS_BCAND]) {
+        // the frame is the background-subtracted image of the last bbx_spline_zoom_sub call, which listed the pixels above
+        // (float)(median * nsigma) as it wrote them (bbx_zoom_candidates): no pass over the frame -- provided the caller's
+        // threshold is that very number (checked on the device: the list-overflow flag otherwise, i.e. the caller sees a failed search, not a wrong one)
+        list = (uint32_t*)ctx->d_ws[WS_BCAND];
+        cnt = &ctx->d_counters[CNT_BCAND];
+        hipLaunchKernelGGL(k_thr_check, dim3(1), dim3(64), 0, s, ctx->bcand_img_med, ctx->bcand_img_nsig, thr, ctx->d_err);
+        ctx->bcand_img = nullptr;
     } else {
         BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
         hipLaunchKernelGGL(k_compact_abs, dim3(2048), dim3(256), 0, s, d_img, npix, thr, list, cnt, (uint32_t)cap, ctx->d_err);

@@ -493,6 +493,13 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     # ---- new frame: mesh, subtraction, sigma image, variance
     mini, mini_std = get_back(ctx, new, new_mask, bkg_boxsize=box)
     work = torch.empty_like(new)
+    want_cat = cat_extract and psf_new is not None
+    if want_cat:
+        # the kernel that writes the background-subtracted frame lists the pixels above cat_nsigma x S-BKGSTD for the
+        # catalogue's peak search; S-BKGSTD = median of the sigma mini image, taken on the device for that
+        d_sstd = torch.empty(1, dtype=torch.float32, device=ctx.device)
+        check(lib.bbx_mini_median(ctx.h, mini_std.numel(), _p(mini_std), _p(d_sstd), ctx.stream()), 'bbx_mini_median', ctx.h)
+        check(lib.bbx_zoom_candidates(ctx.h, _p(d_sstd), float(cat_nsigma)), 'bbx_zoom_candidates', ctx.h)
     mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=new, subtract_into=work)
     bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
     Vn = None                                                        # variance image: only where a consumer needs it

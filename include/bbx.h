@@ -454,6 +454,16 @@ int bbx_bkg_boxstats(bbx_ctx *ctx, int ny, int nx, int box, const float *d_data,
 int bbx_mini_fill_filter(bbx_ctx *ctx, int nby, int nbx, float *d_mini, void *stream);
 int bbx_spline_prefilter(bbx_ctx *ctx, int nby, int nbx, int cy, int cx, int npad, double zn_y, double zn_x,
                          const float *d_mini, double *d_coef, void *stream);
+/* bbx_mini_median: np.median of a float32 device array of n values (exact order statistics; an even count gives the
+ * float32 mean of the middle pair as numpy does; NaN if the array holds one) -> d_med[0].  S-BKGSTD = the median of the
+ * sigma mini image (zogy's header value) without a round trip through the host.
+ * bbx_zoom_candidates(ctx, d_med, nsigma): the NEXT bbx_spline_zoom_sub call of this context also lists the pixels of
+ * the frame it writes with |value| >= (float)(d_med[0] * nsigma) -- the candidates of the source catalogue (peaks above
+ * cat_nsigma x S-BKGSTD) -- and bbx_find_peaks on that frame with that threshold starts from the list instead of a
+ * pass of its own over the frame (a threshold that is not that number raises the device's list-overflow flag: a failed
+ * search, not a wrong one).  d_med = NULL: off. */
+int bbx_mini_median(bbx_ctx *ctx, int n, const float *d_a, float *d_med, void *stream);
+int bbx_zoom_candidates(bbx_ctx *ctx, const float *d_med, double nsigma);
 int bbx_spline_zoom(bbx_ctx *ctx, int ny, int nx, const double *d_coef, int cny, int cnx,
                     const int32_t *d_fy, const double *d_wy, const int32_t *d_fx,
                     const double *d_wx, float *d_data, float *d_bkg, void *stream);

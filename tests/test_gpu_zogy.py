@@ -295,3 +295,54 @@ def test_device_spline_prefilter_bits(shape, channels):
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), np.abs(got - ref).max()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_catalogue_candidates_listed_by_the_zoom_equal_the_search_pass():
+    """bbx_mini_median == np.median (float32 rule, odd and even counts, NaN); bbx_zoom_candidates: the pixels above
+    (float)(median x nsigma) listed by the kernel that writes the background-subtracted frame give the same peaks as
+    bbx_find_peaks' own pass; a threshold that is not that number fails the search instead of answering wrongly"""
+    from blackbox_amd import reduce as R, zogy as G
+    from blackbox_amd._lib import lib, check, BBXError
+    ctx = R.Context(0)
+    dev_ = ctx.device
+    rs = np.random.RandomState(21)
+    for n in (1, 2, 7, 1024, 1025, 30976, 30977, 32768, 32769, 100001):
+        a = rs.normal(8 if n % 3 else -8, 2, n).astype(np.float32)
+        if n == 1024:
+            a[:] = np.round(a)                                         # ties across the middle
+        out = torch.empty(1, dtype=torch.float32, device=dev_)
+        check(lib.bbx_mini_median(ctx.h, n, G._p(torch.from_numpy(a).to(dev_)), G._p(out), ctx.stream()), 'bbx_mini_median')
+        assert out.item() == np.median(a), n
+    a[5] = np.nan
+    check(lib.bbx_mini_median(ctx.h, a.size, G._p(torch.from_numpy(a).to(dev_)), G._p(out), ctx.stream()), 'bbx_mini_median')
+    assert np.isnan(out.item())
+    box, ny, nx = 20, 480, 640
+    img = rs.normal(100, 5, (ny, nx)).astype(np.float32)
+    for _ in range(60):
+        y, x = rs.randint(3, ny - 3), rs.randint(3, nx - 3)
+        img[y - 1:y + 2, x - 1:x + 2] += rs.uniform(30, 3000)
+    img[100:140, 200:260] += 500.0                                   # a block of hits: the workgroup's queue overflows into direct appends
+    d_img = torch.from_numpy(img).to(dev_)
+    mask = torch.zeros((ny, nx), dtype=torch.uint8, device=dev_)
+    mini, mstd = G.get_back(ctx, d_img, mask, bkg_boxsize=box)
+    nsig = 5.0
+    d_med = torch.empty(1, dtype=torch.float32, device=dev_)
+    check(lib.bbx_mini_median(ctx.h, mstd.numel(), G._p(mstd), G._p(d_med), ctx.stream()), 'bbx_mini_median')
+    thr = float(nsig) * float(np.median(mstd.cpu().numpy()))
+    assert np.float32(thr) == np.float32(float(d_med.item()) * nsig)
+    work = torch.empty_like(d_img)
+    check(lib.bbx_zoom_candidates(ctx.h, G._p(d_med), nsig), 'bbx_zoom_candidates')
+    G.mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, subtract_from=d_img, subtract_into=work)
+    a = G.find_peaks_arrays(ctx, work, thr, max_out=20000)           # from the list
+    b = G.find_peaks_arrays(ctx, work.clone(), thr, max_out=20000)   # own pass
+    c = G.find_peaks_arrays(ctx, work, thr, max_out=20000)           # the list is spent: own pass
+    assert a[0].size > 60
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    # another threshold on a listed frame: refused
+    check(lib.bbx_zoom_candidates(ctx.h, G._p(d_med), nsig), 'bbx_zoom_candidates')
+    G.mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, subtract_from=d_img, subtract_into=work)
+    with pytest.raises(BBXError):
+        G.find_peaks_arrays(ctx, work, thr * 1.5, max_out=20000)
+    ctx.close()
