@@ -281,3 +281,41 @@ def test_gpu_short_stream_buffer_and_retry_equal_full_buffer():
         assert t['zscale'][r] == zs and t['zzero'][r] == zz, r
         assert t['heap'][t['offsets'][r]:t['offsets'][r] + t['nbytes'][r]].tobytes() == b, r
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_fullsize_round_trip_properties(tmp_path):
+    """BASELINE frame size (10560 x 10560 float32, q = 16) through fpack_image -> file -> funpack_image on the device: the
+    size-independent properties of CFITSIO's quantisation with subtractive dither -- every pixel comes back within half a
+    quantisation step of its row (ZSCALE), rows that cannot be quantised (constant edge rows) come back exactly, and the
+    file is a fraction of the raw size; the uint8 mask of the same size comes back bit for bit."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R
+    from blackbox_amd import fpack as P
+    ctx = R.Context(0)
+    dev = ctx.device
+    ny = nx = 10560
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    img = 300.0 + 9.0 * torch.randn(ny, nx, device=dev, generator=g)
+    img[:, 4000:4100] += 2.0e4                                            # a bright band: range >> noise
+    img[0:3] = 123.5; img[-2:] = 7.25                                     # filled edge rows: not quantised, stored losslessly
+    path = P.fpack_image(ctx, str(tmp_path / 'full_red.fits'), img, {'OBJECT': 'full'}, quant=16, dither_seed=3)
+    assert os.path.getsize(path) < img.numel() * 4 / 3.5
+    back, hdr = P.funpack_image(ctx, path)
+    assert back.shape == img.shape and back.dtype == torch.float32 and R.hval(hdr, 'OBJECT') == 'full'
+    c = P.compress_tiles(ctx, img, 16, 3)
+    zs = torch.from_numpy(c['zscale'].astype(np.float32)).to(dev)
+    err = (back - img).abs().amax(dim=1)
+    quantised = torch.from_numpy(c['flag'] == 0).to(dev)
+    assert int((~quantised).sum()) == 5
+    assert bool((err[~quantised] == 0).all())
+    # |x' - x| <= ZSCALE / 2 (+ float32 rounding of the reconstruction at the value's magnitude)
+    assert bool((err[quantised] <= 0.5 * zs[quantised] * (1 + 1e-5) + 2.1e4 * 1.2e-7).all())
+    assert float(zs[quantised].max()) < 9.0 / 16 * 1.1 and float(zs[quantised].min()) > 9.0 / 16 * 0.9
+    msk = (torch.rand(ny, nx, device=dev, generator=g) < 0.02).to(torch.uint8) * 32
+    mp = P.fpack_image(ctx, str(tmp_path / 'full_mask.fits'), msk)
+    mback, _ = P.funpack_image(ctx, mp)
+    assert mback.dtype == torch.uint8 and bool((mback == msk).all())
+    ctx.close()
