@@ -279,3 +279,34 @@ def test_zogy_fullsize(scene, branch):
     f_o, e_o = Z.psf_optflux_vec(work_h, V_h, pn, ys_c[pick], xs_c[pick])
     np.testing.assert_allclose(cat['E_FLUX_OPT'][pick], f_o, rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(cat['E_FLUXERR_OPT'][pick], e_o, rtol=1e-5)
+
+
+def test_zogy_fullsize_scaling_and_null_properties():
+    """bbx_zogy_frame on 64 sub-images of 1400^2, properties that hold whatever the frame: (i) new, ref and their noise scalars
+    times 4 (a power of two: every operation scales exactly) make Fpsf exactly 4 times larger, bit for bit, and D (in
+    units of the new frame's flux) 4 times larger to float32 rounding -- D shares its inverse row transform with V(S), whose
+    values do not scale with the frames, so the rounding it picks up there differs; (ii) identical frames with identical PSFs, noise and flux scalars give D = 0 to float32 rounding of the
+    transforms and no transient above 6 sigma"""
+    import bench
+    ctx = R.Context(0)
+    dev = ctx.device
+    ny = nx = 10560
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    new = (20 * torch.randn(ny, nx, device=dev, generator=g)).contiguous()
+    ref = (8 * torch.randn(ny, nx, device=dev, generator=g)).contiguous()
+    new[5000:5003, 7000:7003] += 900.0
+    sn = torch.full((ny, nx), 20.0, device=dev); sr = torch.full((ny, nx), 8.0, device=dev)
+    psf = torch.from_numpy(np.repeat(bench.moffat_stamp(25, 4.0)[None], 64, 0)).to(dev)
+    scal = np.tile(np.array([[20, 8, 1, 0.9, 0.03, 0.02]], np.float32), (64, 1))
+    base = G.run_zogy_frame(ctx, new, ref, sn, sr, psf, psf, scal, 1320, 40)
+    s4 = scal.copy(); s4[:, 0:2] *= 4
+    big = G.run_zogy_frame(ctx, new * 4, ref * 4, sn * 4, sr * 4, psf, psf, s4, 1320, 40)
+    ctx.sync()
+    assert float((big[0] - base[0] * 4).abs().max()) <= 2e-6 * 4 * float(base[0].abs().max())        # D
+    assert bool((big[3] == base[3] * 4).all())                                # Fpsf
+    same = np.tile(np.array([[20, 20, 1, 1, 0.0, 0.0]], np.float32), (64, 1))
+    null = G.run_zogy_frame(ctx, new, new, sn, sn, psf, psf, same, 1320, 40)
+    ctx.sync()
+    assert float(null[0].abs().max()) < 1e-4 * float(new.abs().max())        # D: the frames' own scale is 20 / 900
+    assert float(null[2].abs().max()) < 1e-3                                  # Scorr
+    ctx.close()
