@@ -175,6 +175,25 @@ def synth_reference(torch, dev, scene0, seed, depth=4.0, sky_ref=0.0):
     return ref.contiguous(), torch.zeros(scene0.shape, dtype=torch.uint8, device=dev)
 
 
+def zogy_inputs(torch, dev, nsy, nsx, S, box, ny, nx):
+    """what zogy hands run_ZOGY per sub-image (blackbox.py:3754-3759, call 2460-2465) -- analytic Moffat
+    PSF stamps S x S (49 x 49), one pair per sub-image with a FWHM gradient across the field (new 3.6 .. 4.6 px, co-added
+    reference 3.3 .. 3.9 px), flux ratio and astrometric scatter per sub-image; the reference is a co-add:
+    background-subtracted, with its `_bkg_std_mini` image (buildref products), a smooth 7.6 .. 8.4 e- here"""
+    nsub = nsy * nsx
+    ky, kx = np.divmod(np.arange(nsub), nsx)
+    u, v = kx / max(1, nsx - 1) - 0.5, ky / max(1, nsy - 1) - 0.5
+    fw_n, fw_r = 4.1 + 0.6 * u + 0.37 * v, 3.6 + 0.3 * u - 0.29 * v
+    psf_n = torch.from_numpy(np.stack([moffat_stamp(S, f) for f in fw_n])).to(dev)
+    psf_r = torch.from_numpy(np.stack([moffat_stamp(S, f) for f in fw_r])).to(dev)
+    rs = np.random.RandomState(5)
+    by, bx = np.mgrid[0:ny // box, 0:nx // box]
+    ref_std_mini = (8.0 + 0.4 * (bx / (nx // box) - 0.5) - 0.4 * (by / (ny // box) - 0.5)).astype(np.float32)
+    return dict(psf_new=psf_n, psf_ref=psf_r, fratio=1.0 + 0.04 * u - 0.03 * v + rs.normal(0, 0.005, nsub),
+                dx=0.03 + 0.01 * rs.uniform(-1, 1, nsub), dy=0.03 + 0.01 * rs.uniform(-1, 1, nsub), ref_is_bkgsub=True,
+                ref_bkg_std_mini=ref_std_mini)
+
+
 def _cpu_sample(args):
     """one worker's bounded sample of the CPU path: the oracle restatement (numpy/scipy) of the
     reduction on a 1320x2640 sub-frame (1/32 of a frame), the background mesh on it, and run_zogy
@@ -429,6 +448,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=None, help='stage-C lanes (context + stream + issuing thread) per GPU')
     ap.add_argument('--writers', type=int, default=8, help='writer threads of the output stage (io_inclusive.measured)')
     ap.add_argument('--io-only', action='store_true', help='only the measured I/O-inclusive run (debug)')
+    ap.add_argument('--psf-size', type=int, default=49, help='side of the PSF stamps of the ZOGY stage (SURVEY 8d: 49)')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -479,14 +499,10 @@ def main():
         raws.append(r.to(torch.int32).to(torch.uint16).contiguous() if args.raw == 'u16' else r.contiguous())
     rs = np.random.RandomState(0)
     coeffs = np.zeros((16, 16)); coeffs[~np.eye(16, dtype=bool)] = rs.uniform(0, 2e-4, 240)
-    S = 25
-    psf_n = torch.from_numpy(moffat_stamp(S, 4.0)).to(dev)
-    psf_r = torch.from_numpy(moffat_stamp(S, 4.0)).to(dev)
-    # the reference is a co-add: background-subtracted, with its `_bkg_std_mini` image (buildref products)
-    ref_std_mini = np.full((2 * ysz // box, 8 * xsz // box), 8.0, np.float32)
-    sub_kw = dict(ref=ref, ref_mask=ref_mask, psf_new=psf_n, psf_ref=psf_r, fratio=1.0, dx=0.03, dy=0.03, ref_is_bkgsub=True,
-                  ref_bkg_std_mini=ref_std_mini,
-                  cat_extract=True, trans_extract=True, subimage_size=size, subimage_border=border, bkg_boxsize=box)
+    S = args.psf_size
+    sub_kw = zogy_inputs(torch, dev, 2 * ysz // size, 8 * xsz // size, S, box, 2 * ysz, 8 * xsz)
+    sub_kw.update(ref=ref, ref_mask=ref_mask, cat_extract=True, trans_extract=True, subimage_size=size, subimage_border=border,
+                  bkg_boxsize=box)
     base_kw = dict(mflat=flat, bpm=bpm)
     kws = {
         'calib': dict(base_kw),
@@ -656,8 +672,9 @@ def main():
         names = {'zogy': 'configs[4] per frame on one GPU: one %s -> reduce (gain+overscan+flat+mask+LA-Cosmic(niter=3)+xtalk+'
                          'sat trail+counts+edge fill) + optimal_subtraction vs a co-added, background-subtracted reference with its '
                          'bkg_std_mini (buildref products): bkg mesh of the new frame, variance images, %d '
-                         'sub-images of %d^2 ZOGY, D/Scorr/Fpsf/Fpsferr, transients, PSF-photometry catalogue), ML1'
-                         % (shape, nsub, L),
+                         'sub-images of %d^2 ZOGY with %d distinct %dx%d Moffat PSF pairs and per-sub-image flux ratio / sigma / dx / dy, '
+                         'D/Scorr/Fpsf/Fpsferr, transients, PSF-photometry catalogue), ML1'
+                         % (shape, nsub, L, nsub, S, S),
                  'full': 'configs[2]: one %s -> full calibration + LA-Cosmic + xtalk + sat trail + counts + edge fill + '
                          'background mesh and subtraction, ML1' % shape,
                  'calib': 'configs[1]: one %s -> gain+overscan+flat+mask_init+LA-Cosmic(niter=3), ML1' % shape}
@@ -708,6 +725,15 @@ def main():
                                                lanes=lanes, note='reference not background-subtracted: bkg mesh x2 per frame')
             del ref2
             section('zogy_ref_with_sky')
+            if S != 25:
+                # rounds 1-3 benched one 25 x 25 stamp for all sub-images: the stage's cost depends on S through the row window
+                # of the matched-filter kernels (4 S + 32 of L rows) and the stamp DFT
+                kw25 = dict(kws['zogy'], subtract=dict(sub_kw, psf_new=torch.from_numpy(moffat_stamp(25, 4.0)).to(dev),
+                                                       psf_ref=torch.from_numpy(moffat_stamp(25, 4.0)).to(dev)))
+                r2 = run_pipeline(torch, ctx, tel, geom, raws, kw25, 30, 4, depth, lanes, pool, barrier)
+                others['zogy_psf25'] = dict(frames_per_s=30 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 30, frames_in_flight=depth, lanes=lanes,
+                                            note='one 25 x 25 PSF stamp for all sub-images (the configuration of rounds 1-3)')
+                section('zogy_psf25')
         out['other_workloads'] = others
         # the same steady-state measurement over a long run (the headline's K frames are few)
         r3 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 240, 4, depth, lanes, pool, barrier)

@@ -480,6 +480,13 @@ class Reducer:
                 G.format_cat(G.transient_table(res['transients']), base + '_trans.fits', cat_type='trans', header2add=full_t)
             fitsio.write_header(base + '_trans_hdr.fits', full_t)
 
+    def _limmag_is_flux(self, header):
+        """one rule for the unit of `_trans_limmag`, whichever path writes it: a flux limit only when no zeropoint is known --
+        neither --zeropoint nor a numeric PC-ZP in the frame's header (then the output stage may queue it on the lane)"""
+        if self.args.zeropoint is not None:
+            return False
+        return not ('PC-ZP' in header and not isinstance(self.R.hval(header, 'PC-ZP'), str))
+
     def write_limmag(self, base, res, header):
         """`_trans_limmag.fits` (set_blackbox.py:160-162): the transient detection limit per pixel,
         T-NSIGMA x Fpsferr -- in magnitudes when a zeropoint is known (--zeropoint, or PC-ZP of the header, with the
@@ -584,7 +591,7 @@ class Reducer:
                 if len(written) == len(todo):
                     all_written.set()
             kw = dict(outstage=stage, out_base=lambda idx, h: todo[idx][1].replace('.fits', ''), on_written=on_written,
-                      header_hook=header_hook, stage_limmag=self.args.zeropoint is None)
+                      header_hook=header_hook, stage_limmag=self._limmag_is_flux)
         self._pipe_exptime = exptime
         pipe = FramePipeline(self.ctx, self.tel, geom, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
                              xtalk_coeffs=self.xtalk, exptime=exptime, depth=max(2, min(8, len(todo))), lanes=2,

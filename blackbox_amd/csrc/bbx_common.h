@@ -72,6 +72,7 @@ struct bbx_ctx {
     double bcand_nsig;
     const float* bcand_img;    // the frame the list in WS_BCAND belongs to (consumed by bbx_find_peaks), its median scalar and factor
     const float* bcand_img_med; double bcand_img_nsig; size_t bcand_npix;
+    int    fpack_hist_only;    // BBX_OPT_FPACK_HIST_ONLY: row medians by radix histograms over all keys (tests: same bytes as the bracket path)
     int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context
     int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
@@ -119,7 +120,7 @@ enum {
 // workspace slots
 enum {
     WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
-    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND, WS_BCAND,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND, WS_BCAND, WS_FPHINT,
     WS_MAX
 };
 

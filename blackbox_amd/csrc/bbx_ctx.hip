@@ -151,9 +151,10 @@ int bbx_sync(bbx_ctx* ctx, void* stream) {
     BBX_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (err[0]) {
         BBX_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(err), (hipStream_t)stream));
+        // (the window check first: the caller repeats that call on all rows, and a list overflow of the same call shows again then)
+        if (err[0] & BBX_DERR_PSF_WINDOW) return BBX_ERR_PSFWIN;
         if (err[0] & BBX_DERR_LIST_OVERFLOW) return BBX_ERR_OVERFLOW;
         if (err[0] & BBX_DERR_NOTCONV) return BBX_ERR_NOTCONV;
-        if (err[0] & BBX_DERR_PSF_WINDOW) return BBX_ERR_PSFWIN;
     }
     return BBX_OK;
 }
@@ -175,6 +176,7 @@ int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (option == BBX_OPT_DEBUG_LISTCAP) { ctx->debug_listcap = value > 0 ? value : 0; return BBX_OK; }
     if (option == BBX_OPT_ZOGY_KWIN_OFF) { ctx->zogy_kwin_off = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_FPACK_ONE_WG) { ctx->fpack_one_wg = value ? 1 : 0; return BBX_OK; }
+    if (option == BBX_OPT_FPACK_HIST_ONLY) { ctx->fpack_hist_only = value ? 1 : 0; return BBX_OK; }
     return BBX_ERR_ARG;
 }
 

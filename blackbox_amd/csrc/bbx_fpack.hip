@@ -80,6 +80,77 @@ __device__ __forceinline__ unsigned rice_diff(const int* vals, int i) {
     return d;
 }
 
+// ---- a wave sorts 1024 keys held 16 per lane (sorted position of register r of lane l: 16 l + r): bitonic network,
+// stages between registers of a lane as v_min / v_max (v_med3 against a per-lane 0 / ~0 where the direction depends on the
+// lane), stages between lanes through ds_bpermute (the machinery of k_bkg_boxstats with 16 instead of 64 keys per lane)
+__device__ __forceinline__ uint32_t fp_umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t o;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+template <int K, int J> __device__ __forceinline__ void fp_stage_static(uint32_t (&k)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int q = r ^ J;
+        if (q > r) {
+            const uint32_t a = k[r], b = k[q];
+            const uint32_t lo = min(a, b), hi = max(a, b);
+            if ((r & K) == 0) { k[r] = lo; k[q] = hi; } else { k[r] = hi; k[q] = lo; }
+        }
+    }
+}
+template <int J> __device__ __forceinline__ void fp_stage_lane(uint32_t (&k)[16], uint32_t clo) {
+    const uint32_t chi = ~clo;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int q = r ^ J;
+        if (q > r) {
+            const uint32_t a = k[r], b = k[q];
+            k[r] = fp_umed3(a, b, clo); k[q] = fp_umed3(a, b, chi);
+        }
+    }
+}
+__device__ __forceinline__ void fp_wave_sort1024(uint32_t (&k)[16], int lane) {
+    fp_stage_static<2, 1>(k);
+    fp_stage_static<4, 2>(k); fp_stage_static<4, 1>(k);
+    fp_stage_static<8, 4>(k); fp_stage_static<8, 2>(k); fp_stage_static<8, 1>(k);
+#pragma unroll 1
+    for (int ll = 0; ll <= 6; ll++) {                     // runs of 16 << ll elements
+        const bool asc = (lane & (1 << ll)) == 0;         // ll = 6: one ascending run
+#pragma unroll 1
+        for (int m = (1 << ll) >> 1; m > 0; m >>= 1) {
+            const uint32_t c = (((lane & m) == 0) == asc) ? 0u : 0xffffffffu;   // keep the smaller / the larger
+#pragma unroll
+            for (int r = 0; r < 16; r++) k[r] = fp_umed3(k[r], (uint32_t)__shfl_xor((int)k[r], m), c);
+        }
+        const uint32_t clo = asc ? 0u : 0xffffffffu;
+        fp_stage_lane<8>(k, clo); fp_stage_lane<4>(k, clo); fp_stage_lane<2>(k, clo); fp_stage_lane<1>(k, clo);
+    }
+}
+
+// ---- the bit stream of a row is written by threads that own runs of 8 pixels: a thread assembles its codes in a 64-bit
+// window and stores whole words; only the first and the last word of its run can be shared with a neighbour (atomic OR
+// into the zeroed buffer).  One LDS atomic per thread and end instead of two to four per pixel.
+struct fp_bitw {
+    unsigned* words;
+    unsigned w, nb;                  // current word, bits of it filled
+    unsigned long long acc;          // bits of words w, w + 1, left-aligned
+    bool shared;                     // word w started before this run: a neighbour writes into it as well
+    __device__ __forceinline__ void init(unsigned* wd, unsigned bitpos) { words = wd; w = bitpos >> 5; nb = bitpos & 31u; acc = 0ull; shared = nb != 0u; }
+    __device__ __forceinline__ void flush() {
+        const unsigned hi = (unsigned)(acc >> 32);
+        if (shared) { if (hi) atomicOr(&words[w], hi); } else words[w] = hi;
+        shared = false; acc <<= 32; nb -= 32u; w++;
+    }
+    __device__ __forceinline__ void put(unsigned val, int n) {          // 1 <= n <= 32, val < 2^n
+        acc |= (unsigned long long)val << (64u - nb - (unsigned)n);
+        nb += (unsigned)n;
+        if (nb >= 32u) flush();
+    }
+    __device__ __forceinline__ void zeros(unsigned z) { nb += z; while (nb >= 32u) flush(); }
+    __device__ __forceinline__ void finish() { const unsigned hi = (unsigned)(acc >> 32); if (nb && hi) atomicOr(&words[w], hi); }
+};
+
 // FLOAT_IN: src = float32 rows, quantised first; else src = integer rows of BYTEPIX bytes.
 // dynamic LDS: int vals[nxpad] | unsigned words[maxwords] | unsigned blkbits[nblk+1] | uint8 fsv[nblk] (+ float mode scratch)
 // MODE 0: the bit stream buffer holds the worst case (every pixel at full width): ~100 KB of LDS for a 10560-pixel float row,
@@ -88,16 +159,41 @@ __device__ __forceinline__ unsigned rice_diff(const int* vals, int i) {
 //         take 7-8) -- ~66 KB, TWO workgroups per CU, whose barrier-separated phases then overlap; a row whose stream does
 //         not fit is marked FP_FLAG_RETRY.
 // MODE 2: only the rows marked FP_FLAG_RETRY, with the worst-case buffer (same bytes as MODE 0 would have made).
+//
+// The three exact medians of CFITSIO's noise estimate (lower medians of the |2nd / 3rd / 5th order differences| of the row):
+//   round 3 selected them by radix passes over LDS histograms -- an LDS atomic per key and pass, ~64 cycles per wave
+//   instruction whatever the addresses: 1.0 of the kernel's 1.4 ms.  Now (rows of >= FP_MIN_ND differences):
+//   (1) 1024 keys per kind are sampled at a fixed stride and sorted by one wave per kind in registers; the sample's order
+//       statistics 512 -/+ FP_SAMP_HALF bracket the median's value [lo, hi] (+- 3 sigma of the sample median's rank);
+//   (2) ONE pass over the differences counts the keys below lo / equal to lo / equal to hi in registers and compacts the
+//       keys strictly inside the bracket (~9 % of them) into per-wave segments with ballots -- no atomics;
+//   (3) the rank falls on lo, on hi or inside: then one histogram pass over the ~1000 collected keys on (key - lo) >> s
+//       (2048 bins), the bin's handful of keys are collected and ranked by counting.
+//   Whenever a step does not hold (rank outside the bracket: ~0.3 % of the rows; a segment or the last list overflows:
+//   rows with many equal differences) the row takes the histogram passes over all keys, as before: the result is the
+//   exact order statistic either way.
 #define FP_FLAG_RETRY 3u
 #define FP_NCOLL 128               // keys collected in the last select pass before it falls back to a histogram
+#define FP_NSAMP 1024
+#define FP_SAMP_HALF 48
+#define FP_MIN_ND 4096             // shorter rows: histogram passes (the bracket of a 1024-key sample is no gain there)
+#define FP_MIN_SEG 64              // smallest per-wave segment the bracket path is used with
+#define FP_HINT_FRAC 0.06f          // bracket around a hinted median: -/+ 6 %
+#define FP_HINT_VALID 0x80000000u  // (keys are bit patterns of non-negative floats: the top bit is free)
+// Hints: neighbouring rows of an image have nearly the same noise.  Every workgroup leaves its three exact medians in
+// hint[row][3] (relaxed agent-scope atomics, the top bit marks a written word), and starts from the medians of the row one
+// or two dispatch generations earlier (row - gen, row - 2 gen; gen = workgroups resident at once) -/+ FP_HINT_FRAC when
+// they are there already: ~5 % of the keys inside, no sample, no sort.  Where that bracket misses (or no hint exists yet:
+// the first rows) the sampled bracket takes over, then the histograms.  A hint only chooses the path: the medians are the
+// exact order statistics whichever way, so the bytes do not depend on the timing of other workgroups.
 template <int BYTEPIX, bool FLOAT_IN, int MODE>
 __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
                                                  float qlevel, int dither_seed, const float* __restrict__ rnd,
                                                  uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles,
-                                                 int capwords) {
+                                                 int capwords, int hist_only, unsigned* __restrict__ hint, int gen) {
     typedef rice_par<BYTEPIX> RP;
     extern __shared__ __align__(16) unsigned char lds[];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (MODE == 2 && tiles[row].flag != FP_FLAG_RETRY) return;
     const int nblk = (nx + 31) / 32;
     const int maxwords = MODE == 1 ? capwords : (8 * BYTEPIX + nblk * RP::fsbits + nx * RP::bbits + 31) / 32 + 2;
@@ -105,41 +201,275 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
     unsigned* words = reinterpret_cast<unsigned*>(vals + ((nx + 3) & ~3));
     unsigned* blkbits = words + maxwords;
     uint8_t* fsv = reinterpret_cast<uint8_t*>(blkbits + nblk + 1);
-    __shared__ unsigned hist[3][1024];                              // 2048 bins each: two 16-bit counters per word
+    __shared__ unsigned hist[3][1024];                              // 2048 bins each: two 16-bit counters per word; first the samples
     __shared__ unsigned coll[3][FP_NCOLL], ncoll[3];
-    __shared__ int s_many;
+    __shared__ int s_many, s_fail, s_hint_ok;
     __shared__ unsigned sel_prefix[3], sel_rank[3];
+    __shared__ unsigned br_lo[3], br_hi[3], br_need[3], br_shift[3];
+    __shared__ unsigned segn[3][FP_THREADS / 64], cpart[FP_THREADS / 64][9];
     __shared__ float red_min[FP_THREADS / 64], red_max[FP_THREADS / 64];
     __shared__ double s_delta, s_zero;
     __shared__ int s_flag;
+    __shared__ unsigned wsum[FP_THREADS / 64];
     fp_tile* out = &tiles[row];
+    const bool vec4 = FLOAT_IN && (nx & 3) == 0 && (row_stride_elems & 3) == 0 && (((uintptr_t)src) & 15) == 0;
+    constexpr int NLD = (FP_MAXNX / 4 + FP_THREADS - 1) / FP_THREADS;
 
     if (FLOAT_IN) {
         const float* f = (const float*)src + (size_t)row * row_stride_elems;
         float* fv = reinterpret_cast<float*>(vals);
         float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
         int bad = 0;
-        for (int i = tid; i < nx; i += FP_THREADS) {
-            const float v = f[i];
-            fv[i] = v;
-            if (!isfinite(v)) bad = 1;
-            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        if (vec4) {                                                    // 16-byte accesses
+            float4* fv4 = reinterpret_cast<float4*>(fv);
+            const float4* f4 = reinterpret_cast<const float4*>(f);
+            const int n4 = nx >> 2;
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int i = tid + k * FP_THREADS;
+                if (i < n4) {
+                    const float4 v = f4[i];
+                    fv4[i] = v;
+                    if (!isfinite(v.x) || !isfinite(v.y) || !isfinite(v.z) || !isfinite(v.w)) bad = 1;
+                    mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w))); mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+                }
+            }
+        } else {
+            for (int i = tid; i < nx; i += FP_THREADS) {
+                const float v = f[i];
+                fv[i] = v;
+                if (!isfinite(v)) bad = 1;
+                mn = fminf(mn, v); mx = fmaxf(mx, v);
+            }
         }
-        if (tid == 0) { s_flag = 0; s_many = 0; }
+        if (tid == 0) { s_flag = 0; s_many = 0; s_fail = 0; }
+        if (tid == 64) {
+            // a hint: the medians of the row one (else two) dispatch generations earlier, if they have been written
+            int ok = 0;
+            if (hint && !hist_only) {
+#pragma unroll 1
+                for (int g = 1; g <= 2 && !ok; g++) {
+                    const int hr = row - g * gen;
+                    if (hr < 0) break;
+                    const unsigned h0 = __hip_atomic_load(&hint[3 * hr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned h1 = __hip_atomic_load(&hint[3 * hr + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned h2 = __hip_atomic_load(&hint[3 * hr + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h0 & h1 & h2 & FP_HINT_VALID) {
+                        const unsigned hh[3] = {h0, h1, h2};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const float m = __uint_as_float(hh[k] & ~FP_HINT_VALID);
+                            br_lo[k] = __float_as_uint(m * (1.f - FP_HINT_FRAC)); br_hi[k] = __float_as_uint(m * (1.f + FP_HINT_FRAC));
+                        }
+                        ok = 1;
+                    }
+                }
+            }
+            s_hint_ok = ok;
+        }
         __syncthreads();
         if (bad) s_flag = 2;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
-        if (lane == 0) { red_min[tid >> 6] = mn; red_max[tid >> 6] = mx; }
+        if (lane == 0) { red_min[wave] = mn; red_max[wave] = mx; }
+        const int nd = nx - 8;
+        const unsigned rank0 = nd > 0 ? (unsigned)((nd - 1) / 2) : 0u;
+        if (tid < 3) { sel_prefix[tid] = 0; sel_rank[tid] = rank0; ncoll[tid] = 0; }
+#define FP_KEYS(i)                                                                                                      \
+                    const float v1 = fv[i], v3 = fv[i + 2], v5 = fv[i + 4], v7 = fv[i + 6], v9 = fv[i + 8];               \
+                    const unsigned k2 = __float_as_uint(fabsf(v5 - v7));                                                    \
+                    const unsigned k3 = __float_as_uint(fabsf((2.f * v5) - v3 - v7));                                        \
+                    const unsigned k5 = __float_as_uint(fabsf((6.f * v5) - (4.f * v3) - (4.f * v7) + v1 + v9));
+        // ---- bracket path ------------------------------------------------------------------------------------------
+        const int segcap = maxwords / (3 * (FP_THREADS / 64));            // the segments live in the (still unused) stream buffer
+        const bool bracket = !hist_only && nd >= FP_MIN_ND && segcap >= FP_MIN_SEG;    // workgroup-uniform
+        bool done = false;                                                 // workgroup-uniform: the medians are in sel_prefix[]
+        // (FPV_*: knock-out switches of tools/exp builds; the Makefile never defines them)
+#ifdef FPV_NOMED
+        if (tid < 3) sel_prefix[tid] = __float_as_uint(tid == 0 ? 8.6f : (tid == 1 ? 14.9f : 50.8f));
+        done = true;
+#else
+        if (bracket) {
+            unsigned* samp = &hist[0][0];
+            unsigned* seg = words;                                         // [3][16 waves][segcap]
+#ifdef FPV_NOHINT
+            const int first_attempt = 1;
+#else
+            const int first_attempt = s_hint_ok ? 0 : 1;                   // (workgroup-uniform)
+#endif
+#pragma unroll 1
+            for (int attempt = first_attempt; attempt < 2 && !done; attempt++) {
+            if (attempt == 1) {                                            // (attempt 0: br_lo / br_hi from the hint)
+                {
+                    const int i = (int)(((long long)tid * nd) >> 10);      // FP_NSAMP = FP_THREADS = 1024 samples at a fixed stride
+                    FP_KEYS(i)
+                    samp[tid] = k2; samp[1024 + tid] = k3; samp[2048 + tid] = k5;
+                }
+                __syncthreads();
+                if (wave < 3) {
+                    uint32_t k[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) k[r] = samp[1024 * wave + 64 * r + lane];  // any assignment of keys to slots will do
+                    fp_wave_sort1024(k, lane);
+                    // sorted[16 l + r]: the order statistics 512 - H and 512 + H
+                    constexpr int A = FP_NSAMP / 2 - FP_SAMP_HALF, B = FP_NSAMP / 2 + FP_SAMP_HALF;
+                    if (lane == A / 16) br_lo[wave] = k[A % 16];
+                    if (lane == B / 16) br_hi[wave] = k[B % 16];
+                }
+            }
+            __syncthreads();
+            const unsigned lo0 = br_lo[0], hi0 = br_hi[0], lo1 = br_lo[1], hi1 = br_hi[1], lo2 = br_lo[2], hi2 = br_hi[2];
+            unsigned c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                   // per kind: keys < lo, == lo, == hi (hi != lo)
+            unsigned base0 = 0, base1 = 0, base2 = 0;                      // wave-uniform fill of this wave's segments
+            unsigned* seg0 = seg + (0 * (FP_THREADS / 64) + wave) * segcap;
+            unsigned* seg1 = seg + (1 * (FP_THREADS / 64) + wave) * segcap;
+            unsigned* seg2 = seg + (2 * (FP_THREADS / 64) + wave) * segcap;
+#ifdef FPV_NOB3
+            for (int i0 = wave * 64; i0 < 1024; i0 += FP_THREADS) {
+#else
+            for (int i0 = wave * 64; i0 < nd; i0 += FP_THREADS) {         // (wave-uniform trip count: ballots inside)
+#endif
+                const int i = i0 + lane;
+                const bool in = i < nd;
+                const int ii = in ? i : 0;
+                FP_KEYS(ii)
+#define FP_BRACKET(K, LO, HI, C0, BASE, SEG)                                                                            \
+                {                                                                                                       \
+                    c[C0] += (in && K < LO) ? 1u : 0u; c[C0 + 1] += (in && K == LO) ? 1u : 0u;                          \
+                    c[C0 + 2] += (in && K == HI && HI != LO) ? 1u : 0u;                                                 \
+                    const bool inb = in && K > LO && K < HI;                                                            \
+                    const unsigned long long bal = __ballot(inb);                                                       \
+                    const unsigned pos = BASE + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)); \
+                    if (inb && pos < (unsigned)segcap) SEG[pos] = K;                                                    \
+                    BASE += (unsigned)__popcll(bal);                                                                    \
+                }
+                FP_BRACKET(k2, lo0, hi0, 0, base0, seg0)
+                FP_BRACKET(k3, lo1, hi1, 3, base1, seg1)
+                FP_BRACKET(k5, lo2, hi2, 6, base2, seg2)
+#undef FP_BRACKET
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                unsigned v = c[q];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+                c[q] = v;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 9; q++) cpart[wave][q] = c[q];
+                segn[0][wave] = base0; segn[1][wave] = base1; segn[2][wave] = base2;
+                if (base0 > (unsigned)segcap || base1 > (unsigned)segcap || base2 > (unsigned)segcap) s_fail = 1;
+            }
+            for (int i = tid; i < 3 * 1024; i += FP_THREADS) (&hist[0][0])[i] = 0;      // (the samples are done with)
+            __syncthreads();
+            if (tid < 3) {
+                unsigned lt = 0, eql = 0, eqh = 0, nin = 0;
+                for (int w = 0; w < FP_THREADS / 64; w++) { lt += cpart[w][3 * tid]; eql += cpart[w][3 * tid + 1]; eqh += cpart[w][3 * tid + 2]; nin += segn[tid][w]; }
+                const unsigned r = sel_rank[tid], lo = br_lo[tid], hi = br_hi[tid];
+                unsigned need = 0;
+#ifdef FPV_NOST2
+                if (true) sel_prefix[tid] = __float_as_uint(tid == 0 ? 8.6f : (tid == 1 ? 14.9f : 50.8f));
+                else
+#endif
+                if (r < lt) s_fail = 1;
+                else if (r < lt + eql) sel_prefix[tid] = lo;
+                else if (r < lt + eql + nin) {
+                    need = 1;
+                    sel_rank[tid] = r - lt - eql;
+                    const unsigned span = hi - lo - 2u;                    // keys inside: lo + 1 .. hi - 1 -> rel = key - lo - 1 in [0, span]
+                    const int bits = span ? 32 - __clz((int)span) : 0;
+                    br_shift[tid] = bits > 11 ? (unsigned)(bits - 11) : 0u;
+                } else if (r < lt + eql + nin + eqh) sel_prefix[tid] = hi;
+                else s_fail = 1;
+#ifdef FPV_NOB3
+                s_fail = 0; need = 0; sel_prefix[tid] = __float_as_uint(tid == 0 ? 8.6f : (tid == 1 ? 14.9f : 50.8f));
+#endif
+                br_need[tid] = need;
+            }
+            __syncthreads();
+            if (!s_fail) {                                                 // workgroup-uniform
+                // histogram of the collected keys on (key - lo - 1) >> shift: every wave its own segments
+#pragma unroll 1
+                for (int kd = 0; kd < 3; kd++) {
+                    if (!br_need[kd]) continue;
+                    const unsigned n = segn[kd][wave], lo = br_lo[kd], sh = br_shift[kd];
+                    const unsigned* sg = seg + (kd * (FP_THREADS / 64) + wave) * segcap;
+                    for (unsigned j = lane; j < n; j += 64) { const unsigned d = (sg[j] - lo - 1u) >> sh; atomicAdd(&hist[kd][d >> 1], 1u << ((d & 1u) * 16)); }
+                }
+                __syncthreads();
+                if (tid < 192 && br_need[tid >> 6]) {                      // one wave per histogram, 32 bins (16 words) per lane
+                    const int kd = tid >> 6;
+                    unsigned cw[16], mine = 0;
+#pragma unroll
+                    for (int w = 0; w < 16; w++) { cw[w] = hist[kd][16 * lane + w]; mine += (cw[w] & 0xffffu) + (cw[w] >> 16); }
+                    unsigned incl = mine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                    const unsigned excl = incl - mine, r = sel_rank[kd];
+                    if (r >= excl && r < incl) {                           // the one lane whose bins hold the rank
+                        unsigned rr = r - excl, b = 0, found = 0;
+#pragma unroll
+                        for (int w = 0; w < 32; w++) {
+                            const unsigned cnt = (w & 1) ? (cw[w >> 1] >> 16) : (cw[w >> 1] & 0xffffu);
+                            const bool here = !found && rr < cnt;
+                            if (here) { b = 32u * lane + w; found = 1; }
+                            if (!found) rr -= cnt;
+                        }
+                        sel_rank[kd] = rr;
+                        sel_prefix[kd] = b;                                // the bin for now
+                    }
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int kd = 0; kd < 3; kd++) {
+                    if (!br_need[kd]) continue;
+                    const unsigned n = segn[kd][wave], lo = br_lo[kd], sh = br_shift[kd], bin = sel_prefix[kd];
+                    const unsigned* sg = seg + (kd * (FP_THREADS / 64) + wave) * segcap;
+                    for (unsigned j = lane; j < n; j += 64) {
+                        const unsigned key = sg[j];
+                        if (((key - lo - 1u) >> sh) == bin) { const unsigned q = atomicAdd(&ncoll[kd], 1u); if (q < FP_NCOLL) coll[kd][q] = key; }
+                    }
+                }
+                __syncthreads();
+                if (tid < 3 && br_need[tid]) {                             // the rank-th smallest of the bin's keys
+                    const int n = (int)ncoll[tid];
+                    if (n > FP_NCOLL) s_fail = 1;
+                    else {
+                        const unsigned r = sel_rank[tid];
+                        unsigned best = 0;
+#pragma unroll 1
+                        for (int a = 0; a < n; a++) {
+                            const unsigned ka = coll[tid][a];
+                            unsigned below = 0, equal = 0;
+#pragma unroll 1
+                            for (int cc = 0; cc < n; cc++) { below += coll[tid][cc] < ka; equal += coll[tid][cc] == ka; }
+                            if (r >= below && r < below + equal) { best = ka; break; }
+                        }
+                        sel_prefix[tid] = best;
+                    }
+                }
+                __syncthreads();
+            }
+            done = !s_fail;
+            if (!done) {                                                   // next: the sampled bracket, then the histogram passes; from scratch
+                __syncthreads();
+                if (tid < 3) { sel_prefix[tid] = 0; sel_rank[tid] = rank0; ncoll[tid] = 0; }
+                if (tid == 0) { s_many = 0; s_fail = 0; }
+#ifdef FPV_STAT
+                if (tid == 0 && attempt == 1) s_flag = 16;                 // (experiment: count these rows as refused)
+#endif
+                __syncthreads();
+            }
+            }
+        }
+#endif
+        __syncthreads();
         // lower medians of the 2nd / 3rd / 5th order differences, exact: radix select in two histogram passes of 11 bits
         // (2048 bins as pairs of 16-bit counters in one word: a row has fewer than 65536 pixels) and a third pass that just
         // collects the handful of keys that share the 22 leading bits (a histogram pass over the last 10 bits only if they are
-        // many: rows with long runs of equal differences).  An LDS atomic costs its ~64 cycles per wave instruction whatever
-        // the addresses, and the histogram atomics were 1.0 of this kernel's 1.7 ms with four 8-bit passes.
-        const int nd = nx - 8;
-        if (tid < 3) { sel_prefix[tid] = 0; sel_rank[tid] = nd > 0 ? (unsigned)((nd - 1) / 2) : 0u; ncoll[tid] = 0; }
-        __syncthreads();
-        if (nd > 0) {
+        // many: rows with long runs of equal differences).
+        if (nd > 0 && !done) {
 #pragma unroll 1
             for (int pass = 0; pass < 3; pass++) {
                 const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
@@ -151,11 +481,6 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
                 }
                 const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1], p2 = sel_prefix[2];
                 const int up = pass == 0 ? 31 : (pass == 1 ? 21 : 10);   // keys take part when they agree above this bit position
-#define FP_KEYS(i)                                                                                                      \
-                    const float v1 = fv[i], v3 = fv[i + 2], v5 = fv[i + 4], v7 = fv[i + 6], v9 = fv[i + 8];               \
-                    const unsigned k2 = __float_as_uint(fabsf(v5 - v7));                                                    \
-                    const unsigned k3 = __float_as_uint(fabsf((2.f * v5) - v3 - v7));                                        \
-                    const unsigned k5 = __float_as_uint(fabsf((6.f * v5) - (4.f * v3) - (4.f * v7) + v1 + v9));
                 if (collect) {
                     for (int i = tid; i < nd; i += FP_THREADS) {
                         FP_KEYS(i)
@@ -178,7 +503,6 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
                         if ((k5 >> up) == (p2 >> up)) { const unsigned d = (k5 >> shift) & dmask; atomicAdd(&hist[2][d >> 1], 1u << ((d & 1u) * 16)); }
                     }
                 }
-#undef FP_KEYS
                 __syncthreads();
                 if (collect) {
                     if (ncoll[0] > FP_NCOLL || ncoll[1] > FP_NCOLL || ncoll[2] > FP_NCOLL) {
@@ -228,6 +552,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
                 __syncthreads();
             }
         }
+#undef FP_KEYS
         if (tid == 0) {
             float minv = red_min[0], maxv = red_max[0];
             for (int w = 1; w < FP_THREADS / 64; w++) { minv = fminf(minv, red_min[w]); maxv = fmaxf(maxv, red_max[w]); }
@@ -236,6 +561,10 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
                 n2 = 1.0483579 * (double)__uint_as_float(sel_prefix[0]);
                 n3 = 0.6052697 * (double)__uint_as_float(sel_prefix[1]);
                 n5 = 0.1772048 * (double)__uint_as_float(sel_prefix[2]);
+                if (hint) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) __hip_atomic_store(&hint[3 * row + k], sel_prefix[k] | FP_HINT_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             double stdev = n3;
             if (n2 != 0. && n2 < stdev) stdev = n2;
@@ -262,8 +591,12 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
         if (iseed < 0) iseed += FP_NRANDOM;
         // the float row is replaced in place by the quantised integers (same LDS words; each
         // element is read and rewritten by one thread, and the medians are done with it)
+#ifdef FPV_NOQUANT
+        for (int i = tid; i < nx; i += FP_THREADS) vals[i] = (int)(fv[i] * 2.f);
+#else
         for (int i = tid; i < nx; i += FP_THREADS)
             vals[i] = fp_nint((((double)fv[i] - zeropt) / delta) + (double)rnd[fp_rand_index(rnd, iseed, i)] - 0.5);
+#endif
     } else {
         if (BYTEPIX == 1) {
             const uint8_t* p = (const uint8_t*)src + (size_t)row * row_stride_elems;
@@ -280,32 +613,59 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
     for (int i = tid; i < maxwords; i += FP_THREADS) words[i] = 0;
     __syncthreads();
 
-    // ---- pass 1: per 32-pixel block: split level fs and bit length
-    const int hw = tid >> 5, l32 = tid & 31;                      // FP_THREADS/32 half waves, one block each at a time
-    for (int b = hw; b < nblk; b += FP_THREADS / 32) {
-        const int i = 32 * b + l32;
-        const bool in = i < nx;
-        const unsigned d = in ? rice_diff<BYTEPIX>(vals, i) : 0u;
-        const unsigned long long psum64 = half_sum_u64((unsigned long long)d);
+    // ---- pass 1: a thread takes 8 consecutive pixels, the 4 threads of a quad one 32-pixel block (the last block of a row
+    // may have fewer runs: pixels beyond the row count as absent, the quad works as a whole): zig-zag differences (kept in
+    // registers for pass 2), the block's split level fs, the bit lengths
+    constexpr int NIT = (FP_MAXNX / 8 + FP_THREADS - 1) / FP_THREADS;     // runs of 8 pixels per thread
+    const int nq = (nx + 7) >> 3, sub = tid & 3;
+    unsigned dd[NIT][8], ioff[NIT];                                  // differences; bit offset of the run inside its block's codes
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = tid + it * FP_THREADS, b = q >> 2;
+        unsigned long long ps = 0;
+        int prev = (8 * q - 1 < nx) ? vals[q ? 8 * q - 1 : 0] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = 8 * q + j;
+            const bool in = i < nx;
+            const int v = in ? vals[i] : prev;
+            int pd = v - prev;
+            if (BYTEPIX == 1) pd = (int)(signed char)pd;
+            if (BYTEPIX == 2) pd = (int)(short)pd;
+            unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
+            if (BYTEPIX == 1) d &= 0xffu;
+            if (BYTEPIX == 2) d &= 0xffffu;
+            dd[it][j] = in ? d : 0u;
+            ps += in ? d : 0u;
+            prev = v;
+        }
+        ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
         const int thisblock = min(32, nx - 32 * b);
-        double dpsum = ((double)psum64 - (double)(thisblock / 2) - 1.) / (double)thisblock;
+        double dpsum = ((double)ps - (double)(thisblock / 2) - 1.) / (double)thisblock;
         if (dpsum < 0.) dpsum = 0.;
         unsigned psum = ((unsigned)dpsum) >> 1;
         int fs = 0;
         for (; psum > 0; fs++) psum >>= 1;
-        unsigned len;
-        int code;                                                 // what goes into the fsbits field
-        if (fs >= RP::fsmax) { len = in ? RP::bbits : 0; code = RP::fsmax + 1; }
-        else if (fs == 0 && psum64 == 0) { len = 0; code = 0; }
-        else { len = in ? ((d >> fs) + 1u + (unsigned)fs) : 0u; code = fs + 1; }
-        const unsigned long long tot = half_sum_u64((unsigned long long)len);
-        if (l32 == 0) { blkbits[b] = (unsigned)tot + RP::fsbits; fsv[b] = (uint8_t)code; }
+        int code;                                                     // what goes into the fsbits field
+        if (fs >= RP::fsmax) code = RP::fsmax + 1;
+        else if (fs == 0 && ps == 0) code = 0;
+        else code = fs + 1;
+        unsigned len = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool in = 8 * q + j < nx;
+            if (in) len += code == RP::fsmax + 1 ? (unsigned)RP::bbits : (code == 0 ? 0u : (dd[it][j] >> (code - 1)) + 1u + (unsigned)(code - 1));
+        }
+        unsigned incl = len;
+        { const unsigned t = __shfl_up(incl, 1, 64); if (sub >= 1) incl += t; }
+        { const unsigned t = __shfl_up(incl, 2, 64); if (sub >= 2) incl += t; }
+        ioff[it] = incl - len;
+        if (b < nblk && sub == 3) { blkbits[b] = incl + RP::fsbits; fsv[b] = (uint8_t)code; }
     }
     __syncthreads();
     // ---- exclusive scan of the block lengths (nblk <= 512 <= FP_THREADS); the stream starts
     // with the first pixel
     {
-        __shared__ unsigned wsum[FP_THREADS / 64];
         const unsigned mine = (tid < nblk) ? blkbits[tid] : 0u;
         unsigned incl = mine;
 #pragma unroll
@@ -325,34 +685,39 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
         return;
     }
     // ---- pass 2: write the codes
-    if (tid == 0) {
-        unsigned first = (unsigned)vals[0];
-        if (BYTEPIX == 1) first &= 0xffu;
-        if (BYTEPIX == 2) first &= 0xffffu;
-        put_bits(words, 0, first, 8 * BYTEPIX);
-    }
-    for (int b = hw; b < nblk; b += FP_THREADS / 32) {
-        const int i = 32 * b + l32;
-        const bool in = i < nx;
-        const unsigned d = in ? rice_diff<BYTEPIX>(vals, i) : 0u;
+#ifndef FPV_NOPASS2
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = tid + it * FP_THREADS, b = q >> 2;
+        if (q >= nq) continue;
         const int code = fsv[b];
-        unsigned len = 0;
-        if (in) {
-            if (code == RP::fsmax + 1) len = RP::bbits;
-            else if (code != 0) len = (d >> (code - 1)) + 1u + (unsigned)(code - 1);
-        }
-        const unsigned off = blkbits[b] + RP::fsbits + half_excl_scan_u32(len, l32);
-        if (l32 == 0) put_bits(words, blkbits[b], (unsigned)code, RP::fsbits);
-        if (in && len) {
-            if (code == RP::fsmax + 1) put_bits(words, off, d, RP::bbits);
-            else {
-                const int fs = code - 1;
-                const unsigned top = d >> fs;
-                put_bits(words, off + top, 1u, 1);                 // `top` zeros, then a one
-                if (fs) put_bits(words, off + top + 1u, d & ((1u << fs) - 1u), fs);
+        fp_bitw bw;
+        if (q == 0) {                                                 // the row's first pixel as it is, then block 0
+            bw.init(words, 0u);
+            unsigned first = (unsigned)vals[0];
+            if (BYTEPIX == 1) first &= 0xffu;
+            if (BYTEPIX == 2) first &= 0xffffu;
+            bw.put(first, 8 * BYTEPIX);
+        } else bw.init(words, blkbits[b] + (sub ? RP::fsbits + ioff[it] : 0u));
+        if (sub == 0) bw.put((unsigned)code, RP::fsbits);
+        if (code != 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (8 * q + j < nx) {
+                    const unsigned d = dd[it][j];
+                    if (code == RP::fsmax + 1) bw.put(d, RP::bbits);
+                    else {
+                        const int fs = code - 1;
+                        bw.zeros(d >> fs);                            // `top` zeros, then a one
+                        bw.put(1u, 1);
+                        if (fs) bw.put(d & ((1u << fs) - 1u), fs);
+                    }
+                }
             }
         }
+        bw.finish();
     }
+#endif
     __syncthreads();
     const unsigned totbits = blkbits[nblk];
     const unsigned nbytes = (totbits + 7) >> 3;
@@ -399,19 +764,30 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
     const size_t capwords = maxwords / 2 + 16, ldshalf = fixed + capwords * 4;
     const bool two = ldshalf + 15 * 1024 <= 80 * 1024 && !ctx->fpack_one_wg;       // (+ the kernel's static LDS: histograms 12 KB, lists, sums)
     fp_tile* tiles = (fp_tile*)d_tiles;
+    const int hist_only = ctx->fpack_hist_only;
+    // hints (float rows): one slot of three words per row in the context's workspace, zeroed per call; a dispatch generation =
+    // the workgroups resident at once (two per CU with the short buffer)
+    unsigned* d_hint = nullptr;
+    const int ncu = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const int gen = two ? 2 * ncu : ncu;
+    if (bitpix == -32 && !hist_only) {
+        int rc;
+        d_hint = (unsigned*)bbx_ws(ctx, WS_FPHINT, (size_t)ny * 3 * sizeof(unsigned), &rc); if (rc) return rc;
+        BBX_HIP(hipMemsetAsync(d_hint, 0, (size_t)ny * 3 * sizeof(unsigned), s));
+    }
 #define FP_LAUNCH(BP, FL)                                                                                              \
     do {                                                                                                               \
         if (two) {                                                                                                     \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldshalf)); \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 1>), dim3(ny), dim3(FP_THREADS), ldshalf, s, d_img, ny, nx, (size_t)nx, qlevel, \
-                               dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords);                           \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords, hist_only, d_hint, gen);             \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
-                               dither_seed, d_rnd, d_scratch, stride, tiles, 0);                                       \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen);               \
         } else {                                                                                                       \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 0>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
-                               dither_seed, d_rnd, d_scratch, stride, tiles, 0);                                       \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen);               \
         }                                                                                                              \
     } while (0)
     if (bitpix == -32) FP_LAUNCH(4, true);

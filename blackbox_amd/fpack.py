@@ -177,6 +177,9 @@ def assemble_fz(path, shape, bitpix, heap, nbytes, offsets, zscale=None, zzero=N
 
 
 _BODY = {}
+# fpack_image works in process-wide device / pinned buffers (_BODY, _PIN): one call at a time.  Callers on several threads
+# (the output stage's writers in their overflow fallback, the orchestrating thread writing an unstaged product) queue here.
+_SERIAL = __import__('threading').RLock()
 
 
 def _body_buffers(dev, ny, nx, need=None):
@@ -198,6 +201,11 @@ def fpack_image(ctx, path, img, header=None, quant=None, dither_seed=1):
     lossless.  -> path of the .fz file.  One enqueue on the device (tile streams, offsets, descriptor table:
     bbx_fpack_body), one copy of exactly the bytes of the file body, the rows the quantiser refused gzip-compressed
     on the host as CFITSIO stores them."""
+    with _SERIAL:
+        return _fpack_image(ctx, path, img, header, quant, dither_seed)
+
+
+def _fpack_image(ctx, path, img, header, quant, dither_seed):
     if quant is None:
         quant = 2 if ('Scorr' in path or 'limmag' in path) else (4 if 'Fpsf' in path else 16)
     out = path if path.endswith('.fz') else path + '.fz'
@@ -212,6 +220,7 @@ def fpack_image(ctx, path, img, header=None, quant=None, dither_seed=1):
     dev = img.device
     rowlen = 32 if bitpix == -32 else 8
     need = None
+    # (the kernels run on ctx.stream(); the copies below on torch's current stream: the two must be the same stream)
     for _ in range(2):
         b = _body_buffers(dev, ny, nx, need)
         rnd = _rnd(dev) if bitpix == -32 else None

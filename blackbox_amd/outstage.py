@@ -43,6 +43,20 @@ class _Job:
     __slots__ = ('lane', 'slot', 'img', 'path', 'quant', 'seed', 'bitpix', 'shape', 'header', 'header_ready', 'group', 'bzero')
 
 
+class GroupCancelled(RuntimeError):
+    """the frame this file belongs to was given up (its run failed or was closed): nothing is written"""
+
+
+class _OnStream:
+    """a library context seen through another stream (what fpack.fpack_image asks of a context: .h, .device, .stream())"""
+
+    def __init__(self, ctx, stream):
+        self.h, self.device, self._sp = ctx.h, ctx.device, C.c_void_p(stream.cuda_stream)
+
+    def stream(self):
+        return self._sp
+
+
 class FrameGroup:
     """the files of one frame: done() fires when the last of them is on disk"""
 
@@ -52,9 +66,19 @@ class FrameGroup:
         self.left, self.lock, self.paths, self.error = 1, threading.Lock(), [], None
         self.header_ready = threading.Event()
         self.headers = {}                      # path -> header dict; None -> the header of every other file
+        self.cancelled = False
 
     def set_headers(self, headers):
         self.headers.update(headers)
+        self.header_ready.set()
+
+    def cancel(self, err=None):
+        """the frame will never get its headers (its run failed): writers waiting for them skip the frame's files and
+        release what they hold; the group reports [err]"""
+        with self.lock:
+            self.cancelled = True
+            if self.error is None:
+                self.error = err if err is not None else GroupCancelled('frame cancelled')
         self.header_ready.set()
 
     def seal(self):
@@ -159,12 +183,21 @@ class OutputStage:
         self.q.put(j)
         return out
 
-    def close(self):
+    def close(self, timeout=60.0):
+        """stop the writers.  Frames that never got their headers must have been cancelled by their owner
+        (FrameGroup.cancel; FramePipeline does that when a run fails): a writer still waiting after [timeout] seconds
+        in total is reported instead of being waited for one by one"""
+        import time
         for _ in self.threads:
             self.q.put(None)
+        t_end = time.monotonic() + timeout
         for t in self.threads:
-            t.join(60.0)
+            t.join(max(0.0, t_end - time.monotonic()))
+        stuck = [t.name for t in self.threads if t.is_alive()]
         self.lanes.clear()
+        if stuck:
+            raise RuntimeError('output stage: {} writer thread(s) still waiting (a frame without headers that nobody cancelled?)'
+                               .format(len(stuck)))
 
     # ---- writer thread ----------------------------------------------------------------------------
     def _writer(self, k):
@@ -195,10 +228,14 @@ class OutputStage:
         info = s.h_info.numpy()
         total, nlist, overflow, maxlen = int(info[0]), int(info[1]), int(info[2]), int(info[3])
         if overflow:
-            # heap larger than the slot (an image that hardly compresses) or too many refused rows: the serial path
+            # heap larger than the slot (an image that hardly compresses) or too many refused rows: the serial path, with
+            # its own buffers -- one call at a time in the process (fpack._SERIAL) -- and on THIS thread's stream, behind the
+            # event that says the image is complete
             j.lane.free.put(s)
+            header = self._header(j)
             with torch.cuda.stream(copy_stream):
-                fpack.fpack_image(j.lane.ctx, j.path, j.img, self._header(j), j.quant, j.seed)
+                copy_stream.wait_event(s.ev)
+                fpack.fpack_image(_OnStream(j.lane.ctx, copy_stream), j.path, j.img, header, j.quant, j.seed)
             return
         nbody = ny * rowlen + total
         hb = buf(nbody)
@@ -240,6 +277,8 @@ class OutputStage:
     def _header(j):
         g = j.group
         g.header_ready.wait()
+        if g.cancelled:
+            raise GroupCancelled(j.path)
         h = g.headers.get(j.path)
         if h is None:
             h = g.headers.get(None)

@@ -310,7 +310,8 @@ class FramePipeline:
         self.keep_sub = ('D', 'Scorr', 'Fpsf', 'Fpsferr')        # device products kept on the frame when keep_outputs
         self.log = log
         self.outstage, self.out_base, self.on_written, self.header_hook = outstage, out_base, on_written, header_hook
-        self.stage_limmag = stage_limmag           # False: the caller makes `_trans_limmag` itself (in magnitudes, with a zeropoint)
+        # False: the caller makes `_trans_limmag` itself (in magnitudes, with a zeropoint); a callable(header) decides per frame
+        self.stage_limmag = stage_limmag
         if outstage is not None and out_base is None:
             raise ValueError('outstage needs out_base')
         self.keep_outputs = keep_outputs
@@ -667,7 +668,8 @@ class FramePipeline:
         if sub is not None and sub.get('D') is not None:
             for ext in ('D', 'Scorr', 'Fpsf'):
                 names[ext] = st.submit(ctx, g, sub[ext], '{}_{}.fits'.format(base, ext))
-            if self.stage_limmag:
+            stage_lim = self.stage_limmag(f.header) if callable(self.stage_limmag) else self.stage_limmag
+            if stage_lim:
                 nsig = float(sub['header_trans']['T-NSIGMA'][0])
                 lim = sub['Fpsferr'] * nsig                            # `_trans_limmag` as a flux limit (no zeropoint on this path)
                 names['limmag'] = st.submit(ctx, g, lim, base + '_trans_limmag.fits')
@@ -737,7 +739,10 @@ class FramePipeline:
         live, ndone, exhausted = [], 0, False
         try:
             return self._run(it, live, ndone, exhausted, on_done)
-        except BaseException:
+        except BaseException as e:
+            for f in live:
+                if getattr(f, 'err', None) is None:
+                    f.err = e
             self._abort(live)
             raise
 
@@ -760,6 +765,12 @@ class FramePipeline:
             torch.cuda.synchronize(self.ctx.device)
         except Exception:
             pass
+        # frames of the output stage that will never be finalised: their writers wait for headers -- tell them
+        # (the lanes have drained: every live frame that got as far as _submit_outputs has its group by now)
+        for f in live:
+            g = getattr(f, 'out_group', None)
+            if g is not None and not g.header_ready.is_set():
+                g.cancel(getattr(f, 'err', None))
         self.free_slots = list(range(self.depth))
 
     def _run(self, it, live, ndone, exhausted, on_done):

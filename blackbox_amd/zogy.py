@@ -17,6 +17,8 @@ from . import settings
 from ._lib import lib, check, BBXError as _lib_BBXError
 from .catalogs import format_cat, transient_table         # noqa: F401  (zogy.format_cat)
 
+BBX_ERR_OVERFLOW, BBX_ERR_PSFWIN = -4, -6          # include/bbx.h
+BBX_OPT_ZOGY_KWIN_OFF = 4
 NPAD = 12          # scipy.ndimage.zoom pads 'nearest' inputs by 12 samples before prefiltering
 
 
@@ -457,17 +459,29 @@ class _NoGate:
         return False
 
 
-def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fratio=1.0, dx=0.0, dy=0.0,
-                        subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None,
-                        ref_is_bkgsub=False, ref_bkg_std_mini=None, ref_grid=None, ref_grid_step=32,
-                        cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000,
-                        zogy_gate=None, ref_bkg_std=None):
+def optimal_subtraction(ctx, *args, **kw):
+    try:
+        return _optimal_subtraction(ctx, *args, **kw)
+    finally:
+        # the candidate-list handoffs (zoom -> catalogue search, final ZOGY kernel -> transient search) are keyed on the
+        # frames' addresses inside the context: whatever way this call ends, none of that may outlive it (the caching
+        # allocator hands the same address to the next frame)
+        lib.bbx_zoom_candidates(ctx.h, None, 0.0)
+        lib.bbx_zogy_candidates(ctx.h, 0.0)
+
+
+def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fratio=1.0, dx=0.0, dy=0.0,
+                         subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None,
+                         ref_is_bkgsub=False, ref_bkg_std_mini=None, ref_grid=None, ref_grid_step=32,
+                         cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000,
+                         zogy_gate=None, ref_bkg_std=None):
     """The numerical core of zogy.optimal_subtraction(new_fits, ref_fits, ...) (call sites
     blackbox.py:2350-2354 new-only, 2460-2465 new + ref) on device tensors: background mesh +
     subtraction, variance images, [remapping of the reference to the new frame's grid],
     sub-image ZOGY, stitching, transient candidates with PSF fluxes, [full-source catalogue by
     PSF-weighted optimal photometry].
       new, new_mask : reduced frame (float32, e-) and its mask
+      fratio, dx, dy: flux ratio new / ref and the astrometric scatter, one number or one per sub-image
       ref, ref_mask : reference frame or None (new-only mode, trans_extract False or no ref:
                       the 2350-2354 branch): then only the background products and the catalogue
       ref_is_bkgsub : the reference is a background-subtracted co-add (buildref product);
@@ -532,9 +546,14 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     res['catalog'] = None
     if cat_extract and sub_pn is not None:
         thr = float(cat_nsigma) * hdr['S-BKGSTD'][0]
-        pending = find_peaks_enqueue(ctx, work, thr, max_out=max_sources)
-        scal_n = host_side_meanwhile()
-        ys, xs, pk = find_peaks_collect(ctx, pending)
+        if np.isfinite(thr) and thr > 0:
+            pending = find_peaks_enqueue(ctx, work, thr, max_out=max_sources)
+            scal_n = host_side_meanwhile()
+            ys, xs, pk = find_peaks_collect(ctx, pending)
+        else:                                                        # no usable noise level: nothing is significant
+            lib.bbx_zoom_candidates(ctx.h, None, 0.0)
+            scal_n = host_side_meanwhile()
+            ys = xs = np.zeros(0, np.int32); pk = np.zeros(0, np.float32)
         keep = pk > 0
         ys, xs, pk = ys[keep], xs[keep], pk[keep]
         if ys.size:
@@ -591,17 +610,24 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     # ---- sub-images
     scal = np.zeros((nsub, 6), np.float32)
     scal[:, 0], scal[:, 1] = scal_n, tile_medians(sdr)
-    scal[:, 2], scal[:, 3], scal[:, 4], scal[:, 5] = 1.0, (1.0 / fratio if fratio else 1.0), dx, dy
+    # fratio, dx, dy: one number for the frame or one per sub-image (zogy measures them per sub-image from the matched stars)
+    fr = np.broadcast_to(np.asarray(fratio, np.float64), (nsub,))
+    scal[:, 2], scal[:, 3] = 1.0, np.where(fr != 0, 1.0 / np.where(fr != 0, fr, 1.0), 1.0)
+    scal[:, 4], scal[:, 5] = np.broadcast_to(np.asarray(dx, np.float64), (nsub,)), np.broadcast_to(np.asarray(dy, np.float64), (nsub,))
     sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
-    if frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]:
+    frame_path = frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]
+    if frame_path:
         # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
         outs = zogy_frame_outputs(work)                           # allocated on the caller's stream, filled inside the gate
         sub_pn, sub_pr = sub_pn.contiguous(), sub_pr.contiguous()
-        # the kernel that writes Scorr lists the pixels above the transient threshold for the peak search below
         nsig_cand = float(settings.transient_nsigma if nsigma is None else nsigma)
-        check(lib.bbx_zogy_candidates(ctx.h, nsig_cand), 'bbx_zogy_candidates', ctx.h)
-        with (zogy_gate or _NoGate()):
-            D, _, Scorr, Fpsf, Fpsferr = run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border, outs=outs)
+
+        def zogy_frame_call():
+            # the kernel that writes Scorr lists the pixels above the transient threshold for the peak search below
+            check(lib.bbx_zogy_candidates(ctx.h, nsig_cand), 'bbx_zogy_candidates', ctx.h)
+            with (zogy_gate or _NoGate()):
+                return run_zogy_frame(ctx, work, rwork, bstd, rbstd, sub_pn, sub_pr, scal, size, border, outs=outs)
+        D, _, Scorr, Fpsf, Fpsferr = zogy_frame_call()
         res['D'], res['Scorr'], res['Fpsf'], res['Fpsferr'] = D, Scorr, Fpsf, Fpsferr
     else:
         Vn = Vn if Vn is not None else variance(ctx, work, bstd)
@@ -616,14 +642,29 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
 
     # ---- transient candidates: regions of |Scorr| >= T-NSIGMA, flux = Fpsf at the peak
     nsig = settings.transient_nsigma if nsigma is None else nsigma
-    try:
-        tys, txs, tsc = find_peaks_arrays(ctx, res['Scorr'], nsig)
-        ntrans = int(tys.size)
-    except _lib_BBXError:
-        # more significant pixels than the candidate list holds (a failed subtraction: wrong
-        # reference, gross misalignment): the images stand, the candidate table stays empty
-        tys = txs = np.zeros(0, np.int32); tsc = np.zeros(0, np.float32)
-        ntrans = 'None'
+    for attempt in (0, 1):
+        try:
+            # (the first host wait behind bbx_zogy_frame: its device-side checks surface here)
+            tys, txs, tsc = find_peaks_arrays(ctx, res['Scorr'], nsig)
+            ntrans = int(tys.size)
+        except _lib_BBXError as e:
+            if e.code == BBX_ERR_PSFWIN and frame_path and attempt == 0:
+                # the matched-filter kernels of these PSFs do not fit their row window (include/bbx.h, BBX_OPT_ZOGY_KWIN_OFF):
+                # V(S) of this call is off by more than the tolerance.  Once more on all rows -- the frame keeps its subtraction
+                check(lib.bbx_set_option(ctx.h, BBX_OPT_ZOGY_KWIN_OFF, 1), 'bbx_set_option', ctx.h)
+                try:
+                    zogy_frame_call()
+                finally:
+                    check(lib.bbx_set_option(ctx.h, BBX_OPT_ZOGY_KWIN_OFF, 0), 'bbx_set_option', ctx.h)
+                hdr_t['Z-KWIN'] = (False, 'ZOGY matched-filter kernels on a row window?')
+                continue
+            if e.code != BBX_ERR_OVERFLOW:
+                raise
+            # more significant pixels than the candidate list holds (a failed subtraction: wrong
+            # reference, gross misalignment): the images stand, the candidate table stays empty
+            tys = txs = np.zeros(0, np.int32); tsc = np.zeros(0, np.float32)
+            ntrans = 'None'
+        break
     if tys.size:
         d_ys, d_xs = torch.from_numpy(tys.astype(np.int64)).to(ctx.device), torch.from_numpy(txs.astype(np.int64)).to(ctx.device)
         fe = torch.stack([res['Fpsf'][d_ys, d_xs], res['Fpsferr'][d_ys, d_xs]]).cpu().numpy()
@@ -635,9 +676,9 @@ def optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fra
     for h in (hdr, hdr_t):
         h['Z-SIZE'] = (size, '[pix] size of (square) ZOGY subimages')
         h['Z-BSIZE'] = (border, '[pix] size of ZOGY subimage borders')
-    hdr_t['Z-DX'] = (float(dx), '[pix] dx median offset full image')
-    hdr_t['Z-DY'] = (float(dy), '[pix] dy median offset full image')
-    hdr_t['Z-FNR'] = (float(fratio), 'median flux ratio (Fnew/Fref) full image')
+    hdr_t['Z-DX'] = (float(np.median(dx)), '[pix] dx median offset full image')
+    hdr_t['Z-DY'] = (float(np.median(dy)), '[pix] dy median offset full image')
+    hdr_t['Z-FNR'] = (float(np.median(fratio)), 'median flux ratio (Fnew/Fref) full image')
     if frame_stats:
         # statistics over the unmasked pixels (new frame's mask), clipped like zogy's header values
         # (both queued, one copy back)

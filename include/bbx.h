@@ -101,6 +101,10 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * worst case first (two workgroups per CU) and redo the rows that do not fit with the full buffer; 1: full buffer for
  * every row (one workgroup per CU).  Same bytes either way. */
 #define BBX_OPT_FPACK_ONE_WG 5
+/* BBX_OPT_FPACK_HIST_ONLY (default 0): the three exact row medians of the quantiser's noise estimate come from a sampled
+ * bracket + one counting pass (rows the bracket misses fall back to the radix histograms by themselves); 1: radix
+ * histograms over all keys for every row (round 3's path).  Same medians, same bytes either way. */
+#define BBX_OPT_FPACK_HIST_ONLY 6
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
 
 /* Per-step attribution of device-side errors.  Kernels report list overflow / non-convergence by

@@ -242,6 +242,69 @@ def test_gpu_one_enqueue_path_and_output_stage(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_output_stage_overflow_fallback_with_concurrent_writers_and_cancel(tmp_path):
+    """(i) Every image overflows its slot (heap_frac tiny): all writers take the fallback through fpack.fpack_image at once --
+    its process-wide buffers are used by one call at a time, on the writer's own stream behind the image's event -- and the
+    files equal the step-by-step path byte for byte.  (ii) A frame that never gets its headers is cancelled by its owner:
+    the writers skip its files, release their slots, the group reports the error, close() returns at once."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import threading
+    import time
+    from blackbox_amd import reduce as R
+    from blackbox_amd import fpack as P
+    from blackbox_amd import outstage
+    ctx = R.Context(0)
+    rs = np.random.RandomState(21)
+    ny, nx = 64, 2640
+    imgs = [(100 * (k + 1) + rs.normal(0, 5 + k, (ny, nx))).astype(np.float32) for k in range(6)]
+    hdr = {'OBJECT': 'overflow'}
+    want = []
+    for k, a in enumerate(imgs):
+        pth = P.fpack_image_serial(ctx, str(tmp_path / ('ser%d_red.fits' % k)), torch.from_numpy(a).to(ctx.device), hdr, 16, dither_seed=3)
+        want.append(open(pth, 'rb').read())
+    stage = outstage.OutputStage(ctx.device, ny, nx, nwriters=3, nslots=6, heap_frac=1e-4, dither_seed=3)
+    ev, done = threading.Event(), []
+
+    def on_done(g):
+        done.append(g)
+        ev.set()
+    lane_stream = torch.cuda.Stream(device=ctx.device)
+    keep = []
+    with torch.cuda.stream(lane_stream):
+        g = stage.new_group('f', on_done)
+        for k, a in enumerate(imgs):
+            t = torch.from_numpy(a).to(ctx.device)
+            keep.append(t)
+            stage.submit(ctx, g, t, str(tmp_path / ('ovf%d_red.fits' % k)), quant=16)
+        g.seal()
+    g.set_headers({None: hdr})
+    assert ev.wait(60.0) and done[0].error is None, done and done[0].error
+    for k in range(6):
+        assert open(str(tmp_path / ('ovf%d_red.fits.fz' % k)), 'rb').read() == want[k], k
+    stage.close()
+    # (ii) cancellation
+    stage = outstage.OutputStage(ctx.device, ny, nx, nwriters=2, nslots=2, dither_seed=3)
+    ev2, done2 = threading.Event(), []
+    with torch.cuda.stream(lane_stream):
+        g2 = stage.new_group('dead', lambda g: (done2.append(g), ev2.set()))
+        for k in range(2):
+            stage.submit(ctx, g2, keep[k], str(tmp_path / ('dead%d_red.fits' % k)), quant=16)
+        g2.seal()
+    time.sleep(0.3)                                                # both writers now wait for the headers
+    assert not ev2.is_set()
+    g2.cancel(ValueError('the frame failed'))
+    assert ev2.wait(10.0)
+    assert isinstance(done2[0].error, ValueError) and not any((tmp_path / ('dead%d_red.fits.fz' % k)).exists() for k in range(2))
+    assert stage.lane(ctx).free.qsize() == 2                       # both device slots came back
+    t0 = time.monotonic()
+    stage.close(timeout=20.0)
+    assert time.monotonic() - t0 < 5.0
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_short_stream_buffer_and_retry_equal_full_buffer():
     """k_fp_tile with the half-size bit-stream buffer (two workgroups per CU) + the retry of the rows that do not fit
     (BBX_OPT_FPACK_ONE_WG = 0, the default) against the worst-case buffer for every row (= 1): the same bytes, for float
@@ -280,6 +343,55 @@ def test_gpu_short_stream_buffer_and_retry_equal_full_buffer():
     for r, (b, zs, zz) in enumerate(FP.compress_float_image(img, 16, 5)):
         assert t['zscale'][r] == zs and t['zzero'][r] == zz, r
         assert t['heap'][t['offsets'][r]:t['offsets'][r] + t['nbytes'][r]].tobytes() == b, r
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bracket_medians_equal_histogram_medians():
+    """The three exact row medians of the quantiser's noise estimate: sampled bracket + counting pass (default) against
+    the radix histograms over all keys (BBX_OPT_FPACK_HIST_ONLY = 1) -- identical ZSCALE / ZZERO and streams for ordinary
+    noise rows, rows with heavy ties (integer-valued pixels: the bracket's segments overflow or its ends carry the rank),
+    constant rows, rows with a step in the noise level half way (the sample median sits on the edge of two populations),
+    rows of two values; and both against the oracle's encoder (numpy medians)."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R, _lib
+    from blackbox_amd import fpack as P
+    ctx = R.Context(0)
+    rs = np.random.RandomState(77)
+    nx = 10560
+    rows = []
+    for k in range(24):
+        rows.append((300 + rs.normal(0, 3 + k, nx)).astype(np.float32))                 # ordinary
+    for k in range(6):
+        rows.append(np.round(300 + rs.normal(0, 2 + k, nx)).astype(np.float32))          # integer-valued: ties everywhere
+    rows.append(np.full(nx, 7.5, np.float32))                                            # constant
+    r = (100 + rs.normal(0, 4, nx)).astype(np.float32); r[nx // 2:] += rs.normal(0, 40, nx - nx // 2).astype(np.float32); rows.append(r)
+    r = np.where(rs.rand(nx) < 0.5, 1.0, 2.0).astype(np.float32); rows.append(r)        # two values
+    r = (50 + rs.normal(0, 1e-3, nx)).astype(np.float32); r[::97] += 1e4; rows.append(r)
+    r = (rs.standard_cauchy(nx) * 5).astype(np.float32); rows.append(r)                 # heavy tails
+    r = np.zeros(nx, np.float32); r[: nx // 2 + 7] = rs.normal(0, 5, nx // 2 + 7); rows.append(r)   # half the differences are exactly 0
+    img = np.stack(rows)
+    got = {}
+    for hist in (1, 0):
+        _lib.check(_lib.lib.bbx_set_option(ctx.h, 6, hist), 'bbx_set_option')
+        got[hist] = P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), 16, 9)
+    _lib.check(_lib.lib.bbx_set_option(ctx.h, 6, 0), 'bbx_set_option')
+    a, b = got[0], got[1]
+    for k in ('nbytes', 'offsets', 'flag', 'zscale', 'zzero', 'heap'):
+        assert np.array_equal(a[k], b[k]), k
+    nref = 0
+    for r in range(img.shape[0]):
+        q = FP.quantize_row(img[r], r + 1 + 9 - 1, 16)
+        if q is None:
+            assert a['flag'][r] == 1, r
+            nref += 1
+            continue
+        idata, zs, zz = q
+        assert a['flag'][r] == 0 and a['zscale'][r] == zs and a['zzero'][r] == zz, r
+        assert a['heap'][a['offsets'][r]:a['offsets'][r] + a['nbytes'][r]].tobytes() == FP.rice_encode(idata, 4), r
+    assert nref >= 1
     ctx.close()
 
 

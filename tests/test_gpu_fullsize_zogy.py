@@ -47,9 +47,26 @@ def scene():
     ref, ref_mask = bench.synth_reference(torch, ctx.device, ex['scene0'], 3000)
     del ex['scene0']
     torch.cuda.empty_cache()
-    yield dict(ctx=ctx, data=data, mask=mask, header=header, hm=hm, ref=ref, ref_mask=ref_mask, trans=ex['transients'],
-               pre_sat=stages['data_xtalk'], bpm=bpm)
+    sc = dict(ctx=ctx, data=data, mask=mask, header=header, hm=hm, ref=ref, ref_mask=ref_mask, trans=ex['transients'],
+              pre_sat=stages['data_xtalk'], bpm=bpm)
+    yield sc
     ctx.close()
+
+
+def oracle_mesh(scene, which='new'):
+    """the ORACLE's background mesh of the reduced frame (or of the reference with its own sky): filled + filtered mini
+    images, the background-subtracted frame and the sigma image, all made by oracle/zogy_core.py from the pixels -- nothing
+    of the product's subtraction stage enters (kept with the module's scene: ~1 min of numpy per frame)"""
+    key = 'oracle_mesh_' + which
+    if key not in scene:
+        hd = (scene['data'] if which == 'new' else scene["ref"] + 120.0).cpu().numpy()
+        hm = (scene['mask'] if which == 'new' else scene['ref_mask']).cpu().numpy()
+        med_raw, std_raw = Z.get_back_mini(hd, hm, None, box=BOX)
+        med_o, std_o = Z.fill_filter_mini(med_raw), Z.fill_filter_mini(std_raw)
+        sub_o = (hd - Z.mini2back(med_o, (NY, NX), BOX)).astype(F)
+        sig_o = Z.mini2back(std_o, (NY, NX), BOX, channels=(med_o.shape[0] // 2, med_o.shape[1] // 8) if which == 'new' else None)
+        scene[key] = dict(med_raw=med_raw, med=med_o, std=std_o, sub=sub_o, sig=sig_o)
+    return scene[key]
 
 
 def test_reduce_flags(scene):
@@ -95,10 +112,9 @@ def test_background_mesh_fullsize(scene):
     data, mask = scene['data'], scene['mask']
     med, std = G.get_back(ctx, data, mask, bkg_boxsize=BOX)
     ctx.sync()
-    hd, hm = data.cpu().numpy(), mask.cpu().numpy()
-    med_o, std_o = Z.get_back_mini(hd, hm, None, box=BOX)
-    assert med_o.shape == (NY // BOX, NX // BOX) and np.isnan(med_o).any()      # edge boxes are fully masked
-    med_o, std_o = Z.fill_filter_mini(med_o), Z.fill_filter_mini(std_o)
+    om = oracle_mesh(scene)
+    assert om['med_raw'].shape == (NY // BOX, NX // BOX) and np.isnan(om['med_raw']).any()      # edge boxes are fully masked
+    med_o, std_o = om['med'], om['std']
     mh, sh = med.cpu().numpy(), std.cpu().numpy()
     assert np.array_equal(mh, med_o)
     np.testing.assert_allclose(sh, std_o, rtol=3e-6)
@@ -106,41 +122,70 @@ def test_background_mesh_fullsize(scene):
     G.mini2back(ctx, med, (NY, NX), bkg_boxsize=BOX, interp_Xchan=True, subtract_from=work, want_bkg=False)
     bstd = G.mini2back(ctx, std, (NY, NX), bkg_boxsize=BOX, interp_Xchan=False)
     ctx.sync()
-    bkg_o = Z.mini2back(med_o, (NY, NX), BOX)
-    want = hd - bkg_o
     got = work.cpu().numpy()
     # |bkg| ~ 250 e-: one float32 ulp of the background is 3e-5
-    assert np.abs(got - want).max() <= 6.2e-5
-    del want, got, bkg_o
-    bstd_o = Z.mini2back(std_o, (NY, NX), BOX, channels=(med_o.shape[0] // 2, med_o.shape[1] // 8))
-    np.testing.assert_allclose(bstd.cpu().numpy(), bstd_o, rtol=2e-6)
+    assert np.abs(got - om['sub']).max() <= 6.2e-5
+    del got
+    np.testing.assert_allclose(bstd.cpu().numpy(), om['sig'], rtol=2e-6)
+
+
+PSF_S = 49
+
+
+def tile_medians(mini):
+    """median of a mini image over the boxes of each sub-image (what zogy hands run_ZOGY as sigma_n, sigma_r)"""
+    bs = SIZE // BOX
+    nsy, nsx = NY // SIZE, NX // SIZE
+    return np.median(mini.reshape(nsy, bs, nsx, bs).transpose(0, 2, 1, 3).reshape(nsy * nsx, bs * bs), axis=1).astype(F)
 
 
 @pytest.mark.parametrize('branch', ['ref-with-mesh', 'ref-bkgsub'])
 def test_zogy_fullsize(scene, branch):
-    """optimal_subtraction on the full frame (64 sub-images of 1400^2) against the oracle's
-    run_zogy on whole sub-images (a corner, an interior one, the last one); every injected
-    transient is recovered with its flux; the transient list of those sub-images and the PSF
-    photometry of the catalogue against the oracle.  Both ways a reference comes: with its own sky (mesh + sigma image made here) or as buildref delivers
-    it -- background-subtracted with its `_bkg_std_mini` image ('ref-bkgsub': the configuration bench.py times)."""
+    """optimal_subtraction on the full frame in the SURVEY 8d configuration -- 64 sub-images of 1400^2, one 49 x 49 Moffat PSF
+    pair PER SUB-IMAGE (FWHM gradient across the field), flux ratio, sigma_n, sigma_r, dx, dy per sub-image
+    (blackbox.py:3754-3759, call 2460-2465) -- against the oracle's run_zogy on whole sub-images (a corner, an interior
+    one, the last one).  The oracle's inputs are made BY THE ORACLE from the reduced frame: its own background mesh,
+    background-subtracted frames, sigma images, variance images max(x, 0) + sigma^2 and per-sub-image sigma scalars
+    (oracle_mesh); nothing of the product's subtraction stage is fed back to it.  Every injected transient is recovered with
+    its flux; the transient list of those sub-images and the PSF photometry of the catalogue against the oracle.  Both ways
+    a reference comes: with its own sky (mesh + sigma image made here) or as buildref delivers it -- background-subtracted
+    with its `_bkg_std_mini` image ('ref-bkgsub': the configuration bench.py times)."""
     ctx = scene['ctx']
-    pn, pr = bench.moffat_stamp(25, 4.0), bench.moffat_stamp(25, 3.6)
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)       # noqa: E731
-    dx, dy = 0.03, 0.02
-    kw = dict(ref_is_bkgsub=False)
+    nsy, nsx = NY // SIZE, NX // SIZE
+    zi = bench.zogy_inputs(torch, ctx.device, nsy, nsx, PSF_S, BOX, NY, NX)
+    pn_all, pr_all = zi['psf_new'].cpu().numpy(), zi['psf_ref'].cpu().numpy()
+    assert pn_all.shape == (64, PSF_S, PSF_S) and len({p.tobytes() for p in pn_all}) == 64
+    fr_all, dx_all, dy_all = zi['fratio'], zi['dx'], zi['dy']
+    om = oracle_mesh(scene)
     if branch == 'ref-bkgsub':
-        kw = dict(ref_is_bkgsub=True, ref_bkg_std_mini=np.full((NY // BOX, NX // BOX), 8.0, F))
-    res = G.optimal_subtraction(ctx, scene['data'], scene['ref'], scene['mask'], scene['ref_mask'], d(pn), d(pr),
-                                fratio=1.0, dx=dx, dy=dy, cat_extract=True, **kw)
+        ref_in = scene['ref']
+        kw = dict(ref_is_bkgsub=True, ref_bkg_std_mini=zi['ref_bkg_std_mini'])
+        Rw_o = scene['ref'].cpu().numpy()
+        sdr_o = zi['ref_bkg_std_mini']
+        rsig_o = Z.mini2back(sdr_o, (NY, NX), BOX)
+    else:
+        ref_in = scene["ref"] + 120.0                                              # a reference that still carries its sky
+        kw = dict(ref_is_bkgsub=False)
+        omr = oracle_mesh(scene, 'ref')
+        Rw_o, sdr_o, rsig_o = omr['sub'], omr['std'], omr['sig']
+    res = G.optimal_subtraction(ctx, scene['data'], ref_in, scene['mask'], scene['ref_mask'], zi['psf_new'], zi['psf_ref'],
+                                fratio=fr_all, dx=dx_all, dy=dy_all, cat_extract=True, **kw)
     ctx.sync()
     if branch == 'ref-bkgsub':
         assert res['ref_bkgsub'] is scene['ref'] and 'bkg_mini_ref' not in res          # no mesh of the reference
-        assert float(res['bkg_std_ref'].min()) == float(res['bkg_std_ref'].max()) == 8.0
     hdr = res['header_trans']
     assert res['header_new']['Z-P'][0] is True and hdr['Z-SIZE'][0] == SIZE and hdr['Z-BSIZE'][0] == BORDER
-    nsx = NX // SIZE
-    Nw, Rw = res['data_bkgsub'], res['ref_bkgsub']
-    Vn, Vr = G.variance(ctx, Nw, res['bkg_std']), G.variance(ctx, Rw, res['bkg_std_ref'])
+    assert 'Z-KWIN' not in hdr                                                          # the row window (228 of 1400 rows at S = 49) held
+    # the oracle's side: frames, sigma images, variance images, scalars
+    Nw_o, nsig_o = om['sub'], om['sig']
+    Vn_o = (np.maximum(Nw_o, F(0)) + nsig_o * nsig_o).astype(F)
+    Vr_o = (np.maximum(Rw_o, F(0)) + rsig_o * rsig_o).astype(F)
+    sn_o, sr_o = tile_medians(om['std']), tile_medians(np.asarray(sdr_o, F))
+    # the scalars the product handed its kernels: sigma_n, sigma_r are medians of (identical / 3e-6-close) mini images
+    np.testing.assert_allclose(res['scal'][:, 0], sn_o, rtol=3e-6)
+    np.testing.assert_allclose(res['scal'][:, 1], sr_o, rtol=3e-6)
+    assert len(set(res['scal'][:, 0].tolist())) > 32 and len(set(res['scal'][:, 1].tolist())) > 8
+    Nw = res['data_bkgsub']
 
     def embed(p):
         k = np.zeros((L, L), F); h = p.shape[0] // 2
@@ -150,20 +195,18 @@ def test_zogy_fullsize(scene, branch):
         return k
 
     def cut(t, sy, sx):
-        """one padded sub-image from a device frame"""
+        """one padded sub-image from a host frame"""
         out = np.zeros((L, L), F)
         y0, x0 = sy * SIZE - BORDER, sx * SIZE - BORDER
         ya, yb, xa, xb = max(y0, 0), min(y0 + L, NY), max(x0, 0), min(x0 + L, NX)
-        out[ya - y0:yb - y0, xa - x0:xb - x0] = t[ya:yb, xa:xb].cpu().numpy()
+        out[ya - y0:yb - y0, xa - x0:xb - x0] = t[ya:yb, xa:xb]
         return out
-    Pn, Pr = embed(pn), embed(pr)
     worst = {}
     trans_h = res['transients']
     for (sy, sx) in ((0, 0), (3, 4), (7, 7)):
         k = sy * nsx + sx
-        sn, sr = res['scal'][k, 0], res['scal'][k, 1]
-        D, Sm, Sc, Fp, Fe = Z.run_zogy(cut(Nw, sy, sx), cut(Rw, sy, sx), Pn, Pr, sn, sr, 1.0, 1.0, cut(Vn, sy, sx),
-                                       cut(Vr, sy, sx), dx, dy)
+        D, Sm, Sc, Fp, Fe = Z.run_zogy(cut(Nw_o, sy, sx), cut(Rw_o, sy, sx), embed(pn_all[k]), embed(pr_all[k]), sn_o[k], sr_o[k],
+                                       1.0, 1.0 / fr_all[k], cut(Vn_o, sy, sx), cut(Vr_o, sy, sx), dx_all[k], dy_all[k])
         inner = (slice(BORDER, BORDER + SIZE), slice(BORDER, BORDER + SIZE))
         tile = (slice(sy * SIZE, (sy + 1) * SIZE), slice(sx * SIZE, (sx + 1) * SIZE))
         # float32 rounding of a 2-D FFT spreads along the row and the column of a bright pixel (the
@@ -171,7 +214,7 @@ def test_zogy_fullsize(scene, branch):
         # images carry errors of ~2e-6 of the brightest input pixel of their row / column, on both
         # sides (tools/dbg/zogy_dbg.py: HIP and numpy complex64 are equally far from a float64
         # evaluation, 0.22 / 0.24 e- on the rows of a saturated star with 1.4e5 e- pixels)
-        a = np.abs(cut(Nw, sy, sx)) + np.abs(cut(Rw, sy, sx))
+        a = np.abs(cut(Nw_o, sy, sx)) + np.abs(cut(Rw_o, sy, sx))
         big = np.maximum(a.max(axis=1)[:, None], a.max(axis=0)[None, :])[inner]
         fe = Fe[inner]
         tols = {}
@@ -266,7 +309,7 @@ def test_zogy_fullsize(scene, branch):
     cat = res['catalog']
     assert cat is not None and len(cat['X_POS']) > 5000
     assert np.isfinite(cat['E_FLUX_OPT']).all() and (cat['E_FLUXERR_OPT'] > 0).all()
-    work_h, sig_h = Nw.cpu().numpy(), res['bkg_std'].cpu().numpy()
+    work_h, sig_h = Nw.cpu().numpy(), nsig_o
     thr = 5.0 * res['header_new']['S-BKGSTD'][0]
     peaks_o = [(y, x, v) for (y, x, v) in Z.find_transients_fast(work_h, thr) if v > 0 and mask_h[y, x] == 0]
     ys_c, xs_c = cat['Y_POS'].astype(np.int64) - 1, cat['X_POS'].astype(np.int64) - 1
@@ -276,7 +319,8 @@ def test_zogy_fullsize(scene, branch):
                                      np.argsort(ys_c)[:20], np.argsort(xs_c)[-20:]]))
     assert pick.size >= 1000
     V_h = (np.maximum(work_h, F(0)) + sig_h * sig_h).astype(F)
-    f_o, e_o = Z.psf_optflux_vec(work_h, V_h, pn, ys_c[pick], xs_c[pick])
+    stamps = pn_all[(ys_c[pick] // SIZE) * nsx + xs_c[pick] // SIZE]                     # the PSF of the sub-image a source falls in
+    f_o, e_o = Z.psf_optflux_vec(work_h, V_h, stamps, ys_c[pick], xs_c[pick])
     np.testing.assert_allclose(cat['E_FLUX_OPT'][pick], f_o, rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(cat['E_FLUXERR_OPT'][pick], e_o, rtol=1e-5)
 
