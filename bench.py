@@ -273,7 +273,8 @@ def cpu_baseline(workload):
                                           '(no LA-Cosmic, no ZOGY: packages absent)')
 
 
-def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None, outdir=None, nwriters=8):
+def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, pool, barrier, prof_ctx=None, outdir=None, nwriters=8,
+                 raw_files=None, nreaders=3):
     """Steady-state rate of a FramePipeline: depth + W + K + depth frames go through it in one run, fed
     continuously.  The first [depth] frames fill the pipeline, then W warm-up frames; the clock runs from the
     completion of the last warm-up frame to the completion of the K-th frame after it -- exactly K completions with
@@ -284,6 +285,9 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
     outdir: run the output stage as well (outstage.OutputStage: every image product of a frame tile-compressed on its
     lane and written as .fits.fz by writer threads, the small products by the frame's callback); a frame then counts
     as complete when its last file is on disk (files are removed again at once: the directory may be a RAM disk).
+    raw_files: the input side as well (instage.InputStage): the timed frames are read from these `.fits(.fz)` files (cycled) by
+    reader threads, decoded on the device (bbx_funpack_tiles) and handed to the pipeline with their ready events -- the
+    reference's read_hdulist (blackbox.py:1451) inside the measured loop.
     -> dict(dt, dt_all (idle to idle, all frames), ...)"""
     from blackbox_amd import _lib
     from blackbox_amd.pipeline import FramePipeline
@@ -318,6 +322,7 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
         def on_written(f, group):
             """a writer thread, after the last image of the frame: the small products (mini images, tables, header files),
             then the frame counts; its files are removed again"""
+            t_w, t_c = time.perf_counter(), time.thread_time()
             try:
                 if group.error is not None:
                     raise group.error
@@ -341,6 +346,8 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
                 with lock:
                     mark['bytes'] += nb
                     mark['files'] += len(group.paths) + len(small)
+                    mark['small_wall'] = mark.get('small_wall', 0.0) + time.perf_counter() - t_w
+                    mark['small_cpu'] = mark.get('small_cpu', 0.0) + time.thread_time() - t_c
             except BaseException as e:
                 mark['err'] = e
             count(f)
@@ -362,12 +369,20 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
     pipe.lane_cpu = [0.0, 0.0, 0]
     t_cpu_main = time.thread_time()
 
+    src = None
+    if raw_files is not None:
+        from blackbox_amd import instage
+        src = instage.InputStage(ctx, lambda i: raw_files[i % len(raw_files)] if i < n_all else None, (geom.ny_raw, geom.nx_raw),
+                                 nreaders=nreaders, nbuf=depth + 4, ahead=4)
+
     def on_done(idx, f):
+        if src is not None:
+            src.release(f.raw)                   # the device is through with the frame's raw buffer
         if stage is None:
             count(f)
     barrier()
     t_all0 = time.perf_counter()
-    pipe.run([(raws[i % len(raws)], {}) for i in range(n_all)], on_done=on_done)
+    pipe.run(src if src is not None else [(raws[i % len(raws)], {}) for i in range(n_all)], on_done=on_done)
     torch.cuda.synchronize()
     if stage is not None and not all_done.wait(300.0):
         raise RuntimeError('output stage: %d of %d frames written (%r)' % (mark['n'], n_all, mark['err']))
@@ -394,7 +409,55 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
     pipe.close()
     if stage is not None:
         stage.close()
+        out['writer_ms_per_image'] = {k: dict(wall=1e3 * w / max(1, n), cpu=1e3 * c / max(1, n)) for k, (w, c, n) in stage.phase.items()}
+        out['small_files_ms_per_frame'] = dict(wall=1e3 * mark.get('small_wall', 0.0) / max(1, n_all), cpu=1e3 * mark.get('small_cpu', 0.0) / max(1, n_all))
+    if src is not None:
+        out['bytes_read'] = src.bytes_read
+        src.close()
     return out
+
+
+def measure_io(torch, ctx, tel, geom, raws, kw, depth, lanes, pool, barrier, args, section=lambda name: None, frames=40):
+    """SURVEY 8d timing item (iii), measured: the pipeline from raw files to product files (RAM disk and local scratch)"""
+    # ---- measured: the same pipeline with the output stage in the loop (SURVEY 8d timing item iii) ------------
+    meas = {}
+    import shutil
+    import tempfile
+    for label, root in (('ramdisk', '/dev/shm'), ('scratch', tempfile.gettempdir())):
+        if not os.path.isdir(root) or not os.access(root, os.W_OK):
+            continue
+        td = tempfile.mkdtemp(prefix='bbx_bench_out_', dir=root)
+        try:
+            # the raw frames as the telescope delivers them: fpacked uint16 (`.fits.fz`, lossless Rice), one file per
+            # distinct raw buffer, read back in turn
+            from blackbox_amd import fpack as P
+            raw_files = []
+            for i, rw in enumerate(raws[:8]):
+                raw_files.append(P.fpack_image(ctx, os.path.join(td, 'raw_%02d.fits' % i), rw, {'EXPTIME': 60.0, 'OBJECT': 'synthetic'}))
+            raw_mb = sum(os.path.getsize(p_) for p_ in raw_files) / len(raw_files) / 1e6
+            r4 = run_pipeline(torch, ctx, tel, geom, raws, kw, frames, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers,
+                              raw_files=raw_files, nreaders=args.readers)
+            meas[label] = dict(frames_per_s=frames / r4['dt'], ms_per_frame=1e3 * r4['dt'] / frames, dir=root,
+                               MB_per_frame=r4['bytes_written'] / max(1, r4['n_all']) / 1e6,
+                               files_per_frame=r4['files_written'] / max(1, r4['n_all']), writer_threads=args.writers,
+                               reader_threads=args.readers, raw_MB_per_frame=raw_mb,
+                               host_ms_per_frame=r4['host_ms_per_frame'], writer_ms_per_image=r4.get('writer_ms_per_image'),
+                               small_files_ms_per_frame=r4.get('small_files_ms_per_frame'))
+            r5 = run_pipeline(torch, ctx, tel, geom, raws, kw, frames, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers)
+            meas[label]['output_side_only'] = dict(frames_per_s=frames / r5['dt'], note='inputs resident in HBM (round 3 figure)')
+        except Exception as e:
+            import traceback
+            meas[label] = dict(error=repr(e), trace=traceback.format_exc()[-1500:])
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+        section('io_inclusive.measured ' + label)
+    meas['note'] = ('the timed pipeline from files to files: every raw frame read from its fpacked `.fits.fz` file by reader '
+                    'threads (pinned buffer, one H2D copy, Rice decode on the device: bbx_funpack_tiles), every product of the frame '
+                    'on disk before the frame counts: _red, _mask, _D, _Scorr, '
+                    '_Fpsf, _trans_limmag tile-compressed on the lane that made them (bbx_fpack_body, q = 16 / lossless / 16 / 2 / '
+                    '4 / 2) and written as .fits.fz by writer threads; _bkg_mini, _bkg_std_mini, _cat, _trans, _hdr by the '
+                    'frame\'s callback; steady state over 40 frames; product files removed as soon as written')
+    return meas
 
 
 def load_pmc(args):
@@ -447,6 +510,7 @@ def main():
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
     ap.add_argument('--lanes', type=int, default=None, help='stage-C lanes (context + stream + issuing thread) per GPU')
     ap.add_argument('--writers', type=int, default=8, help='writer threads of the output stage (io_inclusive.measured)')
+    ap.add_argument('--readers', type=int, default=3, help='reader threads of the input stage (io_inclusive.measured)')
     ap.add_argument('--io-only', action='store_true', help='only the measured I/O-inclusive run (debug)')
     ap.add_argument('--psf-size', type=int, default=49, help='side of the PSF stamps of the ZOGY stage (SURVEY 8d: 49)')
     args = ap.parse_args()
@@ -520,6 +584,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.io_only:
+        def section(name):
+            sys.stderr.write('[bench] %s\n' % name); sys.stderr.flush()
+        print(json.dumps(measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section, frames=args.steps)))
+        pool.close()
+        return
     # ---- serial reference run of one frame (stage breakdown + isolated kernel timings; untimed) --
     from blackbox_amd import zogy as G
     stage_ms = {}
@@ -741,29 +811,7 @@ def main():
         section('long_run')
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
         section('io_inclusive (pcie, serial writers)')
-        # ---- measured: the same pipeline with the output stage in the loop (SURVEY 8d timing item iii) ------------
-        meas = {}
-        import shutil
-        import tempfile
-        for label, root in (('ramdisk', '/dev/shm'), ('scratch', tempfile.gettempdir())):
-            if not os.path.isdir(root) or not os.access(root, os.W_OK):
-                continue
-            td = tempfile.mkdtemp(prefix='bbx_bench_out_', dir=root)
-            try:
-                r4 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 40, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers)
-                meas[label] = dict(frames_per_s=40 / r4['dt'], ms_per_frame=1e3 * r4['dt'] / 40, dir=root,
-                                   MB_per_frame=r4['bytes_written'] / max(1, r4['n_all']) / 1e6,
-                                   files_per_frame=r4['files_written'] / max(1, r4['n_all']), writer_threads=args.writers)
-            except Exception as e:
-                meas[label] = dict(error=repr(e))
-            finally:
-                shutil.rmtree(td, ignore_errors=True)
-            section('io_inclusive.measured ' + label)
-        meas['note'] = ('the timed pipeline with every product of a frame on disk before the frame counts: _red, _mask, _D, _Scorr, '
-                        '_Fpsf, _trans_limmag tile-compressed on the lane that made them (bbx_fpack_body, q = 16 / lossless / 16 / 2 / '
-                        '4 / 2) and written as .fits.fz by writer threads; _bkg_mini, _bkg_std_mini, _cat, _trans, _hdr by the '
-                        'frame\'s callback; inputs resident in HBM; steady state over 40 frames; files removed as soon as written')
-        out['io_inclusive']['measured'] = meas
+        out['io_inclusive']['measured'] = measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section)
     pool.close()
     if rank == 0:
         if not args.no_cpu:

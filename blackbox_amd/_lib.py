@@ -53,6 +53,9 @@ SIGNATURES = {
     'bbx_version': (_i, []),
     'bbx_sync': (_i, [_vp, _vp]),
     'bbx_set_option': (_i, [_vp, _i, _i]),
+    'bbx_wait': (_i, [_vp, _vp]),
+    'bbx_copy_kernel': (_i, [_vp, _vp, C.c_size_t, _vp]),
+    'bbx_event_wait': (_i, [_vp, _i]),
     'bbx_step_mark': (_i, [_vp, _vp, _vp]),
     'bbx_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'bbx_event_destroy': (None, [_vp]),
@@ -119,6 +122,83 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 def _strerror(code):
     return lib.bbx_strerror(int(code)).decode()
+
+
+WAIT_SLEEP_US = int(os.environ.get('BBX_WAIT_SLEEP_US', '50'))       # host waits of the multi-threaded paths: poll + sleep (0: spin)
+
+
+KERNEL_COPY_MAX = int(os.environ.get('BBX_KERNEL_COPY_MAX', str(4 << 20)))    # fetch / push: copies up to this size go by a kernel
+
+
+def push(ctx, *arrays):
+    """numpy arrays -> device tensors without a blocking pageable copy: the values go into the context's pinned upload
+    buffer and a kernel on the current stream reads them from there (stream-ordered; the buffer is a ring: a slice is reused
+    after 64 later pushes at the earliest, long after its kernel has run)"""
+    import numpy as np
+    import torch
+    outs = []
+    sp = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        n = a.nbytes
+        t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0].reshape(-1)).dtype, device=ctx.device)
+        if n == 0:
+            outs.append(t)
+            continue
+        if n > KERNEL_COPY_MAX // 4:
+            t.copy_(torch.from_numpy(a))
+            outs.append(t)
+            continue
+        ring = ctx.__dict__.get('_push_ring')
+        if ring is None:
+            ring = ctx.__dict__['_push_ring'] = [torch.empty(64 * (KERNEL_COPY_MAX // 4), dtype=torch.uint8, pin_memory=True), 0]
+        slot = ring[1] % 64
+        ring[1] += 1
+        off = slot * (KERNEL_COPY_MAX // 4)
+        ring[0].numpy()[off:off + n] = a.reshape(-1).view(np.uint8)
+        check(lib.bbx_copy_kernel(C.c_void_p(t.data_ptr()), C.c_void_p(ring[0].data_ptr() + off), n, sp), 'bbx_copy_kernel')
+        outs.append(t)
+    return outs if len(outs) > 1 else outs[0]
+
+
+def wait_event(ev, sleep_us=None):
+    """wait for a torch.cuda.Event without spinning on a core (bbx_event_wait)"""
+    us = WAIT_SLEEP_US if sleep_us is None else sleep_us
+    if us <= 0:
+        ev.synchronize()
+        return
+    h = ev.cuda_event
+    if not h:
+        return                                  # never recorded: nothing to wait for
+    check(lib.bbx_event_wait(C.c_void_p(h), int(us)), 'bbx_event_wait')
+
+
+def fetch(ctx, *tensors):
+    """device tensors -> numpy arrays (copies) with ONE host wait, which sleeps between polls when the context was told to
+    (BBX_OPT_WAIT_SLEEP_US): asynchronous copies into the context's pinned staging buffer on the current stream, bbx_wait.
+    What `.cpu().numpy()` does with a spinning hipStreamSynchronize per tensor."""
+    import torch
+    ts = [t.contiguous() for t in tensors]
+    sizes = [(t.numel() * t.element_size() + 63) // 64 * 64 for t in ts]
+    total = max(64, sum(sizes))
+    pin = ctx.__dict__.get('_fetch_pin')
+    if pin is None or pin.numel() < total:
+        pin = ctx.__dict__['_fetch_pin'] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
+    views, off = [], 0
+    sp = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    for t, nb in zip(ts, sizes):
+        n = t.numel() * t.element_size()
+        v = pin[off:off + n].view(t.dtype).view(t.shape)
+        if n and n <= KERNEL_COPY_MAX:
+            # by a kernel, not by the copy engine: these few bytes must not queue behind the output stage's 100 MB transfers
+            check(lib.bbx_copy_kernel(C.c_void_p(pin.data_ptr() + off), C.c_void_p(t.data_ptr()), n, sp), 'bbx_copy_kernel')
+        elif n:
+            v.copy_(t, non_blocking=True)
+        views.append(v)
+        off += nb
+    check(lib.bbx_wait(ctx.h, sp), 'bbx_wait', ctx.h)
+    out = [v.numpy().copy() for v in views]
+    return out if len(out) > 1 else out[0]
 
 
 def f32x16(values):

@@ -72,6 +72,8 @@ struct bbx_ctx {
     double bcand_nsig;
     const float* bcand_img;    // the frame the list in WS_BCAND belongs to (consumed by bbx_find_peaks), its median scalar and factor
     const float* bcand_img_med; double bcand_img_nsig; size_t bcand_npix;
+    int    wait_sleep_us;      // BBX_OPT_WAIT_SLEEP_US: host waits poll an event and sleep this long between polls (0: hipStreamSynchronize)
+    hipEvent_t wait_ev; int32_t* h_err;   // bbx_wait's event, bbx_sync's pinned copy of the error words
     int    fpack_hist_only;    // BBX_OPT_FPACK_HIST_ONLY: row medians by radix histograms over all keys (tests: same bytes as the bracket path)
     int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context

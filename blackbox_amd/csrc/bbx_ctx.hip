@@ -1,6 +1,7 @@
 // bbx_ctx.hip -- context, workspace and error plumbing of libbbx_hip.so
 #include "bbx_common.h"
 #include <stdlib.h>
+#include <time.h>
 
 int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line) {
     if (ctx)
@@ -55,6 +56,8 @@ void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s) {
     (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], s);
     ctx->prof_n++;
 }
+
+#define BBX_HIP0(call) do { if ((call) != hipSuccess) return BBX_ERR_HIP; } while (0)
 
 extern "C" {
 
@@ -139,18 +142,72 @@ void bbx_ctx_destroy(bbx_ctx* ctx) {
     if (ctx->d_satlist) (void)hipFree(ctx->d_satlist);
     if (ctx->d_nonlin) (void)hipFree(ctx->d_nonlin);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->prof_ev) { for (int i = 0; i < 2 * BBX_PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]); free(ctx->prof_ev); free(ctx->prof_slot); }
     free(ctx);
 }
 
+__global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n, int words) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if (words) {
+        const size_t nw = n >> 2;
+        for (size_t i = i0; i < nw; i += step) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+        for (size_t i = (nw << 2) + i0; i < n; i += step) dst[i] = src[i];
+    } else {
+        for (size_t i = i0; i < n; i += step) dst[i] = src[i];
+    }
+}
+
+int bbx_copy_kernel(void* dst, const void* src, size_t nbytes, void* stream) {
+    if (!dst || !src) return BBX_ERR_ARG;
+    if (nbytes == 0) return BBX_OK;
+    const int words = (((uintptr_t)dst | (uintptr_t)src) & 3) == 0;
+    const size_t items = words ? (nbytes >> 2) + 3 : nbytes;
+    const int blocks = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (uint8_t*)dst, nbytes, words);
+    if (hipGetLastError() != hipSuccess) return BBX_ERR_HIP;
+    return BBX_OK;
+}
+
+// poll + sleep until [ev] has completed
+static int bbx_poll_event(hipEvent_t ev, int sleep_us) {
+    struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)sleep_us * 1000L;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return BBX_OK;
+        if (e != hipErrorNotReady) return BBX_ERR_HIP;
+        (void)hipGetLastError();
+        nanosleep(&ts, nullptr);
+    }
+}
+
+int bbx_event_wait(void* event, int sleep_us) {
+    if (!event) return BBX_ERR_ARG;
+    if (sleep_us <= 0) { BBX_HIP0(hipEventSynchronize((hipEvent_t)event)); return BBX_OK; }
+    return bbx_poll_event((hipEvent_t)event, sleep_us);
+}
+
+int bbx_wait(bbx_ctx* ctx, void* stream) {
+    if (!ctx) return BBX_ERR_ARG;
+    if (ctx->wait_sleep_us <= 0) { BBX_HIP(hipStreamSynchronize((hipStream_t)stream)); return BBX_OK; }
+    if (!ctx->wait_ev) BBX_HIP(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
+    BBX_HIP(hipEventRecord(ctx->wait_ev, (hipStream_t)stream));
+    const int rc = bbx_poll_event(ctx->wait_ev, ctx->wait_sleep_us);
+    if (rc) return bbx_hip_fail(ctx, hipGetLastError(), "hipEventQuery", __LINE__);
+    return BBX_OK;
+}
+
 int bbx_sync(bbx_ctx* ctx, void* stream) {
     if (!ctx) return BBX_ERR_ARG;
-    int32_t err[4] = {0, 0, 0, 0};
-    BBX_HIP(hipMemcpyAsync(err, ctx->d_err, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    BBX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (!ctx->h_err) BBX_HIP(hipHostMalloc((void**)&ctx->h_err, 4 * sizeof(int32_t), hipHostMallocDefault));
+    int32_t* err = ctx->h_err;
+    err[0] = 0;
+    BBX_HIP(hipMemcpyAsync(err, ctx->d_err, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    { const int rc = bbx_wait(ctx, stream); if (rc) return rc; }
     if (err[0]) {
-        BBX_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(err), (hipStream_t)stream));
+        BBX_HIP(hipMemsetAsync(ctx->d_err, 0, 4 * sizeof(int32_t), (hipStream_t)stream));
         // (the window check first: the caller repeats that call on all rows, and a list overflow of the same call shows again then)
         if (err[0] & BBX_DERR_PSF_WINDOW) return BBX_ERR_PSFWIN;
         if (err[0] & BBX_DERR_LIST_OVERFLOW) return BBX_ERR_OVERFLOW;
@@ -177,11 +234,11 @@ int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (option == BBX_OPT_ZOGY_KWIN_OFF) { ctx->zogy_kwin_off = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_FPACK_ONE_WG) { ctx->fpack_one_wg = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_FPACK_HIST_ONLY) { ctx->fpack_hist_only = value ? 1 : 0; return BBX_OK; }
+    if (option == BBX_OPT_WAIT_SLEEP_US) { ctx->wait_sleep_us = value > 0 ? value : 0; return BBX_OK; }
     return BBX_ERR_ARG;
 }
 
 // ---- stream plumbing (see bbx.h) ---------------------------------------------------------
-#define BBX_HIP0(call) do { if ((call) != hipSuccess) return BBX_ERR_HIP; } while (0)
 
 int bbx_event_create(void** out_event) {
     if (!out_event) return BBX_ERR_ARG;

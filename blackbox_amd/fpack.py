@@ -49,6 +49,14 @@ def _pinned(nbytes):
     return t[:nbytes]
 
 
+def gzip_row(row_bytes):
+    """a tile CFITSIO would not quantise, as it goes into the GZIP_COMPRESSED_DATA column: gzip of the big-endian floats.
+    Level 1 like CFITSIO's compress2mem_from_mem (deflateInit2(.., 1, ..)): these are the constant edge rows, and the writer
+    threads of the output stage compress 300 of them per frame"""
+    import gzip
+    return gzip.compress(row_bytes, 1, mtime=0)
+
+
 def compress_tiles(ctx, img, qlevel=16, dither_seed=1, _view=False):
     """img: contiguous 2-D device tensor (float32 -> quantised; uint8 / int16 / int32 ->
     lossless).  -> (heap bytes numpy uint8 [total], tiles numpy structured [ny]: nbytes,
@@ -91,7 +99,7 @@ def compress_tiles(ctx, img, qlevel=16, dither_seed=1, _view=False):
         rows = img[torch.from_numpy(bad).to(dev)].cpu().numpy().astype('>f4')
         parts, pos = [], total
         for k, r in enumerate(bad):
-            g = gzip.compress(rows[k].tobytes(), 6, mtime=0)
+            g = gzip_row(rows[k].tobytes())
             gz_nbytes[r], gz_offsets[r] = len(g), pos
             pos += len(g)
             parts.append(np.frombuffer(g, np.uint8))
@@ -248,7 +256,7 @@ def _fpack_image(ctx, path, img, header, quant, dither_seed):
         table = body[:ny * rowlen].view([('len', '>i4'), ('off', '>i4'), ('glen', '>i4'), ('goff', '>i4'), ('zscale', '>f8'), ('zzero', '>f8')])
         pos = total
         for k, r in enumerate(listed):
-            g = gzip.compress(rows[k].tobytes(), 6, mtime=0)
+            g = gzip_row(rows[k].tobytes())
             table['glen'][r], table['goff'][r] = len(g), pos
             pos += len(g)
             maxgz = max(maxgz, len(g))

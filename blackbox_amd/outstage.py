@@ -20,12 +20,13 @@ import gzip
 import os
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
 
 from . import fitsio, fpack
-from ._lib import lib, check
+from ._lib import lib, check, wait_event
 
 MAX_LIST = 4096                      # rows per image the quantiser may refuse before the image falls back to the serial path
 
@@ -134,7 +135,9 @@ class FzLane:
                                  C.c_void_p(self.d_tiles.data_ptr()), C.c_void_p(self.d_off.data_ptr()),
                                  C.c_void_p(s.d_body.data_ptr()), s.cap, C.c_void_p(s.d_info.data_ptr()), MAX_LIST,
                                  C.c_void_p(st.cuda_stream)), 'bbx_fpack_body', self.ctx.h)
-        s.h_info.copy_(s.d_info, non_blocking=True)
+        # the summary by a kernel copy (the copy engines are busy with other images' 100 MB bodies)
+        check(lib.bbx_copy_kernel(C.c_void_p(s.h_info.data_ptr()), C.c_void_p(s.d_info.data_ptr()), s.h_info.numel() * 8,
+                                  C.c_void_p(st.cuda_stream)), 'bbx_copy_kernel')
         s.ev.record(st)
         return s, bitpix
 
@@ -152,6 +155,7 @@ class OutputStage:
         self.q = queue.Queue()
         self.threads = [threading.Thread(target=self._writer, args=(k,), daemon=True) for k in range(nwriters)]
         self.bytes_written, self.files_written = 0, 0
+        self.phase = {}                       # writer phases: name -> [wall s, cpu s, calls]
         self.stat_lock = threading.Lock()
         for t in self.threads:
             t.start()
@@ -219,12 +223,31 @@ class OutputStage:
             except BaseException as e:                                     # reported with the frame
                 j.group.file_done(j.path, e)
 
+    def _tick(self, acc, name, t):
+        """per-phase accounting of the writers: (wall, cpu) seconds since [t] -> acc[name]; -> new t"""
+        now = (time.perf_counter(), time.thread_time())
+        a = acc.setdefault(name, [0.0, 0.0])
+        a[0] += now[0] - t[0]; a[1] += now[1] - t[1]
+        return now
+
     def _write(self, j, copy_stream, buf):
+        acc = {}
+        try:
+            self._write_timed(j, copy_stream, buf, acc)
+        finally:
+            with self.stat_lock:
+                for k, (w, c) in acc.items():
+                    a = self.phase.setdefault(k, [0.0, 0.0, 0])
+                    a[0] += w; a[1] += c; a[2] += 1
+
+    def _write_timed(self, j, copy_stream, buf, acc):
         ny, nx = j.shape
         quant = j.bitpix == -32
         rowlen = 32 if quant else 8
         s = j.slot
-        s.ev.synchronize()
+        t = (time.perf_counter(), time.thread_time())
+        wait_event(s.ev)
+        t = self._tick(acc, 'wait_image', t)
         info = s.h_info.numpy()
         total, nlist, overflow, maxlen = int(info[0]), int(info[1]), int(info[2]), int(info[3])
         if overflow:
@@ -238,30 +261,44 @@ class OutputStage:
                 fpack.fpack_image(_OnStream(j.lane.ctx, copy_stream), j.path, j.img, header, j.quant, j.seed)
             return
         nbody = ny * rowlen + total
-        hb = buf(nbody)
+        listed = np.sort(info[4:4 + nlist].copy()) if nlist else None
+        # one pinned buffer: [table + heap | the rows the quantiser refused, as float32], one wait for both copies
+        rbytes = nlist * nx * 4 if (nlist and quant) else 0
+        roff = (nbody + 63) // 64 * 64
+        full = buf(roff + rbytes)
+        hb = full[:nbody]
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(s.ev)
             hb.copy_(s.d_body[:nbody], non_blocking=True)
-            listed = np.sort(info[4:4 + nlist].copy()) if nlist else None
             rows = None
-            if nlist:
-                rows = j.img[torch.from_numpy(listed).to(j.img.device)].to('cpu', non_blocking=False).numpy()
-        copy_stream.synchronize()
+            if rbytes:
+                rows_pin = full[roff:roff + rbytes].view(torch.float32).view(nlist, nx)
+                rows_pin.copy_(j.img.index_select(0, torch.from_numpy(listed).to(j.img.device)), non_blocking=True)
+            cev = torch.cuda.Event()
+            cev.record(copy_stream)
+        wait_event(cev)
+        t = self._tick(acc, 'copy_out', t)
         j.lane.free.put(s)                                                 # the device slot can take the next image
         body = hb.numpy()
+        if rbytes:
+            rows = rows_pin.numpy()
         parts, maxgz = [], 0
         if nlist:
             table = body[:ny * rowlen].view([('len', '>i4'), ('off', '>i4'), ('glen', '>i4'), ('goff', '>i4'), ('zscale', '>f8'), ('zzero', '>f8')])
             pos = total
             be = rows.astype('>f4')
             for k, r in enumerate(listed):
-                g = gzip.compress(be[k].tobytes(), 6, mtime=0)
+                g = fpack.gzip_row(be[k].tobytes())
                 table['glen'][r], table['goff'][r] = len(g), pos
                 pos += len(g)
                 maxgz = max(maxgz, len(g))
                 parts.append(g)
         pcount = total + sum(len(g) for g in parts)
-        head = fpack.fz_header_bytes(j.shape, j.bitpix, pcount, maxlen, maxgz, self._header(j), j.seed, j.bzero)
+        t = self._tick(acc, 'gzip_rows', t)
+        header = self._header(j)
+        t = self._tick(acc, 'wait_header', t)
+        head = fpack.fz_header_bytes(j.shape, j.bitpix, pcount, maxlen, maxgz, header, j.seed, j.bzero)
+        t = self._tick(acc, 'format_header', t)
         nb = nbody + (pcount - total)
         with open(j.path, 'wb') as f:
             f.write(head)
@@ -269,6 +306,7 @@ class OutputStage:
             for g in parts:
                 f.write(g)
             f.write(b'\0' * ((-nb) % fitsio.BLOCK))
+        t = self._tick(acc, 'write_file', t)
         with self.stat_lock:
             self.bytes_written += len(head) + nb
             self.files_written += 1

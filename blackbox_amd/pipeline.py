@@ -289,6 +289,12 @@ class FramePipeline:
         self.own_ctx = [R.Context(ctx.device.index) for _ in range(max(1, lanes) - 1)]
         self.lane_stream = [torch.cuda.Stream(device=ctx.device) for _ in range(max(1, lanes))]
         self.lane_ctx = [_LaneCtx(c, st) for c, st in zip([ctx] + self.own_ctx, self.lane_stream)]
+        # many host threads wait on this GPU (lanes, readers, writers): their waits poll + sleep instead of spinning on a core
+        # each (include/bbx.h, BBX_OPT_WAIT_SLEEP_US; BBX_WAIT_SLEEP_US=0 keeps the runtime's spinning waits); the caller's
+        # context gets its setting back in close()
+        for c in self.own_ctx:
+            check(lib.bbx_set_option(c.h, 7, _lib.WAIT_SLEEP_US), 'bbx_set_option', c.h)
+        check(lib.bbx_set_option(ctx.h, 7, _lib.WAIT_SLEEP_US), 'bbx_set_option', ctx.h)
         self.mflat, self.bpm = mflat, bpm
         self.mbias = mbias if (mbias is not None and get_par(settings.subtract_mbias, tel)) else None
         self.xtalk = xtalk_coeffs
@@ -401,6 +407,7 @@ class FramePipeline:
         self.level_feed_left = int(os.environ.get('BBX_LAC_FEED_FRAMES', '0'))
 
     def close(self):
+        lib.bbx_set_option(self.ctx.h, 7, 0)
         if self.own_pool:
             self.pool.close()
         for t in self.lane_thread:
@@ -418,7 +425,9 @@ class FramePipeline:
             c.close()
 
     # ---- stage A ------------------------------------------------------------------
-    def _start(self, idx, raw, header):
+    def _start(self, idx, raw, header, ready=None):
+        """ready: a torch.cuda.Event after which [raw] holds the frame (instage.InputStage: the decode runs on a reader's
+        stream); stage A's stream waits for it, and every later stage of the frame waits for stage A"""
         ctx = self.ctxA
         # device pointers cross the C ABI without their extents: refuse a frame of another shape here
         if (not torch.is_tensor(raw) or not raw.is_cuda or not raw.is_contiguous()
@@ -432,6 +441,8 @@ class FramePipeline:
         f.lane = idx % len(self.lane_ctx)
         sl = self.slots[f.slot]
         sA = self.ctxA.sp
+        if ready is not None:
+            self.sA.wait_event(ready)
         d_mean, d_hos, d_ninf = sl['d_mean'], sl['d_hos'], sl['d_ninf']
         check(lib.bbx_overscan_stats(ctx.h, C.byref(self.geom), R._ptr(raw), R.raw_type_of(raw), self.g32,
                                      R._ptr(d_mean), R._ptr(d_hos), R._ptr(d_ninf), sA),
@@ -629,7 +640,7 @@ class FramePipeline:
                         and self.subtract.get('ref_grid') is None and 'bkg_std_ref' in sub):
                     # the reference's sigma image is the same for every frame of the run: made once, on whichever lane
                     # comes first (its stream has finished with it before any other lane can pick it up: see below)
-                    torch.cuda.current_stream().synchronize()
+                    check(lib.bbx_wait(ctx.h, ctx.sp), 'bbx_wait', ctx.h)
                     self.ref_bkg_std = sub['bkg_std_ref']
                 f.sub = sub
             except (_lib.BBXError, ValueError) as e:
@@ -647,7 +658,8 @@ class FramePipeline:
         # scalar results: one small pinned D2H of the packed record
         f.h_out = (sl['h_std'], sl['h_nobj'] if d_nobj is not None else None, sl['h_stats'] if d_stats is not None else None,
                    sl['h_cnt6'], sl['h_nsats'] if d_nsats is not None else None, sl['h_steps'])
-        check(lib.bbx_copy_async(*sl['cp_res'], sp), 'bbx_copy_async')
+        # (by a kernel: the record must not queue behind the output stage's transfers on the copy engines)
+        check(lib.bbx_copy_kernel(sl['cp_res'][0], sl['cp_res'][1], sl['cp_res'][2], sp), 'bbx_copy_kernel')
         f.evC = sl['evC']
         check(lib.bbx_event_record(f.evC, sp), 'bbx_event_record')
         f.d_keep = (sol, d_std, d_nobj, d_stats, d_cnt)
@@ -733,9 +745,10 @@ class FramePipeline:
 
     # ---- driver --------------------------------------------------------------------
     def run(self, frames, on_done=None):
-        """frames: iterable of (raw device tensor, header dict).  Processes all of them with
+        """frames: iterable of (raw device tensor, header dict[, ready event]).  Processes all of them with
         up to [depth] in flight; calls on_done(idx, frame) in completion order."""
         it = iter(enumerate(frames))
+        self._has_next = getattr(frames, 'has_next', None)        # (instage.InputStage: ask before taking a frame)
         live, ndone, exhausted = [], 0, False
         try:
             return self._run(it, live, ndone, exhausted, on_done)
@@ -777,12 +790,15 @@ class FramePipeline:
         while True:
             progressed = False
             while not exhausted and len(live) < self.depth:
+                if self._has_next is not None and not self._has_next():
+                    break                                          # the next frame is still being read / decoded
                 try:
-                    idx, (raw, header) = next(it)
+                    idx, item = next(it)
                 except StopIteration:
                     exhausted = True
                     break
-                live.append(self._start(idx, raw, header))
+                raw, header = item[0], item[1]
+                live.append(self._start(idx, raw, header, item[2] if len(item) > 2 else None))
                 progressed = True
             for f in live:
                 if f.state == 'A' and lib.bbx_event_query(f.evA) == 1:

@@ -14,7 +14,7 @@ import torch
 from scipy import ndimage
 
 from . import settings
-from ._lib import lib, check, BBXError as _lib_BBXError
+from ._lib import lib, check, fetch, push, BBXError as _lib_BBXError
 from .catalogs import format_cat, transient_table         # noqa: F401  (zogy.format_cat)
 
 BBX_ERR_OVERFLOW, BBX_ERR_PSFWIN = -4, -6          # include/bbx.h
@@ -144,7 +144,7 @@ def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_fr
     if not torch.is_tensor(mini) and np.asarray(mini).dtype != np.float32:
         d_coef = torch.from_numpy(zoom_coefficients(np.asarray(mini), channels)).to(dev)
     else:
-        d_mini = mini if torch.is_tensor(mini) else torch.from_numpy(np.ascontiguousarray(mini)).to(dev)
+        d_mini = mini if torch.is_tensor(mini) else push(ctx, np.ascontiguousarray(mini))
         if d_mini.dtype != torch.float32 or not d_mini.is_contiguous():
             d_mini = d_mini.to(torch.float32).contiguous()
         d_coef = device_zoom_coefficients(ctx, d_mini, channels)
@@ -228,8 +228,7 @@ def psf_optflux(ctx, D, V, psfs, ys, xs, v_is_sigma=False):
     formed at the stamp pixels only"""
     nsrc, S, _ = psfs.shape
     dev = ctx.device
-    d_ys = torch.as_tensor(np.asarray(ys, np.int32)).to(dev)
-    d_xs = torch.as_tensor(np.asarray(xs, np.int32)).to(dev)
+    d_ys, d_xs = push(ctx, np.asarray(ys, np.int32), np.asarray(xs, np.int32))
     flux = torch.empty(nsrc, dtype=torch.float32, device=dev)
     err = torch.empty(nsrc, dtype=torch.float32, device=dev)
     ny, nx = D.shape
@@ -311,8 +310,8 @@ def find_peaks_collect(ctx, pending):
     """-> arrays (y int32, x int32, peak float32), sorted by (y, x)"""
     yx, val, cnt, max_out = pending
     ctx.sync()
-    n = min(int(cnt.item()), max_out)
-    yx, val = yx[:n].cpu().numpy(), val[:n].cpu().numpy()
+    n = min(int(fetch(ctx, cnt)[0]), max_out)
+    yx, val = fetch(ctx, yx[:n], val[:n])
     order = np.lexsort((yx[:, 1], yx[:, 0])) if n else np.zeros(0, int)
     return yx[order, 0], yx[order, 1], val[order]
 
@@ -386,7 +385,7 @@ def source_psfs(ctx, psf, sub_psfs, ys, xs, nsx, size):
     if isinstance(psf, dict):
         return psf_model_stamps(ctx, psf['basis'], np.asarray(xs) + 1.0, np.asarray(ys) + 1.0, psf['polzero'],
                                 psf['polscal'], psf['poldeg'])
-    k = torch.as_tensor((np.asarray(ys) // size) * nsx + (np.asarray(xs) // size), device=ctx.device, dtype=torch.long)
+    k = push(ctx, ((np.asarray(ys) // size) * nsx + (np.asarray(xs) // size)).astype(np.int64))
     return sub_psfs.index_select(0, k).contiguous()
 
 
@@ -408,7 +407,7 @@ def frame_clipped_stats(ctx, img, mask=None, step=8):
     std) as zogy reports them in Z-SCMED / Z-SCSTD / Z-FPEMED / Z-FPESTD.  zogy takes these header
     statistics from a random subset of the pixels; here the subset is the regular lattice of
     every [step]-th pixel in both axes (deterministic; 1.7 10^6 samples of a 10560^2 frame)."""
-    st = frame_clipped_stats_enqueue(ctx, img, mask, step).cpu().numpy()
+    st = fetch(ctx, frame_clipped_stats_enqueue(ctx, img, mask, step))
     return float(st[1]), float(st[3])
 
 
@@ -517,8 +516,8 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=new, subtract_into=work)
     bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
     Vn = None                                                        # variance image: only where a consumer needs it
-    sdn = mini_std.cpu().numpy()
-    res['bkg_mini_new'], res['bkg_std_mini_new'] = mini.cpu().numpy(), sdn
+    res['bkg_mini_new'], sdn = fetch(ctx, mini, mini_std)
+    res['bkg_std_mini_new'] = sdn
     hdr['BKG-SIZE'] = (box, '[pix] background boxsize used')
     hdr['BKG-SUB'] = (False, 'sky background was subtracted?')          # the _red product keeps its sky
     hdr['S-BKGSTD'] = (float(np.median(sdn)), '[e-] sigma (STD) background full-frame image')
@@ -557,14 +556,14 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
         keep = pk > 0
         ys, xs, pk = ys[keep], xs[keep], pk[keep]
         if ys.size:
-            d_ys, d_xs = torch.from_numpy(ys.astype(np.int64)).to(ctx.device), torch.from_numpy(xs.astype(np.int64)).to(ctx.device)
-            ok = new_mask[d_ys, d_xs].cpu().numpy() == 0
+            d_ys, d_xs = push(ctx, ys.astype(np.int64), xs.astype(np.int64))
+            ok = fetch(ctx, new_mask[d_ys, d_xs]) == 0
             ys, xs, pk = ys[ok], xs[ok], pk[ok]
         peaks = ys
         if ys.size:
             stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
             f, e = psf_optflux(ctx, work, bstd, stamps, ys, xs, v_is_sigma=True)
-            f, e = f.cpu().numpy(), e.cpu().numpy()
+            f, e = fetch(ctx, f, e)
         else:
             f = e = np.zeros(0, np.float32)
         res['catalog'] = dict(Y_POS=ys.astype(np.float32) + 1, X_POS=xs.astype(np.float32) + 1,
@@ -584,15 +583,15 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
         rwork = ref
         if ref_bkg_std_mini is None:
             _, rstd_mini = get_back(ctx, ref, ref_mask, bkg_boxsize=box)
-            sdr = rstd_mini.cpu().numpy()
+            sdr = fetch(ctx, rstd_mini)
         else:
             sdr = np.asarray(ref_bkg_std_mini, np.float32)
     else:
         rmini, rstd_mini = get_back(ctx, ref, ref_mask, bkg_boxsize=box)
         rwork = torch.empty_like(ref)
         mini2back(ctx, rmini, (rny, rnx), bkg_boxsize=box, interp_Xchan=True, subtract_from=ref, subtract_into=rwork)
-        sdr = rstd_mini.cpu().numpy() if ref_bkg_std_mini is None else np.asarray(ref_bkg_std_mini, np.float32)
-        res['bkg_mini_ref'] = rmini.cpu().numpy()
+        res['bkg_mini_ref'], sdr_meas = fetch(ctx, rmini, rstd_mini)
+        sdr = sdr_meas if ref_bkg_std_mini is None else np.asarray(ref_bkg_std_mini, np.float32)
     res['bkg_std_mini_ref'] = sdr
     if ref_grid is not None:
         from . import coadd
@@ -666,8 +665,8 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
             ntrans = 'None'
         break
     if tys.size:
-        d_ys, d_xs = torch.from_numpy(tys.astype(np.int64)).to(ctx.device), torch.from_numpy(txs.astype(np.int64)).to(ctx.device)
-        fe = torch.stack([res['Fpsf'][d_ys, d_xs], res['Fpsferr'][d_ys, d_xs]]).cpu().numpy()
+        d_ys, d_xs = push(ctx, tys.astype(np.int64), txs.astype(np.int64))
+        fe = fetch(ctx, torch.stack([res['Fpsf'][d_ys, d_xs], res['Fpsferr'][d_ys, d_xs]]))
         res['transients'] = [dict(y=y, x=x, scorr=sc, fpsf=f, fpsferr=e)
                              for y, x, sc, f, e in zip(tys.tolist(), txs.tolist(), tsc.tolist(), fe[0].tolist(), fe[1].tolist())]
     else:
@@ -682,8 +681,8 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     if frame_stats:
         # statistics over the unmasked pixels (new frame's mask), clipped like zogy's header values
         # (both queued, one copy back)
-        st = torch.stack([frame_clipped_stats_enqueue(ctx, res['Scorr'], new_mask),
-                          frame_clipped_stats_enqueue(ctx, res['Fpsferr'], new_mask)]).cpu().numpy()
+        st = fetch(ctx, torch.stack([frame_clipped_stats_enqueue(ctx, res['Scorr'], new_mask),
+                          frame_clipped_stats_enqueue(ctx, res['Fpsferr'], new_mask)]))
         hdr_t['Z-SCMED'] = (float(st[0, 1]), 'median Scorr full image')
         hdr_t['Z-SCSTD'] = (float(st[0, 3]), 'sigma (STD) Scorr full image')
         hdr_t['Z-FPEMED'] = (float(st[1, 1]), '[e-] median Fpsferr full image')

@@ -105,7 +105,24 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * bracket + one counting pass (rows the bracket misses fall back to the radix histograms by themselves); 1: radix
  * histograms over all keys for every row (round 3's path).  Same medians, same bytes either way. */
 #define BBX_OPT_FPACK_HIST_ONLY 6
+/* BBX_OPT_WAIT_SLEEP_US (default 0): how bbx_sync / bbx_wait wait for the device.  0: the runtime's stream synchronisation
+ * (it spins on a core).  n > 0: the host thread polls an event and sleeps n microseconds between polls -- a pipeline with
+ * several lane, reader and writer threads per GPU would otherwise burn a core per waiting thread (5.4 cores per GPU measured
+ * in round 3); costs up to n us of latency per wait.  (hipDeviceScheduleBlockingSync was tried first: waits never
+ * returned on the GPU boxes of this project.) */
+#define BBX_OPT_WAIT_SLEEP_US 7
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
+/* Host waits that do not spin.  bbx_wait: everything queued on [stream] so far has finished (no error check: bbx_sync does
+ * that); bbx_event_wait: [event] (a hipEvent_t, e.g. of bbx_event_create or a framework's) has completed.  sleep_us > 0:
+ * poll + nanosleep; <= 0: for bbx_wait the context's BBX_OPT_WAIT_SLEEP_US, for bbx_event_wait hipEventSynchronize.
+ * (what the reference does: nothing -- numpy is synchronous; these replace hipStreamSynchronize / blocking copies.) */
+int  bbx_wait(bbx_ctx *ctx, void *stream);
+/* Copy [nbytes] between two device-accessible addresses (device memory, or pinned host memory: hipHostMalloc'ed memory is
+ * mapped into the device's address space) with a KERNEL on [stream] instead of a copy-engine transfer: the few bytes a stage
+ * hands to the host (counts, list heads, scalars) then never queue behind the 100 MB transfers of the output / input stages
+ * on the DMA engines.  Meant for small copies (<= a few MB). */
+int  bbx_copy_kernel(void *dst, const void *src, size_t nbytes, void *stream);
+int  bbx_event_wait(void *event, int sleep_us);
 
 /* Per-step attribution of device-side errors.  Kernels report list overflow / non-convergence by
  * setting bits in a flag word of the context; the calls are asynchronous, so the host cannot see
