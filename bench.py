@@ -423,8 +423,9 @@ def measure_io(torch, ctx, tel, geom, raws, kw, depth, lanes, pool, barrier, arg
     meas = {}
     import shutil
     import tempfile
+    simple = getattr(args, 'io_simple', False)                    # (profiling: one run, RAM disk only)
     for label, root in (('ramdisk', '/dev/shm'), ('scratch', tempfile.gettempdir())):
-        if not os.path.isdir(root) or not os.access(root, os.W_OK):
+        if not os.path.isdir(root) or not os.access(root, os.W_OK) or (simple and label != 'ramdisk'):
             continue
         td = tempfile.mkdtemp(prefix='bbx_bench_out_', dir=root)
         try:
@@ -443,8 +444,9 @@ def measure_io(torch, ctx, tel, geom, raws, kw, depth, lanes, pool, barrier, arg
                                reader_threads=args.readers, raw_MB_per_frame=raw_mb,
                                host_ms_per_frame=r4['host_ms_per_frame'], writer_ms_per_image=r4.get('writer_ms_per_image'),
                                small_files_ms_per_frame=r4.get('small_files_ms_per_frame'))
-            r5 = run_pipeline(torch, ctx, tel, geom, raws, kw, frames, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers)
-            meas[label]['output_side_only'] = dict(frames_per_s=frames / r5['dt'], note='inputs resident in HBM (round 3 figure)')
+            if not simple:
+                r5 = run_pipeline(torch, ctx, tel, geom, raws, kw, frames, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers)
+                meas[label]['output_side_only'] = dict(frames_per_s=frames / r5['dt'], note='inputs resident in HBM (round 3 figure)')
         except Exception as e:
             import traceback
             meas[label] = dict(error=repr(e), trace=traceback.format_exc()[-1500:])
@@ -509,9 +511,10 @@ def main():
     ap.add_argument('--depth', type=int, default=None, help='frames in flight')
     ap.add_argument('--workers', type=int, default=None, help='host fit worker processes')
     ap.add_argument('--lanes', type=int, default=None, help='stage-C lanes (context + stream + issuing thread) per GPU')
-    ap.add_argument('--writers', type=int, default=8, help='writer threads of the output stage (io_inclusive.measured)')
-    ap.add_argument('--readers', type=int, default=3, help='reader threads of the input stage (io_inclusive.measured)')
+    ap.add_argument('--writers', type=int, default=12, help='writer threads of the output stage (io_inclusive.measured)')
+    ap.add_argument('--readers', type=int, default=4, help='reader threads of the input stage (io_inclusive.measured)')
     ap.add_argument('--io-only', action='store_true', help='only the measured I/O-inclusive run (debug)')
+    ap.add_argument('--io-simple', action='store_true', help='with --io-only: one files-to-files run on the RAM disk (profiling)')
     ap.add_argument('--psf-size', type=int, default=49, help='side of the PSF stamps of the ZOGY stage (SURVEY 8d: 49)')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:

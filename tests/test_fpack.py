@@ -374,13 +374,21 @@ def test_gpu_bracket_medians_equal_histogram_medians():
     r = np.zeros(nx, np.float32); r[: nx // 2 + 7] = rs.normal(0, 5, nx // 2 + 7); rows.append(r)   # half the differences are exactly 0
     img = np.stack(rows)
     got = {}
-    for hist in (1, 0):
+    for name, hist in (('hist', 1), ('bracket', 0)):
         _lib.check(_lib.lib.bbx_set_option(ctx.h, 6, hist), 'bbx_set_option')
-        got[hist] = P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), 16, 9)
+        got[name] = P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), 16, 9)
     _lib.check(_lib.lib.bbx_set_option(ctx.h, 6, 0), 'bbx_set_option')
-    a, b = got[0], got[1]
+    a = got['bracket']
     for k in ('nbytes', 'offsets', 'flag', 'zscale', 'zzero', 'heap'):
-        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], got['hist'][k]), k
+    # integer images (ragged last blocks: 12000 = 375 blocks, 4100 = 128 blocks + 4 pixels) against the oracle's encoder
+    raw = rs.randint(0, 65535, (6, 12000)).astype(np.uint16); raw[3:] = (1500 + rs.normal(0, 9, (3, 12000))).astype(np.uint16)
+    msk = (rs.rand(5, nx) < 0.03).astype(np.uint8) * 32; msk[2] = 0
+    i32 = rs.randint(-2 ** 31, 2 ** 31 - 1, (4, 4100)).astype(np.int32); i32[2:] = rs.normal(0, 50, (2, 4100)).astype(np.int32)
+    for arr in ((raw.astype(np.int32) - 32768).astype(np.int16), msk, i32):
+        r2 = P.compress_tiles(ctx, torch.from_numpy(arr).to(ctx.device))
+        for r in range(arr.shape[0]):
+            assert r2['heap'][r2['offsets'][r]:r2['offsets'][r] + r2['nbytes'][r]].tobytes() == FP.rice_encode(arr[r], arr.dtype.itemsize), (arr.dtype, r)
     nref = 0
     for r in range(img.shape[0]):
         q = FP.quantize_row(img[r], r + 1 + 9 - 1, 16)

@@ -36,8 +36,8 @@ def run(a, bitpix, q):
 
 
 ref = {}
-for hist in (1, 0):
-    for one in (1, 0):
+for hist, one, tile in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 0)):
+    if True:
         _lib.check(_lib.lib.bbx_set_option(ctx.h, 6, hist), 'opt')
         _lib.check(_lib.lib.bbx_set_option(ctx.h, 5, one), 'opt')
         for name, a, bp, q in (('float q16', img, -32, 16), ('float q4', img, -32, 4), ('float q2', img, -32, 2), ('mask', msk, 8, 0)):
@@ -56,6 +56,6 @@ for hist in (1, 0):
                 same = 'same bytes' if ref[key] == sig else '*** DIFFERENT ***'
             else:
                 ref[key] = sig
-            print('hist_only=%d one_wg=%d %-10s %.3f ms  %5.1f MB  refused rows %d  %s' % (hist, one, name, ms, tl['nbytes'].sum() / 1e6, (tl['flag'] != 0).sum(), same))
+            print('hist_only=%d one_wg=%d tile_only=%d %-10s %.3f ms  %5.1f MB  refused rows %d  %s' % (hist, one, tile, name, ms, tl['nbytes'].sum() / 1e6, (tl['flag'] != 0).sum(), same))
 _lib.check(_lib.lib.bbx_set_option(ctx.h, 6, 0), 'opt')
 _lib.check(_lib.lib.bbx_set_option(ctx.h, 5, 0), 'opt')
