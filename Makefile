@@ -11,7 +11,13 @@ HOSTLIB := blackbox_amd/libbbx_host.so
 # -ffp-contract=off: results must match numpy's unfused float32/float64 arithmetic
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -ffp-contract=off -std=c++17 -Wall -Wno-unused-function
 
-all: $(LIB) $(HOSTLIB)
+ORACLELIB := oracle/liblacosmic_c.so
+
+all: $(LIB) $(HOSTLIB) $(ORACLELIB)
+
+# the oracle's C twin of LA-Cosmic (test infrastructure: tests/ and bench.py's cpu_baseline leg only)
+$(ORACLELIB): oracle/lacosmic_c.c
+	gcc -O3 -fopenmp -ffp-contract=off -fPIC -shared -o $@ $< -lm
 
 # host-side C helpers of the overscan solve (same float operations as the numpy code)
 $(HOSTLIB): blackbox_amd/chost/bbx_host.c
@@ -27,6 +33,6 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
 
 clean:
-	rm -f $(OBJS) $(LIB) $(HOSTLIB)
+	rm -f $(OBJS) $(LIB) $(HOSTLIB) $(ORACLELIB)
 
 .PHONY: all clean

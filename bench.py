@@ -194,19 +194,23 @@ def zogy_inputs(torch, dev, nsy, nsx, S, box, ny, nx):
                 ref_bkg_std_mini=ref_std_mini)
 
 
+CPU_SAMPLE = (660, 330)                 # channel size of the CPU sample: 16 channels = a 1320 x 2640 sub-frame, 1/32 of a frame
+
+
 def _cpu_sample(args):
-    """one worker's bounded sample of the CPU path: the oracle restatement (numpy/scipy) of the
-    reduction on a 1320x2640 sub-frame (1/32 of a frame), the background mesh on it, and run_zogy
+    """one worker's bounded sample of the CPU path: the oracle restatement of the reduction (numpy / scipy; LA-Cosmic by the
+    oracle's C twin oracle/lacosmic_c.c -- compiled C like the astroscrappy the reference calls, blackbox.py:4323-4332 -- on
+    [nthreads] OpenMP threads) on a 1320x2640 sub-frame (1/32 of a frame), the background mesh on it, and run_zogy
     (numpy FFTs) on one 1400^2 sub-image; returns the seconds of each part"""
-    seed, with_zogy = args
+    seed, with_zogy, nthreads = args
     for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
-        os.environ[k] = '1'
+        os.environ[k] = str(nthreads)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bbx_oracle as O
-    import lacosmic as L
+    import lacosmic_c as LC
     import zogy_core as Z
     from blackbox_amd import settings, synth
-    ys, xs = 660, 330
+    ys, xs = CPU_SAMPLE
     case = synth.make_case(ys, xs, 4242 + seed, tel='ML1', os_y=20, os_x=45, n_stars=200, n_sat=2, n_cr=6)
     t0 = time.perf_counter()
     data = case['raw'].astype('float32')
@@ -215,7 +219,7 @@ def _cpu_sample(args):
     out, h, _ = O.os_corr(data, ys, xs)
     mask, hm = O.mask_init(out, h, case['bpm'], gain, sat, ys, xs)
     out /= case['flat']
-    L.detect_cosmics(out, mask != 0, 15, 0.01, 3, 3, h['RDNOISE'])
+    LC.detect_cosmics(out, mask != 0, 15, 0.01, 3, 3, h['RDNOISE'], nthreads=nthreads)
     t1 = time.perf_counter()
     t_bkg = t_zogy = 0.0
     if with_zogy:
@@ -252,18 +256,28 @@ def cpu_baseline(workload):
         ram_gb = 64.0
     nproc = int(max(1, min(cores, ram_gb // 6)))
     with_zogy = workload == 'zogy'
-    frac = (2 * 660 * 8 * 330) / 111513600.0
+    frac = (2 * CPU_SAMPLE[0] * 8 * CPU_SAMPLE[1]) / 111513600.0
 
     def frame_seconds(t):
         # reduction and mesh scale with the area; ZOGY with the 64 sub-images; the mesh runs on both frames
         return t[0] / frac + (2 * t[1] / frac if workload != 'calib' else 0.0) + (64 * t[2] if with_zogy else 0.0)
-    t1 = _cpu_sample((0, with_zogy))
+    # mode (ii) of SURVEY 8d: one process, all cores (the threads go to the C / OpenMP LA-Cosmic, as in the reference's
+    # environment; numpy's element-wise stages and FFTs stay on one core) -- and the same sample on one thread
+    with mp.get_context('spawn').Pool(1) as pool:
+        t1 = pool.map(_cpu_sample, [(0, with_zogy, 1)])[0]
+        t_all = pool.map(_cpu_sample, [(0, with_zogy, cores)])[0]
+    # mode (i): N_proc single-threaded processes side by side (how the reference farms frames, blackbox.py:363-379)
     with mp.get_context('spawn').Pool(nproc) as pool:
-        ts = pool.map(_cpu_sample, [(k, with_zogy) for k in range(nproc)])
+        ts = pool.map(_cpu_sample, [(k, with_zogy, 1) for k in range(nproc)])
     per_frame_all = float(np.mean([frame_seconds(t) for t in ts]))
     return dict(value=nproc / per_frame_all, unit='frames/s', cores=nproc, kind='port',
                 one_core_frames_per_s=1.0 / frame_seconds(t1),
-                sample='oracle (numpy/scipy) per worker: reduction%s on a 1320x2640 px sub-frame (1/%.0f of a frame, scaled by '
+                one_process_all_cores=dict(frames_per_s=1.0 / frame_seconds(t_all), threads=cores,
+                                           seconds_per_part=[round(float(v), 2) for v in t_all],
+                                           note='SURVEY 8d mode (ii): one process, OMP_NUM_THREADS = cores (LA-Cosmic in C / OpenMP uses them; '
+                                                'the numpy stages and FFTs run on one core)'),
+                sample='oracle per worker: reduction (numpy / scipy; LA-Cosmic = oracle/lacosmic_c.c, vectorised sorting-network '
+                       'medians)%s on a 1320x2640 px sub-frame (1/%.0f of a frame, scaled by '
                        'area)%s; %d single-threaded worker processes at once (cpu budget %d cores, %.0f GB RAM); mean '
                        'seconds per part %s' % (' + background mesh' if workload != 'calib' else '', 1 / frac,
                                                 ' + run_zogy on one 1400^2 sub-image (x64)' if with_zogy else '', nproc, cores,

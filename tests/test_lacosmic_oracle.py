@@ -82,3 +82,30 @@ def test_background_level_used_when_no_good_neighbour():
     crmask, clean = L.detect_cosmics(img, np.zeros(img.shape, bool), 4.5, 0.3, 1e9 * 0 + 0.0, 4, 5.0)
     if crmask[9, 9] and crmask[7:12, 7:12].all():
         assert clean[9, 9] == L.lower_median(img[~np.zeros(img.shape, bool)])
+
+
+def test_c_twin_equals_numpy_oracle():
+    """oracle/lacosmic_c.c (the C / OpenMP statement bench.py times on the host cores) == oracle/lacosmic.py bit for bit:
+    crmask, cleaned pixels and the per-iteration counts, for star fields with cosmic rays, masked regions (incl. a CR pixel
+    whose whole 5 x 5 neighbourhood is masked: the background-level path), both sigclips, 1 and several threads, and frames
+    too small for the 5 x 5 / 7 x 7 filters"""
+    import lacosmic_c as LC
+    for seed, shape, n_cr in ((3, (48, 200), 25), (4, (48, 100), 60), (5, (7, 9), 2), (6, (5, 40), 3)):
+        img, _ = frame(seed, shape, n_cr)
+        if seed >= 5:
+            img = np.ascontiguousarray(img[:shape[0], :shape[1]])                  # frames too small for the larger filters
+        shape = img.shape
+        rs = np.random.RandomState(seed)
+        mask = rs.rand(*shape) < 0.01
+        if shape[0] > 20:
+            mask[10:17, 30:37] = True
+            mask[13, 33] = False
+            img[13, 33] += 5000.0                      # a CR pixel without a single good neighbour
+        for sigclip, niter in ((4.5, 3), (15.0, 3), (4.5, 1)):
+            cr_n, cl_n, it_n = L.detect_cosmics(img, mask, sigclip, 0.01, 3, niter, 8.0, return_iters=True)
+            for nthreads in (1, 3):
+                cr_c, cl_c, it_c = LC.detect_cosmics(img, mask, sigclip, 0.01, 3, niter, 8.0, return_iters=True, nthreads=nthreads)
+                assert np.array_equal(cr_c, cr_n), (seed, sigclip, niter, nthreads)
+                assert np.array_equal(cl_c.view(np.uint32), cl_n.view(np.uint32)), (seed, sigclip, niter, nthreads)
+                assert it_c == it_n, (seed, sigclip, niter)
+        assert cr_n.any() or shape[0] < 20
