@@ -21,11 +21,10 @@ def main():
     ref, ref_mask = bench.synth_reference(torch, dev, ex.pop('scene0'), 4000)
     rs = np.random.RandomState(0)
     coeffs = np.zeros((16, 16)); coeffs[~np.eye(16, dtype=bool)] = rs.uniform(0, 2e-4, 240)
-    psf = torch.from_numpy(bench.moffat_stamp(25, 4.0)).to(dev)
+    zi = bench.zogy_inputs(torch, dev, 8, 8, 49, 60, 2 * ysz, 8 * xsz)          # the SURVEY 8d ZOGY inputs of the headline workload
     for i in range(n + 1):
         data, mask, h, hm = R.reduce_object(ctx, raw, {}, 'ML1', mflat=flat, bpm=bpm, xtalk_coeffs=coeffs, exptime=60.0)
-        res = G.optimal_subtraction(ctx, data, ref, mask, ref_mask, psf, psf, fratio=1.0, dx=0.03, dy=0.03, cat_extract=True,
-                                    ref_is_bkgsub=True, ref_bkg_std_mini=np.full((176, 176), 8.0, np.float32))
+        res = G.optimal_subtraction(ctx, data, ref, mask, ref_mask, cat_extract=True, **zi)
         ctx.sync()
         del res
     print('done', n + 1, 'frames')
