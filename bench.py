@@ -476,6 +476,68 @@ def measure_io(torch, ctx, tel, geom, raws, kw, depth, lanes, pool, barrier, arg
     return meas
 
 
+def process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box):
+    """what ONE `python blackbox.py --image F` process costs at full size (the reference's Slurm contract: one interpreter per
+    file, blackbox_slurm_google.py:305-309): the frame's inputs are written as files (fpacked raw, master flat, bad-pixel
+    mask, crosstalk table, reference image + mask + sigma mini image, PSF stamp cubes), the command line runs as a child
+    process twice (page cache cold-ish, then warm) with --fpack True, and reports where its wall time went (BBX_TIMING)"""
+    import shutil
+    import subprocess
+    import tempfile
+    from blackbox_amd import fitsio
+    from blackbox_amd import fpack as P
+    td = tempfile.mkdtemp(prefix='bbx_proc_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        hdr = {'DATE-OBS': '2024-01-02T03:04:05', 'EXPTIME': 60.0, 'IMAGETYP': 'object', 'FILTER': 'q', 'OBJECT': 'synthetic'}
+        rawf = P.fpack_image(ctx, os.path.join(td, 'ML1_raw.fits'), raw, hdr)
+        fitsio.write_image(os.path.join(td, 'flat.fits'), flat.cpu().numpy())
+        fitsio.write_image(os.path.join(td, 'bpm.fits'), bpm.cpu().numpy())
+        fitsio.write_image(os.path.join(td, 'ref.fits'), ref.cpu().numpy())
+        fitsio.write_image(os.path.join(td, 'ref_mask.fits'), ref_mask.cpu().numpy())
+        fitsio.write_image(os.path.join(td, 'ref_std_mini.fits'), np.asarray(sub_kw['ref_bkg_std_mini'], np.float32))
+        fitsio.write_image(os.path.join(td, 'psf_new.fits'), sub_kw['psf_new'].cpu().numpy())
+        fitsio.write_image(os.path.join(td, 'psf_ref.fits'), sub_kw['psf_ref'].cpu().numpy())
+        with open(os.path.join(td, 'xtalk.dat'), 'w') as f:
+            f.write('victim source correction\n')
+            for s_ in range(16):
+                for v_ in range(16):
+                    if s_ != v_:
+                        f.write('%d %d %.10e\n' % (v_ + 1, s_ + 1, coeffs[s_, v_]))
+        cmd = [sys.executable, os.path.join(ROOT, 'blackbox.py'), '--telescope', 'ML1', '--img_reduce', 'True', '--cat_extract', 'True',
+               '--trans_extract', 'True', '--force_reproc_new', 'True', '--image', rawf, '--mflat', os.path.join(td, 'flat.fits'),
+               '--bpm', os.path.join(td, 'bpm.fits'), '--crosstalk', os.path.join(td, 'xtalk.dat'), '--ref', os.path.join(td, 'ref.fits'),
+               '--ref_mask', os.path.join(td, 'ref_mask.fits'), '--ref_bkg_std_mini', os.path.join(td, 'ref_std_mini.fits'),
+               '--ref_bkgsub', 'True', '--psf_new', os.path.join(td, 'psf_new.fits'), '--psf_ref', os.path.join(td, 'psf_ref.fits'),
+               '--fratio', '1.0', '--zogy_dx', '0.03', '--zogy_dy', '0.03', '--fpack', 'True', '--bkg_boxsize', str(box)]
+        runs = []
+        for k in range(2):
+            out_dir = os.path.join(td, 'out%d' % k)
+            t0 = time.time()
+            r = subprocess.run(cmd + ['--red_dir', out_dir], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=280)
+            wall = time.time() - t0
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('BBX_TIMING ')]
+            if r.returncode != 0 or not line:
+                return dict(error='exit code %d' % r.returncode, stderr=r.stderr[-600:])
+            tm = json.loads(line[-1][len('BBX_TIMING '):])
+            marks = tm['marks']
+            d = {}
+            prev = 0.0
+            for name, t in marks:
+                d[name] = round(t - prev, 3)
+                prev = t
+            files = sorted(os.listdir(out_dir))
+            runs.append(dict(wall_s=round(wall, 3), interpreter_start_s=round(tm['t_module_import_unix'] - t0, 3), seconds_per_phase=d,
+                             files_written=len(files), MB_written=round(sum(os.path.getsize(os.path.join(out_dir, f_)) for f_ in files) / 1e6, 1)))
+        return dict(first_run=runs[0], second_run=runs[1],
+                    note='child process `python blackbox.py --image raw.fits.fz ... --fpack True` at full size, all products of the frame '
+                         'written; seconds_per_phase = time between consecutive marks inside the process (imports, GPU context, masters / '
+                         'reference / PSFs into HBM, raw read + decode, reduction, subtraction, writing)')
+    except Exception as e:
+        return dict(error=repr(e))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def load_pmc(args):
     """HBM traffic per launch from the tracked PMC summary (profiles/*_pmc_traffic.json: two --pmc passes of this
     command, FETCH_SIZE / WRITE_SIZE with the gfx950 corrections) -- only while the kernels it was taken from are
@@ -528,6 +590,7 @@ def main():
     ap.add_argument('--writers', type=int, default=12, help='writer threads of the output stage (io_inclusive.measured)')
     ap.add_argument('--readers', type=int, default=4, help='reader threads of the input stage (io_inclusive.measured)')
     ap.add_argument('--io-only', action='store_true', help='only the measured I/O-inclusive run (debug)')
+    ap.add_argument('--proc-only', action='store_true', help='only the per-file process timing (debug)')
     ap.add_argument('--io-simple', action='store_true', help='with --io-only: one files-to-files run on the RAM disk (profiling)')
     ap.add_argument('--psf-size', type=int, default=49, help='side of the PSF stamps of the ZOGY stage (SURVEY 8d: 49)')
     args = ap.parse_args()
@@ -601,6 +664,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.proc_only:
+        print(json.dumps(process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box)))
+        pool.close()
+        return
     if args.io_only:
         def section(name):
             sys.stderr.write('[bench] %s\n' % name); sys.stderr.flush()
@@ -829,6 +896,9 @@ def main():
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
         section('io_inclusive (pcie, serial writers)')
         out['io_inclusive']['measured'] = measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section)
+        if wl == 'zogy' and not args.small:
+            out['process_per_file'] = process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box)
+            section('process_per_file')
     pool.close()
     if rank == 0:
         if not args.no_cpu:

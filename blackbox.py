@@ -30,6 +30,16 @@ sys.path.insert(0, ROOT)
 KEYWORDS_VERSION = '1.2.2'      # header keywords version this product follows (blackbox.py:123)
 log = logging.getLogger('blackbox')
 
+# BBX_TIMING=1: where the wall time of a `python blackbox.py --image F` process goes (the reference's Slurm contract is one
+# interpreter per file, blackbox_slurm_google.py:305-309): seconds since this module was imported at each mark, printed
+# as one `BBX_TIMING {json}` line when main() returns
+_T0 = time.time()
+_MARKS = []
+
+
+def _mark(name):
+    _MARKS.append((name, time.time() - _T0))
+
 
 def str2bool(v):
     """blackbox.py:8115-8123"""
@@ -167,11 +177,15 @@ class Reducer:
     """per-process state: GPU context + masters / reference / PSFs resident in HBM"""
 
     def __init__(self, tel, args):
+        _mark('main_start')
         import torch
+        _mark('torch_imported')
         from blackbox_amd import fitsio, reduce as R
+        _mark('package_imported')
         self.R, self.torch, self.fitsio = R, torch, fitsio
         _, _, local = __import__('blackbox_amd.farm', fromlist=['rank_world']).rank_world()
         self.ctx = R.Context(local)
+        _mark('gpu_context')
         self.tel = tel
         self.args = args
         dev = self.ctx.device
@@ -206,6 +220,7 @@ class Reducer:
         self.sub = None
         if args.cat_extract or args.trans_extract:
             self.sub = self._load_subtraction_inputs(load)
+        _mark('calibration_and_reference_files_in_hbm')
 
     def _load_psf(self, path):
         """PSF input: a PSFEx .psf table (model evaluated on the GPU) or a FITS image / cube of
@@ -310,6 +325,7 @@ class Reducer:
         R = self.R
         t0 = time.time()
         d_raw, header = self.read_raw(filename)
+        _mark('raw_read')
         if not self.args.red_dir:
             self.args.red_dir = os.path.dirname(os.path.abspath(filename))
         red_dir, fits_out = self.names(header)
@@ -325,6 +341,7 @@ class Reducer:
                 self.ctx, d_raw, header, self.tel, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
                 xtalk_coeffs=self.xtalk, exptime=exptime, ysize_chan=self.args.ysize_chan,
                 xsize_chan=self.args.xsize_chan, nonlin_splines=self.nonlin, imgtype=imgtype, log=log)
+            _mark('reduced')
             if imgtype != 'object':
                 return self.finish_calibration_frame(data, mask, header, imgtype, fits_out)
             return self.finish_object(filename, data, mask, header, hm, fits_out, t0)
@@ -421,6 +438,7 @@ class Reducer:
         self.write_image(fits_out.replace('_red', '_mask'), mask, hm)
         fitsio.write_header(base + '_hdr.fits', header)                       # update_imcathead(create_hdrfile=True), 2011
         log.info('reduced %s -> %s in %.2f s', filename, written, time.time() - t0)
+        _mark('products_written')
         return written
 
     def write_image(self, path, img, header):
@@ -451,6 +469,7 @@ class Reducer:
                 res = G.optimal_subtraction(self.ctx, data, self.sub['ref'], mask, self.sub['ref_mask'],
                                             self.sub['psf_new'], self.sub['psf_ref'], **kw)
                 self.ctx.sync()
+                _mark('subtracted')
         except Exception:
             log.exception('exception was raised during [optimal_subtraction]; saving just the image reduction products')
             header['Z-P'] = (False, 'successfully processed by ZOGY?')
@@ -757,6 +776,10 @@ def main(argv=None):
         out = [red.reduce_logged(f) for f in mine]
     for o in out:
         print(o)
+    if os.environ.get('BBX_TIMING'):
+        import json
+        _mark('done')
+        print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0)))
     return out
 
 

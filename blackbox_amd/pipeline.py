@@ -33,18 +33,19 @@ get_par = settings.get_par
 
 
 def cpu_budget():
-    """cores this process may use: the cgroup CPU quota when there is one (os.cpu_count()
-    reports the whole host inside a container), else the affinity mask"""
+    """cores this process may use: the smaller of the cgroup CPU quota (os.cpu_count() reports the whole host inside
+    a container) and the affinity mask (taskset / a launcher that pins ranks)"""
+    try:
+        naff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        naff = os.cpu_count() or 4
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
         if quota != 'max':
-            return max(1, int(int(quota) / int(period)))
+            return max(1, min(naff, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    try:
-        return len(os.sched_getaffinity(0))
-    except AttributeError:
-        return os.cpu_count() or 4
+    return naff
 
 
 def default_workers():
