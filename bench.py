@@ -395,6 +395,7 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
         if stage is None:
             count(f)
     barrier()
+    wait0 = list(_lib.WAIT_STATS)
     t_all0 = time.perf_counter()
     pipe.run(src if src is not None else [(raws[i % len(raws)], {}) for i in range(n_all)], on_done=on_done)
     torch.cuda.synchronize()
@@ -406,6 +407,7 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
         raise mark['err']
     out = dict(dt=mark['t1'] - mark['t0'], dt_all=t_end - t_all0, n_all=n_all, t_stats=list(pipe.t_stats), last=mark.get('last'),
                nworkers=pipe.pool.n, bytes_written=mark['bytes'], files_written=mark['files'],
+               lane_fetch_wait_ms_per_frame=1e3 * (_lib.WAIT_STATS[0] - wait0[0]) / max(1, n_all), lane_fetch_waits_per_frame=(_lib.WAIT_STATS[1] - wait0[1]) / max(1, n_all),
                host_ms_per_frame=dict(lane_threads_cpu=1e3 * pipe.lane_cpu[0] / max(1, pipe.lane_cpu[2]),
                                       lane_threads_wall=1e3 * pipe.lane_cpu[1] / max(1, pipe.lane_cpu[2]),
                                       orchestrator_cpu=1e3 * (time.thread_time() - t_cpu_main) / n_all))
@@ -424,6 +426,7 @@ def run_pipeline(torch, ctx, tel, geom, raws, kw, steps, warmup, depth, lanes, p
     if stage is not None:
         stage.close()
         out['writer_ms_per_image'] = {k: dict(wall=1e3 * w / max(1, n), cpu=1e3 * c / max(1, n)) for k, (w, c, n) in stage.phase.items()}
+        out['lane_slot_wait_ms_per_frame'] = 1e3 * sum(l.slot_wait for l in stage.lanes.values()) / max(1, n_all)
         out['small_files_ms_per_frame'] = dict(wall=1e3 * mark.get('small_wall', 0.0) / max(1, n_all), cpu=1e3 * mark.get('small_cpu', 0.0) / max(1, n_all))
     if src is not None:
         out['bytes_read'] = src.bytes_read
@@ -457,6 +460,8 @@ def measure_io(torch, ctx, tel, geom, raws, kw, depth, lanes, pool, barrier, arg
                                files_per_frame=r4['files_written'] / max(1, r4['n_all']), writer_threads=args.writers,
                                reader_threads=args.readers, raw_MB_per_frame=raw_mb,
                                host_ms_per_frame=r4['host_ms_per_frame'], writer_ms_per_image=r4.get('writer_ms_per_image'),
+                               lane_slot_wait_ms_per_frame=r4.get('lane_slot_wait_ms_per_frame'),
+                               lane_fetch_wait_ms_per_frame=r4.get('lane_fetch_wait_ms_per_frame'), lane_fetch_waits_per_frame=r4.get('lane_fetch_waits_per_frame'),
                                small_files_ms_per_frame=r4.get('small_files_ms_per_frame'))
             if not simple:
                 r5 = run_pipeline(torch, ctx, tel, geom, raws, kw, frames, 4, depth, lanes, pool, barrier, outdir=td, nwriters=args.writers)

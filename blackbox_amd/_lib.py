@@ -5,6 +5,7 @@ import of this module raises -- there is no CPU fallback in the product path.
 """
 import ctypes as C
 import os
+import time
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBX_LIB_PATH: a scratch build of the library (kernel-variant experiments, tools/exp/zvar.sh); the product is the in-tree one
@@ -127,6 +128,7 @@ def _strerror(code):
 WAIT_SLEEP_US = int(os.environ.get('BBX_WAIT_SLEEP_US', '50'))       # host waits of the multi-threaded paths: poll + sleep (0: spin)
 
 
+WAIT_STATS = [0.0, 0]
 KERNEL_COPY_MAX = int(os.environ.get('BBX_KERNEL_COPY_MAX', str(4 << 20)))    # fetch / push: copies up to this size go by a kernel
 
 
@@ -196,7 +198,9 @@ def fetch(ctx, *tensors):
             v.copy_(t, non_blocking=True)
         views.append(v)
         off += nb
+    t0 = time.perf_counter()
     check(lib.bbx_wait(ctx.h, sp), 'bbx_wait', ctx.h)
+    WAIT_STATS[0] += time.perf_counter() - t0; WAIT_STATS[1] += 1          # (diagnostics: seconds / calls of host waits in fetch)
     out = [v.numpy().copy() for v in views]
     return out if len(out) > 1 else out[0]
 

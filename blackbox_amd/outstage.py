@@ -110,6 +110,7 @@ class FzLane:
         self.d_off = torch.empty(ny, dtype=torch.int64, device=dev)
         self.free = queue.Queue()
         self.slots = []
+        self.slot_wait = 0.0
         cap = ny * 32 + int(heap_frac * ny * nx * 4) + 4096
         for _ in range(nslots):
             s = _Slot()
@@ -127,7 +128,9 @@ class FzLane:
         if tuple(img.shape) != (self.ny, self.nx) or not img.is_contiguous():
             raise ValueError('image of shape {} expected'.format((self.ny, self.nx)))
         bitpix = {torch.float32: -32, torch.uint8: 8, torch.int16: 16, torch.int32: 32}[img.dtype]
+        t0 = time.perf_counter()
         s = self.free.get()
+        self.slot_wait += time.perf_counter() - t0                # (lane thread: time it stood waiting for a free slot)
         rnd = fpack._rnd(img.device) if bitpix == -32 else None
         st = torch.cuda.current_stream(img.device)
         check(lib.bbx_fpack_body(self.ctx.h, self.ny, self.nx, C.c_void_p(img.data_ptr()), bitpix, float(quant), int(seed),
