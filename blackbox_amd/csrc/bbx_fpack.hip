@@ -775,6 +775,9 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
         d_hint = (unsigned*)bbx_ws(ctx, WS_FPHINT, (size_t)ny * 3 * sizeof(unsigned), &rc); if (rc) return rc;
         BBX_HIP(hipMemsetAsync(d_hint, 0, (size_t)ny * 3 * sizeof(unsigned), s));
     }
+#ifndef FPV_SKIP_RETRY
+#define FPV_SKIP_RETRY 0            // (experiment: what the launch of the retry kernel costs when no row needs it)
+#endif
 #define FP_LAUNCH(BP, FL)                                                                                              \
     do {                                                                                                               \
         if (two) {                                                                                                     \
@@ -782,7 +785,7 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 1>), dim3(ny), dim3(FP_THREADS), ldshalf, s, d_img, ny, nx, (size_t)nx, qlevel, \
                                dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords, hist_only, d_hint, gen);             \
-            hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
+            if (!FPV_SKIP_RETRY) hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
                                dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen);               \
         } else {                                                                                                       \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
