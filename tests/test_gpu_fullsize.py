@@ -130,6 +130,33 @@ def test_lacosmic_windows_and_invariants(frame):
     assert ncheck > 0
 
 
+def test_lacosmic_whole_frame_against_the_c_twin(frame):
+    """The whole 10560 x 10560 frame, not windows of it: bbx_lacosmic against oracle/lacosmic_c.c (the oracle's C twin, held bit
+    for bit against oracle/lacosmic.py on small frames in tests/test_lacosmic_oracle.py) -- the cosmic-ray mask of every pixel,
+    every cleaned value (the background-level pixels included: both sides take the lower median of the frame's good pixels)
+    and the number of CR pixels, with the production parameters (sigclip 15, niter 3) and with sigclip 4.5, which flags a
+    hundred times more pixels"""
+    import lacosmic_c as LC
+    f = frame
+    ctx = f['ctx']
+    gp = settings.get_par
+    sigfrac, objlim, niter = gp(settings.sigfrac, 'ML1'), gp(settings.objlim, 'ML1'), gp(settings.niter, 'ML1')
+    d_h, m_h = f['data'].cpu().numpy(), f['mask'].cpu().numpy()
+    nthreads = min(16, len(os.sched_getaffinity(0)))
+    rdnoise = np.float32(R.hval(f['header'], 'RDNOISE'))
+    for sigclip in (gp(settings.sigclip, 'ML1'), 4.5):
+        data, mask = f['data'].clone(), f['mask'].clone()
+        d_stats = R.detect_cosmics(ctx, data, mask, sigclip, sigfrac, objlim, niter, rdnoise)
+        ctx.sync()
+        cr_o, clean_o, iters = LC.detect_cosmics(d_h, m_h != 0, sigclip, sigfrac, objlim, niter, rdnoise, return_iters=True, nthreads=nthreads)
+        got_m, got_d = mask.cpu().numpy(), data.cpu().numpy()
+        assert np.array_equal((got_m & 2) != 0, cr_o), sigclip
+        assert np.array_equal(got_m & ~np.uint8(2), m_h & ~np.uint8(2)), sigclip
+        assert np.array_equal(got_d.view(np.uint32), clean_o.view(np.uint32)), (sigclip, int((got_d != clean_o).sum()))
+        assert int(d_stats[7].item()) == int(cr_o.sum()) and cr_o.sum() > 1000, (sigclip, iters)
+        del got_m, got_d, cr_o, clean_o
+
+
 def test_xtalk_and_edge_fill_fullsize(frame):
     """crosstalk is local to the 16 pixels at the same (flipped) channel position: a mini frame
     assembled from the same window of every channel must transform exactly like the full frame;
