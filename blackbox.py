@@ -626,7 +626,31 @@ class Reducer:
                 live[idx] = (fn, header, fits_out)
                 yield d_raw, header
 
+        # unsigned 16-bit raw frames (plain or fpacked: what the telescopes deliver) come through the input stage: reader
+        # threads, one upload per file, the Rice decode on the device, nothing of it on the orchestrating thread
+        src = None
+        if first_raw.dtype == self.torch.uint16 and len(todo) > 1:
+            from blackbox_amd import instage
+            del first_raw
+            src = instage.InputStage(self.ctx, [fn for fn, _ in todo], (geom.ny_raw, geom.nx_raw), nreaders=2,
+                                     nbuf=pipe.depth + 2, ahead=2)
+
+            class _Source:
+                """the input stage's frames with the bookkeeping this run keeps per frame"""
+                has_next = staticmethod(src.has_next)
+
+                def __iter__(self_):
+                    return self_
+
+                def __next__(self_):
+                    raw, header, ev = next(src)
+                    idx = src.taken - 1
+                    live[idx] = (todo[idx][0], dict(header), todo[idx][1])
+                    return raw, live[idx][1], ev
+
         def on_done(idx, f):
+            if src is not None:
+                src.release(f.raw)
             fn, header, fits_out = live[idx]
             try:
                 if stage is None:
@@ -638,7 +662,7 @@ class Reducer:
             if stage is None:
                 live.pop(idx, None)
         try:
-            pipe.run(frames(), on_done=on_done)
+            pipe.run(_Source() if src is not None else frames(), on_done=on_done)
             if stage is not None and not all_written.wait(600.0):
                 log.error('output stage: %d of %d frames written', len(written), len(todo))
             for idx, err in written.items():
@@ -649,6 +673,8 @@ class Reducer:
             pipe.close()
             if stage is not None:
                 stage.close()
+            if src is not None:
+                src.close()
         return [out.get(fn) for fn in files]
 
     def _finish_from_pipeline(self, f, fn, header, fits_out, t0):
