@@ -1,5 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+[ -x tools/exp/d2h_flags ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/exp/d2h_flags tools/exp/d2h_flags.hip
 TL=$(python3 -c "import torch,os;print(os.path.join(os.path.dirname(torch.__file__),'lib'))")
 mkdir -p gpurun_out/d2h; : > gpurun_out/d2h/flags.txt
 run() { tag=$1; shift
