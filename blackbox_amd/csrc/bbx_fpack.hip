@@ -13,7 +13,12 @@
 #include "bbx_common.h"
 
 #define FP_MAXNX 16384
+#ifndef FP_THREADS
 #define FP_THREADS 1024          // one workgroup per row holds ~100 KB of LDS: one per CU, so make it wide
+#endif
+#ifndef FP_MINW
+#define FP_MINW 8                // waves per SIMD the short-buffer kernel's registers are cut for: two workgroups per CU
+#endif
 #define FP_NRANDOM 10000
 #define FP_NRESERVED 10
 
@@ -187,7 +192,7 @@ struct fp_bitw {
 // the first rows) the sampled bracket takes over, then the histograms.  A hint only chooses the path: the medians are the
 // exact order statistics whichever way, so the bytes do not depend on the timing of other workgroups.
 template <int BYTEPIX, bool FLOAT_IN, int MODE>
-__global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
+__global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
                                                  float qlevel, int dither_seed, const float* __restrict__ rnd,
                                                  uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles,
                                                  int capwords, int hist_only, unsigned* __restrict__ hint, int gen) {
@@ -300,10 +305,10 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? 8 : 4) void k_fp_tile(const
 #pragma unroll 1
             for (int attempt = first_attempt; attempt < 2 && !done; attempt++) {
             if (attempt == 1) {                                            // (attempt 0: br_lo / br_hi from the hint)
-                {
-                    const int i = (int)(((long long)tid * nd) >> 10);      // FP_NSAMP = FP_THREADS = 1024 samples at a fixed stride
+                for (int sidx = tid; sidx < FP_NSAMP; sidx += FP_THREADS) {
+                    const int i = (int)(((long long)sidx * nd) >> 10);     // FP_NSAMP = 1024 samples at a fixed stride
                     FP_KEYS(i)
-                    samp[tid] = k2; samp[1024 + tid] = k3; samp[2048 + tid] = k5;
+                    samp[sidx] = k2; samp[1024 + sidx] = k3; samp[2048 + sidx] = k5;
                 }
                 __syncthreads();
                 if (wave < 3) {
