@@ -317,6 +317,10 @@ int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const doub
     const double q1 = 4.5 / 100.0, q2 = 93.0 / 100.0;             // np.percentile(image, (4.5, 93.0))
     BBX_HIP(hipMemcpyAsync(d_w, h_gauss, (size_t)(radius + 1) * 8, hipMemcpyHostToDevice, s));
     BBX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
+#ifdef SATV                                                        // timing knock-outs (tools/exp/satvar.sh; never in the product build)
+    const int satv = getenv("BBX_DBG_SAT") ? atoi(getenv("BBX_DBG_SAT")) : 0;
+    if (satv >= 5) return BBX_OK;
+#endif
     hipLaunchKernelGGL(k_canny_init, dim3(1), dim3(256), 0, s, par, n, q1, q2, d_w, radius, hist);
     hipLaunchKernelGGL(k_canny_hist<0>, dim3(1024), dim3(256), 0, s, d_bin, n, par, hist);
     hipLaunchKernelGGL(k_canny_scan<0>, dim3(1), dim3(256), 0, s, par, hist);
@@ -326,15 +330,24 @@ int bbx_canny_edges(bbx_ctx* ctx, const float* d_bin, int ny, int nx, const doub
     hipLaunchKernelGGL(k_canny_scan<2>, dim3(1), dim3(256), 0, s, par, hist);
     hipLaunchKernelGGL(k_canny_params, dim3(1), dim3(64), 0, s, par, n, q1, q2, low_frac, high_frac);
     const dim3 gx((nx + 255) / 256, (ny + GH_ROWS - 1) / GH_ROWS), gv((nx + 255) / 256, (ny + GV_RY - 1) / GV_RY);
+#ifdef SATV
+    if (satv >= 4) return BBX_OK;
+#endif
     if (radius == 12) {
         hipLaunchKernelGGL(k_canny_gauss_v<12>, gv, dim3(256), 0, s, d_bin, ny, nx, par, tmp);
         hipLaunchKernelGGL(k_canny_gauss_h<12>, gx, dim3(256), 0, s, tmp, ny, nx, par, sm);
     } else {
         return BBX_ERR_ARG;                                        // sigma = 3 (radius 12) is what sat_detect asks for
     }
+#ifdef SATV
+    if (satv >= 3) return BBX_OK;
+#endif
     hipLaunchKernelGGL(k_canny_tile, dim3((nx + CT_X - 1) / CT_X, (ny + CT_Y * CT_NT - 1) / (CT_Y * CT_NT)), dim3(256), 0, s, sm, ny, nx, par, list, hflag, cnt,
                        (uint32_t)cap, ctx->d_err);
     BBX_LAUNCH_CHECK();
+#ifdef SATV
+    if (satv >= 2) return BBX_OK;
+#endif
     return bbx_cc_filter_list(ctx, list, cnt, cap, ny, nx, hflag, min_size, d_out, d_out_cnt, out_cap, s);
 }
 

@@ -444,50 +444,19 @@ __global__ __launch_bounds__(256) void k_fill_apply(const u64* __restrict__ R, c
 }
 
 // ---------------------------------------------------------------------------------
-// number of 8-connected objects in a sparse pixel list: hash + lock-free union-find
+// number of 8-connected objects in a sparse pixel list: index map + lock-free union-find
 // (ndimage.label(..., structure=ones((3,3)))[1])
 // ---------------------------------------------------------------------------------
-#define HEMPTY 0xffffffffu
-__device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
-    k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k;
-}
-
-// The table is allocated for the list capacity (hundreds of MB for a full frame), but a list
-// of n pixels only uses the first pow2(>= 4 n) slots of it: a typical CR / saturation list then
-// hashes into a few hundred KB that stay in L2 instead of one HBM (and TLB) miss per probe.
-__device__ __forceinline__ uint32_t cc_hmask(int n, uint32_t hmask_max) {
-    const unsigned long long want = 4ull * (unsigned long long)(n > 0 ? n : 0);
-    unsigned long long m = 1024ull;
-    while (m < want) m <<= 1;
-    return (uint32_t)min(m - 1ull, (unsigned long long)hmask_max);
-}
-
+// imap[pixel] = 1 + the list position of a listed pixel, 0 elsewhere: one word per pixel of the frame, of which a call
+// touches the lines around its listed pixels -- a plain store per pixel to fill it and at most four plain loads (three of
+// them in one line) to find a pixel's earlier neighbours, where the hash table of rounds 1-3 took a compare-and-swap and
+// a probe sequence per key.  The map is all-zero between calls: k_cc_count clears the words its call set.
 __global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
-                                                   uint32_t* keys, uint32_t* vals, uint32_t hmask, uint32_t* parent,
-                                                   uint32_t* __restrict__ slot, int cap, int32_t* err, int32_t* out) {
+                                                   uint32_t* __restrict__ imap, int cap, int32_t* err, int32_t* out) {
     int n = *cnt;
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = 0;                 // summed into by k_cc_count
     if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
-    hmask = cc_hmask(n, hmask);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = list[i];
-        uint32_t h = hash_u32(p) & hmask;
-        for (;;) {
-            const uint32_t old = atomicCAS(&keys[h], HEMPTY, p);
-            if (old == HEMPTY || old == p) { vals[h] = (uint32_t)i; slot[i] = h; break; }
-            h = (h + 1) & hmask;
-        }
-    }
-}
-
-__device__ __forceinline__ int cc_lookup(const uint32_t* keys, const uint32_t* vals, uint32_t hmask, uint32_t p) {
-    uint32_t h = hash_u32(p) & hmask;
-    for (;;) {
-        const uint32_t k = keys[h];
-        if (k == p) return (int)vals[h];
-        if (k == HEMPTY) return -1;
-        h = (h + 1) & hmask;
-    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) imap[list[i]] = (uint32_t)i + 1u;
 }
 
 // (device-scope relaxed loads: served by the L2 the atomics go to; `volatile` would make them
@@ -516,34 +485,46 @@ __device__ __forceinline__ uint32_t cc_find(uint32_t* parent, uint32_t i) {
 // tree is searched.  Only the pixels of the middle case need a real union afterwards
 // (k_cc_union) -- a few per object instead of four contended compare-and-swap loops per pixel.
 __global__ __launch_bounds__(256) void k_cc_link(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
-                                                 const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                 uint32_t hmask, uint32_t* __restrict__ parent, int32_t* __restrict__ pend,
-                                                 int ny, int nx, int cap) {
+                                                 const uint32_t* __restrict__ imap, uint32_t* __restrict__ parent,
+                                                 int32_t* __restrict__ pend, int ny, int nx, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
-    hmask = cc_hmask(n, hmask);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
         const int Y = p / nx, X = p - Y * nx;
         int link = i, other = -1;
         if (Y > 0) {
             const uint32_t up = p - (uint32_t)nx;
-            const int jb = cc_lookup(keys, vals, hmask, up);
+            const int jb = (int)imap[up] - 1;
             if (jb >= 0) link = jb;
             else {
-                const int jc = (X + 1 < nx) ? cc_lookup(keys, vals, hmask, up + 1u) : -1;
-                const int ja = (X > 0) ? cc_lookup(keys, vals, hmask, up - 1u) : -1;
+                const int jc = (X + 1 < nx) ? (int)imap[up + 1u] - 1 : -1;
+                const int ja = (X > 0) ? (int)imap[up - 1u] - 1 : -1;
                 if (jc >= 0) {
                     link = jc;
-                    other = ja >= 0 ? ja : ((X > 0) ? cc_lookup(keys, vals, hmask, p - 1u) : -1);
+                    other = ja >= 0 ? ja : ((X > 0) ? (int)imap[p - 1u] - 1 : -1);
                 } else if (ja >= 0) link = ja;
             }
         }
         if (link == i && X > 0) {                                 // nothing in the row above
-            const int jd = cc_lookup(keys, vals, hmask, p - 1u);
+            const int jd = (int)imap[p - 1u] - 1;
             if (jd >= 0) link = jd;
         }
         parent[i] = (uint32_t)link;
         pend[i] = other;
+    }
+}
+
+// every pixel -> the root of its tree.  A chain of first links is as long as the edge it follows (tens of pixels around
+// a star, thousands along a trail); the searches of the kernels that follow would each walk it with device-scope loads.
+// Here the walk uses plain loads and only the walker's own word is written: whatever a load returns -- the first link or a
+// root another thread has put there already -- is an ancestor, so the walk ends at the root whichever it sees.
+__global__ __launch_bounds__(256) void k_cc_flatten(const int32_t* __restrict__ cnt, uint32_t* parent, int cap) {
+    const int n = (*cnt > cap) ? cap : *cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t p = parent[i];
+        if (p == (uint32_t)i) continue;
+        for (;;) { const uint32_t gp = parent[p]; if (gp == p) break; p = gp; }
+        parent[i] = p;
     }
 }
 
@@ -564,19 +545,23 @@ __global__ __launch_bounds__(256) void k_cc_union(const int32_t* __restrict__ cn
     }
 }
 
-// roots = objects; the pass also empties the hash slots this list used, so the table is
-// all-HEMPTY again for the next call (no 100+ MB memset per call)
+// roots = objects (after the second k_cc_flatten every pixel points at its root); the pass also clears the words of the
+// index map this list set, so the map is all-zero again for the next call (no memset of the frame-sized map per call)
 __global__ __launch_bounds__(256) void k_cc_count(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ parent,
-                                                  const uint32_t* __restrict__ slot, uint32_t* __restrict__ keys,
+                                                  const uint32_t* __restrict__ list, uint32_t* __restrict__ imap,
                                                   int32_t* out, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
     int c = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         c += (parent[i] == (uint32_t)i) ? 1 : 0;
-        keys[slot[i]] = HEMPTY;
+        imap[list[i]] = 0u;
     }
+    // one add per workgroup (every returning or same-address atomic queues up at ~11 ns: 45 us for one per wave)
+    __shared__ int s_c[4];
     c = wave_sum_i32(c);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { const int t = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]); if (t) atomicAdd(out, t); }
 }
 
 // compaction of (mask & bit) pixels into a list
@@ -638,30 +623,23 @@ __global__ __launch_bounds__(256) void k_compact_bit_bytes(const uint8_t* __rest
 int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt, size_t cap, int ny, int nx,
                       int32_t* d_out, hipStream_t s) {
     int rc;
-    size_t hsize = 1024;
-    while (hsize < 2 * cap) hsize <<= 1;
-    // keys and values in separate blocks: the key table must not be overwritten by the values
-    // of a call with a different table size
-    uint32_t* hash = (uint32_t*)bbx_ws(ctx, WS_HASH, hsize * sizeof(uint32_t), &rc); if (rc) return rc;
-    uint32_t* vals = (uint32_t*)bbx_ws(ctx, WS_HVALS, hsize * sizeof(uint32_t), &rc); if (rc) return rc;
-    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, 3 * cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
-    uint32_t* slot = parent + cap;
-    int32_t* pend = (int32_t*)(slot + cap);
-    uint32_t* keys = hash;
-    // the key table is kept all-HEMPTY between calls (k_cc_count empties what it used); it is
-    // filled once when the workspace block is new or grew.  Slots of a smaller earlier table
-    // size are still part of the larger table's key range, so "clean" carries over.
-    if (ctx->hash_clean_ptr != (void*)hash || ctx->hash_clean_n < hsize) {
-        BBX_HIP(hipMemsetAsync(keys, 0xff, hsize * sizeof(uint32_t), s));
-        ctx->hash_clean_ptr = (void*)hash; ctx->hash_clean_n = hsize;
+    const size_t npix = (size_t)ny * nx;
+    uint32_t* imap = (uint32_t*)bbx_ws(ctx, WS_HASH, npix * sizeof(uint32_t), &rc); if (rc) return rc;
+    uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, 2 * cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
+    int32_t* pend = (int32_t*)(parent + cap);
+    // the index map is kept all-zero between calls (k_cc_count clears what its call set); it is filled once when the
+    // workspace block is new or grew
+    if (ctx->hash_clean_ptr != (void*)imap || ctx->hash_clean_n < npix) {
+        BBX_HIP(hipMemsetAsync(imap, 0, ctx->ws_bytes[WS_HASH], s));
+        ctx->hash_clean_ptr = (void*)imap; ctx->hash_clean_n = ctx->ws_bytes[WS_HASH] / sizeof(uint32_t);
     }
     const unsigned grid = 1024;
-    hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent,
-                       slot, (int)cap, ctx->d_err, d_out);
-    hipLaunchKernelGGL(k_cc_link, dim3(grid), dim3(256), 0, s, d_list, d_cnt, keys, vals, (uint32_t)(hsize - 1), parent, pend,
-                       ny, nx, (int)cap);
+    hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, imap, (int)cap, ctx->d_err, d_out);
+    hipLaunchKernelGGL(k_cc_link, dim3(grid), dim3(256), 0, s, d_list, d_cnt, imap, parent, pend, ny, nx, (int)cap);
+    hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
     hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_cnt, parent, pend, (int)cap);
-    hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, d_cnt, parent, slot, keys, d_out, (int)cap);
+    hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
+    hipLaunchKernelGGL(k_cc_count, dim3(grid / 4), dim3(256), 0, s, d_cnt, parent, d_list, imap, d_out, (int)cap);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
@@ -669,7 +647,7 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
 // ---- hysteresis + small-object filter on a pixel list (Canny edges of the satellite-trail detector) ----
 // components (8-connected) of the listed pixels; a component stays when one of its pixels carries a flag (the
 // high mask) and it has at least min_size pixels; the pixels of the components that stay go to d_out
-__global__ __launch_bounds__(256) void k_ccf_acc(const int32_t* __restrict__ cnt, int cap, uint32_t* parent, const uint8_t* __restrict__ flag,
+__global__ __launch_bounds__(256) void k_ccf_acc(const int32_t* __restrict__ cnt, int cap, const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flag,
                                                  uint32_t* size, uint32_t* has) {
     const int n = (*cnt > cap) ? cap : *cnt;
     const int lane = threadIdx.x & 63;
@@ -678,7 +656,7 @@ __global__ __launch_bounds__(256) void k_ccf_acc(const int32_t* __restrict__ cnt
         const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         bool on = i < n;
         uint32_t root = 0;
-        if (on) { root = cc_find(parent, (uint32_t)i); if (flag[i]) has[root] = 1u; }
+        if (on) { root = parent[i]; if (flag[i]) has[root] = 1u; }       // (its root: k_cc_flatten ran after the unions)
         // neighbours in the list mostly belong to the same component: one add per root and wave (an add per pixel on the
         // few roots of long edges queues up at ~11 ns each: 117 us for the edges of a frame)
         unsigned long long m = __builtin_amdgcn_ballot_w64(on);
@@ -692,7 +670,7 @@ __global__ __launch_bounds__(256) void k_ccf_acc(const int32_t* __restrict__ cnt
         }
     }
 }
-__global__ __launch_bounds__(256) void k_ccf_emit(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, int cap, uint32_t* parent,
+__global__ __launch_bounds__(256) void k_ccf_emit(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, int cap, const uint32_t* __restrict__ parent,
                                                   const uint32_t* __restrict__ size, const uint32_t* __restrict__ has, uint32_t min_size,
                                                   uint32_t* out, int32_t* out_cnt, uint32_t out_cap, int32_t* err) {
     const int n = (*cnt > cap) ? cap : *cnt;
@@ -701,7 +679,7 @@ __global__ __launch_bounds__(256) void k_ccf_emit(const uint32_t* __restrict__ l
     for (int r = 0; r < nround; r++) {
         const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         bool keep = false;
-        if (i < n) { const uint32_t root = cc_find(parent, (uint32_t)i); keep = has[root] && size[root] >= min_size; }
+        if (i < n) { const uint32_t root = parent[i]; keep = has[root] && size[root] >= min_size; }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (!m) continue;
         unsigned base = 0;
@@ -782,12 +760,12 @@ __global__ __launch_bounds__(256) void k_compact_abs(const float* __restrict__ i
 }
 
 __global__ __launch_bounds__(256) void k_cc_peak(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt, int cap,
-                                                 uint32_t* parent, const float* __restrict__ img,
+                                                 const uint32_t* __restrict__ parent, const float* __restrict__ img,
                                                  unsigned long long* __restrict__ best) {
     const int n = (*cnt > cap) ? cap : *cnt;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
-        const uint32_t root = cc_find(parent, (uint32_t)i);
+        const uint32_t root = parent[i];
         // largest |value| wins, ties go to the smallest pixel index (first in C order)
         const unsigned long long key = ((unsigned long long)__float_as_uint(fabsf(img[p])) << 32) | (0xffffffffu - p);
         atomicMax(&best[root], key);
@@ -798,11 +776,21 @@ __global__ __launch_bounds__(256) void k_cc_peak_emit(const int32_t* __restrict_
                                                       const unsigned long long* __restrict__ best, const float* __restrict__ img,
                                                       int nx, int max_out, int32_t* yx, float* val, int32_t* nout) {
     const int n = (*cnt > cap) ? cap : *cnt;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (parent[i] != (uint32_t)i) continue;
-        const uint32_t p = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
-        const int k = atomicAdd(nout, 1);
-        if (k < max_out) { yx[2 * k] = (int)(p / nx); yx[2 * k + 1] = (int)(p % nx); val[k] = img[p]; }
+    const int lane = threadIdx.x & 63;
+    const int step = (int)(gridDim.x * blockDim.x), nround = (n + step - 1) / step;
+    for (int r = 0; r < nround; r++) {
+        const int i = r * step + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        const bool root = i < n && parent[i] == (uint32_t)i;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(root);          // one reservation per wave
+        if (!m) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(nout, (int)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (root) {
+            const int k = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const uint32_t p = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
+            if (k < max_out) { yx[2 * k] = (int)(p / nx); yx[2 * k + 1] = (int)(p % nx); val[k] = img[p]; }
+        }
     }
 }
 

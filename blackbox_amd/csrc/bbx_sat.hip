@@ -590,6 +590,9 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     hipLaunchKernelGGL(k_bin_minmax, dim3(1024), dim3(256), 0, s, bin, nb, st);
     // acstools' front end: sigma = 3 (sat_detect), low_thresh = 0.1 (default), h_thresh = 0.2 (sat_detect), small_edge = 60
     rc = bbx_canny_edges(ctx, bin, nyb, nxb, h_gauss, gauss_radius, 0.1, 0.2, 60, list, cnt, (uint32_t)cap, s); if (rc) return rc;
+#ifdef SATV                                                        // timing knock-outs (tools/exp/satvar.sh; never in the product build)
+    if (getenv("BBX_DBG_SAT") && atoi(getenv("BBX_DBG_SAT")) >= 1) return BBX_OK;
+#endif
     if ((size_t)nrho * 4 <= 150 * 1024) {
         // rho histogram of one angle fits in LDS (frames up to ~26k binned pixels across)
         hipLaunchKernelGGL(k_hough_lds, dim3(ntheta), dim3(1024), (size_t)nrho * 4, s, list, cnt, (uint32_t)cap, nxb, cs, nrho, st);
