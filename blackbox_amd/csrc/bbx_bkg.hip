@@ -70,10 +70,10 @@ template <bool UPPER> __device__ __forceinline__ int box_count_below(const float
     return (nb - 1) * 64 + __popcll(__ballot(in));
 }
 
-__global__ __launch_bounds__(64) void k_bkg_boxstats(const float* __restrict__ data, const uint8_t* __restrict__ mask,
-                                                     const uint8_t* __restrict__ objmask, int ny, int nx, int box,
-                                                     int nbx, int nboxes, float limfrac, float* __restrict__ mini_med,
-                                                     float* __restrict__ mini_std) {
+
+__device__ __forceinline__ void box_full_sort(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                              const uint8_t* __restrict__ objmask, int nx, int box,
+                                              int nbx, int ibox, float limfrac, float* mini_med, float* mini_std) {
     // one wave per box.  The usable pixels become order-preserving integer keys, 64 per lane
     // in registers, and are sorted once by a bitonic network: stages between registers of a
     // lane are v_min/v_max (or v_med3 against a per-lane 0 / ~0 when the direction depends on
@@ -81,11 +81,6 @@ __global__ __launch_bounds__(64) void k_bkg_boxstats(const float* __restrict__ d
     // pixels go to LDS; the clip iterations then only move the two ends of the index range.
     __shared__ float v[BOX_NS + 64];
     const int lane = threadIdx.x;
-    // workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of boxes, so that
-    // the cache lines which neighbouring boxes share are fetched into one L2 only
-    const int per = (nboxes + 7) >> 3;
-    const int ibox = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (ibox >= nboxes) return;
     const int by = ibox / nbx, bx = ibox - by * nbx;
     const int npx = box * box;
     const int q64 = 64 / box, r64 = 64 - q64 * box;
@@ -179,6 +174,280 @@ __global__ __launch_bounds__(64) void k_bkg_boxstats(const float* __restrict__ d
         if (b - a <= 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[ibox] = nanv; mini_std[ibox] = nanv; }
         else { mini_med[ibox] = (float)med; mini_std[ibox] = (float)sd; }
     }
+}
+
+// all boxes, one workgroup each (BBX_OPT_BKG_FULL_SORT) ...
+__global__ __launch_bounds__(64) void k_bkg_boxstats(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                     const uint8_t* __restrict__ objmask, int ny, int nx, int box,
+                                                     int nbx, int nboxes, float limfrac, float* mini_med, float* mini_std) {
+    // workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of boxes, so that
+    // the cache lines which neighbouring boxes share are fetched into one L2 only
+    const int per = (nboxes + 7) >> 3;
+    const int ibox = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (ibox < nboxes) box_full_sort(data, mask, objmask, nx, box, nbx, ibox, limfrac, mini_med, mini_std);
+}
+// ... or the boxes k_bkg_boxstats_fast has listed (half a percent of a frame's).  The list counters alternate between
+// calls: this launch clears the one the next call will fill, so no call needs a memset.
+__global__ __launch_bounds__(64) void k_bkg_boxstats_list(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                          const uint8_t* __restrict__ objmask, int ny, int nx, int box,
+                                                          int nbx, int nboxes, float limfrac, float* mini_med, float* mini_std,
+                                                          const int32_t* __restrict__ nlist, const int32_t* __restrict__ list, int32_t* nlist_next) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nlist_next = 0;
+    const int n = min(*nlist, nboxes);
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        box_full_sort(data, mask, objmask, nx, box, nbx, list[t], limfrac, mini_med, mini_std);
+        __syncthreads();
+    }
+}
+
+// ---- the same statistics without sorting the box ---------------------------------------------------------------------
+// The clip only ever needs (i) the middle order statistic(s) of the survivors and (ii) the pixels it removes, which sit in
+// the wings.  So: 512 of the box's slots are sorted as a sample (8 registers per lane); its order statistics give a
+// bracket [lo, hi] around the median (sample ranks 0.42 .. 0.58) and two wing limits (0.05 / 0.85).  Two passes over the 64
+// registers, neither with a step that waits for another lane: the first counts per lane the keys of the bracket, of the
+// wings and below the bracket and sums the pixels between the wings about a pivot; after one scan of the lane counts the
+// second writes the bracket (<= 1024 keys) and the wings (<= 1024) into LDS.  The bracket alone is sorted (16 registers
+// per lane).  A clip round then reads its median(s) from the sorted bracket by rank and scans the wing list for what it
+// removes.  Whenever an assumption fails -- bracket or wings overflow (ties, constant boxes), a median outside the bracket,
+// a clip limit inside the unlisted middle, too few samples -- the box is listed and k_bkg_boxstats_list sorts it in full:
+// the medians are the same order statistics whichever path ran.
+#define BOXF_NB 1024
+#define BOXF_NT 1024
+template <int NR, int K, int J> __device__ __forceinline__ void bs_static(uint32_t (&k)[NR]) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int q = r ^ J;
+        if (q > r) {
+            const uint32_t a = k[r], b = k[q];
+            const uint32_t lo = min(a, b), hi = max(a, b);
+            if ((r & K) == 0) { k[r] = lo; k[q] = hi; } else { k[r] = hi; k[q] = lo; }
+        }
+    }
+}
+template <int NR, int J> __device__ __forceinline__ void bs_lane(uint32_t (&k)[NR], uint32_t clo) {
+    const uint32_t chi = ~clo;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int q = r ^ J;
+        if (q > r) {
+            const uint32_t a = k[r], b = k[q];
+            k[r] = umed3(a, b, clo); k[q] = umed3(a, b, chi);
+        }
+    }
+}
+// 64 * NR keys, NR per lane, ascending: sorted position of (lane, r) is lane * NR + r
+template <int NR> __device__ __forceinline__ void bs_sort(uint32_t (&k)[NR], int lane) {
+    bs_static<NR, 2, 1>(k);
+    bs_static<NR, 4, 2>(k); bs_static<NR, 4, 1>(k);
+    if (NR >= 16) { bs_static<NR, 8, 4>(k); bs_static<NR, 8, 2>(k); bs_static<NR, 8, 1>(k); }
+    for (int ll = 0; ll <= 6; ll++) {                     // runs of NR << ll elements
+        const bool asc = (lane & (1 << ll)) == 0;
+        for (int m = (1 << ll) >> 1; m > 0; m >>= 1) {
+            const uint32_t c = (((lane & m) == 0) == asc) ? 0u : 0xffffffffu;
+#pragma unroll
+            for (int r = 0; r < NR; r++) k[r] = umed3(k[r], (uint32_t)__shfl_xor((int)k[r], m), c);
+        }
+        const uint32_t clo = asc ? 0u : 0xffffffffu;
+        if (NR >= 16) bs_lane<NR, 8>(k, clo);
+        bs_lane<NR, 4>(k, clo); bs_lane<NR, 2>(k, clo); bs_lane<NR, 1>(k, clo);
+    }
+}
+__device__ __forceinline__ uint32_t box_float_key(float f) { const uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ int box_bslot(int i) { return i + (i >> 4); }       // sorted bracket in LDS: one pad word per lane's 16
+
+#ifndef BOXF_MINW
+#define BOXF_MINW 3
+#endif
+__global__ __launch_bounds__(64, BOXF_MINW) void k_bkg_boxstats_fast(const float* __restrict__ data, const uint8_t* __restrict__ mask,
+                                                          const uint8_t* __restrict__ objmask, int ny, int nx, int box,
+                                                          int nbx, int nboxes, float limfrac, float* __restrict__ mini_med,
+                                                          float* __restrict__ mini_std, int32_t* nfail, int32_t* __restrict__ flist) {
+    __shared__ uint32_t s_br[BOXF_NB + 128];                 // list (later: sorted, one pad word per 16) | a slot per lane for the stores that do not count
+    __shared__ uint32_t s_tl[BOXF_NT + 64];
+    const int lane = threadIdx.x;
+    const int per = (nboxes + 7) >> 3;
+    const int ibox = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (ibox >= nboxes) return;
+    const int by = ibox / nbx, bx = ibox - by * nbx;
+    const int npx = box * box;
+    const int q64 = 64 / box, r64 = 64 - q64 * box;
+    uint32_t k[64];
+    int cnt = 0;
+    {
+        int yy = lane / box, xx = lane - yy * box;
+        const size_t o0 = (size_t)(by * box) * nx + (size_t)bx * box;
+        const float* pd = data + o0; const uint8_t* pm = mask + o0; const uint8_t* po = objmask + o0;
+        const uint32_t omax = (uint32_t)((box - 1) * nx + box - 1);
+        unsigned mk[64];
+#pragma unroll
+        for (int c = 0; c < 64; c++) {
+            const uint32_t o = min((uint32_t)(yy * nx + xx), omax);
+            k[c] = __float_as_uint(pd[o]);
+            mk[c] = pm[o];
+            if (objmask) mk[c] |= po[o];
+            yy += q64; xx += r64;
+            if (xx >= box) { xx -= box; yy++; }
+        }
+#pragma unroll
+        for (int c = 0; c < 64; c++) {
+            const uint32_t u = k[c];
+            const float d = __uint_as_float(u);
+            const bool ok = (c * 64 + lane < npx) & (mk[c] == 0) & (d != 0.f) & (d == d);
+            k[c] = ok ? (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) : BOX_PAD;
+            cnt += ok;
+        }
+    }
+    const int n0 = wave_sum_i32(cnt);
+    if ((float)n0 < limfrac * (float)npx || n0 == 0) {
+        if (lane == 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[ibox] = nanv; mini_std[ibox] = nanv; }
+        return;
+    }
+#if defined(BOXK_NOFAIL)                                           // (timing knock-outs, tools/dbg/box_knock.sh; never in the product build)
+#define BOXF_LEAVE(why) do { } while (0)
+#elif defined(BOXV)                                                // (tools/dbg/box_fail.py: why boxes are left to the full sort; never in the product build)
+#define BOXF_LEAVE(why) do { if (lane == 0) { flist[atomicAdd(nfail, 1)] = ibox; mini_std[ibox] = __uint_as_float(0x7fc0b0b0u); mini_med[ibox] = (float)(why); } return; } while (0)
+#else
+#define BOXF_LEAVE(why) do { if (lane == 0) flist[atomicAdd(nfail, 1)] = ibox; return; } while (0)
+#endif
+    // ---- the sample: slots 8 j * 64 + lane, spread over the rows of the box
+    uint32_t lo_key, hi_key, tl_key, th_key;
+    double piv;
+    {
+        uint32_t sm[8];
+        int nv = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { sm[j] = k[8 * j]; nv += sm[j] != BOX_PAD; }
+        const int nsv = wave_sum_i32(nv);
+        if (nsv < 128) BOXF_LEAVE(1);
+#ifndef BOXK_NOSAMP
+        bs_sort<8>(sm, lane);
+#endif
+#pragma unroll
+        for (int j = 0; j < 8; j++) s_br[lane * 8 + j] = sm[j];
+        __syncthreads();
+        const int jl = (int)((float)nsv * 0.42f), jh = min((int)((float)nsv * 0.58f) + 1, nsv - 1);
+        // wings: below the sample's 5 % point and above its 85 % point (stars make the upper wing the one a clip reaches into)
+        const int jtl = (int)((float)nsv * 0.05f), jth = min((int)((float)nsv * 0.85f), nsv - 1);
+        lo_key = s_br[jl]; hi_key = s_br[jh]; tl_key = s_br[jtl]; th_key = s_br[jth];
+        piv = (double)box_key_value(s_br[nsv >> 1]);
+        __syncthreads();
+    }
+    // ---- pass 1 (no lane talks to another): per-lane counts of bracket / wing keys and of keys below the bracket, and the
+    // sums about the pivot of the pixels BETWEEN the wings in float32 (they lie within a sigma or two of the pivot: the
+    // float32 partial sums of 64 such terms carry ~1e-7; a star pixel would leave the rounding error of its 1e9-sized square
+    // behind after the clip has removed it -- the wing pixels' sums are taken in float64 from their list below)
+    int c_lo = 0, nb = 0, nt = 0;
+    double s1 = 0.0, s2 = 0.0;
+    const uint32_t wbr = hi_key - lo_key, wth = BOX_PAD - 1u - th_key;
+    int nbl = 0, ntl = 0;
+    {
+        const float pivf = (float)piv;
+        float f1 = 0.f, f2 = 0.f;
+#ifdef BOXK_NOCLASS
+        for (int c = 0; c < 1; c++) {
+#else
+#pragma unroll
+        for (int c = 0; c < 64; c++) {
+#endif
+            const uint32_t u = k[c];
+            const bool inb = (u - lo_key) <= wbr;
+            const bool inw = (u < tl_key) || ((u - th_key - 1u) < wth);          // below the low limit, or th_key < u < BOX_PAD
+            nbl += inb ? 1 : 0; ntl += inw ? 1 : 0;
+            c_lo += (u < lo_key) ? 1 : 0;
+            const uint32_t xb = u ^ ((uint32_t)((int32_t)~u >> 31) | 0x80000000u);          // box_key_value
+            const float t = (inw || u == BOX_PAD) ? 0.f : __uint_as_float(xb) - pivf;
+            f1 += t; f2 = fmaf(t, t, f2);
+        }
+        c_lo = wave_sum_i32(c_lo);
+        s1 = wave_sum_f64((double)f1); s2 = wave_sum_f64((double)f2);
+    }
+    // lane offsets into the two lists
+    int ob = nbl, ow = ntl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int tb = __shfl_up(ob, o), tw = __shfl_up(ow, o);
+        if (lane >= o) { ob += tb; ow += tw; }
+    }
+    nb = __builtin_amdgcn_readlane(ob, 63); nt = __builtin_amdgcn_readlane(ow, 63);
+    ob -= nbl; ow -= ntl;
+    if (nb > BOXF_NB || nt > BOXF_NT) BOXF_LEAVE(nb > BOXF_NB ? 2 : 3);
+    // ---- pass 2: the keys into the lists (lane after lane); a key of neither list goes to a slot of the lane's own behind
+    // the list, so that no store needs a mask of its own
+    {
+        const uint32_t dumpb = BOXF_NB + 64 + lane, dumpw = BOXF_NT + lane;
+#ifdef BOXK_NOCLASS
+        for (int c = 0; c < 1; c++) {
+#else
+#pragma unroll
+        for (int c = 0; c < 64; c++) {
+#endif
+            uint32_t u = k[c];
+            asm volatile("" : "+v"(u));                             // (the compiler would carry pass 1's 128 lane masks over in scalar registers, and spill them)
+            const bool inb = (u - lo_key) <= wbr;
+            const bool inw = (u < tl_key) || ((u - th_key - 1u) < wth);
+            s_br[inb ? (uint32_t)ob : dumpb] = u; ob += inb ? 1 : 0;
+            s_tl[inw ? (uint32_t)ow : dumpw] = u; ow += inw ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    {
+        double d1 = 0.0, d2 = 0.0;
+        for (int i = lane; i < nt; i += 64) { const double t = (double)box_key_value(s_tl[i]) - piv; d1 += t; d2 += t * t; }
+        s1 += wave_sum_f64(d1); s2 += wave_sum_f64(d2);
+    }
+    // ---- the bracket, sorted, back into LDS
+    {
+        uint32_t kb[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) kb[r] = (r * 64 + lane < nb) ? s_br[r * 64 + lane] : BOX_PAD;
+        __syncthreads();
+#ifndef BOXK_NOBR
+        bs_sort<16>(kb, lane);
+#endif
+#pragma unroll
+        for (int r = 0; r < 16; r++) s_br[lane * 17 + r] = kb[r];
+        __syncthreads();
+    }
+    // ---- the clip: survivors = keys in [cl, ch]; a = how many were removed below
+    int a = 0, n = n0;
+    uint32_t cl = 0u, ch = BOX_PAD - 1u;
+    double sd = 0.0, med = 0.0;
+    for (int it = 0; it <= 5; it++) {
+        const double m1 = s1 / (double)n;
+        const double var = s2 / (double)n - m1 * m1;      // std about the mean, ddof 0
+        sd = sqrt(var > 0.0 ? var : 0.0);
+        const int r1 = a + n / 2 - c_lo, r0 = (n & 1) ? r1 : r1 - 1;
+        if (r0 < 0 || r1 >= nb) BOXF_LEAVE(4);            // a median outside the bracket
+        const double v1 = (double)box_key_value(s_br[box_bslot(r1)]);
+        med = (n & 1) ? v1 : ((double)box_key_value(s_br[box_bslot(r0)]) + v1) * 0.5;
+        if (it == 5) break;
+        const double lo = med - 3.0 * sd, hi = med + 3.0 * sd;
+        // x < lo  <=>  key(x) < nl;  x > hi  <=>  key(x) > nh   (for float x: the limits rounded to float, stepped inwards where the rounding went outwards)
+        const float flo = (float)lo, fhi = (float)hi;
+        const uint32_t nl = box_float_key(flo) + (((double)flo < lo) ? 1u : 0u);
+        const uint32_t nh = box_float_key(fhi) - (((double)fhi > hi) ? 1u : 0u);
+        if (nl > tl_key || nh < th_key) BOXF_LEAVE(5);    // a limit inside the unlisted middle
+        int tlo = 0, thi = 0;
+        double d1 = 0.0, d2 = 0.0;
+        for (int i = lane; i < nt; i += 64) {
+            const uint32_t u = s_tl[i];
+            const bool surv = u >= cl && u <= ch;
+            const bool lc = surv && u < nl, hc = surv && u > nh;
+            tlo += lc; thi += hc;
+            if (lc || hc) { const double t = (double)box_key_value(u) - piv; d1 += t; d2 += t * t; }
+        }
+        tlo = wave_sum_i32(tlo); thi = wave_sum_i32(thi);
+        if (tlo == 0 && thi == 0) break;                  // nothing clipped: these are the final statistics
+        s1 -= wave_sum_f64(d1); s2 -= wave_sum_f64(d2);
+        a += tlo; n -= tlo + thi;
+        cl = max(cl, nl); ch = min(ch, nh);
+        if (n <= 0) break;
+    }
+    if (lane == 0) {
+        if (n <= 0) { const float nanv = __uint_as_float(0x7fc00000u); mini_med[ibox] = nanv; mini_std[ibox] = nanv; }
+        else { mini_med[ibox] = (float)med; mini_std[ibox] = (float)sd; }
+    }
+#undef BOXF_LEAVE
 }
 
 // one workgroup; [mini] is updated in place, [tmp] is scratch of the same size
@@ -650,8 +919,22 @@ int bbx_bkg_boxstats(bbx_ctx* ctx, int ny, int nx, int box, const float* d_data,
     if (box < 2 || box > 64 || ny % box || nx % box || (size_t)nx * 64 > 0x7fffffffu) return BBX_ERR_ARG;
     const int nby = ny / box, nbx = nx / box;
     const int nboxes = nby * nbx;
-    hipLaunchKernelGGL(k_bkg_boxstats, dim3(((nboxes + 7) / 8) * 8), dim3(64), 0, (hipStream_t)stream, d_data, d_mask, d_objmask,
-                       ny, nx, box, nbx, nboxes, limfrac, d_mini_med, d_mini_std);
+    if (ctx->bkg_full_sort) {
+        hipLaunchKernelGGL(k_bkg_boxstats, dim3(((nboxes + 7) / 8) * 8), dim3(64), 0, (hipStream_t)stream, d_data, d_mask, d_objmask,
+                           ny, nx, box, nbx, nboxes, limfrac, d_mini_med, d_mini_std);
+    } else {
+        int rc;
+        int32_t* flist = (int32_t*)bbx_ws(ctx, WS_BOXFAIL, (size_t)nboxes * sizeof(int32_t), &rc); if (rc) return rc;
+        int32_t* nf = &ctx->d_counters[CNT_BOXFAIL0 + (ctx->box_pp & 1)], *nf_next = &ctx->d_counters[CNT_BOXFAIL0 + ((ctx->box_pp + 1) & 1)];
+        ctx->box_pp ^= 1;
+        hipLaunchKernelGGL(k_bkg_boxstats_fast, dim3(((nboxes + 7) / 8) * 8), dim3(64), 0, (hipStream_t)stream, d_data, d_mask, d_objmask,
+                           ny, nx, box, nbx, nboxes, limfrac, d_mini_med, d_mini_std, nf, flist);
+#if defined(BOXV) || defined(BOXK_NOFAIL)
+        if (getenv("BBX_DBG_BOX_NOFALLBACK")) return BBX_OK;
+#endif
+        hipLaunchKernelGGL(k_bkg_boxstats_list, dim3(min(nboxes, 1024)), dim3(64), 0, (hipStream_t)stream, d_data, d_mask, d_objmask,
+                           ny, nx, box, nbx, nboxes, limfrac, d_mini_med, d_mini_std, nf, flist, nf_next);
+    }
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -74,6 +74,8 @@ struct bbx_ctx {
     const float* bcand_img_med; double bcand_img_nsig; size_t bcand_npix;
     int    wait_sleep_us;      // BBX_OPT_WAIT_SLEEP_US: host waits poll an event and sleep this long between polls (0: hipStreamSynchronize)
     hipEvent_t wait_ev; int32_t* h_err;   // bbx_wait's event, bbx_sync's pinned copy of the error words
+    int    box_pp;             // which of the two CNT_BOXFAIL counters the next bbx_bkg_boxstats call fills
+    int    bkg_full_sort;      // BBX_OPT_BKG_FULL_SORT: every box of bbx_bkg_boxstats through the full sort (tests: same statistics as the bracket path)
     int    fpack_hist_only;    // BBX_OPT_FPACK_HIST_ONLY: row medians by radix histograms over all keys (tests: same bytes as the bracket path)
     int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context
@@ -116,13 +118,14 @@ enum {
     CNT_TICKET = 192,     // workgroups of the current kernel that have finished (last one does the epilogue)
     CNT_ZCAND = 208,      // bbx_zogy_frame: pixels with |Scorr| >= the candidate threshold (bbx_zogy_candidates)
     CNT_BCAND = 224,      // bbx_spline_zoom_sub: pixels above the catalogue threshold (bbx_zoom_candidates)
+    CNT_BOXFAIL0 = 240,   // bbx_bkg_boxstats: boxes left to the full sort; two counters (CNT_BOXFAIL0, + 1) used by alternate calls
     CNT_MAX = 256
 };
 
 // workspace slots
 enum {
     WS_HASH = 0, WS_CCLIST, WS_PARENT, WS_BITS_M, WS_BITS_C, WS_BITS_R, WS_TILES,
-    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND, WS_BCAND, WS_FPHINT,
+    WS_CAND, WS_FLAGS, WS_STAGE2, WS_CRLIST, WS_HIST, WS_SEL, WS_MISC, WS_STRIP, WS_HVALS, WS_CRORIG, WS_CANNY, WS_ZCAND, WS_BCAND, WS_FPHINT, WS_BOXFAIL,
     WS_MAX
 };
 

@@ -234,6 +234,7 @@ int bbx_set_option(bbx_ctx* ctx, int option, int value) {
     if (option == BBX_OPT_ZOGY_KWIN_OFF) { ctx->zogy_kwin_off = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_FPACK_ONE_WG) { ctx->fpack_one_wg = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_FPACK_HIST_ONLY) { ctx->fpack_hist_only = value ? 1 : 0; return BBX_OK; }
+    if (option == BBX_OPT_BKG_FULL_SORT) { ctx->bkg_full_sort = value ? 1 : 0; return BBX_OK; }
     if (option == BBX_OPT_WAIT_SLEEP_US) { ctx->wait_sleep_us = value > 0 ? value : 0; return BBX_OK; }
     return BBX_ERR_ARG;
 }

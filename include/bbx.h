@@ -111,6 +111,10 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
  * in round 3); costs up to n us of latency per wait.  (hipDeviceScheduleBlockingSync was tried first: waits never
  * returned on the GPU boxes of this project.) */
 #define BBX_OPT_WAIT_SLEEP_US 7
+/* BBX_OPT_BKG_FULL_SORT (default 0): bbx_bkg_boxstats takes the clipped statistics of a box from a sorted bracket around its
+ * median and the list of its wing pixels, and sorts only the boxes where that does not hold (ties, constant boxes); 1: every
+ * box is sorted in full (rounds 2-3).  The medians are the same order statistics either way (tests compare the two). */
+#define BBX_OPT_BKG_FULL_SORT 8
 int  bbx_set_option(bbx_ctx *ctx, int option, int value);
 /* Host waits that do not spin.  bbx_wait: everything queued on [stream] so far has finished (no error check: bbx_sync does
  * that); bbx_event_wait: [event] (a hipEvent_t, e.g. of bbx_event_create or a framework's) has completed.  sleep_us > 0:

@@ -67,6 +67,56 @@ def test_box_statistics_box_sizes(ctx, box):
         assert sh[0, 0] == 0 and mh[0, 0] == F(17.25)
 
 
+def test_box_statistics_bracket_path_equals_full_sort_and_oracle(ctx):
+    """bbx_bkg_boxstats takes the clipped statistics from a sorted bracket around the median + the list of wing pixels and
+    leaves boxes where that does not hold to the full sort (BBX_OPT_BKG_FULL_SORT = 1: all of them).  Continuous sky with
+    stars, cosmic-ray-like outliers on both sides, masked pixels, a gradient across a box, a box that is half star, a box with
+    a few hundred usable pixels: the same medians bit for bit from both paths and from the oracle, std within 2e-6."""
+    from blackbox_amd._lib import lib, check
+    import ctypes as C
+    rs = np.random.RandomState(7)
+    box, nby, nbx = 60, 10, 12
+    ny, nx = nby * box, nbx * box
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    data = 300 + 0.3 * xx + 12 * rs.standard_normal((ny, nx))
+    for _ in range(400):                                            # stars of all sizes
+        y0, x0, f, w = rs.uniform(0, ny), rs.uniform(0, nx), 10 ** rs.uniform(2, 5), rs.uniform(1.2, 4)
+        r2 = (yy - y0) ** 2 + (xx - x0) ** 2
+        sel = r2 < (8 * w) ** 2
+        data[sel] += f * np.exp(-r2[sel] / (2 * w * w))
+    data[rs.random_sample((ny, nx)) < 0.003] -= 400                # negative outliers
+    data[0:box, 0:box] += 40 * (xx[0:box, 0:box] > 30)             # a step inside one box: two populations
+    data[box:2 * box, 0:box] += 2000 * np.exp(-((yy[box:2 * box, 0:box] - 90.) ** 2 + (xx[box:2 * box, 0:box] - 30.) ** 2) / 800.)
+    data = data.astype(F)
+    mask = np.zeros((ny, nx), np.uint8)
+    mask[rs.random_sample((ny, nx)) < 0.03] = 1
+    mask[2 * box:3 * box, 0:box][rs.random_sample((box, box)) < 0.45] = 4          # just above limfrac
+    objmask = (rs.random_sample((ny, nx)) < 0.02).astype(np.uint8)
+    med_o, std_o = Z.get_back_mini(data, mask, objmask, box=box)
+    t_data, t_mask, t_obj = dev(ctx, data), dev(ctx, mask), dev(ctx, objmask)
+    out = {}
+    try:
+        for full in (0, 1):
+            check(lib.bbx_set_option(ctx.h, 8, full), 'bbx_set_option', ctx.h)
+            m = torch.full((nby, nbx), -1.0, dtype=torch.float32, device=ctx.device)
+            s = torch.full((nby, nbx), -1.0, dtype=torch.float32, device=ctx.device)
+            check(lib.bbx_bkg_boxstats(ctx.h, ny, nx, box, C.c_void_p(t_data.data_ptr()), C.c_void_p(t_mask.data_ptr()),
+                                       C.c_void_p(t_obj.data_ptr()), 0.5, C.c_void_p(m.data_ptr()), C.c_void_p(s.data_ptr()),
+                                       ctx.stream()), 'boxstats')
+            ctx.sync()
+            out[full] = (m.cpu().numpy(), s.cpu().numpy())
+    finally:
+        check(lib.bbx_set_option(ctx.h, 8, 0), 'bbx_set_option', ctx.h)
+    ok = ~np.isnan(med_o)
+    assert ok.sum() >= nby * nbx - 2
+    for full in (0, 1):
+        mh, sh = out[full]
+        assert np.array_equal(np.isnan(mh), np.isnan(med_o))
+        assert np.array_equal(mh[ok], med_o[ok]), 'medians, full_sort=%d' % full
+        np.testing.assert_allclose(sh[ok], std_o[ok], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(out[0][1][ok], out[1][1][ok], rtol=3e-7, atol=0)
+
+
 def test_background_mesh(ctx):
     rs = np.random.RandomState(1)
     box, nby, nbx = 20, 12, 16
