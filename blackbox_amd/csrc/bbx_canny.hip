@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void k_canny_gauss_v(const float* __restrict__
 #ifndef GH_ROWS
 #define GH_ROWS 8                                          // rows per workgroup: one barrier, one set of weights for all of them
 #endif
+// (tried in round 4: four neighbouring pixels per thread from one register window, the row in four x-mod-4 planes so that
+// the lanes read consecutive words -- 7 LDS reads per pixel instead of 25 -- 144 us against 116: the kernel is bound by its
+// chains of dependent float64 operations and the per-workgroup set-up, not by the LDS)
 template <int R>
 __global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__ tmp, int ny, int nx, const canny_par* __restrict__ p,
                                                        double* __restrict__ sm) {
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__
 }
 
 // Gradients, magnitude, non-maximum suppression and both thresholds on a 64 x 16 tile: the smoothed image with a
-// 2-pixel halo and the magnitudes with a 1-pixel halo live in LDS; the low-mask pixels of the tile go to the list in
+// 2-pixel halo lives in LDS (float64 + a float32 copy for the screen); the low-mask pixels of the tile go to the list in
 // one reservation, each with a flag "also in the high mask".
 //   ndimage.sobel(axis): derivative along the axis ([-1, 0, 1]), [1, 2, 1] across it, reflecting borders (index -1 -> 0:
 //   the clamped loads below); magnitude sqrt(i^2 + j^2)
@@ -232,13 +235,27 @@ __global__ __launch_bounds__(256) void k_canny_gauss_h(const float* __restrict__
 __global__ __launch_bounds__(256) void k_canny_tile(const double* __restrict__ sm, int ny, int nx, const canny_par* __restrict__ p,
                                                     uint32_t* list, uint8_t* hflag, int32_t* cnt, uint32_t cap, int32_t* err) {
     __shared__ double s_sm[CT_Y + 4][CT_X + 4];
-    __shared__ double s_mag[CT_Y + 2][CT_X + 2];
+    __shared__ float s_smf[CT_Y + 4][CT_X + 4];             // the same tile in float32: the screen below
     __shared__ uint32_t q[CT_Q];
-    __shared__ unsigned qn, gbase;
+    __shared__ uint16_t s_cand[CT_X * CT_Y];                // pixels of the tile that passed the screen
+    __shared__ unsigned qn, gbase, ncand;
     const int tid = threadIdx.x, x0 = blockIdx.x * CT_X;
-    if (tid == 0) qn = 0;
+    if (tid == 0) { qn = 0; ncand = 0; }
     const double low = p->low, high = p->high;
     const bool live = !p->degenerate;
+    // Screen: 99 % of the pixels are far below the low threshold.  Their float32 gradient magnitude (squared; inputs in
+    // [0, 1], error ~2e-5 of low^2 at the threshold) settles that with a margin of 2e-3; only the pixels that pass it -- and,
+    // for the non-maximum test, the neighbours they look at -- get the float64 Sobel sums and the correctly rounded square
+    // root that skimage's float64 arithmetic demands (they were 60 float64 operations for every pixel of the frame).
+    const float low2f = (float)(low * low) * (1.f - 2e-3f) - 1e-12f;
+    // exact gradient / magnitude at s_mag position (r, c) = image position (y0 - 1 + r, x0 - 1 + c): the operations of rounds 2-3
+    auto grad = [&](int r, int c, double& is, double& js) {
+        const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
+        js = d1 * 2.0 + (d0 + d2);
+        const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
+        is = e1 * 2.0 + (e0 + e2);
+    };
+    auto mag = [&](int r, int c) { double is, js; grad(r, c, is, js); return sqrt(is * is + js * js); };
     for (int it = 0; it <= CT_NT; it++) {
         const int y0 = (blockIdx.y * CT_NT + it) * CT_Y;
         const bool more = it < CT_NT && y0 < ny;
@@ -259,39 +276,51 @@ __global__ __launch_bounds__(256) void k_canny_tile(const double* __restrict__ s
         for (int i = tid; i < (CT_Y + 4) * (CT_X + 4); i += 256) {
             const int r = i / (CT_X + 4), c = i - r * (CT_X + 4);
             const int yy = min(max(y0 - 2 + r, 0), ny - 1), xx = min(max(x0 - 2 + c, 0), nx - 1);
-            s_sm[r][c] = sm[(size_t)yy * nx + xx];
+            const double v = sm[(size_t)yy * nx + xx];
+            s_sm[r][c] = v; s_smf[r][c] = (float)v;
         }
         __syncthreads();
-        for (int i = tid; i < (CT_Y + 2) * (CT_X + 2); i += 256) {
-            const int r = i / (CT_X + 2), c = i - r * (CT_X + 2);           // image position (y0 - 1 + r, x0 - 1 + c)
-            const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
-            const double js = d1 * 2.0 + (d0 + d2);
-            const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
-            const double is = e1 * 2.0 + (e0 + e2);
-            s_mag[r][c] = sqrt(is * is + js * js);
-        }
-        __syncthreads();
+        // (a) the screen, every pixel of the tile: those that pass go to a list of the tile ...
         for (int i = tid; i < CT_X * CT_Y; i += 256) {
             const int ty = i / CT_X, tx = i - ty * CT_X, y = y0 + ty, x = x0 + tx;
             if (!live || y < 1 || y > ny - 2 || x < 1 || x > nx - 2) continue;      // binary_erosion of the all-ones mask
-            const int r = ty + 1, c = tx + 1;                                      // in s_mag; s_sm centre is [r + 1][c + 1]
-            const double m = s_mag[r][c];
+            const int r = ty + 1, c = tx + 1;                                      // s_mag position; s_sm centre is [r + 1][c + 1]
+            const float d0 = s_smf[r][c + 2] - s_smf[r][c], d1 = s_smf[r + 1][c + 2] - s_smf[r + 1][c], d2 = s_smf[r + 2][c + 2] - s_smf[r + 2][c];
+            const float e0 = s_smf[r + 2][c] - s_smf[r][c], e1 = s_smf[r + 2][c + 1] - s_smf[r][c + 1], e2 = s_smf[r + 2][c + 2] - s_smf[r][c + 2];
+            const float jf = d1 * 2.f + (d0 + d2), if_ = e1 * 2.f + (e0 + e2);
+            if (if_ * if_ + jf * jf >= low2f) s_cand[atomicAdd(&ncand, 1u)] = (uint16_t)i;
+        }
+        __syncthreads();
+        // (b) ... which all threads then work through in float64 (a wave that met one such pixel among its 64 would otherwise
+        // run the whole exact path for it: more float64 work than without the screen)
+        const unsigned nc = ncand;
+        for (unsigned t = tid; t < nc; t += 256) {
+            const int i = s_cand[t];
+            const int ty = i / CT_X, tx = i - ty * CT_X, y = y0 + ty, x = x0 + tx;
+            const int r = ty + 1, c = tx + 1;
+            double is, js;
+            grad(r, c, is, js);
+            const double m = sqrt(is * is + js * js);
             if (!(m > 0.0 && m >= low)) continue;
-            const double d0 = s_sm[r][c + 2] - s_sm[r][c], d1 = s_sm[r + 1][c + 2] - s_sm[r + 1][c], d2 = s_sm[r + 2][c + 2] - s_sm[r + 2][c];
-            const double js = d1 * 2.0 + (d0 + d2);
-            const double e0 = s_sm[r + 2][c] - s_sm[r][c], e1 = s_sm[r + 2][c + 1] - s_sm[r][c + 1], e2 = s_sm[r + 2][c + 2] - s_sm[r][c + 2];
-            const double is = e1 * 2.0 + (e0 + e2);
             const double ai = fabs(is), aj = fabs(js);
             const bool same = (is >= 0 && js >= 0) || (is <= 0 && js <= 0), opp = (is <= 0 && js >= 0) || (is >= 0 && js <= 0);
-            const double* mu = s_mag[r - 1]; const double* mc = s_mag[r]; const double* md = s_mag[r + 1];
-            bool loc = false;
-            // c2 w + c1 (1 - w) <= m on both sides of the gradient direction; later sectors overwrite earlier ones
-            if (same && ai >= aj) { const double w = aj / ai; loc = (md[c + 1] * w + md[c] * (1 - w) <= m) && (mu[c - 1] * w + mu[c] * (1 - w) <= m); }
-            if (same && ai <= aj) { const double w = ai / aj; loc = (md[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (mu[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
-            if (opp && ai <= aj) { const double w = ai / aj; loc = (mu[c + 1] * w + mc[c + 1] * (1 - w) <= m) && (md[c - 1] * w + mc[c - 1] * (1 - w) <= m); }
-            if (opp && ai >= aj) { const double w = aj / ai; loc = (mu[c + 1] * w + mu[c] * (1 - w) <= m) && (md[c - 1] * w + md[c] * (1 - w) <= m); }
+            // c2 w + c1 (1 - w) <= m on both sides of the gradient direction, c2 the diagonal neighbour, c1 the one along an
+            // axis; of the four sectors (skimage tests them in this order, a later one overwrites an earlier one) the last
+            // that applies decides
+            int sec = 0;
+            if (same && ai >= aj) sec = 1;
+            if (same && ai <= aj) sec = 2;
+            if (opp && ai <= aj) sec = 3;
+            if (opp && ai >= aj) sec = 4;
+            if (!sec) continue;
+            const int dr2 = sec <= 2 ? 1 : -1, dr1 = (sec == 1) ? 1 : (sec == 4 ? -1 : 0), dc1 = (sec == 2 || sec == 3) ? 1 : 0;
+            const double w = (sec == 1 || sec == 4) ? aj / ai : ai / aj;
+            const bool loc = (mag(r + dr2, c + 1) * w + mag(r + dr1, c + dc1) * (1 - w) <= m) &&
+                             (mag(r - dr2, c - 1) * w + mag(r - dr1, c - dc1) * (1 - w) <= m);
             if (loc) { const unsigned k = atomicAdd(&qn, 1u); q[k] = (uint32_t)((size_t)y * nx + x) | (m >= high ? 0x80000000u : 0u); }
         }
+        __syncthreads();
+        if (tid == 0) ncand = 0;
     }
 }
 
