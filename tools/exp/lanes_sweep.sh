@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/r4j/lanes.log; mkdir -p gpurun_out/r4j; : > $out
 for cfg in "$@"; do
   set -- $cfg
-  timeout -k 10 200 python bench.py --steps 150 --warmup 10 --no-extras --no-cpu --lanes $1 --depth $2 > /tmp/b.json 2>/tmp/b.err
+  timeout -k 10 200 python bench.py --steps ${STEPS:-150} --warmup 20 --no-extras --no-cpu --lanes $1 --depth $2 > /tmp/b.json 2>/tmp/b.err
   python3 - "$cfg" >> $out <<PY
 import json,sys
 try:
