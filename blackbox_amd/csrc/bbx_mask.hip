@@ -452,11 +452,14 @@ __global__ __launch_bounds__(256) void k_fill_apply(const u64* __restrict__ R, c
 // them in one line) to find a pixel's earlier neighbours, where the hash table of rounds 1-3 took a compare-and-swap and
 // a probe sequence per key.  The map is all-zero between calls: k_cc_count clears the words its call set.
 __global__ __launch_bounds__(256) void k_cc_insert(const uint32_t* __restrict__ list, const int32_t* __restrict__ cnt,
-                                                   uint32_t* __restrict__ imap, int cap, int32_t* err, int32_t* out) {
+                                                   uint32_t* __restrict__ imap, uint32_t npix, int cap, int32_t* err, int32_t* out) {
     int n = *cnt;
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = 0;                 // summed into by k_cc_count
     if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, BBX_DERR_LIST_OVERFLOW); }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) imap[list[i]] = (uint32_t)i + 1u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = list[i];
+        if (p < npix) imap[p] = (uint32_t)i + 1u; else atomicOr(err, BBX_DERR_LIST_OVERFLOW);     // (a pixel outside the frame: never from this library's lists)
+    }
 }
 
 // (device-scope relaxed loads: served by the L2 the atomics go to; `volatile` would make them
@@ -488,10 +491,12 @@ __global__ __launch_bounds__(256) void k_cc_link(const uint32_t* __restrict__ li
                                                  const uint32_t* __restrict__ imap, uint32_t* __restrict__ parent,
                                                  int32_t* __restrict__ pend, int ny, int nx, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
+    const uint32_t npix = (uint32_t)ny * (uint32_t)nx;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
         const int Y = p / nx, X = p - Y * nx;
         int link = i, other = -1;
+        if (p >= npix) { parent[i] = (uint32_t)i; pend[i] = -1; continue; }
         if (Y > 0) {
             const uint32_t up = p - (uint32_t)nx;
             const int jb = (int)imap[up] - 1;
@@ -549,12 +554,13 @@ __global__ __launch_bounds__(256) void k_cc_union(const int32_t* __restrict__ cn
 // index map this list set, so the map is all-zero again for the next call (no memset of the frame-sized map per call)
 __global__ __launch_bounds__(256) void k_cc_count(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ parent,
                                                   const uint32_t* __restrict__ list, uint32_t* __restrict__ imap,
-                                                  int32_t* out, int cap) {
+                                                  uint32_t npix, int32_t* out, int cap) {
     const int n = (*cnt > cap) ? cap : *cnt;
     int c = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         c += (parent[i] == (uint32_t)i) ? 1 : 0;
-        imap[list[i]] = 0u;
+        const uint32_t p = list[i];
+        if (p < npix) imap[p] = 0u;
     }
     // one add per workgroup (every returning or same-address atomic queues up at ~11 ns: 45 us for one per wave)
     __shared__ int s_c[4];
@@ -624,6 +630,7 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
                       int32_t* d_out, hipStream_t s) {
     int rc;
     const size_t npix = (size_t)ny * nx;
+    if (ny < 1 || nx < 1 || npix >= 0xffffffffull) return BBX_ERR_ARG;
     uint32_t* imap = (uint32_t*)bbx_ws(ctx, WS_HASH, npix * sizeof(uint32_t), &rc); if (rc) return rc;
     uint32_t* parent = (uint32_t*)bbx_ws(ctx, WS_PARENT, 2 * cap * sizeof(uint32_t) + 16, &rc); if (rc) return rc;
     int32_t* pend = (int32_t*)(parent + cap);
@@ -634,12 +641,12 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
         ctx->hash_clean_ptr = (void*)imap; ctx->hash_clean_n = ctx->ws_bytes[WS_HASH] / sizeof(uint32_t);
     }
     const unsigned grid = 1024;
-    hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, imap, (int)cap, ctx->d_err, d_out);
+    hipLaunchKernelGGL(k_cc_insert, dim3(grid), dim3(256), 0, s, d_list, d_cnt, imap, (uint32_t)npix, (int)cap, ctx->d_err, d_out);
     hipLaunchKernelGGL(k_cc_link, dim3(grid), dim3(256), 0, s, d_list, d_cnt, imap, parent, pend, ny, nx, (int)cap);
     hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
     hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_cnt, parent, pend, (int)cap);
     hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
-    hipLaunchKernelGGL(k_cc_count, dim3(grid / 4), dim3(256), 0, s, d_cnt, parent, d_list, imap, d_out, (int)cap);
+    hipLaunchKernelGGL(k_cc_count, dim3(grid / 4), dim3(256), 0, s, d_cnt, parent, d_list, imap, (uint32_t)npix, d_out, (int)cap);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
