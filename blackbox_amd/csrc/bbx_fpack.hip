@@ -198,8 +198,31 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                                                  int capwords, int hist_only, unsigned* __restrict__ hint, int gen) {
     typedef rice_par<BYTEPIX> RP;
     extern __shared__ __align__(16) unsigned char lds[];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (MODE == 2 && tiles[row].flag != FP_FLAG_RETRY) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // MODE 0 / 1: one workgroup per row.  MODE 2: a small grid; workgroup b looks through the flags of rows b, b + G, b + 2 G, ...
+    // (64 at a time, a thread each) and takes the marked ones in turn.  Until round 4 this launch had a workgroup per row of
+    // the image, each asking for the worst-case LDS only to find its row unmarked: 0.6 ms of a stream's time per image when
+    // the CUs are busy.  (No list of marked rows in the context: calls on different streams of one context run at once.)
+    __shared__ int s_rows[64], s_nrows;
+    int row = blockIdx.x, scan0 = (int)blockIdx.x - 64 * (int)gridDim.x, nmark = 0, kmark = 0;
+#define FP_ROW_RETURN do { if (MODE == 2) goto row_done; else return; } while (0)
+  next_row:
+    if (MODE == 2) {
+        while (kmark >= nmark) {                                       // (workgroup-uniform) the next 64 rows of this workgroup
+            scan0 += 64 * (int)gridDim.x;
+            if (scan0 >= ny) return;
+            __syncthreads();
+            if (tid == 0) s_nrows = 0;
+            __syncthreads();
+            const int r = scan0 + tid * (int)gridDim.x;
+            if (tid < 64 && r < ny && tiles[r].flag == FP_FLAG_RETRY) s_rows[atomicAdd(&s_nrows, 1)] = r;
+            __syncthreads();
+            nmark = s_nrows; kmark = 0;
+        }
+        row = s_rows[kmark++];
+        __syncthreads();
+    }
+    {
     const int nblk = (nx + 31) / 32;
     const int maxwords = MODE == 1 ? capwords : (8 * BYTEPIX + nblk * RP::fsbits + nx * RP::bbits + 31) / 32 + 2;
     int* vals = reinterpret_cast<int*>(lds);
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             out->zscale = delta; out->zzero = zeropt; out->flag = (uint32_t)flag;
         }
         __syncthreads();
-        if (s_flag) { if (tid == 0) out->nbytes = 0; return; }
+        if (s_flag) { if (tid == 0) out->nbytes = 0; FP_ROW_RETURN; }
         const double delta = s_delta, zeropt = s_zero;
         int iseed = (row + dither_seed - 1) % FP_NRANDOM;          // (tile number 1.. + ZDITHER0 - 1 - 1) % N_RANDOM
         if (iseed < 0) iseed += FP_NRANDOM;
@@ -687,7 +710,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
     __syncthreads();
     if (MODE == 1 && blkbits[nblk] + 64u > 32u * (unsigned)maxwords) {     // the stream does not fit the short buffer
         if (tid == 0) { out->flag = FP_FLAG_RETRY; out->nbytes = 0; }
-        return;
+        FP_ROW_RETURN;
     }
     // ---- pass 2: write the codes
 #ifndef FPV_NOPASS2
@@ -729,6 +752,10 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
     unsigned* dst = reinterpret_cast<unsigned*>(scratch + (size_t)row * tile_stride);
     for (unsigned w = tid; w < (nbytes + 3) / 4; w += FP_THREADS) dst[w] = __builtin_bswap32(words[w]);
     if (tid == 0) out->nbytes = nbytes;
+    }
+  row_done:
+    if (MODE == 2) goto next_row;
+#undef FP_ROW_RETURN
 }
 
 // tile streams -> contiguous heap
@@ -790,7 +817,7 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 1>), dim3(ny), dim3(FP_THREADS), ldshalf, s, d_img, ny, nx, (size_t)nx, qlevel, \
                                dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords, hist_only, d_hint, gen);             \
-            if (!FPV_SKIP_RETRY) hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
+            if (!FPV_SKIP_RETRY) hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(min(ny, 256)), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
                                dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen);               \
         } else {                                                                                                       \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \

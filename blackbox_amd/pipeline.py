@@ -309,6 +309,7 @@ class FramePipeline:
         # one lane at a time inside bbx_zogy_frame (BBX_ZOGY_GATE=0 switches the gate off)
         self.ref_bkg_std = None
         self.zogy_gate = None
+        self.fpack_in_gate = os.environ.get('BBX_FPACK_GATE', '0') == '1'
         if self.subtract and os.environ.get('BBX_ZOGY_GATE', '1') != '0':
             from . import zogy as G
             # (BBX_ZOGY_PRIO=1: the sections on one high-priority stream instead of the lanes' own -- measured in round 3: the
@@ -651,7 +652,13 @@ class FramePipeline:
             R.step_mark(ctx, d_steps, 'zogy')
         f.out_group = None
         if self.outstage is not None:
-            self._submit_outputs(f, ctx, data, mask)
+            if self.zogy_gate is not None and self.fpack_in_gate:
+                # the compression of the frame's images as a section of its own behind the subtraction's: `k_fp_tile` and the
+                # ZOGY kernels each hold a CU's LDS and wave slots in pairs; side by side each runs with half of them
+                with self.zogy_gate:
+                    self._submit_outputs(f, ctx, data, mask)
+            else:
+                self._submit_outputs(f, ctx, data, mask)
         if not self.keep_outputs and f.sub is not None:
             for k in list(f.sub):
                 if torch.is_tensor(f.sub[k]):
