@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void k_cc_union(const int32_t* __restrict__ cn
     }
 }
 
-// roots = objects (after the second k_cc_flatten every pixel points at its root); the pass also clears the words of the
+// roots = objects (a pixel that is its own parent, flattened or not); the pass also clears the words of the
 // index map this list set, so the map is all-zero again for the next call (no memset of the frame-sized map per call)
 __global__ __launch_bounds__(256) void k_cc_count(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ parent,
                                                   const uint32_t* __restrict__ list, uint32_t* __restrict__ imap,
@@ -645,7 +645,9 @@ int bbx_cc_count_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt
     hipLaunchKernelGGL(k_cc_link, dim3(grid), dim3(256), 0, s, d_list, d_cnt, imap, parent, pend, ny, nx, (int)cap);
     hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
     hipLaunchKernelGGL(k_cc_union, dim3(grid), dim3(256), 0, s, d_cnt, parent, pend, (int)cap);
-    hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
+    // (the count needs no second flatten: a root is a root; the callers that go on to read every pixel's root ask for it)
+    if (ctx->cc_roots) hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, d_cnt, parent, (int)cap);
+    ctx->cc_roots = 0;
     hipLaunchKernelGGL(k_cc_count, dim3(grid / 4), dim3(256), 0, s, d_cnt, parent, d_list, imap, (uint32_t)npix, d_out, (int)cap);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
@@ -701,6 +703,7 @@ __global__ __launch_bounds__(256) void k_ccf_emit(const uint32_t* __restrict__ l
 
 int bbx_cc_filter_list(bbx_ctx* ctx, const uint32_t* d_list, const int32_t* d_cnt, size_t cap, int ny, int nx, const uint8_t* d_flag,
                        int min_size, uint32_t* d_out, int32_t* d_out_cnt, uint32_t out_cap, hipStream_t s) {
+    ctx->cc_roots = 1;
     int rc = bbx_cc_count_list(ctx, d_list, d_cnt, cap, ny, nx, &ctx->d_counters[CNT_CC_ROOTS], s); if (rc) return rc;
     uint32_t* parent = (uint32_t*)ctx->d_ws[WS_PARENT];
     uint32_t* size = (uint32_t*)bbx_ws(ctx, WS_STAGE2, 2 * cap * sizeof(uint32_t), &rc); if (rc) return rc;
@@ -837,6 +840,7 @@ extern "C" int bbx_find_peaks(bbx_ctx* ctx, int ny, int nx, const float* d_img, 
         hipLaunchKernelGGL(k_compact_abs, dim3(2048), dim3(256), 0, s, d_img, npix, thr, list, cnt, (uint32_t)cap, ctx->d_err);
     }
     // union-find over the list (the object count itself is not needed: reuse its scratch)
+    ctx->cc_roots = 1;
     rc = bbx_cc_count_list(ctx, list, cnt, cap, ny, nx, &ctx->d_counters[CNT_CC_ROOTS], s); if (rc) return rc;
     uint32_t* parent = (uint32_t*)ctx->d_ws[WS_PARENT];
     BBX_HIP(hipMemsetAsync(best, 0, cap * sizeof(unsigned long long), s));
