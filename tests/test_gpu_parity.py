@@ -198,6 +198,44 @@ def test_count_objects(ctx):
             assert int(n.item()) == want, (bit, off)
 
 
+def test_count_objects_long_chains_and_late_unions(ctx):
+    """the union-find behind bbx_count_objects links every pixel to an earlier neighbour first (chains as long as the object),
+    flattens, then makes the few real unions: shapes that make those chains thousands of links long and the unions late --
+    full-frame diagonals both ways, a staircase, a comb whose teeth only meet in its last row, nested U shapes, a spiral,
+    a checkerboard (8-connected: one object) -- against scipy.ndimage.label"""
+    ny, nx = 2048, 3000
+    m = np.zeros((ny, nx), bool)
+    i = np.arange(2000)
+    m[i + 10, i + 5] = True                                        # diagonal down-right (first link always NW)
+    m[2040 - i, i + 900] = True                                    # diagonal up-right (first link W / NE)
+    for k in range(300):                                           # staircase
+        m[100 + 2 * k:103 + 2 * k, 2200 + k] = True
+    m[300:900, 100:700:6] = True; m[899, 100:700] = True           # comb: 100 teeth joined by the last row
+    for k in range(0, 60, 4):                                      # nested U shapes, the inner ones standing on the outer one's floor
+        m[1000 + k:1300, 100 + k] = True; m[1000 + k:1300, 500 - k] = True
+        m[1300 - 1 - k, 100 + k:501 - k] = True
+    y, x = 1600, 1500                                              # square spiral, arm spacing 2
+    step, d = 1, 0
+    for seg in range(120):
+        dy, dx = ((0, 1), (1, 0), (0, -1), (-1, 0))[d]
+        for _ in range(step * 2):
+            m[y, x] = True; y += dy; x += dx
+        d = (d + 1) % 4
+        if seg % 2:
+            step += 1
+    cb = np.indices((200, 200)).sum(axis=0) % 2 == 0               # checkerboard
+    m[1800:2000, 2500:2700] |= cb
+    rs = np.random.RandomState(3)
+    m |= rs.random_sample(m.shape) < 0.01
+    assert m.sum() < m.size // 8
+    want = ndimage.label(m, structure=np.ones((3, 3), bool))[1]
+    mask = (m.astype(np.uint8) * 8) | (rs.randint(0, 2, m.shape).astype(np.uint8) * 1)
+    for _ in range(2):                                             # twice: the index map must come back clean
+        n = R.count_objects(ctx, torch.from_numpy(mask).to(ctx.device), 8)
+        ctx.sync()
+        assert int(n.item()) == want
+
+
 def test_fill_holes_shapes(ctx):
     """rings, nested rings, border-touching blobs: mask_init tail vs scipy"""
     ys, xs = 80, 96
