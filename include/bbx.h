@@ -17,7 +17,10 @@
  *  - return value: 0 = BBX_OK, negative = error (bbx_strerror).  HIP errors are
  *    reported, never swallowed; there is no CPU fallback.
  *  - images are C-order, row 0 first (numpy layout of the FITS data array).
- *  - one bbx_ctx per worker process / GPU; a ctx is not thread-safe.
+ *  - one bbx_ctx per worker process / GPU (or per lane of a pipeline); a ctx is not thread-safe, and its calls belong on ONE
+ *    stream at a time: the device work lists, counters and scratch of a ctx are shared by its calls (the exception is
+ *    bbx_fpack_tiles / bbx_fpack_body, whose per-call state lives in the caller's buffers: the output stage runs them on a
+ *    second stream of a lane's ctx).
  *
  * Geometry (reference define_sections, blackbox.py:6334-6402): the raw frame is
  * NY x NX = 2 x 8 channels of (dy x dx) pixels; each channel holds a data
