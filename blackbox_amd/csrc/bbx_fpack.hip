@@ -358,9 +358,6 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             for (int i0 = wave * 64; i0 < nd; i0 += FP_THREADS) {         // (wave-uniform trip count: ballots inside)
 #endif
                 const int i = i0 + lane;
-                const bool in = i < nd;
-                const int ii = in ? i : 0;
-                FP_KEYS(ii)
 #define FP_BRACKET(K, LO, HI, C0, BASE, SEG)                                                                            \
                 {                                                                                                       \
                     c[C0] += (in && K < LO) ? 1u : 0u; c[C0 + 1] += (in && K == LO) ? 1u : 0u;                          \
@@ -371,9 +368,23 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                     if (inb && pos < (unsigned)segcap) SEG[pos] = K;                                                    \
                     BASE += (unsigned)__popcll(bal);                                                                    \
                 }
-                FP_BRACKET(k2, lo0, hi0, 0, base0, seg0)
-                FP_BRACKET(k3, lo1, hi1, 3, base1, seg1)
-                FP_BRACKET(k5, lo2, hi2, 6, base2, seg2)
+#define FP_COUNT_ROUND                                                                                                  \
+                {                                                                                                       \
+                    FP_KEYS(ii)                                                                                         \
+                    FP_BRACKET(k2, lo0, hi0, 0, base0, seg0)                                                            \
+                    FP_BRACKET(k3, lo1, hi1, 3, base1, seg1)                                                            \
+                    FP_BRACKET(k5, lo2, hi2, 6, base2, seg2)                                                            \
+                }
+                if (i0 + 64 <= nd) {                                       // (wave-uniform) all 64 keys inside the row: no bounds in the round
+                    constexpr bool in = true;
+                    const int ii = i;
+                    FP_COUNT_ROUND
+                } else {
+                    const bool in = i < nd;
+                    const int ii = in ? i : 0;
+                    FP_COUNT_ROUND
+                }
+#undef FP_COUNT_ROUND
 #undef FP_BRACKET
             }
 #pragma unroll
@@ -652,38 +663,63 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
         const int q = tid + it * FP_THREADS, b = q >> 2;
         unsigned long long ps = 0;
         int prev = (8 * q - 1 < nx) ? vals[q ? 8 * q - 1 : 0] : 0;
+        const bool full = 8 * q + 8 <= nx;                           // all 8 pixels inside the row: every run but the last one or two
+        if (full) {
+            // (two 16-byte LDS reads, no per-pixel bounds)
+            const int4 va = *reinterpret_cast<const int4*>(&vals[8 * q]), vb = *reinterpret_cast<const int4*>(&vals[8 * q + 4]);
+            const int vv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int i = 8 * q + j;
-            const bool in = i < nx;
-            const int v = in ? vals[i] : prev;
-            int pd = v - prev;
-            if (BYTEPIX == 1) pd = (int)(signed char)pd;
-            if (BYTEPIX == 2) pd = (int)(short)pd;
-            unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
-            if (BYTEPIX == 1) d &= 0xffu;
-            if (BYTEPIX == 2) d &= 0xffffu;
-            dd[it][j] = in ? d : 0u;
-            ps += in ? d : 0u;
-            prev = v;
+            for (int j = 0; j < 8; j++) {
+                int pd = vv[j] - prev;
+                if (BYTEPIX == 1) pd = (int)(signed char)pd;
+                if (BYTEPIX == 2) pd = (int)(short)pd;
+                unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
+                if (BYTEPIX == 1) d &= 0xffu;
+                if (BYTEPIX == 2) d &= 0xffffu;
+                dd[it][j] = d;
+                ps += d;
+                prev = vv[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = 8 * q + j;
+                const bool in = i < nx;
+                const int v = in ? vals[i] : prev;
+                int pd = v - prev;
+                if (BYTEPIX == 1) pd = (int)(signed char)pd;
+                if (BYTEPIX == 2) pd = (int)(short)pd;
+                unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
+                if (BYTEPIX == 1) d &= 0xffu;
+                if (BYTEPIX == 2) d &= 0xffffu;
+                dd[it][j] = in ? d : 0u;
+                ps += in ? d : 0u;
+                prev = v;
+            }
         }
         ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
         const int thisblock = min(32, nx - 32 * b);
-        double dpsum = ((double)ps - (double)(thisblock / 2) - 1.) / (double)thisblock;
-        if (dpsum < 0.) dpsum = 0.;
-        unsigned psum = ((unsigned)dpsum) >> 1;
-        int fs = 0;
-        for (; psum > 0; fs++) psum >>= 1;
+        // CFITSIO: dpsum = (pixelsum - thisblock / 2 - 1) / thisblock in double, < 0 -> 0, psum = (unsigned)dpsum >> 1, fs = bits
+        // of psum.  For a full block the division by 32 is a shift of the integer sum (truncation of a non-negative double =
+        // floor; sums below 2^36 keep (unsigned)dpsum in range): ~6 integer instructions instead of a float64 division per run
+        unsigned psum;
+        if (thisblock == 32 && ps < (1ull << 36)) psum = ps >= 17ull ? (unsigned)((ps - 17ull) >> 5) >> 1 : 0u;
+        else {
+            double dpsum = ((double)ps - (double)(thisblock / 2) - 1.) / (double)thisblock;
+            if (dpsum < 0.) dpsum = 0.;
+            psum = ((unsigned)dpsum) >> 1;
+        }
+        const int fs = psum ? 32 - __builtin_clz(psum) : 0;           // (for (fs = 0; psum > 0; fs++) psum >>= 1)
         int code;                                                     // what goes into the fsbits field
         if (fs >= RP::fsmax) code = RP::fsmax + 1;
         else if (fs == 0 && ps == 0) code = 0;
         else code = fs + 1;
-        unsigned len = 0;
+        // bits of this run: per pixel (d >> fs) + 1 + fs, or bbits (code fsmax + 1), or nothing (code 0)
+        unsigned top = 0;                                             // (pixels beyond the row hold d = 0)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const bool in = 8 * q + j < nx;
-            if (in) len += code == RP::fsmax + 1 ? (unsigned)RP::bbits : (code == 0 ? 0u : (dd[it][j] >> (code - 1)) + 1u + (unsigned)(code - 1));
-        }
+        for (int j = 0; j < 8; j++) top += dd[it][j] >> (fs & 31);
+        const unsigned nin = (unsigned)min(8, max(0, nx - 8 * q));
+        const unsigned len = code == RP::fsmax + 1 ? nin * (unsigned)RP::bbits : (code == 0 ? 0u : top + nin * (unsigned)(fs + 1));
         unsigned incl = len;
         { const unsigned t = __shfl_up(incl, 1, 64); if (sub >= 1) incl += t; }
         { const unsigned t = __shfl_up(incl, 2, 64); if (sub >= 2) incl += t; }
@@ -729,16 +765,24 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
         } else bw.init(words, blkbits[b] + (sub ? RP::fsbits + ioff[it] : 0u));
         if (sub == 0) bw.put((unsigned)code, RP::fsbits);
         if (code != 0) {
+            const int npx = min(8, nx - 8 * q);                       // (8 for every run but the row's last one or two)
+            const int fs = code - 1;
+            const unsigned lowmask = (1u << (fs & 31)) - 1u;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if (8 * q + j < nx) {
+                if (j < npx) {
                     const unsigned d = dd[it][j];
                     if (code == RP::fsmax + 1) bw.put(d, RP::bbits);
                     else {
-                        const int fs = code - 1;
-                        bw.zeros(d >> fs);                            // `top` zeros, then a one
-                        bw.put(1u, 1);
-                        if (fs) bw.put(d & ((1u << fs) - 1u), fs);
+                        // `top` zeros, a one, the fs low bits = the number (1 << fs) | low written in top + 1 + fs bits: one
+                        // step of the window where that fits 32 bits (a pixel thousands of sigma off its neighbour does not)
+                        const unsigned top = d >> fs, n = top + 1u + (unsigned)fs;
+                        if (n <= 32u) bw.put((1u << fs) | (d & lowmask), (int)n);
+                        else {
+                            bw.zeros(top);
+                            bw.put(1u, 1);
+                            if (fs) bw.put(d & lowmask, fs);
+                        }
                     }
                 }
             }
