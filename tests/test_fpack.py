@@ -340,6 +340,24 @@ def test_gpu_short_stream_buffer_and_retry_equal_full_buffer():
             assert np.array_equal(a['zscale'], b['zscale']) and np.array_equal(a['zzero'], b['zzero'])
     t = got[0][0]
     assert (t['nbytes'][8:16] > nx * 2).all() and (t['nbytes'][:8] < nx * 1.5).all()       # the retried rows are the long ones
+    # more rows than the second launch has workgroups (256): a workgroup then scans the flags of several rows and may
+    # find none, one or all of them marked
+    ny2 = 700
+    img2 = (300 + rs.normal(0, 9, (ny2, nx))).astype(np.float32)
+    marked = np.zeros(ny2, bool)
+    marked[rs.rand(ny2) < 0.35] = True
+    marked[256:262] = True; marked[512:515] = True; marked[0] = True; marked[ny2 - 1] = True
+    for r in np.nonzero(marked)[0]:
+        j = rs.rand(nx) < 0.2
+        img2[r, j] += (rs.uniform(-1, 1, int(j.sum())) * 3e6).astype(np.float32)
+    g2 = {}
+    for one in (0, 1):
+        _lib.check(_lib.lib.bbx_set_option(ctx.h, 5, one), 'bbx_set_option')
+        g2[one] = P.compress_tiles(ctx, torch.from_numpy(img2).to(ctx.device), 16, 7)
+    _lib.check(_lib.lib.bbx_set_option(ctx.h, 5, 0), 'bbx_set_option')
+    for k in ('nbytes', 'offsets', 'flag', 'heap', 'zscale', 'zzero'):
+        assert np.array_equal(g2[0][k], g2[1][k]), k
+    assert (g2[0]['nbytes'][marked] > nx * 2).all() and (g2[0]['nbytes'][~marked] < nx * 1.5).all()
     for r, (b, zs, zz) in enumerate(FP.compress_float_image(img, 16, 5)):
         assert t['zscale'][r] == zs and t['zzero'][r] == zz, r
         assert t['heap'][t['offsets'][r]:t['offsets'][r] + t['nbytes'][r]].tobytes() == b, r
