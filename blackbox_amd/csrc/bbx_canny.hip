@@ -70,10 +70,30 @@ __global__ __launch_bounds__(256) void k_canny_hist(const float* __restrict__ b,
     const float4* b4 = (const float4*)b;
     auto count = [&](float f) {
         const unsigned k = fkey(f);
-        if (PASS == 0) atomicAdd(&h[k >> 20], 1u);
-        else {
+        if (PASS == 0) {
+            // the top 12 key bits of a sky frame fall into two or three bins: 64 lanes adding to one LDS word queue up one
+            // after the other (this pass took 60 us for 111 MB).  Up to two rounds in which the bin of the first pending lane
+            // is counted once for every lane that shares it; what is left goes one by one.
+            const unsigned bin = k >> 20;
+            bool pending = true;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const unsigned long long act = __builtin_amdgcn_ballot_w64(pending);
+                if (!act) break;
+                const int leader = (int)__builtin_ctzll(act);
+                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const bool same = pending && bin == b0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(same);
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[b0], (unsigned)__popcll(m));
+                pending = pending && !same;
+            }
+            if (pending) atomicAdd(&h[bin], 1u);
+        } else {
+            // (the four ranks -- two neighbours each of the 4.5 % and the 93 % point -- mostly share their prefix: one histogram
+            // per distinct prefix, k_canny_scan reads the first one of a run of equal prefixes)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                if (q > 0 && pre[q] == pre[q - 1]) continue;
                 if (PASS == 1 && (k >> 20) == pre[q]) atomicAdd(&h[q * 1024 + ((k >> 10) & 1023u)], 1u);
                 if (PASS == 2 && (k >> 10) == pre[q]) atomicAdd(&h[q * 1024 + (k & 1023u)], 1u);
             }
@@ -96,7 +116,10 @@ __global__ __launch_bounds__(256) void k_canny_scan(canny_par* p, unsigned* hist
     __syncthreads();
     // wave q serves rank q: every lane sums a chunk of the histogram, the wave locates the chunk, lane 0 the bin
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned* h = PASS == 0 ? sh : sh + q * 1024;
+    int qh = q;                                                    // the histogram of this rank's prefix: the first of a run of equal prefixes
+    if (PASS != 0) { while (qh > 0 && p->prefix[qh] == p->prefix[qh - 1]) qh--; }
+    __syncthreads();                                               // (all prefixes read before any is extended below)
+    const unsigned* h = PASS == 0 ? sh : sh + qh * 1024;
     constexpr int NB = PASS == 0 ? 4096 : 1024, CH = NB / 64;
     unsigned long long mine = 0;
     for (int i = 0; i < CH; i++) mine += h[lane * CH + i];
