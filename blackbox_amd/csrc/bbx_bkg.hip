@@ -270,29 +270,32 @@ __global__ __launch_bounds__(64, BOXF_MINW) void k_bkg_boxstats_fast(const float
     if (ibox >= nboxes) return;
     const int by = ibox / nbx, bx = ibox - by * nbx;
     const int npx = box * box;
-    const int q64 = 64 / box, r64 = 64 - q64 * box;
     uint32_t k[64];
     int cnt = 0;
     {
-        int yy = lane / box, xx = lane - yy * box;
-        const size_t o0 = (size_t)(by * box) * nx + (size_t)bx * box;
+        // register c = row c of the box, lane = column (the lanes beyond the box width re-read its last column and are
+        // discarded; rows beyond the box are not loaded): the address of a load is the row's scalar base + 4 * lane, and no
+        // element needs a bounds test of its own.  All loads are issued before the first use: the kernel lives on the
+        // memory parallelism of its few waves.
+        const int xl = min(lane, box - 1);
+        const size_t o0 = (size_t)(by * box) * nx + (size_t)bx * box + (size_t)xl;
         const float* pd = data + o0; const uint8_t* pm = mask + o0; const uint8_t* po = objmask + o0;
-        const uint32_t omax = (uint32_t)((box - 1) * nx + box - 1);
+        const bool col = lane < box;
         unsigned mk[64];
 #pragma unroll
         for (int c = 0; c < 64; c++) {
-            const uint32_t o = min((uint32_t)(yy * nx + xx), omax);
-            k[c] = __float_as_uint(pd[o]);
-            mk[c] = pm[o];
-            if (objmask) mk[c] |= po[o];
-            yy += q64; xx += r64;
-            if (xx >= box) { xx -= box; yy++; }
+            k[c] = 0; mk[c] = 1;
+            if (c < box) {                                         // (uniform)
+                k[c] = __float_as_uint(pd[(size_t)c * nx]);
+                mk[c] = pm[(size_t)c * nx];
+                if (objmask) mk[c] |= po[(size_t)c * nx];
+            }
         }
 #pragma unroll
         for (int c = 0; c < 64; c++) {
             const uint32_t u = k[c];
             const float d = __uint_as_float(u);
-            const bool ok = (c * 64 + lane < npx) & (mk[c] == 0) & (d != 0.f) & (d == d);
+            const bool ok = col & (mk[c] == 0) & (d != 0.f) & (d == d);
             k[c] = ok ? (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) : BOX_PAD;
             cnt += ok;
         }
