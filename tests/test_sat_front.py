@@ -74,6 +74,46 @@ def test_hip_front_end_vs_skimage(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('sky,quant', [(1200.0, 0), (1200.0, 1), (3.0, 0), (70000.0, 0)])
+def test_hip_percentile_select_prefix_sharing(sky, quant):
+    """the two percentiles (4.5, 93) are four order statistics found by three radix passes; ranks whose keys share the
+    leading bits share a histogram: sky levels that put all four into one leading bin (1200 +- 18), whole numbers (the two
+    neighbours of a percentile are the same key), a level near zero (keys of both signs) and a large one -- edge maps
+    against the oracle's"""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from blackbox_amd import reduce as R
+    from blackbox_amd._lib import lib, check
+    rs = np.random.RandomState(11)
+    ny, nx = 300, 412
+    b = sky + 18 * rs.standard_normal((ny, nx))
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    for _ in range(10):
+        cy, cx, fl = rs.uniform(0, ny), rs.uniform(0, nx), 10 ** rs.uniform(3.5, 5)
+        b += fl / (2 * np.pi * 6) * np.exp(-0.5 * ((yy - cy) ** 2 + (xx - cx) ** 2) / 6)
+    b += 150 * np.exp(-0.5 * ((xx * np.cos(0.7) + yy * np.sin(0.7) - 0.5 * nx) / 2.0) ** 2)
+    if quant:
+        b = np.round(b)
+    b = b.astype(np.float32)
+    want = S.edges(b)
+    assert want.sum() > 100
+    ctx = R.Context(0)
+    try:
+        d = torch.from_numpy(b).to(ctx.device)
+        d_map = torch.empty(b.shape, dtype=torch.uint8, device=ctx.device)
+        d_n = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+        gw, gr = R.sat_gauss_weights()
+        check(lib.bbx_canny_edge_map(ctx.h, ny, nx, C.c_void_p(d.data_ptr()), gw, gr, 0.1, 0.2, 60,
+                                     C.c_void_p(d_map.data_ptr()), C.c_void_p(d_n.data_ptr()), ctx.stream()), 'bbx_canny_edge_map', ctx.h)
+        ctx.sync()
+        assert int(d_n.item()) == int(want.sum())
+        assert np.array_equal(d_map.cpu().numpy().astype(bool), want)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape,seed', [((101, 203), 1), ((64, 67), 2), ((257, 130), 3), ((40, 1031), 4)])
 def test_hip_front_end_vs_oracle_odd_shapes(shape, seed):
     """frames whose sizes are no multiples of anything (pixel counts not divisible by 4, tiles and row pieces cut
