@@ -7,8 +7,8 @@
 // ysize-1-y -- keeps them in float64 registers, and then takes the 16 victims in turn:
 // the victim's 16 coefficients arrive by scalar loads, its own value comes from the registers
 // and the corrected value written back in place.  Every pixel is read once and written
-// once: 4N + N (mask) + 4N bytes (16 float64 FMAs per output pixel are far below the
-// vector rate, so no MFMA reshaping).
+// once: 4N + N (mask) + 4N bytes.  (Round 4, SQ counters: the kernel fills 0.86 of its vector issue slots -- the 16 float64
+// FMAs per output pixel at 8 cycles each and what surrounds them bound it, not the 3.9 TB/s it moves.)
 #include "bbx_common.h"
 #include <stdlib.h>
 
@@ -74,9 +74,10 @@ __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __res
                 for (int s = 8; s < 16; s++) q_hi = fma(((use[q] >> s) & 1u) ? (double)val[s][q] : 0.0, cv[s], q_hi);
                 const double corr = (0.0 + q_lo) + q_hi;
                 // the victim's own value: register v of the 16 (a run-time index: picked by a chain of selects)
-                float own = val[0][q];
-#pragma unroll
-                for (int c = 1; c < 16; c++) own = (v == c) ? val[c][q] : own;
+                // the victim's own value: register v of the 16, a run-time but wave-uniform index -- the compiler reads it in
+                // GPR-index mode (s_set_gpr_idx_on), one move instead of the chain of 15 selects of rounds 2-3 (a quarter of
+                // the kernel's vector instructions; the kernel is issue-bound: 232 -> 198 us)
+                const float own = val[v][q];
                 o[q] = (float)((double)own - (!((edge[q] >> v) & 1u) ? corr : corr * 0.0));
             }
             if (VEC == 4) *(float4*)(data + off) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
