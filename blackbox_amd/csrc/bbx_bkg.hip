@@ -203,15 +203,19 @@ __global__ __launch_bounds__(64) void k_bkg_boxstats_list(const float* __restric
 // ---- the same statistics without sorting the box ---------------------------------------------------------------------
 // The clip only ever needs (i) the middle order statistic(s) of the survivors and (ii) the pixels it removes, which sit in
 // the wings.  So: 512 of the box's slots are sorted as a sample (8 registers per lane); its order statistics give a
-// bracket [lo, hi] around the median (sample ranks 0.42 .. 0.58) and two wing limits (0.05 / 0.85).  Two passes over the 64
+// bracket [lo, hi] around the median (sample ranks 0.44 .. 0.56) and two wing limits (0.05 / 0.85).  Two passes over the 64
 // registers, neither with a step that waits for another lane: the first counts per lane the keys of the bracket, of the
 // wings and below the bracket and sums the pixels between the wings about a pivot; after one scan of the lane counts the
-// second writes the bracket (<= 1024 keys) and the wings (<= 1024) into LDS.  The bracket alone is sorted (16 registers
+// second writes the bracket (<= 1024 keys) and the wings (<= 1024) into LDS.  The bracket alone is sorted (8 or 16 registers
 // per lane).  A clip round then reads its median(s) from the sorted bracket by rank and scans the wing list for what it
 // removes.  Whenever an assumption fails -- bracket or wings overflow (ties, constant boxes), a median outside the bracket,
 // a clip limit inside the unlisted middle, too few samples -- the box is listed and k_bkg_boxstats_list sorts it in full:
 // the medians are the same order statistics whichever path ran.
 #define BOXF_NB 1024
+#ifndef BOXF_QLO
+#define BOXF_QLO 0.44f            // sample ranks of the bracket's ends: 12 % of the keys, mostly <= 512 -> the 8-register sort;
+#define BOXF_QHI 0.56f            // (0.42 / 0.58: 16 boxes of a frame's 30 976 fall back instead of 209, but 9 % slower; 0.45 / 0.55: 676)
+#endif
 #define BOXF_NT 1024
 template <int NR, int K, int J> __device__ __forceinline__ void bs_static(uint32_t (&k)[NR]) {
 #pragma unroll
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(64, BOXF_MINW) void k_bkg_boxstats_fast(const float
 #pragma unroll
         for (int j = 0; j < 8; j++) s_br[lane * 8 + j] = sm[j];
         __syncthreads();
-        const int jl = (int)((float)nsv * 0.42f), jh = min((int)((float)nsv * 0.58f) + 1, nsv - 1);
+        const int jl = (int)((float)nsv * BOXF_QLO), jh = min((int)((float)nsv * BOXF_QHI) + 1, nsv - 1);
         // wings: below the sample's 5 % point and above its 85 % point (stars make the upper wing the one a clip reaches into)
         const int jtl = (int)((float)nsv * 0.05f), jth = min((int)((float)nsv * 0.85f), nsv - 1);
         lo_key = s_br[jl]; hi_key = s_br[jh]; tl_key = s_br[jtl]; th_key = s_br[jth];
@@ -399,7 +403,18 @@ __global__ __launch_bounds__(64, BOXF_MINW) void k_bkg_boxstats_fast(const float
         s1 += wave_sum_f64(d1); s2 += wave_sum_f64(d2);
     }
     // ---- the bracket, sorted, back into LDS
-    {
+    if (nb <= 512) {                                               // (uniform) half the network for a bracket that fits 8 registers per lane
+        uint32_t kb[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) kb[r] = (r * 64 + lane < nb) ? s_br[r * 64 + lane] : BOX_PAD;
+        __syncthreads();
+#ifndef BOXK_NOBR
+        bs_sort<8>(kb, lane);
+#endif
+#pragma unroll
+        for (int r = 0; r < 8; r++) s_br[box_bslot(lane * 8 + r)] = kb[r];
+        __syncthreads();
+    } else {
         uint32_t kb[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) kb[r] = (r * 64 + lane < nb) ? s_br[r * 64 + lane] : BOX_PAD;
