@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void k_xtalk(float* data, const uint8_t* __res
                 if (m[q] & BBX_MASK_EDGE) edge[q] |= 1u << c;
             }
         }
-#pragma unroll 1
+#ifndef XTALK_UNROLL
+#define XTALK_UNROLL 2                     // (1: 193 us, 2: 188, 4: 191 -- the next victim's coefficients load while this one computes)
+#endif
+#pragma unroll XTALK_UNROLL
         for (int v = 0; v < 16; v++) {
             const size_t off = ((v >> 3) ? off_hi : off_lo) + (size_t)(v & 7) * d.xsz;
             const double* cv = &cf.v[v * 16];
