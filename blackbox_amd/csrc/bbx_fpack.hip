@@ -633,8 +633,19 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
 #ifdef FPV_NOQUANT
         for (int i = tid; i < nx; i += FP_THREADS) vals[i] = (int)(fv[i] * 2.f);
 #else
-        for (int i = tid; i < nx; i += FP_THREADS)
-            vals[i] = fp_nint((((double)fv[i] - zeropt) / delta) + (double)rnd[fp_rand_index(rnd, iseed, i)] - 0.5);
+        {
+            // the dither index of pixel i (fp_rand_index): the table is read from start0 + i until its end, then from start1 on
+            // (rows of up to 2 x 9500 pixels take two segments: both starts once per row instead of a table load, a float64
+            // product and a loop per pixel)
+            const int is1 = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
+            const int start0 = (int)((double)rnd[iseed] * 500.), start1 = (int)((double)rnd[is1] * 500.);
+            const int n0 = FP_NRANDOM - start0, n1 = FP_NRANDOM - start1;
+            for (int i = tid; i < nx; i += FP_THREADS) {
+                const int j = i - n0;
+                const int ri = j < 0 ? start0 + i : (j < n1 ? start1 + j : fp_rand_index(rnd, iseed, i));
+                vals[i] = fp_nint((((double)fv[i] - zeropt) / delta) + (double)rnd[ri] - 0.5);
+            }
+        }
 #endif
     } else {
         if (BYTEPIX == 1) {
