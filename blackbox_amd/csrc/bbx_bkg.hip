@@ -2,11 +2,11 @@
 // buildref.py:2398-2405, 2480-2495).  [EXT: parity unpinned, the
 // conventions are the ones written down in oracle/zogy_core.py]
 //
-//   k_bkg_boxstats   one workgroup per bkg_boxsize x bkg_boxsize box: the usable pixels
-//                    (mask == 0, objmask == 0, value != 0) are sorted once in LDS; the
-//                    astropy-style clip (centre = median, std about the mean, 3 sigma,
-//                    <= 5 iterations) then only narrows an index range of the sorted array.
-//                    One read of the frame + mask: 5N bytes, HBM-bound.
+//   k_bkg_boxstats_fast  one wave per bkg_boxsize x bkg_boxsize box: the astropy-style clip (centre = median, std about
+//                    the mean, 3 sigma, <= 5 iterations) of the usable pixels (mask == 0, objmask == 0, value != 0) from a
+//                    sorted bracket around the median + the list of the wing pixels (round 4; vector-issue-bound);
+//   k_bkg_boxstats(_list)  the same from a full sort of the box in registers (rounds 2-3): the boxes the bracket kernel
+//                    lists, or all of them (BBX_OPT_BKG_FULL_SORT).  One read of the frame + mask: 5N bytes.
 //   k_mini_fill_filter  NaN boxes <- nan-median of 3x3 neighbours (repeated), then a 3x3
 //                    median filter with replicated edges, on the 176x176 mini image.
 //   k_spline_zoom    scipy.ndimage.zoom(order=3, mode='nearest') evaluation: the cubic

@@ -1,7 +1,7 @@
 """GPU box: CPU seconds (user + system) of the whole bench process tree per wall second, sampled while it runs"""
 import subprocess, sys, time, os
 import psutil
-p = subprocess.Popen([sys.executable, 'bench.py', '--no-cpu', '--no-extras', '--steps', '600', '--warmup', '20'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+p = subprocess.Popen([sys.executable, 'bench.py'] + (sys.argv[1:] or ['--no-cpu', '--no-extras', '--steps', '600', '--warmup', '20']), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
 proc = psutil.Process(p.pid)
 samples = []
 t0 = time.time()
