@@ -139,7 +139,7 @@ def push(ctx, *arrays):
     import numpy as np
     import torch
     outs = []
-    sp = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    sp = ctx.stream()
     for a in arrays:
         a = np.ascontiguousarray(a)
         n = a.nbytes
@@ -187,7 +187,7 @@ def fetch(ctx, *tensors):
     if pin is None or pin.numel() < total:
         pin = ctx.__dict__['_fetch_pin'] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
     views, off = [], 0
-    sp = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    sp = ctx.stream()
     for t, nb in zip(ts, sizes):
         n = t.numel() * t.element_size()
         v = pin[off:off + n].view(t.dtype).view(t.shape)
