@@ -133,9 +133,6 @@ enum {
 int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line);
 void bbx_zogy2_release(bbx_ctx* ctx);
 int bbx_zogy3_supported(int L);
-int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, int L, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
-                  const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
-                  float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s);     // bbx_zogy3.hip
 void bbx_zogy_release(bbx_ctx* ctx);      // bbx_zogy.hip: frees ctx->zogy_state (called by bbx_ctx_destroy)
 void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc);
 

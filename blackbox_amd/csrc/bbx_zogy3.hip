@@ -23,6 +23,24 @@ namespace z3 {
 
 struct zscal { float sn, sr, fn, fr, dx, dy; };
 
+// Diagnostic builds only (tools/exp/zvar.sh -DZ3_STAMPS; the Makefile never defines it): thread 0 of every workgroup writes
+// the shader clock at the phase boundaries of the kernel into a buffer set by bbx_z3_stamps (tools/dbg/z3_stamps.py).
+#ifdef Z3_STAMPS
+#define Z3_STAMP_WGS 24576
+__device__ unsigned long long* g_z3_stamps;
+#define ZSTAMP(kid, i)                                                                                                     \
+    do { if (threadIdx.x == 0 && g_z3_stamps && blockIdx.x < Z3_STAMP_WGS)                                                \
+            g_z3_stamps[((size_t)(kid) * Z3_STAMP_WGS + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ZSTAMP_HEAD(kid)                                                                                                   \
+    do { if (threadIdx.x == 0 && g_z3_stamps && blockIdx.x < Z3_STAMP_WGS) {                                              \
+            unsigned long long* q_ = g_z3_stamps + ((size_t)(kid) * Z3_STAMP_WGS + blockIdx.x) * 16;                       \
+            q_[14] = __builtin_amdgcn_s_memrealtime(); q_[15] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); \
+            q_[0] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define ZSTAMP(kid, i)
+#define ZSTAMP_HEAD(kid)
+#endif
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 #ifndef Z3_SPREAD
 #define Z3_SPREAD 1
@@ -245,8 +263,15 @@ __device__ __forceinline__ int xcd_task() { return (int)blockIdx.x; }
 static inline dim3 grid8(int nx, int ny) { return dim3((unsigned)(((size_t)nx * ny + 7) / 8 * 8)); }
 
 // ---- data movement (loops over the workgroup) ---------------------------------------------------
+// The final kernel's workgroups take chunks of consecutive row blocks of one sub-image: chunk c of nch covers the blocks
+// start[c] .. start[c + 1] - 1 (the same cut for every sub-image; host: chunk_plan); only the row above a chunk's first block
+// travels through the halo arrays H[sub][c][HP] (inside a chunk the row above a block is the last row of the block before
+// it, still in LDS).
+struct chunk_args { const int* start; int nch; };
+__device__ __forceinline__ int chunk_start(const chunk_args& ch, int c) { return ch.start[c]; }
 // LDS (natural order, after an inverse column pass) -> U tiles U[sub][g][y][l]; halo rows on request
-template <class P> __device__ __forceinline__ void store_u(const float2* s, float2* __restrict__ U, int sub, int g, float2* __restrict__ halo = nullptr) {
+template <class P> __device__ __forceinline__ void store_u(const float2* s, float2* __restrict__ U, int sub, int g, float2* __restrict__ halo = nullptr,
+                                                            chunk_args ch = chunk_args{nullptr, 0}) {
     float2* base = U + (size_t)sub * P::UNIT + (size_t)g * P::L * P::NL;
     // two neighbouring lines per item: one 16-byte store
     constexpr int HL = P::NL / 2;
@@ -254,8 +279,14 @@ template <class P> __device__ __forceinline__ void store_u(const float2* s, floa
         const int y = e / HL, l = 2 * (e - y * HL), py = npos(y);
         const float2 v0 = s[l * P::LS + py], v1 = s[(l + 1) * P::LS + py];
         *reinterpret_cast<float4*>(base + (size_t)y * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
-        if (halo && (y % P::NL == P::NL - 1 || y == P::L - 1))
-            *reinterpret_cast<float4*>(halo + ((size_t)sub * P::LB + y / P::NL) * P::HP + g * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+    if (halo) {
+        for (int e = threadIdx.x; e < ch.nch * HL; e += blockDim.x) {
+            const int c = e / HL, l = 2 * (e - c * HL), yb = chunk_start(ch, c);
+            const int y = yb ? yb * P::NL - 1 : P::L - 1, py = npos(y);                    // row L - 1 above row 0: np.roll
+            const float2 v0 = s[l * P::LS + py], v1 = s[(l + 1) * P::LS + py];
+            *reinterpret_cast<float4*>(halo + ((size_t)sub * ch.nch + c) * P::HP + g * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
     }
 }
 // The matched-filter kernels k_n, k_r live around the origin: of the inverse column pass of k^ only the rows
@@ -369,19 +400,20 @@ template <class P> __device__ __forceinline__ void load_halo_pair(const float2* 
 // The same loads split in two: all of a workgroup's 16-byte loads into registers first (issued before a
 // transform of other data, so that their latency hides behind it), the LDS stores later.
 template <class P, int T> struct t_regs { static constexpr int N = (P::LB * P::NL * P::NL / 2 + T - 1) / T; float4 v[N]; };
-template <class P, int T> __device__ __forceinline__ void fetch_t_lines(const float2* __restrict__ Tin, int sub, int g, t_regs<P, T>& r) {
+// (I0, I1: the part of a thread's loads to issue / store; a kernel short of registers takes the rest in a second round)
+template <class P, int T, int I0 = 0, int I1 = 1 << 30> __device__ __forceinline__ void fetch_t_lines(const float2* __restrict__ Tin, int sub, int g, t_regs<P, T>& r) {
     const float2* src = Tin + (size_t)sub * P::UNIT + (size_t)g * P::NL * P::NL;
     constexpr int TV = P::NL * P::NL / 2, NV = P::LB * TV;
 #pragma unroll
-    for (int i = 0; i < t_regs<P, T>::N; i++) {
+    for (int i = I0; i < (I1 < t_regs<P, T>::N ? I1 : t_regs<P, T>::N); i++) {
         const int e = (int)threadIdx.x + i * T;
         if (e < NV) { const int yb = e / TV, j = e - yb * TV; r.v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
     }
 }
-template <class P, int T> __device__ __forceinline__ void pack_t_lines(const t_regs<P, T>& r, float2* s) {
+template <class P, int T, int I0 = 0, int I1 = 1 << 30> __device__ __forceinline__ void pack_t_lines(const t_regs<P, T>& r, float2* s) {
     constexpr int TV = P::NL * P::NL / 2, NV = P::LB * TV;
 #pragma unroll
-    for (int i = 0; i < t_regs<P, T>::N; i++) {
+    for (int i = I0; i < (I1 < t_regs<P, T>::N ? I1 : t_regs<P, T>::N); i++) {
         const int e = (int)threadIdx.x + i * T;
         if (e < NV) {
             const int yb = e / TV, j = e - yb * TV, l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
@@ -394,12 +426,12 @@ template <class P, int T> __device__ __forceinline__ void pack_t_lines(const t_r
 }
 template <class P, int T> struct u_regs { static constexpr int N = (P::G * P::NL * P::NL / 2 + T - 1) / T; float4 a[N], b[N]; };
 template <class P, int T> __device__ __forceinline__ void fetch_u_pair(const float2* __restrict__ Ua, const float2* __restrict__ Ub, int sub, int yb,
-                                                                        u_regs<P, T>& r) {
+                                                                        u_regs<P, T>& r, int tid = (int)threadIdx.x) {
     constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
     const size_t base = (size_t)sub * P::UNIT + (size_t)yb * P::NL * P::NL;
 #pragma unroll
     for (int i = 0; i < u_regs<P, T>::N; i++) {
-        const int e = (int)threadIdx.x + i * T;
+        const int e = tid + i * T;
         if (e < NV) {
             const int g = e / TV, j = e - g * TV;
             const size_t o = base + (size_t)g * P::L * P::NL + 2 * j;
@@ -407,11 +439,12 @@ template <class P, int T> __device__ __forceinline__ void fetch_u_pair(const flo
         }
     }
 }
-template <class P, int T> __device__ __forceinline__ void pack_u_pair(const u_regs<P, T>& r, int yb, float2* s, const unsigned short* pp) {
+template <class P, int T> __device__ __forceinline__ void pack_u_pair(const u_regs<P, T>& r, int yb, float2* s, const unsigned short* pp,
+                                                                       int tid = (int)threadIdx.x) {
     constexpr int TV = P::NL * P::NL / 2, NV = P::G * TV;
 #pragma unroll
     for (int i = 0; i < u_regs<P, T>::N; i++) {
-        const int e = (int)threadIdx.x + i * T;
+        const int e = tid + i * T;
         if (e < NV) {
             const int g = e / TV, j = e - g * TV, row = (2 * j) / P::NL, l = (2 * j) % P::NL;
             if (yb * P::NL + row < P::L) {
@@ -458,16 +491,84 @@ template <class P> __device__ __forceinline__ void e2lp(int e, int& l, int& p) {
         if (e = t_ + k * RT, e2lp<P>(e, l, p), e < P::NL * P::L)                      /* RT: the kernel's thread count */
 #define C_LOOP(e, l, p) for (int e = threadIdx.x, l, p; e2lp<P>(e, l, p), e < P::NL * P::L; e += blockDim.x)
 
+// V(S)^ is scaled by a power of two before it shares a transform with D (float32 rounding leaks ~1e-7 of the larger part of a
+// complex transform into the smaller; the scale, chosen per sub-image from Parseval sums of k^2, is exact to undo)
+__device__ __forceinline__ float vs_scale_of(double a, double b, const zscal& z, double n2) {
+    const float level = (float)(((double)z.sn * z.sn * a + (double)z.sr * z.sr * b) / n2);            // Parseval: sum_x k^2 = sum_k |k^|^2 / L^2
+    if (!(level > 0.f) || !isfinite(level)) return 1.f;
+    return exp2f(-rintf(log2f(level)));
+}
+// The per-sub-image scalars every later workgroup needs -- F_S, the scale of V(S)^ and its inverse -- from k_psf_cols'
+// partial sums, and the check of the row window: one wave per sub-image (first workgroup of k_psf_rows; rounds 3-4: a
+// serial loop over the G partial sums in thread 0 of every workgroup of k_var_cols and k_final_rows).
+struct sub_scal { float fs, beta, ibeta, pad; };
+template <class P> __device__ __forceinline__ void sub_scalars(const double* __restrict__ fs_partial, int nsub, int sub, const zscal& z, bool win,
+                                                                sub_scal* __restrict__ out, int32_t* __restrict__ d_err) {
+    // lanes 0 .. 63 of one wave
+    const int lane = (int)(threadIdx.x & 63);
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int g = lane; g < P::G; g += 64) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (i < 3 || win) v[i] += fs_partial[((size_t)i * nsub + sub) * P::G + g];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) v[i] = wave_sum_f64(v[i]);
+    if (lane == 0) {
+        const double n2 = (double)P::L * (double)P::L;
+        sub_scal r;
+        r.fs = (float)(v[0] / n2);
+        r.beta = vs_scale_of(v[1], v[2], z, n2);
+        r.ibeta = 1.0f / r.beta; r.pad = 0.f;
+        out[sub] = r;
+        // the rows the window dropped from k_n, k_r must hold nothing a float32 transform could tell from zero
+        if (win && !(v[4] <= Z3_KWIN_TOL * v[3])) atomicOr(d_err, BBX_DERR_PSF_WINDOW);
+    }
+}
+
 // ---- PSF side ---------------------------------------------------------------------------------
+// Row DFT of the S non-zero rows of every PSF stamp, summed directly: Q[which][sub][j][kx] = sum_x p[j][x] W^(kx (x - h)),
+// kx < H (the stamp's columns sit at x = -h .. S-1-h mod L).  A thread takes one kx and ZQ_J stamp rows: the twiddle of a
+// column is read once for all of them, the stamp values are wave-uniform.  (Round 5: this sum sat inside k_psf_cols, one
+// L2 round trip per four terms in every workgroup: 2 x 11 000 of its 75 000 cycles.)
+#define ZQ_J 7
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S,
+__global__ __launch_bounds__(256) void k_psf_rowdft(const float* __restrict__ psf_n, const float* __restrict__ psf_r, int S, const float2* __restrict__ twg,
+                                                    float2* __restrict__ Q, int nsub) {
+    __shared__ float2 tw[P::L];
+    for (int e = threadIdx.x; e < P::L; e += blockDim.x) tw[e] = twg[e];
+    __syncthreads();
+    const int kx = (int)(blockIdx.x * blockDim.x + threadIdx.x), j0 = (int)blockIdx.y * ZQ_J;
+    const int which = (int)blockIdx.z / nsub, sub = (int)blockIdx.z - which * nsub;
+    if (kx >= P::H) return;
+    const float* st = (which ? psf_r : psf_n) + (size_t)sub * S * S;
+    const int h = S / 2;
+    float2 acc[ZQ_J];
+#pragma unroll
+    for (int jj = 0; jj < ZQ_J; jj++) acc[jj] = make_float2(0.f, 0.f);
+    int idx = (kx * ((P::L - h % P::L) % P::L)) % P::L;             // kx (L - h) < H L: 32-bit
+    for (int x = 0; x < S; x++) {
+        const float2 w = tw[idx];
+#pragma unroll
+        for (int jj = 0; jj < ZQ_J; jj++) {
+            if (j0 + jj < S) { const float pv = st[(j0 + jj) * S + x]; acc[jj].x += pv * w.x; acc[jj].y += pv * w.y; }
+        }
+        idx += kx; if (idx >= P::L) idx -= P::L;
+    }
+#pragma unroll
+    for (int jj = 0; jj < ZQ_J; jj++)
+        if (j0 + jj < S) Q[(((size_t)which * nsub + sub) * S + (j0 + jj)) * P::HP + kx] = acc[jj];
+}
+
+template <class P>
+__global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const float2* __restrict__ Q, int S,
                                                          const zscal* __restrict__ sc, const float2* __restrict__ twg,
-                                                         float2* __restrict__ cA, float2* __restrict__ cB, float* __restrict__ cSd,
+                                                         float4* __restrict__ cP,
                                                          float2* __restrict__ Ukn, float2* __restrict__ Ukr,
                                                          double* __restrict__ fs_partial, int nsub, int wh) {
     extern __shared__ float2 s[];
     __shared__ double red[5][P::THREADS / 64];
     WG_TASK(P::G, nsub, g, sub);
+    ZSTAMP_HEAD(0);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     const int h = S / 2;
@@ -475,44 +576,22 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
     constexpr int RT = P::THREADS, NE = (P::NL * P::L + RT - 1) / RT;
     float2 park[NE];                                               // Pn^, then kn^
     for (int pass = 0; pass < 2; pass++) {
-        const float* st = (pass ? psf_r : psf_n) + (size_t)sub * S * S;
+        const float2* qs = Q + ((size_t)pass * nsub + sub) * S * P::HP;
         for (int e = threadIdx.x; e < P::NL * P::LS; e += blockDim.x) s[e] = make_float2(0.f, 0.f);
         __syncthreads();
-        // row DFT of the S non-zero rows, summed directly: line[y] = sum_x p[y][x] W^(kx x)
+        ZSTAMP(0, 1 + 3 * pass);
+        // the stamp's S non-zero rows, row-transformed by k_psf_rowdft: line[y] = sum_x p[y][x] W^(kx x)
         for (int e = threadIdx.x; e < P::NL * S; e += blockDim.x) {
             const int ll = e % P::NL, j = e / P::NL;
             const int kk = g * P::NL + ll;
             if (kk >= P::H) continue;
-            float2 acc = make_float2(0.f, 0.f);
-            // the stamp's columns sit at x = -h .. S-1-h (mod L): the twiddle index kx x advances by kx per column
-            int idx = (kk * ((P::L - h % P::L) % P::L)) % P::L;         // kx (L - h) < H L: 32-bit
-            // four terms per round: their loads (stamp row from global memory, twiddles from the workgroup's table) go out
-            // together instead of one round trip per term
-            const float* row = st + j * S;
-            int i = 0;
-            for (; i + 4 <= S; i += 4) {
-                int i1 = idx + kk; if (i1 >= P::L) i1 -= P::L;
-                int i2 = i1 + kk; if (i2 >= P::L) i2 -= P::L;
-                int i3 = i2 + kk; if (i3 >= P::L) i3 -= P::L;
-                const float p0 = row[i], p1 = row[i + 1], p2 = row[i + 2], p3 = row[i + 3];
-                const float2 w0 = tw[idx], w1 = tw[i1], w2 = tw[i2], w3 = tw[i3];
-                acc.x += p0 * w0.x; acc.y += p0 * w0.y;
-                acc.x += p1 * w1.x; acc.y += p1 * w1.y;
-                acc.x += p2 * w2.x; acc.y += p2 * w2.y;
-                acc.x += p3 * w3.x; acc.y += p3 * w3.y;
-                idx = i3 + kk; if (idx >= P::L) idx -= P::L;
-            }
-            for (; i < S; i++) {
-                const float2 w = tw[idx];
-                const float p = row[i];
-                acc.x += p * w.x; acc.y += p * w.y;
-                idx += kk; if (idx >= P::L) idx -= P::L;
-            }
             const int y = ((j - h) % P::L + P::L) % P::L;
-            s[ll * P::LS + npos(y)] = acc;
+            s[ll * P::LS + npos(y)] = qs[(size_t)j * P::HP + kk];
         }
         __syncthreads();
+        ZSTAMP(0, 2 + 3 * pass);
         fft_fwd<P>(s, tw, S - h);                                      // the stamp's rows: [0, S - h) and [L - h, L)
+        ZSTAMP(0, 3 + 3 * pass);
         if (pass == 0) {
             R_LOOP(k, e, l, p) park[k] = s[l * P::LS + npos(p)];      // Pn^ waits in registers while Pr^ is transformed
             __syncthreads();
@@ -523,8 +602,8 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
     double fs = 0.0, sk2n = 0.0, sk2r = 0.0;                      // F_S and the Parseval sums of kn^2, kr^2
     R_LOOP(k, e, l, p) {
         const int kx = g * P::NL + l;
-        float2 a = make_float2(0.f, 0.f), b = a, kn = a, kr = a;
-        float sdv = 0.f;
+        float2 kn = make_float2(0.f, 0.f), kr = kn;
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kx < P::H) {
             const double wgt = (kx == 0 || (P::L % 2 == 0 && kx == P::L / 2)) ? 1.0 : 2.0;
             const float2 pn = park[k], pr = s[l * P::LS + npos(p)];
@@ -533,30 +612,32 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
             // one division per entry: 1 / den as the square of 1 / sqrt(den) (a float32 division is ~10 instructions,
             // four of them were a fifth of this kernel's arithmetic)
             const float sd = sqrtf(den), isd = 1.0f / sd, rden = isd * isd;
-            sdv = sd;
-            a = cscale(pr, z.fr * isd);                                   // D^ = A N^ - B R^
-            b = cscale(pn, z.fn * isd);
+            cp = make_float4(pn.x, pn.y, pr.x, pr.y);
             kr = cscale(make_float2(pr.x, -pr.y), z.fr * fn2 * pn2 * rden);
             kn = cscale(make_float2(pn.x, -pn.y), z.fn * fr2 * pr2 * rden);
             fs += wgt * (double)(fn2 * pn2 * fr2 * pr2 * rden);
             sk2n += wgt * (double)(kn.x * kn.x + kn.y * kn.y);
             sk2r += wgt * (double)(kr.x * kr.x + kr.y * kr.y);
         }
-        // k_n^ = conj(B) |A|^2 sqrt(den), k_r^ = conj(A) |B|^2 sqrt(den): k_img_cols gets A, B and sqrt(den) (20 bytes
-        // per entry, read once) instead of four complex arrays (32 bytes, read in two loops)
-        cA[cbase + e] = a; cB[cbase + e] = b; cSd[cbase + e] = sdv;
+        // k_img_cols gets the two spectra themselves (16 bytes per entry, one load) and forms 1 / sqrt(den) and the
+        // coefficients of D^, S_n^, S_r^ from them again (rounds 3-4: A, B and sqrt(den), 20 bytes in three loads)
+        cP[cbase + e] = cp;
         s[l * P::LS + npos(p)] = kr;
         park[k] = kn;
     }
     __syncthreads();
+    ZSTAMP(0, 7);
     fft_inv<P>(s, tw);
+    ZSTAMP(0, 8);
     const bool win = 2 * wh < P::L;
     double e_all = 0.0, e_out = 0.0;
     if (win) store_u_win<P>(s, Ukr, sub, g, wh, e_all, e_out); else store_u<P>(s, Ukr, sub, g);
     __syncthreads();
     R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = park[k];
     __syncthreads();
+    ZSTAMP(0, 9);
     fft_inv<P>(s, tw);
+    ZSTAMP(0, 10);
     if (win) store_u_win<P>(s, Ukn, sub, g, wh, e_all, e_out); else store_u<P>(s, Ukn, sub, g);
     fs = wave_sum_f64(fs); sk2n = wave_sum_f64(sk2n); sk2r = wave_sum_f64(sk2r);
     e_all = wave_sum_f64(e_all); e_out = wave_sum_f64(e_out);
@@ -577,31 +658,41 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
         for (int i = 0; i < (int)blockDim.x / 64; i++) tot += red[threadIdx.x][i];
         fs_partial[((size_t)threadIdx.x * nsub + sub) * P::G + g] = tot;      // [5][nsub][G]
     }
+    ZSTAMP(0, 11);
 }
 
 // inverse row pass of kr^, kn^ -> kr, kn -> squares -> forward row pass, T tiles
 template <class P>
 __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_psf_rows(const float2* __restrict__ Ukr, const float2* __restrict__ Ukn, float inv_n2,
                                                          const float2* __restrict__ twg, float2* __restrict__ Tkr2, float2* __restrict__ Tkn2,
-                                                         int nsub, int nyb, int wb) {
+                                                         int nsub, int nyb, int wb, const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
+                                                         sub_scal* __restrict__ sub_sc, int32_t* __restrict__ d_err) {
     extern __shared__ float2 s[];
     WG_TASK(nyb, nsub, ybw, sub);
+    if (ybw == 0 && threadIdx.x < 64) sub_scalars<P>(fs_partial, nsub, sub, sc[sub], nyb != P::LB, sub_sc, d_err);
     // with a row window only the blocks that hold rows < wh or >= L - wh exist: nyb = 2 wb of them
     const int yb = (nyb == P::LB || ybw < wb) ? ybw : P::LB - 2 * wb + ybw;
+    ZSTAMP_HEAD(1);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     __syncthreads();                                                // the position table is used right away
+    ZSTAMP(1, 1);
     load_u_pair<P>(Ukr, Ukn, sub, yb, s, aux.pp);
     __syncthreads();
+    ZSTAMP(1, 2);
     fft_inv<P>(s, tw);
+    ZSTAMP(1, 3);
     C_LOOP(e, l, p) {
         float2* q = s + l * P::LS + npos(p);
         const float a = q->x * inv_n2, b = q->y * inv_n2;
         *q = make_float2(a * a, b * b);
     }
     __syncthreads();
+    ZSTAMP(1, 4);
     fft_fwd<P>(s, tw);
+    ZSTAMP(1, 5);
     store_t_split<P>(s, aux.pp, Tkr2, Tkn2, sub, yb);
+    ZSTAMP(1, 6);
 }
 
 // forward column pass of one T array -> C layout
@@ -616,20 +707,6 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_LIGHT) void k_cols_fwd(const fl
     fft_fwd<P>(s, tw);
     const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
     C_LOOP(e, l, p) Cout[cbase + e] = s[l * P::LS + npos(p)];
-}
-
-// V(S)^ is scaled by a power of two before it shares a transform with D (float32 rounding leaks ~1e-7 of the larger part of a
-// complex transform into the smaller; the scale, chosen per sub-image from Parseval sums of k^2, is exact to undo)
-template <class P> __device__ __forceinline__ float vs_scale(const double* __restrict__ fs_partial, int nsub, int sub, const zscal& z) {
-    double a = 0.0, b = 0.0;
-    for (int g = 0; g < P::G; g++) {
-        a += fs_partial[((size_t)1 * nsub + sub) * P::G + g];
-        b += fs_partial[((size_t)2 * nsub + sub) * P::G + g];
-    }
-    const double n2 = (double)P::L * (double)P::L;
-    const float level = (float)(((double)z.sn * z.sn * a + (double)z.sr * z.sr * b) / n2);            // Parseval: sum_x k^2 = sum_k |k^|^2 / L^2
-    if (!(level > 0.f) || !isfinite(level)) return 1.f;
-    return exp2f(-rintf(log2f(level)));
 }
 
 // ---- image side -------------------------------------------------------------------------------
@@ -712,6 +789,7 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
                                                                                 float2* __restrict__ Tb, float2* __restrict__ Tva, float2* __restrict__ Tvb, int nsub) {
     extern __shared__ float2 s[];
     WG_TASK_ROWS(P::LB, nsub, yb, sub);
+    ZSTAMP_HEAD(2);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     const int y0 = yb * P::NL;
@@ -752,9 +830,12 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
         }
     }
     __syncthreads();
+    ZSTAMP(2, 1);
     fft_fwd<P>(s, tw);
+    ZSTAMP(2, 2);
     store_t_split<P>(s, aux.pp, Ta, Tb, sub, yb);
     __syncthreads();
+    ZSTAMP(2, 3);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const int e = (int)threadIdx.x + i * P::LIGHT_THREADS;
@@ -766,18 +847,22 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
         }
     }
     __syncthreads();
+    ZSTAMP(2, 4);
     fft_fwd<P>(s, tw);
+    ZSTAMP(2, 5);
     store_t_split<P>(s, aux.pp, Tva, Tvb, sub, yb);
+    ZSTAMP(2, 6);
 }
 
 // column pass of the image pair: D^ = A N^ - B R^, Sn^ = kn^ N^, Sr^ = kr^ R^ and back (U tiles)
 template <class P>
-__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* __restrict__ TN, const float2* __restrict__ TR, const float2* __restrict__ cA,
-                                                         const float2* __restrict__ cB, const float* __restrict__ cSd, const float2* __restrict__ twg,
+__global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* __restrict__ TN, const float2* __restrict__ TR, const float4* __restrict__ cP,
+                                                         const zscal* __restrict__ sc, const float2* __restrict__ twg,
                                                          float2* __restrict__ UD, float2* __restrict__ USn, float2* __restrict__ USr,
-                                                         float2* __restrict__ HSn, float2* __restrict__ HSr, int nsub) {
+                                                         float2* __restrict__ HSn, float2* __restrict__ HSr, int nsub, chunk_args ch) {
     extern __shared__ float2 s[];
     WG_TASK(P::G, nsub, g, sub);
+    ZSTAMP_HEAD(3);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
     const size_t cbase = (size_t)(sub * P::G + g) * P::NL * P::L;
@@ -787,7 +872,9 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     fetch_t_lines<P, P::THREADS>(TR, sub, g, rr);
 #endif
     __syncthreads();
+    ZSTAMP(3, 1);
     fft_fwd<P>(s, tw);
+    ZSTAMP(3, 2);
     constexpr int RT = P::THREADS, NE = (P::NL * P::L + RT - 1) / RT;
     // N^ waits in registers for R^; then one loop makes D^, S_n^ (both parked) and S_r^ (into the lines) from A, B, sqrt(den)
     float2 park[NE], parkd[NE];
@@ -799,30 +886,62 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     load_t_lines<P>(TR, sub, g, s);
 #endif
     __syncthreads();
+    ZSTAMP(3, 3);
+    // the PSF spectra of this column group: the first half of a thread's entries is on its way while R is transformed, the
+    // second half goes out in one round behind it (a load inside the guarded loop below waits for its own round trip in
+    // every iteration: 8 x 2 700 cycles of this kernel's 95 000 in round 4)
+    constexpr int NC0 = NE / 2;
+    float4 c0[NC0], c1[NE - NC0];
+    {
+        const int t = opaque_tid();
+#pragma unroll
+        for (int k = 0; k < NC0; k++) c0[k] = cP[cbase + min(t + k * RT, P::NL * P::L - 1)];
+    }
     fft_fwd<P>(s, tw);
+    ZSTAMP(3, 4);
+    {
+        const int t = opaque_tid();
+#pragma unroll
+        for (int k = NC0; k < NE; k++) c1[k - NC0] = cP[cbase + min(t + k * RT, P::NL * P::L - 1)];
+    }
+    const zscal z = sc[sub];
+    const float cn = (z.sr * z.sr) * (z.fn * z.fn), cr = (z.sn * z.sn) * (z.fr * z.fr);      // den = cr |Pr^|^2 + cn |Pn^|^2
+    const float kfn = z.fn * (z.fr * z.fr), kfr = z.fr * (z.fn * z.fn);
     R_LOOP(k, e, l, p) {
         float2* q = s + l * P::LS + npos(p);
-        const float2 r = *q, n = park[k], A = cA[cbase + e], B = cB[cbase + e];
-        const float sd = cSd[cbase + e];
-        const float qn = (A.x * A.x + A.y * A.y) * sd, qr = (B.x * B.x + B.y * B.y) * sd;
-        const float2 an = cmul(A, n), br = cmul(B, r);
-        parkd[k] = make_float2(an.x - br.x, an.y - br.y);
-        park[k] = cscale(cmulc(n, B), qn);                          // conj(B) n
-        *q = cscale(cmulc(r, A), qr);
+        const float2 r = *q, n = park[k];
+        const float4 c = k < NC0 ? c0[k < NC0 ? k : 0] : c1[k >= NC0 ? k - NC0 : 0];      // (Pn^, Pr^); zero in the padding columns kx >= H
+        const float2 pn = make_float2(c.x, c.y), pr = make_float2(c.z, c.w);
+        const float pn2 = pn.x * pn.x + pn.y * pn.y, pr2 = pr.x * pr.x + pr.y * pr.y;
+        const float den = cr * pr2 + cn * pn2;
+        const float isd = (g * P::NL + l < P::H) ? __builtin_amdgcn_rsqf(den) : 0.f, rden = isd * isd;
+        // D^ = (f_r Pr^ N^ - f_n Pn^ R^) / sqrt(den), S_n^ = k_n^ N^, S_r^ = k_r^ R^ with k_n^ = f_n f_r^2 conj(Pn^) |Pr^|^2 / den
+        const float2 an = cmul(pr, n), br = cmul(pn, r);
+        const float da = z.fr * isd, db = z.fn * isd;
+        parkd[k] = make_float2(an.x * da - br.x * db, an.y * da - br.y * db);
+        park[k] = cscale(cmulc(n, pn), kfn * pr2 * rden);           // conj(Pn^) n
+        *q = cscale(cmulc(r, pr), kfr * pn2 * rden);
     }
     __syncthreads();
+    ZSTAMP(3, 5);
     fft_inv<P>(s, tw);
-    store_u<P>(s, USr, sub, g, HSr);
+    ZSTAMP(3, 6);
+    store_u<P>(s, USr, sub, g, HSr, ch);
     __syncthreads();
     R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = park[k];
     __syncthreads();
+    ZSTAMP(3, 7);
     fft_inv<P>(s, tw);
-    store_u<P>(s, USn, sub, g, HSn);
+    ZSTAMP(3, 8);
+    store_u<P>(s, USn, sub, g, HSn, ch);
     __syncthreads();
     R_LOOP(k, e, l, p) s[l * P::LS + npos(p)] = parkd[k];
     __syncthreads();
+    ZSTAMP(3, 9);
     fft_inv<P>(s, tw);
+    ZSTAMP(3, 10);
     store_u<P>(s, UD, sub, g);
+    ZSTAMP(3, 11);
 }
 
 // column pass of the variance pair: V(S)^ = Vn^ (kn^2)^ + Vr^ (kr^2)^ and back (U tiles).  The spectra (kn^2)^, (kr^2)^
@@ -831,53 +950,66 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
 template <class P>
 __global__ __launch_bounds__(P::VAR_THREADS, P::VAR_MINW) void k_var_cols(const float2* __restrict__ TVn, const float2* __restrict__ TVr, const float2* __restrict__ Tk2n,
                                                          const float2* __restrict__ Tk2r, const float2* __restrict__ twg,
-                                                         float2* __restrict__ UVS, const zscal* __restrict__ sc,
-                                                         const double* __restrict__ fs_partial, int nsub, int wh, int32_t* __restrict__ d_err) {
+                                                         float2* __restrict__ UVS, const sub_scal* __restrict__ sub_sc, int nsub, int wh,
+                                                         int32_t* __restrict__ ticket) {
     extern __shared__ float2 s[];
-    __shared__ float s_beta;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;          // the final kernel's chunk counter (next launch on this stream)
     WG_TASK(P::G, nsub, g, sub);
+    ZSTAMP_HEAD(4);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
     const float2* tw = aux.tw;
-    if (threadIdx.x == 0) s_beta = vs_scale<P>(fs_partial, nsub, sub, sc[sub]);
-    if (2 * wh < P::L && g == 0 && threadIdx.x == 64) {
-        // the rows the window dropped from k_n, k_r must hold nothing a float32 transform could tell from zero
-        double ta = 0.0, to = 0.0;
-        for (int gg = 0; gg < P::G; gg++) {
-            ta += fs_partial[((size_t)3 * nsub + sub) * P::G + gg];
-            to += fs_partial[((size_t)4 * nsub + sub) * P::G + gg];
-        }
-        if (!(to <= Z3_KWIN_TOL * ta)) atomicOr(d_err, BBX_DERR_PSF_WINDOW);
-    }
     constexpr int RT = P::VAR_THREADS, NE = (P::NL * P::L + RT - 1) / RT;        // two parked arrays: 512 threads, <= 128 VGPRs, no spills
     float2 park[NE], coef[NE];
     const bool win = 2 * wh < P::L;
     if (win) load_t_lines_win<P>(Tk2n, sub, g, s, wh); else load_t_lines<P>(Tk2n, sub, g, s);
+    t_regs<P, P::VAR_THREADS> rr;                                  // Vn^ (then Vr^) on its way while the k^2 spectrum is transformed
+    fetch_t_lines<P, P::VAR_THREADS>(TVn, sub, g, rr);
     __syncthreads();
+    ZSTAMP(4, 1);
     fft_fwd<P>(s, tw, win ? wh : 0);
+    ZSTAMP(4, 2);
+#if defined(Z3_STAMPS) && defined(Z3_FFT2X)          // diagnostic: the same transform once more (results wrong, timing only)
+    fft_fwd<P>(s, tw, win ? wh : 0);
+    ZSTAMP(4, 12);
+    fft_fwd<P>(s, tw, win ? wh : 0);
+    ZSTAMP(4, 13);
+#endif
     R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kn^2)^
     __syncthreads();
-    load_t_lines<P>(TVn, sub, g, s);
+    pack_t_lines<P, P::VAR_THREADS>(rr, s);
     __syncthreads();
+    ZSTAMP(4, 3);
     fft_fwd<P>(s, tw);
+    ZSTAMP(4, 4);
     R_LOOP(k, e, l, p) park[k] = cmul(coef[k], s[l * P::LS + npos(p)]);
     __syncthreads();
     if (win) load_t_lines_win<P>(Tk2r, sub, g, s, wh); else load_t_lines<P>(Tk2r, sub, g, s);
+    constexpr int NH = t_regs<P, P::VAR_THREADS>::N / 4;          // (more of it beside the parked product: spills)
+    fetch_t_lines<P, P::VAR_THREADS, 0, NH>(TVr, sub, g, rr);
     __syncthreads();
+    ZSTAMP(4, 5);
     fft_fwd<P>(s, tw, win ? wh : 0);
+    ZSTAMP(4, 6);
     R_LOOP(k, e, l, p) coef[k] = s[l * P::LS + npos(p)];                       // (kr^2)^
     __syncthreads();
-    load_t_lines<P>(TVr, sub, g, s);
+    fetch_t_lines<P, P::VAR_THREADS, NH>(TVr, sub, g, rr);
+    pack_t_lines<P, P::VAR_THREADS>(rr, s);
     __syncthreads();
+    ZSTAMP(4, 7);
     fft_fwd<P>(s, tw);
-    const float beta = s_beta;
+    ZSTAMP(4, 8);
+    const float beta = sub_sc[sub].beta;
     R_LOOP(k, e, l, p) {
         float2* q = s + l * P::LS + npos(p);
         const float2 v = cmul(coef[k], *q);
         *q = make_float2((park[k].x + v.x) * beta, (park[k].y + v.y) * beta);
     }
     __syncthreads();
+    ZSTAMP(4, 9);
     fft_inv<P>(s, tw);
+    ZSTAMP(4, 10);
     store_u<P>(s, UVS, sub, g);
+    ZSTAMP(4, 11);
 }
 
 struct out_args {
@@ -885,161 +1017,226 @@ struct out_args {
     int ny, nx, size, border, nsx, vec4;
 };
 
-// inverse row pass of (D, V_S) and (Sn, Sr) + the final algebra, written into the full frames.  A
-// workgroup takes one block of NL rows; the row above the block comes from the halo arrays as one more line.
+// inverse row pass of (D, V_S) and (Sn, Sr) + the final algebra, written into the full frames.  A workgroup takes a chunk of
+// consecutive blocks of NL rows of one sub-image (round 5; one block per workgroup before): the tables are set up once, the
+// tiles of the next block are on their way while this one is transformed (registers), and the row above a block -- needed
+// for the finite differences of V_ast -- is the last row of the block before it, kept in LDS: only a chunk's first block
+// transforms a fifth line, taken from the halo arrays.
 template <class P>
 __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(const float2* __restrict__ UD, const float2* __restrict__ UVS,
                                                            const float2* __restrict__ USn, const float2* __restrict__ USr,
                                                            const float2* __restrict__ HSn, const float2* __restrict__ HSr,
-                                                           const zscal* __restrict__ sc, const double* __restrict__ fs_partial,
-                                                           float inv_n2, const float2* __restrict__ twg, out_args o, int yb0, int nyb,
+                                                           const zscal* __restrict__ sc, const sub_scal* __restrict__ sub_sc,
+                                                           float inv_n2, const float2* __restrict__ twg, out_args o, chunk_args ch,
+                                                           const int2* __restrict__ tasks, int ntasks, int32_t* __restrict__ ticket,
                                                            int nsub, float cand_thr, uint32_t* __restrict__ cand_list,
                                                            int32_t* __restrict__ cand_cnt, uint32_t cand_cap, int32_t* __restrict__ d_err) {
     extern __shared__ float2 s[];
-    float2* hline = s + P::NL * P::LS;                              // the halo line
-    __shared__ float s_fs, s_ibeta;
-    WG_TASK_ROWS(nyb, nsub, ybi, sub);
+    float2* hline = s + P::NL * P::LS;                              // the row above the block
+    __shared__ int s_task;
+    ZSTAMP_HEAD(5);
     const aux_t aux = aux_setup<P>(s + (P::NL + 1) * P::LS, twg);
     const float2* tw = aux.tw;
-    __syncthreads();                                                // the position table is used right away
-    const int yb = yb0 + ybi, y0 = yb * P::NL;
+    // chunks are handed out by a ticket counter (zeroed by k_var_cols), longest first: the workgroups of a CU do not run at
+    // the same speed (the older one wins the issue slots), a fixed share per workgroup left the slow ones 15 % behind
+    for (;;) {
+    __syncthreads();                                                // the chunk before is done with the lines and s_task
+    if (threadIdx.x == 0) s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int task_ = __builtin_amdgcn_readfirstlane(s_task);      // wave-uniform: what follows from it lives in scalar registers
+    if (task_ >= ntasks) break;
+    const int sub = tasks[task_].x, cc = tasks[task_].y;
+    const int ybA = chunk_start(ch, cc), ybB = chunk_start(ch, cc + 1);
     const zscal z = sc[sub];
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int g = 0; g < P::G; g++) tot += fs_partial[(size_t)sub * P::G + g];
-        s_fs = (float)(tot / ((double)P::L * (double)P::L));
-        s_ibeta = 1.0f / vs_scale<P>(fs_partial, nsub, sub, z);
-    }
+    const sub_scal ss = sub_sc[sub];
     const float sn2 = z.sn * z.sn, sr2 = z.sr * z.sr, fn2 = z.fn * z.fn, fr2 = z.fr * z.fr;
     const float fD = z.fr * z.fn / sqrtf(sn2 * fr2 + sr2 * fn2);
+    const float dx2 = z.dx * z.dx, dy2 = z.dy * z.dy;
     const int sy = sub / o.nsx, sx = sub - sy * o.nsx;
-    // (D, V_S): D goes out at once, V_S waits in registers (the same thread takes the same pixels below)
     constexpr int KX = (P::L + P::FIN_THREADS - 1) / P::FIN_THREADS;   // pixels of a row per thread: x = border + t + k T
-    float vsr[P::NL][KX];
-#ifndef Z3_NO_PREFETCH
-    // all of this workgroup's global loads go out now; the second pair waits in registers behind the first transform
+    // the chunk's first block: both pairs and the row above it go out now
     u_regs<P, P::FIN_THREADS> ra, rb;
-    fetch_u_pair<P, P::FIN_THREADS>(UD, UVS, sub, yb, ra);
-    fetch_u_pair<P, P::FIN_THREADS>(USn, USr, sub, yb, rb);
+    fetch_u_pair<P, P::FIN_THREADS>(UD, UVS, sub, ybA, ra);
+    fetch_u_pair<P, P::FIN_THREADS>(USn, USr, sub, ybA, rb);
     static_assert(P::H <= 2 * P::FIN_THREADS, "halo line: two entries per thread");
     float2 ha[2], hb[2];
     {
-        const size_t hbase = ((size_t)sub * P::LB + (yb ? yb - 1 : P::LB - 1)) * P::HP;
+        const size_t hbase = ((size_t)sub * ch.nch + cc) * P::HP;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int kx = (int)threadIdx.x + i * P::FIN_THREADS;
             if (kx < P::H) { ha[i] = HSn[hbase + kx]; hb[i] = HSr[hbase + kx]; }
         }
     }
-    pack_u_pair<P, P::FIN_THREADS>(ra, yb, s, aux.pp);
-#else
-    load_u_pair<P>(UD, UVS, sub, yb, s, aux.pp);
-#endif
-    __syncthreads();
-    fft_inv<P>(s, tw);
-    const float ibeta = s_ibeta, ifs = 1.0f / s_fs, ifD = inv_n2 / fD, vscale = inv_n2 * ibeta;
-#pragma unroll
-    for (int l = 0; l < P::NL; l++) {
-        const int y = y0 + l, Y = sy * o.size + (y - o.border);
-        const bool rowok = y >= o.border && y < o.border + o.size && Y < o.ny;
-#pragma unroll
-        for (int k = 0; k < KX; k++) {
-            const int xi = (int)threadIdx.x + k * P::FIN_THREADS, Xf = sx * o.size + xi;
-            vsr[l][k] = 0.f;
-            if (xi < o.size) {
-                const float2 v = s[l * P::LS + npos(o.border + xi)];
-                vsr[l][k] = v.y * vscale;
-                if (rowok && Xf < o.nx) o.D[(size_t)Y * o.nx + Xf] = v.x * ifD;
-            }
-        }
-    }
-    __syncthreads();
-    // (Sn, Sr): the block's rows + the row above it (row L - 1 above row 0: np.roll)
-#ifndef Z3_NO_PREFETCH
-    pack_u_pair<P, P::FIN_THREADS>(rb, yb, s, aux.pp);
+    __syncthreads();                                                // tables and scalars
+    ZSTAMP(5, 1);
+    // the row above the chunk (spectrum order) waits in the fifth line: the first (D, V_S) transform leaves it alone
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int kx = (int)threadIdx.x + i * P::FIN_THREADS;
         if (kx < P::H) pack_store<P>(hline, aux.pp, kx, ha[i], hb[i]);
     }
-#else
-    load_u_pair<P>(USn, USr, sub, yb, s, aux.pp);
-    load_halo_pair<P>(HSn, HSr, sub, yb ? yb - 1 : P::LB - 1, hline, aux.pp);
-#endif
-    __syncthreads();
-    fft_inv<P, P::NL + 1>(s, tw);
-    const float dx2 = z.dx * z.dx, dy2 = z.dy * z.dy;
+    const float ifs = 1.0f / ss.fs, ifD = inv_n2 / fD, vscale = inv_n2 * ss.ibeta;
+    for (int yb = ybA; yb < ybB; yb++) {
+        const int y0 = yb * P::NL;
+        const bool first = yb == ybA, more = yb + 1 < ybB;
+        // (D, V_S): D goes out at once, V_S waits in registers (the same thread takes the same pixels below)
+        float vsr[P::NL][KX];
+        // (the thread index goes through an empty asm in every phase: the offsets of each phase are worked out again instead of
+        // living in registers across the whole loop -- with them the kernel spills)
+        pack_u_pair<P, P::FIN_THREADS>(ra, yb, s, aux.pp, opaque_tid());
+        __syncthreads();
+        fft_inv<P>(s, tw);
+        if (more) fetch_u_pair<P, P::FIN_THREADS>(UD, UVS, sub, yb + 1, ra, opaque_tid());         // on its way behind the rest of this block
+        const int td = opaque_tid();
 #pragma unroll
-    for (int l = 0; l < P::NL; l++) {
-        const int y = y0 + l, Y = sy * o.size + (y - o.border);
-        if (!(y >= o.border && y < o.border + o.size && Y < o.ny)) continue;
-        const float2* line = s + l * P::LS;
-        const float2* upline = l ? line - P::LS : hline;
+        for (int l = 0; l < P::NL; l++) {
+            const int y = y0 + l, Y = sy * o.size + (y - o.border);
+            const bool rowok = y >= o.border && y < o.border + o.size && Y < o.ny;
 #pragma unroll
-        for (int k = 0; k < KX; k++) {
-            const int xi = (int)threadIdx.x + k * P::FIN_THREADS, Xf = sx * o.size + xi, xx = o.border + xi;
-            if (xi >= o.size || Xf >= o.nx) continue;
-            const float2 c = cscale(line[npos(xx)], inv_n2);                              // (Sn, Sr) here
-            const float2 up = cscale(upline[npos(xx)], inv_n2), lf = cscale(line[npos(xx == 0 ? P::L - 1 : xx - 1)], inv_n2);
-            const float sval = c.x - c.y;                                                  // S = Sn - Sr
-            const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
-            const float vast = dx2 * (dSndx * dSndx + dSrdx * dSrdx) + dy2 * (dSndy * dSndy + dSrdy * dSrdy);
-            const float vs = vsr[l][k];
-            const size_t q = (size_t)Y * o.nx + Xf;
-            if (o.S) o.S[q] = sval;
+            for (int k = 0; k < KX; k++) {
+                const int xi = td + k * P::FIN_THREADS, Xf = sx * o.size + xi;
+                vsr[l][k] = 0.f;
+                if (xi < o.size) {
+                    const float2 v = s[l * P::LS + npos(o.border + xi)];
+                    vsr[l][k] = v.y * vscale;
+                    if (rowok && Xf < o.nx) o.D[(size_t)Y * o.nx + Xf] = v.x * ifD;
+                }
+            }
+        }
+        __syncthreads();
+        // (Sn, Sr): the block's rows; the row above them is in hline already (real space) unless this is the chunk's first block
+        pack_u_pair<P, P::FIN_THREADS>(rb, yb, s, aux.pp, opaque_tid());
+        __syncthreads();
+        if (first) fft_inv<P, P::NL + 1>(s, tw); else fft_inv<P>(s, tw);
+        if (more) fetch_u_pair<P, P::FIN_THREADS>(USn, USr, sub, yb + 1, rb, opaque_tid());
+        const int tf = opaque_tid();
+#pragma unroll
+        for (int l = 0; l < P::NL; l++) {
+            const int y = y0 + l, Y = sy * o.size + (y - o.border);
+            if (!(y >= o.border && y < o.border + o.size && Y < o.ny)) continue;
+            const float2* line = s + l * P::LS;
+            const float2* upline = l ? line - P::LS : hline;
+#pragma unroll
+            for (int k = 0; k < KX; k++) {
+                const int xi = tf + k * P::FIN_THREADS, Xf = sx * o.size + xi, xx = o.border + xi;
+                if (xi >= o.size || Xf >= o.nx) continue;
+                const float2 c = cscale(line[npos(xx)], inv_n2);                              // (Sn, Sr) here
+                const float2 up = cscale(upline[npos(xx)], inv_n2), lf = cscale(line[npos(xx == 0 ? P::L - 1 : xx - 1)], inv_n2);
+                const float sval = c.x - c.y;                                                  // S = Sn - Sr
+                const float dSndy = c.x - up.x, dSndx = c.x - lf.x, dSrdy = c.y - up.y, dSrdx = c.y - lf.y;
+                const float vast = dx2 * (dSndx * dSndx + dSrdx * dSrdx) + dy2 * (dSndy * dSndy + dSrdy * dSrdy);
+                const float vs = vsr[l][k];
+                const size_t q = (size_t)Y * o.nx + Xf;
+                if (o.S) o.S[q] = sval;
 #ifndef Z3_EXACT_SQRT
-            // v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded division and square roots (~30 instructions per
-            // pixel: 8 % of this kernel); the transforms in front are good to ~1e-6 of the image scale
-            const float scv = sval * __builtin_amdgcn_rsqf(vs + vast);
-            o.Scorr[q] = scv;
-            o.Fpsf[q] = sval * ifs;
-            o.Fpsferr[q] = __builtin_amdgcn_sqrtf(fmaxf(vs, 0.f)) * ifs;
+                // v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded division and square roots (~30 instructions per
+                // pixel: 8 % of this kernel); the transforms in front are good to ~1e-6 of the image scale
+                const float scv = sval * __builtin_amdgcn_rsqf(vs + vast);
+                o.Scorr[q] = scv;
+                o.Fpsf[q] = sval * ifs;
+                o.Fpsferr[q] = __builtin_amdgcn_sqrtf(fmaxf(vs, 0.f)) * ifs;
 #else
-            const float scv = sval / sqrtf(vs + vast);
-            o.Scorr[q] = scv;
-            o.Fpsf[q] = sval * ifs;
-            o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) * ifs;
+                const float scv = sval / sqrtf(vs + vast);
+                o.Scorr[q] = scv;
+                o.Fpsf[q] = sval * ifs;
+                o.Fpsferr[q] = sqrtf(fmaxf(vs, 0.f)) * ifs;
 #endif
-            // transient candidates (bbx_zogy_candidates): the pixels bbx_find_peaks would collect in a pass of its own over
-            // the Scorr frame.  They are rare (a few thousand per frame): one reservation per wave that holds any.
-            if (cand_thr > 0.f) {
-                const bool hit = fabsf(scv) >= cand_thr;             // NaN compares false
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
-                if (hm) {
-                    const int leader = (int)__builtin_ctzll(hm);
-                    unsigned base = 0;
-                    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd((unsigned*)cand_cnt, (unsigned)__popcll(hm));
-                    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-                    if (hit) {
-                        const unsigned k = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                        if (k < cand_cap) cand_list[k] = (uint32_t)q; else atomicOr(d_err, BBX_DERR_LIST_OVERFLOW);
+                // transient candidates (bbx_zogy_candidates): the pixels bbx_find_peaks would collect in a pass of its own over
+                // the Scorr frame.  They are rare (a few thousand per frame): one reservation per wave that holds any.
+                if (cand_thr > 0.f) {
+                    const bool hit = fabsf(scv) >= cand_thr;             // NaN compares false
+                    const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                    if (hm) {
+                        const int leader = (int)__builtin_ctzll(hm);
+                        unsigned base = 0;
+                        if ((tf & 63) == leader) base = atomicAdd((unsigned*)cand_cnt, (unsigned)__popcll(hm));
+                        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                        if (hit) {
+                            const unsigned k2 = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                            if (k2 < cand_cap) cand_list[k2] = (uint32_t)q; else atomicOr(d_err, BBX_DERR_LIST_OVERFLOW);
+                        }
                     }
                 }
             }
         }
+        if (more) {
+            // the block's last row is the row above the next block
+            __syncthreads();
+            const float2* last = s + (P::NL - 1) * P::LS;
+            for (int e = opaque_tid(); e < P::LP; e += P::FIN_THREADS) hline[e] = last[e];
+            __syncthreads();
+        }
     }
+    }
+    ZSTAMP(5, 8);
 }
 
 // ---- host side --------------------------------------------------------------------------------
+}  // namespace z3
+// Chunks of the final kernel: every sub-image's nyb row blocks are cut the same way into runs of decreasing length (guided
+// schedule: a round of nslots / nsub chunks per sub-image takes two thirds of what is left, down to 2 blocks), and the tasks
+// (sub-image, chunk) are listed longest first: the first round fills every workgroup slot, the short ones at the end even
+// out the workgroups' different speeds.  Built once per geometry, kept with the context's twiddle table.
+struct zogy_chunk_plan { int key[4]; int nch, ntasks; int* d_start; int2* d_tasks; };
+static int chunk_plan(bbx_ctx* ctx, zogy_chunk_plan* pl, int yb0, int nyb, int nsub, int nslots) {
+    if (pl->d_start && pl->key[0] == yb0 && pl->key[1] == nyb && pl->key[2] == nsub && pl->key[3] == nslots) return BBX_OK;
+    int per = nslots / nsub; if (per < 1) per = 1;
+    int* len = (int*)malloc((size_t)(nyb + 1) * sizeof(int));
+    if (!len) return BBX_ERR_NOMEM;
+    int nch = 0, rem = nyb;
+    while (rem > 0) {
+        int sz = (2 * rem) / (3 * per); if (sz < 2) sz = 2;
+        for (int i = 0; i < per && rem > 0; i++) { const int l = sz < rem ? sz : rem; len[nch++] = l; rem -= l; }
+    }
+    int* start = (int*)malloc((size_t)(nch + 1) * sizeof(int));
+    int2* tasks = (int2*)malloc((size_t)nch * nsub * sizeof(int2));
+    if (!start || !tasks) { free(len); free(start); free(tasks); return BBX_ERR_NOMEM; }
+    start[0] = yb0;
+    for (int c = 0; c < nch; c++) start[c + 1] = start[c] + len[c];
+    int nt = 0;
+    for (int c = 0; c < nch; c++)                                   // len[] is non-increasing: chunk-major = longest first
+        for (int sub = 0; sub < nsub; sub++) tasks[nt++] = make_int2(sub, c);
+    if (pl->d_start) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_start); (void)hipFree(pl->d_tasks); pl->d_start = nullptr; pl->d_tasks = nullptr; }
+    hipError_t e = hipMalloc((void**)&pl->d_start, (size_t)(nch + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&pl->d_tasks, (size_t)nt * sizeof(int2));
+    if (e == hipSuccess) e = hipMemcpy(pl->d_start, start, (size_t)(nch + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d_tasks, tasks, (size_t)nt * sizeof(int2), hipMemcpyHostToDevice);
+    free(len); free(start); free(tasks);
+    if (e != hipSuccess) return bbx_hip_fail(ctx, e, "chunk plan", __LINE__);
+    pl->key[0] = yb0; pl->key[1] = nyb; pl->key[2] = nsub; pl->key[3] = nslots; pl->nch = nch; pl->ntasks = nt;
+    return BBX_OK;
+}
+namespace z3 {
 template <class P>
-static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
                const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
                float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
     const int nsy = ny / size, nsx = nx / size, nsub = nsy * nsx;
     int rc;
-    const size_t unit = (size_t)nsub * P::UNIT, hunit = (size_t)nsub * P::LB * P::HP;
-    // 4 T + 4 U + 4 C arrays + sqrt(den) (float: half an array, rounded up to one) + 2 halo arrays + scalars + partial sums
-    const size_t bytes = (13 * unit + 2 * hunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 5 * (size_t)nsub * P::G * sizeof(double) + 4096;
+    // chunks of the final kernel (chunk_plan; cached with the twiddle table)
+    const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL, nyb = yb1 - yb0 + 1;
+    const int nslots = 2 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
+    rc = chunk_plan(ctx, plan, yb0, nyb, nsub, nslots); if (rc) return rc;
+    const int nch = plan->nch;
+    const z3::chunk_args ch{plan->d_start, nch};
+    const size_t unit = (size_t)nsub * P::UNIT, hunit = (size_t)nsub * nch * P::HP;
+    // 4 T + 4 U arrays + the PSF spectra (Pn^, Pr^) as float4 (two arrays) + 2 row-transformed k^2 arrays + 2 halo arrays +
+    // the row DFTs of the stamps + scalars + partial sums
+    constexpr int NARR = 12;
+    const size_t qunit = 2 * (size_t)nsub * S * P::HP;
+    const size_t bytes = (NARR * unit + 2 * hunit + qunit) * sizeof(float2) + (size_t)nsub * sizeof(zscal) + 5 * (size_t)nsub * P::G * sizeof(double) + (size_t)nsub * sizeof(z3::sub_scal) + 4096;
     char* ws = (char*)bbx_ws(ctx, WS_CAND, bytes, &rc); if (rc) return rc;
-    float2* arr[13]; for (int i = 0; i < 13; i++) arr[i] = (float2*)ws + (size_t)i * unit;
-    float2 *HSn = (float2*)ws + 13 * unit, *HSr = HSn + hunit;
-    char* p = ws + (13 * unit + 2 * hunit) * sizeof(float2);
+    float2* arr[NARR]; for (int i = 0; i < NARR; i++) arr[i] = (float2*)ws + (size_t)i * unit;
+    float2 *HSn = (float2*)ws + NARR * unit, *HSr = HSn + hunit, *Qdft = HSr + hunit;
+    char* p = ws + (NARR * unit + 2 * hunit + qunit) * sizeof(float2);
     zscal* d_sc = (zscal*)p; p += (size_t)nsub * sizeof(zscal);
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-    double* fs_partial = (double*)p;
+    double* fs_partial = (double*)p; p += 5 * (size_t)nsub * P::G * sizeof(double);
+    sub_scal* sub_sc = (sub_scal*)p;
     float2 *T0 = arr[0], *T1 = arr[1], *T2 = arr[2], *T3 = arr[3], *U0 = arr[4], *U1 = arr[5], *U2 = arr[6], *U3 = arr[7];
-    float2 *cA = arr[8], *cB = arr[9], *cK2n = arr[11], *cK2r = arr[12];
-    float* cSd = (float*)arr[10];
+    float4* cP = (float4*)arr[8];                            // arr[8], arr[9]
+    float2 *cK2n = arr[10], *cK2r = arr[11];
     BBX_HIP(hipMemcpyAsync(d_sc, h_scal, (size_t)nsub * sizeof(zscal), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
 #ifndef Z3_LDS_PAD
 #define Z3_LDS_PAD 0           // experiments: extra dynamic LDS per workgroup (forces one workgroup per CU)
@@ -1071,11 +1268,11 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
     }
     const bool win = 2 * wh < P::L;
     const int wb = win ? wh / P::NL : 0, nyb_psf = win ? 2 * wb : P::LB;
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, d_psf_n, d_psf_r, S, d_sc, tw, cA, cB, cSd, U0, U1, fs_partial, nsub,
-                     wh);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_rowdft<P>, dim3((P::H + 255) / 256, (S + ZQ_J - 1) / ZQ_J, 2 * nsub), dim3(256), 0, s, d_psf_n, d_psf_r, S, tw, Qdft, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, Qdft, S, d_sc, tw, cP, U0, U1, fs_partial, nsub, wh);
     float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_ROWS, k_psf_rows<P>, grid8(nyb_psf, nsub), dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub,
-                     nyb_psf, wb);
+                     nyb_psf, wb, d_sc, fs_partial, sub_sc, ctx->d_err);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
 #ifndef Z3_ROWS_SPLIT
@@ -1089,12 +1286,11 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
         fa.sa = d_sig_new; fa.sb = d_sig_ref;
         BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T2, T3, nsub);
     }
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cA, cB, cSd, tw, U0, U1, U2, HSn, HSr, nsub);      // D, Sn, Sr
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, d_sc, fs_partial, nsub, wh, ctx->d_err);            // V_S
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_COLS, k_img_cols<P>, gcol, blk, lds, s, T0, T1, cP, d_sc, tw, U0, U1, U2, HSn, HSr, nsub, ch);      // D, Sn, Sr
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_VAR_COLS, k_var_cols<P>, gcol, dim3(P::VAR_THREADS), lds, s, T2, T3, TK2n, TK2r, tw, U3, sub_sc, nsub, wh, &ctx->d_counters[CNT_TICKET]);            // V_S
     out_args oa; oa.D = d_D; oa.S = d_S; oa.Scorr = d_Scorr; oa.Fpsf = d_Fpsf; oa.Fpsferr = d_Fpsferr;
     oa.ny = ny; oa.nx = nx; oa.size = size; oa.border = border; oa.nsx = nsx; oa.vec4 = 0;
-    const int yb0 = border / P::NL, yb1 = (border + size - 1) / P::NL;
-    const dim3 gfin = grid8(yb1 - yb0 + 1, nsub);
+    const dim3 gfin = grid8(plan->ntasks < nslots ? plan->ntasks : nslots, 1);
     // transient candidates on request (bbx_zogy_candidates): listed by the kernel that writes Scorr
     float cand_thr = 0.f; uint32_t* cand_list = nullptr; uint32_t cand_cap = 0;
     int32_t* cand_cnt = &ctx->d_counters[CNT_ZCAND];
@@ -1105,8 +1301,9 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
         BBX_HIP(hipMemsetAsync(cand_cnt, 0, sizeof(int32_t), s));
         cand_thr = ctx->zcand_thr;
     }
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_ZOGY_FINAL, k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, fs_partial,
-                     inv_n2, tw, oa, yb0, yb1 - yb0 + 1, nsub, cand_thr, cand_list, cand_cnt, cand_cap, ctx->d_err);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_ZOGY_FINAL, k_final_rows<P>, gfin, dim3(P::FIN_THREADS), lds_fin, s, U0, U3, U1, U2, HSn, HSr, d_sc, sub_sc,
+                     inv_n2, tw, oa, ch, plan->d_tasks, plan->ntasks, &ctx->d_counters[CNT_TICKET], nsub, cand_thr, cand_list, cand_cnt, cand_cap,
+                     ctx->d_err);
     if (cand_thr > 0.f) { ctx->zcand_img = d_Scorr; ctx->zcand_thr_used = cand_thr; ctx->zcand_npix = (size_t)ny * nx; }
     BBX_LAUNCH_CHECK();
     return BBX_OK;
@@ -1116,10 +1313,10 @@ static int run(bbx_ctx* ctx, const float2* d_tw, int ny, int nx, int size, int b
 
 int bbx_zogy3_supported(int L) { return (L == 1400 || L == 140 || L == 128 || L == 100 || L == 64) ? 1 : 0; }
 
-int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, int L, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+static int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int L, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
                   const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
                   float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
-#define Z3_RUN(...) return z3::run<z3::Plan<__VA_ARGS__>>(ctx, d_tw, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, \
+#define Z3_RUN(...) return z3::run<z3::Plan<__VA_ARGS__>>(ctx, d_tw, plan, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, \
                                                           h_scal, d_D, d_S, d_Scorr, d_Fpsf, d_Fpsferr, s)
     switch (L) {
         case 1400: Z3_RUN(Z3_PLAN1400);
@@ -1132,15 +1329,25 @@ int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, int L, int ny, int nx, int s
 }
 
 // ---- entry points (include/bbx.h) ------------------------------------------------------------------------------------
-struct zogy_tw_state { float2* d_tw; int L; };
+struct zogy_tw_state { float2* d_tw; int L; zogy_chunk_plan plan; };
 
 void bbx_zogy2_release(bbx_ctx* ctx) {          // (name kept: bbx_ctx_destroy calls it) frees the context's twiddle table
     if (!ctx || !ctx->zogy2_state) return;
     zogy_tw_state* st = (zogy_tw_state*)ctx->zogy2_state;
     if (st->d_tw) (void)hipFree(st->d_tw);
+    if (st->plan.d_start) (void)hipFree(st->plan.d_start);
+    if (st->plan.d_tasks) (void)hipFree(st->plan.d_tasks);
     free(st);
     ctx->zogy2_state = nullptr;
 }
+
+#ifdef Z3_STAMPS
+// diagnostic builds: buf = device buffer of 6 * Z3_STAMP_WGS * 16 uint64 (or NULL: stamps off)
+extern "C" int bbx_z3_stamps(void* buf) {
+    unsigned long long* p = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(z3::g_z3_stamps), &p, sizeof(p)) == hipSuccess ? BBX_OK : BBX_ERR_HIP;
+}
+#endif
 
 extern "C" int bbx_zogy_frame_supported(int L) { return bbx_zogy3_supported(L); }
 
@@ -1181,6 +1388,6 @@ extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border
         if (e != hipSuccess) return bbx_hip_fail(ctx, e, "twiddle table", __LINE__);
         st->L = L;
     }
-    return bbx_zogy3_run(ctx, st->d_tw, L, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, h_scal, d_D, d_S,
+    return bbx_zogy3_run(ctx, st->d_tw, &st->plan, L, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, h_scal, d_D, d_S,
                          d_Scorr, d_Fpsf, d_Fpsferr, s);
 }

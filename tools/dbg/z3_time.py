@@ -15,7 +15,8 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 new = (20 * torch.randn(ny, nx, device=dev, generator=g)).contiguous()
 ref = (8 * torch.randn(ny, nx, device=dev, generator=g)).contiguous()
 sn = torch.full((ny, nx), 20.0, device=dev); sr = torch.full((ny, nx), 8.0, device=dev)
-psf = torch.from_numpy(np.repeat(bench.moffat_stamp(25, 4.0)[None], 64, 0)).to(dev)
+S = int(os.environ.get('S', 49))
+psf = torch.from_numpy(np.repeat(bench.moffat_stamp(S, 4.0)[None], 64, 0)).to(dev)
 scal = np.tile(np.array([[20, 8, 1, 1, 0.03, 0.03]], np.float32), (64, 1))
 for rep in range(2):
     outs = G.run_zogy_frame(ctx, new, ref, sn, sr, psf, psf, scal, 1320, 40)
