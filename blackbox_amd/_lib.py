@@ -28,6 +28,12 @@ class Geom(C.Structure):
                 ('ysize_chan', C.c_int32), ('xsize_chan', C.c_int32)]
 
 
+class SplineImage(C.Structure):
+    """bbx_spline_image (include/bbx.h): a mini image as the B-spline coefficients of its edge-padded patches"""
+    _fields_ = [('d_coef', C.c_void_p), ('nby', C.c_int32), ('nbx', C.c_int32), ('cy', C.c_int32), ('cx', C.c_int32),
+                ('box', C.c_int32), ('npad', C.c_int32)]
+
+
 if not os.path.isfile(LIB_PATH):
     raise ImportError('{} not found: build it with `make` (hipcc, gfx950); the '
                       'reduction has no CPU fallback'.format(LIB_PATH))
@@ -57,6 +63,7 @@ SIGNATURES = {
     'bbx_wait': (_i, [_vp, _vp]),
     'bbx_copy_kernel': (_i, [_vp, _vp, C.c_size_t, _vp]),
     'bbx_event_wait': (_i, [_vp, _i]),
+    'bbx_build_flags': (_i, []),
     'bbx_step_mark': (_i, [_vp, _vp, _vp]),
     'bbx_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'bbx_event_destroy': (None, [_vp]),
@@ -110,6 +117,8 @@ SIGNATURES = {
     'bbx_zogy_frame_supported': (_i, [_i]),
     'bbx_zogy_candidates': (_i, [_vp, _f]),
     'bbx_zogy_frame': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_zogy_frame_mini': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _pf, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bbx_psf_optflux_mini': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_psf_optflux_sigma': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_find_peaks': (_i, [_vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp]),

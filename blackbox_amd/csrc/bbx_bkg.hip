@@ -1043,3 +1043,12 @@ int bbx_zoom_candidates(bbx_ctx* ctx, const float* d_med, double nsigma) {
 }
 
 }  // extern "C"
+
+// bbx_build_flags (bbx_ctx.hip): any timing knock-out of this file compiled in?
+int bbx_build_flags_bkg(void) {
+#if defined(BOXK_NOBR) || defined(BOXK_NOCLASS) || defined(BOXK_NOFAIL) || defined(BOXK_NOSAMP)
+    return 4;
+#else
+    return 0;
+#endif
+}

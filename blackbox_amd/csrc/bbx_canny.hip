@@ -424,3 +424,12 @@ extern "C" int bbx_canny_edge_map(bbx_ctx* ctx, int ny, int nx, const float* d_i
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
+
+// bbx_build_flags (bbx_ctx.hip): this file's timing knock-outs compiled in?
+int bbx_build_flags_canny(void) {
+#ifdef SATV
+    return 8;
+#else
+    return 0;
+#endif
+}

@@ -133,6 +133,7 @@ enum {
 int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line);
 void bbx_zogy2_release(bbx_ctx* ctx);
 int bbx_zogy3_supported(int L);
+int bbx_build_flags_fpack(void); int bbx_build_flags_zogy(void); int bbx_build_flags_bkg(void); int bbx_build_flags_sat(void); int bbx_build_flags_canny(void);
 void bbx_zogy_release(bbx_ctx* ctx);      // bbx_zogy.hip: frees ctx->zogy_state (called by bbx_ctx_destroy)
 void* bbx_ws(bbx_ctx* ctx, int slot, size_t bytes, int* rc);
 

@@ -62,6 +62,7 @@ void bbx_prof_stop(bbx_ctx* ctx, hipStream_t s) {
 extern "C" {
 
 int bbx_version(void) { return 100; }
+int bbx_build_flags(void) { return bbx_build_flags_fpack() | bbx_build_flags_zogy() | bbx_build_flags_bkg() | bbx_build_flags_sat() | bbx_build_flags_canny(); }
 
 int bbx_profile_enable(bbx_ctx* ctx, int on) {
     if (!ctx) return BBX_ERR_ARG;

@@ -1281,3 +1281,12 @@ extern "C" int bbx_funpack_tiles(bbx_ctx* ctx, int ny, int nx, int bytepix, cons
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }
+
+// bbx_build_flags (bbx_ctx.hip): any timing knock-out of this file compiled in?
+int bbx_build_flags_fpack(void) {
+#if defined(FPV_NOB3) || defined(FPV_NOHINT) || defined(FPV_NOMED) || defined(FPV_NOPASS2) || defined(FPV_NOQUANT) || defined(FPV_NOST2) || defined(FPV_SKIP_RETRY) || defined(FPV_STAT)
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -621,3 +621,12 @@ extern "C" int bbx_sat_trails(bbx_ctx* ctx, int ny, int nx, const float* d_data,
     BBX_LAUNCH_CHECK();
     return bbx_count_objects(ctx, ny, nx, d_mask, BBX_MASK_SATELLITE, d_nsats, stream);
 }
+
+// bbx_build_flags (bbx_ctx.hip): the satellite stage's timing knock-outs (this file, bbx_canny.hip) compiled in?
+int bbx_build_flags_sat(void) {
+#ifdef SATV
+    return 8;
+#else
+    return 0;
+#endif
+}

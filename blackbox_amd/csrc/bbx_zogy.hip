@@ -12,6 +12,7 @@
 //           S_n, S_r), F_psf = S / F_S, F_psf_err = sqrt(V_S) / F_S
 // rocFFT transforms are unnormalised: the 1/L^2 of every inverse is folded into the kernels.
 #include "bbx_common.h"
+#include "bbx_spline.h"
 #include <rocfft/rocfft.h>
 #include <stdlib.h>
 #include <mutex>
@@ -262,6 +263,35 @@ __global__ __launch_bounds__(256) void k_psf_optflux(int ny, int nx, const float
     }
 }
 
+// the same with sigma evaluated from its mini image at every stamp pixel (no sigma frame)
+__global__ __launch_bounds__(256) void k_psf_optflux_mini(int ny, int nx, const float* __restrict__ D, bbx_spl sp,
+                                                          const float* __restrict__ psfs, int S, int nsrc,
+                                                          const int32_t* __restrict__ ys, const int32_t* __restrict__ xs,
+                                                          float* __restrict__ flux, float* __restrict__ err) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int h = S / 2;
+    for (int k = wave; k < nsrc; k += nwaves) {
+        double num = 0.0, den = 0.0;
+        for (int t = lane; t < S * S; t += 64) {
+            const int j = t / S, i = t - j * S;
+            const int y = ys[k] + j - h, x = xs[k] + i - h;
+            if (y < 0 || y >= ny || x < 0 || x >= nx) continue;
+            const float sg = bbx_spl_eval(sp, y, x), d = D[(size_t)y * nx + x];
+            const double v = (double)(fmaxf(d, 0.f) + sg * sg);
+            if (!(v > 0.0)) continue;
+            const double p = (double)psfs[((size_t)k * S + j) * S + i];
+            num += p * (double)d / v;
+            den += p * p / v;
+        }
+        num = wave_sum_f64(num); den = wave_sum_f64(den);
+        if (lane == 0) {
+            flux[k] = den > 0.0 ? (float)(num / den) : 0.f;
+            err[k] = den > 0.0 ? (float)(1.0 / sqrt(den)) : 0.f;
+        }
+    }
+}
+
 // variance image of a background-subtracted frame: V = max(data, 0) + bkg_std^2
 __global__ __launch_bounds__(256) void k_variance(size_t n, const float* __restrict__ d, const float* __restrict__ sd, float* v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -375,6 +405,18 @@ int bbx_psf_optflux_sigma(bbx_ctx* ctx, int ny, int nx, const float* d_D, const 
     if (nsrc == 0) return BBX_OK;
     unsigned grid = (unsigned)((nsrc + 3) / 4); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_psf_optflux<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ny, nx, d_D, d_sigma, d_psfs, S, nsrc, d_ys, d_xs, d_flux, d_err);
+    BBX_LAUNCH_CHECK();
+    return BBX_OK;
+}
+
+int bbx_psf_optflux_mini(bbx_ctx* ctx, int ny, int nx, const float* d_D, const bbx_spline_image* sigma, const float* d_psfs, int S, int nsrc,
+                         const int32_t* d_ys, const int32_t* d_xs, float* d_flux, float* d_err, void* stream) {
+    if (!ctx || !d_D || !sigma || !d_psfs || !d_ys || !d_xs || !d_flux || !d_err || S < 1 || nsrc < 0) return BBX_ERR_ARG;
+    bbx_spl sp;
+    const int rc = bbx_spl_make(sigma, ny, nx, &sp); if (rc) return rc;
+    if (nsrc == 0) return BBX_OK;
+    unsigned grid = (unsigned)((nsrc + 3) / 4); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_psf_optflux_mini, dim3(grid), dim3(256), 0, (hipStream_t)stream, ny, nx, d_D, sp, d_psfs, S, nsrc, d_ys, d_xs, d_flux, d_err);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
 }

@@ -16,6 +16,7 @@
 #pragma clang fp contract(fast)      // the transforms are compared within a tolerance, not bit by bit: let mul + add fuse
 #endif
 #include "bbx_fft_gen.h"
+#include "bbx_spline.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -784,10 +785,16 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows(fr
 
 // The same for both pairs in one launch (frames whose groups of four pixels are aligned): the four frames are read once;
 // the variance pair (max(N, 0) + sigma_N^2, max(R, 0) + sigma_R^2) waits in registers behind the first transform.
-template <class P>
+// SPL (round 5, bbx_zogy_frame_mini): the sigma images do not exist as frames -- the kernel reads them off their mini images
+// (bbx_spline.h): the cubics of its NL rows on every box interval of its x range go into LDS while the pixel loads are
+// on their way, a pixel then costs one 16-byte LDS read and three multiply-adds per image instead of 8 bytes from HBM.
+#define ZSPL_NIV 80            // coefficient columns (= box intervals + the padding between two channels' patches) a sub-image's x range may span
+template <class P, bool SPL>
 __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_both(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta,
-                                                                                float2* __restrict__ Tb, float2* __restrict__ Tva, float2* __restrict__ Tvb, int nsub) {
+                                                                                float2* __restrict__ Tb, float2* __restrict__ Tva, float2* __restrict__ Tvb, int nsub,
+                                                                                bbx_spl spn, bbx_spl spr) {
     extern __shared__ float2 s[];
+    __shared__ float4 spoly[SPL ? 2 * P::NL * ZSPL_NIV : 1];
     WG_TASK_ROWS(P::LB, nsub, yb, sub);
     ZSTAMP_HEAD(2);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
@@ -809,7 +816,45 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
                 if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
                     const size_t o = (size_t)Y * f.nx + X;
                     va[i] = *reinterpret_cast<const float4*>(f.a + o); vb[i] = *reinterpret_cast<const float4*>(f.b + o);
-                    pa[i] = *reinterpret_cast<const float4*>(f.sa + o); pb[i] = *reinterpret_cast<const float4*>(f.sb + o);
+                    if (!SPL) { pa[i] = *reinterpret_cast<const float4*>(f.sa + o); pb[i] = *reinterpret_cast<const float4*>(f.sb + o); }
+                }
+            }
+        }
+        if (SPL) {
+            // the sigma maps on this workgroup's rows: cubic of every coefficient column its x range touches
+            int cmn, cmr, r_;
+            const int Xa = X0 > 0 ? X0 : 0;
+            bbx_spl_axis(Xa, spn.pw, spn.rpw, spn.px, spn.npad, spn.nx1, spn.dx, spn.rdx, cmn, r_);
+            bbx_spl_axis(Xa, spr.pw, spr.rpw, spr.px, spr.npad, spr.nx1, spr.dx, spr.rdx, cmr, r_);
+            for (int e = threadIdx.x; e < 2 * P::NL * ZSPL_NIV; e += blockDim.x) {
+                const int m = e / (P::NL * ZSPL_NIV), ll = (e / ZSPL_NIV) % P::NL, iv = e % ZSPL_NIV;
+                const int Y = Y0 + y0 + ll;
+                if (y0 + ll < P::L && Y >= 0 && Y < f.ny) spoly[e] = m ? bbx_spl_poly(spr, Y, cmr + iv) : bbx_spl_poly(spn, Y, cmn + iv);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int e = (int)threadIdx.x + i * P::LIGHT_THREADS;
+                if (e < NV) {
+                    const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
+                    const int Y = Y0 + y0 + ll, X = X0 + x;
+                    if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
+                        // four pixels of one patch (patch widths, X0 multiples of 4): the first pixel's interval and remainder, then steps
+                        int cn, rn, cr, rr;
+                        bbx_spl_axis(X, spn.pw, spn.rpw, spn.px, spn.npad, spn.nx1, spn.dx, spn.rdx, cn, rn);
+                        bbx_spl_axis(X, spr.pw, spr.rpw, spr.px, spr.npad, spr.nx1, spr.dx, spr.rdx, cr, rr);
+                        const float4* pn = spoly + ll * ZSPL_NIV - cmn;
+                        const float4* pr = spoly + (P::NL + ll) * ZSPL_NIV - cmr;
+                        float sgn[4], sgr[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            sgn[k] = bbx_spl_horner(pn[cn], (float)rn * spn.rdx);
+                            sgr[k] = bbx_spl_horner(pr[cr], (float)rr * spr.rdx);
+                            rn += spn.nx1; if (rn >= spn.dx) { rn -= spn.dx; cn++; }
+                            rr += spr.nx1; if (rr >= spr.dx) { rr -= spr.dx; cr++; }
+                        }
+                        pa[i] = make_float4(sgn[0], sgn[1], sgn[2], sgn[3]); pb[i] = make_float4(sgr[0], sgr[1], sgr[2], sgr[3]);
+                    }
                 }
             }
         }
@@ -1210,7 +1255,7 @@ static int chunk_plan(bbx_ctx* ctx, zogy_chunk_plan* pl, int yb0, int nyb, int n
 namespace z3 {
 template <class P>
 static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
-               const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
+               const float* d_sig_new, const float* d_sig_ref, const bbx_spl* spn, const bbx_spl* spr, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
                float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
     const int nsy = ny / size, nsx = nx / size, nsub = nsy * nsx;
     int rc;
@@ -1248,7 +1293,8 @@ static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, 
         BBX_HIP(hipFuncSetAttribute((const void*)k_psf_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_cols_fwd<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows_both<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows_both<P, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBX_HIP(hipFuncSetAttribute((const void*)k_img_rows_both<P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_img_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_var_cols<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         BBX_HIP(hipFuncSetAttribute((const void*)k_final_rows<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
@@ -1275,10 +1321,23 @@ static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, 
                      nyb_psf, wb, d_sc, fs_partial, sub_sc, ctx->d_err);
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
+    if (spn) {
+        // sigma maps read off their mini images: aligned groups of four pixels inside one patch, and every sub-image's x range
+        // within ZSPL_NIV coefficient columns
+        if (!fa.vec4 || spn->pw % 4 || spr->pw % 4) return BBX_ERR_ARG;
+        for (int sx = 0; sx < nsx; sx++) {
+            const int xa = sx * size - border > 0 ? sx * size - border : 0, xb = (sx * size - border + P::L < nx ? sx * size - border + P::L : nx) - 1;
+            for (const bbx_spl* sp : {spn, spr}) {
+                const int ca = (xa / sp->pw) * sp->px + ((xa % sp->pw) * sp->nx1) / sp->dx, cb = (xb / sp->pw) * sp->px + ((xb % sp->pw) * sp->nx1) / sp->dx;
+                if (cb - ca + 1 > ZSPL_NIV) return BBX_ERR_ARG;
+            }
+        }
+        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, (k_img_rows_both<P, true>), grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, T2, T3, nsub, *spn, *spr);
+    } else
 #ifndef Z3_ROWS_SPLIT
     if (fa.vec4) {
         fa.sa = d_sig_new; fa.sb = d_sig_ref;
-        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, k_img_rows_both<P>, grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, T2, T3, nsub);
+        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, (k_img_rows_both<P, false>), grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, T2, T3, nsub, bbx_spl{}, bbx_spl{});
     } else
 #endif
     {
@@ -1314,9 +1373,9 @@ static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, 
 int bbx_zogy3_supported(int L) { return (L == 1400 || L == 140 || L == 128 || L == 100 || L == 64) ? 1 : 0; }
 
 static int bbx_zogy3_run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int L, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
-                  const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
+                  const float* d_sig_new, const float* d_sig_ref, const bbx_spl* spn, const bbx_spl* spr, const float* d_psf_n, const float* d_psf_r, int S, const float* h_scal,
                   float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, hipStream_t s) {
-#define Z3_RUN(...) return z3::run<z3::Plan<__VA_ARGS__>>(ctx, d_tw, plan, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, \
+#define Z3_RUN(...) return z3::run<z3::Plan<__VA_ARGS__>>(ctx, d_tw, plan, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, spn, spr, d_psf_n, d_psf_r, S, \
                                                           h_scal, d_D, d_S, d_Scorr, d_Fpsf, d_Fpsferr, s)
     switch (L) {
         case 1400: Z3_RUN(Z3_PLAN1400);
@@ -1358,15 +1417,20 @@ extern "C" int bbx_zogy_candidates(bbx_ctx* ctx, float thr) {
     return BBX_OK;
 }
 
-extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
-                              const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S,
-                              const float* h_scal, float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr,
-                              void* stream) {
-    if (!ctx || !d_new || !d_ref || !d_sig_new || !d_sig_ref || !d_psf_n || !d_psf_r || !h_scal || !d_D || !d_Scorr || !d_Fpsf || !d_Fpsferr)
-        return BBX_ERR_ARG;
+static int zogy_frame_entry(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+                            const float* d_sig_new, const float* d_sig_ref, const bbx_spline_image* sig_new, const bbx_spline_image* sig_ref,
+                            const float* d_psf_n, const float* d_psf_r, int S,
+                            const float* h_scal, float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr, void* stream) {
+    if (!ctx || !d_new || !d_ref || !d_psf_n || !d_psf_r || !h_scal || !d_D || !d_Scorr || !d_Fpsf || !d_Fpsferr) return BBX_ERR_ARG;
     if (size < 1 || border < 0 || ny < size || nx < size || ny % size || nx % size || S < 1) return BBX_ERR_ARG;
     const int L = size + 2 * border;
     if (!bbx_zogy_frame_supported(L) || S > L || (ny / size) * (nx / size) > 4096) return BBX_ERR_ARG;
+    bbx_spl spn, spr;
+    const bool spl = sig_new != nullptr;
+    if (spl) {
+        int rc = bbx_spl_make(sig_new, ny, nx, &spn); if (rc) return rc;
+        rc = bbx_spl_make(sig_ref, ny, nx, &spr); if (rc) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (!ctx->zogy2_state) {
         ctx->zogy2_state = calloc(1, sizeof(zogy_tw_state));
@@ -1388,6 +1452,34 @@ extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border
         if (e != hipSuccess) return bbx_hip_fail(ctx, e, "twiddle table", __LINE__);
         st->L = L;
     }
-    return bbx_zogy3_run(ctx, st->d_tw, &st->plan, L, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, d_psf_n, d_psf_r, S, h_scal, d_D, d_S,
-                         d_Scorr, d_Fpsf, d_Fpsferr, s);
+    return bbx_zogy3_run(ctx, st->d_tw, &st->plan, L, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, spl ? &spn : nullptr, spl ? &spr : nullptr,
+                         d_psf_n, d_psf_r, S, h_scal, d_D, d_S, d_Scorr, d_Fpsf, d_Fpsferr, s);
+}
+
+extern "C" int bbx_zogy_frame(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+                              const float* d_sig_new, const float* d_sig_ref, const float* d_psf_n, const float* d_psf_r, int S,
+                              const float* h_scal, float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr,
+                              void* stream) {
+    if (!d_sig_new || !d_sig_ref) return BBX_ERR_ARG;
+    return zogy_frame_entry(ctx, ny, nx, size, border, d_new, d_ref, d_sig_new, d_sig_ref, nullptr, nullptr, d_psf_n, d_psf_r, S, h_scal, d_D, d_S, d_Scorr,
+                            d_Fpsf, d_Fpsferr, stream);
+}
+
+extern "C" int bbx_zogy_frame_mini(bbx_ctx* ctx, int ny, int nx, int size, int border, const float* d_new, const float* d_ref,
+                                   const bbx_spline_image* sig_new, const bbx_spline_image* sig_ref, const float* d_psf_n, const float* d_psf_r,
+                                   int S, const float* h_scal, float* d_D, float* d_S, float* d_Scorr, float* d_Fpsf, float* d_Fpsferr,
+                                   void* stream) {
+    if (!sig_new || !sig_ref) return BBX_ERR_ARG;
+    return zogy_frame_entry(ctx, ny, nx, size, border, d_new, d_ref, nullptr, nullptr, sig_new, sig_ref, d_psf_n, d_psf_r, S, h_scal, d_D, d_S, d_Scorr,
+                            d_Fpsf, d_Fpsferr, stream);
+}
+
+// bbx_build_flags (bbx_ctx.hip): any timing / diagnostic switch of this file compiled in?
+int bbx_build_flags_zogy(void) {
+#if defined(Z3_SKIP_FFT) || defined(Z3_STAMPS) || defined(Z3_FFT2X) || defined(Z3_NO_PREFETCH) || defined(Z3_NO_XCD) || defined(Z3_NO_CONTRACT) || defined(Z3_NO_ZSKIP) || \
+    defined(Z3_TWPOW) || defined(Z3_ROWS_SPLIT) || defined(Z3_ROWS_XCD) || defined(Z3_EXACT_SQRT)
+    return 2;
+#else
+    return 0;
+#endif
 }

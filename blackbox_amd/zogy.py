@@ -14,7 +14,7 @@ import torch
 from scipy import ndimage
 
 from . import settings
-from ._lib import lib, check, fetch, push, BBXError as _lib_BBXError
+from ._lib import lib, check, fetch, push, BBXError as _lib_BBXError, SplineImage as _SplineImage
 from .catalogs import format_cat, transient_table         # noqa: F401  (zogy.format_cat)
 
 BBX_ERR_OVERFLOW, BBX_ERR_PSFWIN = -4, -6          # include/bbx.h
@@ -161,6 +161,54 @@ def mini2back(ctx, mini, shape, bkg_boxsize=None, interp_Xchan=True, subtract_fr
     return bkg
 
 
+class MiniImage:
+    """A mini (per-box) image in the form the kernels read it at frame pixels (bbx_zogy_frame_mini, bbx_psf_optflux_mini):
+    the B-spline coefficients of its edge-padded patches on the device + the geometry of zogy.mini2back(mini, shape,
+    bkg_boxsize, interp_Xchan).  The full-frame image is never made; frame() makes it for callers that need one."""
+
+    def __init__(self, ctx, mini, box, interp_Xchan=True):
+        nby, nbx = mini.shape
+        self.channels = None
+        if not interp_Xchan:
+            if nby % settings.ny or nbx % settings.nx:
+                raise ValueError('interp_Xchan=False needs a whole number of boxes per channel: mini image {}x{} over {}x{} channels'
+                                 .format(nby, nbx, settings.ny, settings.nx))
+            self.channels = (nby // settings.ny, nbx // settings.nx)
+        cy, cx = (nby, nbx) if self.channels is None else self.channels
+        if torch.is_tensor(mini) or np.asarray(mini).dtype == np.float32:
+            d_mini = mini if torch.is_tensor(mini) else push(ctx, np.ascontiguousarray(mini))
+            if d_mini.dtype != torch.float32 or not d_mini.is_contiguous():
+                d_mini = d_mini.to(torch.float32).contiguous()
+            self.coef = device_zoom_coefficients(ctx, d_mini, self.channels)
+        else:
+            self.coef = torch.from_numpy(zoom_coefficients(np.asarray(mini), self.channels)).to(ctx.device)
+        self.box, self.shape = int(box), (nby * int(box), nbx * int(box))
+        self.c = _SplineImage(self.coef.data_ptr(), nby, nbx, cy, cx, int(box), NPAD)
+
+    def ref(self):
+        return C.byref(self.c)
+
+    def frame(self, ctx):
+        """the full-frame image (bbx_spline_zoom of the same coefficients)"""
+        nby, nbx = self.c.nby, self.c.nbx
+        d_fy, d_wy, d_fx, d_wx = _device_taps(ctx, nby, nbx, self.box, self.c.cy, self.c.cx)
+        out = torch.empty(self.shape, dtype=torch.float32, device=ctx.device)
+        check(lib.bbx_spline_zoom(ctx.h, self.shape[0], self.shape[1], _p(self.coef), self.coef.shape[0], self.coef.shape[1], _p(d_fy), _p(d_wy),
+                                  _p(d_fx), _p(d_wx), None, _p(out), ctx.stream()), 'bbx_spline_zoom', ctx.h)
+        return out
+
+
+def mini_path_supported(shape, size, border, box, *minis):
+    """can bbx_zogy_frame_mini read these mini images for a frame of this geometry (aligned groups of four pixels)?"""
+    ny, nx = shape
+    if size % 4 or border % 4 or nx % 4 or (size + 2 * border) % 4:
+        return False
+    for m in minis:
+        if m.shape != (ny, nx) or (m.c.cx * m.box) % 4:
+            return False
+    return True
+
+
 # ---- ZOGY ---------------------------------------------------------------------------------
 def cut_subimages(ctx, img, size=None, border=None):
     size = size or settings.subimage_size
@@ -209,13 +257,19 @@ def zogy_frame_outputs(new, want_S=False):
 
 def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, border, want_S=False, outs=None):
     """ZOGY of whole frames (bbx_zogy_frame): background-subtracted frames + sigma images + PSF
-    stamps [nsub, S, S] -> D, S (or None), Scorr, Fpsf, Fpsferr full frames"""
+    stamps [nsub, S, S] -> D, S (or None), Scorr, Fpsf, Fpsferr full frames.  sig_new, sig_ref: frames, or both
+    MiniImage (bbx_zogy_frame_mini: the sigma maps are read off their mini images, no frames exist)"""
     ny, nx = new.shape
     nsub = (ny // size) * (nx // size)
     scal = np.ascontiguousarray(scal, dtype=np.float32)
     assert scal.shape == (nsub, 6) and psf_n.shape[0] == nsub and psf_r.shape[0] == nsub
     S = int(psf_n.shape[1])
     outs = outs or zogy_frame_outputs(new, want_S)
+    if isinstance(sig_new, MiniImage):
+        check(lib.bbx_zogy_frame_mini(ctx.h, ny, nx, int(size), int(border), _p(new), _p(ref), sig_new.ref(), sig_ref.ref(),
+                                      _p(psf_n.contiguous()), _p(psf_r.contiguous()), S, scal.ctypes.data_as(C.POINTER(C.c_float)),
+                                      *[_p(o) for o in outs], ctx.stream()), 'bbx_zogy_frame_mini', ctx.h)
+        return outs
     check(lib.bbx_zogy_frame(ctx.h, ny, nx, int(size), int(border), _p(new), _p(ref), _p(sig_new), _p(sig_ref),
                              _p(psf_n.contiguous()), _p(psf_r.contiguous()), S, scal.ctypes.data_as(C.POINTER(C.c_float)),
                              *[_p(o) for o in outs], ctx.stream()), 'bbx_zogy_frame', ctx.h)
@@ -224,14 +278,18 @@ def run_zogy_frame(ctx, new, ref, sig_new, sig_ref, psf_n, psf_r, scal, size, bo
 
 def psf_optflux(ctx, D, V, psfs, ys, xs, v_is_sigma=False):
     """zogy.get_psfoptflux at integer positions -> (flux, fluxerr) float32 device tensors; with v_is_sigma
-    V is the sigma image of the background-subtracted frame D and the variance max(D, 0) + sigma^2 is
-    formed at the stamp pixels only"""
+    V is the sigma image of the background-subtracted frame D -- a frame, or a MiniImage read at the stamp pixels --
+    and the variance max(D, 0) + sigma^2 is formed at the stamp pixels only"""
     nsrc, S, _ = psfs.shape
     dev = ctx.device
     d_ys, d_xs = push(ctx, np.asarray(ys, np.int32), np.asarray(xs, np.int32))
     flux = torch.empty(nsrc, dtype=torch.float32, device=dev)
     err = torch.empty(nsrc, dtype=torch.float32, device=dev)
     ny, nx = D.shape
+    if isinstance(V, MiniImage):
+        check(lib.bbx_psf_optflux_mini(ctx.h, ny, nx, _p(D), V.ref(), _p(psfs), S, nsrc, _p(d_ys), _p(d_xs), _p(flux), _p(err), ctx.stream()),
+              'bbx_psf_optflux_mini', ctx.h)
+        return flux, err
     fn = lib.bbx_psf_optflux_sigma if v_is_sigma else lib.bbx_psf_optflux
     check(fn(ctx.h, ny, nx, _p(D), _p(V), _p(psfs), S, nsrc, _p(d_ys), _p(d_xs), _p(flux), _p(err), ctx.stream()), 'bbx_psf_optflux', ctx.h)
     return flux, err
@@ -473,7 +531,7 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
                          subimage_size=None, subimage_border=None, bkg_boxsize=None, nsigma=None,
                          ref_is_bkgsub=False, ref_bkg_std_mini=None, ref_grid=None, ref_grid_step=32,
                          cat_extract=False, cat_nsigma=5.0, trans_extract=True, frame_stats=True, max_sources=200000,
-                         zogy_gate=None, ref_bkg_std=None):
+                         zogy_gate=None, ref_bkg_std=None, sigma_frames=False):
     """The numerical core of zogy.optimal_subtraction(new_fits, ref_fits, ...) (call sites
     blackbox.py:2350-2354 new-only, 2460-2465 new + ref) on device tensors: background mesh +
     subtraction, variance images, [remapping of the reference to the new frame's grid],
@@ -485,8 +543,10 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
                       the 2350-2354 branch): then only the background products and the catalogue
       ref_is_bkgsub : the reference is a background-subtracted co-add (buildref product);
                       ref_bkg_std_mini: its `_bkg_std_mini` image (else measured here);
-                      ref_bkg_std: the full-frame sigma image made from it, when the caller keeps it
-                      for many frames of the same field (res['bkg_std_ref'] of an earlier call)
+                      ref_bkg_std: what an earlier call made from it (res['bkg_std_ref']: a MiniImage, or the
+                      full-frame sigma image), when the caller keeps it for many frames of the same field
+      sigma_frames  : True: the two sigma images are made as full frames (rounds 1-4; bbx_zogy_frame) instead of
+                      being read off their mini images inside the kernels (bbx_zogy_frame_mini)
       ref_grid      : projection lattice (coadd.projection_grid) when the reference lives on
                       another pixel grid: it is remapped with the LANCZOS3 kernel (zogy runs SWarp)
       psf_new/ref   : PSF stamps [nsub, S, S] / [S, S] (unit sum) or a PSFEx model dict
@@ -514,7 +574,18 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
         check(lib.bbx_mini_median(ctx.h, mini_std.numel(), _p(mini_std), _p(d_sstd), ctx.stream()), 'bbx_mini_median', ctx.h)
         check(lib.bbx_zoom_candidates(ctx.h, _p(d_sstd), float(cat_nsigma)), 'bbx_zoom_candidates', ctx.h)
     mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=new, subtract_into=work)
-    bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
+    # the sigma image of the new frame: read off its mini image by the kernels that need it (catalogue photometry, the cut
+    # into sub-images) where the geometry allows, a frame otherwise
+    use_mini = frame_path_supported(L) and not sigma_frames
+    bstd = None
+    if use_mini:
+        try:
+            bstd = MiniImage(ctx, mini_std, box, interp_Xchan=False)
+            use_mini = mini_path_supported((ny, nx), size, border, box, bstd)
+        except ValueError:
+            use_mini = False
+    if not use_mini:
+        bstd = mini2back(ctx, mini_std, (ny, nx), bkg_boxsize=box, interp_Xchan=False)
     Vn = None                                                        # variance image: only where a consumer needs it
     res['bkg_mini_new'], sdn = fetch(ctx, mini, mini_std)
     res['bkg_std_mini_new'] = sdn
@@ -562,7 +633,7 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
         peaks = ys
         if ys.size:
             stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
-            f, e = psf_optflux(ctx, work, bstd, stamps, ys, xs, v_is_sigma=True)
+            f, e = psf_optflux(ctx, work, bstd, stamps, ys, xs, v_is_sigma=True)        # (bstd: frame or MiniImage)
             f, e = fetch(ctx, f, e)
         else:
             f = e = np.zeros(0, np.float32)
@@ -601,8 +672,20 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     elif (rny, rnx) != (ny, nx):
         raise ValueError('reference frame of another shape needs ref_grid')
     # co-added reference: no channel structure in its noise -> interpolation across the frame
-    rbstd = ref_bkg_std if (ref_bkg_std is not None and ref_grid is None and tuple(ref_bkg_std.shape) == (ny, nx)) \
-        else mini2back(ctx, sdr, (ny, nx), bkg_boxsize=box, interp_Xchan=True)
+    sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
+    frame_path = frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]
+    if ref_bkg_std is not None and ref_grid is None and tuple(ref_bkg_std.shape) == (ny, nx) and isinstance(ref_bkg_std, MiniImage) == use_mini:
+        rbstd = ref_bkg_std
+    elif use_mini and frame_path:
+        rbstd = MiniImage(ctx, np.asarray(sdr, np.float32), box, interp_Xchan=True)
+        if not mini_path_supported((ny, nx), size, border, box, rbstd):
+            rbstd = rbstd.frame(ctx)
+    else:
+        rbstd = mini2back(ctx, sdr, (ny, nx), bkg_boxsize=box, interp_Xchan=True)
+    if isinstance(bstd, MiniImage) and not (frame_path and isinstance(rbstd, MiniImage)):
+        bstd = res['bkg_std'] = bstd.frame(ctx)                   # the other side needs frames: both as frames
+        if isinstance(rbstd, MiniImage):
+            rbstd = rbstd.frame(ctx)
     res['ref_bkgsub'], res['bkg_std_ref'] = rwork, rbstd
     hdr_t['S-BKGSTDR'] = (float(np.median(sdr)), '[e-] sigma (STD) background reference image')
 
@@ -613,8 +696,6 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     fr = np.broadcast_to(np.asarray(fratio, np.float64), (nsub,))
     scal[:, 2], scal[:, 3] = 1.0, np.where(fr != 0, 1.0 / np.where(fr != 0, fr, 1.0), 1.0)
     scal[:, 4], scal[:, 5] = np.broadcast_to(np.asarray(dx, np.float64), (nsub,)), np.broadcast_to(np.asarray(dy, np.float64), (nsub,))
-    sub_pr = subimage_psfs(ctx, psf_ref, nsy, nsx, size)
-    frame_path = frame_path_supported(L) and sub_pn.shape[1] == sub_pr.shape[1]
     if frame_path:
         # hand-written FFT path: cut, variance images, ZOGY and stitching in one library call
         outs = zogy_frame_outputs(work)                           # allocated on the caller's stream, filled inside the gate

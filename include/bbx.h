@@ -73,6 +73,11 @@ void bbx_ctx_destroy(bbx_ctx *ctx);                      /* synchronises */
 const char *bbx_strerror(int code);
 const char *bbx_last_hip_error(const bbx_ctx *ctx);
 int  bbx_version(void);
+/* Timing experiments compile parts of kernels out of scratch builds of this library (tools/exp: -DFPV_*, -DZ3_SKIP_FFT,
+ * -DBOXK_*, -DSATV, -DZ3_STAMPS ...; such a build computes wrong results by design).  The Makefile defines none of them;
+ * bbx_build_flags() returns 0 for a product build and a bit per family compiled in otherwise (1 fpack, 2 ZOGY, 4 box
+ * statistics, 8 satellite stage), so a harness can refuse a knocked-out library. */
+int  bbx_build_flags(void);
 /* hipStreamSynchronize(stream) + check of the ctx's device-side error flags
  * (list overflow, non-convergence).  Call before trusting host copies. */
 int  bbx_sync(bbx_ctx *ctx, void *stream);
@@ -550,6 +555,27 @@ int bbx_zogy_frame(bbx_ctx *ctx, int ny, int nx, int size, int border, const flo
                    float *d_D, float *d_S, float *d_Scorr, float *d_Fpsf, float *d_Fpsferr,
                    void *stream);
 
+/* bbx_zogy_frame_mini: bbx_zogy_frame with the two sigma images given as their mini images instead of frames.  zogy makes
+ * the full-frame sigma image of each side with mini2back(data_bkg_std_mini, ...) [EXT; call sites buildref.py:2480-2495] only
+ * to form the variance images: here the kernel that cuts the sub-images reads sigma off the B-spline coefficients of the
+ * mini image (bbx_spline_prefilter's output; one patch per channel for the new frame: interp_Xchan False), so the two
+ * frames are never written to HBM nor read back (2 x 4N bytes written, 2 x 4N x (L / size)^2 read per frame of N pixels).
+ * Per pixel the spline is evaluated as a float32 cubic of the float64-folded coefficients: within 3e-7 (relative) of
+ * what bbx_spline_zoom writes (csrc/bbx_spline.h).  Needs frames whose groups of four pixels are aligned (size, border,
+ * nx, channel width multiples of 4; 16-byte aligned pointers), BBX_ERR_ARG otherwise: callers then zoom the mini images
+ * (bbx_spline_zoom) and use bbx_zogy_frame. */
+typedef struct {
+    const double *d_coef;      /* bbx_spline_prefilter output: [(nby / cy) * (cy + 2 npad)][(nbx / cx) * (cx + 2 npad)] */
+    int32_t nby, nbx;          /* mini image shape in boxes; the frame is nby * box by nbx * box pixels */
+    int32_t cy, cx;            /* boxes per patch: (nby, nbx) = one patch, (boxes per channel) = one patch per channel */
+    int32_t box, npad;         /* box size [pix]; padding of every patch in boxes (12 = scipy.ndimage.zoom's) */
+} bbx_spline_image;
+int bbx_zogy_frame_mini(bbx_ctx *ctx, int ny, int nx, int size, int border, const float *d_new,
+                        const float *d_ref, const bbx_spline_image *sig_new, const bbx_spline_image *sig_ref,
+                        const float *d_psf_n, const float *d_psf_r, int S, const float *h_scal,
+                        float *d_D, float *d_S, float *d_Scorr, float *d_Fpsf, float *d_Fpsferr,
+                        void *stream);
+
 /* ---- a17: PSFEx model evaluation [EXT: zogy.get_psf / psfex poly] ----------------------
  * stamp[s][p] = sum_k terms[s][k] * basis[k][p]: terms [nsrc][ncoef] f32 = the polynomial
  * terms x'^i y'^j (i + j <= poldeg, PSFEx order) of each source position, basis
@@ -570,6 +596,10 @@ int bbx_psf_optflux(bbx_ctx *ctx, int ny, int nx, const float *d_D, const float 
 int bbx_psf_optflux_sigma(bbx_ctx *ctx, int ny, int nx, const float *d_D, const float *d_sigma,
                           const float *d_psfs, int S, int nsrc, const int32_t *d_ys,
                           const int32_t *d_xs, float *d_flux, float *d_err, void *stream);
+/* the same with sigma read off its mini image at the stamp pixels (bbx_zogy_frame_mini's companion: no sigma frame exists) */
+int bbx_psf_optflux_mini(bbx_ctx *ctx, int ny, int nx, const float *d_D, const bbx_spline_image *sigma,
+                         const float *d_psfs, int S, int nsrc, const int32_t *d_ys,
+                         const int32_t *d_xs, float *d_flux, float *d_err, void *stream);
 
 /* ---- a17: transient candidates: 8-connected regions of |img| >= thr (|S_corr| >= T-NSIGMA,
  * set_qc.py:387); per region the pixel of largest |value| (first in C order on ties).

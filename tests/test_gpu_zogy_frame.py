@@ -214,3 +214,52 @@ def test_candidates_listed_by_the_final_kernel_equal_the_peak_search_pass(ctx, s
             assert np.array_equal(x, y)
     finally:
         check(lib.bbx_zogy_candidates(ctx.h, 0.0), 'bbx_zogy_candidates')
+
+
+def test_sigma_maps_read_off_their_mini_images(ctx):
+    """bbx_zogy_frame_mini / bbx_psf_optflux_mini: the sigma images of the two sides as mini images (new frame: one patch
+    per channel, interp_Xchan False; reference: one patch) against the same calls on the full-frame images that
+    bbx_spline_zoom makes of the same coefficients -- what rounds 1-4 fed bbx_zogy_frame.  The kernels evaluate the spline
+    as a float32 cubic per box interval: the sigma values agree to 3e-7 (relative), the images that come out of the
+    transforms to 2e-6 of their scale; and the zoom itself against scipy (the oracle's mini2back) as before."""
+    size, border, box, S = 100, 20, 20, 13
+    nsy, nsx = 4, 8
+    ny, nx = nsy * size, nsx * size
+    new, ref, _, _, pn, pr, scal = make(size, border, nsy, nsx, S, 11)
+    rs = np.random.RandomState(5)
+    nby, nbx = ny // box, nx // box
+    yy, xx = np.mgrid[0:nby, 0:nbx]
+    mini_n = (14 + 2 * np.sin(yy / 5.0) * np.cos(xx / 7.0) + 0.3 * rs.random_sample((nby, nbx))
+              + 1.5 * ((yy // (nby // 2)) * 8 + xx // (nbx // 8)) / 16).astype(F)            # steps between the 16 channels
+    mini_r = (6 + np.cos(yy / 6.0 + xx / 9.0) + 0.2 * rs.random_sample((nby, nbx))).astype(F)
+    mn = G.MiniImage(ctx, mini_n, box, interp_Xchan=False)
+    mr = G.MiniImage(ctx, mini_r, box, interp_Xchan=True)
+    assert G.mini_path_supported((ny, nx), size, border, box, mn, mr)
+    sig_n, sig_r = mn.frame(ctx), mr.frame(ctx)
+    np.testing.assert_allclose(sig_n.cpu().numpy(), Z.mini2back(mini_n, (ny, nx), box, channels=(nby // 2, nbx // 8)), rtol=2.4e-7)
+    np.testing.assert_allclose(sig_r.cpu().numpy(), Z.mini2back(mini_r, (ny, nx), box), rtol=2.4e-7)
+    d_new, d_ref, d_pn, d_pr = dev(ctx, new), dev(ctx, ref), dev(ctx, pn), dev(ctx, pr)
+    want = [o.cpu().numpy() for o in G.run_zogy_frame(ctx, d_new, d_ref, sig_n, sig_r, d_pn, d_pr, scal, size, border, want_S=True)]
+    got = [o.cpu().numpy() for o in G.run_zogy_frame(ctx, d_new, d_ref, mn, mr, d_pn, d_pr, scal, size, border, want_S=True)]
+    ctx.sync()
+    for name, g, w in zip(('D', 'S', 'Scorr', 'Fpsf', 'Fpsferr'), got, want):
+        assert np.isfinite(g).all() and np.isfinite(w).all(), name
+        scale = np.abs(w).max()
+        assert np.abs(g - w).max() <= 2e-6 * scale, (name, float(np.abs(g - w).max() / scale))
+    # D does not see the variance images at all: the same transforms of the same pixels (another instantiation of the row
+    # kernel: the compiler contracts a few multiply-adds differently, nothing else)
+    assert np.abs(got[0] - want[0]).max() <= 1e-6 * np.abs(want[0]).max()
+    # the photometry at 300 positions, some at the frame edge (stamps cut) and on channel borders
+    ys = np.concatenate([rs.randint(0, ny, 280), [0, 1, ny - 1, ny // 2, ny // 2 - 1] * 4]).astype(np.int32)
+    xs = np.concatenate([rs.randint(0, nx, 280), [0, nx - 1, 3, size, size - 1] * 4]).astype(np.int32)
+    stamps = dev(ctx, np.stack([moffat(S, 3.0 + 0.01 * (k % 50)) for k in range(ys.size)]))
+    f0, e0 = G.psf_optflux(ctx, d_new, sig_n, stamps, ys, xs, v_is_sigma=True)
+    f1, e1 = G.psf_optflux(ctx, d_new, mn, stamps, ys, xs, v_is_sigma=True)
+    np.testing.assert_allclose(f1.cpu().numpy(), f0.cpu().numpy(), rtol=3e-6, atol=1e-4)
+    np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=1e-6)
+    # a geometry the mini path does not take (groups of four pixels not aligned) is refused, not mis-evaluated
+    bad = G.MiniImage(ctx, mini_r[:, :-1].copy(), box, interp_Xchan=True)
+    assert not G.mini_path_supported((ny, nx), size, border, box, bad)
+    rc = lib.bbx_zogy_frame_mini(ctx.h, ny, nx, size, border, G._p(d_new), G._p(d_ref), bad.ref(), mr.ref(), G._p(d_pn), G._p(d_pr), S,
+                                 scal.ctypes.data_as(C.POINTER(C.c_float)), *[G._p(dev(ctx, w)) for w in want], ctx.stream())
+    assert rc == -1

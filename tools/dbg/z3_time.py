@@ -18,6 +18,11 @@ sn = torch.full((ny, nx), 20.0, device=dev); sr = torch.full((ny, nx), 8.0, devi
 S = int(os.environ.get('S', 49))
 psf = torch.from_numpy(np.repeat(bench.moffat_stamp(S, 4.0)[None], 64, 0)).to(dev)
 scal = np.tile(np.array([[20, 8, 1, 1, 0.03, 0.03]], np.float32), (64, 1))
+if os.environ.get('MINI'):
+    # the sigma maps as mini images (bbx_zogy_frame_mini): new per channel, reference one patch
+    rs = np.random.RandomState(3)
+    sn = G.MiniImage(ctx, (20 + rs.random_sample((176, 176))).astype(np.float32), 60, interp_Xchan=False)
+    sr = G.MiniImage(ctx, (8 + rs.random_sample((176, 176))).astype(np.float32), 60, interp_Xchan=True)
 for rep in range(2):
     outs = G.run_zogy_frame(ctx, new, ref, sn, sr, psf, psf, scal, 1320, 40)
 torch.cuda.synchronize()
@@ -32,5 +37,5 @@ ms = (C.c_double * 13)(); calls = (C.c_int32 * 13)()
 _lib.lib.bbx_profile_read(ctx.h, ms, calls, 13)
 names = {7: 'final_rows', 8: 'psf_cols', 9: 'psf_rows', 10: 'img_rows(x2)', 11: 'img_cols', 12: 'var_cols'}
 per = {names[k]: ms[k] / n for k in names if calls[k]}
-print(os.environ.get('BBX_LIB_PATH', 'product'), 'total %.3f ms |' % (e0.elapsed_time(e1) / n), ' '.join('%s %.3f' % kv for kv in per.items()),
+print(os.environ.get('BBX_LIB_PATH', 'product') + (' MINI' if os.environ.get('MINI') else ''), 'total %.3f ms |' % (e0.elapsed_time(e1) / n), ' '.join('%s %.3f' % kv for kv in per.items()),
       '| Scorr std %.4f' % float(outs[2].std()))
