@@ -567,21 +567,38 @@ class Reducer:
                 out[fn] = None
         if not todo:
             return [out.get(fn) for fn in files]
-        first_raw, first_hdr = self.read_raw(todo[0][0])
+        # the list's geometry from its first readable file (one that is not fails alone, like any other: blackbox.py:948-999)
+        first_raw = None
+        while todo and first_raw is None:
+            try:
+                first_raw, first_hdr = self.read_raw(todo[0][0])
+            except Exception:
+                log.exception('exception was raised while reading %s', todo[0][0])
+                out[todo.pop(0)[0]] = None
+        if not todo:
+            return [out.get(fn) for fn in files]
         geom = R.geometry(first_raw.shape, self.args.ysize_chan, self.args.xsize_chan)
         exptime = R.hval(first_hdr, 'EXPTIME') if 'EXPTIME' in first_hdr else 1.0
         sub = dict(self.sub) if self.sub is not None else None
         os.makedirs(self.args.red_dir, exist_ok=True)
         t0 = time.time()
         live = {}                                                  # idx -> (fn, header, fits_out)
-        stage, written = None, {}
+        stage, written, input_failed = None, {}, set()
         import threading
         all_written = threading.Event()
         kw = {}
+        # threads and frames in flight from the cores this process may use (cgroup quota / affinity mask), like bench.py's
+        # files-to-files run: on the 16 cores of a one-GPU box 6 lanes, 16 frames, 12 writers, 4 readers
+        from blackbox_amd import pipeline as _pl
+        cores = _pl.cpu_budget()
+        lanes = max(2, min(6, cores // 2))
+        depth = max(2, min(16 if cores >= 12 else 8, len(todo)))
+        nwriters = max(2, min(12, cores - 4))
+        nreaders = max(2, min(4, cores // 4))
         if self.args.fpack:
             from blackbox_amd import outstage
             ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
-            stage = outstage.OutputStage(self.ctx.device, ny, nx, nwriters=4)
+            stage = outstage.OutputStage(self.ctx.device, ny, nx, nwriters=nwriters)
 
             def header_hook(f, hdrs):
                 """the frame's scalars are in: complete the headers (bookkeeping, QC flags, subtraction keywords) through
@@ -607,33 +624,50 @@ class Reducer:
                         except OSError:
                             pass
                 written[f.idx] = group.error
-                if len(written) == len(todo):
+                if len(written) + len(input_failed) >= len(todo):
                     all_written.set()
             kw = dict(outstage=stage, out_base=lambda idx, h: todo[idx][1].replace('.fits', ''), on_written=on_written,
                       header_hook=header_hook, stage_limmag=self._limmag_is_flux)
         self._pipe_exptime = exptime
         pipe = FramePipeline(self.ctx, self.tel, geom, mflat=self.mflat, mbias=self.mbias, bpm=self.bpm,
-                             xtalk_coeffs=self.xtalk, exptime=exptime, depth=max(2, min(8, len(todo))), lanes=2,
+                             xtalk_coeffs=self.xtalk, exptime=exptime, depth=depth, lanes=min(lanes, depth),
                              do_finish=True, detect_sats=True, keep_outputs=True, subtract=sub, log=log, **kw)
 
-        def frames():
-            """read + upload a frame when the pipeline asks for the next one"""
-            for idx, (fn, fits_out) in enumerate(todo):
-                d_raw, header = (first_raw, first_hdr) if idx == 0 else self.read_raw(fn)
-                if tuple(d_raw.shape) != (geom.ny_raw, geom.nx_raw):
-                    raise ValueError('frames of different shapes in one --image_list: {} vs {}'.format(
-                        tuple(d_raw.shape), (geom.ny_raw, geom.nx_raw)))
+        from blackbox_amd import instage
+
+        class _Serial:
+            """read + upload a frame when the pipeline asks for the next one (raw frames that are not unsigned 16-bit); a file
+            that cannot be read fails alone (instage.InputError in its place)"""
+
+            def __init__(self_):
+                self_.k = 0
+
+            def __iter__(self_):
+                return self_
+
+            def __next__(self_):
+                idx = self_.k
+                if idx >= len(todo):
+                    raise StopIteration
+                self_.k += 1
+                fn, fits_out = todo[idx]
+                try:
+                    d_raw, header = (first_raw, first_hdr) if idx == 0 else self.read_raw(fn)
+                    if tuple(d_raw.shape) != (geom.ny_raw, geom.nx_raw):
+                        raise ValueError('frames of different shapes in one --image_list: {} vs {}'.format(
+                            tuple(d_raw.shape), (geom.ny_raw, geom.nx_raw)))
+                except Exception as e:
+                    raise instage.InputError(idx, fn, e)
                 live[idx] = (fn, header, fits_out)
-                yield d_raw, header
+                return d_raw, header
 
         # unsigned 16-bit raw frames (plain or fpacked: what the telescopes deliver) come through the input stage: reader
         # threads, one upload per file, the Rice decode on the device, nothing of it on the orchestrating thread
         src = None
         if first_raw.dtype == self.torch.uint16 and len(todo) > 1:
-            from blackbox_amd import instage
             del first_raw
-            src = instage.InputStage(self.ctx, [fn for fn, _ in todo], (geom.ny_raw, geom.nx_raw), nreaders=2,
-                                     nbuf=pipe.depth + 2, ahead=2)
+            src = instage.InputStage(self.ctx, [fn for fn, _ in todo], (geom.ny_raw, geom.nx_raw), nreaders=nreaders,
+                                     nbuf=pipe.depth + 4, ahead=max(2, min(4, nreaders)))
 
             class _Source:
                 """the input stage's frames with the bookkeeping this run keeps per frame"""
@@ -661,8 +695,23 @@ class Reducer:
                 out[fn] = None
             if stage is None:
                 live.pop(idx, None)
+        def on_input_error(idx, e):
+            # this file fails (blackbox.py:948-999: exception logged, None for the file), the list goes on
+            log.error('exception was raised while reading %s: %r', todo[idx][0], e.cause)
+            out[todo[idx][0]] = None
+            input_failed.add(idx)
+            if stage is not None and len(written) + len(input_failed) >= len(todo):
+                all_written.set()
         try:
-            pipe.run(_Source() if src is not None else frames(), on_done=on_done)
+            try:
+                pipe.run(_Source() if src is not None else _Serial(), on_done=on_done, on_input_error=on_input_error)
+            except Exception:
+                # the pipeline itself gave up (not a file's fault): what it finished stands, the rest goes one by one below
+                log.exception('pipelined run failed; the files without products are reduced one by one')
+                for idx, (fn, fits_out) in enumerate(todo):
+                    if fn not in out and idx not in written:
+                        input_failed.add(idx)                        # (no product of the stage will come for it)
+                all_written.set()
             if stage is not None and not all_written.wait(600.0):
                 log.error('output stage: %d of %d frames written', len(written), len(todo))
             for idx, err in written.items():
@@ -675,6 +724,9 @@ class Reducer:
                 stage.close()
             if src is not None:
                 src.close()
+        for fn, _ in todo:
+            if fn not in out:
+                out[fn] = self.reduce_logged(fn)
         return [out.get(fn) for fn in files]
 
     def _finish_from_pipeline(self, f, fn, header, fits_out, t0):
@@ -793,11 +845,7 @@ def main(argv=None):
         return out
     red = Reducer(tel, args)
     if args.image_list and len(mine) > 1:
-        try:
-            out = red.reduce_list(mine)
-        except Exception:
-            log.exception('pipelined run failed; reducing the files one by one')
-            out = [red.reduce_logged(f) for f in mine]
+        out = red.reduce_list(mine)
     else:
         out = [red.reduce_logged(f) for f in mine]
     for o in out:

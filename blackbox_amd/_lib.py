@@ -84,6 +84,7 @@ SIGNATURES = {
     'bbx_fpack_tiles': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'bbx_fpack_gather': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'bbx_fpack_body': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _i, _vp]),
+    'bbx_raw_be16': (_i, [_vp, _vp, C.c_size_t, _vp]),
     'bbx_funpack_tiles': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     'bbx_coadd_prep': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'bbx_resample_lanczos3': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
@@ -141,10 +142,21 @@ WAIT_STATS = [0.0, 0]
 KERNEL_COPY_MAX = int(os.environ.get('BBX_KERNEL_COPY_MAX', str(4 << 20)))    # fetch / push: copies up to this size go by a kernel
 
 
+def _thread_state(ctx):
+    """the calling thread's staging buffers of this context (fetch's pinned buffer, push's pinned ring): a context is driven
+    from several threads -- the caller's and lane 0 of a pipeline share one -- and each moves its own small tensors"""
+    import threading
+    tls = ctx.__dict__.get('_tls')
+    if tls is None:
+        tls = ctx.__dict__.setdefault('_tls', threading.local())
+    return tls.__dict__
+
+
 def push(ctx, *arrays):
-    """numpy arrays -> device tensors without a blocking pageable copy: the values go into the context's pinned upload
-    buffer and a kernel on the current stream reads them from there (stream-ordered; the buffer is a ring: a slice is reused
-    after 64 later pushes at the earliest, long after its kernel has run)"""
+    """numpy arrays -> device tensors without a blocking pageable copy: the values go into the thread's pinned upload
+    buffer and a kernel on the current stream reads them from there (stream-ordered).  The buffer is a ring of 64 slices; a
+    slice carries the event recorded behind the kernel that read it last, and is written again only when that has
+    completed (a caller pushing in a loop on a backed-up stream waits there instead of overwriting an upload in flight)"""
     import numpy as np
     import torch
     outs = []
@@ -160,14 +172,21 @@ def push(ctx, *arrays):
             t.copy_(torch.from_numpy(a))
             outs.append(t)
             continue
-        ring = ctx.__dict__.get('_push_ring')
+        st = _thread_state(ctx)
+        ring = st.get('push_ring')
         if ring is None:
-            ring = ctx.__dict__['_push_ring'] = [torch.empty(64 * (KERNEL_COPY_MAX // 4), dtype=torch.uint8, pin_memory=True), 0]
+            ring = st['push_ring'] = [torch.empty(64 * (KERNEL_COPY_MAX // 4), dtype=torch.uint8, pin_memory=True), 0, [None] * 64]
         slot = ring[1] % 64
         ring[1] += 1
+        ev = ring[2][slot]
+        if ev is not None and not ev.query():
+            wait_event(ev)
         off = slot * (KERNEL_COPY_MAX // 4)
         ring[0].numpy()[off:off + n] = a.reshape(-1).view(np.uint8)
         check(lib.bbx_copy_kernel(C.c_void_p(t.data_ptr()), C.c_void_p(ring[0].data_ptr() + off), n, sp), 'bbx_copy_kernel')
+        if ev is None:
+            ev = ring[2][slot] = torch.cuda.Event()
+        ev.record()                                               # (the current stream: the one the kernel went to)
         outs.append(t)
     return outs if len(outs) > 1 else outs[0]
 
@@ -192,9 +211,10 @@ def fetch(ctx, *tensors):
     ts = [t.contiguous() for t in tensors]
     sizes = [(t.numel() * t.element_size() + 63) // 64 * 64 for t in ts]
     total = max(64, sum(sizes))
-    pin = ctx.__dict__.get('_fetch_pin')
+    st = _thread_state(ctx)
+    pin = st.get('fetch_pin')
     if pin is None or pin.numel() < total:
-        pin = ctx.__dict__['_fetch_pin'] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
+        pin = st['fetch_pin'] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
     views, off = [], 0
     sp = ctx.stream()
     for t, nb in zip(ts, sizes):

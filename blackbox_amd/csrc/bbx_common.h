@@ -73,7 +73,6 @@ struct bbx_ctx {
     const float* bcand_img;    // the frame the list in WS_BCAND belongs to (consumed by bbx_find_peaks), its median scalar and factor
     const float* bcand_img_med; double bcand_img_nsig; size_t bcand_npix;
     int    wait_sleep_us;      // BBX_OPT_WAIT_SLEEP_US: host waits poll an event and sleep this long between polls (0: hipStreamSynchronize)
-    hipEvent_t wait_ev; int32_t* h_err;   // bbx_wait's event, bbx_sync's pinned copy of the error words
     int    cc_roots;           // set by a caller of bbx_cc_count_list that reads the roots afterwards (second k_cc_flatten); cleared by the call
     int    box_pp;             // which of the two CNT_BOXFAIL counters the next bbx_bkg_boxstats call fills
     int    bkg_full_sort;      // BBX_OPT_BKG_FULL_SORT: every box of bbx_bkg_boxstats through the full sort (tests: same statistics as the bracket path)

@@ -143,8 +143,6 @@ void bbx_ctx_destroy(bbx_ctx* ctx) {
     if (ctx->d_satlist) (void)hipFree(ctx->d_satlist);
     if (ctx->d_nonlin) (void)hipFree(ctx->d_nonlin);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
-    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
-    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->prof_ev) { for (int i = 0; i < 2 * BBX_PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]); free(ctx->prof_ev); free(ctx->prof_slot); }
     free(ctx);
@@ -190,20 +188,29 @@ int bbx_event_wait(void* event, int sleep_us) {
     return bbx_poll_event((hipEvent_t)event, sleep_us);
 }
 
+// The state of a host wait belongs to the waiting THREAD, not to the context: several threads wait on one context (a lane
+// thread inside _lib.fetch while the orchestrating thread calls bbx_sync), and a second hipEventRecord on a shared event
+// would let the other thread's poll return before ITS work has finished (round 4 kept one event and one pinned error word
+// per context).  One event per thread and device, one pinned error buffer per thread; both live as long as the thread
+// (a few bytes per pool thread, never freed: HIP may be gone by the time a thread-local destructor runs).
+struct wait_tls { hipEvent_t ev[16]; int32_t* h_err; };
+static thread_local wait_tls g_wait;
+
 int bbx_wait(bbx_ctx* ctx, void* stream) {
     if (!ctx) return BBX_ERR_ARG;
     if (ctx->wait_sleep_us <= 0) { BBX_HIP(hipStreamSynchronize((hipStream_t)stream)); return BBX_OK; }
-    if (!ctx->wait_ev) BBX_HIP(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
-    BBX_HIP(hipEventRecord(ctx->wait_ev, (hipStream_t)stream));
-    const int rc = bbx_poll_event(ctx->wait_ev, ctx->wait_sleep_us);
+    hipEvent_t& ev = g_wait.ev[ctx->device & 15];
+    if (!ev) BBX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    BBX_HIP(hipEventRecord(ev, (hipStream_t)stream));
+    const int rc = bbx_poll_event(ev, ctx->wait_sleep_us);
     if (rc) return bbx_hip_fail(ctx, hipGetLastError(), "hipEventQuery", __LINE__);
     return BBX_OK;
 }
 
 int bbx_sync(bbx_ctx* ctx, void* stream) {
     if (!ctx) return BBX_ERR_ARG;
-    if (!ctx->h_err) BBX_HIP(hipHostMalloc((void**)&ctx->h_err, 4 * sizeof(int32_t), hipHostMallocDefault));
-    int32_t* err = ctx->h_err;
+    if (!g_wait.h_err) BBX_HIP(hipHostMalloc((void**)&g_wait.h_err, 4 * sizeof(int32_t), hipHostMallocDefault));
+    int32_t* err = g_wait.h_err;
     err[0] = 0;
     BBX_HIP(hipMemcpyAsync(err, ctx->d_err, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     { const int rc = bbx_wait(ctx, stream); if (rc) return rc; }

@@ -1282,6 +1282,35 @@ extern "C" int bbx_funpack_tiles(bbx_ctx* ctx, int ny, int nx, int bytepix, cons
     return BBX_OK;
 }
 
+// big-endian int16 + BZERO 32768 (an uncompressed raw frame as it lies in its FITS file) -> uint16: eight pixels per thread where
+// both pointers are 16-byte aligned, else one
+__global__ __launch_bounds__(256) void k_raw_be16(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, size_t n, int vec) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const uint4* in4 = reinterpret_cast<const uint4*>(in); uint4* out4 = reinterpret_cast<uint4*>(out);
+        for (size_t i = t; i < n / 8; i += nt) {
+            uint4 v = in4[i];
+            // per 32-bit word: swap the bytes of each half (v_perm), flip the top bit of each
+            v.x = __builtin_amdgcn_perm(0u, v.x, 0x02030001u) ^ 0x80008000u; v.y = __builtin_amdgcn_perm(0u, v.y, 0x02030001u) ^ 0x80008000u;
+            v.z = __builtin_amdgcn_perm(0u, v.z, 0x02030001u) ^ 0x80008000u; v.w = __builtin_amdgcn_perm(0u, v.w, 0x02030001u) ^ 0x80008000u;
+            out4[i] = v;
+        }
+        for (size_t i = (n / 8) * 8 + t; i < n; i += nt) { const uint16_t x = in[i]; out[i] = (uint16_t)(((x >> 8) | (x << 8)) ^ 0x8000u); }
+    } else {
+        for (size_t i = t; i < n; i += nt) { const uint16_t x = in[i]; out[i] = (uint16_t)(((x >> 8) | (x << 8)) ^ 0x8000u); }
+    }
+}
+extern "C" int bbx_raw_be16(const void* d_file_pixels, uint16_t* d_out, size_t n, void* stream) {
+    if (!d_file_pixels || !d_out || ((uintptr_t)d_file_pixels & 1) || ((uintptr_t)d_out & 1)) return BBX_ERR_ARG;
+    if (n == 0) return BBX_OK;
+    const int vec = (((uintptr_t)d_file_pixels | (uintptr_t)d_out) & 15) == 0;
+    const size_t items = vec ? n / 8 + 1 : n;
+    const unsigned blocks = (unsigned)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_raw_be16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_file_pixels, d_out, n, vec);
+    if (hipGetLastError() != hipSuccess) return BBX_ERR_HIP;
+    return BBX_OK;
+}
+
 // bbx_build_flags (bbx_ctx.hip): any timing knock-out of this file compiled in?
 int bbx_build_flags_fpack(void) {
 #if defined(FPV_NOB3) || defined(FPV_NOHINT) || defined(FPV_NOMED) || defined(FPV_NOPASS2) || defined(FPV_NOQUANT) || defined(FPV_NOST2) || defined(FPV_SKIP_RETRY) || defined(FPV_STAT)

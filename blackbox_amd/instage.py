@@ -26,6 +26,15 @@ from . import fitsio, fpack
 from ._lib import lib, check, wait_event
 
 
+class InputError(Exception):
+    """one file of the list could not be read or decoded (blackbox.py:948-999: the reference fails that file and goes on):
+    raised by the iterator in that file's place; the frames behind it follow as if nothing had happened"""
+
+    def __init__(self, idx, path, cause):
+        Exception.__init__(self, '{}: {!r}'.format(path, cause))
+        self.idx, self.path, self.cause = idx, path, cause
+
+
 class RawFile:
     """what the host needs from a raw frame file: header dict, geometry, where the pixels (or their tile streams) are"""
     __slots__ = ('header', 'ny', 'nx', 'compressed', 'data_off', 'data_len', 'desc', 'heap_off', 'heap_len', 'bitpix', 'bzero', 'bytepix')
@@ -65,16 +74,24 @@ def parse_raw(buf, nbytes):
             lay = fpack._table_layout(h)
             rowlen = shape[1]
             o = lay['COMPRESSED_DATA'][0]
+            if pos + r.ny * rowlen > nbytes:
+                raise EOFError('truncated file: the tile table ends at byte {}, {} bytes read'.format(pos + r.ny * rowlen, nbytes))
             tb = buf[pos:pos + r.ny * rowlen].reshape(r.ny, rowlen)
             r.desc = np.ascontiguousarray(tb[:, o:o + 8]).view('>i4').astype(np.int32)
             r.compressed, r.heap_off, r.heap_len = True, pos + dbytes, pcount
             if (r.desc < 0).any() or int((r.desc[:, 0].astype(np.int64) + r.desc[:, 1]).max(initial=0)) > pcount:
                 raise ValueError('tile descriptors point outside the heap')
+            if r.heap_off + r.heap_len > nbytes:
+                # (a file still being written, a broken transfer: what was read so far parses, its tail would be decoded from
+                # whatever the buffer held before -- astropy raises on such a file, so does this)
+                raise EOFError('truncated file: the heap ends at byte {}, {} bytes read'.format(r.heap_off + r.heap_len, nbytes))
             r.bzero = hv(h, 'BZERO', 0)
             out = r
         elif naxis == 2 and str(hv(h, 'XTENSION', 'IMAGE')).strip() in ('IMAGE',):
             r.ny, r.nx, r.bitpix = shape[0], shape[1], bitpix
             r.compressed, r.data_off, r.data_len = False, pos, dbytes
+            if pos + dbytes > nbytes:
+                raise EOFError('truncated file: the image ends at byte {}, {} bytes read'.format(pos + dbytes, nbytes))
             r.bzero = hv(h, 'BZERO', 0)
             out = r
         nb = dbytes + pcount
@@ -152,7 +169,7 @@ class InputStage:
             self.nfiles = k                                      # the source ended
             raise StopIteration
         if isinstance(item, BaseException):
-            raise item
+            raise InputError(k, self.files[k] if not callable(self.files) else None, item)
         return item
 
     def release(self, raw):
@@ -191,10 +208,11 @@ class InputStage:
             if path is None:
                 self._put(idx, None)
                 return
+            raw = self.pool.get()
+            if raw is None:
+                return
+            queued = False                                        # device work of this frame is on the stream
             try:
-                raw = self.pool.get()
-                if raw is None:
-                    return
                 wait_event(done)                                 # this thread's previous frame has left the staging buffers
                 with open(path, 'rb', buffering=0) as f:
                     n = 0
@@ -210,6 +228,7 @@ class InputStage:
                 if (r.ny, r.nx) != (self.ny, self.nx):
                     raise ValueError('{}: frame of shape {} expected, got {}'.format(path, (self.ny, self.nx), (r.ny, r.nx)))
                 with torch.cuda.stream(stream):
+                    queued = True
                     if r.compressed:
                         if not (r.bitpix == 16 and r.bzero == 32768):
                             raise ValueError('{}: unsigned 16-bit raw frame expected'.format(path))
@@ -228,17 +247,26 @@ class InputStage:
                         a = r.data_off & ~15
                         nb = r.data_off + r.data_len - a
                         staging[:nb].copy_(pinned[a:a + nb], non_blocking=True)
-                        be = staging[r.data_off - a:r.data_off - a + r.data_len].view(torch.int16).view(r.ny, r.nx)
-                        # big-endian int16 + BZERO -> uint16: swap the bytes, flip the sign bit
-                        u = be.view(torch.uint8).view(r.ny, r.nx, 2).flip(2).contiguous().view(torch.int16).view(r.ny, r.nx)
-                        raw.copy_((u.to(torch.int32) + 32768).to(torch.uint16))
+                        # big-endian int16 + BZERO -> uint16: bytes swapped, sign bit flipped, one pass (bbx_raw_be16)
+                        check(lib.bbx_raw_be16(C.c_void_p(staging.data_ptr() + (r.data_off - a)), C.c_void_p(raw.data_ptr()), r.ny * r.nx, sp),
+                              'bbx_raw_be16', self.ctx.h)
                     done.record(stream)
                     ev = torch.cuda.Event()
                     ev.record(stream)
                 self._put(idx, (raw, r.header, ev))
-            except BaseException as e:                            # handed to the consumer in order
+            except BaseException as e:
+                # this file fails, the thread and its buffers live on: whatever was queued for the frame leaves the staging
+                # buffers and the raw buffer first, the raw buffer goes back to the pool, the consumer gets the exception
+                # in the file's place (in order)
+                try:
+                    if queued:
+                        stream.synchronize()
+                except BaseException:
+                    pass
+                self.pool.put(raw)
                 self._put(idx, e)
-                return
+                if not isinstance(e, Exception):                  # KeyboardInterrupt / SystemExit: stop reading
+                    return
 
     def _put(self, idx, item):
         with self.cv:

@@ -752,11 +752,15 @@ class FramePipeline:
         f.state = 'done'
 
     # ---- driver --------------------------------------------------------------------
-    def run(self, frames, on_done=None):
+    def run(self, frames, on_done=None, on_input_error=None):
         """frames: iterable of (raw device tensor, header dict[, ready event]).  Processes all of them with
-        up to [depth] in flight; calls on_done(idx, frame) in completion order."""
-        it = iter(enumerate(frames))
+        up to [depth] in flight; calls on_done(idx, frame) in completion order.
+        on_input_error(idx, exc): a source that fails ONE frame raises instage.InputError in its place and goes on with the
+        next (instage.InputStage does; a generator cannot): the frame's index is skipped, the hook is told, the run goes on
+        (blackbox.py:948-999: the reference fails that file and continues).  Without the hook the error ends the run."""
+        it = iter(frames)
         self._has_next = getattr(frames, 'has_next', None)        # (instage.InputStage: ask before taking a frame)
+        self._on_input_error = on_input_error
         live, ndone, exhausted = [], 0, False
         try:
             return self._run(it, live, ndone, exhausted, on_done)
@@ -795,16 +799,29 @@ class FramePipeline:
         self.free_slots = list(range(self.depth))
 
     def _run(self, it, live, ndone, exhausted, on_done):
+        from .instage import InputError
+        nxt = 0                                                    # index of the next frame of the source (failed ones count)
         while True:
             progressed = False
             while not exhausted and len(live) < self.depth:
                 if self._has_next is not None and not self._has_next():
                     break                                          # the next frame is still being read / decoded
                 try:
-                    idx, item = next(it)
+                    item = next(it)
                 except StopIteration:
                     exhausted = True
                     break
+                except InputError as e:
+                    if self._on_input_error is None:
+                        raise
+                    if self.log is not None:
+                        self.log.error('frame %d: input failed: %s', nxt, e)
+                    self._on_input_error(nxt, e)
+                    nxt += 1
+                    progressed = True
+                    continue
+                idx = nxt
+                nxt += 1
                 raw, header = item[0], item[1]
                 live.append(self._start(idx, raw, header, item[2] if len(item) > 2 else None))
                 progressed = True

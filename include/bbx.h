@@ -116,8 +116,8 @@ int  bbx_sync(bbx_ctx *ctx, void *stream);
 /* BBX_OPT_WAIT_SLEEP_US (default 0): how bbx_sync / bbx_wait wait for the device.  0: the runtime's stream synchronisation
  * (it spins on a core).  n > 0: the host thread polls an event and sleeps n microseconds between polls -- a pipeline with
  * several lane, reader and writer threads per GPU would otherwise burn a core per waiting thread (5.4 cores per GPU measured
- * in round 3); costs up to n us of latency per wait.  (hipDeviceScheduleBlockingSync was tried first: waits never
- * returned on the GPU boxes of this project.) */
+ * in round 3); costs up to n us of latency per wait.  The wait's event and the pinned copy of the error words belong to
+ * the calling thread: any number of threads may wait on one context. */
 #define BBX_OPT_WAIT_SLEEP_US 7
 /* BBX_OPT_BKG_FULL_SORT (default 0): bbx_bkg_boxstats takes the clipped statistics of a box from a sorted bracket around its
  * median and the list of its wing pixels, and sorts only the boxes where that does not hold (ties, constant boxes); 1: every
@@ -373,6 +373,11 @@ int bbx_fpack_body(bbx_ctx *ctx, int ny, int nx, const void *d_img, int bitpix, 
 int bbx_funpack_tiles(bbx_ctx *ctx, int ny, int nx, int bytepix, const int *d_desc,
                       const uint8_t *d_heap, int out_kind, void *d_out, const double *d_zscale,
                       const double *d_zzero, int dither_seed, const float *d_rnd, void *stream);
+
+/* Uncompressed raw frames: FITS stores BITPIX 16 pixels big-endian with BZERO 32768 (read_hdulist, blackbox.py:1451:
+ * astropy scales them on the host).  bbx_raw_be16: n pixels as they lie in the file -> uint16 = byteswap(x) ^ 0x8000 in
+ * one pass on the device (round 4 did this with four frame-sized tensor passes of the host framework). */
+int bbx_raw_be16(const void *d_file_pixels, uint16_t *d_out, size_t n, void *stream);
 
 /* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
  * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1

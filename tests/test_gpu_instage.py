@@ -48,15 +48,36 @@ def test_input_stage_and_pipeline_from_files(tmp_path):
         n += 1
     assert n == nframes and st.bytes_read == sum(os.path.getsize(f) for f in files)
     st.close()
-    # a missing file surfaces at its place in the order
-    st = instage.InputStage(ctx, files[:2] + [str(tmp_path / 'nope.fits.fz')], tuple(raws[0].shape), nreaders=2, nbuf=3, ahead=2)
+    # one bad file fails one file (blackbox.py:948-999): a missing file, an fpacked file cut short (still being written), a frame
+    # of another shape -- each surfaces as instage.InputError at its place in the order, the frames behind it follow, the ONE
+    # reader thread lives on and every raw buffer is back in the pool
+    cut = str(tmp_path / 'cut.fits.fz')
+    whole = open(files[0], 'rb').read()
+    with open(cut, 'wb') as f:
+        f.write(whole[:len(whole) - 4000])
+    other = str(tmp_path / 'other.fits')
+    fitsio.write_image(other, cases[0]['raw'][:-2], {'EXPTIME': 60.0})
+    mixed = [files[0], str(tmp_path / 'nope.fits.fz'), files[1], cut, files[2], other, files[3]]
+    st = instage.InputStage(ctx, mixed, tuple(raws[0].shape), nreaders=1, nbuf=3, ahead=2)
     it = iter(st)
-    for _ in range(2):
-        raw, _, ev = next(it)
+    got, errs = [], []
+    for k in range(len(mixed)):
+        try:
+            raw, _, ev = next(it)
+        except instage.InputError as e:
+            errs.append((k, e.idx, type(e.cause)))
+            continue
         ev.synchronize()
+        got.append((k, raw.clone()))
         st.release(raw)
-    with pytest.raises(OSError):
+    with pytest.raises(StopIteration):
         next(it)
+    assert [k for k, *_ in errs] == [1, 3, 5] and [i for _, i, _ in errs] == [1, 3, 5]
+    assert issubclass(errs[0][2], OSError) and errs[1][2] is EOFError and errs[2][2] is ValueError
+    assert [k for k, _ in got] == [0, 2, 4, 6]
+    for (k, rw), want in zip(got, (raws[0], raws[1], raws[2], raws[3])):
+        assert torch.equal(rw, want), k
+    assert st.pool.qsize() == 3          # (the ONE reader delivered the frames behind every bad file: it lived on; it ends with the list)
     st.close()
     # (ii) the pipeline fed from the files == the pipeline fed from HBM
     flat = torch.from_numpy(cases[0]['flat']).to(dev)
@@ -88,6 +109,28 @@ def test_input_stage_and_pipeline_from_files(tmp_path):
             for key in ('BIASMEAN', 'RDNOISE', 'NCOSMICS', 'NOBJ-SAT'):
                 assert R.hval(a[2], key) == R.hval(b[2], key), (k, key)
             assert R.hval(b[2], 'OBJECT') == 'frame%d' % k                     # the file's header went along
+        # the pipeline on the list with the bad files in it: their indices are skipped (the hook hears of them), the others come
+        # out as from the clean list, nothing is restarted
+        pipe = FramePipeline(ctx, tel, geom, mflat=flat, bpm=bpm, xtalk_coeffs=coeffs, exptime=60.0, pool=pool, depth=3, lanes=2,
+                             do_finish=True, keep_outputs=True)
+        st = instage.InputStage(ctx, mixed, tuple(raws[0].shape), nreaders=2, nbuf=5, ahead=2)
+        res, bad = {}, {}
+
+        def on_done2(idx, f):
+            res[idx] = (f.data.cpu().numpy(), f.mask.cpu().numpy())
+            st.release(f.raw)
+        nd = pipe.run(st, on_done=on_done2, on_input_error=lambda idx, e: bad.__setitem__(idx, e))
+        assert nd == 4 and sorted(res) == [0, 2, 4, 6] and sorted(bad) == [1, 3, 5]
+        for idx, k in ((0, 0), (2, 1), (4, 2), (6, 3)):
+            assert np.array_equal(res[idx][0], out['hbm'][k][0]) and np.array_equal(res[idx][1], out['hbm'][k][1]), idx
+        # without the hook the first bad file ends the run (the old contract), and the pipeline is usable afterwards
+        st2 = instage.InputStage(ctx, mixed[:3], tuple(raws[0].shape), nreaders=2, nbuf=5, ahead=2)
+        with pytest.raises(instage.InputError):
+            pipe.run(st2, on_done=lambda idx, f: st2.release(f.raw))
+        st2.close()
+        assert pipe.run([(raws[0], {})]) == 1
+        pipe.close()
+        st.close()
     finally:
         pool.close()
     ctx.close()

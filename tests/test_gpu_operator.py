@@ -362,3 +362,50 @@ def test_cli_image_list_through_output_stage(tmp_path, ctx, case):
         assert os.path.isfile(b2 + ext), ext
     for k in (1, 2):
         assert os.path.isfile(str(tmp_path / 'lst' / ('ML1_20240102_03040%d_red_Scorr.fits.fz' % k)))
+
+
+def test_cli_image_list_one_bad_file_fails_one_file(tmp_path, ctx, case):
+    """blackbox.py:948-999: an exception while a file is reduced is logged, that file yields None, the list goes on.  A
+    six-file --image_list with a raw frame cut short (still being written) and a frame of another shape in it: four sets of
+    products, two None, through the pipeline (input stage, lanes, output stage) -- which is not restarted and reduces
+    nothing one by one."""
+    cli = load_cli()
+    hdr = {'EXPTIME': 60.0, 'IMAGETYP': 'object', 'FILTER': 'q'}
+    raws = []
+    for k in range(6):
+        p = str(tmp_path / ('ML1_raw%d.fits' % k))
+        img = case['raw'] if k != 4 else case['raw'][:-2]                  # file 4: another shape
+        fitsio.write_image(p, img, dict(hdr, **{'DATE-OBS': '2024-01-02T03:04:0%d' % k}))
+        raws.append(p)
+    n = os.path.getsize(raws[1])
+    with open(raws[1], 'r+b') as f:                                        # file 1: the last third of the pixels missing
+        f.truncate(n - n // 3)
+    fitsio.write_image(str(tmp_path / 'flat.fits'), case['flat'])
+    fitsio.write_image(str(tmp_path / 'bpm.fits'), case['bpm'])
+    synth.write_xtalk(str(tmp_path / 'xtalk.dat'), case['xtalk'])
+    lst = str(tmp_path / 'list.txt')
+    with open(lst, 'w') as f:
+        f.write('\n'.join(raws) + '\n')
+    calls = []
+    orig = cli.Reducer.reduce_logged
+
+    def spy(self, fn):
+        calls.append(fn)
+        return orig(self, fn)
+    cli.Reducer.reduce_logged = spy
+    try:
+        outs = cli.main(['--telescope', TEL, '--mflat', str(tmp_path / 'flat.fits'), '--bpm', str(tmp_path / 'bpm.fits'),
+                         '--crosstalk', str(tmp_path / 'xtalk.dat'), '--ysize_chan', str(YS), '--xsize_chan', str(XS), '--fpack', 'True',
+                         '--image_list', lst, '--red_dir', str(tmp_path / 'red')])
+    finally:
+        cli.Reducer.reduce_logged = orig
+    assert len(outs) == 6 and outs[1] is None and outs[4] is None, outs
+    good = [outs[k] for k in (0, 2, 3, 5)]
+    assert all(o and o.endswith('_red.fits.fz') and os.path.isfile(o) and os.path.isfile(o.replace('_red', '_mask')) for o in good), outs
+    assert not calls                                                       # nothing went through the one-by-one path
+    from blackbox_amd import fpack as P
+    _, m0, _, _ = run(ctx, case)
+    for o in good:
+        got = P.funpack_image(ctx, o.replace('_red', '_mask'))
+        got = got[0] if isinstance(got, tuple) else got
+        assert np.array_equal(np.asarray(got.cpu() if hasattr(got, 'cpu') else got), m0.cpu().numpy()), o

@@ -102,3 +102,47 @@ def test_pipeline_refuses_bad_input_and_reports_lane_errors(pool):
     assert sorted(pipe.free_slots) == [0, 1]                       # nothing leaked by the aborted run
     pipe.close()
     ctx.close()
+
+
+def test_two_threads_wait_on_one_context():
+    """bbx_wait / bbx_sync keep their event and pinned error word per THREAD: a lane thread inside _lib.fetch and the caller
+    inside ctx.sync() on the same context (round 4 shared one event per context: the second hipEventRecord let the first
+    thread's poll return early and fetch read its staging buffer before the copy had landed -- stale values, no error)."""
+    import threading
+    from blackbox_amd import _lib
+    ctx = R.Context(0)
+    check = _lib.check
+    check(_lib.lib.bbx_set_option(ctx.h, 7, 50), 'bbx_set_option', ctx.h)          # BBX_OPT_WAIT_SLEEP_US
+    dev = ctx.device
+    stop, bad, rounds = threading.Event(), [], [0]
+
+    def fetcher():
+        torch.cuda.set_device(dev)
+        s = torch.cuda.Stream(device=dev)
+        big = torch.zeros(1 << 26, dtype=torch.float32, device=dev)             # 256 MB: a fill takes ~0.1 ms, several in a row
+        small = torch.zeros(64, dtype=torch.float32, device=dev)
+        with torch.cuda.stream(s):
+            for k in range(1, 151):
+                for _ in range(6):
+                    big.add_(1.0)                                                # work in front of the value that is fetched
+                small.fill_(float(k))
+                got = _lib.fetch(ctx, small)
+                if not (got == float(k)).all():
+                    bad.append((k, got[:4].tolist()))
+                rounds[0] = k
+        stop.set()
+
+    def syncer():
+        torch.cuda.set_device(dev)
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            while not stop.is_set():
+                ctx.sync()                                                       # an idle stream: returns at once, recording its event
+
+    ts = [threading.Thread(target=fetcher), threading.Thread(target=syncer)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120.0)
+    assert rounds[0] == 150 and not bad, bad[:3]
+    ctx.close()

@@ -62,3 +62,17 @@ def test_parse_raw_fz_and_plain(tmp_path):
     b3 = np.fromfile(ph, np.uint8)
     with pytest.raises(ValueError):
         instage.parse_raw(b3, b3.size)
+    # truncated files -- still being written, a broken transfer -- parse as far as they go; their pixels would be decoded from
+    # whatever the reader's buffer held before.  Refused like astropy refuses them: a heap cut short, a tile table cut
+    # short, an uncompressed image cut short (nbytes = what was read; the buffer behind it may hold anything)
+    bz = np.fromfile(pz, np.uint8)
+    big = np.concatenate([bz, np.full(4096, 7, np.uint8)])
+    rz = instage.parse_raw(big, bz.size)
+    for cut in (rz.heap_off + rz.heap_len - 1, rz.heap_off + 5, rz.heap_off - 3):
+        with pytest.raises(EOFError):
+            instage.parse_raw(big, cut)
+    bp = np.fromfile(pp, np.uint8)
+    rp = instage.parse_raw(bp, bp.size)
+    with pytest.raises(EOFError):
+        instage.parse_raw(np.concatenate([bp, bp]), rp.data_off + rp.data_len - 2)
+    assert instage.parse_raw(np.concatenate([bp, bp]), rp.data_off + rp.data_len).data_len == rp.data_len      # padding missing: the pixels are all there
