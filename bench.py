@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
-NSL = 13                                                         # BBX_PROF_NSLOTS (launch slots of bbx_profile_read)
+NSL = 14                                                         # BBX_PROF_NSLOTS (launch slots of bbx_profile_read)
 
 
 def moffat_stamp(S, fwhm, beta=2.5):
@@ -53,12 +53,17 @@ def moffat_stamp(S, fwhm, beta=2.5):
     return (p / p.sum()).astype(np.float32)
 
 
-def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras=False, ntrans=0, trail=None):
+def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras=False, ntrans=0, trail=None, psf_field=None):
     """full-size synthetic raw frame + flat + BPM, generated on the GPU (SURVEY 8d recipe:
     per-channel bias/read noise, sky, stars incl. saturated ones, cosmic-ray tracks).
     extras: also return dict(scene0 = the noiseless sky + stars scene in e- (what a deep reference
     image of the field shows), transients = [(y, x, flux)] of [ntrans] point sources (Moffat FWHM 4)
-    added to this frame only, S/N 6-100); trail = (xa, ya, xb, yb, amp, fwhm): a satellite trail."""
+    added to this frame only, S/N 6-100); trail = (xa, ya, xb, yb, amp, fwhm): a satellite trail.
+    psf_field = dict(size, nsx, fw_n, fw_r, fratio) (zogy_psf_field): the scene follows the PSF model that ZOGY is handed --
+    a star (and a transient) of the new frame has the FWHM of the sub-image it lies in, the reference scene (scene0) shows
+    the same stars with the reference's FWHM there and their fluxes divided by the flux ratio, wings out to 24 px.  Without
+    it every star draws its own FWHM (3-5 px) in both images: each bright star then leaves a PSF-mismatch residual in the
+    subtraction (round 4's bench scene: ~1900 such detections beside its 50 transients)."""
     from blackbox_amd import settings
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -75,22 +80,34 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras
     nsat = max(2, nstar // 1000)
     flux[:nsat] = rs.uniform(2e7, 6e7, nsat)
     fwhm = rs.uniform(3.0, 5.0, nstar)
-    R = 12
-    oy, ox = np.mgrid[-R:R + 1, -R:R + 1]
-    for s0 in range(0, nstar, 4096):
-        sl = slice(s0, min(nstar, s0 + 4096))
-        cx = torch.tensor(sx[sl], device=dev, dtype=torch.float32)[:, None]
-        cy = torch.tensor(sy[sl], device=dev, dtype=torch.float32)[:, None]
-        fl = torch.tensor(flux[sl], device=dev, dtype=torch.float32)[:, None]
-        a = torch.tensor(fwhm[sl] / (2 * np.sqrt(2 ** (1 / 2.5) - 1)), device=dev, dtype=torch.float32)[:, None]
-        px = (cx.floor() + torch.tensor(ox.ravel(), device=dev, dtype=torch.float32)[None, :])
-        py = (cy.floor() + torch.tensor(oy.ravel(), device=dev, dtype=torch.float32)[None, :])
-        r2 = (px - cx) ** 2 + (py - cy) ** 2
-        val = fl * 1.5 / (np.pi * a * a) * (1 + r2 / (a * a)) ** (-2.5)
-        ok = (px >= 0) & (px < nx) & (py >= 0) & (py < ny)
-        idx = (py.long() * nx + px.long())[ok]
-        scene.view(-1).index_add_(0, idx, val[ok])
-    scene0 = scene.clone() if extras else None
+    R = 12 if psf_field is None else 24
+
+    def add_stars(img, fw, fl_all):
+        oy, ox = np.mgrid[-R:R + 1, -R:R + 1]
+        chunk = 4096 if R <= 12 else 1024
+        for s0 in range(0, nstar, chunk):
+            sl = slice(s0, min(nstar, s0 + chunk))
+            cx = torch.tensor(sx[sl], device=dev, dtype=torch.float32)[:, None]
+            cy = torch.tensor(sy[sl], device=dev, dtype=torch.float32)[:, None]
+            fl = torch.tensor(fl_all[sl], device=dev, dtype=torch.float32)[:, None]
+            a = torch.tensor(fw[sl] / (2 * np.sqrt(2 ** (1 / 2.5) - 1)), device=dev, dtype=torch.float32)[:, None]
+            px = (cx.floor() + torch.tensor(ox.ravel(), device=dev, dtype=torch.float32)[None, :])
+            py = (cy.floor() + torch.tensor(oy.ravel(), device=dev, dtype=torch.float32)[None, :])
+            r2 = (px - cx) ** 2 + (py - cy) ** 2
+            val = fl * 1.5 / (np.pi * a * a) * (1 + r2 / (a * a)) ** (-2.5)
+            ok = (px >= 0) & (px < nx) & (py >= 0) & (py < ny)
+            idx = (py.long() * nx + px.long())[ok]
+            img.view(-1).index_add_(0, idx, val[ok])
+    scene0 = None
+    if psf_field is None:
+        add_stars(scene, fwhm, flux)
+        scene0 = scene.clone() if extras else None
+    else:
+        ksub = (np.minimum(sy.astype(int), ny - 1) // psf_field['size']) * psf_field['nsx'] + np.minimum(sx.astype(int), nx - 1) // psf_field['size']
+        if extras:
+            scene0 = scene.clone()
+            add_stars(scene0, np.asarray(psf_field['fw_r'])[ksub], flux / np.asarray(psf_field['fratio'])[ksub])
+        add_stars(scene, np.asarray(psf_field['fw_n'])[ksub], flux)
     transients = []
     if ntrans:
         rt = np.random.RandomState(seed + 77)
@@ -101,6 +118,9 @@ def synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, raw_dtype, extras
             ty, tx = int(rt.randint(40, ny - 40)), int(rt.randint(40, nx - 40))
             fl = float(110.0 * 10 ** rt.uniform(np.log10(6), 2))               # S/N 6 .. 100 for ~110 e- of noise per PSF
             idx = torch.tensor(((ty + oyx[0]) * nx + (tx + oyx[1])).ravel(), device=dev)
+            if psf_field is not None:
+                st = torch.tensor(moffat_stamp(S, float(psf_field['fw_n'][(ty // psf_field['size']) * psf_field['nsx'] + tx // psf_field['size']])),
+                                  device=dev).reshape(-1)
             scene.view(-1).index_add_(0, idx, st * fl)
             transients.append((ty, tx, fl))
     if trail is not None:
@@ -175,6 +195,18 @@ def synth_reference(torch, dev, scene0, seed, depth=4.0, sky_ref=0.0):
     return ref.contiguous(), torch.zeros(scene0.shape, dtype=torch.uint8, device=dev)
 
 
+def zogy_psf_field(nsy, nsx, size):
+    """the PSF model of the synthetic field, per sub-image: FWHM of the new frame (3.6 .. 4.6 px) and of the co-added reference
+    (3.3 .. 3.9 px), flux ratio new / reference -- what zogy_inputs turns into stamps and scalars and synth_frame_device into
+    stars"""
+    nsub = nsy * nsx
+    ky, kx = np.divmod(np.arange(nsub), nsx)
+    u, v = kx / max(1, nsx - 1) - 0.5, ky / max(1, nsy - 1) - 0.5
+    rs = np.random.RandomState(5)
+    return dict(size=size, nsx=nsx, fw_n=4.1 + 0.6 * u + 0.37 * v, fw_r=3.6 + 0.3 * u - 0.29 * v,
+                fratio=1.0 + 0.04 * u - 0.03 * v + rs.normal(0, 0.005, nsub))
+
+
 def zogy_inputs(torch, dev, nsy, nsx, S, box, ny, nx):
     """what zogy hands run_ZOGY per sub-image (blackbox.py:3754-3759, call 2460-2465) -- analytic Moffat
     PSF stamps S x S (49 x 49), one pair per sub-image with a FWHM gradient across the field (new 3.6 .. 4.6 px, co-added
@@ -242,7 +274,50 @@ def _cpu_sample(args):
     return (t1 - t0, t_bkg, t_zogy)
 
 
-def cpu_baseline(workload):
+def _cpu_full_frame(args):
+    """the same parts as _cpu_sample on ONE WHOLE frame of the bench's own workload (the raw frame, flat and bad-pixel mask the
+    GPU run used, handed over as .npy files), one process, one thread: what the area extrapolation of the sample is checked
+    against.  -> seconds of (reduction, mesh of the new frame, run_zogy on the 64 sub-images)"""
+    path, with_zogy = args
+    for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[k] = '1'
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import bbx_oracle as O
+    import lacosmic_c as LC
+    import zogy_core as Z
+    from blackbox_amd import settings
+    raw, flat, bpm = (np.load(path + k + '.npy') for k in ('raw', 'flat', 'bpm'))
+    ys, xs = 5280, 1320
+    t0 = time.perf_counter()
+    data = raw.astype('float32')
+    gain, sat = settings.gain['ML1'], settings.satlevel['ML1']
+    O.gain_corr(data, gain, ys, xs)
+    out, h, _ = O.os_corr(data, ys, xs)
+    mask, hm = O.mask_init(out, h, bpm, gain, sat, ys, xs)
+    out /= flat
+    LC.detect_cosmics(out, mask != 0, 15, 0.01, 3, 3, h['RDNOISE'], nthreads=1)
+    t1 = time.perf_counter()
+    t_bkg = t_zogy = 0.0
+    if with_zogy:
+        med, std = Z.get_back_mini(out, mask, None, box=60)
+        med, std = Z.fill_filter_mini(med), Z.fill_filter_mini(std)
+        sub = (out - Z.mini2back(med, out.shape, 60)).astype('float32')
+        sig = Z.mini2back(std, out.shape, 60)
+        t2 = time.perf_counter()
+        Ls = 1400
+        psf = np.zeros((Ls, Ls), 'float32'); st = moffat_stamp(25, 4.0)
+        for j in range(25):
+            for i in range(25):
+                psf[(j - 12) % Ls, (i - 12) % Ls] = st[j, i]
+        N_s, V_s = Z.cut_subimages(sub, 1320, 40), Z.cut_subimages((np.maximum(sub, 0) + sig * sig).astype('float32'), 1320, 40)
+        for k in range(N_s.shape[0]):
+            Z.run_zogy(N_s[k], N_s[k][::-1].copy(), psf, psf, 20.0, 10.0, 1.0, 1.0, V_s[k], V_s[k], 0.03, 0.03)
+        t3 = time.perf_counter()
+        t_bkg, t_zogy = t2 - t1, t3 - t2
+    return (t1 - t0, t_bkg, t_zogy)
+
+
+def cpu_baseline(workload, full_frame=None):
     """the CPU restatement (oracle: numpy / scipy, kind "port") timed on the host cores of this
     box the way the reference farms frames (blackbox.py:363-379: one process per frame, each
     single-threaded): N_proc = min(cores, RAM / 6 GB) workers run the same bounded sample
@@ -259,8 +334,9 @@ def cpu_baseline(workload):
     frac = (2 * CPU_SAMPLE[0] * 8 * CPU_SAMPLE[1]) / 111513600.0
 
     def frame_seconds(t):
-        # reduction and mesh scale with the area; ZOGY with the 64 sub-images; the mesh runs on both frames
-        return t[0] / frac + (2 * t[1] / frac if workload != 'calib' else 0.0) + (64 * t[2] if with_zogy else 0.0)
+        # reduction and mesh scale with the area; ZOGY with the 64 sub-images; the mesh runs on the new frame only (the
+        # headline's reference is a background-subtracted co-add with its bkg_std_mini, as buildref delivers it)
+        return t[0] / frac + (t[1] / frac if workload != 'calib' else 0.0) + (64 * t[2] if with_zogy else 0.0)
     # mode (ii) of SURVEY 8d: one process, all cores (the threads go to the C / OpenMP LA-Cosmic, as in the reference's
     # environment; numpy's element-wise stages and FFTs stay on one core) -- and the same sample on one thread
     with mp.get_context('spawn').Pool(1) as pool:
@@ -270,7 +346,22 @@ def cpu_baseline(workload):
     with mp.get_context('spawn').Pool(nproc) as pool:
         ts = pool.map(_cpu_sample, [(k, with_zogy, 1) for k in range(nproc)])
     per_frame_all = float(np.mean([frame_seconds(t) for t in ts]))
-    return dict(value=nproc / per_frame_all, unit='frames/s', cores=nproc, kind='port',
+    full = None
+    if full_frame is not None:
+        # the extrapolation checked once against a whole frame (one process, one thread, nothing else running)
+        try:
+            with mp.get_context('spawn').Pool(1) as pool:
+                tf = pool.map(_cpu_full_frame, [(full_frame, with_zogy)])[0]
+            sec_full, sec_extra = float(sum(tf)), float(frame_seconds(t1))
+            full = dict(seconds=round(sec_full, 2), seconds_per_part=[round(float(v), 2) for v in tf],
+                        extrapolated_seconds=round(sec_extra, 2), extrapolated_seconds_per_part=[
+                            round(float(t1[0] / frac), 2), round(float(t1[1] / frac), 2), round(float(64 * t1[2]), 2)],
+                        ratio_full_over_extrapolated=round(sec_full / sec_extra, 3),
+                        note='one single-threaded process on the whole 10600x12000 raw frame of the GPU run (reduction, mesh, run_zogy on '
+                             'its 64 sub-images) against the same process on the 1/32-frame sample scaled by area (+ one sub-image x 64)')
+        except Exception as e:                                       # the validation is an extra: its failure is reported, not fatal
+            full = dict(error=repr(e))
+    return dict(value=nproc / per_frame_all, full_frame_check=full, unit='frames/s', cores=nproc, kind='port',
                 one_core_frames_per_s=1.0 / frame_seconds(t1),
                 one_process_all_cores=dict(frames_per_s=1.0 / frame_seconds(t_all), threads=cores,
                                            seconds_per_part=[round(float(v), 2) for v in t_all],
@@ -610,7 +701,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     # rehearsal knobs (a 1-GPU box): BBX_BENCH_BACKEND=gloo BBX_BENCH_ONE_GPU=1 run all ranks on cuda:0
     backend = os.environ.get('BBX_BENCH_BACKEND', 'nccl')
-    if os.environ.get('BBX_BENCH_ONE_GPU'):
+    one_gpu = bool(os.environ.get('BBX_BENCH_ONE_GPU'))
+    if one_gpu:
         local = 0
     if world > 1:
         import torch.distributed as dist
@@ -633,10 +725,17 @@ def main():
     lanes = args.lanes or {'zogy': 6, 'full': 6, 'calib': 8}[wl]          # (calib: 4 / 6 / 8 / 10 lanes -> 1180 / 1230 / 1370 / 1210 frames/s)
     depth = args.depth or {'zogy': 16, 'full': 18, 'calib': 24}[wl]
     seed = 1000 * 4 + rank
-    raw, flat, bpm, ex = synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, args.raw, extras=True, ntrans=50)
+    # the scene follows the PSF model ZOGY is handed (zogy_psf_field): star shapes per sub-image, reference fluxes / fratio
+    raw, flat, bpm, ex = synth_frame_device(torch, dev, ysz, xsz, os_y, os_x, seed, args.raw, extras=True, ntrans=50,
+                                            psf_field=zogy_psf_field(2 * ysz // size, 8 * xsz // size, size))
     ref, ref_mask = synth_reference(torch, dev, ex.pop('scene0'), seed)
     geom = R.geometry(raw.shape, ysz, xsz)
     tel = 'ML1'
+    cpu_full = None
+    if rank == 0 and world == 1 and not args.no_cpu and not args.small and args.raw == 'u16' and not (args.io_only or args.proc_only):
+        # the frame of this run for the CPU baseline's whole-frame check (host copies on the RAM disk, removed after use)
+        cpu_full = os.path.join('/dev/shm' if os.path.isdir('/dev/shm') else '/tmp', 'bbx_cpu_full_%d_' % os.getpid())
+        np.save(cpu_full + 'raw.npy', raw.cpu().numpy()); np.save(cpu_full + 'flat.npy', flat.cpu().numpy()); np.save(cpu_full + 'bpm.npy', bpm.cpu().numpy())
     N = 2 * ysz * 8 * xsz
     # distinct raw buffers for the frames in flight (same scene, fresh read noise): the working set
     # of consecutive frames must not sit in the 256 MB Infinity Cache
@@ -757,15 +856,17 @@ def main():
             'k_lac_cand': (1, 4 * N),
             # the kernels of bbx_zogy_frame, half-spectrum arrays of [spec] bytes:
             'k_final_rows': (7, 4 * spec + 4 * 4 * N),          # reads D^, V_S^, S_n^, S_r^ (column-transformed), writes D, Scorr, Fpsf, Fpsferr
-            'k_psf_cols': (8, int((2.5 + 2 * wfrac) * spec)),   # writes A, B, sqrt(den) (float) and the window rows of the two column-inverted k^
+            'k_psf_rowdft': (13, int(2 * nsub * S * (S * 4 + HP * 8))),        # the stamps in, their row DFTs out
+            'k_psf_cols': (8, int((2 + 2 * wfrac) * spec)),     # writes the two PSF spectra (one float4 array) and the window rows of the two column-inverted k^
             'k_psf_rows': (9, int(4 * wfrac * spec)),           # the window rows of k_r, k_n in, their squares' row pass out
             # one launch for both pairs (4 frame cuts read, 4 half spectra written); frames whose rows are not 16-byte aligned
             # take two launches (2 + 4 cuts read, 2 spectra written each: the average below)
-            'k_img_rows': (10, int(4 * spec + 4 * cut) if rows_once else int(2 * spec + 3 * cut)),
-            'k_img_cols': (11, int(7.5 * spec)),                # N^, R^, A, B, sqrt(den) in; D^, S_n^, S_r^ out
+            # (round 5: the sigma maps come off their mini images, bbx_zogy_frame_mini: 2 frame cuts read instead of 4)
+            'k_img_rows': (10, int(4 * spec + 2 * cut) if rows_once else int(2 * spec + 3 * cut)),
+            'k_img_cols': (11, int(7 * spec)),                  # N^, R^, (Pn^, Pr^) in; D^, S_n^, S_r^ out
             'k_var_cols': (12, int((3 + 2 * wfrac) * spec)),    # V_n^, V_r^ and the window rows of (k^2)^ in, V_S^ out
         }
-        zogy_kernels = ('k_psf_cols', 'k_psf_rows', 'k_img_rows', 'k_img_cols', 'k_var_cols', 'k_final_rows')
+        zogy_kernels = ('k_psf_rowdft', 'k_psf_cols', 'k_psf_rows', 'k_img_rows', 'k_img_cols', 'k_var_cols', 'k_final_rows')
         zogy_io_model = int(4 * 4 * nsub * L * L + 4 * 4 * N)     # 4 inputs read with the tile overlap, 4 outputs written
         iso = {k: (iso_ms[sl] / max(1, iso_calls[sl]), by, iso_calls[sl]) for k, (sl, by) in kern.items() if iso_calls[sl]}
         live = {k: (ms_tot[sl] / max(1, calls[sl]), by, calls[sl]) for k, (sl, by) in kern.items() if calls[sl]}
@@ -794,7 +895,7 @@ def main():
             zms = sum(live[k][0] * per_frame[k] for k in zogy_kernels)
             zms_iso = sum(iso[k][0] * per_frame[k] for k in zogy_kernels)
             moved = int(sum(live[k][1] * per_frame[k] for k in zogy_kernels))
-            roof = dict(bound='hbm', kernel='bbx_zogy_frame (launch group: k_psf_cols, k_psf_rows, k_img_rows, k_img_cols, '
+            roof = dict(bound='hbm', kernel='bbx_zogy_frame (launch group: k_psf_rowdft, k_psf_cols, k_psf_rows, k_img_rows, k_img_cols, '
                                             'k_var_cols, k_final_rows)',
                         achieved=zogy_io_model / (zms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                         avg_launch_ms=zms, launches=int(min(live[k][2] // per_frame[k] for k in zogy_kernels)),
@@ -839,12 +940,15 @@ def main():
                  'calib': 'configs[1]: one %s -> gain+overscan+flat+mask_init+LA-Cosmic(niter=3), ML1' % shape}
         out = dict(metric='10560x10560 fp32 frames/sec end-to-end reduce+ZOGY; % HBM roofline' if wl == 'zogy' else
                    '10560x10560 fp32 frames/sec end-to-end reduce (%s)' % wl,
-                   value=args.steps * world / dt, unit='frames/s', n_gpus=world, steps=args.steps,
+                   value=args.steps * world / dt, unit='frames/s', n_gpus=1 if one_gpu else world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=names[wl],
                                frames_per_gpu=args.steps, frames_in_flight=depth, stageC_lanes=lanes, host_fit_workers=r['nworkers'],
-                               distinct_raw_buffers=nbuf, parallelism='frame-per-gpu x%d (no collective)' % world),
+                               distinct_raw_buffers=nbuf, parallelism='frame-per-gpu x%d (no collective)' % world,
+                               **(dict(rehearsal_one_gpu=True, ranks=world,
+                                       rehearsal_note='BBX_BENCH_ONE_GPU: all %d ranks share cuda:0 -- a rehearsal of the multi-rank '
+                                                      'path on a one-GPU box, NOT a scaling measurement' % world) if one_gpu else {})),
                    timing='steady state: %d frames fill the pipeline, %d warm-up frames, then the clock runs from the completion of '
                           'the last warm-up frame to the completion of the %d-th frame after it, with %d more frames in flight '
                           'behind it (no fill, no drain inside the region); barrier + device synchronisation around the run'
@@ -894,6 +998,24 @@ def main():
                                             note='one 25 x 25 PSF stamp for all sub-images (the configuration of rounds 1-3)')
                 section('zogy_psf25')
         out['other_workloads'] = others
+        # the stage figures next to the headline's roofline (north_star: >= 60 % of the HBM roofline on the calibration +
+        # LA-Cosmic stage): frames/s of the stage workloads x their SURVEY 8d algorithmic bytes, and the launch-level
+        # fractions of the two kernels that carry that stage, from the headline's timed region.  (8d prices LA-Cosmic at 22N;
+        # the exact sparse formulation moves ~4N + lists -- the whole-frame bit-exact test proves the work is done -- so the
+        # stage fraction is a statement about throughput in 8d's currency, the kernel fractions about the kernels.)
+        b_raw2 = 2 if args.raw == 'u16' else 4
+        by_calib = int(b_raw2 * raw.numel() + 10 * N + 22 * N)
+        by_full = by_calib + int(9 * N + 6 * N + 8 * N + 9 * N)
+        stages = {}
+        for w2, by in (('calib', by_calib), ('full', by_full)):
+            fps = others[w2]['frames_per_s'] if w2 in others else (out['value'] if w2 == wl else None)
+            if fps:
+                stages[w2] = dict(frames_per_s=fps, bytes_8d=by, achieved=by * fps / 1e9, frac=by * fps / 1e9 / HBM_PEAK_GBS, unit='GB/s')
+        ko = out['roofline'].get('others', {})
+        for k in ('k_calibrate', 'k_lac_cand'):
+            if k in ko:
+                stages.setdefault('kernels', {})[k] = dict(frac_moved=ko[k]['frac_moved'], avg_launch_ms=ko[k]['avg_launch_ms'])
+        out['roofline']['stages'] = stages
         # the same steady-state measurement over a long run (the headline's K frames are few)
         r3 = run_pipeline(torch, ctx, tel, geom, raws, kws[wl], 240, 4, depth, lanes, pool, barrier)
         out['long_run'] = dict(frames=240, frames_per_s=240 / r3['dt'], ms_per_frame=1e3 * r3['dt'] / 240)
@@ -907,7 +1029,16 @@ def main():
     pool.close()
     if rank == 0:
         if not args.no_cpu:
-            out['cpu_baseline'] = cpu_baseline(wl)
+            full_path = None
+            if not args.small and world == 1 and cpu_full is not None:
+                full_path = cpu_full
+            out['cpu_baseline'] = cpu_baseline(wl, full_path)
+            if full_path:
+                for k in ('raw', 'flat', 'bpm'):
+                    try:
+                        os.unlink(full_path + k + '.npy')
+                    except OSError:
+                        pass
             section('cpu_baseline')
         print(json.dumps(out))
     if world > 1:

@@ -77,6 +77,7 @@ struct bbx_ctx {
     int    box_pp;             // which of the two CNT_BOXFAIL counters the next bbx_bkg_boxstats call fills
     int    bkg_full_sort;      // BBX_OPT_BKG_FULL_SORT: every box of bbx_bkg_boxstats through the full sort (tests: same statistics as the bracket path)
     int    fpack_hist_only;    // BBX_OPT_FPACK_HIST_ONLY: row medians by radix histograms over all keys (tests: same bytes as the bracket path)
+    struct { void* stream; void* ptr; size_t bytes; } fphint[16];   // bbx_fpack_tiles: its row-hint table, one per calling stream (bbx_fpack.hip)
     int    fpack_one_wg;       // BBX_OPT_FPACK_ONE_WG: k_fp_tile with the worst-case stream buffer only (tests: both paths make the same bytes)
     int    spf_attr_bytes;     // dynamic-LDS attribute of the spline prefilter kernels set through this context
     int    zogy3_attr_L;       // sub-image side whose kernels have their dynamic-LDS attribute set through this context
@@ -131,6 +132,7 @@ enum {
 
 int bbx_hip_fail(bbx_ctx* ctx, hipError_t e, const char* what, int line);
 void bbx_zogy2_release(bbx_ctx* ctx);
+void bbx_fpack_release(bbx_ctx* ctx);     // bbx_fpack.hip: frees the per-stream hint tables (called by bbx_ctx_destroy)
 int bbx_zogy3_supported(int L);
 int bbx_build_flags_fpack(void); int bbx_build_flags_zogy(void); int bbx_build_flags_bkg(void); int bbx_build_flags_sat(void); int bbx_build_flags_canny(void);
 void bbx_zogy_release(bbx_ctx* ctx);      // bbx_zogy.hip: frees ctx->zogy_state (called by bbx_ctx_destroy)

@@ -139,6 +139,7 @@ void bbx_ctx_destroy(bbx_ctx* ctx) {
     (void)hipDeviceSynchronize();
     bbx_zogy_release(ctx);
     bbx_zogy2_release(ctx);
+    bbx_fpack_release(ctx);
     for (int i = 0; i < WS_MAX; i++) if (ctx->d_ws[i]) (void)hipFree(ctx->d_ws[i]);
     if (ctx->d_satlist) (void)hipFree(ctx->d_satlist);
     if (ctx->d_nonlin) (void)hipFree(ctx->d_nonlin);

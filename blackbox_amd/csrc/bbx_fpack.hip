@@ -833,6 +833,36 @@ static size_t fp_tile_stride(int nx, int bytepix) {
 extern "C" size_t bbx_fpack_tile_stride(int nx, int bytepix) { return fp_tile_stride(nx, bytepix); }
 
 // d_rnd: the 10000-value random table (float32) on the device.  d_scratch: ny * tile_stride bytes.
+// The row-hint table of a call lives with the STREAM the call is made on: the output stage compresses on the lane's stream
+// and -- its overflow fallback -- on a writer thread's own stream of the same context at the same time.  (Round 4 took the
+// table from the context's workspace slots: bbx_ws frees and reallocates, two threads inside it raced on the slot table, and
+// two calls in flight shared one table.)  A table grows only when its own stream needs more; nothing another stream uses is
+// ever freed before the context goes.
+#include <mutex>
+static std::mutex g_fphint_mutex;
+static void* fp_hint_table(bbx_ctx* ctx, hipStream_t s, size_t bytes, int* rc) {
+    *rc = BBX_OK;
+    std::lock_guard<std::mutex> lock(g_fphint_mutex);
+    int k = -1;
+    for (int i = 0; i < 16; i++) {
+        if (ctx->fphint[i].ptr && ctx->fphint[i].stream == (void*)s) { k = i; break; }
+        if (k < 0 && !ctx->fphint[i].ptr) k = i;                     // first free entry
+    }
+    if (k < 0) k = 0;                                                // more than 16 streams: share the first table (hints only choose a path)
+    if (ctx->fphint[k].ptr && ctx->fphint[k].stream == (void*)s && ctx->fphint[k].bytes >= bytes) return ctx->fphint[k].ptr;
+    if (ctx->fphint[k].ptr && ctx->fphint[k].stream != (void*)s) return ctx->fphint[k].bytes >= bytes ? ctx->fphint[k].ptr : (*rc = BBX_ERR_NOMEM, nullptr);
+    if (ctx->fphint[k].ptr) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->fphint[k].ptr); ctx->fphint[k].ptr = nullptr; }
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes + bytes / 8 + 256);
+    if (e != hipSuccess) { *rc = bbx_hip_fail(ctx, e, "hipMalloc(fpack hints)", __LINE__); return nullptr; }
+    ctx->fphint[k].ptr = p; ctx->fphint[k].stream = (void*)s; ctx->fphint[k].bytes = bytes + bytes / 8 + 256;
+    return p;
+}
+void bbx_fpack_release(bbx_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_fphint_mutex);
+    for (int i = 0; i < 16; i++) if (ctx->fphint[i].ptr) { (void)hipFree(ctx->fphint[i].ptr); ctx->fphint[i].ptr = nullptr; }
+}
+
 extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed,
                                const float* d_rnd, uint8_t* d_scratch, void* d_tiles, void* stream) {
     if (!ctx || !d_img || !d_scratch || !d_tiles || ny < 1 || nx < 1 || nx > FP_MAXNX) return BBX_ERR_ARG;
@@ -859,7 +889,7 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
     const int gen = two ? 2 * ncu : ncu;
     if (bitpix == -32 && !hist_only) {
         int rc;
-        d_hint = (unsigned*)bbx_ws(ctx, WS_FPHINT, (size_t)ny * 3 * sizeof(unsigned), &rc); if (rc) return rc;
+        d_hint = (unsigned*)fp_hint_table(ctx, s, (size_t)ny * 3 * sizeof(unsigned), &rc); if (rc) return rc;
         BBX_HIP(hipMemsetAsync(d_hint, 0, (size_t)ny * 3 * sizeof(unsigned), s));
     }
 #ifndef FPV_SKIP_RETRY

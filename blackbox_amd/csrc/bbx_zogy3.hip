@@ -1314,7 +1314,7 @@ static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, 
     }
     const bool win = 2 * wh < P::L;
     const int wb = win ? wh / P::NL : 0, nyb_psf = win ? 2 * wb : P::LB;
-    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_rowdft<P>, dim3((P::H + 255) / 256, (S + ZQ_J - 1) / ZQ_J, 2 * nsub), dim3(256), 0, s, d_psf_n, d_psf_r, S, tw, Qdft, nsub);
+    BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_DFT, k_psf_rowdft<P>, dim3((P::H + 255) / 256, (S + ZQ_J - 1) / ZQ_J, 2 * nsub), dim3(256), 0, s, d_psf_n, d_psf_r, S, tw, Qdft, nsub);
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_COLS, k_psf_cols<P>, gcol, blk, lds, s, Qdft, S, d_sc, tw, cP, U0, U1, fs_partial, nsub, wh);
     float2 *TK2r = cK2r, *TK2n = cK2n;                      // row-transformed (kr^2)^, (kn^2)^: T layout, column pass inside k_var_cols
     BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_PSF_ROWS, k_psf_rows<P>, grid8(nyb_psf, nsub), dim3(P::LIGHT_THREADS), lds, s, U1, U0, inv_n2, tw, TK2r, TK2n, nsub,

@@ -591,6 +591,9 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     res['bkg_std_mini_new'] = sdn
     hdr['BKG-SIZE'] = (box, '[pix] background boxsize used')
     hdr['BKG-SUB'] = (False, 'sky background was subtracted?')          # the _red product keeps its sky
+    # zogy's per-channel background correction factors (BKG-CF1..16, BKG-FDEG, BKG-FC0: blackbox.py:3061-3066, all None_OK)
+    # are [EXT] without a source in the reference tree: not applied here, and the header says so
+    hdr['BKG-CORR'] = (False, 'channel background correction applied?')
     hdr['S-BKGSTD'] = (float(np.median(sdn)), '[e-] sigma (STD) background full-frame image')
     res['data_bkgsub'], res['bkg_std'] = work, bstd
     bs = size // box if size % box == 0 else None

@@ -18,9 +18,10 @@
  *    reported, never swallowed; there is no CPU fallback.
  *  - images are C-order, row 0 first (numpy layout of the FITS data array).
  *  - one bbx_ctx per worker process / GPU (or per lane of a pipeline); a ctx is not thread-safe, and its calls belong on ONE
- *    stream at a time: the device work lists, counters and scratch of a ctx are shared by its calls (the exception is
- *    bbx_fpack_tiles / bbx_fpack_body, whose per-call state lives in the caller's buffers: the output stage runs them on a
- *    second stream of a lane's ctx).
+ *    stream at a time: the device work lists, counters and scratch of a ctx are shared by its calls.  Exceptions: the host
+ *    waits (bbx_wait, bbx_sync: their state belongs to the calling thread), and bbx_fpack_tiles / bbx_fpack_body, whose
+ *    per-call state lives in the caller's buffers and in a hint table the library keeps per calling STREAM: the output stage
+ *    runs them on a second and -- from a writer thread -- a third stream of a lane's ctx at the same time.
  *
  * Geometry (reference define_sections, blackbox.py:6334-6402): the raw frame is
  * NY x NX = 2 x 8 channels of (dy x dx) pixels; each channel holds a data
@@ -174,8 +175,9 @@ int  bbx_copy_async(void *dst, const void *src, size_t nbytes, int kind, void *s
 #define BBX_PROF_Z_PSF_ROWS 9  /*   k_psf_rows, */
 #define BBX_PROF_Z_IMG_ROWS 10 /*   k_img_rows (2 launches / frame), */
 #define BBX_PROF_Z_IMG_COLS 11 /*   k_img_cols, */
-#define BBX_PROF_Z_VAR_COLS 12 /*   k_var_cols */
-#define BBX_PROF_NSLOTS 13
+#define BBX_PROF_Z_VAR_COLS 12 /*   k_var_cols, */
+#define BBX_PROF_Z_PSF_DFT 13  /*   k_psf_rowdft (the stamps' row DFTs, in front of k_psf_cols) */
+#define BBX_PROF_NSLOTS 14
 int  bbx_profile_enable(bbx_ctx *ctx, int on);   /* 1: clear + record; 0: clear + stop; 2: stop, keep the records */
 /* synchronises on the recorded events; ms_total/calls have nslots entries; resets */
 int  bbx_profile_read(bbx_ctx *ctx, double *ms_total, int32_t *calls, int nslots);

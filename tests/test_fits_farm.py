@@ -63,3 +63,24 @@ def test_farm_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert 'FARM_OK 11' in r.stdout
+
+
+def test_eight_ranks_stay_inside_the_cpu_budget_of_a_node(monkeypatch):
+    """configs[3] / [4]: eight ranks on one node, one GPU each (blackbox.py:363-379 farms on the host's cores).  The threads
+    and worker processes a rank starts are sized from the cores the process may use (cgroup quota / affinity) divided by the
+    ranks of the node: on a 64- and a 128-core node the eight ranks together ask for no more processes than there are
+    cores, every rank keeps at least two fit workers, and a rank alone on a 16-core box gets the twelve that were measured
+    best there."""
+    from blackbox_amd import pipeline
+    for cores, world in ((64, 8), (128, 8), (16, 1), (32, 8), (8, 2)):
+        monkeypatch.setattr(pipeline, 'cpu_budget', lambda c=cores: c)
+        monkeypatch.setenv('LOCAL_WORLD_SIZE', str(world))
+        monkeypatch.delenv('BBX_HOST_WORKERS', raising=False)
+        w = pipeline.default_workers()
+        assert 2 <= w <= 12
+        # per rank: the fit workers + the orchestrating thread + one lane thread that is busy at a time (the others sleep in
+        # bbx_wait, measured 6-10 ms of CPU per frame for all of them: DESIGN section 1)
+        assert world * (w + 2) <= max(cores, world * 4), (cores, world, w)
+    monkeypatch.setattr(pipeline, 'cpu_budget', lambda: 16)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    assert pipeline.default_workers() == 12

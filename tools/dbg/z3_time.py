@@ -33,9 +33,9 @@ e0.record()
 for rep in range(n):
     outs = G.run_zogy_frame(ctx, new, ref, sn, sr, psf, psf, scal, 1320, 40)
 e1.record(); torch.cuda.synchronize()
-ms = (C.c_double * 13)(); calls = (C.c_int32 * 13)()
-_lib.lib.bbx_profile_read(ctx.h, ms, calls, 13)
-names = {7: 'final_rows', 8: 'psf_cols', 9: 'psf_rows', 10: 'img_rows(x2)', 11: 'img_cols', 12: 'var_cols'}
+ms = (C.c_double * 14)(); calls = (C.c_int32 * 14)()
+_lib.lib.bbx_profile_read(ctx.h, ms, calls, 14)
+names = {7: 'final_rows', 8: 'psf_cols', 9: 'psf_rows', 10: 'img_rows(x2)', 11: 'img_cols', 12: 'var_cols', 13: 'psf_rowdft'}
 per = {names[k]: ms[k] / n for k in names if calls[k]}
 print(os.environ.get('BBX_LIB_PATH', 'product') + (' MINI' if os.environ.get('MINI') else ''), 'total %.3f ms |' % (e0.elapsed_time(e1) / n), ' '.join('%s %.3f' % kv for kv in per.items()),
       '| Scorr std %.4f' % float(outs[2].std()))
