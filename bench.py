@@ -572,7 +572,69 @@ def measure_io(torch, ctx, tel, geom, raws, kw, depth, lanes, pool, barrier, arg
     return meas
 
 
-def process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box):
+def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
+    """files to files through the operator's own entry: a child `python blackbox.py --image_list L ... --fpack True` over [nfiles]
+    full-size fpacked raw frames on the RAM disk (blackbox_slurm_google.py:305-309 is the contract), every product of every
+    frame written.  The child reports when each file's products were all on disk (BBX_TIMING files_done_unix): the
+    steady-state rate is taken between the completions of file [skip] and the last one (the pipeline is full by then, at
+    most 16 frames in flight), next to the rate of the whole list from the first input to the last product and the
+    process's wall time (imports, GPU context, masters into HBM included)."""
+    import shutil
+    import subprocess
+    from blackbox_amd import fpack as P
+    free = shutil.disk_usage(td).free
+    need = nfiles * (100e6 + 400e6) + 2e9
+    if free < need:
+        return dict(skipped='%.1f GB free in %s, %.1f GB needed' % (free / 1e9, td, need / 1e9))
+    files = []
+    for k in range(nfiles):
+        h = dict(hdr, **{'DATE-OBS': '2024-01-02T03:%02d:%02d' % (k // 60, k % 60)})
+        files.append(P.fpack_image(ctx, os.path.join(td, 'ML1_list_%03d.fits' % k), raws[k % len(raws)], h))
+    ctx.sync()
+    lst = os.path.join(td, 'list.txt')
+    with open(lst, 'w') as f:
+        f.write('\n'.join(files) + '\n')
+    import torch
+    torch.cuda.empty_cache()                                      # (the parent's cached blocks: the child needs the HBM)
+    cmd = [c for c in cmd1]
+    i = cmd.index('--image')
+    cmd[i:i + 2] = ['--image_list', lst]
+    out_dir = os.path.join(td, 'out_list')
+    prof = os.environ.get('BBX_CLI_PROFILE')                      # (debug: cProfile of the child's orchestrating thread -> stderr)
+    if prof:
+        cmd = [cmd[0], '-m', 'cProfile', '-o', os.path.join(td, 'cli.prof')] + cmd[1:]
+    t0 = time.time()
+    r = subprocess.run(cmd + ['--red_dir', out_dir], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=540)
+    if prof and os.path.isfile(os.path.join(td, 'cli.prof')):
+        import pstats
+        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('cumulative').print_stats(45)
+        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('tottime').print_stats(40)
+        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).print_callees('subtract_and_write|finish_object|_run$')
+    wall = time.time() - t0
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('BBX_TIMING ')]
+    if r.returncode != 0 or not line:
+        return dict(error='exit code %d' % r.returncode, stderr=r.stderr[-800:])
+    tm = json.loads(line[-1][len('BBX_TIMING '):])
+    done = tm.get('files_done_unix', [])
+    marks = dict(tm['marks'])
+    nout = len([f_ for f_ in os.listdir(out_dir) if f_.endswith('_red.fits.fz')])
+    mb = sum(os.path.getsize(os.path.join(out_dir, f_)) for f_ in os.listdir(out_dir)) / 1e6
+    shutil.rmtree(out_dir, ignore_errors=True)
+    skip = min(16, max(1, len(done) // 3))
+    res = dict(files=nfiles, products_of=nout, MB_written=round(mb, 1), process_wall_s=round(wall, 2), hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
+               seconds_before_the_list=round(marks.get('calibration_and_reference_files_in_hbm', 0.0), 2))
+    if len(done) <= skip + 1:
+        res['note'] = 'only %d completion stamps came back' % len(done)
+        res['stderr_tail'] = r.stderr[-1500:]
+    if len(done) > skip + 1:
+        res['frames_per_s'] = (len(done) - 1 - skip) / (done[-1] - done[skip])
+        res['frames_per_s_whole_list'] = len(done) / (done[-1] - (tm['t_module_import_unix'] + marks.get('calibration_and_reference_files_in_hbm', 0.0)))
+        res['frames_per_s_process'] = len(done) / wall
+        res['steady_state_from_file'] = skip
+    return res
+
+
+def process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box, raws=None, list_frames=0):
     """what ONE `python blackbox.py --image F` process costs at full size (the reference's Slurm contract: one interpreter per
     file, blackbox_slurm_google.py:305-309): the frame's inputs are written as files (fpacked raw, master flat, bad-pixel
     mask, crosstalk table, reference image + mask + sigma mini image, PSF stamp cubes), the command line runs as a child
@@ -624,10 +686,13 @@ def process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box)
             files = sorted(os.listdir(out_dir))
             runs.append(dict(wall_s=round(wall, 3), interpreter_start_s=round(tm['t_module_import_unix'] - t0, 3), seconds_per_phase=d,
                              files_written=len(files), MB_written=round(sum(os.path.getsize(os.path.join(out_dir, f_)) for f_ in files) / 1e6, 1)))
-        return dict(first_run=runs[0], second_run=runs[1],
-                    note='child process `python blackbox.py --image raw.fits.fz ... --fpack True` at full size, all products of the frame '
-                         'written; seconds_per_phase = time between consecutive marks inside the process (imports, GPU context, masters / '
-                         'reference / PSFs into HBM, raw read + decode, reduction, subtraction, writing)')
+        res = dict(first_run=runs[0], second_run=runs[1],
+                   note='child process `python blackbox.py --image raw.fits.fz ... --fpack True` at full size, all products of the frame '
+                        'written; seconds_per_phase = time between consecutive marks inside the process (imports, GPU context, masters / '
+                        'reference / PSFs into HBM, raw read + decode, reduction, subtraction, writing)')
+        if list_frames:
+            res['image_list'] = cli_image_list(ctx, td, cmd, raws or [raw], hdr, list_frames)
+        return res
     except Exception as e:
         return dict(error=repr(e))
     finally:
@@ -769,7 +834,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.proc_only:
-        print(json.dumps(process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box)))
+        print(json.dumps(process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box, raws=raws, list_frames=args.steps if args.steps != 60 else 96)))
         pool.close()
         return
     if args.io_only:
@@ -1024,8 +1089,12 @@ def main():
         section('io_inclusive (pcie, serial writers)')
         out['io_inclusive']['measured'] = measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section)
         if wl == 'zogy' and not args.small:
-            out['process_per_file'] = process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box)
-            section('process_per_file')
+            out['process_per_file'] = process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box, raws=raws, list_frames=96)
+            section('process_per_file + image_list')
+            il = out['process_per_file'].pop('image_list', None)
+            if il is not None:
+                # the files-to-files figure of the operator surface itself (the in-process figures above run bench.py's own loop)
+                out['io_inclusive']['cli_image_list'] = il
     pool.close()
     if rank == 0:
         if not args.no_cpu:

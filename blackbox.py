@@ -35,6 +35,7 @@ log = logging.getLogger('blackbox')
 # as one `BBX_TIMING {json}` line when main() returns
 _T0 = time.time()
 _MARKS = []
+_FILES_DONE = []          # --image_list: the moment every product of a file was on disk (BBX_TIMING: the list's rate)
 
 
 def _mark(name):
@@ -515,11 +516,13 @@ class Reducer:
         if res.get('Fpsferr') is None:
             return
         nsig = float(R.hval(header, 'T-NSIGMA')) if 'T-NSIGMA' in header else 6.0
-        lim = res['Fpsferr'] * nsig
         zp = self.args.zeropoint
         staged = getattr(self, '_staged', None)
-        if staged is not None and (base + '_trans_limmag.fits.fz') in staged['names']:
-            zp = None                                   # the output stage has queued the flux limit already: describe that file
+        is_staged = staged is not None and (base + '_trans_limmag.fits.fz') in staged['names']
+        # (the output stage has queued the flux limit already: only its header is made here, no image)
+        lim = None if is_staged else res['Fpsferr'] * nsig
+        if is_staged:
+            zp = None
         elif zp is None and 'PC-ZP' in header and not isinstance(R.hval(header, 'PC-ZP'), str):
             zp = float(R.hval(header, 'PC-ZP'))
         h = dict(header)
@@ -536,7 +539,7 @@ class Reducer:
         else:
             h['LIMUNIT'] = ('e-', 'limit in flux: no zeropoint was given')
         h['LIMNSIG'] = (nsig, '[sigma] significance of the limit')
-        self.write_image(base + '_trans_limmag.fits', lim.contiguous(), h)
+        self.write_image(base + '_trans_limmag.fits', lim.contiguous() if lim is not None else None, h)
 
     # ---- many object frames: frames-in-flight pipeline ------------------------------------------
     def reduce_list(self, files):
@@ -624,6 +627,7 @@ class Reducer:
                         except OSError:
                             pass
                 written[f.idx] = group.error
+                _FILES_DONE.append(time.time())
                 if len(written) + len(input_failed) >= len(todo):
                     all_written.set()
             kw = dict(outstage=stage, out_base=lambda idx, h: todo[idx][1].replace('.fits', ''), on_written=on_written,
@@ -695,6 +699,8 @@ class Reducer:
                 out[fn] = None
             if stage is None:
                 live.pop(idx, None)
+                _FILES_DONE.append(time.time())
+
         def on_input_error(idx, e):
             # this file fails (blackbox.py:948-999: exception logged, None for the file), the list goes on
             log.error('exception was raised while reading %s: %r', todo[idx][0], e.cause)
@@ -853,7 +859,9 @@ def main(argv=None):
     if os.environ.get('BBX_TIMING'):
         import json
         _mark('done')
-        print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0)))
+        import torch
+        print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0, files_done_unix=sorted(_FILES_DONE),
+                                              hbm_peak_GB_tensors=round(torch.cuda.max_memory_allocated() / 1e9, 2))))
     return out
 
 

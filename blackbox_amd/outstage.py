@@ -95,7 +95,12 @@ class FrameGroup:
                 self.error = err
             last = self.left == 0
         if last and self.on_done is not None:
-            self.on_done(self)
+            try:
+                self.on_done(self)
+            finally:
+                # the frame and its group point at each other: without this the frame's device tensors (its subtraction
+                # images, 2.7 GB per frame) wait for the cyclic collector -- a list of a hundred frames ran the GPU out of memory
+                self.token = self.on_done = None
 
 
 class FzLane:

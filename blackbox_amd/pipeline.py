@@ -328,6 +328,16 @@ class FramePipeline:
         # while lane 0 (the caller's context) is driven from a lane thread
         self.own_ctx.append(R.Context(ctx.device.index))
         self.ctxA = _LaneCtx(self.own_ctx[-1], self.sA)
+        self._finisher = None
+        # A dozen threads of this process take turns on the interpreter lock: lane threads and the orchestrating thread make
+        # many short library calls (each gives the lock up and must get it back), the completion hook and the header formatting
+        # of the writers are plain Python.  At CPython's default switch interval (5 ms) a thread that wants the lock back waits
+        # up to that long per call while a Python-bound thread runs: a convoy (measured: the list run of blackbox.py fell from
+        # 37 to 13 frames/s when the hook moved to a thread of its own).  0.2 ms keeps the hand-over latency below a launch.
+        import sys
+        us = float(os.environ.get('BBX_SWITCH_US', '200'))
+        if us > 0 and sys.getswitchinterval() > us * 1e-6:
+            sys.setswitchinterval(us * 1e-6)
         self.lane_thread = [_LaneThread(self, ctx.device) for _ in self.lane_ctx]
         for t in self.lane_thread:
             t.start()
@@ -412,11 +422,11 @@ class FramePipeline:
         lib.bbx_set_option(self.ctx.h, 7, 0)
         if self.own_pool:
             self.pool.close()
-        for t in self.lane_thread:
+        for t in self.lane_thread + ([self._finisher] if self._finisher is not None else []):
             t.q.put(None)
-        for t in self.lane_thread:
+        for t in self.lane_thread + ([self._finisher] if self._finisher is not None else []):
             t.join()
-        self.lane_thread = []
+        self.lane_thread, self._finisher = [], None
         for sl in self.slots:
             for k in ('evA', 'evS', 'evC'):
                 lib.bbx_event_destroy(sl[k])
@@ -742,13 +752,27 @@ class FramePipeline:
                     if k in f.out_names:
                         hdrs[f.out_names[k]] = ht
             if self.header_hook is not None:
-                try:
-                    hdrs = self.header_hook(f, hdrs)
-                except BaseException as e:                          # the files still get the default headers
-                    if self.log is not None:
-                        self.log.exception('frame %d: header hook failed: %s', f.idx, e)
+                # the caller's completion of the frame (header bookkeeping, QC flags, its small files: ~15 ms of Python per
+                # frame in blackbox.py) runs on a thread of its own: the orchestrating thread goes back to its frames at once;
+                # the frame counts as done -- on_done, its slot -- when the hook has returned
+                f.d_keep = None
+                f.state = 'H'
+                if self._finisher is None:
+                    self._finisher = _LaneThread(self, self.ctx.device)
+                    self._finisher.start()
+                self._finisher.q.put((self._run_hook, f, hdrs))
+                return
             f.out_group.set_headers(hdrs)
         f.d_keep = None
+        f.state = 'done'
+
+    def _run_hook(self, f, hdrs):
+        try:
+            hdrs = self.header_hook(f, hdrs)
+        except BaseException as e:                                  # the files still get the default headers
+            if self.log is not None:
+                self.log.exception('frame %d: header hook failed: %s', f.idx, e)
+        f.out_group.set_headers(hdrs)
         f.state = 'done'
 
     # ---- driver --------------------------------------------------------------------
@@ -781,8 +805,9 @@ class FramePipeline:
                         r.wait(30.0)
                 except Exception:
                     pass
-        done = [threading.Event() for _ in self.lane_thread]
-        for t, ev in zip(self.lane_thread, done):
+        threads = self.lane_thread + ([self._finisher] if self._finisher is not None else [])
+        done = [threading.Event() for _ in threads]
+        for t, ev in zip(threads, done):
             t.q.put((lambda f, r, ev=ev: ev.set(), None, None))
         for ev in done:
             ev.wait(30.0)
@@ -876,6 +901,7 @@ class FramePipeline:
                 ndone += 1
                 if on_done:
                     on_done(f.idx, f)
+                f.out_group = None                                 # (frame <-> group: no reference cycle left behind)
             if exhausted and not live:
                 break
             if not progressed:
