@@ -263,21 +263,58 @@ __global__ __launch_bounds__(256) void k_psf_optflux(int ny, int nx, const float
     }
 }
 
-// the same with sigma evaluated from its mini image at every stamp pixel (no sigma frame)
+// the same with sigma read off its mini image (no sigma frame).  A stamp of S <= 64 pixels a side crosses at most four
+// coefficient columns (box intervals; one more at a channel border): a wave first works out, per stamp column, which of them
+// it lies in and its place t inside (49 divisions instead of 2401), then the cubics of the stamp's rows on those intervals
+// (bbx_spl_poly: the float64 fold of the row weights, 4 S of them instead of S^2), and a pixel costs one 16-byte LDS read
+// and three multiply-adds.  (First version, one full evaluation per pixel: 0.31 ms for the bench's 11 000 sources against
+// 0.13 ms of the kernel that reads a sigma frame.)
+#define OPT_SMAX 64
+#define OPT_KI 4
 __global__ __launch_bounds__(256) void k_psf_optflux_mini(int ny, int nx, const float* __restrict__ D, bbx_spl sp,
                                                           const float* __restrict__ psfs, int S, int nsrc,
                                                           const int32_t* __restrict__ ys, const int32_t* __restrict__ xs,
                                                           float* __restrict__ flux, float* __restrict__ err) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    __shared__ float4 s_poly[4][OPT_SMAX][OPT_KI];
+    __shared__ float s_t[4][OPT_SMAX];
+    __shared__ int s_k[4][OPT_SMAX], s_c[4][OPT_KI + 1];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int h = S / 2;
+    const bool table = S <= OPT_SMAX;
     for (int k = wave; k < nsrc; k += nwaves) {
+        const int y0 = ys[k] - h, x0 = xs[k] - h;
+        bool fits = table;
+        if (table) {
+            // stamp columns -> (compact interval number, t); the distinct coefficient columns in order
+            int c = 0, r = 0;
+            const int X = min(max(x0 + lane, 0), nx - 1);
+            bbx_spl_axis(X, sp.pw, sp.rpw, sp.px, sp.npad, sp.nx1, sp.dx, sp.rdx, c, r);
+            const int cprev = __shfl_up(c, 1, 64);
+            const bool act = lane < S;
+            const unsigned long long chg = __ballot(act && lane > 0 && c != cprev);
+            const int kk = __popcll(chg & ((2ull << lane) - 1ull));            // changes at lanes <= this one
+            const int nk = __popcll(chg) + 1;
+            fits = nk <= OPT_KI;                                                // (wave-uniform)
+            if (fits) {
+                if (act) { s_k[wib][lane] = kk; s_t[wib][lane] = (float)r * sp.rdx; }
+                if (act && (lane == 0 || ((chg >> lane) & 1ull))) s_c[wib][kk] = c;
+                // (same wave: LDS writes are visible to its later reads in program order)
+                for (int t = lane; t < S * nk; t += 64) {
+                    const int j = t / nk, q = t - j * nk;
+                    const int Y = min(max(y0 + j, 0), ny - 1);
+                    s_poly[wib][j][q] = bbx_spl_poly(sp, Y, s_c[wib][q]);
+                }
+            }
+        }
         double num = 0.0, den = 0.0;
         for (int t = lane; t < S * S; t += 64) {
             const int j = t / S, i = t - j * S;
-            const int y = ys[k] + j - h, x = xs[k] + i - h;
+            const int y = y0 + j, x = x0 + i;
             if (y < 0 || y >= ny || x < 0 || x >= nx) continue;
-            const float sg = bbx_spl_eval(sp, y, x), d = D[(size_t)y * nx + x];
+            const float sg = fits ? bbx_spl_horner(s_poly[wib][j][s_k[wib][i]], s_t[wib][i]) : bbx_spl_eval(sp, y, x);
+            const float d = D[(size_t)y * nx + x];
             const double v = (double)(fmaxf(d, 0.f) + sg * sg);
             if (!(v > 0.0)) continue;
             const double p = (double)psfs[((size_t)k * S + j) * S + i];

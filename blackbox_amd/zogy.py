@@ -576,7 +576,8 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     mini2back(ctx, mini, (ny, nx), bkg_boxsize=box, interp_Xchan=True, subtract_from=new, subtract_into=work)
     # the sigma image of the new frame: read off its mini image by the kernels that need it (catalogue photometry, the cut
     # into sub-images) where the geometry allows, a frame otherwise
-    use_mini = frame_path_supported(L) and not sigma_frames
+    import os
+    use_mini = frame_path_supported(L) and not sigma_frames and not os.environ.get('BBX_SIGMA_FRAMES')     # (the switch: A/B timing)
     bstd = None
     if use_mini:
         try:
