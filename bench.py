@@ -623,6 +623,31 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
     skip = min(16, max(1, len(done) // 3))
     res = dict(files=nfiles, products_of=nout, MB_written=round(mb, 1), process_wall_s=round(wall, 2), hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
                seconds_before_the_list=round(marks.get('calibration_and_reference_files_in_hbm', 0.0), 2))
+    # the reference's own farm on one GPU (blackbox.py:363-379: pool_func(try_blackbox_reduce, files, nproc)): persistent
+    # worker processes, a GPU context and the masters in HBM each, one file at a time per worker
+    try:
+        npool, nf = 4, min(nfiles, 32)
+        lst2 = os.path.join(td, 'list_pool.txt')
+        with open(lst2, 'w') as f:
+            f.write('\n'.join(files[:nf]) + '\n')
+        cmd2 = [c for c in cmd1]
+        i = cmd2.index('--image')
+        cmd2[i:i + 2] = ['--image_list', lst2, '--nproc', str(npool)]
+        out2 = os.path.join(td, 'out_pool')
+        t0 = time.time()
+        r2 = subprocess.run(cmd2 + ['--red_dir', out2], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=540)
+        wall2 = time.time() - t0
+        n2 = len([f_ for f_ in os.listdir(out2) if f_.endswith('_red.fits.fz')]) if os.path.isdir(out2) else 0
+        shutil.rmtree(out2, ignore_errors=True)
+        res['process_pool'] = dict(workers=npool, files=nf, products_of=n2, wall_s=round(wall2, 2), frames_per_s=round(n2 / wall2, 2),
+                                   returncode=r2.returncode,
+                                   note='child `python blackbox.py --image_list L --nproc %d`: a spawn pool of persistent workers, each with its '
+                                        'own GPU context and masters, files one by one per worker; wall time of the whole process '
+                                        '(interpreter, pool start, %d x [torch import + context + masters into HBM] included)' % (npool, npool))
+        if r2.returncode != 0:
+            res['process_pool']['stderr'] = r2.stderr[-600:]
+    except Exception as e:
+        res['process_pool'] = dict(error=repr(e))
     if len(done) <= skip + 1:
         res['note'] = 'only %d completion stamps came back' % len(done)
         res['stderr_tail'] = r.stderr[-1500:]
@@ -1094,7 +1119,10 @@ def main():
             il = out['process_per_file'].pop('image_list', None)
             if il is not None:
                 # the files-to-files figure of the operator surface itself (the in-process figures above run bench.py's own loop)
+                pp = il.pop('process_pool', None)
                 out['io_inclusive']['cli_image_list'] = il
+                if pp is not None:
+                    out['process_pool'] = pp
     pool.close()
     if rank == 0:
         if not args.no_cpu:

@@ -841,6 +841,7 @@ def main(argv=None):
     if args.nproc > 1 and len(mine) > 1:
         # the reference's farm (blackbox.py:375-379): a pool of workers over the file list, one GPU context each
         configure(argv)
+        _mark('pool_start')
         try:
             out = pool_func(try_blackbox_reduce, mine, nproc=args.nproc)
         except WrapException as e:
@@ -848,6 +849,10 @@ def main(argv=None):
             raise
         for o in out:
             print(o)
+        if os.environ.get('BBX_TIMING'):
+            import json
+            _mark('done')
+            print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0)))
         return out
     red = Reducer(tel, args)
     if args.image_list and len(mine) > 1:

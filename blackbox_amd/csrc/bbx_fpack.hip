@@ -195,7 +195,7 @@ template <int BYTEPIX, bool FLOAT_IN, int MODE>
 __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile(const void* __restrict__ src, int ny, int nx, size_t row_stride_elems,
                                                  float qlevel, int dither_seed, const float* __restrict__ rnd,
                                                  uint8_t* __restrict__ scratch, size_t tile_stride, fp_tile* __restrict__ tiles,
-                                                 int capwords, int hist_only, unsigned* __restrict__ hint, int gen) {
+                                                 int capwords, int hist_only, unsigned* __restrict__ hint, int gen, float in_scale) {
     typedef rice_par<BYTEPIX> RP;
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             for (int k = 0; k < NLD; k++) {
                 const int i = tid + k * FP_THREADS;
                 if (i < n4) {
-                    const float4 v = f4[i];
+                    float4 v = f4[i];
+                    v.x *= in_scale; v.y *= in_scale; v.z *= in_scale; v.w *= in_scale;      // (1.0f: the pixels as they are, bit for bit)
                     fv4[i] = v;
                     if (!isfinite(v.x) || !isfinite(v.y) || !isfinite(v.z) || !isfinite(v.w)) bad = 1;
                     mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w))); mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             }
         } else {
             for (int i = tid; i < nx; i += FP_THREADS) {
-                const float v = f[i];
+                const float v = f[i] * in_scale;
                 fv[i] = v;
                 if (!isfinite(v)) bad = 1;
                 mn = fminf(mn, v); mx = fmaxf(mx, v);
@@ -863,8 +864,8 @@ void bbx_fpack_release(bbx_ctx* ctx) {
     for (int i = 0; i < 16; i++) if (ctx->fphint[i].ptr) { (void)hipFree(ctx->fphint[i].ptr); ctx->fphint[i].ptr = nullptr; }
 }
 
-extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed,
-                               const float* d_rnd, uint8_t* d_scratch, void* d_tiles, void* stream) {
+static int fpack_tiles_scaled(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed,
+                              const float* d_rnd, uint8_t* d_scratch, void* d_tiles, float in_scale, void* stream) {
     if (!ctx || !d_img || !d_scratch || !d_tiles || ny < 1 || nx < 1 || nx > FP_MAXNX) return BBX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int bytepix = bitpix == -32 ? 4 : bitpix / 8;
@@ -901,13 +902,13 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldshalf)); \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 1>), dim3(ny), dim3(FP_THREADS), ldshalf, s, d_img, ny, nx, (size_t)nx, qlevel, \
-                               dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords, hist_only, d_hint, gen);             \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, (int)capwords, hist_only, d_hint, gen, in_scale);   \
             if (!FPV_SKIP_RETRY) hipLaunchKernelGGL((k_fp_tile<BP, FL, 2>), dim3(min(ny, 256)), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
-                               dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen);               \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen, in_scale);     \
         } else {                                                                                                       \
             BBX_HIP(hipFuncSetAttribute((const void*)k_fp_tile<BP, FL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsbytes)); \
             hipLaunchKernelGGL((k_fp_tile<BP, FL, 0>), dim3(ny), dim3(FP_THREADS), ldsbytes, s, d_img, ny, nx, (size_t)nx, qlevel, \
-                               dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen);               \
+                               dither_seed, d_rnd, d_scratch, stride, tiles, 0, hist_only, d_hint, gen, in_scale);     \
         }                                                                                                              \
     } while (0)
     if (bitpix == -32) FP_LAUNCH(4, true);
@@ -917,6 +918,11 @@ extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, 
 #undef FP_LAUNCH
     BBX_LAUNCH_CHECK();
     return BBX_OK;
+}
+
+extern "C" int bbx_fpack_tiles(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed,
+                               const float* d_rnd, uint8_t* d_scratch, void* d_tiles, void* stream) {
+    return fpack_tiles_scaled(ctx, ny, nx, d_img, bitpix, qlevel, dither_seed, d_rnd, d_scratch, d_tiles, 1.0f, stream);
 }
 
 extern "C" int bbx_fpack_gather(bbx_ctx* ctx, int ny, int nx, int bitpix, const uint8_t* d_scratch, const void* d_tiles,
@@ -1008,11 +1014,21 @@ __global__ __launch_bounds__(256) void k_fp_gather4(const uint8_t* __restrict__ 
     if (threadIdx.x < n - done) d[done + threadIdx.x] = s[done + threadIdx.x];
 }
 
+extern "C" int bbx_fpack_body_scaled(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed, const float* d_rnd,
+                                     uint8_t* d_scratch, void* d_tiles, long long* d_offsets, uint8_t* d_body, long long cap_body, long long* d_info,
+                                     int max_list, float scale, void* stream);
 extern "C" int bbx_fpack_body(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed, const float* d_rnd,
                               uint8_t* d_scratch, void* d_tiles, long long* d_offsets, uint8_t* d_body, long long cap_body, long long* d_info,
                               int max_list, void* stream) {
+    return bbx_fpack_body_scaled(ctx, ny, nx, d_img, bitpix, qlevel, dither_seed, d_rnd, d_scratch, d_tiles, d_offsets, d_body, cap_body, d_info, max_list,
+                                 1.0f, stream);
+}
+extern "C" int bbx_fpack_body_scaled(bbx_ctx* ctx, int ny, int nx, const void* d_img, int bitpix, float qlevel, int dither_seed, const float* d_rnd,
+                                     uint8_t* d_scratch, void* d_tiles, long long* d_offsets, uint8_t* d_body, long long cap_body, long long* d_info,
+                                     int max_list, float scale, void* stream) {
     if (!d_offsets || !d_body || !d_info || max_list < 0) return BBX_ERR_ARG;
-    const int rc = bbx_fpack_tiles(ctx, ny, nx, d_img, bitpix, qlevel, dither_seed, d_rnd, d_scratch, d_tiles, stream);
+    if (scale != 1.0f && bitpix != -32) return BBX_ERR_ARG;
+    const int rc = fpack_tiles_scaled(ctx, ny, nx, d_img, bitpix, qlevel, dither_seed, d_rnd, d_scratch, d_tiles, scale, stream);
     if (rc) return rc;
     const int quant = bitpix == -32, rowlen = quant ? 32 : 8, bytepix = quant ? 4 : bitpix / 8;
     const long long table = (long long)ny * rowlen;

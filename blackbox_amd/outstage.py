@@ -41,7 +41,7 @@ class _Slot:
 
 
 class _Job:
-    __slots__ = ('lane', 'slot', 'img', 'path', 'quant', 'seed', 'bitpix', 'shape', 'header', 'header_ready', 'group', 'bzero')
+    __slots__ = ('lane', 'slot', 'img', 'path', 'quant', 'seed', 'bitpix', 'shape', 'header', 'header_ready', 'group', 'bzero', 'scale')
 
 
 class GroupCancelled(RuntimeError):
@@ -127,7 +127,7 @@ class FzLane:
             self.slots.append(s)
             self.free.put(s)
 
-    def enqueue(self, img, quant, seed):
+    def enqueue(self, img, quant, seed, scale=1.0):
         """queue the compression of [img] (contiguous 2-D float32 / uint8 / int16 / int32 device tensor of this lane's
         shape) on the current stream -> slot (blocks only when all slots are still waiting for their writer)"""
         if tuple(img.shape) != (self.ny, self.nx) or not img.is_contiguous():
@@ -138,11 +138,11 @@ class FzLane:
         self.slot_wait += time.perf_counter() - t0                # (lane thread: time it stood waiting for a free slot)
         rnd = fpack._rnd(img.device) if bitpix == -32 else None
         st = torch.cuda.current_stream(img.device)
-        check(lib.bbx_fpack_body(self.ctx.h, self.ny, self.nx, C.c_void_p(img.data_ptr()), bitpix, float(quant), int(seed),
-                                 C.c_void_p(rnd.data_ptr()) if rnd is not None else None, C.c_void_p(self.d_scratch.data_ptr()),
-                                 C.c_void_p(self.d_tiles.data_ptr()), C.c_void_p(self.d_off.data_ptr()),
-                                 C.c_void_p(s.d_body.data_ptr()), s.cap, C.c_void_p(s.d_info.data_ptr()), MAX_LIST,
-                                 C.c_void_p(st.cuda_stream)), 'bbx_fpack_body', self.ctx.h)
+        check(lib.bbx_fpack_body_scaled(self.ctx.h, self.ny, self.nx, C.c_void_p(img.data_ptr()), bitpix, float(quant), int(seed),
+                                        C.c_void_p(rnd.data_ptr()) if rnd is not None else None, C.c_void_p(self.d_scratch.data_ptr()),
+                                        C.c_void_p(self.d_tiles.data_ptr()), C.c_void_p(self.d_off.data_ptr()),
+                                        C.c_void_p(s.d_body.data_ptr()), s.cap, C.c_void_p(s.d_info.data_ptr()), MAX_LIST, float(scale),
+                                        C.c_void_p(st.cuda_stream)), 'bbx_fpack_body', self.ctx.h)
         # the summary by a kernel copy (the copy engines are busy with other images' 100 MB bodies)
         check(lib.bbx_copy_kernel(C.c_void_p(s.h_info.data_ptr()), C.c_void_p(s.d_info.data_ptr()), s.h_info.numel() * 8,
                                   C.c_void_p(st.cuda_stream)), 'bbx_copy_kernel')
@@ -178,16 +178,21 @@ class OutputStage:
     def new_group(self, token=None, on_done=None):
         return FrameGroup(token, on_done)
 
-    def submit(self, ctx, group, img, path, quant=None, bzero=None):
-        """queue [img] -> [path].fz.  The caller keeps [img] unchanged until the group reports the file done."""
+    def submit(self, ctx, group, img, path, quant=None, bzero=None, scale=1.0):
+        """queue [img] -> [path].fz.  The caller keeps [img] unchanged until the group reports the file done.
+        scale (float images): the file holds float32(scale) x img, multiplied as the kernel loads the pixels"""
         lane = self.lane(ctx)
         out = path if path.endswith('.fz') else path + '.fz'
         q = default_quant(path) if quant is None else quant
         if img.dtype == torch.uint16:                       # FITS stores uint16 as int16 with BZERO = 32768
             img = (img.to(torch.int32) - 32768).to(torch.int16)
             bzero = 32768
-        slot, bitpix = lane.enqueue(img, q, self.seed)
+        scale = float(np.float32(scale))
+        if scale != 1.0 and img.dtype != torch.float32:
+            raise ValueError('scale: float32 images only')
+        slot, bitpix = lane.enqueue(img, q, self.seed, scale)
         j = _Job()
+        j.scale = scale
         j.lane, j.slot, j.img, j.path, j.quant, j.seed, j.bitpix, j.shape, j.group, j.bzero = lane, slot, img, out, q, self.seed, bitpix, \
             (self.ny, self.nx), group, bzero
         with group.lock:
@@ -266,7 +271,8 @@ class OutputStage:
             header = self._header(j)
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(s.ev)
-                fpack.fpack_image(_OnStream(j.lane.ctx, copy_stream), j.path, j.img, header, j.quant, j.seed)
+                fpack.fpack_image(_OnStream(j.lane.ctx, copy_stream), j.path, j.img if j.scale == 1.0 else j.img * j.scale, header, j.quant,
+                                  j.seed)
             return
         nbody = ny * rowlen + total
         listed = np.sort(info[4:4 + nlist].copy()) if nlist else None
@@ -281,7 +287,8 @@ class OutputStage:
             rows = None
             if rbytes:
                 rows_pin = full[roff:roff + rbytes].view(torch.float32).view(nlist, nx)
-                rows_pin.copy_(j.img.index_select(0, torch.from_numpy(listed).to(j.img.device)), non_blocking=True)
+                sel = j.img.index_select(0, torch.from_numpy(listed).to(j.img.device))
+                rows_pin.copy_(sel if j.scale == 1.0 else sel * j.scale, non_blocking=True)
             cev = torch.cuda.Event()
             cev.record(copy_stream)
         wait_event(cev)

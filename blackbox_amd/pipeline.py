@@ -701,8 +701,9 @@ class FramePipeline:
             stage_lim = self.stage_limmag(f.header) if callable(self.stage_limmag) else self.stage_limmag
             if stage_lim:
                 nsig = float(sub['header_trans']['T-NSIGMA'][0])
-                lim = sub['Fpsferr'] * nsig                            # `_trans_limmag` as a flux limit (no zeropoint on this path)
-                names['limmag'] = st.submit(ctx, g, lim, base + '_trans_limmag.fits')
+                # `_trans_limmag` as a flux limit (no zeropoint on this path): T-NSIGMA x Fpsferr, multiplied by the compression
+                # kernel as it loads Fpsferr (no image of its own)
+                names['limmag'] = st.submit(ctx, g, sub['Fpsferr'], base + '_trans_limmag.fits', scale=nsig)
         f.out_names = names
         g.seal()
 

@@ -363,6 +363,12 @@ int bbx_fpack_gather(bbx_ctx *ctx, int ny, int nx, int bitpix, const uint8_t *d_
 int bbx_fpack_body(bbx_ctx *ctx, int ny, int nx, const void *d_img, int bitpix, float qlevel, int dither_seed,
                    const float *d_rnd, uint8_t *d_scratch, void *d_tiles, long long *d_offsets, uint8_t *d_body,
                    long long cap_body, long long *d_info, int max_list, void *stream);
+/* the same of [scale] x the float image (bitpix -32), the product taken as the pixels are loaded -- float32, the bytes of
+ * compressing the multiplied image: `_trans_limmag` = T-NSIGMA x Fpsferr (set_blackbox.py:160-162) is then never made as a
+ * frame of its own (a 4N write and a 4N read of HBM per frame less) */
+int bbx_fpack_body_scaled(bbx_ctx *ctx, int ny, int nx, const void *d_img, int bitpix, float qlevel, int dither_seed,
+                          const float *d_rnd, uint8_t *d_scratch, void *d_tiles, long long *d_offsets, uint8_t *d_body,
+                          long long cap_body, long long *d_info, int max_list, float scale, void *stream);
 
 
 /* ---- a1 / f2: funpack -- reading tile-compressed images (raw frames arrive as .fits.fz;

@@ -238,6 +238,20 @@ def test_gpu_one_enqueue_path_and_output_stage(tmp_path):
             got = open(str(tmp_path / ('async%d_a_%s.fits.fz' % (k, name))), 'rb').read()
             assert got == open(str(tmp_path / ('one_a_%s.fits.fz' % name)), 'rb').read(), (k, name)
     assert stage.files_written == 6
+    # `_trans_limmag` = T-NSIGMA x Fpsferr without an image of its own (submit(..., scale=)): the kernel multiplies as it loads
+    # the pixels -- the bytes of compressing the multiplied image, refused rows (NaN, constant) included
+    stage = outstage.OutputStage(ctx.device, ny, nx, nwriters=2, nslots=3, dither_seed=5)
+    t = torch.from_numpy(img).to(ctx.device)
+    want = P.fpack_image(ctx, str(tmp_path / 'mul_trans_limmag.fits'), t * 6.0, hdr, None, dither_seed=5)
+    ev2 = threading.Event()
+    with torch.cuda.stream(lane_stream):
+        g = stage.new_group('s', lambda grp: ev2.set())
+        stage.submit(ctx, g, t, str(tmp_path / 'scl_trans_limmag.fits'), scale=6.0)
+        g.seal()
+    g.set_headers({None: hdr})
+    assert ev2.wait(60.0) and g.error is None
+    stage.close()
+    assert open(str(tmp_path / 'scl_trans_limmag.fits.fz'), 'rb').read() == open(want, 'rb').read()
     ctx.close()
 
 
