@@ -786,15 +786,14 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows(fr
 // The same for both pairs in one launch (frames whose groups of four pixels are aligned): the four frames are read once;
 // the variance pair (max(N, 0) + sigma_N^2, max(R, 0) + sigma_R^2) waits in registers behind the first transform.
 // SPL (round 5, bbx_zogy_frame_mini): the sigma images do not exist as frames -- the kernel reads them off their mini images
-// (bbx_spline.h): the cubics of its NL rows on every box interval of its x range go into LDS while the pixel loads are
-// on their way, a pixel then costs one 16-byte LDS read and three multiply-adds per image instead of 8 bytes from HBM.
-#define ZSPL_NIV 80            // coefficient columns (= box intervals + the padding between two channels' patches) a sub-image's x range may span
+// (bbx_spline.h): a table of the cubics of every frame row on every box interval (k_spl_polytable, 96 MB for both maps,
+// mostly L2 hits here: the ~15 groups of four pixels of an interval read the same entry) instead of the two frames (2 x 4N
+// written, 2 x 4N x 1.125 read); a pixel costs a share of a 16-byte load and three multiply-adds per map.
 template <class P, bool SPL>
 __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_both(frame_args f, const float2* __restrict__ twg, float2* __restrict__ Ta,
                                                                                 float2* __restrict__ Tb, float2* __restrict__ Tva, float2* __restrict__ Tvb, int nsub,
                                                                                 bbx_spl spn, bbx_spl spr) {
     extern __shared__ float2 s[];
-    __shared__ float4 spoly[SPL ? 2 * P::NL * ZSPL_NIV : 1];
     WG_TASK_ROWS(P::LB, nsub, yb, sub);
     ZSTAMP_HEAD(2);
     const aux_t aux = aux_setup<P>(s + P::NL * P::LS, twg);
@@ -821,17 +820,6 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
             }
         }
         if (SPL) {
-            // the sigma maps on this workgroup's rows: cubic of every coefficient column its x range touches
-            int cmn, cmr, r_;
-            const int Xa = X0 > 0 ? X0 : 0;
-            bbx_spl_axis(Xa, spn.pw, spn.rpw, spn.px, spn.npad, spn.nx1, spn.dx, spn.rdx, cmn, r_);
-            bbx_spl_axis(Xa, spr.pw, spr.rpw, spr.px, spr.npad, spr.nx1, spr.dx, spr.rdx, cmr, r_);
-            for (int e = threadIdx.x; e < 2 * P::NL * ZSPL_NIV; e += blockDim.x) {
-                const int m = e / (P::NL * ZSPL_NIV), ll = (e / ZSPL_NIV) % P::NL, iv = e % ZSPL_NIV;
-                const int Y = Y0 + y0 + ll;
-                if (y0 + ll < P::L && Y >= 0 && Y < f.ny) spoly[e] = m ? bbx_spl_poly(spr, Y, cmr + iv) : bbx_spl_poly(spn, Y, cmn + iv);
-            }
-            __syncthreads();
 #pragma unroll
             for (int i = 0; i < NP; i++) {
                 const int e = (int)threadIdx.x + i * P::LIGHT_THREADS;
@@ -839,19 +827,23 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
                     const int q = 4 * e, ll = q / P::L, x = q - ll * P::L;
                     const int Y = Y0 + y0 + ll, X = X0 + x;
                     if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
-                        // four pixels of one patch (patch widths, X0 multiples of 4): the first pixel's interval and remainder, then steps
+                        // four pixels of one patch (patch widths, X0 multiples of 4): interval and remainder of the first, steps
+                        // for the others; the group lies in one interval or in two neighbouring ones: both cubics are loaded
                         int cn, rn, cr, rr;
                         bbx_spl_axis(X, spn.pw, spn.rpw, spn.px, spn.npad, spn.nx1, spn.dx, spn.rdx, cn, rn);
                         bbx_spl_axis(X, spr.pw, spr.rpw, spr.px, spr.npad, spr.nx1, spr.dx, spr.rdx, cr, rr);
-                        const float4* pn = spoly + ll * ZSPL_NIV - cmn;
-                        const float4* pr = spoly + (P::NL + ll) * ZSPL_NIV - cmr;
+                        const float4* tn = spn.poly + (size_t)Y * spn.cnx + cn;
+                        const float4* tr = spr.poly + (size_t)Y * spr.cnx + cr;
+                        const int stepn = (rn + 3 * spn.nx1 >= spn.dx) ? 1 : 0, stepr = (rr + 3 * spr.nx1 >= spr.dx) ? 1 : 0;
+                        const float4 pn0 = tn[0], pn1 = tn[stepn], pr0 = tr[0], pr1 = tr[stepr];
                         float sgn[4], sgr[4];
+                        bool wn = false, wr = false;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            sgn[k] = bbx_spl_horner(pn[cn], (float)rn * spn.rdx);
-                            sgr[k] = bbx_spl_horner(pr[cr], (float)rr * spr.rdx);
-                            rn += spn.nx1; if (rn >= spn.dx) { rn -= spn.dx; cn++; }
-                            rr += spr.nx1; if (rr >= spr.dx) { rr -= spr.dx; cr++; }
+                            sgn[k] = bbx_spl_horner(wn ? pn1 : pn0, (float)rn * spn.rdx);
+                            sgr[k] = bbx_spl_horner(wr ? pr1 : pr0, (float)rr * spr.rdx);
+                            rn += spn.nx1; if (rn >= spn.dx) { rn -= spn.dx; wn = true; }
+                            rr += spr.nx1; if (rr >= spr.dx) { rr -= spr.dx; wr = true; }
                         }
                         pa[i] = make_float4(sgn[0], sgn[1], sgn[2], sgn[3]); pb[i] = make_float4(sgr[0], sgr[1], sgr[2], sgr[3]);
                     }
@@ -1322,17 +1314,16 @@ static int run(bbx_ctx* ctx, const float2* d_tw, zogy_chunk_plan* plan, int ny, 
     frame_args fa; fa.a = d_new; fa.b = d_ref; fa.sa = nullptr; fa.sb = nullptr; fa.ny = ny; fa.nx = nx; fa.size = size; fa.border = border; fa.nsx = nsx;
     fa.vec4 = (size % 4 == 0 && border % 4 == 0 && nx % 4 == 0 && P::L % 4 == 0 && ((uintptr_t)d_new | (uintptr_t)d_ref | (uintptr_t)d_sig_new | (uintptr_t)d_sig_ref) % 16 == 0) ? 1 : 0;
     if (spn) {
-        // sigma maps read off their mini images: aligned groups of four pixels inside one patch, and every sub-image's x range
-        // within ZSPL_NIV coefficient columns
-        if (!fa.vec4 || spn->pw % 4 || spr->pw % 4) return BBX_ERR_ARG;
-        for (int sx = 0; sx < nsx; sx++) {
-            const int xa = sx * size - border > 0 ? sx * size - border : 0, xb = (sx * size - border + P::L < nx ? sx * size - border + P::L : nx) - 1;
-            for (const bbx_spl* sp : {spn, spr}) {
-                const int ca = (xa / sp->pw) * sp->px + ((xa % sp->pw) * sp->nx1) / sp->dx, cb = (xb / sp->pw) * sp->px + ((xb % sp->pw) * sp->nx1) / sp->dx;
-                if (cb - ca + 1 > ZSPL_NIV) return BBX_ERR_ARG;
-            }
-        }
-        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, (k_img_rows_both<P, true>), grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, T2, T3, nsub, *spn, *spr);
+        // sigma maps read off their mini images: aligned groups of four pixels inside one patch, at most one interval step
+        // inside a group (boxes wider than 3 pixels)
+        if (!fa.vec4 || spn->pw % 4 || spr->pw % 4 || 3 * spn->nx1 >= spn->dx || 3 * spr->nx1 >= spr->dx) return BBX_ERR_ARG;
+        bbx_spl tn = *spn, tr = *spr;
+        const size_t nbn = (size_t)ny * tn.cnx * sizeof(float4), nbr = (size_t)ny * tr.cnx * sizeof(float4);
+        char* tab = (char*)bbx_ws(ctx, WS_ZSPL, nbn + nbr + 256, &rc); if (rc) return rc;
+        tn.poly = (const float4*)tab; tr.poly = (const float4*)(tab + ((nbn + 255) & ~(size_t)255));
+        hipLaunchKernelGGL(k_spl_polytable, dim3((tn.cnx + 255) / 256, ny), dim3(256), 0, s, tn, ny, (float4*)tn.poly);
+        hipLaunchKernelGGL(k_spl_polytable, dim3((tr.cnx + 255) / 256, ny), dim3(256), 0, s, tr, ny, (float4*)tr.poly);
+        BBX_LAUNCH_TIMED(ctx, BBX_PROF_Z_IMG_ROWS, (k_img_rows_both<P, true>), grow, dim3(P::LIGHT_THREADS), lds, s, fa, tw, T0, T1, T2, T3, nsub, tn, tr);
     } else
 #ifndef Z3_ROWS_SPLIT
     if (fa.vec4) {
