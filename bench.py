@@ -1078,15 +1078,8 @@ def main():
                                                lanes=lanes, note='reference not background-subtracted: bkg mesh x2 per frame')
             del ref2
             section('zogy_ref_with_sky')
-            if S != 25:
-                # rounds 1-3 benched one 25 x 25 stamp for all sub-images: the stage's cost depends on S through the row window
-                # of the matched-filter kernels (4 S + 32 of L rows) and the stamp DFT
-                kw25 = dict(kws['zogy'], subtract=dict(sub_kw, psf_new=torch.from_numpy(moffat_stamp(25, 4.0)).to(dev),
-                                                       psf_ref=torch.from_numpy(moffat_stamp(25, 4.0)).to(dev)))
-                r2 = run_pipeline(torch, ctx, tel, geom, raws, kw25, 30, 4, depth, lanes, pool, barrier)
-                others['zogy_psf25'] = dict(frames_per_s=30 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 30, frames_in_flight=depth, lanes=lanes,
-                                            note='one 25 x 25 PSF stamp for all sub-images (the configuration of rounds 1-3)')
-                section('zogy_psf25')
+            # (rounds 1-4 also timed one 25 x 25 stamp for all sub-images here: the scene now follows the PSF field that ZOGY is
+            # handed, a single stamp no longer matches its stars -- the stage's dependence on S is in HISTORY.md: 0.05 ms)
         out['other_workloads'] = others
         # the stage figures next to the headline's roofline (north_star: >= 60 % of the HBM roofline on the calibration +
         # LA-Cosmic stage): frames/s of the stage workloads x their SURVEY 8d algorithmic bytes, and the launch-level

@@ -758,9 +758,11 @@ __global__ __launch_bounds__(256) void k_spline_zoom4(int ny, int nx, const doub
             typedef float zv4 __attribute__((ext_vector_type(4)));
             if (bkg) __builtin_nontemporal_store(zv4{v[0], v[1], v[2], v[3]}, reinterpret_cast<zv4*>(bkg + o));
             if (data) {
-                const float4 d = *reinterpret_cast<const float4*>((src ? src : data) + o);
+                // (streamed once in, once out: non-temporal -- plain stores of a read + write stream keep their lines in L2 and
+                // cost the reads their share of it, tools/exp/tile_bw.hip)
+                const zv4 d = __builtin_nontemporal_load(reinterpret_cast<const zv4*>((src ? src : data) + o));
                 const float r0 = d.x - v[0], r1 = d.y - v[1], r2 = d.z - v[2], r3 = d.w - v[3];
-                *reinterpret_cast<float4*>(data + o) = make_float4(r0, r1, r2, r3);
+                __builtin_nontemporal_store(zv4{r0, r1, r2, r3}, reinterpret_cast<zv4*>(data + o));
                 if (cand_list) {
                     const float rr[4] = {r0, r1, r2, r3};
                     bool hit[4]; unsigned long long hm[4]; unsigned tot = 0;

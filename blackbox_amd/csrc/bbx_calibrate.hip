@@ -14,6 +14,9 @@
 //   data /= data_mflat                   f32 (IEEE division)  blackbox.py:1825
 // Compile with -ffp-contract=off: no fused multiply-adds may be formed.
 #include "bbx_common.h"
+#ifndef CAL_NT
+#define CAL_NT 1
+#endif
 
 // ---- nonlin_corr (blackbox.py:7394-7437, off upstream): per channel,
 //   counts = data / gain[c]                       (float32 / float32)
@@ -132,8 +135,11 @@ __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
         const double vf = a.vfit[c * d.dy + rl];
         float fl[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
         uint8_t m[4] = {0, 0, 0, 0};
-        if (a.flat) { const float4 t = *(const float4*)(a.flat + o); fl[0] = t.x; fl[1] = t.y; fl[2] = t.z; fl[3] = t.w; }
-        if (a.bias) { const float4 t = *(const float4*)(a.bias + o); bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
+        // (CAL_NT: the masters and the raw frame stream through once, the outputs are written once: non-temporal, see
+        // tools/exp/tile_bw.hip -- plain stores of a read + write stream crowd the reads out of L2)
+        typedef float cv4 __attribute__((ext_vector_type(4)));
+        if (a.flat) { const cv4 t = CAL_NT ? __builtin_nontemporal_load((const cv4*)(a.flat + o)) : *(const cv4*)(a.flat + o); fl[0] = t.x; fl[1] = t.y; fl[2] = t.z; fl[3] = t.w; }
+        if (a.bias) { const cv4 t = CAL_NT ? __builtin_nontemporal_load((const cv4*)(a.bias + o)) : *(const cv4*)(a.bias + o); bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
         if (a.bpm) { const uchar4 t = *(const uchar4*)(a.bpm + o); m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w; }
         const double os[4] = {os0, os1, os2, os3};
         float ov[4];
@@ -151,8 +157,13 @@ __global__ __launch_bounds__(256) void k_calibrate_v4(calib_args a) {
             if (a.flat) v = v / fl[q];
             ov[q] = v;
         }
-        *(float4*)(a.data + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-        *(uchar4*)(a.mask + o) = make_uchar4(m[0], m[1], m[2], m[3]);
+        if (CAL_NT) {
+            __builtin_nontemporal_store(cv4{ov[0], ov[1], ov[2], ov[3]}, (cv4*)(a.data + o));
+            __builtin_nontemporal_store((unsigned)m[0] | ((unsigned)m[1] << 8) | ((unsigned)m[2] << 16) | ((unsigned)m[3] << 24), (unsigned*)(a.mask + o));
+        } else {
+            *(float4*)(a.data + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            *(uchar4*)(a.mask + o) = make_uchar4(m[0], m[1], m[2], m[3]);
+        }
     }
     // saturated-pixel queue: one reservation per wave for all the rows of the block (a returning
     // atomic per pixel on one counter retires at ~11 ns each: a frame with 1 % saturated pixels

@@ -124,6 +124,38 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return from_v(bbx_c
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return from_v(bbx_cmulc(to_v(a), to_v(b))); }   // a * conj(b)
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
 
+// Streaming accesses of the big arrays (frames, T / U tiles, the PSF spectra: written once, read once, 0.5 GB each): non-temporal.
+// Measured with the kernels' own access shape (tools/exp/tile_bw.hip: a workgroup reads 350 pieces of 128 bytes at a 22.5 KB
+// stride and writes 45 KB contiguously, 2 workgroups per CU): plain loads + plain stores 3.5 TB/s, plain loads + non-temporal
+// stores 6.1, both non-temporal 6.9 (a contiguous copy of the same shape: 5.9) -- plain stores keep their lines in the
+// XCD's L2 and push out the lines the scattered reads still need.
+#ifndef Z3_NT
+#define Z3_NT 1
+#endif
+typedef float z3_v4 __attribute__((ext_vector_type(4)));
+typedef float z3_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_nt(const float4* p) {
+#if Z3_NT
+    const z3_v4 v = __builtin_nontemporal_load(reinterpret_cast<const z3_v4*>(p)); return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_nt(float4* p, float4 v) {
+#if Z3_NT
+    __builtin_nontemporal_store(z3_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<z3_v4*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_nt(float* p, float v) {
+#if Z3_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ int npos(int n) { return n + (n >> 3); }                       // LDS position of entry n of a line
 // position of spectral index k after the forward transform (digit reversal of the in-place passes)
 template <class P> __device__ __forceinline__ int ppos(int k) {
@@ -279,7 +311,7 @@ template <class P> __device__ __forceinline__ void store_u(const float2* s, floa
     for (int e = threadIdx.x; e < P::L * HL; e += blockDim.x) {
         const int y = e / HL, l = 2 * (e - y * HL), py = npos(y);
         const float2 v0 = s[l * P::LS + py], v1 = s[(l + 1) * P::LS + py];
-        *reinterpret_cast<float4*>(base + (size_t)y * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        st_nt(reinterpret_cast<float4*>(base + (size_t)y * P::NL + l), make_float4(v0.x, v0.y, v1.x, v1.y));
     }
     if (halo) {
         for (int e = threadIdx.x; e < ch.nch * HL; e += blockDim.x) {
@@ -303,7 +335,7 @@ template <class P> __device__ __forceinline__ void store_u_win(const float2* s, 
         const float2 v0 = s[l * P::LS + py], v1 = s[(l + 1) * P::LS + py];
         const float en = (v0.x * v0.x + v0.y * v0.y) + (v1.x * v1.x + v1.y * v1.y);
         ea += en;
-        if (y < wh || y >= P::L - wh) *reinterpret_cast<float4*>(base + (size_t)y * P::NL + l) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        if (y < wh || y >= P::L - wh) st_nt(reinterpret_cast<float4*>(base + (size_t)y * P::NL + l), make_float4(v0.x, v0.y, v1.x, v1.y));
         else eo += en;
     }
     e_all += (double)ea; e_out += (double)eo;
@@ -320,7 +352,7 @@ template <class P> __device__ __forceinline__ void load_t_lines_win(const float2
     }
     for (int e = threadIdx.x; e < NVW; e += blockDim.x) {
         const int ybw = e / TV, j = e - ybw * TV, yb = ybw < wb ? ybw : P::LB - 2 * wb + ybw;
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j);
+        const float4 v = ld_nt(reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j));
         const int l = (2 * j) / P::NL, y = yb * P::NL + (2 * j) % P::NL;
         float2* line = s + l * P::LS;
         line[npos(y)] = make_float2(v.x, v.y); line[npos(y + 1)] = make_float2(v.z, v.w);
@@ -337,7 +369,7 @@ template <class P> __device__ __forceinline__ void load_t_lines(const float2* T,
 #pragma unroll
         for (int i = 0; i < TD; i++) {
             const int e = e0 + i * (int)blockDim.x;
-            if (e < NV) { const int yb = e / TV, j = e - yb * TV; v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
+            if (e < NV) { const int yb = e / TV, j = e - yb * TV; v[i] = ld_nt(reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j)); }
         }
 #pragma unroll
         for (int i = 0; i < TD; i++) {
@@ -376,7 +408,7 @@ template <class P> __device__ __forceinline__ void load_u_pair(const float2* __r
             if (e < NV) {
                 const int g = e / TV, j = e - g * TV;
                 const size_t o = base + (size_t)g * P::L * P::NL + 2 * j;
-                va[i] = *reinterpret_cast<const float4*>(Ua + o); vb[i] = *reinterpret_cast<const float4*>(Ub + o);
+                va[i] = ld_nt(reinterpret_cast<const float4*>(Ua + o)); vb[i] = ld_nt(reinterpret_cast<const float4*>(Ub + o));
             }
         }
 #pragma unroll
@@ -408,7 +440,7 @@ template <class P, int T, int I0 = 0, int I1 = 1 << 30> __device__ __forceinline
 #pragma unroll
     for (int i = I0; i < (I1 < t_regs<P, T>::N ? I1 : t_regs<P, T>::N); i++) {
         const int e = (int)threadIdx.x + i * T;
-        if (e < NV) { const int yb = e / TV, j = e - yb * TV; r.v[i] = *reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j); }
+        if (e < NV) { const int yb = e / TV, j = e - yb * TV; r.v[i] = ld_nt(reinterpret_cast<const float4*>(src + (size_t)yb * P::HP * P::NL + 2 * j)); }
     }
 }
 template <class P, int T, int I0 = 0, int I1 = 1 << 30> __device__ __forceinline__ void pack_t_lines(const t_regs<P, T>& r, float2* s) {
@@ -436,7 +468,7 @@ template <class P, int T> __device__ __forceinline__ void fetch_u_pair(const flo
         if (e < NV) {
             const int g = e / TV, j = e - g * TV;
             const size_t o = base + (size_t)g * P::L * P::NL + 2 * j;
-            r.a[i] = *reinterpret_cast<const float4*>(Ua + o); r.b[i] = *reinterpret_cast<const float4*>(Ub + o);
+            r.a[i] = ld_nt(reinterpret_cast<const float4*>(Ua + o)); r.b[i] = ld_nt(reinterpret_cast<const float4*>(Ub + o));
         }
     }
 }
@@ -468,8 +500,8 @@ template <class P> __device__ __forceinline__ void store_t_split(const float2* s
 #pragma unroll
         for (int r = 0; r < P::NL; r += 2) {
             const float2 zk0 = s[r * P::LS + pk], zm0 = s[r * P::LS + pm], zk1 = s[(r + 1) * P::LS + pk], zm1 = s[(r + 1) * P::LS + pm];
-            ta[r / 2] = make_float4(0.5f * (zk0.x + zm0.x), 0.5f * (zk0.y - zm0.y), 0.5f * (zk1.x + zm1.x), 0.5f * (zk1.y - zm1.y));
-            tb[r / 2] = make_float4(0.5f * (zk0.y + zm0.y), 0.5f * (zm0.x - zk0.x), 0.5f * (zk1.y + zm1.y), 0.5f * (zm1.x - zk1.x));
+            st_nt(ta + r / 2, make_float4(0.5f * (zk0.x + zm0.x), 0.5f * (zk0.y - zm0.y), 0.5f * (zk1.x + zm1.x), 0.5f * (zk1.y - zm1.y)));
+            st_nt(tb + r / 2, make_float4(0.5f * (zk0.y + zm0.y), 0.5f * (zm0.x - zk0.x), 0.5f * (zk1.y + zm1.y), 0.5f * (zm1.x - zk1.x)));
         }
     }
 }
@@ -622,7 +654,7 @@ __global__ __launch_bounds__(P::THREADS, P::MINW_PSF) void k_psf_cols(const floa
         }
         // k_img_cols gets the two spectra themselves (16 bytes per entry, one load) and forms 1 / sqrt(den) and the
         // coefficients of D^, S_n^, S_r^ from them again (rounds 3-4: A, B and sqrt(den), 20 bytes in three loads)
-        cP[cbase + e] = cp;
+        st_nt(cP + cbase + e, cp);
         s[l * P::LS + npos(p)] = kr;
         park[k] = kn;
     }
@@ -744,7 +776,7 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows(fr
                     if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
                         const size_t o = (size_t)Y * f.nx + X;
                         in[i] = true;
-                        va[i] = *reinterpret_cast<const float4*>(f.a + o); vb[i] = *reinterpret_cast<const float4*>(f.b + o);
+                        va[i] = ld_nt(reinterpret_cast<const float4*>(f.a + o)); vb[i] = ld_nt(reinterpret_cast<const float4*>(f.b + o));
                         if (f.sa) {
                             const float4 p = *reinterpret_cast<const float4*>(f.sa + o), q4 = *reinterpret_cast<const float4*>(f.sb + o);
                             va[i] = make_float4(fmaxf(va[i].x, 0.f) + p.x * p.x, fmaxf(va[i].y, 0.f) + p.y * p.y, fmaxf(va[i].z, 0.f) + p.z * p.z,
@@ -814,8 +846,8 @@ __global__ __launch_bounds__(P::LIGHT_THREADS, P::MINW_LIGHT) void k_img_rows_bo
                 const int Y = Y0 + y0 + ll, X = X0 + x;
                 if (y0 + ll < P::L && Y >= 0 && Y < f.ny && X >= 0 && X < f.nx) {
                     const size_t o = (size_t)Y * f.nx + X;
-                    va[i] = *reinterpret_cast<const float4*>(f.a + o); vb[i] = *reinterpret_cast<const float4*>(f.b + o);
-                    if (!SPL) { pa[i] = *reinterpret_cast<const float4*>(f.sa + o); pb[i] = *reinterpret_cast<const float4*>(f.sb + o); }
+                    va[i] = ld_nt(reinterpret_cast<const float4*>(f.a + o)); vb[i] = ld_nt(reinterpret_cast<const float4*>(f.b + o));
+                    if (!SPL) { pa[i] = ld_nt(reinterpret_cast<const float4*>(f.sa + o)); pb[i] = ld_nt(reinterpret_cast<const float4*>(f.sb + o)); }
                 }
             }
         }
@@ -932,14 +964,14 @@ __global__ __launch_bounds__(P::THREADS, P::MINW) void k_img_cols(const float2* 
     {
         const int t = opaque_tid();
 #pragma unroll
-        for (int k = 0; k < NC0; k++) c0[k] = cP[cbase + min(t + k * RT, P::NL * P::L - 1)];
+        for (int k = 0; k < NC0; k++) c0[k] = ld_nt(cP + cbase + min(t + k * RT, P::NL * P::L - 1));
     }
     fft_fwd<P>(s, tw);
     ZSTAMP(3, 4);
     {
         const int t = opaque_tid();
 #pragma unroll
-        for (int k = NC0; k < NE; k++) c1[k - NC0] = cP[cbase + min(t + k * RT, P::NL * P::L - 1)];
+        for (int k = NC0; k < NE; k++) c1[k - NC0] = ld_nt(cP + cbase + min(t + k * RT, P::NL * P::L - 1));
     }
     const zscal z = sc[sub];
     const float cn = (z.sr * z.sr) * (z.fn * z.fn), cr = (z.sn * z.sn) * (z.fr * z.fr);      // den = cr |Pr^|^2 + cn |Pn^|^2
@@ -1137,7 +1169,7 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
                 if (xi < o.size) {
                     const float2 v = s[l * P::LS + npos(o.border + xi)];
                     vsr[l][k] = v.y * vscale;
-                    if (rowok && Xf < o.nx) o.D[(size_t)Y * o.nx + Xf] = v.x * ifD;
+                    if (rowok && Xf < o.nx) st_nt(o.D + (size_t)Y * o.nx + Xf, v.x * ifD);
                 }
             }
         }
@@ -1165,14 +1197,14 @@ __global__ __launch_bounds__(P::FIN_THREADS, P::FIN_MINW) void k_final_rows(cons
                 const float vast = dx2 * (dSndx * dSndx + dSrdx * dSrdx) + dy2 * (dSndy * dSndy + dSrdy * dSrdy);
                 const float vs = vsr[l][k];
                 const size_t q = (size_t)Y * o.nx + Xf;
-                if (o.S) o.S[q] = sval;
+                if (o.S) st_nt(o.S + q, sval);
 #ifndef Z3_EXACT_SQRT
                 // v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded division and square roots (~30 instructions per
                 // pixel: 8 % of this kernel); the transforms in front are good to ~1e-6 of the image scale
                 const float scv = sval * __builtin_amdgcn_rsqf(vs + vast);
-                o.Scorr[q] = scv;
-                o.Fpsf[q] = sval * ifs;
-                o.Fpsferr[q] = __builtin_amdgcn_sqrtf(fmaxf(vs, 0.f)) * ifs;
+                st_nt(o.Scorr + q, scv);
+                st_nt(o.Fpsf + q, sval * ifs);
+                st_nt(o.Fpsferr + q, __builtin_amdgcn_sqrtf(fmaxf(vs, 0.f)) * ifs);
 #else
                 const float scv = sval / sqrtf(vs + vast);
                 o.Scorr[q] = scv;
