@@ -133,6 +133,36 @@ __device__ __forceinline__ void fp_wave_sort1024(uint32_t (&k)[16], int lane) {
     }
 }
 
+// (the result of an asm statement counts as a per-lane value: without this a population count of the mask is done in the
+// vector unit, two instructions per word and one more to add)
+__device__ __forceinline__ unsigned long long fp_uniform64(unsigned long long m) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}
+// the lanes with a <= b as a mask, straight from the compare (a ballot of a condition that also guards a branch is
+// otherwise rebuilt from a 0 / 1 register: two more vector instructions per key in the median count)
+__device__ __forceinline__ unsigned long long fp_mask_le(unsigned a, unsigned b) {
+    unsigned long long m;
+    asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
+    return fp_uniform64(m);
+}
+
+// a for the lanes outside the mask, b for the lanes in it
+__device__ __forceinline__ unsigned fp_select(unsigned long long mask, unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+typedef float fp_v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) unsigned fp_lds_u32;
+// a - b and the lanes where it borrows (a < b)
+__device__ __forceinline__ unsigned fp_sub_borrow(unsigned a, unsigned b, unsigned long long& borrow) {
+    unsigned r;
+    unsigned long long m;
+    asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(m) : "v"(a), "s"(b));
+    borrow = fp_uniform64(m);
+    return r;
+}
+
 // ---- the bit stream of a row is written by threads that own runs of 8 pixels: a thread assembles its codes in a 64-bit
 // window and stores whole words; only the first and the last word of its run can be shared with a neighbour (atomic OR
 // into the zeroed buffer).  One LDS atomic per thread and end instead of two to four per pixel.
@@ -183,7 +213,10 @@ struct fp_bitw {
 #define FP_SAMP_HALF 48
 #define FP_MIN_ND 4096             // shorter rows: histogram passes (the bracket of a 1024-key sample is no gain there)
 #define FP_MIN_SEG 64              // smallest per-wave segment the bracket path is used with
+#define FP_BR_BITS 9               // the bracket's histogram: 512 bins (two 16-bit counters per word) over the ~5 % of a row's keys inside
+#define FP_BR_WORDS 256
 #define FP_HINT_FRAC 0.06f          // bracket around a hinted median: -/+ 6 %
+#define FP_FAST_NMAX 14u            // longest code word of the pair / quad writer: 4 of them + the fs field stay below 64 bits
 #define FP_HINT_VALID 0x80000000u  // (keys are bit patterns of non-negative floats: the top bit is free)
 // Hints: neighbouring rows of an image have nearly the same noise.  Every workgroup leaves its three exact medians in
 // hint[row][3] (relaxed agent-scope atomics, the top bit marks a written word), and starts from the medians of the row one
@@ -198,7 +231,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                                                  int capwords, int hist_only, unsigned* __restrict__ hint, int gen, float in_scale) {
     typedef rice_par<BYTEPIX> RP;
     extern __shared__ __align__(16) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (a scalar: loops over a wave's share stay uniform)
     // MODE 0 / 1: one workgroup per row.  MODE 2: a small grid; workgroup b looks through the flags of rows b, b + G, b + 2 G, ...
     // (64 at a time, a thread each) and takes the marked ones in turn.  Until round 4 this launch had a workgroup per row of
     // the image, each asking for the worst-case LDS only to find its row unmarked: 0.6 ms of a stream's time per image when
@@ -229,12 +262,12 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
     unsigned* words = reinterpret_cast<unsigned*>(vals + ((nx + 3) & ~3));
     unsigned* blkbits = words + maxwords;
     uint8_t* fsv = reinterpret_cast<uint8_t*>(blkbits + nblk + 1);
-    __shared__ unsigned hist[3][1024];                              // 2048 bins each: two 16-bit counters per word; first the samples
+    __shared__ __align__(16) unsigned hist[3][1024];                              // 2048 bins each: two 16-bit counters per word; first the samples
     __shared__ unsigned coll[3][FP_NCOLL], ncoll[3];
     __shared__ int s_many, s_fail, s_hint_ok;
     __shared__ unsigned sel_prefix[3], sel_rank[3];
     __shared__ unsigned br_lo[3], br_hi[3], br_need[3], br_shift[3];
-    __shared__ unsigned segn[3][FP_THREADS / 64], cpart[FP_THREADS / 64][9];
+    __shared__ unsigned segn[3][FP_THREADS / 64], cpart[FP_THREADS / 64][3];
     __shared__ float red_min[FP_THREADS / 64], red_max[FP_THREADS / 64];
     __shared__ double s_delta, s_zero;
     __shared__ int s_flag;
@@ -347,81 +380,111 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                 }
             }
             __syncthreads();
-            const unsigned lo0 = br_lo[0], hi0 = br_hi[0], lo1 = br_lo[1], hi1 = br_hi[1], lo2 = br_lo[2], hi2 = br_hi[2];
-            unsigned c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                   // per kind: keys < lo, == lo, == hi (hi != lo)
+            const unsigned lo0 = __builtin_amdgcn_readfirstlane(br_lo[0]), lo1 = __builtin_amdgcn_readfirstlane(br_lo[1]), lo2 = __builtin_amdgcn_readfirstlane(br_lo[2]);
+            const unsigned sp0 = __builtin_amdgcn_readfirstlane(br_hi[0]) - lo0, sp1 = __builtin_amdgcn_readfirstlane(br_hi[1]) - lo1,
+                           sp2 = __builtin_amdgcn_readfirstlane(br_hi[2]) - lo2;      // (hi >= lo: order statistics / a hint's -/+ 6 %)
+            // Per kind a wave counts its keys >= lo (ballot + scalar population count: no vector work besides the compare) and
+            // compacts the keys inside [lo, hi], ends included, into its segment.  (Round 4 counted < lo, == lo, == hi per lane
+            // -- nine counters and nine wave reductions per thread.)
+            unsigned lt0 = 0, lt1 = 0, lt2 = 0;                            // wave-uniform: keys < lo
             unsigned base0 = 0, base1 = 0, base2 = 0;                      // wave-uniform fill of this wave's segments
-            unsigned* seg0 = seg + (0 * (FP_THREADS / 64) + wave) * segcap;
-            unsigned* seg1 = seg + (1 * (FP_THREADS / 64) + wave) * segcap;
-            unsigned* seg2 = seg + (2 * (FP_THREADS / 64) + wave) * segcap;
-#ifdef FPV_NOB3
-            for (int i0 = wave * 64; i0 < 1024; i0 += FP_THREADS) {
+            const unsigned off0 = (unsigned)((0 * (FP_THREADS / 64) + wave) * segcap), off1 = (unsigned)((1 * (FP_THREADS / 64) + wave) * segcap),
+                           off2 = (unsigned)((2 * (FP_THREADS / 64) + wave) * segcap);
+            unsigned* seg0 = seg + off0;
+            unsigned* seg1 = seg + off1;
+            unsigned* seg2 = seg + off2;
+            // (a) Whole blocks of 128 keys, two neighbouring keys per lane: the differences in packed float32 arithmetic (the
+            // products by 2 and 4 are exact, so fma(-4, v3, 6 v5) rounds once like CFITSIO's (6 v5) - (4 v3)), and every lane
+            // stores -- the lanes outside the bracket into 64 spare words behind the stream buffer (blkbits, unused until the
+            // Rice pass) -- so that the store needs no second compare and no branch.
+            const unsigned seg_lds = (unsigned)(uintptr_t)(fp_lds_u32*)seg;                // the segments' address inside the LDS
+            const unsigned trash = seg_lds + 4u * ((unsigned)maxwords + (unsigned)lane);
+#ifndef FPV_NOB3
+            const int nblk128 = nd >> 7;
 #else
-            for (int i0 = wave * 64; i0 < nd; i0 += FP_THREADS) {         // (wave-uniform trip count: ballots inside)
+            const int nblk128 = 8;
+#endif
+#define FP_BRACKET2(K, LO, SPAN, LT, BASE, OFF)                                                                         \
+                {                                                                                                       \
+                    unsigned long long below;                              /* the lanes with K < lo: the subtraction's borrow */ \
+                    const unsigned rel = fp_sub_borrow(K, LO, below);                                                   \
+                    LT += (unsigned)__popcll(below);                                                                    \
+                    const unsigned long long bal = fp_mask_le(rel, SPAN);  /* (rel wraps below lo) */                   \
+                    const unsigned cnt = (unsigned)__popcll(bal);                                                       \
+                    if (BASE + cnt <= (unsigned)segcap) {                  /* (wave-uniform; past it the kind fails anyway) */ \
+                        const unsigned at = __builtin_amdgcn_readfirstlane(seg_lds + 4u * (OFF + BASE));   /* (kept scalar) */ \
+                        const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)); \
+                        *reinterpret_cast<fp_lds_u32*>((uintptr_t)fp_select(bal, trash, (pos << 2) + at)) = K;          \
+                    }                                                                                                   \
+                    BASE += cnt;                                                                                        \
+                }
+            for (int blk = wave; blk < nblk128; blk += FP_THREADS / 64) {
+                const fp_v2f* pv = reinterpret_cast<const fp_v2f*>(fv + 128 * blk + 2 * lane);
+                const fp_v2f v1 = pv[0], v3 = pv[1], v5 = pv[2], v7 = pv[3], v9 = pv[4];
+                const fp_v2f d2 = v5 - v7;
+                const fp_v2f d3 = __builtin_elementwise_fma(fp_v2f{2.f, 2.f}, v5, -v3) - v7;
+                const fp_v2f d5 = __builtin_elementwise_fma(fp_v2f{-4.f, -4.f}, v7, __builtin_elementwise_fma(fp_v2f{-4.f, -4.f}, v3, v5 * 6.f)) + v1 + v9;
+                const unsigned k2a = __float_as_uint(d2.x) & 0x7fffffffu, k2b = __float_as_uint(d2.y) & 0x7fffffffu;
+                const unsigned k3a = __float_as_uint(d3.x) & 0x7fffffffu, k3b = __float_as_uint(d3.y) & 0x7fffffffu;
+                const unsigned k5a = __float_as_uint(d5.x) & 0x7fffffffu, k5b = __float_as_uint(d5.y) & 0x7fffffffu;
+                FP_BRACKET2(k2a, lo0, sp0, lt0, base0, off0)
+                FP_BRACKET2(k2b, lo0, sp0, lt0, base0, off0)
+                FP_BRACKET2(k3a, lo1, sp1, lt1, base1, off1)
+                FP_BRACKET2(k3b, lo1, sp1, lt1, base1, off1)
+                FP_BRACKET2(k5a, lo2, sp2, lt2, base2, off2)
+                FP_BRACKET2(k5b, lo2, sp2, lt2, base2, off2)
+            }
+#undef FP_BRACKET2
+            // (b) the keys behind the last whole block, one per lane, by the wave whose turn that block would have been
+#ifndef FPV_NOB3
+            for (int i0 = 128 * nblk128; i0 < nd && wave == (nblk128 & (FP_THREADS / 64 - 1)); i0 += 64) {
+#else
+            for (int i0 = 128 * nblk128; i0 < 0; i0 += 64) {
 #endif
                 const int i = i0 + lane;
-#define FP_BRACKET(K, LO, HI, C0, BASE, SEG)                                                                            \
+#define FP_BRACKET(K, LO, SPAN, GE, BASE, SEG)                                                                          \
                 {                                                                                                       \
-                    c[C0] += (in && K < LO) ? 1u : 0u; c[C0 + 1] += (in && K == LO) ? 1u : 0u;                          \
-                    c[C0 + 2] += (in && K == HI && HI != LO) ? 1u : 0u;                                                 \
-                    const bool inb = in && K > LO && K < HI;                                                            \
-                    const unsigned long long bal = __ballot(inb);                                                       \
+                    GE += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(in && K < LO));                                \
+                    const bool inb = in && K - LO <= SPAN;                                                              \
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(inb);                                    \
                     const unsigned pos = BASE + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)); \
                     if (inb && pos < (unsigned)segcap) SEG[pos] = K;                                                    \
                     BASE += (unsigned)__popcll(bal);                                                                    \
                 }
-#define FP_COUNT_ROUND                                                                                                  \
-                {                                                                                                       \
-                    FP_KEYS(ii)                                                                                         \
-                    FP_BRACKET(k2, lo0, hi0, 0, base0, seg0)                                                            \
-                    FP_BRACKET(k3, lo1, hi1, 3, base1, seg1)                                                            \
-                    FP_BRACKET(k5, lo2, hi2, 6, base2, seg2)                                                            \
-                }
-                if (i0 + 64 <= nd) {                                       // (wave-uniform) all 64 keys inside the row: no bounds in the round
-                    constexpr bool in = true;
-                    const int ii = i;
-                    FP_COUNT_ROUND
-                } else {
-                    const bool in = i < nd;
-                    const int ii = in ? i : 0;
-                    FP_COUNT_ROUND
-                }
-#undef FP_COUNT_ROUND
+                const bool in = i < nd;
+                const int ii = in ? i : 0;
+                FP_KEYS(ii)
+                FP_BRACKET(k2, lo0, sp0, lt0, base0, seg0)
+                FP_BRACKET(k3, lo1, sp1, lt1, base1, seg1)
+                FP_BRACKET(k5, lo2, sp2, lt2, base2, seg2)
 #undef FP_BRACKET
             }
-#pragma unroll
-            for (int q = 0; q < 9; q++) {
-                unsigned v = c[q];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
-                c[q] = v;
-            }
             if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 9; q++) cpart[wave][q] = c[q];
+                cpart[wave][0] = lt0; cpart[wave][1] = lt1; cpart[wave][2] = lt2;                      // keys < lo
                 segn[0][wave] = base0; segn[1][wave] = base1; segn[2][wave] = base2;
-                if (base0 > (unsigned)segcap || base1 > (unsigned)segcap || base2 > (unsigned)segcap) s_fail = 1;
             }
-            for (int i = tid; i < 3 * 1024; i += FP_THREADS) (&hist[0][0])[i] = 0;      // (the samples are done with)
+            for (int i = tid; i < 3 * FP_BR_WORDS; i += FP_THREADS) hist[i / FP_BR_WORDS][i % FP_BR_WORDS] = 0;      // (the samples are done with)
             __syncthreads();
             if (tid < 3) {
-                unsigned lt = 0, eql = 0, eqh = 0, nin = 0;
-                for (int w = 0; w < FP_THREADS / 64; w++) { lt += cpart[w][3 * tid]; eql += cpart[w][3 * tid + 1]; eqh += cpart[w][3 * tid + 2]; nin += segn[tid][w]; }
+                unsigned lt = 0, nin = 0;
+                bool over = false;                                         // a segment of this kind did not hold its keys
+                for (int w = 0; w < FP_THREADS / 64; w++) { lt += cpart[w][tid]; nin += segn[tid][w]; over |= segn[tid][w] > (unsigned)segcap; }
                 const unsigned r = sel_rank[tid], lo = br_lo[tid], hi = br_hi[tid];
                 unsigned need = 0;
 #ifdef FPV_NOST2
                 if (true) sel_prefix[tid] = __float_as_uint(tid == 0 ? 8.6f : (tid == 1 ? 14.9f : 50.8f));
                 else
 #endif
-                if (r < lt) s_fail = 1;
-                else if (r < lt + eql) sel_prefix[tid] = lo;
-                else if (r < lt + eql + nin) {
+                if (r < lt || r >= lt + nin) s_fail = 1;                   // the median lies outside the bracket
+                else if (hi == lo) sel_prefix[tid] = lo;                   // (every key inside is the same value)
+                else if (over) s_fail = 1;
+                else {
                     need = 1;
-                    sel_rank[tid] = r - lt - eql;
-                    const unsigned span = hi - lo - 2u;                    // keys inside: lo + 1 .. hi - 1 -> rel = key - lo - 1 in [0, span]
-                    const int bits = span ? 32 - __clz((int)span) : 0;
-                    br_shift[tid] = bits > 11 ? (unsigned)(bits - 11) : 0u;
-                } else if (r < lt + eql + nin + eqh) sel_prefix[tid] = hi;
-                else s_fail = 1;
+                    sel_rank[tid] = r - lt;
+                    const unsigned span = hi - lo;                         // keys inside: lo .. hi -> rel = key - lo in [0, span]
+                    const int bits = 32 - __clz((int)span);
+                    br_shift[tid] = bits > FP_BR_BITS ? (unsigned)(bits - FP_BR_BITS) : 0u;
+                }
 #ifdef FPV_NOB3
                 s_fail = 0; need = 0; sel_prefix[tid] = __float_as_uint(tid == 0 ? 8.6f : (tid == 1 ? 14.9f : 50.8f));
 #endif
@@ -429,20 +492,22 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             }
             __syncthreads();
             if (!s_fail) {                                                 // workgroup-uniform
-                // histogram of the collected keys on (key - lo - 1) >> shift: every wave its own segments
+                // histogram of the collected keys on (key - lo) >> shift: every wave its own segments
 #pragma unroll 1
                 for (int kd = 0; kd < 3; kd++) {
                     if (!br_need[kd]) continue;
                     const unsigned n = segn[kd][wave], lo = br_lo[kd], sh = br_shift[kd];
                     const unsigned* sg = seg + (kd * (FP_THREADS / 64) + wave) * segcap;
-                    for (unsigned j = lane; j < n; j += 64) { const unsigned d = (sg[j] - lo - 1u) >> sh; atomicAdd(&hist[kd][d >> 1], 1u << ((d & 1u) * 16)); }
+                    for (unsigned j = lane; j < n; j += 64) { const unsigned d = (sg[j] - lo) >> sh; atomicAdd(&hist[kd][d >> 1], 1u << ((d & 1u) * 16)); }
                 }
                 __syncthreads();
-                if (tid < 192 && br_need[tid >> 6]) {                      // one wave per histogram, 32 bins (16 words) per lane
+                if (tid < 192 && br_need[tid >> 6]) {                      // one wave per histogram, 8 bins (4 words) per lane
                     const int kd = tid >> 6;
-                    unsigned cw[16], mine = 0;
+                    const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[kd][4 * lane]);
+                    const unsigned cb[8] = {h4.x & 0xffffu, h4.x >> 16, h4.y & 0xffffu, h4.y >> 16, h4.z & 0xffffu, h4.z >> 16, h4.w & 0xffffu, h4.w >> 16};
+                    unsigned mine = 0;
 #pragma unroll
-                    for (int w = 0; w < 16; w++) { cw[w] = hist[kd][16 * lane + w]; mine += (cw[w] & 0xffffu) + (cw[w] >> 16); }
+                    for (int w = 0; w < 8; w++) mine += cb[w];
                     unsigned incl = mine;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -450,11 +515,10 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                     if (r >= excl && r < incl) {                           // the one lane whose bins hold the rank
                         unsigned rr = r - excl, b = 0, found = 0;
 #pragma unroll
-                        for (int w = 0; w < 32; w++) {
-                            const unsigned cnt = (w & 1) ? (cw[w >> 1] >> 16) : (cw[w >> 1] & 0xffffu);
-                            const bool here = !found && rr < cnt;
-                            if (here) { b = 32u * lane + w; found = 1; }
-                            if (!found) rr -= cnt;
+                        for (int w = 0; w < 8; w++) {
+                            const bool here = !found && rr < cb[w];
+                            if (here) { b = 8u * lane + w; found = 1; }
+                            if (!found) rr -= cb[w];
                         }
                         sel_rank[kd] = rr;
                         sel_prefix[kd] = b;                                // the bin for now
@@ -468,7 +532,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                     const unsigned* sg = seg + (kd * (FP_THREADS / 64) + wave) * segcap;
                     for (unsigned j = lane; j < n; j += 64) {
                         const unsigned key = sg[j];
-                        if (((key - lo - 1u) >> sh) == bin) { const unsigned q = atomicAdd(&ncoll[kd], 1u); if (q < FP_NCOLL) coll[kd][q] = key; }
+                        if (((key - lo) >> sh) == bin) { const unsigned q = atomicAdd(&ncoll[kd], 1u); if (q < FP_NCOLL) coll[kd][q] = key; }
                     }
                 }
                 __syncthreads();
@@ -641,10 +705,21 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             const int is1 = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
             const int start0 = (int)((double)rnd[iseed] * 500.), start1 = (int)((double)rnd[is1] * 500.);
             const int n0 = FP_NRANDOM - start0, n1 = FP_NRANDOM - start1;
+            // CFITSIO divides by delta in float64.  Here the quotient comes from a multiplication by 1 / delta -- off by an
+            // ulp or two of the quotient at most, which changes the integer only when the value about to be truncated lies
+            // within ~2^-18 of an integer (|quotient| < 2^32: an ulp is below 2^-20): those pixels, one in 10^5, take the
+            // division.  Same integers as fp_nint(((x - zero) / delta) + r - 0.5) for every pixel.
+            const double rdelta = 1.0 / delta;
             for (int i = tid; i < nx; i += FP_THREADS) {
                 const int j = i - n0;
                 const int ri = j < 0 ? start0 + i : (j < n1 ? start1 + j : fp_rand_index(rnd, iseed, i));
-                vals[i] = fp_nint((((double)fv[i] - zeropt) / delta) + (double)rnd[ri] - 0.5);
+                const double x = (double)fv[i] - zeropt, r = (double)rnd[ri];
+                const double y = fma(x, rdelta, r) - 0.5;
+                const double z = y + copysign(0.5, y);                    // (fp_nint's two branches)
+                const double fr = __builtin_amdgcn_fract(z);
+                int qv = (int)z;
+                if (!(fr > 0x1p-17 && fr < 1.0 - 0x1p-17)) qv = fp_nint((x / delta) + r - 0.5);
+                vals[i] = qv;
             }
         }
 #endif
@@ -661,7 +736,11 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
         }
         if (tid == 0) { out->zscale = 1.0; out->zzero = 0.0; out->flag = 0; }
     }
-    for (int i = tid; i < maxwords; i += FP_THREADS) words[i] = 0;
+    {   // (words starts 16-byte aligned: vals holds a multiple of 4 ints)
+        uint4* w4 = reinterpret_cast<uint4*>(words);
+        for (int i = tid; i < (maxwords >> 2); i += FP_THREADS) w4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < (maxwords & 3)) words[(maxwords & ~3) + tid] = 0;
+    }
     __syncthreads();
 
     // ---- pass 1: a thread takes 8 consecutive pixels, the 4 threads of a quad one 32-pixel block (the last block of a row
@@ -673,6 +752,12 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int q = tid + it * FP_THREADS, b = q >> 2;
+        if (it * FP_THREADS + 64 * wave >= 4 * nblk) {               // (wave-uniform) no block of the row in this wave's runs
+#pragma unroll
+            for (int j = 0; j < 8; j++) dd[it][j] = 0;
+            ioff[it] = 0;
+            continue;
+        }
         unsigned long long ps = 0;
         int prev = (8 * q - 1 < nx) ? vals[q ? 8 * q - 1 : 0] : 0;
         const bool full = 8 * q + 8 <= nx;                           // all 8 pixels inside the row: every run but the last one or two
@@ -765,6 +850,61 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int q = tid + it * FP_THREADS, b = q >> 2;
+        if (it * FP_THREADS + (tid & ~63) >= nq) continue;           // (wave-uniform) the whole wave lies beyond the row
+#ifndef FPV_NOFASTW
+        if (!hist_only) {
+            // The common case, decided per wave: every run of the wave has its 8 pixels inside the row, a split level (no
+            // all-zero block, no block of raw pixels) and code words of at most FP_FAST_NMAX bits.  Then two code words make
+            // a 32-bit pair, two pairs a 64-bit quad -- fixed shifts by the lengths, no window, no flush test per pixel --,
+            // the block's fs field rides in front of its first quad, and the run's two quads go into the stream as five
+            // words at most: whole words stored, the two end words OR-ed (a neighbour's run may share them).  Same bits as
+            // the window below makes; rows of stars and the row's ends take that one.
+            const bool act = q < nq;
+            const int code = act ? (int)fsv[b] : 1;
+            if (!__all(!act || (8 * q + 8 <= nx && code >= 1 && code <= RP::fsmax))) goto window;     // (wave-uniform)
+            const int fs = code - 1;
+            const unsigned lowmask = (1u << (fs & 31)) - 1u, bit = 1u << (fs & 31);
+            unsigned pr[4], mp[4], nmax = 0;                           // pairs of code words and their lengths
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned d0 = dd[it][2 * k], d1 = dd[it][2 * k + 1];
+                const unsigned n0 = (d0 >> (fs & 31)) + (unsigned)(fs + 1), n1 = (d1 >> (fs & 31)) + (unsigned)(fs + 1);
+                nmax = max(nmax, max(n0, n1));
+                pr[k] = (((d0 & lowmask) | bit) << (n1 & 31u)) | ((d1 & lowmask) | bit);
+                mp[k] = n0 + n1;
+            }
+            if (__all(!act || nmax <= FP_FAST_NMAX)) {                                          // (all 64 lanes are here: the loop is wave-uniform)
+                if (act) {
+                    const unsigned p01 = pr[0], p23 = pr[1], p45 = pr[2], p67 = pr[3], m01 = mp[0], m23 = mp[1], m45 = mp[2], m67 = mp[3];
+                    unsigned long long q0 = ((unsigned long long)p01 << m23) | p23, q1 = ((unsigned long long)p45 << m67) | p67;
+                    unsigned m0 = m01 + m23;                          // 4 .. 4 FP_FAST_NMAX bits
+                    const unsigned m1 = m45 + m67;
+                    if (sub == 0) { q0 |= (unsigned long long)(unsigned)code << m0; m0 += RP::fsbits; }
+                    if (q == 0) {                                     // the row's first pixel as it is, in front of block 0
+                        unsigned first = (unsigned)vals[0];
+                        if (BYTEPIX == 1) first &= 0xffu;
+                        if (BYTEPIX == 2) first &= 0xffffu;
+                        atomicOr(&words[0], first << (32 - 8 * BYTEPIX));
+                    }
+                    const unsigned P = blkbits[b] + (sub ? RP::fsbits + ioff[it] : 0u);
+                    const unsigned long long A = q0 << (64u - m0), B = q1 << (64u - m1);      // left-aligned
+                    const unsigned long long Chi = A | (B >> m0), Clo = B << (64u - m0);     // 128 bits, the run's first bit on top
+                    const unsigned c0 = (unsigned)(Chi >> 32), c1 = (unsigned)Chi, c2 = (unsigned)(Clo >> 32), c3 = (unsigned)Clo;
+                    const unsigned o = P & 31u, end = o + m0 + m1;
+                    unsigned* wp = words + (P >> 5);
+                    const unsigned T0 = c0 >> o, T1 = __builtin_amdgcn_alignbit(c0, c1, o), T2 = __builtin_amdgcn_alignbit(c1, c2, o),
+                                   T3 = __builtin_amdgcn_alignbit(c2, c3, o), T4 = __builtin_amdgcn_alignbit(c3, 0u, o);
+                    if (o == 0u && end >= 32u) wp[0] = T0; else atomicOr(&wp[0], T0);
+                    if (end >= 64u) wp[1] = T1; else if (end > 32u) atomicOr(&wp[1], T1);
+                    if (end >= 96u) wp[2] = T2; else if (end > 64u) atomicOr(&wp[2], T2);
+                    if (end >= 128u) wp[3] = T3; else if (end > 96u) atomicOr(&wp[3], T3);
+                    if (end > 128u) atomicOr(&wp[4], T4);
+                }
+                continue;
+            }
+        }
+      window:
+#endif
         if (q >= nq) continue;
         const int code = fsv[b];
         fp_bitw bw;
