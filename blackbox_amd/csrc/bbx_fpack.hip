@@ -153,6 +153,9 @@ __device__ __forceinline__ unsigned fp_select(unsigned long long mask, unsigned 
     return r;
 }
 typedef float fp_v2f __attribute__((ext_vector_type(2)));
+// the value of lane ^ 1 / lane ^ 2 (DPP quad permutes: one vector instruction, no LDS)
+__device__ __forceinline__ unsigned fp_quad_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned fp_quad_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
 typedef __attribute__((address_space(3))) unsigned fp_lds_u32;
 // a - b and the lanes where it borrows (a < b)
 __device__ __forceinline__ unsigned fp_sub_borrow(unsigned a, unsigned b, unsigned long long& borrow) {
@@ -705,21 +708,25 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             const int is1 = (iseed + 1 == FP_NRANDOM) ? 0 : iseed + 1;
             const int start0 = (int)((double)rnd[iseed] * 500.), start1 = (int)((double)rnd[is1] * 500.);
             const int n0 = FP_NRANDOM - start0, n1 = FP_NRANDOM - start1;
-            // CFITSIO divides by delta in float64.  Here the quotient comes from a multiplication by 1 / delta -- off by an
-            // ulp or two of the quotient at most, which changes the integer only when the value about to be truncated lies
-            // within ~2^-18 of an integer (|quotient| < 2^32: an ulp is below 2^-20): those pixels, one in 10^5, take the
-            // division.  Same integers as fp_nint(((x - zero) / delta) + r - 0.5) for every pixel.
+            // CFITSIO: NINT((x - zero) / delta + r - 0.5), NINT(y) = (int)(y + 0.5) for y >= 0, (int)(y - 0.5) below.  Here
+            // u = (x - zero) (1 / delta) + r in one fused step stands for y + 0.5 and the integer is floor(u): the same
+            // integer unless u lies within the rounding error of the shortcut (a few ulp of a quotient below 2^32: < 2^-19)
+            // of an integer -- there the two roundings may fall on different sides, and an exact tie rounds away from zero
+            // in NINT --, so the pixels with fract(u) within 2^-17 of 0 or 1, one in 10^5, take CFITSIO's expression.
             const double rdelta = 1.0 / delta;
-            for (int i = tid; i < nx; i += FP_THREADS) {
-                const int j = i - n0;
-                const int ri = j < 0 ? start0 + i : (j < n1 ? start1 + j : fp_rand_index(rnd, iseed, i));
+            auto quant = [&](int i, int ri) {
                 const double x = (double)fv[i] - zeropt, r = (double)rnd[ri];
-                const double y = fma(x, rdelta, r) - 0.5;
-                const double z = y + copysign(0.5, y);                    // (fp_nint's two branches)
-                const double fr = __builtin_amdgcn_fract(z);
-                int qv = (int)z;
-                if (!(fr > 0x1p-17 && fr < 1.0 - 0x1p-17)) qv = fp_nint((x / delta) + r - 0.5);
+                const double u = fma(x, rdelta, r);
+                const double fr = __builtin_amdgcn_fract(u);
+                int qv = (int)floor(u);
+                if (!(fabs(fr - 0.5) < 0.5 - 0x1p-17)) qv = fp_nint((x / delta) + r - 0.5);
                 vals[i] = qv;
+            };
+            int k = 0;
+            for (; (k + 1) * FP_THREADS <= min(n0, nx); k++) quant(tid + k * FP_THREADS, start0 + tid + k * FP_THREADS);   // (uniform bounds: no index arithmetic)
+            for (int i = tid + k * FP_THREADS; i < nx; i += FP_THREADS) {
+                const int j = i - n0;
+                quant(i, j < 0 ? start0 + i : (j < n1 ? start1 + j : fp_rand_index(rnd, iseed, i)));
             }
         }
 #endif
@@ -758,7 +765,6 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
             ioff[it] = 0;
             continue;
         }
-        unsigned long long ps = 0;
         int prev = (8 * q - 1 < nx) ? vals[q ? 8 * q - 1 : 0] : 0;
         const bool full = 8 * q + 8 <= nx;                           // all 8 pixels inside the row: every run but the last one or two
         if (full) {
@@ -770,11 +776,10 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                 int pd = vv[j] - prev;
                 if (BYTEPIX == 1) pd = (int)(signed char)pd;
                 if (BYTEPIX == 2) pd = (int)(short)pd;
-                unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
+                unsigned d = ((unsigned)pd << 1) ^ (unsigned)(pd >> 31);          // (pd < 0 ? ~(pd << 1) : pd << 1)
                 if (BYTEPIX == 1) d &= 0xffu;
                 if (BYTEPIX == 2) d &= 0xffffu;
                 dd[it][j] = d;
-                ps += d;
                 prev = vv[j];
             }
         } else {
@@ -786,30 +791,51 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
                 int pd = v - prev;
                 if (BYTEPIX == 1) pd = (int)(signed char)pd;
                 if (BYTEPIX == 2) pd = (int)(short)pd;
-                unsigned d = (pd < 0) ? ~((unsigned)pd << 1) : ((unsigned)pd << 1);
+                unsigned d = ((unsigned)pd << 1) ^ (unsigned)(pd >> 31);
                 if (BYTEPIX == 1) d &= 0xffu;
                 if (BYTEPIX == 2) d &= 0xffffu;
                 dd[it][j] = in ? d : 0u;
-                ps += in ? d : 0u;
                 prev = v;
             }
         }
-        ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
+        // the block's sum of differences over the quad's four runs: in 32 bits where no difference has a bit above 2^26 (32
+        // of them stay below 2^31) -- quad exchanges as DPP moves, no LDS --, else (wave-uniform) in 64 bits
+        unsigned s32 = 0, anyb = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { s32 += dd[it][j]; anyb |= dd[it][j]; }
+        s32 += fp_quad_xor1(s32); s32 += fp_quad_xor2(s32);
+        anyb |= fp_quad_xor1(anyb); anyb |= fp_quad_xor2(anyb);
         const int thisblock = min(32, nx - 32 * b);
         // CFITSIO: dpsum = (pixelsum - thisblock / 2 - 1) / thisblock in double, < 0 -> 0, psum = (unsigned)dpsum >> 1, fs = bits
         // of psum.  For a full block the division by 32 is a shift of the integer sum (truncation of a non-negative double =
-        // floor; sums below 2^36 keep (unsigned)dpsum in range): ~6 integer instructions instead of a float64 division per run
+        // floor; sums below 2^36 keep (unsigned)dpsum in range): a few integer instructions instead of a float64 division per run
         unsigned psum;
-        if (thisblock == 32 && ps < (1ull << 36)) psum = ps >= 17ull ? (unsigned)((ps - 17ull) >> 5) >> 1 : 0u;
-        else {
-            double dpsum = ((double)ps - (double)(thisblock / 2) - 1.) / (double)thisblock;
-            if (dpsum < 0.) dpsum = 0.;
-            psum = ((unsigned)dpsum) >> 1;
+        bool pszero;
+        if (BYTEPIX == 4 && __any(anyb >> 26)) {
+            unsigned long long ps = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ps += dd[it][j];
+            ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
+            pszero = ps == 0ull;
+            if (thisblock == 32 && ps < (1ull << 36)) psum = ps >= 17ull ? (unsigned)((ps - 17ull) >> 5) >> 1 : 0u;
+            else {
+                double dpsum = ((double)ps - (double)(thisblock / 2) - 1.) / (double)thisblock;
+                if (dpsum < 0.) dpsum = 0.;
+                psum = ((unsigned)dpsum) >> 1;
+            }
+        } else {
+            pszero = s32 == 0u;
+            if (thisblock == 32) psum = s32 >= 17u ? (s32 - 17u) >> 6 : 0u;
+            else {
+                double dpsum = ((double)s32 - (double)(thisblock / 2) - 1.) / (double)thisblock;
+                if (dpsum < 0.) dpsum = 0.;
+                psum = ((unsigned)dpsum) >> 1;
+            }
         }
         const int fs = psum ? 32 - __builtin_clz(psum) : 0;           // (for (fs = 0; psum > 0; fs++) psum >>= 1)
         int code;                                                     // what goes into the fsbits field
         if (fs >= RP::fsmax) code = RP::fsmax + 1;
-        else if (fs == 0 && ps == 0) code = 0;
+        else if (fs == 0 && pszero) code = 0;
         else code = fs + 1;
         // bits of this run: per pixel (d >> fs) + 1 + fs, or bbits (code fsmax + 1), or nothing (code 0)
         unsigned top = 0;                                             // (pixels beyond the row hold d = 0)

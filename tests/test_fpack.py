@@ -93,7 +93,8 @@ def test_gpu_tiles_equal_cfitsio_and_oracle(tmp_path):
                 assert t['zscale'][r] == g['c%d_zscale' % k][r] and t['zzero'][r] == g['c%d_zzero' % k][r], (k, r)
     # other shapes against the oracle: long rows (dither sequence wraps), ragged last block, smooth and spiky rows
     rs = np.random.RandomState(12)
-    for (ny, nx, q, seed) in ((3, 10560, 16, 9990), (5, 1000, 4, 1), (4, 33, 16, 10000), (2, 4097, 2, 123)):
+    # (150 rows of a full-width frame: ~1.6 M pixels, a few dozen of which take the quantiser's exact division -- test_fpack_quant_shortcut.py)
+    for (ny, nx, q, seed) in ((3, 10560, 16, 9990), (5, 1000, 4, 1), (4, 33, 16, 10000), (2, 4097, 2, 123), (150, 10560, 4, 77)):
         img = (1000 + 0.01 * np.arange(nx)[None, :] + rs.normal(0, 30, (ny, nx))).astype(np.float32)
         img[rs.randint(0, ny, 6), rs.randint(0, nx, 6)] += 4e4
         t = P.compress_tiles(ctx, torch.from_numpy(img).to(ctx.device), q, seed)
