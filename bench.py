@@ -603,6 +603,9 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
     prof = os.environ.get('BBX_CLI_PROFILE')                      # (debug: cProfile of the child's orchestrating thread -> stderr)
     if prof:
         cmd = [cmd[0], '-m', 'cProfile', '-o', os.path.join(td, 'cli.prof')] + cmd[1:]
+    trace = os.environ.get('BBX_CLI_TRACE')                       # (debug: the child under rocprofv3 --kernel-trace, output in this directory)
+    if trace:
+        cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', trace, '-o', 'r', '--'] + cmd
     t0 = time.time()
     r = subprocess.run(cmd + ['--red_dir', out_dir], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=540)
     if prof and os.path.isfile(os.path.join(td, 'cli.prof')):
@@ -621,11 +624,13 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
     mb = sum(os.path.getsize(os.path.join(out_dir, f_)) for f_ in os.listdir(out_dir)) / 1e6
     shutil.rmtree(out_dir, ignore_errors=True)
     skip = min(16, max(1, len(done) // 3))
-    res = dict(files=nfiles, products_of=nout, MB_written=round(mb, 1), process_wall_s=round(wall, 2), hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
+    res = dict(files=nfiles, products_of=nout, pipeline=tm.get('pipeline'), MB_written=round(mb, 1), process_wall_s=round(wall, 2), hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
                seconds_before_the_list=round(marks.get('calibration_and_reference_files_in_hbm', 0.0), 2))
     # the reference's own farm on one GPU (blackbox.py:363-379: pool_func(try_blackbox_reduce, files, nproc)): persistent
     # worker processes, a GPU context and the masters in HBM each, one file at a time per worker
     try:
+        if os.environ.get('BBX_CLI_NO_POOL'):                       # (debug runs of the list alone)
+            raise RuntimeError('skipped (BBX_CLI_NO_POOL)')
         npool, nf = 4, min(nfiles, 32)
         lst2 = os.path.join(td, 'list_pool.txt')
         with open(lst2, 'w') as f:

@@ -35,11 +35,57 @@ log = logging.getLogger('blackbox')
 # as one `BBX_TIMING {json}` line when main() returns
 _T0 = time.time()
 _MARKS = []
+_PIPE_STATS = {}          # --image_list: mean wall time of a frame per pipeline state (BBX_TIMING)
 _FILES_DONE = []          # --image_list: the moment every product of a file was on disk (BBX_TIMING: the list's rate)
 
 
 def _mark(name):
     _MARKS.append((name, time.time() - _T0))
+
+
+def _start_sampler(path):
+    """BBX_CLI_SAMPLE=<file> (debug): every 5 ms the innermost Python frame of every thread; at exit the most frequent
+    (thread, function) pairs go to the file -- where the threads of a list run spend their wall time (a thread inside a
+    library call that released the interpreter lock shows the calling line; one waiting for the lock shows wherever it
+    stopped)"""
+    if not path:
+        return None
+    import atexit
+    import collections
+    import threading
+    counts = collections.Counter()
+    stop = threading.Event()
+
+    def run():
+        me = threading.get_ident()
+        while not stop.wait(0.005):
+            names = {t.ident: t.name for t in threading.enumerate()}
+            for tid, fr in sys._current_frames().items():
+                if tid == me:
+                    continue
+                name = names.get(tid, '?').rstrip('0123456789-_ ')
+                chain = []
+                f = fr
+                while f is not None and len(chain) < 3:
+                    chain.append('%s:%s:%d' % (os.path.basename(f.f_code.co_filename), f.f_code.co_name, f.f_lineno))
+                    f = f.f_back
+                counts[(name, ' < '.join(chain))] += 1
+    th = threading.Thread(target=run, daemon=True, name='sampler')
+    th.start()
+
+    def dump():
+        stop.set()
+        per = collections.Counter()
+        for (name, _), c in counts.items():
+            per[name] += c
+        with open(path, 'w') as f:
+            for name, tot in per.most_common():
+                f.write('== %s: %d samples\n' % (name, tot))
+                for (n2, where), c in counts.most_common():
+                    if n2 == name and c >= 0.02 * tot:
+                        f.write('   %5.1f %%  %s\n' % (100.0 * c / tot, where))
+    atexit.register(dump)
+    return th
 
 
 def str2bool(v):
@@ -437,10 +483,20 @@ class Reducer:
             self.subtract_and_write(data, mask, header, base, sub_result)
         written = self.write_image(fits_out, data, header)
         self.write_image(fits_out.replace('_red', '_mask'), mask, hm)
-        fitsio.write_header(base + '_hdr.fits', header)                       # update_imcathead(create_hdrfile=True), 2011
+        self._small('header', base + '_hdr.fits', dict(header))               # update_imcathead(create_hdrfile=True), 2011
         log.info('reduced %s -> %s in %.2f s', filename, written, time.time() - t0)
         _mark('products_written')
         return written
+
+    def _small(self, kind, *args):
+        """a small product (mini image, table, header file): written at once -- or, for a frame of the list run whose
+        images the output stage is writing, noted for one call of catalogs.write_small_products in a worker process"""
+        staged = getattr(self, '_staged', None)
+        if staged is not None and staged.get('deferred') is not None:
+            staged['deferred'].append((kind, args))
+            return
+        from blackbox_amd import catalogs
+        catalogs.write_small_products([(kind, args)])
 
     def write_image(self, path, img, header):
         staged = getattr(self, '_staged', None)
@@ -478,15 +534,15 @@ class Reducer:
         hnew, htrans = res['header_new'], res['header_trans']
         header.update(hnew)
         bkg_hdr = {'BKG-SIZE': hnew['BKG-SIZE']}
-        fitsio.write_image(base + '_bkg_mini.fits', res['bkg_mini_new'], bkg_hdr)
-        fitsio.write_image(base + '_bkg_std_mini.fits', res['bkg_std_mini_new'], bkg_hdr)
+        self._small('image', base + '_bkg_mini.fits', np.asarray(res['bkg_mini_new']), bkg_hdr)
+        self._small('image', base + '_bkg_std_mini.fits', np.asarray(res['bkg_std_mini_new']), bkg_hdr)
         qc_flag = qc.run_qc_check(header, self.tel, check_key_type='full')
         if res.get('catalog') is not None:
             if qc_flag == 'red':
                 qc.run_qc_check(header, self.tel, cat_type='new', cat_dummy=base + '_cat.fits', check_key_type='full')
             else:
-                G.format_cat(res['catalog'], base + '_cat.fits', cat_type='new', header2add=header)
-            fitsio.write_header(base + '_cat_hdr.fits', header)
+                self._small('cat', res['catalog'], base + '_cat.fits', 'new', dict(header))
+            self._small('header', base + '_cat_hdr.fits', dict(header))
         if res.get('D') is not None:
             full_t = dict(header)
             full_t.update(htrans)
@@ -497,8 +553,8 @@ class Reducer:
             if tqc == 'red' or qc_flag == 'red':
                 qc.run_qc_check(full_t, self.tel, cat_type='trans', cat_dummy=base + '_trans.fits', check_key_type='trans')
             else:
-                G.format_cat(G.transient_table(res['transients']), base + '_trans.fits', cat_type='trans', header2add=full_t)
-            fitsio.write_header(base + '_trans_hdr.fits', full_t)
+                self._small('trans', res['transients'], base + '_trans.fits', dict(full_t))
+            self._small('header', base + '_trans_hdr.fits', dict(full_t))
 
     def _limmag_is_flux(self, header):
         """one rule for the unit of `_trans_limmag`, whichever path writes it: a flux limit only when no zeropoint is known --
@@ -598,6 +654,10 @@ class Reducer:
         depth = max(2, min(16 if cores >= 12 else 8, len(todo)))
         nwriters = max(2, min(12, cores - 4))
         nreaders = max(2, min(4, cores // 4))
+        # (tuning runs: BBX_LIST_LANES / BBX_LIST_DEPTH / BBX_LIST_WRITERS override the choice above)
+        lanes = int(os.environ.get('BBX_LIST_LANES', lanes))
+        depth = max(2, min(int(os.environ.get('BBX_LIST_DEPTH', depth)), len(todo)))
+        nwriters = int(os.environ.get('BBX_LIST_WRITERS', nwriters))
         if self.args.fpack:
             from blackbox_amd import outstage
             ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
@@ -607,12 +667,22 @@ class Reducer:
                 """the frame's scalars are in: complete the headers (bookkeeping, QC flags, subtraction keywords) through
                 the very code of the serial path; its image writes only hand their headers to the stage"""
                 fn, header, fits_out = live[f.idx]
-                self._staged = dict(names=set(f.out_names.values()), headers={}, wanted=set())
+                self._staged = dict(names=set(f.out_names.values()), headers={}, wanted=set(), deferred=[])
                 try:
                     self._finish_from_pipeline(f, fn, header, fits_out, t0)
                     f.staged_wanted = set(self._staged['wanted'])
                     res = dict(hdrs)
                     res.update(self._staged['headers'])
+                    jobs = self._staged['deferred']
+                    if jobs:
+                        # the frame's small files: one task of the host pool (a worker process formats and writes them);
+                        # they count among the frame's files -- on_written fires when they and the images are on disk
+                        g = f.out_group
+                        with g.lock:
+                            g.left += 1
+                        from blackbox_amd import catalogs
+                        pipe.pool.pool.apply_async(catalogs.write_small_products, (jobs,), callback=lambda r, g=g: g.file_done(None),
+                                                   error_callback=lambda e, g=g: g.file_done(None, e))
                     return res
                 finally:
                     self._staged = None
@@ -725,6 +795,10 @@ class Reducer:
                     log.error('writing the products of %s failed: %r', todo[idx][0], err)
                     out[todo[idx][0]] = None
         finally:
+            n = max(1, pipe.t_stats[3])
+            _PIPE_STATS.update(frames=pipe.t_stats[3], lanes=len(pipe.lane_thread), depth=pipe.depth,
+                               ms_start_to_strip_statistics=round(1e3 * pipe.t_stats[0] / n, 2), ms_overscan_fits=round(1e3 * pipe.t_stats[1] / n, 2),
+                               ms_device_stage_and_lane_queue=round(1e3 * pipe.t_stats[2] / n, 2))
             pipe.close()
             if stage is not None:
                 stage.close()
@@ -855,6 +929,7 @@ def main(argv=None):
             print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0)))
         return out
     red = Reducer(tel, args)
+    sampler = _start_sampler(os.environ.get('BBX_CLI_SAMPLE'))
     if args.image_list and len(mine) > 1:
         out = red.reduce_list(mine)
     else:
@@ -865,7 +940,7 @@ def main(argv=None):
         import json
         _mark('done')
         import torch
-        print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0, files_done_unix=sorted(_FILES_DONE),
+        print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0, files_done_unix=sorted(_FILES_DONE), pipeline=_PIPE_STATS,
                                               hbm_peak_GB_tensors=round(torch.cuda.max_memory_allocated() / 1e9, 2))))
     return out
 

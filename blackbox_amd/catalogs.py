@@ -49,3 +49,24 @@ def transient_table(transients):
                 SNR_ZOGY=np.array([d['scorr'] for d in t], np.float32),
                 E_FLUX_ZOGY=np.array([d['fpsf'] for d in t], np.float32),
                 E_FLUXERR_ZOGY=np.array([d['fpsferr'] for d in t], np.float32))
+
+
+def write_small_products(jobs):
+    """the small files of a frame in one call (a worker process of the host pool runs it for blackbox.py's list run, so
+    that their formatting does not hold the interpreter lock of the process that drives the GPU): jobs = [(kind, args)],
+    kind in 'image' (fitsio.write_image), 'header' (fitsio.write_header), 'cat' (format_cat), 'trans' (format_cat of
+    transient_table(args[0]))"""
+    done = []
+    for kind, args in jobs:
+        if kind == 'image':
+            fitsio.write_image(*args)
+        elif kind == 'header':
+            fitsio.write_header(*args)
+        elif kind == 'cat':
+            format_cat(args[0], args[1], cat_type=args[2], header2add=args[3])
+        elif kind == 'trans':
+            format_cat(transient_table(args[0]), args[1], cat_type='trans', header2add=args[2])
+        else:
+            raise ValueError('unknown small product {!r}'.format(kind))
+        done.append(args[1] if kind in ('cat', 'trans') else args[0])
+    return done

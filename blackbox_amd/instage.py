@@ -139,7 +139,7 @@ class InputStage:
         self.ready, self.cv = {}, threading.Condition()
         self.stop = False
         self.bytes_read = 0
-        self.threads = [threading.Thread(target=self._reader, args=(k,), daemon=True) for k in range(nreaders)]
+        self.threads = [threading.Thread(target=self._reader, args=(k,), daemon=True, name='bbx-reader') for k in range(nreaders)]
         for t in self.threads:
             t.start()
 

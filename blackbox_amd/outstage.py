@@ -161,7 +161,7 @@ class OutputStage:
         self.nslots, self.heap_frac, self.seed = nslots, heap_frac, dither_seed
         self.lanes = {}
         self.q = queue.Queue()
-        self.threads = [threading.Thread(target=self._writer, args=(k,), daemon=True) for k in range(nwriters)]
+        self.threads = [threading.Thread(target=self._writer, args=(k,), daemon=True, name='bbx-writer') for k in range(nwriters)]
         self.bytes_written, self.files_written = 0, 0
         self.phase = {}                       # writer phases: name -> [wall s, cpu s, calls]
         self.stat_lock = threading.Lock()

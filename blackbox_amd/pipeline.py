@@ -245,8 +245,8 @@ class _LaneThread(threading.Thread):
     most of it inside the library (ctypes drops the GIL there), so the lanes and the
     orchestrating thread overlap.  Work items: (method, frame, results)."""
 
-    def __init__(self, pipe, device):
-        super().__init__(daemon=True)
+    def __init__(self, pipe, device, name='bbx-lane'):
+        super().__init__(daemon=True, name=name)
         self.pipe, self.device, self.q = pipe, device, queue.SimpleQueue()
 
     def run(self):
@@ -759,7 +759,7 @@ class FramePipeline:
                 f.d_keep = None
                 f.state = 'H'
                 if self._finisher is None:
-                    self._finisher = _LaneThread(self, self.ctx.device)
+                    self._finisher = _LaneThread(self, self.ctx.device, name='bbx-finisher')
                     self._finisher.start()
                 self._finisher.q.put((self._run_hook, f, hdrs))
                 return

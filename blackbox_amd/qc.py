@@ -61,13 +61,19 @@ QC_RANGE = {
 }
 
 
+_DEPLOYED = None
+
+
 def _table(telescope, qc_range):
     if qc_range is None:
-        try:
-            import set_qc                                   # the deployment's full table
-            qc_range = set_qc.qc_range
-        except ImportError:
-            qc_range = QC_RANGE
+        global _DEPLOYED
+        if _DEPLOYED is None:                               # (once: a failing import searches sys.path every time)
+            try:
+                import set_qc                               # the deployment's full table
+                _DEPLOYED = set_qc.qc_range
+            except ImportError:
+                _DEPLOYED = QC_RANGE
+        qc_range = _DEPLOYED
     if telescope in qc_range:
         return qc_range[telescope]
     return qc_range[telescope[0:2]]                         # all BlackGEM telescopes share 'BG' (qc.py:121-125)

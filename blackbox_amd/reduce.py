@@ -22,6 +22,8 @@ import ctypes as C
 import numpy as np
 import torch
 
+import os
+
 from . import _lib, overscan, settings
 from ._lib import lib, check, Geom, BBX_RAW_U16, BBX_RAW_F32
 
@@ -44,6 +46,9 @@ class Context:
         h = C.c_void_p()
         check(lib.bbx_ctx_create(device, C.byref(h)), 'bbx_ctx_create')
         self.h = h
+        for kv in filter(None, os.environ.get('BBX_DEBUG_OPTIONS', '').split(',')):      # (tuning runs: "id=value,..." of include/bbx.h's BBX_OPT_*)
+            k, v = kv.split('=')
+            check(lib.bbx_set_option(self.h, int(k), int(v)), 'bbx_set_option', self.h)
 
     def stream(self):
         # (the raw handle of torch's current stream: ~0.3 us; torch.cuda.current_stream() builds a Stream object, ~5 us, and a
