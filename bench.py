@@ -599,33 +599,63 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
     cmd = [c for c in cmd1]
     i = cmd.index('--image')
     cmd[i:i + 2] = ['--image_list', lst]
-    out_dir = os.path.join(td, 'out_list')
     prof = os.environ.get('BBX_CLI_PROFILE')                      # (debug: cProfile of the child's orchestrating thread -> stderr)
     if prof:
         cmd = [cmd[0], '-m', 'cProfile', '-o', os.path.join(td, 'cli.prof')] + cmd[1:]
     trace = os.environ.get('BBX_CLI_TRACE')                       # (debug: the child under rocprofv3 --kernel-trace, output in this directory)
     if trace:
         cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', trace, '-o', 'r', '--'] + cmd
-    t0 = time.time()
-    r = subprocess.run(cmd + ['--red_dir', out_dir], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=540)
+    import tempfile
+
+    def one_run(out_dir):
+        t0 = time.time()
+        r = subprocess.run(cmd + ['--red_dir', out_dir], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=540)
+        wall = time.time() - t0
+        try:
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('BBX_TIMING ')]
+            if r.returncode != 0 or not line:
+                return dict(error='exit code %d' % r.returncode, stderr=r.stderr[-800:])
+            tm = json.loads(line[-1][len('BBX_TIMING '):])
+            done = tm.get('files_done_unix', [])
+            marks = dict(tm['marks'])
+            names = os.listdir(out_dir)
+            nout = len([f_ for f_ in names if f_.endswith('_red.fits.fz')])
+            mb = sum(os.path.getsize(os.path.join(out_dir, f_)) for f_ in names) / 1e6
+            skip = min(16, max(1, len(done) // 3))
+            d = dict(dir=os.path.dirname(out_dir), files=nfiles, products_of=nout, files_per_frame=round(len(names) / max(1, nout), 1),
+                     MB_per_frame=round(mb / max(1, nout), 1), pipeline=tm.get('pipeline'), process_wall_s=round(wall, 2),
+                     hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
+                     seconds_before_the_list=round(marks.get('calibration_and_reference_files_in_hbm', 0.0), 2))
+            if len(done) > skip + 1:
+                d['frames_per_s'] = (len(done) - 1 - skip) / (done[-1] - done[skip])
+                d['ms_per_frame'] = 1e3 / d['frames_per_s']
+                d['frames_per_s_whole_list'] = len(done) / (done[-1] - (tm['t_module_import_unix'] + marks.get('calibration_and_reference_files_in_hbm', 0.0)))
+                d['frames_per_s_process'] = len(done) / wall
+                d['steady_state_from_file'] = skip
+            return d
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    res = dict(ramdisk=one_run(os.path.join(td, 'out_list')))
     if prof and os.path.isfile(os.path.join(td, 'cli.prof')):
         import pstats
         pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('cumulative').print_stats(45)
         pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('tottime').print_stats(40)
-        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).print_callees('subtract_and_write|finish_object|_run$')
-    wall = time.time() - t0
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith('BBX_TIMING ')]
-    if r.returncode != 0 or not line:
-        return dict(error='exit code %d' % r.returncode, stderr=r.stderr[-800:])
-    tm = json.loads(line[-1][len('BBX_TIMING '):])
-    done = tm.get('files_done_unix', [])
-    marks = dict(tm['marks'])
-    nout = len([f_ for f_ in os.listdir(out_dir) if f_.endswith('_red.fits.fz')])
-    mb = sum(os.path.getsize(os.path.join(out_dir, f_)) for f_ in os.listdir(out_dir)) / 1e6
-    shutil.rmtree(out_dir, ignore_errors=True)
-    skip = min(16, max(1, len(done) // 3))
-    res = dict(files=nfiles, products_of=nout, pipeline=tm.get('pipeline'), MB_written=round(mb, 1), process_wall_s=round(wall, 2), hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
-               seconds_before_the_list=round(marks.get('calibration_and_reference_files_in_hbm', 0.0), 2))
+    if not (prof or trace) and not os.environ.get('BBX_CLI_NO_POOL'):
+        # the same list with the products on local scratch (the raw files stay on the RAM disk)
+        sd = tempfile.mkdtemp(prefix='bbx_list_out_', dir=tempfile.gettempdir())
+        try:
+            if shutil.disk_usage(sd).free > nfiles * 400e6 + 2e9:
+                res['scratch'] = one_run(os.path.join(sd, 'out_list'))
+            else:
+                res['scratch'] = dict(skipped='not enough room in %s' % sd)
+        finally:
+            shutil.rmtree(sd, ignore_errors=True)
+    res['note'] = ('files to files through the operator\'s own entry: a child `python blackbox.py --image_list L ... --fpack True` over %d full-size '
+                   'fpacked raw frames on the RAM disk; every product of every frame written (_red, _mask, _D, _Scorr, _Fpsf, _trans_limmag '
+                   'tile-compressed on the lane that made them and written as .fits.fz by writer threads; _bkg_mini, _bkg_std_mini, _cat, '
+                   '_trans and the header files by a worker process of the host pool); frames_per_s = steady state between the completion of '
+                   'file [steady_state_from_file] and the last one, frames_per_s_whole_list from the first input to the last product, '
+                   'frames_per_s_process over the process\'s wall time (imports, GPU context, masters into HBM included)' % nfiles)
     # the reference's own farm on one GPU (blackbox.py:363-379: pool_func(try_blackbox_reduce, files, nproc)): persistent
     # worker processes, a GPU context and the masters in HBM each, one file at a time per worker
     try:
@@ -653,14 +683,6 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
             res['process_pool']['stderr'] = r2.stderr[-600:]
     except Exception as e:
         res['process_pool'] = dict(error=repr(e))
-    if len(done) <= skip + 1:
-        res['note'] = 'only %d completion stamps came back' % len(done)
-        res['stderr_tail'] = r.stderr[-1500:]
-    if len(done) > skip + 1:
-        res['frames_per_s'] = (len(done) - 1 - skip) / (done[-1] - done[skip])
-        res['frames_per_s_whole_list'] = len(done) / (done[-1] - (tm['t_module_import_unix'] + marks.get('calibration_and_reference_files_in_hbm', 0.0)))
-        res['frames_per_s_process'] = len(done) / wall
-        res['steady_state_from_file'] = skip
     return res
 
 
@@ -1110,17 +1132,19 @@ def main():
         section('long_run')
         out['io_inclusive'] = io_inclusive(torch, ctx, raw, N, out['ms_per_step'], wl)
         section('io_inclusive (pcie, serial writers)')
-        out['io_inclusive']['measured'] = measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section)
         if wl == 'zogy' and not args.small:
             out['process_per_file'] = process_cold(torch, ctx, raw, flat, bpm, ref, ref_mask, coeffs, sub_kw, box, raws=raws, list_frames=96)
             section('process_per_file + image_list')
             il = out['process_per_file'].pop('image_list', None)
             if il is not None:
-                # the files-to-files figure of the operator surface itself (the in-process figures above run bench.py's own loop)
+                # files to files, measured through the operator's own entry: a child `python blackbox.py --image_list` (round 4
+                # timed bench.py's own loop around the pipeline here; that loop is still there as `bench.py --io-only`)
                 pp = il.pop('process_pool', None)
-                out['io_inclusive']['cli_image_list'] = il
+                out['io_inclusive']['measured'] = il
                 if pp is not None:
                     out['process_pool'] = pp
+        else:
+            out['io_inclusive']['measured'] = measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section)
     pool.close()
     if rank == 0:
         if not args.no_cpu:
