@@ -647,11 +647,12 @@ class Reducer:
         all_written = threading.Event()
         kw = {}
         # threads and frames in flight from the cores this process may use (cgroup quota / affinity mask), like bench.py's
-        # files-to-files run: on the 16 cores of a one-GPU box 6 lanes, 16 frames, 12 writers, 4 readers
+        # files-to-files run: on the 16 cores of a one-GPU box 6 lanes, 16 frames, 12 writers, 4 readers (one process), or 4 lanes,
+        # 12 frames, 4 writers, 2 readers in each of two (list_processes)
         from blackbox_amd import pipeline as _pl
         cores = _pl.cpu_budget()
         lanes = max(2, min(6, cores // 2))
-        depth = max(2, min(16 if cores >= 12 else 8, len(todo)))
+        depth = max(2, min(16 if cores >= 12 else (12 if cores >= 8 else 8), len(todo)))
         nwriters = max(2, min(12, cores - 4))
         nreaders = max(2, min(4, cores // 4))
         # (tuning runs: BBX_LIST_LANES / BBX_LIST_DEPTH / BBX_LIST_WRITERS override the choice above)
@@ -843,6 +844,90 @@ def f_exptime(reducer, f):
     return getattr(reducer, '_pipe_exptime', 1.0)
 
 
+def list_processes(args, nfiles):
+    """how many pipelined processes a list run uses on its GPU.  One interpreter drives the GPU through some 300 library
+    calls and a dozen file writes per frame from ~25 threads that share its lock: at ~60-75 frames/s that lock, not the
+    GPU, is what a 16-core host runs out of.  Two processes with half the list, half the cores and a GPU context each have
+    two locks (the GPU time-slices their queues; the masters are in HBM twice)."""
+    if not args.image_list or nfiles < 2 or args.nproc > 1:
+        return 1
+    nlp = args.list_procs or int(os.environ.get('BBX_LIST_PROCS', '0'))     # (the variable: tuning runs)
+    if nlp > 0:
+        return min(nlp, nfiles)
+    from blackbox_amd import pipeline as _pl
+    world = int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)
+    return 2 if (_pl.cpu_budget() // max(1, world) >= 16 and nfiles >= 32) else 1
+
+
+def reduce_list_in_processes(argv, files, nproc):
+    """--image_list over [nproc] child processes `python blackbox.py ... --image_list <share> --list_procs 1` (the file k of
+    the list goes to child k mod nproc; each child is told its share of the cores: BBX_CPU_BUDGET).  The parent makes no
+    GPU call.  -> the results in the order of [files]; a child that dies reports None for the files it had not finished"""
+    import json
+    import subprocess
+    import tempfile
+    from blackbox_amd import pipeline as _pl
+    cores = _pl.cpu_budget()
+    base = []
+    skip = False
+    for a in argv:                                               # the parent's flags without the list and the split
+        if skip:
+            skip = False
+            continue
+        if a in ('--image_list', '--list_procs', '--image'):
+            skip = True
+            continue
+        if a.startswith('--image_list=') or a.startswith('--list_procs=') or a.startswith('--image='):
+            continue
+        base.append(a)
+    td = tempfile.mkdtemp(prefix='bbx_list_')
+    procs = []
+    try:
+        for k in range(nproc):
+            share = files[k::nproc]
+            lst = os.path.join(td, 'share_%d.txt' % k)
+            with open(lst, 'w') as f:
+                f.write('\n'.join(share) + '\n')
+            env = dict(os.environ, BBX_CPU_BUDGET=str(max(2, cores // nproc)), BBX_TIMING='1')
+            procs.append((share, subprocess.Popen([sys.executable, os.path.abspath(__file__)] + base + ['--image_list', lst, '--list_procs', '1'],
+                                                  env=env, stdout=subprocess.PIPE, text=True)))
+        _mark('list_processes_started')
+        out = {}
+        done, stats = [], []
+        for share, p in procs:
+            text, _ = p.communicate()
+            lines = [ln for ln in text.splitlines() if ln.strip()]
+            tm = [ln for ln in lines if ln.startswith('BBX_TIMING ')]
+            res = [ln for ln in lines if not ln.startswith('BBX_TIMING ')][-len(share):]
+            if p.returncode != 0 or len(res) != len(share):
+                log.error('list process for %d files ended with code %s and %d result lines', len(share), p.returncode, len(res))
+                res = (res + ['None'] * len(share))[:len(share)] if p.returncode == 0 else ['None'] * len(share)
+            for fn, r in zip(share, res):
+                out[fn] = None if r == 'None' else r
+            if tm:
+                t = json.loads(tm[-1][len('BBX_TIMING '):])
+                done += t.get('files_done_unix', [])
+                stats.append(dict(pipeline=t.get('pipeline'), hbm_peak_GB_tensors=t.get('hbm_peak_GB_tensors'), marks=t.get('marks'), t0=t.get('t_module_import_unix', _T0)))
+    finally:
+        for _, p in procs:
+            if p.poll() is None:
+                p.kill()
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
+    res = [out.get(fn) for fn in files]
+    for o in res:
+        print(o)
+    if os.environ.get('BBX_TIMING'):
+        _mark('done')
+        # (the moment the last child had its masters in HBM, on this process's clock)
+        first = [s_['t0'] + dict(s_['marks']).get('calibration_and_reference_files_in_hbm', 0.0) - _T0 for s_ in stats if s_.get('marks')]
+        print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS + [('calibration_and_reference_files_in_hbm', max(first) if first else 0.0)],
+                                              t_module_import_unix=_T0, files_done_unix=sorted(done), list_processes=nproc,
+                                              pipeline=[s_['pipeline'] for s_ in stats],
+                                              hbm_peak_GB_tensors=round(sum(s_.get('hbm_peak_GB_tensors') or 0.0 for s_ in stats), 2))))
+    return res
+
+
 def build_parser():
     ap = argparse.ArgumentParser(description='BlackBOX per-image reduction on MI355X')
     ap.add_argument('--telescope', type=str, default='ML1')
@@ -888,6 +973,9 @@ def build_parser():
     ap.add_argument('--zeropoint', type=float, default=None,
                     help='[mag] photometric zeropoint for 1 e-/s (else header PC-ZP): _trans_limmag in magnitudes')
     ap.add_argument('--nproc', type=int, default=1, help='worker processes for --image_list (one GPU context each)')
+    ap.add_argument('--list_procs', type=int, default=0,
+                    help='--image_list: this many pipelined processes share the GPU, each with a share of the list and of the cores '
+                         '(0 = by the cores this process may use; 1 = one process)')
     return ap
 
 
@@ -928,6 +1016,9 @@ def main(argv=None):
             _mark('done')
             print('BBX_TIMING ' + json.dumps(dict(marks=_MARKS, t_module_import_unix=_T0)))
         return out
+    nlp = list_processes(args, len(mine))
+    if nlp > 1:
+        return reduce_list_in_processes(argv, mine, nlp)
     red = Reducer(tel, args)
     sampler = _start_sampler(os.environ.get('BBX_CLI_SAMPLE'))
     if args.image_list and len(mine) > 1:

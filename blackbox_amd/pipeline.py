@@ -35,6 +35,8 @@ get_par = settings.get_par
 def cpu_budget():
     """cores this process may use: the smaller of the cgroup CPU quota (os.cpu_count() reports the whole host inside
     a container) and the affinity mask (taskset / a launcher that pins ranks)"""
+    if os.environ.get('BBX_CPU_BUDGET'):                     # (a parent that shares its cores among several processes says so)
+        return max(1, int(os.environ['BBX_CPU_BUDGET']))
     try:
         naff = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -245,15 +247,30 @@ class _LaneThread(threading.Thread):
     most of it inside the library (ctypes drops the GIL there), so the lanes and the
     orchestrating thread overlap.  Work items: (method, frame, results)."""
 
+    _profiled = False
+
     def __init__(self, pipe, device, name='bbx-lane'):
         super().__init__(daemon=True, name=name)
         self.pipe, self.device, self.q = pipe, device, queue.SimpleQueue()
 
     def run(self):
         torch.cuda.set_device(self.device)              # the current HIP device is per thread
+        prof = None
+        if os.environ.get('BBX_LANE_PROFILE') and not _LaneThread._profiled:      # (debug: cProfile of the first lane thread)
+            import cProfile
+            _LaneThread._profiled = True
+            prof = cProfile.Profile()
+            prof.enable()
         while True:
             item = self.q.get()
             if item is None:
+                if prof is not None:
+                    import pstats
+                    prof.disable()
+                    with open(os.environ['BBX_LANE_PROFILE'], 'w') as fh:
+                        st = pstats.Stats(prof, stream=fh)
+                        st.sort_stats('tottime').print_stats(45)
+                        st.sort_stats('cumulative').print_stats(60)
                 return
             fn, f, results = item
             try:

@@ -409,3 +409,38 @@ def test_cli_image_list_one_bad_file_fails_one_file(tmp_path, ctx, case):
         got = P.funpack_image(ctx, o.replace('_red', '_mask'))
         got = got[0] if isinstance(got, tuple) else got
         assert np.array_equal(np.asarray(got.cpu() if hasattr(got, 'cpu') else got), m0.cpu().numpy()), o
+
+
+def test_cli_image_list_in_two_processes(tmp_path, ctx, case):
+    """--image_list --list_procs 2: two pipelined child processes share the GPU, the files of the list alternate between
+    them.  Results come back in the order of the list, a file that cannot be read is None in its place, and the products are
+    the bytes the one-process list makes."""
+    cli = load_cli()
+    hdr = {'EXPTIME': 60.0, 'IMAGETYP': 'object', 'FILTER': 'q'}
+    raws = []
+    for k in range(5):
+        p = str(tmp_path / ('ML1_raw%d.fits' % k))
+        fitsio.write_image(p, case['raw'], dict(hdr, **{'DATE-OBS': '2024-01-02T03:04:0%d' % k}))
+        raws.append(p)
+    n = os.path.getsize(raws[3])
+    with open(raws[3], 'r+b') as f:                                        # file 3 (second child's): cut short
+        f.truncate(n - n // 3)
+    fitsio.write_image(str(tmp_path / 'flat.fits'), case['flat'])
+    fitsio.write_image(str(tmp_path / 'bpm.fits'), case['bpm'])
+    synth.write_xtalk(str(tmp_path / 'xtalk.dat'), case['xtalk'])
+    lst = str(tmp_path / 'list.txt')
+    with open(lst, 'w') as f:
+        f.write('\n'.join(raws) + '\n')
+    common = ['--telescope', TEL, '--mflat', str(tmp_path / 'flat.fits'), '--bpm', str(tmp_path / 'bpm.fits'),
+              '--crosstalk', str(tmp_path / 'xtalk.dat'), '--ysize_chan', str(YS), '--xsize_chan', str(XS), '--fpack', 'True',
+              '--image_list', lst]
+    one = cli.main(common + ['--red_dir', str(tmp_path / 'p1'), '--list_procs', '1'])
+    two = cli.main(common + ['--red_dir', str(tmp_path / 'p2'), '--list_procs', '2'])
+    assert len(two) == 5 and two[3] is None and one[3] is None, (one, two)
+    for k in (0, 1, 2, 4):
+        assert two[k] and os.path.basename(two[k]) == os.path.basename(one[k]) and os.path.isfile(two[k]), (k, two)
+        for a, b in ((one[k], two[k]), (one[k].replace('_red', '_mask'), two[k].replace('_red', '_mask'))):
+            (_, _), (ha, ta) = fitsio.read_hdus(a)
+            (_, _), (hb, tb) = fitsio.read_hdus(b)
+            assert np.array_equal(ta, tb) and np.array_equal(ha['__heap__'], hb['__heap__']), (k, a)
+        assert os.path.isfile(two[k].replace('.fits.fz', '_hdr.fits'))
