@@ -203,10 +203,12 @@ struct fp_bitw {
 //   instruction whatever the addresses: 1.0 of the kernel's 1.4 ms.  Now (rows of >= FP_MIN_ND differences):
 //   (1) 1024 keys per kind are sampled at a fixed stride and sorted by one wave per kind in registers; the sample's order
 //       statistics 512 -/+ FP_SAMP_HALF bracket the median's value [lo, hi] (+- 3 sigma of the sample median's rank);
-//   (2) ONE pass over the differences counts the keys below lo / equal to lo / equal to hi in registers and compacts the
-//       keys strictly inside the bracket (~9 % of them) into per-wave segments with ballots -- no atomics;
-//   (3) the rank falls on lo, on hi or inside: then one histogram pass over the ~1000 collected keys on (key - lo) >> s
-//       (2048 bins), the bin's handful of keys are collected and ranked by counting.
+//   (2) ONE pass over the differences counts the keys below lo and compacts the keys inside [lo, hi] (ends included; ~9 %
+//       of them) into per-wave segments -- masks from one compare of the wrapped difference key - lo, the count below lo
+//       from that subtraction's borrow, population counts in the scalar unit, two keys per lane in packed float32
+//       arithmetic, a store without a branch (round 5; 25 vector instructions per key, round 4: 77);
+//   (3) the rank falls inside: one histogram pass over the ~1000 collected keys on (key - lo) >> s (512 bins), the bin's
+//       handful of keys are collected and ranked by counting (hi == lo: every key inside is that value).
 //   Whenever a step does not hold (rank outside the bracket: ~0.3 % of the rows; a segment or the last list overflows:
 //   rows with many equal differences) the row takes the histogram passes over all keys, as before: the result is the
 //   exact order statistic either way.
