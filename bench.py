@@ -632,6 +632,9 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
                 d['frames_per_s_whole_list'] = len(done) / (done[-1] - (tm['t_module_import_unix'] + marks.get('calibration_and_reference_files_in_hbm', 0.0)))
                 d['frames_per_s_process'] = len(done) / wall
                 d['steady_state_from_file'] = skip
+                t_list = tm['t_module_import_unix'] + marks.get('calibration_and_reference_files_in_hbm', 0.0)
+                d['seconds_to_first_product'] = round(done[0] - t_list, 2)
+                d['seconds_to_product_%d' % skip] = round(done[skip] - t_list, 2)
             return d
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)

@@ -14,10 +14,10 @@
 
 #define FP_MAXNX 16384
 #ifndef FP_THREADS
-#define FP_THREADS 1024          // one workgroup per row holds ~100 KB of LDS: one per CU, so make it wide
-#endif
+#define FP_THREADS 768           // threads per row.  Two rows per CU: 24 of its 32 wave slots, 80 registers per thread (1024 threads:
+#endif                           // all slots, 64 registers, the same time alone -- and no slot left for the copy and decode kernels beside it)
 #ifndef FP_MINW
-#define FP_MINW 8                // waves per SIMD the short-buffer kernel's registers are cut for: two workgroups per CU
+#define FP_MINW 6                // waves per SIMD the short-buffer kernel's registers are cut for: two workgroups per CU
 #endif
 #define FP_NRANDOM 10000
 #define FP_NRESERVED 10
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(FP_THREADS, MODE == 1 ? FP_MINW : 4) void k_fp_tile
 #undef FP_BRACKET2
             // (b) the keys behind the last whole block, one per lane, by the wave whose turn that block would have been
 #ifndef FPV_NOB3
-            for (int i0 = 128 * nblk128; i0 < nd && wave == (nblk128 & (FP_THREADS / 64 - 1)); i0 += 64) {
+            for (int i0 = 128 * nblk128; i0 < nd && wave == nblk128 % (FP_THREADS / 64); i0 += 64) {
 #else
             for (int i0 = 128 * nblk128; i0 < 0; i0 += 64) {
 #endif
