@@ -1038,3 +1038,11 @@ def main(argv=None):
 
 if __name__ == '__main__':
     main()
+    # Every product is on disk and every line printed: leave without the interpreter's teardown (module destructors, the
+    # GPU runtime's unload, the worker pools' joins: 0.3-0.6 s of a 2 s per-file process -- the reference's Slurm contract
+    # is one process per file).  An exception never gets here: it ends the process the ordinary way, with its traceback.
+    logging.shutdown()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if os.environ.get('BBX_FAST_EXIT', '1') != '0':
+        os._exit(0)
