@@ -242,7 +242,7 @@ class Reducer:
             if not path:
                 return None
             try:
-                return torch.from_numpy(np.ascontiguousarray(fitsio.read_image(path, dtype=dtype))).to(dev)
+                return R.image_to_device(self.ctx, path, dtype)      # (float32 files: bytes up, swapped on the device)
             except Exception:
                 log.exception('exception was raised while reading the %s %s', what, path)
                 return None

@@ -86,6 +86,7 @@ SIGNATURES = {
     'bbx_fpack_body': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _i, _vp]),
     'bbx_fpack_body_scaled': (_i, [_vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _i, _f, _vp]),
     'bbx_raw_be16': (_i, [_vp, _vp, C.c_size_t, _vp]),
+    'bbx_be32': (_i, [_vp, _vp, C.c_size_t, _vp]),
     'bbx_funpack_tiles': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     'bbx_coadd_prep': (_i, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'bbx_resample_lanczos3': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),

@@ -1525,6 +1525,33 @@ extern "C" int bbx_raw_be16(const void* d_file_pixels, uint16_t* d_out, size_t n
     return BBX_OK;
 }
 
+// big-endian 32-bit words (float32 / int32 pixels as they lie in a FITS file: master flat, master bias, reference image) ->
+// host order; in place allowed (d_out == d_in)
+__global__ __launch_bounds__(256) void k_be32(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n, int vec) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const uint4* in4 = reinterpret_cast<const uint4*>(in); uint4* out4 = reinterpret_cast<uint4*>(out);
+        for (size_t i = t; i < n / 4; i += nt) {
+            uint4 v = in4[i];
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+            out4[i] = v;
+        }
+        for (size_t i = (n / 4) * 4 + t; i < n; i += nt) out[i] = __builtin_bswap32(in[i]);
+    } else {
+        for (size_t i = t; i < n; i += nt) out[i] = __builtin_bswap32(in[i]);
+    }
+}
+extern "C" int bbx_be32(const void* d_file_words, void* d_out, size_t n, void* stream) {
+    if (!d_file_words || !d_out || ((uintptr_t)d_file_words & 3) || ((uintptr_t)d_out & 3)) return BBX_ERR_ARG;
+    if (n == 0) return BBX_OK;
+    const int vec = (((uintptr_t)d_file_words | (uintptr_t)d_out) & 15) == 0;
+    const size_t items = vec ? n / 4 + 1 : n;
+    const unsigned blocks = (unsigned)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_be32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)d_file_words, (uint32_t*)d_out, n, vec);
+    if (hipGetLastError() != hipSuccess) return BBX_ERR_HIP;
+    return BBX_OK;
+}
+
 // bbx_build_flags (bbx_ctx.hip): any timing knock-out of this file compiled in?
 int bbx_build_flags_fpack(void) {
 #if defined(FPV_NOB3) || defined(FPV_NOHINT) || defined(FPV_NOMED) || defined(FPV_NOPASS2) || defined(FPV_NOQUANT) || defined(FPV_NOST2) || defined(FPV_SKIP_RETRY) || defined(FPV_STAT)

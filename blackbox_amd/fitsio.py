@@ -143,6 +143,21 @@ def read_image(path, dtype=None, get_header=False):
     return (data, h) if get_header else data
 
 
+def read_image_file_order(path):
+    """last HDU with data as it lies in the file: (array in the file's big-endian dtype -- a view, nothing converted --,
+    header) when no BSCALE / BZERO applies, else None (the caller takes read_image).  For images that go to the device,
+    which swaps the bytes there (bbx_be32)."""
+    h, data = None, None
+    for hh, dd in read_hdus(path):
+        if dd is not None:
+            h, data = hh, dd
+    if data is None:
+        raise ValueError('no image data in {}'.format(path))
+    if (_hv(h, 'BZERO', 0) or 0) != 0 or (_hv(h, 'BSCALE', 1) or 1) != 1 or 'XTENSION' in h and str(_hv(h, 'XTENSION', '')).strip() == 'BINTABLE':
+        return None
+    return data, h
+
+
 def _card(key, value, comment=''):
     if isinstance(value, tuple):
         value, comment = value[0], (value[1] if len(value) > 1 else comment)

@@ -564,6 +564,22 @@ def count_objects(ctx, data_mask, bit):
     return d_n
 
 
+def image_to_device(ctx, path, dtype):
+    """a FITS image (master frame, reference image, mask) -> device tensor of [dtype].  float32 and uint8 files go up as
+    their bytes, float32 words are put into host order on the device (bbx_be32); anything else is converted on the host"""
+    from . import fitsio
+    got = fitsio.read_image_file_order(path) if str(path).endswith(('.fits', '.fit')) else None
+    if got is not None:
+        data = got[0]
+        if data.dtype == np.dtype('>f4') and np.dtype(dtype) == np.float32:
+            t = torch.from_numpy(data.view(np.int32)).to(ctx.device)       # (the bytes; int32 is only the carrier)
+            check(lib.bbx_be32(_ptr(t), _ptr(t), t.numel(), ctx.stream()), 'bbx_be32')
+            return t.view(torch.float32)
+        if data.dtype == np.uint8 and np.dtype(dtype) == np.uint8:
+            return torch.from_numpy(data).to(ctx.device)
+    return torch.from_numpy(np.ascontiguousarray(fitsio.read_image(path, dtype=dtype))).to(ctx.device)
+
+
 def hval(header, key):
     v = header[key]
     return v[0] if isinstance(v, tuple) else v

@@ -386,6 +386,10 @@ int bbx_funpack_tiles(bbx_ctx *ctx, int ny, int nx, int bytepix, const int *d_de
  * astropy scales them on the host).  bbx_raw_be16: n pixels as they lie in the file -> uint16 = byteswap(x) ^ 0x8000 in
  * one pass on the device (round 4 did this with four frame-sized tensor passes of the host framework). */
 int bbx_raw_be16(const void *d_file_pixels, uint16_t *d_out, size_t n, void *stream);
+/* The same for the 32-bit images a process reads before its first frame (master bias and flat: read_hdulist at
+ * blackbox.py:1677, 1823; the reference image of the subtraction): n big-endian words as they lie in the file -> host
+ * order, in place allowed.  The host uploads the file's bytes untouched instead of swapping 446 MB per image on one core. */
+int bbx_be32(const void *d_file_words, void *d_out, size_t n, void *stream);
 
 /* ---- a7: nonlin_corr (blackbox.py:7394-7437; set_bb.correct_nonlin is False upstream) ----
  * per channel: counts = data/gain[c]; frac = spline_c(counts) where counts <= 50000, else 1

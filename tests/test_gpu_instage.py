@@ -134,3 +134,49 @@ def test_input_stage_and_pipeline_from_files(tmp_path):
     finally:
         pool.close()
     ctx.close()
+
+
+def test_master_frames_go_up_in_file_order_and_are_swapped_on_the_device(tmp_path):
+    """read_hdulist of a master flat / bias / reference image (blackbox.py:1677, 1823): reduce.image_to_device uploads the
+    file's big-endian bytes and bbx_be32 puts them into host order -- the very bits fitsio.read_image makes on the host,
+    for sizes that are and are not a multiple of the kernel's 16-byte groups; uint8 masks go up as they are; a file with
+    BZERO takes the host path."""
+    ctx = R.Context(0)
+    rs = np.random.RandomState(4)
+    for shape in ((33, 47), (64, 128), (1, 5), (257, 1023)):
+        a = (rs.standard_normal(shape) * 10.0 ** rs.uniform(-20, 20, shape)).astype(np.float32)
+        a.flat[0] = np.float32(-0.0); a.flat[-1] = np.float32(np.inf)
+        p = str(tmp_path / ('f_%dx%d.fits' % shape))
+        fitsio.write_image(p, a)
+        assert fitsio.read_image_file_order(p)[0].dtype == np.dtype('>f4')
+        got = R.image_to_device(ctx, p, np.float32)
+        ctx.sync()
+        assert got.dtype == torch.float32 and tuple(got.shape) == shape
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), fitsio.read_image(p, dtype=np.float32).view(np.uint32)), shape
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), a.view(np.uint32))
+    m = (rs.rand(40, 50) < 0.1).astype(np.uint8) * 32
+    p = str(tmp_path / 'm.fits')
+    fitsio.write_image(p, m)
+    got = R.image_to_device(ctx, p, np.uint8)
+    assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), m)
+    # an int16 file read as float32, and unsigned 16-bit (BZERO 32768): converted on the host as before
+    p = str(tmp_path / 'i.fits')
+    fitsio.write_image(p, rs.randint(-100, 100, (12, 13)).astype(np.int16))
+    got = R.image_to_device(ctx, p, np.float32)
+    assert np.array_equal(got.cpu().numpy(), fitsio.read_image(p, dtype=np.float32))
+    p = str(tmp_path / 'u.fits')
+    u = rs.randint(0, 65535, (12, 13)).astype(np.uint16)
+    fitsio.write_image(p, u)
+    assert fitsio.read_image_file_order(p) is None
+    assert np.array_equal(R.image_to_device(ctx, p, np.float32).cpu().numpy(), u.astype(np.float32))
+    # unaligned views of a device buffer (the one-word tail and the scalar path of the kernel)
+    from blackbox_amd._lib import lib, check
+    import ctypes as C
+    w = torch.from_numpy(rs.randint(0, 2 ** 31 - 1, 1001).astype(np.int32)).to(ctx.device)
+    for off, n in ((0, 1001), (1, 1000), (3, 5), (4, 997)):
+        src = w[off:off + n]
+        dst = torch.empty(n + 1, dtype=torch.int32, device=ctx.device)[1:] if off == 1 else torch.empty(n, dtype=torch.int32, device=ctx.device)
+        check(lib.bbx_be32(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, ctx.stream()), 'bbx_be32')
+        ctx.sync()
+        assert np.array_equal(dst.cpu().numpy(), src.cpu().numpy().byteswap()), (off, n)
+    ctx.close()
