@@ -231,6 +231,8 @@ class Reducer:
         _mark('package_imported')
         self.R, self.torch, self.fitsio = R, torch, fitsio
         _, _, local = __import__('blackbox_amd.farm', fromlist=['rank_world']).rank_world()
+        if os.environ.get('BBX_ONE_GPU'):                          # rehearsal of a multi-rank run on a one-GPU box: every rank on device 0
+            local = 0
         self.ctx = R.Context(local)
         _mark('gpu_context')
         self.tel = tel

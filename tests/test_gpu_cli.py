@@ -118,3 +118,51 @@ def test_cli_object_and_flat(tmp_path):
     r = cli.main(['--telescope', tel, '--image', str(tmp_path / 'ML1_flatraw.fits'), '--bpm', str(tmp_path / 'bpm.fits'),
                   '--ysize_chan', str(ys), '--xsize_chan', str(xs), '--red_dir', str(tmp_path / 'c')])
     assert r == [None]          # main() logs the WrapException of a failing file and reports None for it
+
+
+def test_cli_farm_of_four_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[3] at reduced size (a batch of frames farmed over the ranks of a node, no collective: blackbox.py:363-379
+    is the farm it stands for): `python -m torch.distributed.run --nproc-per-node 4 blackbox.py --image_list L` -- rank r reduces
+    the files r, r + 4, ... (farm.shard) through the pipelined list path; here all four ranks share the one GPU of the box
+    (BBX_ONE_GPU).  Every file of the list gets its products, each exactly once, and they are the bytes a single process
+    makes of the same list."""
+    import socket
+    import subprocess
+    import sys
+    ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    ys, xs, tel, nfiles = 64, 330, 'ML1', 18
+    fitsio_hdr = {'EXPTIME': 60.0, 'IMAGETYP': 'object', 'FILTER': 'q'}
+    raws = []
+    for k in range(nfiles):
+        case = synth.make_case(ys, xs, 500 + k % 5, tel=tel, os_y=20, os_x=45, n_stars=30, n_sat=1, n_cr=20)
+        p = str(tmp_path / ('ML1_raw%02d.fits' % k))
+        fitsio.write_image(p, case['raw'], dict(fitsio_hdr, **{'DATE-OBS': '2024-01-02T03:%02d:%02d' % (k // 60, k % 60)}))
+        raws.append(p)
+        if k == 0:
+            fitsio.write_image(str(tmp_path / 'flat.fits'), case['flat'])
+            fitsio.write_image(str(tmp_path / 'bpm.fits'), case['bpm'])
+    lst = str(tmp_path / 'list.txt')
+    with open(lst, 'w') as f:
+        f.write('\n'.join(raws) + '\n')
+    common = ['--telescope', tel, '--mflat', str(tmp_path / 'flat.fits'), '--bpm', str(tmp_path / 'bpm.fits'), '--ysize_chan', str(ys),
+              '--xsize_chan', str(xs), '--fpack', 'True', '--image_list', lst, '--list_procs', '1']
+    cli = load_cli()
+    one = cli.main(common + ['--red_dir', str(tmp_path / 'one')])
+    assert len(one) == nfiles and all(o and os.path.isfile(o) for o in one)
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, BBX_ONE_GPU='1', BBX_CPU_BUDGET='4', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'blackbox.py')] + common + ['--red_dir', str(tmp_path / 'farm')],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    printed = [ln.strip() for ln in r.stdout.splitlines() if ln.strip().endswith('_red.fits.fz')]
+    assert sorted(os.path.basename(p_) for p_ in printed) == sorted(os.path.basename(o) for o in one)       # each file once, by one rank
+    for o in one:
+        b = os.path.join(str(tmp_path / 'farm'), os.path.basename(o))
+        for x, y in ((o, b), (o.replace('_red', '_mask'), b.replace('_red', '_mask'))):
+            (_, _), (ha, ta) = fitsio.read_hdus(x)
+            (_, _), (hb, tb) = fitsio.read_hdus(y)
+            assert np.array_equal(ta, tb) and np.array_equal(ha['__heap__'], hb['__heap__']), y
+        assert os.path.isfile(b.replace('.fits.fz', '_hdr.fits')) and os.path.isfile(b.replace('.fits.fz', '.log'))
