@@ -518,6 +518,64 @@ __global__ __launch_bounds__(1024) void k_mini_fill_filter(float* mini, float* t
     (void)err;
 }
 
+// The same with the mini image in LDS (a 176 x 176 mini image: 124 KB of the CU's 160): every neighbour read of the fill
+// passes and of the 3 x 3 median is an LDS read instead of a ~1 us trip to L2 by one lonely workgroup (91 -> ~20 us per
+// launch, two launches per frame, all of it latency of the frame).  A fill pass reads the snapshot, then writes: all new
+// values are formed (registers) before the first is stored, as the two-buffer version does.
+#define MINI_LDS_MAX (36 * 1024)                              // floats: 144 KB
+#define MINI_PER_THREAD ((MINI_LDS_MAX + 1023) / 1024)
+__global__ __launch_bounds__(1024) void k_mini_fill_filter_lds(float* mini, int nby, int nbx) {
+    extern __shared__ float s_mini[];
+    __shared__ int nbad, nfixed;
+    const int n = nby * nbx;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_mini[i] = mini[i];
+    __syncthreads();
+    for (int iter = 0; iter < n + 1; iter++) {
+        if (threadIdx.x == 0) { nbad = 0; nfixed = 0; }
+        __syncthreads();
+        float nv[MINI_PER_THREAD];                           // the new values of this thread's NaN entries (few)
+        unsigned long long fixed = 0ull;
+        int k = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x, k++) {
+            const float val = s_mini[i];
+            if (!(val == val)) {
+                const int y = i / nbx, x = i - y * nbx;
+                float w[9]; int m = 0;
+                for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || xx < 0 || yy >= nby || xx >= nbx) continue;
+                    const float t = s_mini[yy * nbx + xx];
+                    if (t == t) w[m++] = t;
+                }
+                if (m > 0) {
+                    for (int a = 1; a < m; a++) { const float t = w[a]; int b = a - 1; while (b >= 0 && w[b] > t) { w[b + 1] = w[b]; b--; } w[b + 1] = t; }
+                    nv[k] = (m & 1) ? w[m / 2] : (float)(((double)w[m / 2 - 1] + (double)w[m / 2]) * 0.5);
+                    fixed |= 1ull << k;
+                    atomicAdd(&nfixed, 1);
+                } else atomicAdd(&nbad, 1);
+            }
+        }
+        __syncthreads();                                     // every read of the snapshot is done
+        k = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x, k++) if ((fixed >> k) & 1ull) s_mini[i] = nv[k];
+        const int nb = nbad, nf = nfixed;
+        __syncthreads();
+        if (nb == 0 && nf == 0) break;                    // nothing left to fill
+        if (nf == 0) break;                               // all-NaN image: cannot be filled
+    }
+    // 3x3 median, replicated edges
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / nbx, x = i - y * nbx;
+        float w[9]; int m = 0;
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            const int yy = min(max(y + dy, 0), nby - 1), xx = min(max(x + dx, 0), nbx - 1);
+            w[m++] = s_mini[yy * nbx + xx];
+        }
+        BBX_MED9(w);
+        mini[i] = w[4];
+    }
+}
+
 // np.median of a float32 array (one workgroup): exact radix select of the middle element(s) on order-preserving keys,
 // an even count gives the float32 mean of the two (numpy: np.mean of the pair in float32); NaN when the array holds one.
 // The same for n <= 32768 (a 176 x 176 mini image): the keys stay in registers, 32 per thread, and the middle element is
@@ -963,6 +1021,17 @@ int bbx_mini_fill_filter(bbx_ctx* ctx, int nby, int nbx, float* d_mini, void* st
     if (!ctx || !d_mini || nby < 1 || nbx < 1 || (size_t)nby * nbx > (1u << 22)) return BBX_ERR_ARG;
     int rc;
     float* tmp = (float*)bbx_ws(ctx, WS_MISC, (size_t)nby * nbx * 4 + 256, &rc); if (rc) return rc;
+    const size_t n = (size_t)nby * nbx;
+    if (n <= MINI_LDS_MAX) {
+        static bool attr_set = false;                        // (idempotent: a race only sets it twice)
+        if (!attr_set) {
+            BBX_HIP(hipFuncSetAttribute((const void*)k_mini_fill_filter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, MINI_LDS_MAX * 4));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_mini_fill_filter_lds, dim3(1), dim3(1024), n * sizeof(float), (hipStream_t)stream, d_mini, nby, nbx);
+        BBX_LAUNCH_CHECK();
+        return BBX_OK;
+    }
     hipLaunchKernelGGL(k_mini_fill_filter, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_mini, tmp + 64, nby, nbx, ctx->d_err);
     BBX_LAUNCH_CHECK();
     return BBX_OK;
