@@ -205,7 +205,7 @@ def wait_event(ev, sleep_us=None):
     check(lib.bbx_event_wait(C.c_void_p(h), int(us)), 'bbx_event_wait')
 
 
-def fetch(ctx, *tensors):
+def fetch(ctx, *tensors, check_device_errors=False):
     """device tensors -> numpy arrays (copies) with ONE host wait, which sleeps between polls when the context was told to
     (BBX_OPT_WAIT_SLEEP_US): asynchronous copies into the context's pinned staging buffer on the current stream, bbx_wait.
     What `.cpu().numpy()` does with a spinning hipStreamSynchronize per tensor."""
@@ -230,7 +230,12 @@ def fetch(ctx, *tensors):
         views.append(v)
         off += nb
     t0 = time.perf_counter()
-    check(lib.bbx_wait(ctx.h, sp), 'bbx_wait', ctx.h)
+    if check_device_errors:
+        # the same wait, and the context's device error word read with it (bbx_sync): a list that overflowed, a PSF window
+        # that does not hold raise here, as they would at a ctx.sync() -- without a host wait of their own
+        check(lib.bbx_sync(ctx.h, sp), 'bbx_sync', ctx.h)
+    else:
+        check(lib.bbx_wait(ctx.h, sp), 'bbx_wait', ctx.h)
     WAIT_STATS[0] += time.perf_counter() - t0; WAIT_STATS[1] += 1          # (diagnostics: seconds / calls of host waits in fetch)
     out = [v.numpy().copy() for v in views]
     return out if len(out) > 1 else out[0]

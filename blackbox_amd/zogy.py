@@ -367,9 +367,15 @@ def find_peaks_enqueue(ctx, Scorr, nsigma=None, max_out=100000):
 def find_peaks_collect(ctx, pending):
     """-> arrays (y int32, x int32, peak float32), sorted by (y, x)"""
     yx, val, cnt, max_out = pending
-    ctx.sync()
-    n = min(int(fetch(ctx, cnt)[0]), max_out)
-    yx, val = fetch(ctx, yx[:n], val[:n])
+    if max_out * 12 <= (2 << 20):
+        # the count and the whole list (1.2 MB at the default capacity) in ONE copy back and one host wait: asking for the
+        # count first costs a second round trip -- with the stream's other work in front of it each time
+        c, yx, val = fetch(ctx, cnt, yx, val, check_device_errors=True)
+        n = min(int(c[0]), max_out)
+        yx, val = yx[:n], val[:n]
+    else:
+        n = min(int(fetch(ctx, cnt, check_device_errors=True)[0]), max_out)
+        yx, val = fetch(ctx, yx[:n], val[:n])
     order = np.lexsort((yx[:, 1], yx[:, 0])) if n else np.zeros(0, int)
     return yx[order, 0], yx[order, 1], val[order]
 
@@ -631,16 +637,18 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
         keep = pk > 0
         ys, xs, pk = ys[keep], xs[keep], pk[keep]
         if ys.size:
+            # peaks on masked pixels are dropped; their mask values come back with the fluxes (one host wait: the photometry
+            # of the few masked ones is made and thrown away)
             d_ys, d_xs = push(ctx, ys.astype(np.int64), xs.astype(np.int64))
-            ok = fetch(ctx, new_mask[d_ys, d_xs]) == 0
-            ys, xs, pk = ys[ok], xs[ok], pk[ok]
-        peaks = ys
-        if ys.size:
+            d_mk = new_mask[d_ys, d_xs]
             stamps = source_psfs(ctx, psf_new, sub_pn, ys, xs, nsx, size)
             f, e = psf_optflux(ctx, work, bstd, stamps, ys, xs, v_is_sigma=True)        # (bstd: frame or MiniImage)
-            f, e = fetch(ctx, f, e)
+            mk, f, e = fetch(ctx, d_mk, f, e)
+            ok = mk == 0
+            ys, xs, pk, f, e = ys[ok], xs[ok], pk[ok], f[ok], e[ok]
         else:
             f = e = np.zeros(0, np.float32)
+        peaks = ys
         res['catalog'] = dict(Y_POS=ys.astype(np.float32) + 1, X_POS=xs.astype(np.float32) + 1,
                               E_FLUX_PEAK=pk.astype(np.float32), E_FLUX_OPT=f, E_FLUXERR_OPT=e,
                               SNR_OPT=np.where(e > 0, f / np.where(e > 0, e, 1), 0).astype(np.float32))
@@ -749,9 +757,20 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
             tys = txs = np.zeros(0, np.int32); tsc = np.zeros(0, np.float32)
             ntrans = 'None'
         break
+    # the fluxes at the candidates and the frame statistics of the header: queued together, one copy back, one host wait
+    d_fe = d_st = None
     if tys.size:
         d_ys, d_xs = push(ctx, tys.astype(np.int64), txs.astype(np.int64))
-        fe = fetch(ctx, torch.stack([res['Fpsf'][d_ys, d_xs], res['Fpsferr'][d_ys, d_xs]]))
+        d_fe = torch.stack([res['Fpsf'][d_ys, d_xs], res['Fpsferr'][d_ys, d_xs]])
+    if frame_stats:
+        # statistics over the unmasked pixels (new frame's mask), clipped like zogy's header values
+        d_st = torch.stack([frame_clipped_stats_enqueue(ctx, res['Scorr'], new_mask),
+                            frame_clipped_stats_enqueue(ctx, res['Fpsferr'], new_mask)])
+    back = [t for t in (d_fe, d_st) if t is not None]
+    got = (fetch(ctx, *back) if len(back) > 1 else [fetch(ctx, back[0])]) if back else []
+    fe = got.pop(0) if d_fe is not None else None
+    st = got.pop(0) if d_st is not None else None
+    if tys.size:
         res['transients'] = [dict(y=y, x=x, scorr=sc, fpsf=f, fpsferr=e)
                              for y, x, sc, f, e in zip(tys.tolist(), txs.tolist(), tsc.tolist(), fe[0].tolist(), fe[1].tolist())]
     else:
@@ -764,10 +783,6 @@ def _optimal_subtraction(ctx, new, ref, new_mask, ref_mask, psf_new, psf_ref, fr
     hdr_t['Z-DY'] = (float(np.median(dy)), '[pix] dy median offset full image')
     hdr_t['Z-FNR'] = (float(np.median(fratio)), 'median flux ratio (Fnew/Fref) full image')
     if frame_stats:
-        # statistics over the unmasked pixels (new frame's mask), clipped like zogy's header values
-        # (both queued, one copy back)
-        st = fetch(ctx, torch.stack([frame_clipped_stats_enqueue(ctx, res['Scorr'], new_mask),
-                          frame_clipped_stats_enqueue(ctx, res['Fpsferr'], new_mask)]))
         hdr_t['Z-SCMED'] = (float(st[0, 1]), 'median Scorr full image')
         hdr_t['Z-SCSTD'] = (float(st[0, 3]), 'sigma (STD) Scorr full image')
         hdr_t['Z-FPEMED'] = (float(st[1, 1]), '[e-] median Fpsferr full image')
