@@ -595,7 +595,11 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
     with open(lst, 'w') as f:
         f.write('\n'.join(files) + '\n')
     import torch
-    torch.cuda.empty_cache()                                      # (the parent's cached blocks: the child needs the HBM)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                      # (the parent's cached blocks: the children need the HBM)
+    free_b, total_b = torch.cuda.mem_get_info()
     cmd = [c for c in cmd1]
     i = cmd.index('--image')
     cmd[i:i + 2] = ['--image_list', lst]
@@ -607,7 +611,15 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
         cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', trace, '-o', 'r', '--'] + cmd
     import tempfile
 
+    def cpu_stat():
+        """the cgroup's CPU accounting (usage and throttling: a box gives this run a quota of cores)"""
+        try:
+            return {k: int(v) for k, v in (ln.split() for ln in open('/sys/fs/cgroup/cpu.stat'))}
+        except (OSError, ValueError):
+            return {}
+
     def one_run(out_dir):
+        c0 = cpu_stat()
         t0 = time.time()
         r = subprocess.run(cmd + ['--red_dir', out_dir], env=dict(os.environ, BBX_TIMING='1'), capture_output=True, text=True, timeout=540)
         wall = time.time() - t0
@@ -626,6 +638,11 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
                      MB_per_frame=round(mb / max(1, nout), 1), pipeline=tm.get('pipeline'), process_wall_s=round(wall, 2),
                      hbm_peak_GB_tensors=tm.get('hbm_peak_GB_tensors'),
                      seconds_before_the_list=round(marks.get('calibration_and_reference_files_in_hbm', 0.0), 2))
+            c1 = cpu_stat()
+            if c0 and c1:
+                d['cgroup_cpu'] = dict(cores_used=round((c1.get('usage_usec', 0) - c0.get('usage_usec', 0)) / 1e6 / wall, 1),
+                                       throttled_s=round((c1.get('throttled_usec', 0) - c0.get('throttled_usec', 0)) / 1e6, 2),
+                                       periods_throttled=c1.get('nr_throttled', 0) - c0.get('nr_throttled', 0))
             if len(done) > skip + 1:
                 d['frames_per_s'] = (len(done) - 1 - skip) / (done[-1] - done[skip])
                 d['ms_per_frame'] = 1e3 / d['frames_per_s']
@@ -638,21 +655,27 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
             return d
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)
-    res = dict(ramdisk=one_run(os.path.join(td, 'out_list')))
-    if prof and os.path.isfile(os.path.join(td, 'cli.prof')):
-        import pstats
-        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('cumulative').print_stats(45)
-        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('tottime').print_stats(40)
-    if not (prof or trace) and not os.environ.get('BBX_CLI_NO_POOL'):
+    def scratch_run():
         # the same list with the products on local scratch (the raw files stay on the RAM disk)
         sd = tempfile.mkdtemp(prefix='bbx_list_out_', dir=tempfile.gettempdir())
         try:
             if shutil.disk_usage(sd).free > nfiles * 400e6 + 2e9:
-                res['scratch'] = one_run(os.path.join(sd, 'out_list'))
-            else:
-                res['scratch'] = dict(skipped='not enough room in %s' % sd)
+                return one_run(os.path.join(sd, 'out_list'))
+            return dict(skipped='not enough room in %s' % sd)
         finally:
             shutil.rmtree(sd, ignore_errors=True)
+    both = not (prof or trace) and not os.environ.get('BBX_CLI_NO_POOL')
+    res = {}
+    if both and os.environ.get('BBX_CLI_SCRATCH_FIRST'):          # (debug: the order of the two runs)
+        res['scratch'] = scratch_run()
+    res['ramdisk'] = one_run(os.path.join(td, 'out_list'))
+    res['hbm_free_GB_before_the_children'] = round(free_b / 1e9, 1)                 # (what this bench process still holds is the rest of the card)
+    if prof and os.path.isfile(os.path.join(td, 'cli.prof')):
+        import pstats
+        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('cumulative').print_stats(45)
+        pstats.Stats(os.path.join(td, 'cli.prof'), stream=sys.stderr).sort_stats('tottime').print_stats(40)
+    if both and 'scratch' not in res:
+        res['scratch'] = scratch_run()
     res['note'] = ('files to files through the operator\'s own entry: a child `python blackbox.py --image_list L ... --fpack True` over %d full-size '
                    'fpacked raw frames on the RAM disk; every product of every frame written (_red, _mask, _D, _Scorr, _Fpsf, _trans_limmag '
                    'tile-compressed on the lane that made them and written as .fits.fz by writer threads; _bkg_mini, _bkg_std_mini, _cat, '

@@ -9,7 +9,7 @@ for e in "$@"; do
 import json, sys
 d = json.loads(open('gpurun_out/cli_sweep.json').read().strip().splitlines()[-1])['image_list']['ramdisk']
 print('%-40s steady %.1f  whole list %.1f  process %.1f frames/s  (products of %s files)' % (sys.argv[1], d.get('frames_per_s', 0), d.get('frames_per_s_whole_list', 0), d.get('frames_per_s_process', 0), d.get('products_of')))
-print('      ', d.get('pipeline'), 'first product after', d.get('seconds_to_first_product'), 's; file 16 after', d.get('seconds_to_product_16'), 's; before the list', d.get('seconds_before_the_list'))
+print('      ', d.get('pipeline'), 'first product after', d.get('seconds_to_first_product'), 's; file 16 after', d.get('seconds_to_product_16'), 's; before the list', d.get('seconds_before_the_list'), d.get('cgroup_cpu'))
 PY
 done
 cat gpurun_out/cli_sweep.txt
