@@ -1269,6 +1269,20 @@ struct ringreader {
         pos += lz + 1u;
         return lz;
     }
+    // a whole code word -- `top` zeros, a one, fs low bits -- from ONE look at the next 32 bits: the value (top << fs) | low.
+    // Valid when the word fits them (top + 1 + fs <= 32; else [viol] is raised and the caller decodes the block again with
+    // unary() + get()).  One window step per pixel instead of two on the chain that is the kernel's time.
+    __device__ __forceinline__ unsigned code_fast(int fs, bool& viol) {
+        norm();
+        const unsigned p = peek();
+        const unsigned lz = p ? (unsigned)__clz((int)p) : 31u;
+        const unsigned nb = lz + 1u + (unsigned)fs;
+        viol |= (p == 0u) | (nb > 32u);
+        // the fs bits behind the one: (p << (lz + 1)) >> (32 - fs), written so that lz = 31 and fs = 0 shift by less than 32
+        const unsigned low = (((p << lz) << 1) >> 1) >> (31u - (unsigned)fs);
+        pos += nb;
+        return (lz << fs) | low;
+    }
     __device__ __forceinline__ unsigned unary() {              // number of zeros before the next one
         unsigned z = 0;
         for (;;) {
@@ -1412,8 +1426,7 @@ __global__ __launch_bounds__(64) void k_funpack(const int* __restrict__ desc, co
                         bool viol = false;
 #pragma unroll 4
                         for (int j = 0; j < n; j++) {
-                            const unsigned top = br.unary_fast(viol);
-                            const unsigned d = (top << fs) | br.get(fs);
+                            const unsigned d = br.code_fast(fs, viol);
                             last += (int)(d >> 1) ^ -(int)(d & 1u);
                             if (BYTEPIX == 1) last = (int)(signed char)last;
                             if (BYTEPIX == 2) last = (int)(short)last;
