@@ -27,6 +27,12 @@ around the run).  `idle_to_idle` is the rate of all those frames from an idle de
 device, `long_run` the same steady-state measurement over 240 frames.
 
 Prints ONE JSON line (rank 0) with the roofline of the dominant kernel and a CPU baseline.
+
+Beside the headline (N = 1, default run): `roofline.stages` (the calibration and full-calibration workloads),
+`io_inclusive.measured` = files to files through the operator's own entry -- a child `python blackbox.py --image_list`
+over 96 full-size fpacked raws, every product written, once onto the RAM disk and once onto local scratch (after an
+untimed 16-file warm-up run) --, `process_per_file` (one `python blackbox.py --image` process), `process_pool`
+(`--nproc 4`), `cpu_baseline` (the oracle on the box's cores, checked against one whole frame).
 """
 import argparse
 import json
