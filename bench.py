@@ -31,7 +31,7 @@ Prints ONE JSON line (rank 0) with the roofline of the dominant kernel and a CPU
 Beside the headline (N = 1, default run): `roofline.stages` (the calibration and full-calibration workloads),
 `io_inclusive.measured` = files to files through the operator's own entry -- a child `python blackbox.py --image_list`
 over 96 full-size fpacked raws, every product written, once onto the RAM disk and once onto local scratch (after an
-untimed 16-file warm-up run) --, `process_per_file` (one `python blackbox.py --image` process), `process_pool`
+untimed 48-file warm-up run) --, `process_per_file` (one `python blackbox.py --image` process), `process_pool`
 (`--nproc 4`), `cpu_baseline` (the oracle on the box's cores, checked against one whole frame).
 """
 import argparse
@@ -673,12 +673,12 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
     both = not (prof or trace) and not os.environ.get('BBX_CLI_NO_POOL')
     res = {}
     if both and nfiles >= 48:
-        # untimed warm-up, like the W warm-up steps of the headline: the same command over the first 16 files (a fresh box
+        # untimed warm-up, like the W warm-up steps of the headline: the same command over the first 48 files (a fresh box
         # gives its first list run 50-60 % of the rate of its third: page cache of the interpreter's modules, first-touch
         # pages of the RAM disk and of the pinned buffers)
         lstw = os.path.join(td, 'list_warm.txt')
         with open(lstw, 'w') as f:
-            f.write('\n'.join(files[:16]) + '\n')
+            f.write('\n'.join(files[:48]) + '\n')
         cw = [c for c in cmd]
         cw[cw.index('--image_list') + 1] = lstw
         outw = os.path.join(td, 'out_warm')
@@ -686,7 +686,7 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
             subprocess.run(cw + ['--red_dir', outw], env=dict(os.environ), capture_output=True, text=True, timeout=300)
         finally:
             shutil.rmtree(outw, ignore_errors=True)
-        res['warmup_files'] = 16
+        res['warmup_files'] = 48
     if both and os.environ.get('BBX_CLI_SCRATCH_FIRST'):          # (debug: the order of the two runs)
         res['scratch'] = scratch_run()
     res['ramdisk'] = one_run(os.path.join(td, 'out_list'))
