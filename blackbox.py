@@ -650,12 +650,12 @@ class Reducer:
         kw = {}
         # threads and frames in flight from the cores this process may use (cgroup quota / affinity mask), like bench.py's
         # files-to-files run: on the 16 cores of a one-GPU box 6 lanes, 16 frames, 12 writers, 4 readers (one process), or 4 lanes,
-        # 12 frames, 4 writers, 2 readers in each of two (list_processes)
+        # 12 frames, 8 writers, 2 readers in each of two (list_processes)
         from blackbox_amd import pipeline as _pl
         cores = _pl.cpu_budget()
         lanes = max(2, min(6, cores // 2))
         depth = max(2, min(16 if cores >= 12 else (12 if cores >= 8 else 8), len(todo)))
-        nwriters = max(2, min(12, cores - 4))
+        nwriters = max(2, min(12, cores))                     # (they wait in copies and write calls: 4 per 8 cores held the RAM-disk run at 70-75 frames/s, 8 give 90-95)
         nreaders = max(2, min(4, cores // 4))
         # (tuning runs: BBX_LIST_LANES / BBX_LIST_DEPTH / BBX_LIST_WRITERS override the choice above)
         lanes = int(os.environ.get('BBX_LIST_LANES', lanes))
