@@ -657,10 +657,11 @@ class Reducer:
         depth = max(2, min(16 if cores >= 12 else (12 if cores >= 8 else 8), len(todo)))
         nwriters = max(2, min(12, cores))                     # (they wait in copies and write calls: 4 per 8 cores held the RAM-disk run at 70-75 frames/s, 8 give 90-95)
         nreaders = max(2, min(4, cores // 4))
-        # (tuning runs: BBX_LIST_LANES / BBX_LIST_DEPTH / BBX_LIST_WRITERS override the choice above)
+        # (tuning runs: BBX_LIST_LANES / BBX_LIST_DEPTH / BBX_LIST_WRITERS / BBX_LIST_READERS override the choice above)
         lanes = int(os.environ.get('BBX_LIST_LANES', lanes))
         depth = max(2, min(int(os.environ.get('BBX_LIST_DEPTH', depth)), len(todo)))
         nwriters = int(os.environ.get('BBX_LIST_WRITERS', nwriters))
+        nreaders = int(os.environ.get('BBX_LIST_READERS', nreaders))
         if self.args.fpack:
             from blackbox_amd import outstage
             ny, nx = 2 * geom.ysize_chan, 8 * geom.xsize_chan
