@@ -1152,7 +1152,7 @@ def main():
         for w2 in ('calib', 'full'):
             if w2 == wl:
                 continue
-            l2, d2 = (8, 24) if w2 == 'calib' else (6, 18)
+            l2, d2 = (8, 48) if w2 == 'calib' else (6, 18)      # (calib: a frame takes ~20 ms from its strip statistics to its last kernel; 24 in flight cap the rate near 1100)
             r2 = run_pipeline(torch, ctx, tel, geom, raws, kws[w2], 60, 4, d2, l2, pool, barrier)
             others[w2] = dict(frames_per_s=60 / r2['dt'], ms_per_frame=1e3 * r2['dt'] / 60, frames_in_flight=d2, lanes=l2)
             section('workload ' + w2)
