@@ -868,12 +868,29 @@ class FramePipeline:
                 raw, header = item[0], item[1]
                 live.append(self._start(idx, raw, header, item[2] if len(item) > 2 else None))
                 progressed = True
+            # events of one stream complete in order: behind the first frame whose stage-A event (one stream for all frames) or
+            # whose lane's event is still pending, the later frames of that stream need no query of their own -- with 48
+            # frames in flight the loop made ~40 library calls per round, each giving the interpreter lock away
+            a_pending, lane_pending = False, set()
             for f in live:
-                if f.state == 'A' and lib.bbx_event_query(f.evA) == 1:
+                st = f.state                                       # (read once: lane threads move a frame from 'Q' to 'S' / 'C' meanwhile)
+                if st == 'A':
+                    if a_pending:
+                        continue
+                    if lib.bbx_event_query(f.evA) != 1:
+                        a_pending = True
+                        continue
+                elif st in ('S', 'C'):
+                    if f.lane in lane_pending:
+                        continue
+                    if lib.bbx_event_query(f.evS if st == 'S' else f.evC) != 1:
+                        lane_pending.add(f.lane)
+                        continue
+                if st == 'A':
                     f.tA = time.perf_counter()
                     self._submit_fits(f)
                     progressed = True
-                elif f.state == 'B' and f.res.ready():
+                elif st == 'B' and f.res.ready():
                     f.tB = time.perf_counter()
                     try:
                         results = f.res.get()
@@ -886,10 +903,10 @@ class FramePipeline:
                     second = self.two_phase and results is not None and f.os_fail is None
                     self.lane_thread[f.lane].q.put((self._satcol if second else self._device_stage, f, results))
                     progressed = True
-                elif f.state == 'S' and lib.bbx_event_query(f.evS) == 1:
+                elif st == 'S':
                     self._submit_phase2(f)
                     progressed = True
-                elif f.state == 'B2' and f.res2.ready():
+                elif st == 'B2' and f.res2.ready():
                     try:
                         r2 = f.res2.get()
                         bad = [c for c, r in enumerate(r2) if isinstance(r, dict)]
@@ -903,9 +920,9 @@ class FramePipeline:
                     f.state = 'Q'
                     self.lane_thread[f.lane].q.put((self._device_stage, f, f.p1))
                     progressed = True
-                elif f.state == 'err':
+                elif st == 'err':
                     raise f.err
-                elif f.state == 'C' and lib.bbx_event_query(f.evC) == 1:
+                elif st == 'C':
                     f.tC = time.perf_counter()
                     self.t_stats[0] += f.tA - f.t0
                     self.t_stats[1] += f.tB - f.tA
