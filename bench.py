@@ -1203,7 +1203,7 @@ def main():
             out['io_inclusive']['measured'] = measure_io(torch, ctx, tel, geom, raws, kws[wl], depth, lanes, pool, barrier, args, section)
     pool.close()
     if rank == 0:
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                           # (the CPU baseline: at N = 1 only)
             full_path = None
             if not args.small and world == 1 and cpu_full is not None:
                 full_path = cpu_full
