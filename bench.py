@@ -687,6 +687,7 @@ def cli_image_list(ctx, td, cmd1, raws, hdr, nfiles):
         finally:
             shutil.rmtree(outw, ignore_errors=True)
         res['warmup_files'] = 48
+        time.sleep(float(os.environ.get('BBX_CLI_SETTLE_S', '0')))     # (debug: idle seconds between the warm-up's exit and the measured runs)
     if both and os.environ.get('BBX_CLI_SCRATCH_FIRST'):          # (debug: the order of the two runs)
         res['scratch'] = scratch_run()
     res['ramdisk'] = one_run(os.path.join(td, 'out_list'))
